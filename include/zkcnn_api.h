@@ -1,0 +1,61 @@
+/* Whole-proof driver C-ABI (host side): build a CNN circuit + witness, run the interactive
+ * GKR protocol (verifier <-> prover) and return timings, acceptance and the canonical transcript.
+ *
+ * It replaces what the reference does in main(): reference src/main_demo_lenet.cpp:19-41 and
+ * src/main_demo_vgg.cpp:20-43 (model ctor -> nn.create(p,false) -> verifier v(&p,p.C) -> v.verify()
+ * -> 16-column result row), as a library call so that Python tests / bench.py (ctypes) and C/C++
+ * callers share one entry point. The product library (libzkcnn_host.so) runs the prover on the
+ * GPU through include/zkcnn_hip.h; oracle/liboracle.so exports the same three functions with the
+ * `oracle_` prefix, backed by the CPU restatement (test infrastructure only).
+ */
+#ifndef ZKCNN_API_H
+#define ZKCNN_API_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    const char *model;     /* "lenet", "lenet.avg", "lenetCifar", "vgg11", "vgg16", "vgg:<tokens>", "custom:<spec>" */
+    int32_t pic_x, pic_y, pic_channel;
+    int32_t pic_cnt;       /* pictures folded into ONE circuit (reference pic_parallel) */
+    uint64_t data_seed;    /* synthetic picture / weights / biases (reference data.tar.gz is absent) */
+} zkcnn_model_desc;
+
+#define ZKCNN_MODE_VERIFY      0u  /* full verifier (reference behaviour) */
+#define ZKCNN_MODE_DRIVE_ONLY  1u  /* same challenges and prover calls, verifier checks skipped */
+#define ZKCNN_MODE_REUSE_GENS  2u  /* keep the session's commitment generators instead of drawing new ones */
+
+typedef struct {
+    int32_t accepted;          /* 1 = "Verification pass" + Hyrax opening ok, 0 = rejected, -1 = not checked */
+    int32_t n_layers;
+    uint64_t input_size;       /* layer-0 size (witness size column) */
+    int32_t input_bits;
+    int32_t n_rounds;          /* prover round-polynomial calls */
+    double prove_s;            /* prover::proveTime()            (column PT) */
+    double poly_prove_s;       /* prover::polyProverTime()       (column POLY_PT); TOT_PT = sum of the two */
+    double verify_s;           /* verifier time                  (column VT) */
+    double poly_verify_s;
+    double proof_kb, poly_proof_kb;
+    double witness_s;          /* circuit + witness generation (not prover time, as in the reference) */
+    double upload_s;           /* host -> HBM transfer of circuit and witness (0 for the oracle) */
+    double wall_s;             /* wall clock of the whole prove call */
+    uint64_t transcript_len;   /* bytes of canonical transcript produced */
+    uint64_t gate_cnt_uni, gate_cnt_bin, table_entries;   /* circuit statistics */
+    char message[128];         /* failure reason, if any */
+} zkcnn_result;
+
+/* Builds the circuit and the witness (and, for the product library, uploads both to `device`).
+ * Returns NULL on error. */
+void *zkcnn_session_create(const zkcnn_model_desc *desc, int32_t device);
+/* One proof. `transcript` may be NULL; at most `cap` bytes are written, the full length is reported. */
+int32_t zkcnn_session_prove(void *session, uint64_t challenge_seed, uint32_t mode, uint8_t *transcript,
+                            uint64_t cap, zkcnn_result *out);
+void zkcnn_session_destroy(void *session);
+/* The reference CLI's 16-column result row of the last prove call ("a, b, c, ..."), NUL terminated. */
+int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,71 @@
+#include "circuit.h"
+#include "utils.hpp"
+
+// two_mul table and layer storage (behaviour of reference src/circuit.cpp:90-100)
+void layeredCircuit::init(u8 q_bit_size, u8 layer_cnt) {
+    const int q = q_bit_size;
+    two_mul.assign((size_t) 2 * (q + 1), F_ZERO);
+    F pw = F_ONE;
+    for (int k = 0; k <= q; ++k) {
+        two_mul[k] = pw;
+        two_mul[q + 1 + k] = -pw;
+        pw = pw + pw;
+    }
+    size = layer_cnt;
+    circuit.assign(size, layer());
+}
+
+namespace {
+// Dense renumbering of the layer-0 wires one layer touches, in first-use order.
+struct subsetMap {
+    vector<u32> stamp, slot;
+    explicit subsetMap(size_t n) : stamp(n, 0), slot(n, 0) {}
+    u32 place(u32 wire, u32 layer_id, vector<u32> &ori, u32 &count) {
+        if (stamp[wire] != layer_id) {
+            stamp[wire] = layer_id;
+            slot[wire] = count++;
+            ori.push_back(wire);
+        }
+        return slot[wire];
+    }
+};
+}
+
+// Compact every layer's references into layer 0 to a dense subset (ori_id_u / ori_id_v) and fix
+// the table bit lengths the sumcheck uses. Behaviour of reference src/circuit.cpp:4-88: uni gates
+// are visited before bin gates, and first-use order defines the subset numbering (that order is
+// visible in the transcript, so it is kept).
+void layeredCircuit::initSubset() {
+    subsetMap mu(circuit[0].size), mv(circuit[0].size);
+    for (u32 i = 1; i < size; ++i) {
+        layer &cur = circuit[i];
+        const layer &prev = circuit[i - 1];
+        const bool is_fft = cur.ty == layerType::FFT, is_ifft = cur.ty == layerType::IFFT;
+        bool u_in_prev = is_fft || is_ifft, v_in_prev = false;
+
+        for (uniGate &gt : cur.uni_gates) {
+            if (gt.lu == 0) gt.u = mu.place(gt.u, i, cur.ori_id_u, cur.size_u[0]);
+            else u_in_prev = true;
+        }
+        for (binGate &gt : cur.bin_gates) {
+            if (gt.getLayerIdU(i) == 0) gt.u = mu.place(gt.u, i, cur.ori_id_u, cur.size_u[0]);
+            else u_in_prev = true;
+            if (gt.getLayerIdV(i) == 0) gt.v = mv.place(gt.v, i, cur.ori_id_v, cur.size_v[0]);
+            else v_in_prev = true;
+        }
+        cur.bit_length_u[0] = ceilPow2BitLength(cur.size_u[0]);
+        cur.bit_length_v[0] = ceilPow2BitLength(cur.size_v[0]);
+
+        if (!u_in_prev) { cur.size_u[1] = 0; cur.bit_length_u[1] = -1; }
+        else if (is_fft) { cur.bit_length_u[1] = cur.fft_bit_length - 1; cur.size_u[1] = 1u << cur.bit_length_u[1]; }
+        else if (is_ifft) { cur.bit_length_u[1] = cur.fft_bit_length; cur.size_u[1] = 1u << cur.bit_length_u[1]; }
+        else { cur.size_u[1] = prev.size; cur.bit_length_u[1] = prev.bit_length; }
+
+        if (!v_in_prev) { cur.size_v[1] = 0; cur.bit_length_v[1] = -1; }
+        else if (cur.ty == layerType::DOT_PROD) {
+            cur.size_v[1] = prev.size >> cur.fft_bit_length;
+            cur.bit_length_v[1] = prev.bit_length - cur.fft_bit_length;
+        } else { cur.size_v[1] = prev.size; cur.bit_length_v[1] = prev.bit_length; }
+        cur.updateSize();
+    }
+}

@@ -1,0 +1,128 @@
+// CNN -> layered circuit + witness generator (host side, not part of the timed prover path).
+// Public shape follows reference src/neuralNetwork.hpp:55-168 (constructor arguments, create(),
+// conv_section / pool / full_conn topology tables that the model classes fill); the reference's
+// data files are absent (data.tar.gz is a missing blob), so next to the file reader there is a
+// seeded synthetic source that produces the same value counts in the same order.
+#pragma once
+#include <memory>
+#include "circuit.h"
+#include "utils.hpp"
+
+enum convType { FFT, NAIVE, NAIVE_FAST };
+enum poolType { AVG, MAX, NONE };
+enum actType { RELU_ACT };
+
+struct convKernel {
+    convType ty;
+    i64 channel_out, channel_in, size, stride_bl, padding, weight_start_id, bias_start_id;
+    convKernel(convType t, i64 co, i64 ci, i64 ksize, i64 log_stride, i64 pad)
+            : ty(t), channel_out(co), channel_in(ci), size(ksize), stride_bl(log_stride), padding(pad),
+              weight_start_id(0), bias_start_id(0) {}
+    convKernel(convType t, i64 co, i64 ci, i64 ksize) : convKernel(t, co, ci, ksize, 0, ksize >> 1) {}
+};
+
+struct fconKernel {
+    i64 channel_out, channel_in, weight_start_id, bias_start_id;
+    fconKernel(i64 co, i64 ci) : channel_out(co), channel_in(ci), weight_start_id(0), bias_start_id(0) {}
+};
+
+struct poolKernel {
+    poolType ty;
+    i64 size, stride_bl;
+    poolKernel(poolType t, i64 sz, i64 log_stride) : ty(t), size(sz), stride_bl(log_stride) {}
+};
+
+// Source of the real-valued picture / weights / biases, consumed strictly in reference file order:
+// picture (c,x,y); then per layer conv weight (co,ci,x,y), conv bias (co); ...; fc weight (co,ci), fc bias.
+class dataSource {
+public:
+    enum kind { PICTURE, WEIGHT, BIAS };
+    virtual ~dataSource() {}
+    virtual double next(kind k, i64 fan_in) = 0;
+};
+
+class neuralNetwork {
+public:
+    neuralNetwork(i64 psize_x, i64 psize_y, i64 pchannel, i64 pparallel, const string &i_filename,
+                  const string &c_filename, const string &o_filename);
+    virtual ~neuralNetwork() {}
+
+    // replace the input file by a seeded synthetic stream (picture ~ U[0,1), weights/biases ~ U(-k,k),
+    // k = 1/sqrt(fan_in)); must be called before create()
+    void useSyntheticData(u64 seed);
+
+    // Fills pr.C (circuit) and pr.val (value of every gate). Works for any prover type exposing those two.
+    template <class P>
+    void create(P &pr, bool only_compute) { build(pr.C, pr.val, only_compute); }
+
+    void build(layeredCircuit &C, vector<vector<F>> &val, bool only_compute);
+
+    i64 layerCount() const { return SIZE; }
+    i64 inputSize() const { return total_in_size; }
+    const vector<int> &inferred() const { return infer_result; }
+
+protected:
+    vector<vector<convKernel>> conv_section;
+    vector<poolKernel> pool;
+    vector<fconKernel> full_conn;
+
+    i64 pic_size_x, pic_size_y, pic_channel, pic_parallel;
+    i64 SIZE;
+    const i64 NCONV_FAST_SIZE, NCONV_SIZE, FFT_SIZE, AVE_POOL_SIZE, FC_SIZE, RELU_SIZE;
+    const i64 Q = 9;               // quantisation width
+    const i64 Q_BIT_SIZE = 220;    // two_mul holds 2^0..2^220 and their negatives
+    i64 T, Q_MAX;
+
+private:
+    std::unique_ptr<dataSource> src;
+    string out_filename;
+    vector<int> infer_result;
+
+    poolType pool_ty;
+    i64 pool_bl, pool_sz, pool_stride_bl, pool_stride, pool_layer_cnt, conv_layer_cnt;
+    i64 nx_in, nx_out, ny_in, ny_out, m, channel_in, channel_out, log_stride, padding;
+    i64 new_nx_in, new_ny_in, nx_padded_in, ny_padded_in;
+    i64 total_in_size, total_para_size, total_relu_in_size, total_ave_in_size, total_max_in_size;
+    int x_bit, w_bit, x_next_bit;
+
+    vector<vector<F>> *vals;       // == &pr.val while building
+    const F *two_mul;
+
+    void planLayout();
+    void setConv(i64 nx, i64 ny, const convKernel &conv);
+    void setFC(const fconKernel &fc);
+    void setPool(const poolKernel &p);
+    i64 fftBits() const;
+    i64 poolAuxSize() const;
+    int nextScaleBits(i64 layer_id);
+
+    // witness helpers
+    void loadPicture(layer &L);
+    void loadConvWeight(i64 first_id);
+    void loadFcWeight(i64 first_id);
+    void loadBias(i64 first_id);
+    int quantBits(double mx, double mn) const;
+    void putBit(i64 layer_id, i64 idx, i64 dst, i64 shift);
+    void putFieldBit(const F &data, i64 dst, i64 shift);
+    void putSign(i64 layer_id, i64 idx, i64 dst);
+    void putMax(i64 layer_id, i64 idx, i64 dst);
+    void evalGates(const layer &L, i64 layer_id);
+    void evalDotProd(const layer &L, i64 layer_id);
+    void evalTransform(const layer &L, i64 layer_id);
+
+    // layer emitters
+    void emitInput(layer &L);
+    void emitPadding(layer &L, i64 &layer_id, i64 first_conv_id);
+    void emitFFT(layer &L, i64 &layer_id);
+    void emitDotProd(layer &L, i64 &layer_id);
+    void emitIFFT(layer &L, i64 &layer_id);
+    void emitAddBias(layer &L, i64 &layer_id, i64 first_bias_id);
+    void emitConvFast(layer &L, i64 &layer_id, i64 first_conv_id, i64 first_bias_id);
+    void emitConvMul(layer &L, i64 &layer_id, i64 first_conv_id);
+    void emitConvAdd(layer &L, i64 &layer_id, i64 first_bias_id);
+    void emitRelu(layer &L, i64 &layer_id, i64 block_len);
+    void emitAvgPool(layer &L, i64 &layer_id);
+    void emitMaxPool(layeredCircuit &C, i64 &layer_id);
+    void emitFC(layer &L, i64 &layer_id, i64 first_fc_id, i64 first_bias_id);
+    void reportInference(const layeredCircuit &C);
+};

@@ -1,0 +1,87 @@
+// One circuit + witness kept alive across proofs; shared by the product driver (api.cpp, HIP
+// prover) and the oracle driver (oracle/oracle_api.cpp, CPU prover). Mirrors the reference main()
+// flow (reference src/main_demo_lenet.cpp:19-41).
+#pragma once
+#include <chrono>
+#include <memory>
+#include "../../../include/zkcnn_api.h"
+#include "models.hpp"
+#include "verifier.hpp"
+
+template <class ProverT>
+struct sessionT {
+    ProverT p;
+    std::unique_ptr<neuralNetwork> nn;
+    std::vector<G1> gens;
+    string model_name;
+    int pic_cnt = 1;
+    double witness_s = 0;
+    string row;
+
+    static double now() {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+
+    bool build(const zkcnn_model_desc *d) {
+        model_name = d->model ? d->model : "";
+        pic_cnt = d->pic_cnt;
+        nn.reset(makeModel(model_name, d->pic_x, d->pic_y, d->pic_channel, d->pic_cnt));
+        if (!nn) return false;
+        nn->useSyntheticData(d->data_seed);
+        double t0 = now();
+        nn->create(p, false);
+        witness_s = now() - t0;
+        return true;
+    }
+
+    int prove(uint64_t challenge_seed, uint32_t mode, uint8_t *transcript, uint64_t cap, zkcnn_result *out) {
+        std::memset(out, 0, sizeof(*out));
+        double t0 = now();
+        Fr::seedCSPRNG(challenge_seed);
+        const bool drive = mode & ZKCNN_MODE_DRIVE_ONLY, reuse = mode & ZKCNN_MODE_REUSE_GENS;
+        const u8 logn = p.C.circuit[0].bit_length;
+        const size_t n_sqrt = (size_t) 1 << (logn - (logn >> 1));
+        if (reuse && gens.size() != n_sqrt) {
+            // session generators come from their own stream so that they do not depend on the proof seed
+            Fr::seedCSPRNG(0x67656e73ULL);
+            drawGenerators(gens, n_sqrt);
+            Fr::seedCSPRNG(challenge_seed);
+        }
+        output_tb.assign(OUT_COLUMN_CNT, "");
+        output_tb[MO_INFO_OUT_ID] = model_name;
+        output_tb[PCNT_OUT_ID] = std::to_string(pic_cnt);
+        verifierT<ProverT> v(&p, p.C);
+        v.drive_only = drive;
+        if (reuse) v.fixed_gens = &gens;
+        bool ok = v.verify();
+        out->accepted = drive ? -1 : (ok ? 1 : 0);
+        out->n_layers = p.C.size;
+        out->input_size = p.C.circuit[0].size;
+        out->input_bits = p.C.circuit[0].bit_length;
+        out->prove_s = p.proveTime();
+        out->poly_prove_s = p.polyProverTime();
+        out->verify_s = v.verifierTime();
+        out->poly_verify_s = v.polyVerifierTime();
+        out->proof_kb = p.proofSize();
+        out->poly_proof_kb = p.polyProofSize();
+        out->witness_s = witness_s;
+        out->transcript_len = v.transcript.bytes.size();
+        if (transcript && cap) std::memcpy(transcript, v.transcript.bytes.data(), std::min<uint64_t>(cap, out->transcript_len));
+        int rounds = 0;
+        u64 nu = 0, nb = 0, tbl = 0;
+        for (int i = 0; i < p.C.size; ++i) {
+            const layer &L = p.C.circuit[i];
+            if (i) { rounds += L.max_bl_u + L.max_bl_v; nu += L.uni_gates.size(); nb += L.bin_gates.size(); }
+            tbl += (u64) 1 << L.bit_length;
+        }
+        out->n_rounds = rounds + p.C.circuit[0].bit_length;
+        out->gate_cnt_uni = nu;
+        out->gate_cnt_bin = nb;
+        out->table_entries = tbl;
+        std::snprintf(out->message, sizeof(out->message), "%s", ok ? "" : v.failure());
+        row.clear();
+        for (auto &s : output_tb) { row += s; row += ", "; }
+        out->wall_s = now() - t0;
+        return 0;
+    }
+};

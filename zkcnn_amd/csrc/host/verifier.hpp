@@ -1,0 +1,373 @@
+// Interactive GKR verifier: owns the protocol loop, draws every challenge, calls the prover once
+// per sumcheck round and checks each layer. Protocol, challenge ORDER and acceptance conditions
+// follow reference src/verifier.cpp:118-373 (the consumer side of the hot path; it stays on the
+// CPU). It is a template over the prover type so that the same driver runs against the HIP-backed
+// `prover` and against the CPU checker in oracle/; `verifier` below is the drop-in name.
+//
+// Additions over the reference: a transcript recorder (every value the prover returns, in call
+// order, canonically serialised -- the reference has no serialised proof), an
+// option to re-use generators, and a "drive only" mode that draws the same challenges and makes the
+// same prover calls but skips the verifier's own (gate-walking) work so a bench can time the prover.
+#pragma once
+#include "circuit.h"
+#include "polynomial.h"
+#include "utils.hpp"
+
+struct proofTranscript : public hyrax_bls12_381::transcriptSink {
+    std::vector<u8> bytes;
+    void put(const Fr &x) override {
+        size_t o = bytes.size();
+        bytes.resize(o + 32);
+        x.toBytesLE(&bytes[o]);
+    }
+    void put(const G1 &p) override {
+        size_t o = bytes.size();
+        bytes.resize(o + 48);
+        p.serialize(&bytes[o]);
+    }
+    void put(const quadratic_poly &p) { put(p.a); put(p.b); put(p.c); }
+    void put(const cubic_poly &p) { put(p.a); put(p.b); put(p.c); put(p.d); }
+};
+
+// random multiples of the base point (reference src/verifier.cpp:121-126), via a fixed-base table
+inline void drawGenerators(std::vector<G1> &gens, size_t count) {
+    static std::vector<G1Affine> table;      // table[w * 16 + d] = d * 16^w * G
+    if (table.empty()) {
+        std::vector<G1> jac(64 * 16);
+        G1 base = G1::generator();
+        for (int w = 0; w < 64; ++w) {
+            jac[w * 16] = G1();
+            for (int d = 1; d < 16; ++d) G1::add(jac[w * 16 + d], jac[w * 16 + d - 1], base);
+            G1 nb;
+            G1::add(nb, jac[w * 16 + 15], base);
+            base = nb;
+        }
+        zkff::batchToAffine(jac, table);
+    }
+    gens.resize(count);
+    for (auto &x : gens) {
+        Fr k;
+        k.setByCSPRNG();
+        uint64_t e[4];
+        k.toCanonical(e);
+        G1 acc;
+        for (int w = 0; w < 64; ++w) {
+            unsigned d = (e[w >> 4] >> ((w & 15) * 4)) & 15;
+            if (d) G1::addMixed(acc, acc, table[w * 16 + d]);
+        }
+        x = acc;
+    }
+}
+
+template <class ProverT>
+class verifierT {
+public:
+    ProverT *p;
+    const layeredCircuit &C;
+
+    verifierT(ProverT *pr, const layeredCircuit &cir) : p(pr), C(cir), poly_v(nullptr) {
+        final_claim_u0.assign(C.size + 2, F_ZERO);
+        final_claim_v0.assign(C.size + 2, F_ZERO);
+        r_u.assign(C.size + 2, vector<F>());
+        r_v.assign(C.size + 2, vector<F>());
+        p->init();
+    }
+    ~verifierT() { delete poly_v; }
+
+    // options (all default to reference behaviour)
+    bool drive_only = false;                 // skip the verifier's checks, keep challenges + prover calls
+    const std::vector<G1> *fixed_gens = nullptr;   // re-use generators instead of drawing new ones
+    proofTranscript transcript;
+
+    bool verify() {
+        const u8 logn = C.circuit[0].bit_length;
+        const size_t n_sqrt = (size_t) 1 << (logn - (logn >> 1));
+        if (fixed_gens) gens = *fixed_gens;
+        else drawGenerators(gens, n_sqrt);
+        if (gens.size() != n_sqrt) return false;
+        delete poly_v;
+        poly_v = new hyrax_bls12_381::polyVerifier(p->commitInput(gens), gens, &transcript);
+        poly_v->drive_only = drive_only;
+        return verifyInnerLayers() && verifyFirstLayer() && verifyInput();
+    }
+
+    timer total_timer, total_slow_timer;
+    double verifierTime() const { return total_timer.elapse_sec(); }
+    double verifierSlowTime() const { return total_slow_timer.elapse_sec(); }
+    double polyVerifierTime() const { return poly_v ? poly_v->getVT() : 0.0; }
+    const char *failure() const { return fail_msg.c_str(); }
+
+private:
+    vector<vector<F>> r_u, r_v;
+    vector<F> final_claim_u0, final_claim_v0;
+    vector<F> beta_g, beta_u, beta_v, beta_gs;
+    F uni_value[2], bin_value[3];
+    F eval_in;
+    std::vector<G1> gens;
+    hyrax_bls12_381::polyVerifier *poly_v;
+    string fail_msg;
+
+    void tic() { total_timer.start(); total_slow_timer.start(); }
+    void toc() { total_timer.stop(); total_slow_timer.stop(); }
+    bool fail(const string &msg) {
+        toc();
+        fail_msg = msg;
+        fprintf(stderr, "Verification fail, %s\n", msg.c_str());
+        return false;
+    }
+    static void draw(vector<F> &v, size_t n) {
+        v.resize(n);
+        for (auto &x : v) x.setByCSPRNG();
+    }
+
+    // ---- predicate side: wiring-polynomial evaluations the final check of a layer needs ----
+    // eq tables for phase 1 of layer `d` (reference src/verifier.cpp:36-82). r_0 / r_1 are the
+    // points the layer's own output claim sits at, alpha / beta the combination weights.
+    void betaInitPhase1(u8 d, const F &alpha, const F &beta, const vector<F>::const_iterator &r_0,
+                        const vector<F>::const_iterator &r_1, const F &relu_rou) {
+        const layer &L = C.circuit[d];
+        const i8 bl = L.bit_length, fft_bl = L.fft_bit_length, fft_blh = fft_bl - 1;
+        if (L.ty == layerType::FFT || L.ty == layerType::IFFT) {
+            beta_gs.resize((size_t) 1 << fft_bl);
+            phiGInit(beta_gs, r_0, L.scale, fft_bl, L.ty == layerType::IFFT);
+            beta_u.resize((size_t) 1 << L.max_bl_u);
+            initBetaTable(beta_u, L.max_bl_u, r_u[d].begin(), F_ONE);
+        } else if (L.ty == layerType::PADDING) {
+            // outputs are (vector, position): the vector part carries the two-point claim of the
+            // DOT_PROD layer two levels up, the position part the FFT layer's sumcheck point
+            beta_g.resize((size_t) 1 << bl);
+            beta_gs.resize((size_t) 1 << fft_blh);
+            initBetaTable(beta_g, bl - fft_blh, r_u[d + 2].begin() + fft_bl, r_v[d + 2].begin(), alpha, beta);
+            initBetaTable(beta_gs, fft_blh, r_0, F_ONE);
+            const size_t mask = ((size_t) 1 << fft_blh) - 1;
+            for (size_t g = (size_t) 1 << bl; g-- > 0;) beta_g[g] = beta_g[g >> fft_blh] * beta_gs[g & mask];
+            beta_u.resize((size_t) 1 << L.max_bl_u);
+            initBetaTable(beta_u, L.max_bl_u, r_u[d].begin(), F_ONE);
+        } else if (L.ty == layerType::DOT_PROD) {
+            const i8 cnt_bl = bl - fft_bl, cnt_bl2 = L.max_bl_u - fft_bl;
+            beta_g.resize((size_t) 1 << cnt_bl);
+            initBetaTable(beta_g, cnt_bl, r_u[d + 2].begin() + fft_bl - 1, alpha);
+            beta_u.resize((size_t) 1 << cnt_bl2);
+            initBetaTable(beta_u, cnt_bl2, r_u[d].begin() + fft_bl, F_ONE);
+            F same = F_ONE;     // eq(r_0, r_u[d]) on the frequency bits
+            for (i8 j = 0; j < fft_bl; ++j)
+                same = same * (r_0[j] * r_u[d][j] + (F_ONE - r_0[j]) * (F_ONE - r_u[d][j]));
+            for (auto &x : beta_u) x = x * same;
+        } else {
+            beta_g.resize((size_t) 1 << bl);
+            initBetaTable(beta_g, bl, r_0, r_1, alpha * L.scale, beta * L.scale);
+            if (L.zero_start_id < L.size)
+                for (size_t g = L.zero_start_id; g < ((size_t) 1 << bl); ++g) beta_g[g] = beta_g[g] * relu_rou;
+            beta_u.resize((size_t) 1 << L.max_bl_u);
+            initBetaTable(beta_u, L.max_bl_u, r_u[d].begin(), F_ONE);
+        }
+    }
+    void betaInitPhase2(u8 d) {                                       // reference src/verifier.cpp:84-87
+        beta_v.resize((size_t) 1 << C.circuit[d].max_bl_v);
+        initBetaTable(beta_v, C.circuit[d].max_bl_v, r_v[d].begin(), F_ONE);
+    }
+    void predicatePhase1(u8 d) {                                      // reference src/verifier.cpp:89-102
+        const layer &L = C.circuit[d];
+        uni_value[0].clear();
+        uni_value[1].clear();
+        if (L.ty == layerType::FFT || L.ty == layerType::IFFT) {
+            for (size_t u = 0; u < ((size_t) 1 << L.max_bl_u); ++u) uni_value[1] = uni_value[1] + beta_gs[u] * beta_u[u];
+        } else for (const uniGate &gt : L.uni_gates) {
+            int idx = gt.lu != 0;
+            uni_value[idx] = uni_value[idx] + beta_g[gt.g] * beta_u[gt.u] * C.two_mul[gt.sc];
+        }
+        bin_value[0] = bin_value[1] = bin_value[2] = F_ZERO;
+    }
+    void predicatePhase2(u8 d) {                                      // reference src/verifier.cpp:104-116
+        const layer &L = C.circuit[d];
+        uni_value[0] = uni_value[0] * beta_v[0];
+        uni_value[1] = uni_value[1] * beta_v[0];
+        const bool dot = L.ty == layerType::DOT_PROD;
+        for (const binGate &gt : L.bin_gates) {
+            F t = beta_g[gt.g] * beta_u[gt.u] * beta_v[gt.v];
+            if (!dot) t = t * C.two_mul[gt.sc];
+            bin_value[gt.l] = bin_value[gt.l] + t;
+        }
+    }
+
+    // ---- stage 1: layers size-1 .. 1 (reference src/verifier.cpp:132-266) ----
+    bool verifyInnerLayers() {
+        tic();
+        F alpha = F_ONE, beta = F_ZERO, relu_rou = F_ONE, claim_u1 = F_ZERO, claim_v1 = F_ZERO;
+        const layer &top = C.circuit[C.size - 1];
+        draw(r_u[C.size], top.bit_length);
+        vector<F>::const_iterator r_0 = r_u[C.size].begin(), r_1 = r_v[C.size].begin();
+        toc();
+
+        F previousSum = p->Vres(r_0, top.size, top.bit_length);
+        transcript.put(previousSum);
+        p->sumcheckInitAll(r_0);
+
+        for (u8 i = C.size - 1; i; --i) {
+            const layer &cur = C.circuit[i];
+            const bool dot = cur.ty == layerType::DOT_PROD;
+            p->sumcheckInit(alpha, beta);
+            tic();
+            draw(r_u[i], cur.max_bl_u);
+            if (cur.zero_start_id < cur.size) relu_rou.setByCSPRNG();
+            else relu_rou = F_ONE;
+            toc();
+            if (dot) p->sumcheckDotProdInitPhase1();
+            else p->sumcheckInitPhase1(relu_rou);
+
+            F previousRandom = F_ZERO;
+            for (i8 j = 0; j < cur.max_bl_u; ++j) {
+                F at01, at_r;
+                if (dot) {
+                    cubic_poly poly = p->sumcheckDotProdUpdate1(previousRandom);
+                    transcript.put(poly);
+                    tic();
+                    at01 = poly.eval(F_ZERO) + poly.eval(F_ONE);
+                    at_r = poly.eval(r_u[i][j]);
+                } else {
+                    quadratic_poly poly = p->sumcheckUpdate1(previousRandom);
+                    transcript.put(poly);
+                    tic();
+                    at01 = poly.eval(F_ZERO) + poly.eval(F_ONE);
+                    at_r = poly.eval(r_u[i][j]);
+                }
+                if (!drive_only && at01 != previousSum)
+                    return fail("phase1, circuit " + std::to_string(i) + ", current bit " + std::to_string(j));
+                previousRandom = r_u[i][j];
+                previousSum = at_r;
+                toc();
+            }
+            if (dot) {
+                p->sumcheckDotProdFinalize1(previousRandom, claim_u1);
+                transcript.put(claim_u1);
+            } else {
+                p->sumcheckFinalize1(previousRandom, final_claim_u0[i], claim_u1);
+                transcript.put(final_claim_u0[i]);
+                transcript.put(claim_u1);
+            }
+
+            total_slow_timer.start();
+            if (!drive_only) {
+                betaInitPhase1(i, alpha, beta, r_0, r_1, relu_rou);
+                predicatePhase1(i);
+            }
+            total_timer.start();
+            if (cur.need_phase2) {
+                draw(r_v[i], cur.max_bl_v);
+                toc();
+                p->sumcheckInitPhase2();
+                previousRandom = F_ZERO;
+                for (i8 j = 0; j < cur.max_bl_v; ++j) {
+                    quadratic_poly poly = p->sumcheckUpdate2(previousRandom);
+                    transcript.put(poly);
+                    tic();
+                    if (!drive_only && poly.eval(F_ZERO) + poly.eval(F_ONE) != previousSum)
+                        return fail("phase2, circuit level " + std::to_string(i) + ", current bit " + std::to_string(j));
+                    previousRandom = r_v[i][j];
+                    previousSum = poly.eval(previousRandom);
+                    toc();
+                }
+                p->sumcheckFinalize2(previousRandom, final_claim_v0[i], claim_v1);
+                transcript.put(final_claim_v0[i]);
+                transcript.put(claim_v1);
+                total_slow_timer.start();
+                if (!drive_only) {
+                    betaInitPhase2(i);
+                    predicatePhase2(i);
+                }
+                total_timer.start();
+            }
+            if (!drive_only) {
+                // sum over gate types of (wiring predicate) x (claimed operand values)
+                F expect = bin_value[0] * (final_claim_u0[i] * final_claim_v0[i]) + bin_value[1] * (claim_u1 * claim_v1) +
+                           bin_value[2] * (claim_u1 * final_claim_v0[i]) + uni_value[0] * final_claim_u0[i] +
+                           uni_value[1] * claim_u1;
+                if (previousSum != expect) return fail("semi final, circuit level " + std::to_string(i));
+            }
+            if (cur.ty == layerType::FFT || cur.ty == layerType::IFFT) {
+                previousSum = claim_u1;                 // carry the claim, alpha / beta stay as they are
+            } else {
+                if (~cur.bit_length_u[1]) alpha.setByCSPRNG();
+                else alpha.clear();
+                if (~cur.bit_length_v[1]) beta.setByCSPRNG();
+                else beta.clear();
+                previousSum = alpha * claim_u1 + beta * claim_v1;
+            }
+            r_0 = r_u[i].begin();
+            r_1 = r_v[i].begin();
+            toc();
+            beta_u.clear();
+            beta_v.clear();
+        }
+        return true;
+    }
+
+    // ---- stage 2: all claims about layer 0 in one sumcheck (reference src/verifier.cpp:268-357) ----
+    bool verifyFirstLayer() {
+        tic();
+        const layer &cur = C.circuit[0];
+        vector<F> sig_u, sig_v;
+        draw(sig_u, C.size - 1);
+        draw(sig_v, C.size - 1);
+        draw(r_u[0], cur.bit_length);
+        F previousSum = F_ZERO;
+        for (int i = 1; i < C.size; ++i) {
+            if (~C.circuit[i].bit_length_u[0]) previousSum = previousSum + sig_u[i - 1] * final_claim_u0[i];
+            if (~C.circuit[i].bit_length_v[0]) previousSum = previousSum + sig_v[i - 1] * final_claim_v0[i];
+        }
+        toc();
+
+        p->sumcheckLiuInit(sig_u, sig_v);
+        F previousRandom = F_ZERO;
+        for (int j = 0; j < cur.bit_length; ++j) {
+            quadratic_poly poly = p->sumcheckLiuUpdate(previousRandom);
+            transcript.put(poly);
+            if (!drive_only && poly.eval(F_ZERO) + poly.eval(F_ONE) != previousSum)
+                return fail("Liu, circuit 0, current bit " + std::to_string(j));
+            previousRandom = r_u[0][j];
+            previousSum = poly.eval(previousRandom);
+        }
+        p->sumcheckLiuFinalize(previousRandom, eval_in);
+        transcript.put(eval_in);
+
+        if (!drive_only) {
+            total_slow_timer.start();
+            F gr = F_ZERO;
+            beta_g.resize((size_t) 1 << cur.bit_length);
+            initBetaTable(beta_g, cur.bit_length, r_u[0].begin(), F_ONE);
+            for (int i = 1; i < C.size; ++i) {
+                const layer &L = C.circuit[i];
+                if (~L.bit_length_u[0]) {
+                    beta_u.resize((size_t) 1 << L.bit_length_u[0]);
+                    initBetaTable(beta_u, L.bit_length_u[0], r_u[i].begin(), sig_u[i - 1]);
+                    for (u32 j = 0; j < L.size_u[0]; ++j) gr = gr + beta_g[L.ori_id_u[j]] * beta_u[j];
+                }
+                if (~L.bit_length_v[0]) {
+                    beta_v.resize((size_t) 1 << L.bit_length_v[0]);
+                    initBetaTable(beta_v, L.bit_length_v[0], r_v[i].begin(), sig_v[i - 1]);
+                    for (u32 j = 0; j < L.size_v[0]; ++j) gr = gr + beta_g[L.ori_id_v[j]] * beta_v[j];
+                }
+            }
+            total_timer.start();
+            if (eval_in * gr != previousSum) return fail("Liu, semi final, circuit 0");
+            toc();
+        }
+        output_tb[PT_OUT_ID] = to_string_wp(p->proveTime());
+        output_tb[VT_OUT_ID] = to_string_wp(verifierTime());
+        output_tb[PS_OUT_ID] = to_string_wp(p->proofSize());
+        beta_g.clear(); beta_gs.clear(); beta_u.clear(); beta_v.clear();
+        return true;
+    }
+
+    // ---- stage 3: open the committed input at r_u[0] (reference src/verifier.cpp:359-373) ----
+    bool verifyInput() {
+        if (!poly_v->verify(r_u[0], eval_in)) return fail("final input check fail");
+        output_tb[POLY_PT_OUT_ID] = to_string_wp(p->polyProverTime());
+        output_tb[POLY_VT_OUT_ID] = to_string_wp(poly_v->getVT());
+        output_tb[POLY_PS_OUT_ID] = to_string_wp(p->polyProofSize());
+        output_tb[TOT_PT_OUT_ID] = to_string_wp(p->polyProverTime() + p->proveTime());
+        output_tb[TOT_VT_OUT_ID] = to_string_wp(poly_v->getVT() + verifierTime());
+        output_tb[TOT_PS_OUT_ID] = to_string_wp(p->polyProofSize() + p->proofSize());
+        return true;
+    }
+};

@@ -1,0 +1,191 @@
+// <hyrax-bls12-381/polyCommit.hpp> -- the header the reference includes for its field, curve,
+// timer, integer typedefs and polynomial commitment (reference src/global_var.hpp:6,
+// src/circuit.h:6, src/prover.hpp:40-46,74, src/verifier.hpp:43). The upstream submodule
+// (TAMUCrypto/hyrax-bls12-381 + herumi/mcl) is EMPTY in /root/reference, so this is a from-scratch
+// implementation of the surface the call sites need, not a copy of it.
+//
+// Commitment scheme (Hyrax, Wahby et al. S&P'18, matrix form, no blinding -- the reference README
+// states the released version is not fully zero-knowledge):
+//   Z has 2^n entries, viewed as 2^rb rows x 2^cb columns, rb = n/2, cb = n - rb, entry (i, j) at
+//   index i * 2^cb + j (column bits are the LOW bits, matching the little-endian variable order
+//   of the sumcheck). Commitment = one Pedersen vector commitment per row over `gens`.
+//   Opening at x: w = L^T Z with L = eq(x[cb..n)), then a log-round inner-product argument for
+//   <w, R> = y, R = eq(x[0..cb)), against P = sum_i L[i] * C_i:
+//     round: prover sends  Lk = <a_lo, g_hi>, Rk = <a_hi, g_lo>, yL = <a_lo, b_hi>, yR = <a_hi, b_lo>
+//            verifier sends c;   a' = a_lo + c a_hi,  g' = c g_lo + g_hi,  b' = c b_lo + b_hi
+//            P' = Lk + c P + c^2 Rk,   y' = yL + c y + c^2 yR
+//     final: prover sends the scalar a*;  verifier checks  P* == a* g*  and  y* == a* b*.
+// Message order/format of the upstream library is unknowable here ("parity unpinned").
+#pragma once
+#include <chrono>
+#include <memory>
+#include <vector>
+#include "../ff/fr.hpp"
+#include "../ff/g1.hpp"
+
+typedef unsigned char u8;
+typedef unsigned short u16;
+typedef unsigned int u32;
+typedef unsigned long long u64;
+typedef char i8;               // the reference relies on i8 == (signed) char: utils.hpp:13 vs utils.cpp:23
+typedef short i16;
+typedef int i32;
+typedef long long i64;
+
+using zkff::Fr;
+using zkff::G1;
+using zkff::G1Affine;
+
+namespace mcl {
+enum CurveId { BLS12_381 = 5 };
+namespace bn {
+inline const G1 &getG1basePoint() { return G1::generator(); }
+}
+}
+inline void initPairing(mcl::CurveId) {}
+
+// accumulate-on-start/stop wall clock (reference use: src/prover.hpp:42-43, src/verifier.hpp:20-22)
+class timer {
+public:
+    timer() : total_(0), running_(false) {}
+    void start() {
+        if (!running_) { t0_ = std::chrono::steady_clock::now(); running_ = true; }
+    }
+    void stop() {
+        if (running_) {
+            total_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count();
+            running_ = false;
+        }
+    }
+    void clear() { total_ = 0; running_ = false; }
+    double elapse_sec() const {
+        if (!running_) return total_;
+        return total_ + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count();
+    }
+private:
+    double total_;
+    bool running_;
+    std::chrono::steady_clock::time_point t0_;
+};
+
+namespace hyrax_bls12_381 {
+
+// eq(r, .) over `n` little-endian variables scaled by `init`
+inline void eqTable(std::vector<Fr> &out, const Fr *r, int n, const Fr &init) {
+    out.assign((size_t) 1 << n, Fr(0LL));
+    out[0] = init;
+    for (int i = 0; i < n; ++i) {
+        size_t half = (size_t) 1 << i;
+        for (size_t j = 0; j < half; ++j) {
+            Fr t = out[j] * r[i];
+            out[j | half] = t;
+            out[j] = out[j] - t;
+        }
+    }
+}
+
+struct ipaRoundMsg {
+    G1 L, R;
+    Fr yL, yR;
+};
+
+// What the verifier needs from a commitment prover. Two implementations exist: the HIP one
+// (class polyProver, zkcnn_amd/csrc/host/polyProver.{hpp,cpp}) and the CPU checker under oracle/.
+class polyProverBase {
+public:
+    virtual ~polyProverBase() {}
+    virtual const std::vector<G1> &commitment() const = 0;
+    virtual void openInit(const std::vector<Fr> &x) = 0;
+    virtual ipaRoundMsg openRound() = 0;
+    virtual void openFold(const Fr &c) = 0;
+    virtual Fr openFinal() = 0;
+    virtual double getPT() const = 0;      // seconds
+    virtual double getPS() const = 0;      // KB
+};
+
+// hook so a transcript recorder can observe every commitment-phase message in order
+struct transcriptSink {
+    virtual ~transcriptSink() {}
+    virtual void put(const Fr &) = 0;
+    virtual void put(const G1 &) = 0;
+};
+
+class polyVerifier {
+public:
+    polyVerifier(polyProverBase &prover, const std::vector<G1> &gens, transcriptSink *sink = nullptr)
+            : p(prover), g(gens), comm(prover.commitment()), sink_(sink) {
+        if (sink_) for (auto &c : comm) sink_->put(c);
+    }
+
+    bool verify(const std::vector<Fr> &x, const Fr &eval) {
+        vt.start();
+        const int n = (int) x.size();
+        const int rb = n >> 1, cb = n - rb;
+        bool ok = ((size_t) 1 << cb) == g.size() && ((size_t) 1 << rb) == comm.size();
+        if (!ok) { vt.stop(); return false; }
+
+        std::vector<Fr> Lrow, b;
+        eqTable(Lrow, x.data() + cb, rb, Fr::one());
+        eqTable(b, x.data(), cb, Fr::one());
+        G1 P;
+        if (!drive_only) {
+            std::vector<G1Affine> commA;
+            zkff::batchToAffine(comm, commA);
+            P = zkff::msmCPU(Lrow.data(), commA.data(), commA.size());
+        }
+        Fr y = eval;
+        vt.stop();
+
+        p.openInit(x);
+        std::vector<Fr> cs(cb);
+        for (int t = 0; t < cb; ++t) {
+            ipaRoundMsg m = p.openRound();
+            if (sink_) { sink_->put(m.L); sink_->put(m.R); sink_->put(m.yL); sink_->put(m.yR); }
+            vt.start();
+            cs[t].setByCSPRNG();
+            const Fr &c = cs[t];
+            if (!drive_only) {
+                Fr c2 = c * c;
+                P = m.L + P * c + m.R * c2;
+                y = m.yL + c * y + c2 * m.yR;
+            }
+            vt.stop();
+            p.openFold(c);
+        }
+        Fr a = p.openFinal();
+        if (sink_) sink_->put(a);
+
+        if (drive_only) return true;
+        vt.start();
+        // coef(j) = prod_t (bit_{cb-1-t}(j) ? 1 : c_t): round t splits on bit cb-1-t
+        std::vector<Fr> coef((size_t) 1 << cb);
+        coef[0] = Fr::one();
+        for (int t = cb - 1; t >= 0; --t) {
+            // bit index handled in this step: cb-1-t; tables grow from the low bits upward
+            size_t half = (size_t) 1 << (cb - 1 - t);
+            for (size_t j = 0; j < half; ++j) {
+                coef[j | half] = coef[j];
+                coef[j] = coef[j] * cs[t];
+            }
+        }
+        Fr bstar(0LL);
+        for (size_t j = 0; j < coef.size(); ++j) bstar = bstar + coef[j] * b[j];
+        std::vector<G1Affine> gA;
+        zkff::batchToAffine(g, gA);
+        G1 gstar = zkff::msmCPU(coef.data(), gA.data(), gA.size());
+        ok = (P == gstar * a) && (y == a * bstar);
+        vt.stop();
+        return ok;
+    }
+    double getVT() const { return vt.elapse_sec(); }
+    bool drive_only = false;   // make the prover calls and draw the challenges, skip the checks (bench mode)
+
+private:
+    polyProverBase &p;
+    const std::vector<G1> &g;
+    std::vector<G1> comm;
+    transcriptSink *sink_;
+    timer vt;
+};
+
+} // namespace hyrax_bls12_381
