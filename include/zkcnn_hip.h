@@ -1,0 +1,113 @@
+/* C-ABI of the MI355X (gfx950) GKR prover: libzkcnn_hip.so.
+ *
+ * This is the drop-in boundary for the hot path of TAMUCrypto/zkCNN: every entry point below is
+ * the binding of ONE method of the reference's `class prover` (reference src/prover.hpp:18-49) or
+ * of the Hyrax `polyProver` the reference links (reference src/prover.cpp:503-511,
+ * src/verifier.cpp:128,360), with plain pointers and sizes only. The host-side C++14 class
+ * `prover` (zkcnn_amd/csrc/host/prover.{hpp,cpp}) keeps the reference's public C++ API and forwards
+ * to these calls, so the unchanged interactive verifier drives the GPU.
+ *
+ * Conventions
+ *   - a field element (BLS12-381 scalar field) is 4 x uint64_t little-endian limbs in MONTGOMERY
+ *     form (R = 2^256) -- the in-memory form of the host `Fr`;
+ *   - a G1 point is affine, 12 x uint64_t: x then y, 6 Montgomery limbs each (R = 2^384), with
+ *     x = y = 0 encoding the point at infinity;
+ *   - every call returns 0 on success, a negative zk_status otherwise; zk_last_error() has text;
+ *   - calls on one context are not thread safe (neither is the reference prover: file-scope statics,
+ *     reference src/prover.cpp:9); use one context per GPU / per proof stream.
+ */
+#ifndef ZKCNN_HIP_H
+#define ZKCNN_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zk_ctx zk_ctx;
+
+enum zk_status { ZK_OK = 0, ZK_ERR_HIP = -1, ZK_ERR_ARG = -2, ZK_ERR_STATE = -3, ZK_ERR_NOMEM = -4 };
+
+/* gate records exactly as the reference stores them (reference src/circuit.h:15-33) */
+typedef struct { uint32_t g, u; uint8_t lu, sc; uint8_t pad_[2]; } zk_uni_gate;          /* 12 bytes */
+typedef struct { uint32_t g, u, v; uint8_t sc, l; uint8_t pad_[2]; } zk_bin_gate;        /* 16 bytes */
+
+/* layerType values (reference src/circuit.h:35-37) */
+enum zk_layer_type { ZK_INPUT = 0, ZK_FFT, ZK_IFFT, ZK_ADD_BIAS, ZK_RELU, ZK_SQR, ZK_OPT_AVG_POOL, ZK_MAX_POOL,
+                     ZK_AVG_POOL, ZK_DOT_PROD, ZK_PADDING, ZK_FCONN, ZK_NCONV, ZK_NCONV_MUL, ZK_NCONV_ADD };
+
+/* one `layer` of the reference layeredCircuit after initSubset (reference src/circuit.h:39-78) */
+typedef struct {
+    int32_t ty;
+    uint32_t size, size_u[2], size_v[2];
+    int8_t bit_length, bit_length_u[2], bit_length_v[2], max_bl_u, max_bl_v, fft_bit_length;
+    uint8_t need_phase2;
+    uint32_t zero_start_id;
+    uint64_t scale[4];
+    const zk_uni_gate *uni_gates; uint64_t n_uni;
+    const zk_bin_gate *bin_gates; uint64_t n_bin;
+    const uint32_t *ori_id_u, *ori_id_v;      /* size_u[0] / size_v[0] entries */
+} zk_layer_desc;
+
+/* ---- context ---------------------------------------------------------------------------- */
+int32_t zk_ctx_create(int32_t device, zk_ctx **out);
+void zk_ctx_destroy(zk_ctx *ctx);
+const char *zk_last_error(const zk_ctx *ctx);      /* ctx may be NULL: error of the last failed create */
+int32_t zk_device_count(void);
+
+/* ---- residency: prover::C and prover::val (reference src/prover.hpp:48-49) move to HBM ------ */
+/* Uploads the circuit, sorts every layer's gates by destination table entry (the CSR order the
+ * scatter kernels need) and sizes all work buffers. two_mul = layeredCircuit::two_mul. */
+int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul,
+                          int32_t n_two_mul);
+/* val[layer] (n = layer size); stored zero-padded to 2^bit_length */
+int32_t zk_upload_layer_values(zk_ctx *ctx, int32_t layer, const uint64_t *values, uint64_t n);
+
+/* ---- prover state machine: one call per reference method ------------------------------------ */
+int32_t zk_prover_init(zk_ctx *ctx);                                                   /* prover::init            prover.cpp:17  */
+int32_t zk_vres(zk_ctx *ctx, const uint64_t *r, uint32_t output_size, uint32_t r_size, uint64_t out[4]);   /* Vres   :434 */
+int32_t zk_sumcheck_init_all(zk_ctx *ctx, const uint64_t *r_0, uint32_t n);            /* sumcheckInitAll         :28  */
+int32_t zk_sumcheck_init(zk_ctx *ctx, const uint64_t alpha[4], const uint64_t beta[4]); /* sumcheckInit           :43  */
+int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx);                                  /* sumcheckDotProdInitPhase1 :57 */
+int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[4]);              /* sumcheckInitPhase1      :155 */
+int32_t zk_sumcheck_init_phase2(zk_ctx *ctx);                                          /* sumcheckInitPhase2      :241 */
+int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t out_abcd[16]);   /* :103 cubic a,b,c,d */
+int32_t zk_sumcheck_update1(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t out_abc[12]);            /* :360 quadratic */
+int32_t zk_sumcheck_update2(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t out_abc[12]);            /* :364 */
+int32_t zk_sumcheck_dotprod_finalize1(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t claim_1[4]);  /* :146 */
+int32_t zk_sumcheck_finalize1(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t claim_0[4], uint64_t claim_1[4]);   /* :459 */
+int32_t zk_sumcheck_finalize2(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t claim_0[4], uint64_t claim_1[4]);   /* :473 */
+int32_t zk_sumcheck_liu_init(zk_ctx *ctx, const uint64_t *s_u, const uint64_t *s_v, uint32_t n);    /* sumcheckLiuInit :312 */
+int32_t zk_sumcheck_liu_update(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t out_abc[12]);        /* :385 */
+int32_t zk_sumcheck_liu_finalize(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t claim_1[4]);       /* :487 */
+uint64_t zk_proof_bytes(const zk_ctx *ctx);                                            /* proof_size counter  prover.hpp:44 */
+
+/* ---- Hyrax commitment of layer 0 (protocol: zkcnn_amd/csrc/hyrax-bls12-381/polyCommit.hpp) ------ */
+/* commitInput: prover.cpp:503-511. gens: n_gens = 2^(bl0 - bl0/2) affine points; out_comm: 2^(bl0/2) affine points */
+int32_t zk_commit_input(zk_ctx *ctx, const uint64_t *gens, uint64_t n_gens, uint64_t *out_comm, uint64_t n_rows);
+int32_t zk_hyrax_open_init(zk_ctx *ctx, const uint64_t *x, uint32_t n);
+int32_t zk_hyrax_open_round(zk_ctx *ctx, uint64_t L[12], uint64_t R[12], uint64_t yL[4], uint64_t yR[4]);
+int32_t zk_hyrax_open_fold(zk_ctx *ctx, const uint64_t c[4]);
+int32_t zk_hyrax_open_final(zk_ctx *ctx, uint64_t a[4]);
+
+/* ---- kernel-level entry points (host arrays in/out; used by the parity tests and the micro-benches) ---- */
+int32_t zk_k_fr_mul(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n);
+int32_t zk_k_fr_add(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n);
+int32_t zk_k_fr_sub(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n);
+int32_t zk_k_eq_table(zk_ctx *ctx, uint64_t *out, int32_t n, const uint64_t *r0, const uint64_t *r1,
+                      const uint64_t alpha[4], const uint64_t beta[4]);
+int32_t zk_k_phi_table(zk_ctx *ctx, uint64_t *out, const uint64_t *rx, const uint64_t scale[4], int32_t n, int32_t inverse);
+/* one quadratic sumcheck round on two n-entry tables: fold with r unless `first`, then round polynomial.
+ * V / M are updated in place to the folded tables; returns the folded length in *n_out. */
+int32_t zk_k_round_quadratic(zk_ctx *ctx, uint64_t *V, uint64_t *M, uint64_t n, const uint64_t r[4], int32_t first,
+                             uint64_t out_abc[12], uint64_t *n_out);
+int32_t zk_k_msm(zk_ctx *ctx, uint64_t out[12], const uint64_t *scalars, const uint64_t *bases, uint64_t n);
+/* device-resident micro-benchmarks: seconds per launch, averaged over `iters` launches with HIP events */
+int32_t zk_bench_fr_mul(zk_ctx *ctx, uint64_t n_threads, uint32_t muls_per_thread, uint32_t iters, double *sec);
+int32_t zk_bench_round_quadratic(zk_ctx *ctx, uint32_t log_n, uint32_t iters, double *sec_per_launch,
+                                 double *algorithmic_bytes);
+int32_t zk_bench_copy(zk_ctx *ctx, uint64_t bytes, uint32_t iters, double *sec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

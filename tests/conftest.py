@@ -1,0 +1,35 @@
+import ctypes
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """native libraries, built once per test session (hipcc cross-compiles without a GPU)"""
+    import __graft_entry__
+    __graft_entry__.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def oracle(built):
+    """CPU checker: oracle/liboracle.so (test infrastructure)"""
+    from tests import oracle_ffi
+    return oracle_ffi.load()
+
+
+@pytest.fixture(scope="session")
+def hip(built):
+    import zkcnn_amd
+    ctx = zkcnn_amd.HipContext(0)
+    yield ctx
+    ctx.close()

@@ -1,0 +1,136 @@
+"""ctypes bindings of oracle/liboracle.so -- the CPU checker. Test infrastructure only."""
+import ctypes
+import os
+
+import numpy as np
+
+import zkcnn_amd
+from zkcnn_amd import u64p
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+
+    # ---- field ----
+    def from_canonical(self, a):
+        out = np.zeros_like(a)
+        self.lib.oracle_fr_from_canonical(u64p(out), u64p(a), ctypes.c_uint64(a.shape[0]))
+        return out
+
+    def to_canonical(self, a):
+        out = np.zeros_like(a)
+        self.lib.oracle_fr_to_canonical(u64p(out), u64p(a), ctypes.c_uint64(a.shape[0]))
+        return out
+
+    def binop(self, op, a, b):
+        out = np.zeros_like(a)
+        getattr(self.lib, "oracle_fr_" + op)(u64p(out), u64p(a), u64p(b), ctypes.c_uint64(a.shape[0]))
+        return out
+
+    def inv(self, a):
+        out = np.zeros_like(a)
+        self.lib.oracle_fr_inv(u64p(out), u64p(a), ctypes.c_uint64(a.shape[0]))
+        return out
+
+    def random(self, n, seed):
+        out = np.zeros((n, 4), dtype=np.uint64)
+        self.lib.oracle_fr_random(u64p(out), ctypes.c_uint64(n), ctypes.c_uint64(seed))
+        return out
+
+    def root_of_unity(self, n):
+        out = np.zeros((1, 4), dtype=np.uint64)
+        self.lib.oracle_root_of_unity(u64p(out), ctypes.c_int32(n))
+        return out
+
+    # ---- tables ----
+    def eq_table2(self, n, r0, r1, alpha, beta):
+        out = np.zeros((1 << n, 4), dtype=np.uint64)
+        self.lib.oracle_eq_table2(u64p(out), ctypes.c_int32(n), u64p(r0), u64p(r1), u64p(alpha), u64p(beta))
+        return out
+
+    def eq_table1(self, n, r, init):
+        out = np.zeros((1 << n, 4), dtype=np.uint64)
+        self.lib.oracle_eq_table1(u64p(out), ctypes.c_int32(n), u64p(r), u64p(init))
+        return out
+
+    def phi_table(self, rx, scale, n, inverse):
+        cnt = (1 << n) if inverse else (1 << (n - 1))
+        out = np.zeros((cnt, 4), dtype=np.uint64)
+        self.lib.oracle_phi_table(u64p(out), u64p(rx), u64p(scale), ctypes.c_int32(n), ctypes.c_int32(int(inverse)))
+        return out
+
+    def ntt(self, data, logn, inverse):
+        data = np.ascontiguousarray(data.copy())
+        batch = data.shape[0] >> logn
+        self.lib.oracle_ntt(u64p(data), ctypes.c_int32(logn), ctypes.c_int32(int(inverse)), ctypes.c_uint64(batch))
+        return data
+
+    def round_quadratic(self, V, M, r, first):
+        out = np.zeros((3, 4), dtype=np.uint64)
+        self.lib.oracle_round_quadratic.restype = ctypes.c_uint64
+        n = self.lib.oracle_round_quadratic(u64p(V), u64p(M), ctypes.c_uint64(V.shape[0]), u64p(r), ctypes.c_int32(int(first)), u64p(out))
+        return out, n
+
+    # ---- curve ----
+    def generators(self, n, seed):
+        out = np.zeros((n, 12), dtype=np.uint64)
+        self.lib.oracle_g1_generators(u64p(out), ctypes.c_uint64(n), ctypes.c_uint64(seed))
+        return out
+
+    def msm(self, scalars, bases):
+        out = np.zeros(12, dtype=np.uint64)
+        self.lib.oracle_msm(u64p(out), u64p(scalars), u64p(bases), ctypes.c_uint64(scalars.shape[0]))
+        return out
+
+    def g1_base(self):
+        out = np.zeros(12, dtype=np.uint64)
+        self.lib.oracle_g1_base(u64p(out))
+        return out
+
+    def g1_mul(self, p, k):
+        out = np.zeros(12, dtype=np.uint64)
+        self.lib.oracle_g1_mul(u64p(out), u64p(p), u64p(k))
+        return out
+
+    def g1_add(self, p, q):
+        out = np.zeros(12, dtype=np.uint64)
+        self.lib.oracle_g1_add(u64p(out), u64p(p), u64p(q))
+        return out
+
+    def g1_on_curve(self, p):
+        return bool(self.lib.oracle_g1_on_curve(u64p(p)))
+
+    def g1_serialize(self, p):
+        buf = (ctypes.c_uint8 * 48)()
+        self.lib.oracle_g1_serialize(buf, u64p(p))
+        return bytes(buf)
+
+    def fp_to_canonical(self, a):
+        a = np.ascontiguousarray(a.reshape(-1, 6))
+        out = np.zeros_like(a)
+        self.lib.oracle_fp_to_canonical(u64p(out), u64p(a), ctypes.c_uint64(a.shape[0]))
+        return out
+
+
+class OracleSession(zkcnn_amd._SessionBase):
+    """whole-proof driver of include/zkcnn_api.h backed by the CPU restatement"""
+    _prefix = "oracle_"
+
+    def __init__(self, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928):
+        super().__init__(load().lib, model, pic, pic_cnt, data_seed, 0)
+
+
+_oracle = None
+
+
+def load():
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/liboracle.so missing: run `make -C oracle`")
+        _oracle = Oracle(ctypes.CDLL(path))
+    return _oracle

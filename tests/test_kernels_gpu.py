@@ -1,0 +1,102 @@
+"""Kernel-level parity on the GPU: every zk_k_* entry point of include/zkcnn_hip.h against the CPU oracle
+(bit-exact: integer field arithmetic) and against Python big-int arithmetic."""
+import numpy as np
+import pytest
+
+import zkcnn_amd
+from zkcnn_amd import R_MOD, from_mont, to_mont
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(oracle, n, seed):
+    return oracle.random(n, seed)
+
+
+def test_fr_ops_match_oracle_and_bigint(hip, oracle):
+    n = 5000
+    a, b = _rand(oracle, n, 1), _rand(oracle, n, 2)
+    # edge values: 0, 1, r-1 in every pairing
+    edge = to_mont([0, 1, R_MOD - 1, 2, R_MOD - 2, (R_MOD - 1) // 2, (R_MOD + 1) // 2])
+    a[:7], b[:7] = edge, edge[::-1]
+    ai, bi = from_mont(a), from_mont(b)
+    for op, f in (("mul", lambda x, y: x * y % R_MOD), ("add", lambda x, y: (x + y) % R_MOD), ("sub", lambda x, y: (x - y) % R_MOD)):
+        g = hip.fr_binop(op, a, b)
+        assert np.array_equal(g, oracle.binop(op, a, b)), op
+        assert from_mont(g[:200]) == [f(x, y) for x, y in zip(ai[:200], bi[:200])], op
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 5, 10, 13, 17])
+def test_eq_table(hip, oracle, n):
+    r0, r1 = _rand(oracle, max(n, 1), 10 + n), _rand(oracle, max(n, 1), 50 + n)
+    al, be = _rand(oracle, 1, 3), _rand(oracle, 1, 4)
+    zero = np.zeros((1, 4), dtype=np.uint64)
+    for alpha, beta in ((al, be), (al, zero), (zero, be), (zero, zero)):
+        g = hip.eq_table(n, r0, r1, alpha, beta)
+        assert np.array_equal(g, oracle.eq_table2(n, r0, r1, alpha, beta))
+
+
+@pytest.mark.parametrize("n", [2, 5, 9, 12])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_phi_table_closed_form_equals_reference_recursion(hip, oracle, n, inverse):
+    rx, scale = _rand(oracle, n, 77 + n), _rand(oracle, 1, 5)
+    assert np.array_equal(hip.phi_table(rx, scale, n, inverse), oracle.phi_table(rx, scale, n, inverse))
+
+
+@pytest.mark.parametrize("logn", [1, 2, 3, 8, 14, 18])
+def test_round_quadratic_full_sumcheck(hip, oracle, logn):
+    """run a whole sumcheck (first round + folds) on GPU and oracle, compare every round polynomial,
+    check the round identity p(0) + p(1) == claim, and the final folded values"""
+    n = 1 << logn
+    V, M = _rand(oracle, n, 100 + logn), _rand(oracle, n, 200 + logn)
+    if logn >= 3:       # zero tail, like a padded table
+        V[n - n // 3:] = 0
+    Vg, Mg, Vo, Mo = V.copy(), M.copy(), V.copy(), M.copy()
+    rs = _rand(oracle, logn, 300 + logn)
+    claim = sum(x * y for x, y in zip(from_mont(V), from_mont(M))) % R_MOD if logn <= 8 else None
+    first, ng = True, n
+    for k in range(logn):
+        r = rs[max(k - 1, 0):max(k - 1, 0) + 1]
+        cg, ng2 = hip.round_quadratic(Vg[:ng], Mg[:ng], r, first)
+        co, no2 = oracle.round_quadratic(Vo[:ng], Mo[:ng], r, first)
+        assert ng2 == no2
+        assert np.array_equal(cg, co), f"round {k}"
+        assert np.array_equal(Vg[:ng2], Vo[:ng2]) and np.array_equal(Mg[:ng2], Mo[:ng2])
+        if claim is not None:
+            a, b, c = from_mont(cg)
+            assert (c + a + b + c) % R_MOD == claim
+            x = from_mont(rs[k:k + 1])[0]
+            claim = (a * x * x + b * x + c) % R_MOD
+        first, ng = False, ng2
+
+
+def test_microbench_report(hip):
+    """not a pass/fail test: prints the ALU and HBM ceilings the roofline numbers are read against"""
+    sec = hip.bench_fr_mul(1 << 20, 256, iters=3)
+    rate = (1 << 20) * 256 / sec
+    cp = hip.bench_copy(1 << 30, iters=10)
+    rq, nbytes = hip.bench_round_quadratic(24, iters=10)
+    print(f"\nfr_mul: {rate / 1e9:.1f} G mul/s; copy: {2 * (1 << 30) / cp / 1e9:.0f} GB/s; "
+          f"round_quad 2^24: {rq * 1e3:.3f} ms = {nbytes / rq / 1e9:.0f} GB/s algorithmic")
+    assert rate > 1e9
+
+
+@pytest.mark.parametrize("n,kind", [(1, "rand"), (7, "rand"), (300, "rand"), (1024, "small"), (2048, "bits"), (513, "mixed")])
+def test_msm_matches_cpu_pippenger(hip, oracle, n, kind):
+    bases = oracle.generators(n, 1000 + n)
+    if kind == "rand":
+        sc = oracle.random(n, 5 + n)
+    elif kind == "small":        # signed 9-bit quantised weights
+        rng = np.random.default_rng(n)
+        sc = to_mont([int(x) % R_MOD for x in rng.integers(-255, 256, n)])
+    elif kind == "bits":
+        rng = np.random.default_rng(n)
+        sc = to_mont([int(x) for x in rng.integers(0, 2, n)])
+    else:
+        sc = oracle.random(n, 9)
+        sc[::3] = 0
+        sc[1::7] = to_mont([R_MOD - 1])[0]
+        bases[5] = 0             # point at infinity among the bases
+    g = hip.msm(sc, bases)
+    assert np.array_equal(g, oracle.msm(sc, bases))
+    assert oracle.g1_on_curve(g)

@@ -1,0 +1,224 @@
+"""zkcnn_amd -- MI355X-native GKR prover for zkCNN (ctypes bindings over the C-ABI libraries).
+
+Product libraries (built in-tree by zkcnn_amd/build.py):
+  lib/libzkcnn_hip.so   include/zkcnn_hip.h   HIP kernels + prover state machine
+  lib/libzkcnn_host.so  include/zkcnn_api.h   C++14 host: circuit generator, verifier, prover adapter
+
+Nothing here falls back to a CPU implementation: without the HIP library and a GPU the calls raise.
+The CPU checker lives in oracle/ and is only ever loaded by tests, smoke() and bench.py's cpu_baseline.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_DIR = os.path.join(ROOT, "zkcnn_amd", "lib")
+
+R_MOD = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+P_MOD = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+
+MODE_VERIFY, MODE_DRIVE_ONLY, MODE_REUSE_GENS = 0, 1, 2
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [("model", ctypes.c_char_p), ("pic_x", ctypes.c_int32), ("pic_y", ctypes.c_int32),
+                ("pic_channel", ctypes.c_int32), ("pic_cnt", ctypes.c_int32), ("data_seed", ctypes.c_uint64)]
+
+
+class Result(ctypes.Structure):
+    _fields_ = [("accepted", ctypes.c_int32), ("n_layers", ctypes.c_int32), ("input_size", ctypes.c_uint64),
+                ("input_bits", ctypes.c_int32), ("n_rounds", ctypes.c_int32),
+                ("prove_s", ctypes.c_double), ("poly_prove_s", ctypes.c_double), ("verify_s", ctypes.c_double),
+                ("poly_verify_s", ctypes.c_double), ("proof_kb", ctypes.c_double), ("poly_proof_kb", ctypes.c_double),
+                ("witness_s", ctypes.c_double), ("upload_s", ctypes.c_double), ("wall_s", ctypes.c_double),
+                ("transcript_len", ctypes.c_uint64), ("gate_cnt_uni", ctypes.c_uint64), ("gate_cnt_bin", ctypes.c_uint64),
+                ("table_entries", ctypes.c_uint64), ("message", ctypes.c_char * 128)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["message"] = self.message.decode(errors="replace")
+        return d
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python zkcnn_amd/build.py` (or __graft_entry__.build())")
+    return ctypes.CDLL(path)
+
+
+_hip = None
+_host = None
+
+
+def hip_lib():
+    """libzkcnn_hip.so (raises if it has not been built)."""
+    global _hip
+    if _hip is None:
+        _hip = _load(os.path.join(LIB_DIR, "libzkcnn_hip.so"))
+        _hip.zk_last_error.restype = ctypes.c_char_p
+        _hip.zk_proof_bytes.restype = ctypes.c_uint64
+    return _hip
+
+
+def host_lib():
+    """libzkcnn_host.so (needs libzkcnn_hip.so next to it)."""
+    global _host
+    if _host is None:
+        hip_lib()
+        _host = _load(os.path.join(LIB_DIR, "libzkcnn_host.so"))
+        _host.zkcnn_session_create.restype = ctypes.c_void_p
+    return _host
+
+
+# ---- field helpers: python ints <-> (n, 4) uint64 limb arrays -----------------------------------------
+def to_limbs(xs, n=4):
+    a = np.zeros((len(xs), n), dtype=np.uint64)
+    for i, x in enumerate(xs):
+        for j in range(n):
+            a[i, j] = (x >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    return a
+
+
+def from_limbs(a):
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, a.shape[-1])
+    return [sum(int(a[i, j]) << (64 * j) for j in range(a.shape[1])) for i in range(a.shape[0])]
+
+
+def to_mont(xs):
+    """canonical python ints -> Montgomery-form limb array (the C-ABI form)"""
+    return to_limbs([(x % R_MOD) * (1 << 256) % R_MOD for x in xs])
+
+
+def from_mont(a):
+    rinv = pow(1 << 256, -1, R_MOD)
+    return [x * rinv % R_MOD for x in from_limbs(a)]
+
+
+def u64p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+
+class HipContext:
+    """One GPU prover context (zk_ctx). Raises RuntimeError when no GPU / library is available."""
+
+    def __init__(self, device=0):
+        self.lib = hip_lib()
+        self.ctx = ctypes.c_void_p()
+        rc = self.lib.zk_ctx_create(ctypes.c_int32(device), ctypes.byref(self.ctx))
+        if rc != 0:
+            raise RuntimeError("zk_ctx_create failed: " + self.lib.zk_last_error(None).decode())
+
+    def close(self):
+        if self.ctx:
+            self.lib.zk_ctx_destroy(self.ctx)
+            self.ctx = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): " + self.lib.zk_last_error(self.ctx).decode())
+
+    def fr_binop(self, op, a, b):
+        out = np.zeros_like(a)
+        fn = getattr(self.lib, "zk_k_fr_" + op)
+        self._check(fn(self.ctx, u64p(out), u64p(a), u64p(b), ctypes.c_uint64(a.shape[0])), "zk_k_fr_" + op)
+        return out
+
+    def eq_table(self, n, r0, r1, alpha, beta):
+        out = np.zeros((1 << n, 4), dtype=np.uint64)
+        self._check(self.lib.zk_k_eq_table(self.ctx, u64p(out), ctypes.c_int32(n), u64p(r0), u64p(r1), u64p(alpha), u64p(beta)),
+                    "zk_k_eq_table")
+        return out
+
+    def phi_table(self, rx, scale, n, inverse):
+        cnt = (1 << n) if inverse else (1 << (n - 1))
+        out = np.zeros((cnt, 4), dtype=np.uint64)
+        self._check(self.lib.zk_k_phi_table(self.ctx, u64p(out), u64p(rx), u64p(scale), ctypes.c_int32(n), ctypes.c_int32(int(inverse))),
+                    "zk_k_phi_table")
+        return out
+
+    def round_quadratic(self, V, M, r, first):
+        """in-place on V / M; returns (coefficients (3,4), new length)"""
+        out = np.zeros((3, 4), dtype=np.uint64)
+        n_out = ctypes.c_uint64()
+        self._check(self.lib.zk_k_round_quadratic(self.ctx, u64p(V), u64p(M), ctypes.c_uint64(V.shape[0]), u64p(r),
+                                                  ctypes.c_int32(int(first)), u64p(out), ctypes.byref(n_out)), "zk_k_round_quadratic")
+        return out, n_out.value
+
+    def msm(self, scalars, bases):
+        out = np.zeros(12, dtype=np.uint64)
+        self._check(self.lib.zk_k_msm(self.ctx, u64p(out), u64p(scalars), u64p(bases), ctypes.c_uint64(scalars.shape[0])), "zk_k_msm")
+        return out
+
+    def bench_fr_mul(self, n_threads, muls, iters=5):
+        sec = ctypes.c_double()
+        self._check(self.lib.zk_bench_fr_mul(self.ctx, ctypes.c_uint64(n_threads), ctypes.c_uint32(muls), ctypes.c_uint32(iters),
+                                             ctypes.byref(sec)), "zk_bench_fr_mul")
+        return sec.value
+
+    def bench_copy(self, nbytes, iters=10):
+        sec = ctypes.c_double()
+        self._check(self.lib.zk_bench_copy(self.ctx, ctypes.c_uint64(nbytes), ctypes.c_uint32(iters), ctypes.byref(sec)), "zk_bench_copy")
+        return sec.value
+
+    def bench_round_quadratic(self, log_n, iters=10):
+        sec, nbytes = ctypes.c_double(), ctypes.c_double()
+        self._check(self.lib.zk_bench_round_quadratic(self.ctx, ctypes.c_uint32(log_n), ctypes.c_uint32(iters), ctypes.byref(sec),
+                                                      ctypes.byref(nbytes)), "zk_bench_round_quadratic")
+        return sec.value, nbytes.value
+
+
+class _SessionBase:
+    _prefix = None
+
+    def _fn(self, name):
+        return getattr(self.lib, self._prefix + name)
+
+    def __init__(self, lib, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0):
+        self.lib = lib
+        self._fn("session_create").restype = ctypes.c_void_p
+        self.desc = ModelDesc(model.encode(), pic[0], pic[1], pic[2], pic_cnt, data_seed)
+        self.h = self._fn("session_create")(ctypes.byref(self.desc), ctypes.c_int32(device))
+        if not self.h:
+            raise RuntimeError(f"{self._prefix}session_create({model}) failed")
+
+    def prove(self, seed=0x5EED0001, mode=MODE_VERIFY, want_transcript=True):
+        cap = (1 << 24) if want_transcript else 0
+        buf = (ctypes.c_uint8 * max(cap, 1))()
+        res = Result()
+        rc = self._fn("session_prove")(ctypes.c_void_p(self.h), ctypes.c_uint64(seed), ctypes.c_uint32(mode), buf,
+                                       ctypes.c_uint64(cap), ctypes.byref(res))
+        if rc != 0:
+            raise RuntimeError(f"{self._prefix}session_prove failed ({rc}): {res.message.decode(errors='replace')}")
+        data = bytes(buf[:min(res.transcript_len, cap)]) if want_transcript else b""
+        return res, data
+
+    def row(self):
+        buf = ctypes.create_string_buffer(1024)
+        self._fn("session_row")(ctypes.c_void_p(self.h), buf, ctypes.c_uint64(1024))
+        return buf.value.decode()
+
+    def close(self):
+        if self.h:
+            self._fn("session_destroy")(ctypes.c_void_p(self.h))
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class Session(_SessionBase):
+    """Circuit + witness resident on one GPU; prove() runs verifier <-> HIP prover (include/zkcnn_api.h)."""
+    _prefix = "zkcnn_"
+
+    def __init__(self, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0):
+        super().__init__(host_lib(), model, pic, pic_cnt, data_seed, device)

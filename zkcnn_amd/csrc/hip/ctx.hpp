@@ -1,0 +1,113 @@
+// Internal state of one prover context (one GPU). Shared by sumcheck.hip and hyrax.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "../../../include/zkcnn_hip.h"
+#include "../ff/fr.hpp"
+#include "types.cuh"
+
+typedef zkff::Fr HFr;      // host-side field element (same 32-byte layout as fr_t)
+
+struct dev_buf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct dev_layer {
+    zk_layer_desc d;               // copy of the descriptor (host pointers nulled)
+    fr_t *val = nullptr;           // 2^bit_length entries, zero padded
+    uint64_t val_len = 0;
+    // phase-1 lists: gates whose u operand lives in table b (0: layer-0 subset, 1: previous layer), sorted by u
+    gate_rec *p1[2] = {nullptr, nullptr};
+    uint64_t n_p1[2] = {0, 0};
+    // phase-2 lists: bin gates whose v operand lives in table b, sorted by v
+    gate_rec *p2[2] = {nullptr, nullptr};
+    uint64_t n_p2[2] = {0, 0};
+    gate_rec *uni2 = nullptr;      // uni gates for the phase-2 constant term (aux = u, bit 10 = u in previous layer)
+    uint64_t n_uni2 = 0;
+    uint32_t *ori_u = nullptr, *ori_v = nullptr;
+    // DOT_PROD: gates sorted by u (aux = v) with CSR row pointers
+    gate_rec *d1 = nullptr;
+    uint32_t *d1_rowptr = nullptr;
+    uint32_t d1_rows = 0;
+};
+
+// one (V, M) bookkeeping-table pair of a sumcheck, ping-pong buffered
+struct table_pair {
+    fr_t *V[2] = {nullptr, nullptr};
+    fr_t *M[2] = {nullptr, nullptr};
+    int cur = 0;
+    uint64_t len = 0;              // current (pre-fold) length; 0 = absent or already absorbed
+    bool absorbed = false;         // collapsed to a constant whose product went into add_term
+    HFr final_v;                   // value of V when it collapsed
+};
+
+struct msm_state;                  // hyrax.hip
+
+struct zk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    std::vector<dev_layer> L;
+    fr_t *two_mul = nullptr;
+    int n_two_mul = 0;
+    std::vector<void *> owned;     // every device allocation, freed in zk_ctx_destroy
+
+    // work buffers
+    table_pair tp[2];
+    uint64_t max_table = 0;
+    fr_t *beta_g[2] = {nullptr, nullptr};   // ping-pong (the PADDING layer expands the FFT layer's table)
+    int beta_g_cur = 0;
+    uint64_t beta_g_cap = 0;
+    fr_t *beta_u = nullptr; uint64_t beta_u_cap = 0;
+    fr_t *beta_gs = nullptr; uint64_t beta_gs_cap = 0;
+    fr_t *small[2] = {nullptr, nullptr};    // periodic table of the cubic rounds (ping-pong)
+    uint32_t small_len = 0; int small_cur = 0;
+    fr_t *eq_lo = nullptr, *eq_hi = nullptr; uint32_t eq_stride = 0;
+    fr_t *partials = nullptr; uint32_t partial_blocks = 0;
+    fr_t *d_result = nullptr;      // 32 elements
+    HFr *h_result = nullptr;       // pinned, 32 elements
+    uint32_t *carry_key = nullptr; fr_t *carry_val = nullptr; uint64_t carry_slots = 0;
+    dev_buf scratch;               // growable (mat-vec partial sums, ...)
+    std::vector<fr_t *> root_pw[2];  // [inverse][n] powers of the 2^n-th root of unity
+
+    // prover state machine (names follow reference src/prover.hpp:55-74)
+    std::vector<std::vector<HFr>> r_u, r_v;
+    const HFr *r_0 = nullptr, *r_1 = nullptr;
+    HFr alpha, beta, relu_rou, add_term, V_u0, V_u1;
+    HFr small_final;               // collapsed periodic table (DOT_PROD)
+    uint64_t proof_size = 0;
+    int sumcheck_id = 0, round = 0;
+    bool circuit_ready = false;
+
+    msm_state *msm = nullptr;
+};
+
+#define ZK_HIP(call)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+            return ZK_ERR_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+static inline fr_t to_dev(const HFr &x) {
+    fr_t z;
+    std::memcpy(&z, &x, 32);
+    return z;
+}
+static inline uint32_t grid_for(uint64_t work, uint32_t cap = 2048) {
+    uint64_t b = (work + ZK_BLOCK - 1) / ZK_BLOCK;
+    if (b < 1) b = 1;
+    return (uint32_t) (b > cap ? cap : b);
+}
+
+int32_t zk_dev_alloc(zk_ctx *ctx, void **p, size_t bytes);          // tracked allocation
+int32_t zk_scratch(zk_ctx *ctx, size_t bytes);                       // grow ctx->scratch
+void zk_msm_destroy(zk_ctx *ctx);
+// device-side helpers implemented in sumcheck.hip and re-used by hyrax.hip
+int32_t zk_eq_table1_dev(zk_ctx *ctx, fr_t *out, int n, const HFr *r, const HFr &init);
+int32_t zk_col_combine_dev(zk_ctx *ctx, fr_t *out, const fr_t *Z, const fr_t *L, uint32_t cols, uint32_t rows);

@@ -1,0 +1,254 @@
+// Device-side BLS12-381 base field Fp (381 bits, 12 x 32-bit limbs, Montgomery R = 2^384) and G1
+// (y^2 = x^3 + 4) point arithmetic for the Hyrax commitment kernels (K13/K14 in SURVEY.md).
+// Replaces the G1 arithmetic of mcl that the absent hyrax-bls12-381 library uses for its Pedersen
+// commitments. Limb layout equals the host zkff::Fp (6 x u64) so points cross the C-ABI unchanged.
+#pragma once
+#include "fr_dev.cuh"
+
+struct __align__(16) fp_t {
+    uint32_t v[12];
+};
+
+#define FP_MOD_INIT {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u, \
+                     0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau}
+#define FP_ONE_INIT {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu, 0x53c758bau, 0x5f489857u, \
+                     0x70525745u, 0x77ce5853u, 0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u}
+#define FP_INV32 0xfffcfffdu
+
+__device__ __forceinline__ fp_t fp_zero() {
+    fp_t z;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) z.v[i] = 0;
+    return z;
+}
+__device__ __forceinline__ fp_t fp_one() {
+    const uint32_t o[12] = FP_ONE_INIT;
+    fp_t z;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) z.v[i] = o[i];
+    return z;
+}
+__device__ __forceinline__ bool fp_is_zero(const fp_t &a) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc |= a.v[i];
+    return acc == 0;
+}
+__device__ __forceinline__ bool fp_eq(const fp_t &a, const fp_t &b) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc |= a.v[i] ^ b.v[i];
+    return acc == 0;
+}
+__device__ __forceinline__ void fp_cond_sub(fp_t &z, const uint32_t *t) {
+    const uint32_t m[12] = FP_MOD_INIT;
+    uint32_t d[12];
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        uint64_t x = (uint64_t) t[i] - m[i] - borrow;
+        d[i] = (uint32_t) x;
+        borrow = (x >> 32) & 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) z.v[i] = borrow ? t[i] : d[i];
+}
+__device__ __forceinline__ fp_t fp_add(const fp_t &a, const fp_t &b) {
+    uint32_t t[12];
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        c += (uint64_t) a.v[i] + b.v[i];
+        t[i] = (uint32_t) c;
+        c >>= 32;
+    }
+    fp_t z;
+    fp_cond_sub(z, t);          // p < 2^381: no carry out of the top limb
+    return z;
+}
+__device__ __forceinline__ fp_t fp_sub(const fp_t &a, const fp_t &b) {
+    const uint32_t m[12] = FP_MOD_INIT;
+    uint32_t t[12];
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        uint64_t x = (uint64_t) a.v[i] - b.v[i] - borrow;
+        t[i] = (uint32_t) x;
+        borrow = (x >> 32) & 1;
+    }
+    const uint32_t mask = borrow ? 0xffffffffu : 0u;
+    fp_t z;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        c += (uint64_t) t[i] + (m[i] & mask);
+        z.v[i] = (uint32_t) c;
+        c >>= 32;
+    }
+    return z;
+}
+__device__ __forceinline__ fp_t fp_neg(const fp_t &a) { return fp_sub(fp_zero(), a); }
+__device__ __forceinline__ fp_t fp_dbl(const fp_t &a) { return fp_add(a, a); }
+
+// CIOS Montgomery product over 12 limbs (288 32x32 MADs)
+__device__ __noinline__ fp_t fp_mul(const fp_t a, const fp_t b) {
+    const uint32_t m[12] = FP_MOD_INIT;
+    uint32_t t[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            c += (uint64_t) a.v[j] * b.v[i] + t[j];
+            t[j] = (uint32_t) c;
+            c >>= 32;
+        }
+        c += t[12];
+        t[12] = (uint32_t) c;
+        t[13] = (uint32_t) (c >> 32);
+        const uint32_t q = t[0] * FP_INV32;
+        c = (uint64_t) q * m[0] + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 12; ++j) {
+            c += (uint64_t) q * m[j] + t[j];
+            t[j - 1] = (uint32_t) c;
+            c >>= 32;
+        }
+        c += t[12];
+        t[11] = (uint32_t) c;
+        t[12] = t[13] + (uint32_t) (c >> 32);
+    }
+    fp_t z;
+    fp_cond_sub(z, t);
+    return z;
+}
+__device__ __forceinline__ fp_t fp_sqr(const fp_t &a) { return fp_mul(a, a); }
+
+// a^(p-2): Fermat inverse (inv(0) = 0)
+__device__ inline fp_t fp_inv(const fp_t &a) {
+    const uint32_t e[12] = {0xffffaaa9u, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                            0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+    fp_t acc = fp_one(), base = a;
+    for (int i = 0; i < 12; ++i) {
+        uint32_t w = e[i];
+        for (int b = 0; b < 32; ++b) {
+            if (i == 11 && b >= 29) break;          // p has 381 bits
+            if ((w >> b) & 1) acc = fp_mul(acc, base);
+            base = fp_sqr(base);
+        }
+    }
+    return acc;
+}
+
+struct g1a_t { fp_t x, y; };                 // affine; (0,0) = infinity
+struct g1j_t { fp_t X, Y, Z; };              // Jacobian; Z == 0 = infinity
+
+__device__ __forceinline__ g1j_t g1_inf() {
+    g1j_t p;
+    p.X = fp_zero(); p.Y = fp_one(); p.Z = fp_zero();
+    return p;
+}
+__device__ __forceinline__ bool g1_is_inf(const g1j_t &p) { return fp_is_zero(p.Z); }
+__device__ __forceinline__ bool g1a_is_inf(const g1a_t &p) { return fp_is_zero(p.x) && fp_is_zero(p.y); }
+
+__device__ inline g1j_t g1_dbl(const g1j_t &p) {
+    if (g1_is_inf(p)) return p;
+    fp_t A = fp_sqr(p.X), B = fp_sqr(p.Y), C = fp_sqr(B);
+    fp_t t = fp_add(p.X, B);
+    fp_t D = fp_sub(fp_sub(fp_sqr(t), A), C);
+    D = fp_dbl(D);
+    fp_t E = fp_add(fp_dbl(A), A), F = fp_sqr(E);
+    g1j_t r;
+    r.X = fp_sub(F, fp_dbl(D));
+    fp_t C8 = fp_dbl(fp_dbl(fp_dbl(C)));
+    r.Y = fp_sub(fp_mul(E, fp_sub(D, r.X)), C8);
+    r.Z = fp_dbl(fp_mul(p.Y, p.Z));
+    return r;
+}
+
+// general Jacobian addition (handles infinity, doubling and inverse points)
+__device__ inline g1j_t g1_add(const g1j_t &p, const g1j_t &q) {
+    if (g1_is_inf(p)) return q;
+    if (g1_is_inf(q)) return p;
+    fp_t Z1Z1 = fp_sqr(p.Z), Z2Z2 = fp_sqr(q.Z);
+    fp_t U1 = fp_mul(p.X, Z2Z2), U2 = fp_mul(q.X, Z1Z1);
+    fp_t S1 = fp_mul(fp_mul(p.Y, q.Z), Z2Z2), S2 = fp_mul(fp_mul(q.Y, p.Z), Z1Z1);
+    if (fp_eq(U1, U2)) {
+        if (fp_eq(S1, S2)) return g1_dbl(p);
+        return g1_inf();
+    }
+    fp_t H = fp_sub(U2, U1), Rr = fp_sub(S2, S1);
+    fp_t HH = fp_sqr(H), HHH = fp_mul(H, HH), V = fp_mul(U1, HH);
+    g1j_t r;
+    r.X = fp_sub(fp_sub(fp_sqr(Rr), HHH), fp_dbl(V));
+    r.Y = fp_sub(fp_mul(Rr, fp_sub(V, r.X)), fp_mul(S1, HHH));
+    r.Z = fp_mul(fp_mul(p.Z, q.Z), H);
+    return r;
+}
+
+// Jacobian + affine
+__device__ inline g1j_t g1_madd(const g1j_t &p, const g1a_t &q) {
+    if (g1a_is_inf(q)) return p;
+    if (g1_is_inf(p)) {
+        g1j_t r;
+        r.X = q.x; r.Y = q.y; r.Z = fp_one();
+        return r;
+    }
+    fp_t Z1Z1 = fp_sqr(p.Z);
+    fp_t U2 = fp_mul(q.x, Z1Z1), S2 = fp_mul(fp_mul(q.y, p.Z), Z1Z1);
+    if (fp_eq(p.X, U2)) {
+        if (fp_eq(p.Y, S2)) return g1_dbl(p);
+        return g1_inf();
+    }
+    fp_t H = fp_sub(U2, p.X), Rr = fp_sub(S2, p.Y);
+    fp_t HH = fp_sqr(H), HHH = fp_mul(H, HH), V = fp_mul(p.X, HH);
+    g1j_t r;
+    r.X = fp_sub(fp_sub(fp_sqr(Rr), HHH), fp_dbl(V));
+    r.Y = fp_sub(fp_mul(Rr, fp_sub(V, r.X)), fp_mul(p.Y, HHH));
+    r.Z = fp_mul(p.Z, H);
+    return r;
+}
+
+__device__ inline g1a_t g1_to_affine(const g1j_t &p) {
+    g1a_t a;
+    if (g1_is_inf(p)) { a.x = fp_zero(); a.y = fp_zero(); return a; }
+    fp_t zi = fp_inv(p.Z), zi2 = fp_sqr(zi);
+    a.x = fp_mul(p.X, zi2);
+    a.y = fp_mul(fp_mul(p.Y, zi2), zi);
+    return a;
+}
+
+// Fr in Montgomery form -> canonical integer (one Montgomery product with 1)
+__device__ __forceinline__ fr_t fr_to_canonical(const fr_t &a) {
+    fr_t one_raw = fr_zero();
+    one_raw.v[0] = 1;
+    return fr_mul(a, one_raw);
+}
+
+// signed form for the MSM: |s| <= (r-1)/2 in limbs 0..7, sign returned separately
+__device__ __forceinline__ fr_t fr_signed_magnitude(const fr_t &mont, bool &neg) {
+    const uint32_t half[8] = {0x80000000u, 0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u};
+    fr_t c = fr_to_canonical(mont);
+    // c > (r-1)/2 ?
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t x = (uint64_t) half[i] - c.v[i] - borrow;
+        borrow = (x >> 32) & 1;
+    }
+    neg = borrow != 0;
+    if (neg) {
+        const uint32_t m[8] = FR_MOD_INIT;
+        uint64_t b2 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint64_t x = (uint64_t) m[i] - c.v[i] - b2;
+            c.v[i] = (uint32_t) x;
+            b2 = (x >> 32) & 1;
+        }
+    }
+    return c;
+}

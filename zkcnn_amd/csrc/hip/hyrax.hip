@@ -1,0 +1,369 @@
+// libzkcnn_hip.so, part 2: Hyrax commitment of the layer-0 witness on the GPU (K13/K14).
+// Replaces hyrax_bls12_381::polyProver of the absent upstream library (call sites: reference
+// src/prover.cpp:503-511, src/verifier.cpp:128,360). Protocol: zkcnn_amd/csrc/hyrax-bls12-381/polyCommit.hpp.
+//
+// MSM structure (many MSMs over ONE generator vector, scalars mostly tiny and signed):
+//   * per generator set, window tables T[w][j] = 2^(8w) g_j (affine) are built once, so a 255-bit
+//     scalar becomes 32 independent 8-bit digits and no doubling chain is left on the critical path;
+//   * scalars are folded to |s| <= (r-1)/2 with a sign, so quantised weights / bits only touch w = 0;
+//   * digit d contributes d * T[w][j] = sum_k bit_k(d) 2^k T[w][j]: for each of the 8 bit planes one
+//     block sums the selected table points (thread-sequential, then an LDS tree), and the row result
+//     is sum_k 2^k S_k (7 doublings). No buckets, no sorting, no atomics on 144-byte points.
+#include <algorithm>
+#include <cstring>
+#include "ctx.hpp"
+#include "g1_dev.cuh"
+#include "../ff/g1.hpp"
+
+#define MSM_WINDOWS 32
+#define MSM_PLANES 8
+
+struct msm_state {
+    g1a_t *tables = nullptr;           // [MSM_WINDOWS][m]
+    uint64_t m = 0;
+    std::vector<uint64_t> gens_host;   // generators the tables were built for
+    g1j_t *partials = nullptr; size_t partials_cap = 0;
+    g1j_t *rowsJ = nullptr; g1a_t *rowsA = nullptr; size_t rows_cap = 0;
+    // inner-product argument state
+    int rb = 0, cb = 0;
+    uint32_t len = 0;                  // current length of a / b
+    fr_t *a = nullptr, *b = nullptr, *coef = nullptr, *Lrow = nullptr;
+    fr_t *sL = nullptr, *sR = nullptr; uint32_t *idxL = nullptr, *idxR = nullptr;
+    fr_t *d_y = nullptr;               // 2 elements
+    void *tbl_scratch = nullptr; size_t tbl_scratch_cap = 0;
+};
+
+void zk_msm_destroy(zk_ctx *ctx) {
+    if (!ctx->msm) return;
+    msm_state *s = ctx->msm;
+    void *bufs[] = {s->tables, s->partials, s->rowsJ, s->rowsA, s->a, s->b, s->coef, s->Lrow, s->sL, s->sR, s->idxL, s->idxR,
+                    s->d_y, s->tbl_scratch};
+    for (void *p : bufs) if (p) hipFree(p);
+    delete s;
+    ctx->msm = nullptr;
+}
+
+static int32_t regrow(zk_ctx *ctx, void **p, size_t *cap, size_t bytes) {
+    if (*cap >= bytes) return ZK_OK;
+    if (*p) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(*p)); *p = nullptr; *cap = 0; }
+    ZK_HIP(hipMalloc(p, bytes));
+    *cap = bytes;
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+// T[0][j] = g_j is already in place; fills T[w][j] = 2^(8w) g_j for w >= 1, converted to affine with
+// one field inversion per generator (Montgomery's trick over the 31 Jacobian points of that thread).
+__global__ void k_window_tables(g1a_t *T, g1j_t *J, fp_t *pre, uint32_t m) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const g1a_t g = T[j];
+    if (g1a_is_inf(g)) {
+        for (int w = 1; w < MSM_WINDOWS; ++w) T[(size_t) w * m + j] = g;
+        return;
+    }
+    g1j_t P;
+    P.X = g.x; P.Y = g.y; P.Z = fp_one();
+    fp_t run = fp_one();
+    for (int w = 1; w < MSM_WINDOWS; ++w) {
+        for (int d = 0; d < 8; ++d) P = g1_dbl(P);
+        J[(size_t) (w - 1) * m + j] = P;
+        pre[(size_t) (w - 1) * m + j] = run;
+        run = fp_mul(run, P.Z);
+    }
+    fp_t inv = fp_inv(run);
+    for (int w = MSM_WINDOWS - 1; w >= 1; --w) {
+        const g1j_t Q = J[(size_t) (w - 1) * m + j];
+        const fp_t zi = fp_mul(inv, pre[(size_t) (w - 1) * m + j]);
+        inv = fp_mul(inv, Q.Z);
+        const fp_t zi2 = fp_sqr(zi);
+        g1a_t a;
+        a.x = fp_mul(Q.X, zi2);
+        a.y = fp_mul(fp_mul(Q.Y, zi2), zi);
+        T[(size_t) w * m + j] = a;
+    }
+}
+
+// One block = (row, bit plane, column chunk x window group). Each thread walks `cpt` columns
+// (stride 256: coalesced scalar and table reads), adds the selected table points, then the block
+// tree-reduces through LDS. out[(row * 8 + plane) * nparts + part]
+__global__ void __launch_bounds__(256) k_msm_planes(g1j_t *out, const fr_t *scalars, uint64_t ld, const uint32_t *idx,
+                                                     const g1a_t *T, uint32_t m, uint32_t cols, uint32_t cpt, uint32_t wsplit) {
+    __shared__ g1j_t sm[256];
+    const uint32_t plane = blockIdx.y, row = blockIdx.z;
+    const uint32_t wg = blockIdx.x % wsplit, chunk = blockIdx.x / wsplit;
+    const uint32_t wpg = MSM_WINDOWS / wsplit, w0 = wg * wpg;
+    g1j_t acc = g1_inf();
+    for (uint32_t i = 0; i < cpt; ++i) {
+        const uint32_t c = chunk * (256 * cpt) + i * 256 + threadIdx.x;
+        if (c >= cols) break;
+        bool neg;
+        const fr_t s = fr_signed_magnitude(fr_load(scalars + (size_t) row * ld + c), neg);
+        const uint32_t j = idx ? idx[c] : c;
+        for (uint32_t w = w0; w < w0 + wpg; ++w) {
+            const uint32_t byte = (s.v[w >> 2] >> ((w & 3) * 8)) & 0xffu;
+            if ((byte >> plane) & 1u) {
+                g1a_t pt = T[(size_t) w * m + j];
+                if (neg) pt.y = fp_neg(pt.y);
+                acc = g1_madd(acc, pt);
+            }
+        }
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = 128; s >= 1; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[((size_t) row * MSM_PLANES + plane) * gridDim.x + blockIdx.x] = sm[0];
+}
+
+// one wave per row: sums the partial points of every plane and combines the planes, R = sum_k 2^k S_k
+__global__ void __launch_bounds__(64) k_msm_finish(g1j_t *outJ, const g1j_t *partials, uint32_t nparts) {
+    __shared__ g1j_t sm[64];
+    const uint32_t row = blockIdx.x, lane = threadIdx.x;
+    g1j_t R = g1_inf();
+    for (int k = MSM_PLANES - 1; k >= 0; --k) {
+        g1j_t acc = g1_inf();
+        const g1j_t *src = partials + ((size_t) row * MSM_PLANES + k) * nparts;
+        for (uint32_t p = lane; p < nparts; p += 64) acc = g1_add(acc, src[p]);
+        sm[lane] = acc;
+        __syncthreads();
+        for (uint32_t s = 32; s >= 1; s >>= 1) {
+            if (lane < s) sm[lane] = g1_add(sm[lane], sm[lane + s]);
+            __syncthreads();
+        }
+        if (lane == 0) R = g1_add(g1_dbl(R), sm[0]);
+        __syncthreads();
+    }
+    if (lane == 0) outJ[row] = R;
+}
+
+__global__ void k_to_affine(g1a_t *out, const g1j_t *in, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = g1_to_affine(in[i]);
+}
+
+// scalars of the two cross terms of one inner-product round, expressed over the ORIGINAL generators:
+//   g^(k)_i = sum_{j = i mod len} coef[j] g_j, so  L = <a_lo, g_hi> = sum_{j: (j mod len) >= h} a[(j mod len) - h] coef[j] g_j
+__global__ void k_ipa_scalars(fr_t *sL, uint32_t *idxL, fr_t *sR, uint32_t *idxR, const fr_t *a, const fr_t *coef, uint32_t m,
+                              uint32_t len) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t h = len >> 1, i = j & (len - 1), pos = (j / len) * h + (i & (h - 1));
+    const fr_t cj = fr_load(coef + j);
+    if (i >= h) {
+        fr_store(sL + pos, fr_mul(fr_load(a + i - h), cj));
+        idxL[pos] = j;
+    } else {
+        fr_store(sR + pos, fr_mul(fr_load(a + i + h), cj));
+        idxR[pos] = j;
+    }
+}
+
+// y[0] = <a_lo, b_hi>, y[1] = <a_hi, b_lo>; single block
+__global__ void __launch_bounds__(256) k_ipa_dots(fr_t *y, const fr_t *a, const fr_t *b, uint32_t h) {
+    __shared__ fr_t smem[2 * 256 / 64];
+    fr_t acc[2] = {fr_zero(), fr_zero()};
+    for (uint32_t i = threadIdx.x; i < h; i += 256) {
+        acc[0] = fr_add(acc[0], fr_mul(fr_load(a + i), fr_load(b + i + h)));
+        acc[1] = fr_add(acc[1], fr_mul(fr_load(a + i + h), fr_load(b + i)));
+    }
+    fr_block_sum<2>(acc, smem);
+    if (threadIdx.x == 0) { fr_store(y, acc[0]); fr_store(y + 1, acc[1]); }
+}
+
+// a' = a_lo + c a_hi, b' = c b_lo + b_hi (in place), coef[j] *= c for generators in the low half
+__global__ void k_ipa_fold(fr_t *a, fr_t *b, fr_t *coef, fr_t c, uint32_t m, uint32_t len) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t h = len >> 1;
+    if (j < m && (j & (len - 1)) < h) fr_store(coef + j, fr_mul(fr_load(coef + j), c));
+    if (j < h) {
+        fr_store(a + j, fr_add(fr_load(a + j), fr_mul(c, fr_load(a + j + h))));
+        fr_store(b + j, fr_add(fr_mul(c, fr_load(b + j)), fr_load(b + j + h)));
+    }
+}
+
+__global__ void k_fill(fr_t *dst, fr_t v, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fr_store(dst + i, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int32_t ensure_state(zk_ctx *ctx) {
+    if (!ctx->msm) ctx->msm = new msm_state();
+    return ZK_OK;
+}
+
+// window tables for `m` affine generators (host pointer, C-ABI layout); cached while the generators stay the same
+static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
+    msm_state *s = ctx->msm;
+    if (s->m == m && s->gens_host.size() == m * 12 && std::memcmp(s->gens_host.data(), gens, m * 96) == 0) return ZK_OK;
+    if (s->m != m) {
+        if (s->tables) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->tables)); s->tables = nullptr; }
+        ZK_HIP(hipMalloc((void **) &s->tables, (size_t) MSM_WINDOWS * m * sizeof(g1a_t)));
+        s->m = m;
+    }
+    s->gens_host.assign(gens, gens + m * 12);
+    ZK_HIP(hipMemcpyAsync(s->tables, gens, m * sizeof(g1a_t), hipMemcpyHostToDevice, ctx->stream));
+    const size_t need = (size_t) (MSM_WINDOWS - 1) * m * (sizeof(g1j_t) + sizeof(fp_t));
+    int32_t rc = regrow(ctx, &s->tbl_scratch, &s->tbl_scratch_cap, need);
+    if (rc) return rc;
+    g1j_t *J = (g1j_t *) s->tbl_scratch;
+    fp_t *pre = (fp_t *) (J + (size_t) (MSM_WINDOWS - 1) * m);
+    hipLaunchKernelGGL(k_window_tables, dim3((uint32_t) ((m + 63) / 64)), dim3(64), 0, ctx->stream, s->tables, J, pre, (uint32_t) m);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+// rows independent MSMs over the cached generator tables; results (Jacobian) in s->rowsJ[0..rows)
+static int32_t run_msm(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint32_t *idx, uint32_t rows, uint32_t cols) {
+    msm_state *s = ctx->msm;
+    uint32_t wsplit, cpt;
+    if (rows >= 64) { wsplit = 1; cpt = std::min<uint32_t>(16, (cols + 255) / 256); }
+    else { wsplit = MSM_WINDOWS; cpt = std::min<uint32_t>(4, (cols + 255) / 256); }
+    cpt = std::max<uint32_t>(cpt, 1);
+    const uint32_t chunks = (cols + 256 * cpt - 1) / (256 * cpt), nparts = chunks * wsplit;
+    int32_t rc;
+    if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * MSM_PLANES * nparts * sizeof(g1j_t)))) return rc;
+    if (s->rows_cap < rows) {
+        if (s->rowsJ) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->rowsJ)); ZK_HIP(hipFree(s->rowsA)); }
+        ZK_HIP(hipMalloc((void **) &s->rowsJ, (size_t) rows * sizeof(g1j_t)));
+        ZK_HIP(hipMalloc((void **) &s->rowsA, (size_t) rows * sizeof(g1a_t)));
+        s->rows_cap = rows;
+    }
+    // gridDim.z is limited to 65535 rows per launch
+    for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
+        const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
+        hipLaunchKernelGGL(k_msm_planes, dim3(nparts, MSM_PLANES, nr), dim3(256), 0, ctx->stream,
+                           s->partials + (size_t) r0 * MSM_PLANES * nparts, scalars + (size_t) r0 * ld, ld, idx, s->tables,
+                           (uint32_t) s->m, cols, cpt, wsplit);
+    }
+    hipLaunchKernelGGL(k_msm_finish, dim3(rows), dim3(64), 0, ctx->stream, s->rowsJ, s->partials, nparts);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+// few points: Jacobian -> affine on the host (one inversion each); many: on the device
+static int32_t fetch_points(zk_ctx *ctx, uint32_t rows, uint64_t *out) {
+    msm_state *s = ctx->msm;
+    if (rows > 8) {
+        hipLaunchKernelGGL(k_to_affine, dim3((rows + 63) / 64), dim3(64), 0, ctx->stream, s->rowsA, s->rowsJ, rows);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipMemcpyAsync(out, s->rowsA, (size_t) rows * sizeof(g1a_t), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        return ZK_OK;
+    }
+    zkff::G1 pj[8];
+    ZK_HIP(hipMemcpyAsync(pj, s->rowsJ, (size_t) rows * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < rows; ++i) {
+        zkff::G1Affine a = pj[i].toAffine();
+        std::memcpy(out + 12 * i, &a, 96);
+    }
+    return ZK_OK;
+}
+
+static_assert(sizeof(zkff::G1) == sizeof(g1j_t) && sizeof(zkff::G1Affine) == sizeof(g1a_t), "host / device point layouts must agree");
+
+#define CHECK_READY() do { if (!ctx || !ctx->circuit_ready) return ZK_ERR_STATE; ZK_HIP(hipSetDevice(ctx->device)); } while (0)
+static inline const HFr &H(const uint64_t *p) { return *reinterpret_cast<const HFr *>(p); }
+
+extern "C" int32_t zk_commit_input(zk_ctx *ctx, const uint64_t *gens, uint64_t n_gens, uint64_t *out_comm, uint64_t n_rows) {
+    CHECK_READY();
+    const dev_layer &L0 = ctx->L[0];
+    const int n = L0.d.bit_length, rb = n >> 1, cb = n - rb;
+    if (n_gens != (1ull << cb) || n_rows != (1ull << rb) || !gens || !out_comm) { ctx->err = "commit: wrong generator / row count"; return ZK_ERR_ARG; }
+    int32_t rc;
+    if ((rc = ensure_state(ctx)) || (rc = ensure_tables(ctx, gens, n_gens))) return rc;
+    ctx->msm->rb = rb;
+    ctx->msm->cb = cb;
+    if ((rc = run_msm(ctx, L0.val, n_gens, nullptr, (uint32_t) n_rows, (uint32_t) n_gens))) return rc;
+    return fetch_points(ctx, (uint32_t) n_rows, out_comm);
+}
+
+extern "C" int32_t zk_hyrax_open_init(zk_ctx *ctx, const uint64_t *x, uint32_t n) {
+    CHECK_READY();
+    msm_state *s = ctx->msm;
+    if (!s || !s->tables) { ctx->err = "open before commit"; return ZK_ERR_STATE; }
+    const dev_layer &L0 = ctx->L[0];
+    if ((int) n != L0.d.bit_length) return ZK_ERR_ARG;
+    const uint32_t rows = 1u << s->rb, m = 1u << s->cb;
+    if (!s->a) {
+        ZK_HIP(hipMalloc((void **) &s->a, (size_t) m * 32)); ZK_HIP(hipMalloc((void **) &s->b, (size_t) m * 32));
+        ZK_HIP(hipMalloc((void **) &s->coef, (size_t) m * 32)); ZK_HIP(hipMalloc((void **) &s->Lrow, (size_t) rows * 32));
+        ZK_HIP(hipMalloc((void **) &s->sL, (size_t) m * 16)); ZK_HIP(hipMalloc((void **) &s->sR, (size_t) m * 16));
+        ZK_HIP(hipMalloc((void **) &s->idxL, (size_t) m * 2)); ZK_HIP(hipMalloc((void **) &s->idxR, (size_t) m * 2));
+        ZK_HIP(hipMalloc((void **) &s->d_y, 64));
+    }
+    const HFr *xs = reinterpret_cast<const HFr *>(x);
+    int32_t rc;
+    if ((rc = zk_eq_table1_dev(ctx, s->Lrow, s->rb, xs + s->cb, HFr::one()))) return rc;
+    if ((rc = zk_eq_table1_dev(ctx, s->b, s->cb, xs, HFr::one()))) return rc;
+    if ((rc = zk_col_combine_dev(ctx, s->a, L0.val, s->Lrow, m, rows))) return rc;        // w = L^T Z
+    hipLaunchKernelGGL(k_fill, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, s->coef, to_dev(HFr::one()), m);
+    ZK_HIP(hipGetLastError());
+    s->len = m;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_hyrax_open_round(zk_ctx *ctx, uint64_t Lp[12], uint64_t Rp[12], uint64_t yL[4], uint64_t yR[4]) {
+    CHECK_READY();
+    msm_state *s = ctx->msm;
+    if (!s || s->len < 2) return ZK_ERR_STATE;
+    const uint32_t m = 1u << s->cb, h = s->len >> 1;
+    hipLaunchKernelGGL(k_ipa_scalars, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, s->sL, s->idxL, s->sR, s->idxR, s->a, s->coef,
+                       m, s->len);
+    hipLaunchKernelGGL(k_ipa_dots, dim3(1), dim3(256), 0, ctx->stream, s->d_y, s->a, s->b, h);
+    ZK_HIP(hipGetLastError());
+    // two MSMs over m/2 generators each, launched as two rows of one batch (row stride = m/2 scalars)
+    // sL and sR are separate buffers; run them one after the other into rowsJ[0], rowsJ[1]
+    int32_t rc;
+    uint64_t pts[24];
+    if ((rc = run_msm(ctx, s->sL, m / 2, s->idxL, 1, m / 2))) return rc;
+    if ((rc = fetch_points(ctx, 1, pts))) return rc;
+    if ((rc = run_msm(ctx, s->sR, m / 2, s->idxR, 1, m / 2))) return rc;
+    if ((rc = fetch_points(ctx, 1, pts + 12))) return rc;
+    ZK_HIP(hipMemcpy(ctx->h_result, s->d_y, 64, hipMemcpyDeviceToHost));
+    std::memcpy(Lp, pts, 96);
+    std::memcpy(Rp, pts + 12, 96);
+    std::memcpy(yL, &ctx->h_result[0], 32);
+    std::memcpy(yR, &ctx->h_result[1], 32);
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_hyrax_open_fold(zk_ctx *ctx, const uint64_t c[4]) {
+    CHECK_READY();
+    msm_state *s = ctx->msm;
+    if (!s || s->len < 2) return ZK_ERR_STATE;
+    const uint32_t m = 1u << s->cb;
+    hipLaunchKernelGGL(k_ipa_fold, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, s->a, s->b, s->coef, to_dev(H(c)), m, s->len);
+    ZK_HIP(hipGetLastError());
+    s->len >>= 1;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_hyrax_open_final(zk_ctx *ctx, uint64_t a[4]) {
+    CHECK_READY();
+    msm_state *s = ctx->msm;
+    if (!s || s->len != 1) return ZK_ERR_STATE;
+    ZK_HIP(hipMemcpyAsync(a, s->a, 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+// stand-alone MSM over arbitrary bases (kernel-level parity tests)
+extern "C" int32_t zk_k_msm(zk_ctx *ctx, uint64_t out[12], const uint64_t *scalars, const uint64_t *bases, uint64_t n) {
+    if (!ctx || !n || n > (1u << 20)) return ZK_ERR_ARG;
+    ZK_HIP(hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = ensure_state(ctx)) || (rc = ensure_tables(ctx, bases, n))) return rc;
+    if ((rc = zk_scratch(ctx, n * 32))) return rc;
+    ZK_HIP(hipMemcpyAsync(ctx->scratch.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = run_msm(ctx, (const fr_t *) ctx->scratch.p, n, nullptr, 1, (uint32_t) n))) return rc;
+    return fetch_points(ctx, 1, out);
+}

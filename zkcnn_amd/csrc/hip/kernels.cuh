@@ -1,0 +1,437 @@
+// HIP kernels of the GKR prover for gfx950 (wave64). One kernel per hot loop of the reference
+// prover; every kernel names the reference lines it replaces.
+// All arithmetic is exact in the BLS12-381 scalar field, so any reduction order returns the same
+// field element as the reference's sequential loops.
+#pragma once
+#include "types.cuh"
+
+// ------------------------------------------------------------------------------------------------
+// element-wise helpers (tests / micro-benchmarks)
+// ------------------------------------------------------------------------------------------------
+template <int OP>
+__global__ void k_fr_binop(fr_t *out, const fr_t *a, const fr_t *b, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        fr_t x = fr_load(a + i), y = fr_load(b + i);
+        fr_t z = OP == 0 ? fr_mul(x, y) : OP == 1 ? fr_add(x, y) : fr_sub(x, y);
+        fr_store(out + i, z);
+    }
+}
+
+// dependent multiply chains on per-thread operands: measures the integer-ALU ceiling of K0
+// (operands come from memory so that nothing is wave-uniform; traffic is 64 B per thread, negligible)
+__global__ void k_bench_fr_mul(fr_t *buf, uint32_t muls, uint64_t n) {
+    const uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const fr_t x = fr_load(buf + i), y = fr_load(buf + ((i + 1) % n));
+    fr_t a = x, b = y;
+    for (uint32_t k = 0; k < muls; k += 2) {       // two independent chains for ILP
+        a = fr_mul(a, x);
+        b = fr_mul(b, y);
+    }
+    fr_store(buf + n + i, fr_add(a, b));
+}
+
+__global__ void k_bench_copy(uint4 *dst, const uint4 *src, uint64_t n16) {
+    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n16; i += (uint64_t) gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: eq ("beta") tables.  reference src/utils.cpp:32-51 (half tables), 147-180 (expansion)
+// ------------------------------------------------------------------------------------------------
+struct eq_args {
+    fr_vec r[2];
+    fr_t init[2];
+    int32_t npoints, fh, sh;
+};
+
+// single block: lo[p] = init_p * eq(r_p[0..fh), .),  hi[p] = eq(r_p[fh..fh+sh), .)
+// lo tables are `lo_stride` apart, hi tables `hi_stride` apart.
+__global__ void __launch_bounds__(1024) k_eq_halves(fr_t *lo, fr_t *hi, uint32_t lo_stride, uint32_t hi_stride, eq_args a) {
+    for (int p = 0; p < a.npoints; ++p) {
+        fr_t *L = lo + (size_t) p * lo_stride, *H = hi + (size_t) p * hi_stride;
+        if (threadIdx.x == 0) {
+            fr_store(L, a.init[p]);
+            fr_store(H, fr_one());
+        }
+        __syncthreads();
+        for (int i = 0; i < a.fh; ++i) {
+            const uint32_t half = 1u << i;
+            const fr_t ri = a.r[p].v[i];
+            for (uint32_t j = threadIdx.x; j < half; j += blockDim.x) {
+                fr_t cur = fr_load(L + j);
+                fr_t t = fr_mul(cur, ri);
+                fr_store(L + (j | half), t);
+                fr_store(L + j, fr_sub(cur, t));
+            }
+            __syncthreads();
+        }
+        for (int i = 0; i < a.sh; ++i) {
+            const uint32_t half = 1u << i;
+            const fr_t ri = a.r[p].v[a.fh + i];
+            for (uint32_t j = threadIdx.x; j < half; j += blockDim.x) {
+                fr_t cur = fr_load(H + j);
+                fr_t t = fr_mul(cur, ri);
+                fr_store(H + (j | half), t);
+                fr_store(H + j, fr_sub(cur, t));
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// out[i] = sum_p lo_p[i & mask] * hi_p[i >> fh]; entries >= tail_start are additionally scaled
+// (the relu_rou factor on the constraint rows, reference src/prover.cpp:221-222)
+__global__ void k_eq_expand(fr_t *out, const fr_t *lo, const fr_t *hi, uint32_t lo_stride, uint32_t hi_stride, int npoints,
+                            int fh, uint64_t n, uint64_t tail_start, fr_t tail_scale) {
+    const uint64_t mask = (1ull << fh) - 1;
+    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        fr_t acc = fr_zero();
+        if (npoints >= 1) acc = fr_mul(fr_load(lo + (i & mask)), fr_load(hi + (i >> fh)));
+        if (npoints >= 2)
+            acc = fr_add(acc, fr_mul(fr_load(lo + lo_stride + (i & mask)), fr_load(hi + hi_stride + (i >> fh))));
+        if (i >= tail_start) acc = fr_mul(acc, tail_scale);
+        fr_store(out + i, acc);
+    }
+}
+
+// PADDING layer: out[g] = coarse[g >> bits] * fine[g & mask]   (reference src/prover.cpp:214-219)
+__global__ void k_outer_expand(fr_t *out, const fr_t *coarse, const fr_t *fine, int bits, uint64_t n) {
+    const uint64_t mask = (1ull << bits) - 1;
+    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+        fr_store(out + i, fr_mul(fr_load(coarse + (i >> bits)), fr_load(fine + (i & mask))));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: table gather.  reference src/prover.cpp:205-212, 291-296 (getCirValue :499)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_gather(fr_t *dst, const fr_t *src, const uint32_t *idx, uint64_t n_valid, uint64_t n_total) {
+    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n_total; i += (uint64_t) gridDim.x * blockDim.x) {
+        fr_t x = fr_zero();
+        if (i < n_valid) x = fr_load(src + (idx ? idx[i] : i));
+        fr_store(dst + i, x);
+    }
+}
+
+// K12: layer-0 combine, M[ori[h]] += beta[h]; ori is injective inside one launch.
+// reference src/prover.cpp:334-354
+__global__ void k_scatter_add_unique(fr_t *M, const uint32_t *ori, const fr_t *beta, uint64_t n) {
+    for (uint64_t h = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; h < n; h += (uint64_t) gridDim.x * blockDim.x) {
+        fr_t *dst = M + ori[h];
+        fr_store(dst, fr_add(fr_load(dst), fr_load(beta + h)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: gate scatter as a segmented reduction over gates pre-sorted by destination.
+// reference src/prover.cpp:224-233 (phase 1), 286-288 and 297-305 (phase 2)
+// ------------------------------------------------------------------------------------------------
+struct gate_args {
+    const gate_rec *recs;
+    uint64_t n;
+    const fr_t *beta_g;
+    const fr_t *beta_u;      // phase 2 only
+    const fr_t *val0;        // layer-0 values
+    const fr_t *val_prev;    // previous-layer values
+    const fr_t *two_mul;
+    fr_t Vu0, Vu1;           // phase 2: claimed values of the u operands
+    int32_t phase;           // 1 or 2
+};
+
+__device__ __forceinline__ fr_t gate_term(const gate_rec &rc, const gate_args &a) {
+    fr_t t = fr_load(a.beta_g + rc.g);
+    if (a.phase == 1) {
+        if (GATE_HAS_VAL(rc.meta)) t = fr_mul(t, fr_load((GATE_IN_PREV(rc.meta) ? a.val_prev : a.val0) + rc.aux));
+    } else {
+        t = fr_mul(t, fr_load(a.beta_u + rc.aux));
+        t = fr_mul(t, GATE_IN_PREV(rc.meta) ? a.Vu1 : a.Vu0);
+    }
+    const uint32_t sc = GATE_SC(rc.meta);
+    if (sc) t = fr_mul(t, fr_load(a.two_mul + sc));
+    return t;
+}
+
+// One gate per thread. Wave-level segmented scan with cross-lane moves, cross-wave carry through
+// LDS. Segments that lie inside a block are stored straight to `out`; the block's first and last
+// segment go to `carry` (2 slots per block) and are combined by k_gate_fixup.
+__global__ void __launch_bounds__(ZK_BLOCK) k_gate_reduce(fr_t *out, uint32_t *carry_key, fr_t *carry_val, gate_args a) {
+    __shared__ uint32_t s_head[ZK_BLOCK / 64], s_tail[ZK_BLOCK / 64];
+    __shared__ fr_t s_tailval[ZK_BLOCK / 64];
+    const uint64_t idx = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool live = idx < a.n;
+
+    uint32_t key = GATE_NOKEY;
+    fr_t val = fr_zero();
+    if (live) {
+        gate_rec rc = a.recs[idx];
+        key = rc.key;
+        val = gate_term(rc, a);
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t k2 = (uint32_t) __shfl_up((int) key, d, 64);
+        fr_t v2 = fr_shfl_up(val, d);
+        if (lane >= d && k2 == key) val = fr_add(val, v2);
+    }
+    if (lane == 0) s_head[wave] = key;
+    if (lane == 63) { s_tail[wave] = key; s_tailval[wave] = val; }
+    __syncthreads();
+    if (key == s_head[wave]) {                       // leading run of this wave: add what earlier waves hold
+        for (int pw = wave - 1; pw >= 0; --pw) {
+            if (s_tail[pw] != key) break;
+            val = fr_add(val, s_tailval[pw]);
+            if (s_head[pw] != key) break;
+        }
+    }
+    if (!live) return;
+    const uint64_t blk_last = min(a.n, (blockIdx.x + 1) * (uint64_t) ZK_BLOCK) - 1;
+    uint32_t next_key = (uint32_t) __shfl_down((int) key, 1, 64);
+    if (lane == 63) next_key = (wave + 1 < ZK_BLOCK / 64) ? s_head[wave + 1] : GATE_NOKEY;
+    const uint32_t kf = s_head[0];
+    if (idx == blk_last) {
+        const int slot = (key == kf) ? 0 : 1;
+        carry_key[2 * blockIdx.x + slot] = key;
+        fr_store(carry_val + 2 * blockIdx.x + slot, val);
+        if (slot == 0) carry_key[2 * blockIdx.x + 1] = GATE_NOKEY;
+    } else if (next_key != key) {
+        if (key == kf) {
+            carry_key[2 * blockIdx.x] = key;
+            fr_store(carry_val + 2 * blockIdx.x, val);
+        } else fr_store(out + key, val);
+    }
+}
+
+__global__ void k_gate_fixup(fr_t *out, const uint32_t *carry_key, const fr_t *carry_val, uint64_t nslots) {
+    for (uint64_t s = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; s < nslots; s += (uint64_t) gridDim.x * blockDim.x) {
+        const uint32_t key = carry_key[s];
+        if (key == GATE_NOKEY) continue;
+        // previous valid slot (invalid slots are isolated: only a block's second slot can be empty)
+        bool head = true;
+        if (s >= 1) {
+            uint32_t pk = carry_key[s - 1];
+            if (pk == GATE_NOKEY && s >= 2) pk = carry_key[s - 2];
+            head = pk != key;
+        }
+        if (!head) continue;
+        fr_t total = fr_load(carry_val + s);
+        for (uint64_t t = s + 1; t < nslots; ++t) {
+            const uint32_t k2 = carry_key[t];
+            if (k2 == GATE_NOKEY) continue;
+            if (k2 != key) break;
+            total = fr_add(total, fr_load(carry_val + t));
+        }
+        fr_store(out + key, total);
+    }
+}
+
+// phase-2 constant term: sums of beta_g[g] * beta_u[u] * two_mul[sc] over the uni gates, split by
+// where u lives (slot 0: layer 0, slot 1: previous layer).  reference src/prover.cpp:297-300
+__global__ void __launch_bounds__(ZK_BLOCK) k_gate_sum2(fr_t *partials, gate_args a) {
+    __shared__ fr_t smem[2 * ZK_BLOCK / 64];
+    fr_t acc[2] = {fr_zero(), fr_zero()};
+    for (uint64_t i = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x; i < a.n; i += (uint64_t) gridDim.x * ZK_BLOCK) {
+        gate_rec rc = a.recs[i];
+        fr_t t = fr_mul(fr_load(a.beta_g + rc.g), fr_load(a.beta_u + rc.aux));
+        const uint32_t sc = GATE_SC(rc.meta);
+        if (sc) t = fr_mul(t, fr_load(a.two_mul + sc));
+        if (GATE_IN_PREV(rc.meta)) acc[1] = fr_add(acc[1], t);
+        else acc[0] = fr_add(acc[0], t);
+    }
+    fr_block_sum<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        fr_store(partials + 2 * blockIdx.x, acc[0]);
+        fr_store(partials + 2 * blockIdx.x + 1, acc[1]);
+    }
+}
+
+// out[k] (+)= sum_b partials[b * K + k]; single block
+template <int K>
+__global__ void __launch_bounds__(ZK_BLOCK) k_sum_partials(fr_t *out, const fr_t *partials, uint32_t nblocks, int accumulate) {
+    __shared__ fr_t smem[K * ZK_BLOCK / 64];
+    fr_t acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = fr_zero();
+    for (uint32_t b = threadIdx.x; b < nblocks; b += ZK_BLOCK)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = fr_add(acc[k], fr_load(partials + (size_t) b * K + k));
+    fr_block_sum<K>(acc, smem);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < K; ++k) fr_store(out + k, accumulate ? fr_add(fr_load(out + k), acc[k]) : acc[k]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: fold + quadratic round polynomial.  reference src/prover.cpp:396-426 (sumcheckUpdateEach)
+// Tables hold plain values (32 B/entry, not the reference's 64 B linear polynomials). A round
+//   1. folds the n-entry tables with the previous challenge:  T'[j] = T[2j] + r (T[2j+1] - T[2j])
+//   2. accumulates, over pairs of the folded tables,  c = sum v0 m0,  a = sum dv dm,  p1 = sum v1 m1
+// (b = p1 - a - c is recovered by the caller). Algorithmic traffic: read 2n, write n elements.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(ZK_BLOCK) k_round_quad(const fr_t *Vin, const fr_t *Min, fr_t *Vout, fr_t *Mout, uint64_t n,
+                                                         fr_t r, int first, fr_t *partials) {
+    __shared__ fr_t smem[3 * ZK_BLOCK / 64];
+    fr_t acc[3] = {fr_zero(), fr_zero(), fr_zero()};       // a, c, p1
+    const uint64_t tid = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x, stride = (uint64_t) gridDim.x * ZK_BLOCK;
+    if (first) {
+        for (uint64_t p = tid; p < n / 2; p += stride) {
+            fr_t v0 = fr_load(Vin + 2 * p), v1 = fr_load(Vin + 2 * p + 1);
+            fr_t m0 = fr_load(Min + 2 * p), m1 = fr_load(Min + 2 * p + 1);
+            acc[0] = fr_add(acc[0], fr_mul(fr_sub(v1, v0), fr_sub(m1, m0)));
+            acc[1] = fr_add(acc[1], fr_mul(v0, m0));
+            acc[2] = fr_add(acc[2], fr_mul(v1, m1));
+        }
+    } else {
+        for (uint64_t q = tid; q < n / 4; q += stride) {
+            fr_t a0 = fr_load(Vin + 4 * q), a1 = fr_load(Vin + 4 * q + 1), a2 = fr_load(Vin + 4 * q + 2), a3 = fr_load(Vin + 4 * q + 3);
+            fr_t v0 = fr_lerp(a0, a1, r), v1 = fr_lerp(a2, a3, r);
+            fr_store(Vout + 2 * q, v0);
+            fr_store(Vout + 2 * q + 1, v1);
+            a0 = fr_load(Min + 4 * q); a1 = fr_load(Min + 4 * q + 1); a2 = fr_load(Min + 4 * q + 2); a3 = fr_load(Min + 4 * q + 3);
+            fr_t m0 = fr_lerp(a0, a1, r), m1 = fr_lerp(a2, a3, r);
+            fr_store(Mout + 2 * q, m0);
+            fr_store(Mout + 2 * q + 1, m1);
+            acc[0] = fr_add(acc[0], fr_mul(fr_sub(v1, v0), fr_sub(m1, m0)));
+            acc[1] = fr_add(acc[1], fr_mul(v0, m0));
+            acc[2] = fr_add(acc[2], fr_mul(v1, m1));
+        }
+    }
+    fr_block_sum<3>(acc, smem);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fr_store(partials + 3 * blockIdx.x + k, acc[k]);
+}
+
+// plain fold (tables shorter than one quad, the periodic table of the cubic rounds, Vres)
+__global__ void k_fold(const fr_t *in, fr_t *out, uint64_t n, fr_t r) {
+    for (uint64_t j = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; j < n / 2; j += (uint64_t) gridDim.x * blockDim.x)
+        fr_store(out + j, fr_lerp(fr_load(in + 2 * j), fr_load(in + 2 * j + 1), r));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: fold + cubic round polynomial of the DOT_PROD layer.  reference src/prover.cpp:103-144
+// Two big tables (V0, V1) and one periodic table Ms (already folded for this round; length ls,
+// ls == 1 means it has collapsed to a constant). Coefficients c3..c0 of
+//   sum_i (V0 pair)(x) * (V1 pair)(x) * (Ms pair[i mod ls/2])(x)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, const fr_t *V1in, fr_t *V0out, fr_t *V1out,
+                                                          const fr_t *Ms, uint32_t ls, uint64_t n, fr_t r, int first,
+                                                          fr_t *partials) {
+    __shared__ fr_t smem[4 * ZK_BLOCK / 64];
+    fr_t acc[4] = {fr_zero(), fr_zero(), fr_zero(), fr_zero()};      // c3, c2, c1, c0
+    const uint64_t tid = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x, stride = (uint64_t) gridDim.x * ZK_BLOCK;
+    const uint64_t npairs = first ? n / 2 : n / 4;
+    const uint32_t mpairs = ls >> 1;
+    for (uint64_t p = tid; p < npairs; p += stride) {
+        fr_t x0, x1, y0, y1;
+        if (first) {
+            x0 = fr_load(V0in + 2 * p); x1 = fr_load(V0in + 2 * p + 1);
+            y0 = fr_load(V1in + 2 * p); y1 = fr_load(V1in + 2 * p + 1);
+        } else {
+            x0 = fr_lerp(fr_load(V0in + 4 * p), fr_load(V0in + 4 * p + 1), r);
+            x1 = fr_lerp(fr_load(V0in + 4 * p + 2), fr_load(V0in + 4 * p + 3), r);
+            y0 = fr_lerp(fr_load(V1in + 4 * p), fr_load(V1in + 4 * p + 1), r);
+            y1 = fr_lerp(fr_load(V1in + 4 * p + 2), fr_load(V1in + 4 * p + 3), r);
+            fr_store(V0out + 2 * p, x0); fr_store(V0out + 2 * p + 1, x1);
+            fr_store(V1out + 2 * p, y0); fr_store(V1out + 2 * p + 1, y1);
+        }
+        fr_t m0, dm;
+        if (mpairs) {
+            const uint32_t mi = (uint32_t) (p & (mpairs - 1));
+            m0 = fr_load(Ms + 2 * mi);
+            dm = fr_sub(fr_load(Ms + 2 * mi + 1), m0);
+        } else {
+            m0 = fr_load(Ms);
+            dm = fr_zero();
+        }
+        const fr_t dx = fr_sub(x1, x0), dy = fr_sub(y1, y0);
+        const fr_t q2 = fr_mul(dx, dy), q0 = fr_mul(x0, y0);
+        const fr_t q1 = fr_sub(fr_sub(fr_mul(x1, y1), q2), q0);
+        acc[0] = fr_add(acc[0], fr_mul(q2, dm));
+        acc[1] = fr_add(acc[1], fr_add(fr_mul(q2, m0), fr_mul(q1, dm)));
+        acc[2] = fr_add(acc[2], fr_add(fr_mul(q1, m0), fr_mul(q0, dm)));
+        acc[3] = fr_add(acc[3], fr_mul(q0, m0));
+    }
+    fr_block_sum<4>(acc, smem);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fr_store(partials + 4 * blockIdx.x + k, acc[k]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: FFT / IFFT layer claim combine  V[u] = sum_g val[g * stride + u] * beta[g]
+// reference src/prover.cpp:190-197.   grid = (u tiles, g chunks); partial sums per g chunk.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_strided_matvec(fr_t *out, const fr_t *val, const fr_t *beta, uint32_t len, uint32_t stride, uint32_t cnt,
+                                 uint32_t g_per_chunk) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= len) return;
+    const uint32_t g0 = blockIdx.y * g_per_chunk, g1 = min(cnt, g0 + g_per_chunk);
+    fr_t acc = fr_zero();
+    for (uint32_t g = g0; g < g1; ++g) acc = fr_add(acc, fr_mul(fr_load(val + (size_t) g * stride + u), fr_load(beta + g)));
+    fr_store(out + (size_t) blockIdx.y * len + u, acc);
+}
+// out[u] = sum_c part[c * len + u]
+__global__ void k_sum_rows(fr_t *out, const fr_t *part, uint32_t len, uint32_t chunks) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= len) return;
+    fr_t acc = fr_load(part + u);
+    for (uint32_t c = 1; c < chunks; ++c) acc = fr_add(acc, fr_load(part + (size_t) c * len + u));
+    fr_store(out + u, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7: MLE of the DFT matrix, closed form  phi[u] = scale * prod_j (1 - rx_j + rx_j w^{(u 2^j) mod N})
+// reference src/utils.cpp:61-103 (recursive there).  pw = powers of the 2^n-th root (or its inverse)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_phi(fr_t *out, const fr_t *pw, fr_vec rx, fr_t scale, int n, int vars, uint32_t cnt) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= cnt) return;
+    const uint32_t N1 = (1u << n) - 1;
+    const fr_t one = fr_one();
+    fr_t acc = scale;
+    for (int j = 0; j < vars; ++j) {
+        const fr_t rj = rx.v[j];
+        fr_t f = fr_add(fr_sub(one, rj), fr_mul(rj, fr_load(pw + ((u << j) & N1))));
+        acc = fr_mul(acc, f);
+    }
+    fr_store(out + u, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: DOT_PROD layer tables.
+//  phase 1: V0[(u,t)] = sum_{gates with .u = u} beta_g[g] * F[(v,t)]     reference src/prover.cpp:86-91
+//  phase 2: V1[v]     = sum_t F[(v,t)] * eq(r_k, t)                      reference src/prover.cpp:277-284
+// ------------------------------------------------------------------------------------------------
+// gates sorted by u; row_ptr[u]..row_ptr[u+1] delimit the gates of one u. grid = (t tiles, u rows)
+__global__ void k_dot_v0(fr_t *V0, const fr_t *F, const fr_t *beta_g, const gate_rec *recs, const uint32_t *row_ptr, int fft_bl) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, u = blockIdx.y;
+    if (t >= (1u << fft_bl)) return;
+    fr_t acc = fr_zero();
+    for (uint32_t e = row_ptr[u]; e < row_ptr[u + 1]; ++e) {
+        const gate_rec rc = recs[e];
+        acc = fr_add(acc, fr_mul(fr_load(beta_g + rc.g), fr_load(F + (((size_t) rc.aux) << fft_bl) + t)));
+    }
+    fr_store(V0 + (((size_t) u) << fft_bl) + t, acc);
+}
+// one wave per row v
+__global__ void __launch_bounds__(ZK_BLOCK) k_row_dot(fr_t *out, const fr_t *F, const fr_t *w, uint32_t rows, int fft_bl) {
+    const uint32_t v = blockIdx.x * (ZK_BLOCK / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (v >= rows) return;
+    fr_t acc = fr_zero();
+    for (uint32_t t = lane; t < (1u << fft_bl); t += 64)
+        acc = fr_add(acc, fr_mul(fr_load(F + (((size_t) v) << fft_bl) + t), fr_load(w + t)));
+    acc = fr_wave_sum(acc);
+    if (lane == 0) fr_store(out + v, acc);
+}
+
+// w[j] = <L, Z[:, j]>: Hyrax opening vector (rows x cols, row-major), partial sums over row chunks
+__global__ void k_col_combine(fr_t *out, const fr_t *Z, const fr_t *L, uint32_t cols, uint32_t rows, uint32_t rows_per_chunk) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cols) return;
+    const uint32_t i0 = blockIdx.y * rows_per_chunk, i1 = min(rows, i0 + rows_per_chunk);
+    fr_t acc = fr_zero();
+    for (uint32_t i = i0; i < i1; ++i) acc = fr_add(acc, fr_mul(fr_load(Z + (size_t) i * cols + j), fr_load(L + i)));
+    fr_store(out + (size_t) blockIdx.y * cols + j, acc);
+}

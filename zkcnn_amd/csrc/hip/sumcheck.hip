@@ -1,0 +1,1006 @@
+// libzkcnn_hip.so, part 1: context, residency and the GKR sumcheck state machine on the GPU.
+// Each extern "C" function is the binding of one reference prover method (see include/zkcnn_hip.h);
+// the O(1)-per-round scalar bookkeeping (add_term, round counters, proof-size counter) stays in
+// host code here exactly as in the reference, everything that is O(table) or O(gates) is a kernel.
+#include <algorithm>
+#include <cstring>
+#include "ctx.hpp"
+#include "kernels.cuh"
+
+static std::string g_create_err;
+
+// ------------------------------------------------------------------------------------------------
+// memory helpers
+// ------------------------------------------------------------------------------------------------
+int32_t zk_dev_alloc(zk_ctx *ctx, void **p, size_t bytes) {
+    if (bytes == 0) bytes = 32;
+    ZK_HIP(hipMalloc(p, bytes));
+    ctx->owned.push_back(*p);
+    return ZK_OK;
+}
+int32_t zk_scratch(zk_ctx *ctx, size_t bytes) {
+    if (ctx->scratch.bytes >= bytes) return ZK_OK;
+    if (ctx->scratch.p) {
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        ZK_HIP(hipFree(ctx->scratch.p));
+        ctx->scratch.p = nullptr;
+        ctx->scratch.bytes = 0;
+    }
+    size_t want = bytes + bytes / 4;
+    ZK_HIP(hipMalloc(&ctx->scratch.p, want));
+    ctx->scratch.bytes = want;
+    return ZK_OK;
+}
+template <class T>
+static int32_t upload(zk_ctx *ctx, T **dst, const std::vector<T> &src) {
+    *dst = nullptr;
+    if (src.empty()) return ZK_OK;
+    int32_t rc = zk_dev_alloc(ctx, (void **) dst, src.size() * sizeof(T));
+    if (rc) return rc;
+    ZK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
+    if (!out) return ZK_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_err = std::string("no HIP device: ") + hipGetErrorString(e);
+        return ZK_ERR_HIP;
+    }
+    if (device < 0 || device >= n) { g_create_err = "device index out of range"; return ZK_ERR_ARG; }
+    zk_ctx *ctx = new zk_ctx();
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
+        g_create_err = hipGetErrorString(e);
+        delete ctx;
+        return ZK_ERR_HIP;
+    }
+    // fixed-size work buffers
+    ctx->eq_stride = 1u << 15;
+    ctx->partial_blocks = 4096;
+    if (zk_dev_alloc(ctx, (void **) &ctx->eq_lo, 2 * (size_t) ctx->eq_stride * 32) ||
+        zk_dev_alloc(ctx, (void **) &ctx->eq_hi, 2 * (size_t) ctx->eq_stride * 32) ||
+        zk_dev_alloc(ctx, (void **) &ctx->partials, (size_t) ctx->partial_blocks * 4 * 32) ||
+        zk_dev_alloc(ctx, (void **) &ctx->d_result, 32 * 32) ||
+        hipHostMalloc((void **) &ctx->h_result, 32 * 32) != hipSuccess) {
+        g_create_err = ctx->err.empty() ? "allocation failed" : ctx->err;
+        zk_ctx_destroy(ctx);
+        return ZK_ERR_NOMEM;
+    }
+    *out = ctx;
+    return ZK_OK;
+}
+
+extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    zk_msm_destroy(ctx);
+    for (void *p : ctx->owned) hipFree(p);
+    if (ctx->scratch.p) hipFree(ctx->scratch.p);
+    if (ctx->h_result) hipHostFree(ctx->h_result);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char *zk_last_error(const zk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+extern "C" uint64_t zk_proof_bytes(const zk_ctx *ctx) { return ctx->proof_size; }
+
+// ------------------------------------------------------------------------------------------------
+// residency
+// ------------------------------------------------------------------------------------------------
+static void counting_sort(std::vector<gate_rec> &recs, uint32_t nkeys) {
+    std::vector<uint32_t> cnt((size_t) nkeys + 1, 0);
+    for (const gate_rec &r : recs) ++cnt[r.key + 1];
+    for (uint32_t k = 0; k < nkeys; ++k) cnt[k + 1] += cnt[k];
+    std::vector<gate_rec> out(recs.size());
+    for (const gate_rec &r : recs) out[cnt[r.key]++] = r;
+    recs.swap(out);
+}
+
+extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul,
+                                     int32_t n_two_mul) {
+    if (!ctx || !layers || n_layers < 2 || !two_mul || n_two_mul > 512) return ZK_ERR_ARG;
+    ZK_HIP(hipSetDevice(ctx->device));
+    if (ctx->circuit_ready) { ctx->err = "circuit already uploaded; create a new context"; return ZK_ERR_STATE; }
+    int32_t rc;
+    ctx->n_two_mul = n_two_mul;
+    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->two_mul, (size_t) n_two_mul * 32))) return rc;
+    ZK_HIP(hipMemcpy(ctx->two_mul, two_mul, (size_t) n_two_mul * 32, hipMemcpyHostToDevice));
+
+    ctx->L.assign(n_layers, dev_layer());
+    uint64_t max_table = 1, max_bg = 1, max_bu = 1, max_gs = 1, max_list = 1;
+    for (int i = 0; i < n_layers; ++i) {
+        dev_layer &D = ctx->L[i];
+        const zk_layer_desc &S = layers[i];
+        D.d = S;
+        D.d.uni_gates = nullptr; D.d.bin_gates = nullptr; D.d.ori_id_u = nullptr; D.d.ori_id_v = nullptr;
+        if (S.bit_length < 0 || S.bit_length > ZK_MAX_VARS) { ctx->err = "layer bit length out of range"; return ZK_ERR_ARG; }
+        D.val_len = 1ull << S.bit_length;
+        if ((rc = zk_dev_alloc(ctx, (void **) &D.val, D.val_len * 32))) return rc;
+        ZK_HIP(hipMemset(D.val, 0, D.val_len * 32));
+        max_table = std::max<uint64_t>(max_table, D.val_len);
+        if (i == 0) continue;
+        max_bg = std::max<uint64_t>(max_bg, D.val_len);
+        for (int b = 0; b < 2; ++b) {
+            if (S.bit_length_u[b] >= 0) max_table = std::max<uint64_t>(max_table, 1ull << S.bit_length_u[b]);
+            if (S.bit_length_v[b] >= 0) max_table = std::max<uint64_t>(max_table, 1ull << S.bit_length_v[b]);
+        }
+        if (S.bit_length_u[0] >= 0) max_bg = std::max<uint64_t>(max_bg, 1ull << S.bit_length_u[0]);
+        if (S.bit_length_v[0] >= 0) max_bg = std::max<uint64_t>(max_bg, 1ull << S.bit_length_v[0]);
+        max_bu = std::max<uint64_t>(max_bu, 1ull << std::max<int>(S.max_bl_u, S.max_bl_v));
+        if (S.fft_bit_length >= 0) max_gs = std::max<uint64_t>(max_gs, 1ull << S.fft_bit_length);
+
+        if (S.size_u[0]) {
+            std::vector<uint32_t> t(S.ori_id_u, S.ori_id_u + S.size_u[0]);
+            if ((rc = upload(ctx, &D.ori_u, t))) return rc;
+        }
+        if (S.size_v[0]) {
+            std::vector<uint32_t> t(S.ori_id_v, S.ori_id_v + S.size_v[0]);
+            if ((rc = upload(ctx, &D.ori_v, t))) return rc;
+        }
+        const bool dot = S.ty == ZK_DOT_PROD, xf = S.ty == ZK_FFT || S.ty == ZK_IFFT;
+        if (xf) continue;          // no gates: the transform layers are proved through the DFT-matrix MLE
+
+        // phase-2 list of the bin gates, keyed by v (also used by DOT_PROD)
+        std::vector<gate_rec> q[2];
+        for (uint64_t k = 0; k < S.n_bin; ++k) {
+            const zk_bin_gate &g = S.bin_gates[k];
+            const uint32_t v_prev = g.l & 1, u_prev = g.l != 0;
+            gate_rec r = {g.g, g.v, g.u, (uint32_t) g.sc | (u_prev << 10)};
+            q[v_prev].push_back(r);
+        }
+        for (int b = 0; b < 2; ++b) {
+            if (q[b].empty()) continue;
+            if (S.bit_length_v[b] < 0) { ctx->err = "bin gate refers to an absent v table"; return ZK_ERR_ARG; }
+            counting_sort(q[b], 1u << S.bit_length_v[b]);
+            D.n_p2[b] = q[b].size();
+            max_list = std::max<uint64_t>(max_list, q[b].size());
+            if ((rc = upload(ctx, &D.p2[b], q[b]))) return rc;
+            std::vector<gate_rec>().swap(q[b]);
+        }
+        if (dot) {
+            std::vector<gate_rec> d;
+            d.reserve(S.n_bin);
+            uint32_t rows = S.size_u[1] >> S.fft_bit_length;
+            for (uint64_t k = 0; k < S.n_bin; ++k) {
+                const zk_bin_gate &g = S.bin_gates[k];
+                if (g.u >= rows) { ctx->err = "DOT_PROD gate out of range"; return ZK_ERR_ARG; }
+                gate_rec r = {g.g, g.u, g.v, 0};
+                d.push_back(r);
+            }
+            counting_sort(d, rows);
+            std::vector<uint32_t> ptr((size_t) rows + 1, 0);
+            for (const gate_rec &r : d) ++ptr[r.key + 1];
+            for (uint32_t k = 0; k < rows; ++k) ptr[k + 1] += ptr[k];
+            D.d1_rows = rows;
+            if ((rc = upload(ctx, &D.d1, d)) || (rc = upload(ctx, &D.d1_rowptr, ptr))) return rc;
+            continue;
+        }
+        // phase-1 lists keyed by u; uni and bin gates of one table merged into one sorted list
+        std::vector<gate_rec> p[2], un;
+        un.reserve(S.n_uni);
+        for (uint64_t k = 0; k < S.n_uni; ++k) {
+            const zk_uni_gate &g = S.uni_gates[k];
+            const uint32_t in_prev = g.lu != 0;
+            gate_rec r = {g.g, g.u, 0, (uint32_t) g.sc};
+            p[in_prev].push_back(r);
+            gate_rec r2 = {g.g, 0, g.u, (uint32_t) g.sc | (in_prev << 10)};
+            un.push_back(r2);
+        }
+        for (uint64_t k = 0; k < S.n_bin; ++k) {
+            const zk_bin_gate &g = S.bin_gates[k];
+            const uint32_t v_prev = g.l & 1, u_prev = g.l != 0;
+            const uint32_t vres = v_prev ? g.v : S.ori_id_v[g.v];     // resolve the layer-0 subset index once
+            gate_rec r = {g.g, g.u, vres, (uint32_t) g.sc | (1u << 9) | (v_prev << 10)};
+            p[u_prev].push_back(r);
+        }
+        for (int b = 0; b < 2; ++b) {
+            if (p[b].empty()) continue;
+            if (S.bit_length_u[b] < 0) { ctx->err = "gate refers to an absent u table"; return ZK_ERR_ARG; }
+            counting_sort(p[b], 1u << S.bit_length_u[b]);
+            D.n_p1[b] = p[b].size();
+            max_list = std::max<uint64_t>(max_list, p[b].size());
+            if ((rc = upload(ctx, &D.p1[b], p[b]))) return rc;
+            std::vector<gate_rec>().swap(p[b]);
+        }
+        D.n_uni2 = un.size();
+        if ((rc = upload(ctx, &D.uni2, un))) return rc;
+    }
+    // work buffers sized for the largest layer
+    ctx->max_table = max_table;
+    for (int b = 0; b < 2; ++b)
+        for (int k = 0; k < 2; ++k) {
+            if ((rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].V[k], max_table * 32))) return rc;
+            if ((rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].M[k], max_table * 32))) return rc;
+        }
+    ctx->beta_g_cap = max_bg;
+    for (int k = 0; k < 2; ++k) if ((rc = zk_dev_alloc(ctx, (void **) &ctx->beta_g[k], max_bg * 32))) return rc;
+    ctx->beta_u_cap = max_bu;
+    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->beta_u, max_bu * 32))) return rc;
+    ctx->beta_gs_cap = max_gs;
+    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->beta_gs, max_gs * 32))) return rc;
+    for (int k = 0; k < 2; ++k) if ((rc = zk_dev_alloc(ctx, (void **) &ctx->small[k], max_gs * 32))) return rc;
+    ctx->carry_slots = 2 * ((max_list + ZK_BLOCK - 1) / ZK_BLOCK) + 2;
+    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->carry_key, ctx->carry_slots * 4))) return rc;
+    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->carry_val, ctx->carry_slots * 32))) return rc;
+    if ((rc = zk_scratch(ctx, (size_t) 1 << 24))) return rc;
+    ctx->circuit_ready = true;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_upload_layer_values(zk_ctx *ctx, int32_t layer, const uint64_t *values, uint64_t n) {
+    if (!ctx || !ctx->circuit_ready || layer < 0 || layer >= (int) ctx->L.size()) return ZK_ERR_ARG;
+    dev_layer &D = ctx->L[layer];
+    if (n > D.val_len) { ctx->err = "more values than the layer holds"; return ZK_ERR_ARG; }
+    ZK_HIP(hipSetDevice(ctx->device));
+    ZK_HIP(hipMemcpy(D.val, values, n * 32, hipMemcpyHostToDevice));
+    if (n < D.val_len) ZK_HIP(hipMemset(D.val + n, 0, (D.val_len - n) * 32));
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// building blocks
+// ------------------------------------------------------------------------------------------------
+// out[i] = a * eq(r0, i) + b * eq(r1, i), i < 2^n; entries >= tail_start additionally scaled
+static int32_t eq_table(zk_ctx *ctx, fr_t *out, int n, const HFr *r0, const HFr &a, const HFr *r1, const HFr &b,
+                        uint64_t tail_start, const HFr &tail_scale) {
+    if (n < 0) return ZK_OK;
+    if (n > ZK_MAX_VARS) { ctx->err = "eq table too large"; return ZK_ERR_ARG; }
+    const uint64_t len = 1ull << n;
+    eq_args A;
+    A.npoints = 0;
+    A.fh = n >> 1;
+    A.sh = n - A.fh;
+    if (!b.isZero()) {
+        for (int i = 0; i < n; ++i) A.r[A.npoints].v[i] = to_dev(r1[i]);
+        A.init[A.npoints++] = to_dev(b);
+    }
+    if (!a.isZero()) {
+        for (int i = 0; i < n; ++i) A.r[A.npoints].v[i] = to_dev(r0[i]);
+        A.init[A.npoints++] = to_dev(a);
+    }
+    if (A.npoints == 0) {
+        ZK_HIP(hipMemsetAsync(out, 0, len * 32, ctx->stream));
+        return ZK_OK;
+    }
+    hipLaunchKernelGGL(k_eq_halves, dim3(1), dim3(1024), 0, ctx->stream, ctx->eq_lo, ctx->eq_hi, ctx->eq_stride,
+                       ctx->eq_stride, A);
+    hipLaunchKernelGGL(k_eq_expand, dim3(grid_for(len)), dim3(ZK_BLOCK), 0, ctx->stream, out, ctx->eq_lo, ctx->eq_hi,
+                       ctx->eq_stride, ctx->eq_stride, A.npoints, A.fh, len, tail_start, to_dev(tail_scale));
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+static int32_t eq_table1(zk_ctx *ctx, fr_t *out, int n, const HFr *r, const HFr &init) {
+    return eq_table(ctx, out, n, r, init, nullptr, HFr(0LL), ~0ull, HFr::one());
+}
+
+int32_t zk_eq_table1_dev(zk_ctx *ctx, fr_t *out, int n, const HFr *r, const HFr &init) { return eq_table1(ctx, out, n, r, init); }
+
+// out[j] = sum_i L[i] * Z[i * cols + j]  (Hyrax opening vector w = L^T Z)
+int32_t zk_col_combine_dev(zk_ctx *ctx, fr_t *out, const fr_t *Z, const fr_t *L, uint32_t cols, uint32_t rows) {
+    uint32_t chunks = std::max<uint32_t>(1, std::min<uint32_t>(rows, (1u << 18) / std::max<uint32_t>(cols, 1)));
+    chunks = std::min<uint32_t>(chunks, 65535);
+    const uint32_t per = (rows + chunks - 1) / chunks;
+    chunks = (rows + per - 1) / per;
+    int32_t rc = zk_scratch(ctx, (size_t) chunks * cols * 32);
+    if (rc) return rc;
+    fr_t *part = chunks == 1 ? out : (fr_t *) ctx->scratch.p;
+    dim3 grid((cols + ZK_BLOCK - 1) / ZK_BLOCK, chunks);
+    hipLaunchKernelGGL(k_col_combine, grid, dim3(ZK_BLOCK), 0, ctx->stream, part, Z, L, cols, rows, per);
+    if (chunks > 1)
+        hipLaunchKernelGGL(k_sum_rows, dim3((cols + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), 0, ctx->stream, out, part, cols, chunks);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+// copies `count` elements of d_result to the pinned host mirror and waits for the stream
+static int32_t fetch_result(zk_ctx *ctx, int count) {
+    ZK_HIP(hipMemcpyAsync(ctx->h_result, ctx->d_result, (size_t) count * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+static int32_t gate_scatter(zk_ctx *ctx, fr_t *out, const gate_rec *recs, uint64_t n, int phase, const dev_layer &cur,
+                            const dev_layer &prev) {
+    if (!n) return ZK_OK;
+    gate_args A;
+    A.recs = recs;
+    A.n = n;
+    A.beta_g = ctx->beta_g[ctx->beta_g_cur];
+    A.beta_u = ctx->beta_u;
+    A.val0 = ctx->L[0].val;
+    A.val_prev = prev.val;
+    A.two_mul = ctx->two_mul;
+    A.Vu0 = to_dev(ctx->V_u0);
+    A.Vu1 = to_dev(ctx->V_u1);
+    A.phase = phase;
+    (void) cur;
+    const uint32_t blocks = (uint32_t) ((n + ZK_BLOCK - 1) / ZK_BLOCK);
+    if (2ull * blocks > ctx->carry_slots) { ctx->err = "carry buffer too small"; return ZK_ERR_STATE; }
+    hipLaunchKernelGGL(k_gate_reduce, dim3(blocks), dim3(ZK_BLOCK), 0, ctx->stream, out, ctx->carry_key, ctx->carry_val, A);
+    hipLaunchKernelGGL(k_gate_fixup, dim3(grid_for(2ull * blocks)), dim3(ZK_BLOCK), 0, ctx->stream, out, ctx->carry_key,
+                       ctx->carry_val, 2ull * blocks);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+// V-table of one side: layer-0 subset through ori ids, or the previous layer as it is
+static int32_t load_v_table(zk_ctx *ctx, fr_t *dst, int b, int bl, uint32_t size, const uint32_t *ori, const dev_layer &prev) {
+    if (bl < 0) return ZK_OK;
+    const uint64_t len = 1ull << bl;
+    if (b == 0) {
+        hipLaunchKernelGGL(k_gather, dim3(grid_for(len)), dim3(ZK_BLOCK), 0, ctx->stream, dst, ctx->L[0].val, ori,
+                           (uint64_t) size, len);
+        ZK_HIP(hipGetLastError());
+    } else {
+        const uint64_t have = std::min<uint64_t>(len, prev.val_len);
+        ZK_HIP(hipMemcpyAsync(dst, prev.val, have * 32, hipMemcpyDeviceToDevice, ctx->stream));
+        if (have < len) ZK_HIP(hipMemsetAsync(dst + have, 0, (len - have) * 32, ctx->stream));
+    }
+    return ZK_OK;
+}
+
+static void reset_pairs(zk_ctx *ctx, int bl0, int bl1) {
+    const int bl[2] = {bl0, bl1};
+    for (int b = 0; b < 2; ++b) {
+        ctx->tp[b].cur = 0;
+        ctx->tp[b].len = bl[b] >= 0 ? 1ull << bl[b] : 0;
+        ctx->tp[b].absorbed = false;
+        ctx->tp[b].final_v.clear();
+    }
+}
+
+static fr_t *powers_of_root(zk_ctx *ctx, int n, bool inverse) {
+    auto &tab = ctx->root_pw[inverse ? 1 : 0];
+    if ((int) tab.size() <= n) tab.resize(n + 1, nullptr);
+    if (tab[n]) return tab[n];
+    // n-1 successive square roots of -1 (reference src/utils.cpp:224-232), then the power table
+    HFr w = HFr::one();
+    if (n > 0) {
+        w = -HFr::one();
+        for (int k = 1; k < n; ++k) HFr::squareRoot(w, w);
+    }
+    if (inverse) HFr::inv(w, w);
+    std::vector<HFr> pw((size_t) 1 << n);
+    pw[0] = HFr::one();
+    for (size_t i = 1; i < pw.size(); ++i) pw[i] = pw[i - 1] * w;
+    fr_t *d = nullptr;
+    if (zk_dev_alloc(ctx, (void **) &d, pw.size() * 32)) return nullptr;
+    if (hipMemcpy(d, pw.data(), pw.size() * 32, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    tab[n] = d;
+    return d;
+}
+
+static int32_t phi_table(zk_ctx *ctx, fr_t *out, const HFr *rx, const HFr &scale, int n, bool inverse) {
+    fr_t *pw = powers_of_root(ctx, n, inverse);
+    if (!pw) { ctx->err = "root table allocation failed"; return ZK_ERR_NOMEM; }
+    const int vars = inverse ? n - 1 : n;
+    const uint32_t cnt = inverse ? 1u << n : 1u << (n - 1);
+    fr_vec R;
+    for (int j = 0; j < vars; ++j) R.v[j] = to_dev(rx[j]);
+    hipLaunchKernelGGL(k_phi, dim3((cnt + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), 0, ctx->stream, out, pw, R, to_dev(scale),
+                       n, vars, cnt);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+// out[u] = sum_g val[g * stride + u] * beta[g]
+static int32_t strided_matvec(zk_ctx *ctx, fr_t *out, const fr_t *val, const fr_t *beta, uint32_t len, uint32_t stride,
+                              uint32_t cnt) {
+    uint32_t chunks = std::max<uint32_t>(1, std::min<uint32_t>(cnt, (1u << 16) / std::max<uint32_t>(len, 1)));
+    chunks = std::min<uint32_t>(chunks, 65535);
+    const uint32_t per = (cnt + chunks - 1) / chunks;
+    chunks = (cnt + per - 1) / per;
+    int32_t rc = zk_scratch(ctx, (size_t) chunks * len * 32);
+    if (rc) return rc;
+    fr_t *part = chunks == 1 ? out : (fr_t *) ctx->scratch.p;
+    dim3 grid((len + ZK_BLOCK - 1) / ZK_BLOCK, chunks);
+    hipLaunchKernelGGL(k_strided_matvec, grid, dim3(ZK_BLOCK), 0, ctx->stream, part, val, beta, len, stride, cnt, per);
+    if (chunks > 1)
+        hipLaunchKernelGGL(k_sum_rows, dim3((len + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), 0, ctx->stream, out, part, len, chunks);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+// folds table `b`'s V (and M if with_m) with r; len must be >= 2
+static int32_t fold_pair(zk_ctx *ctx, table_pair &t, const HFr &r, bool with_m) {
+    const fr_t rr = to_dev(r);
+    hipLaunchKernelGGL(k_fold, dim3(grid_for(t.len / 2)), dim3(ZK_BLOCK), 0, ctx->stream, t.V[t.cur], t.V[t.cur ^ 1], t.len, rr);
+    if (with_m)
+        hipLaunchKernelGGL(k_fold, dim3(grid_for(t.len / 2)), dim3(ZK_BLOCK), 0, ctx->stream, t.M[t.cur], t.M[t.cur ^ 1], t.len, rr);
+    ZK_HIP(hipGetLastError());
+    t.cur ^= 1;
+    t.len >>= 1;
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// state machine
+// ------------------------------------------------------------------------------------------------
+#define CHECK_READY() do { if (!ctx || !ctx->circuit_ready) return ZK_ERR_STATE; ZK_HIP(hipSetDevice(ctx->device)); } while (0)
+static inline const HFr &H(const uint64_t *p) { return *reinterpret_cast<const HFr *>(p); }
+static inline void put(uint64_t *dst, const HFr &x) { std::memcpy(dst, &x, 32); }
+
+extern "C" int32_t zk_prover_init(zk_ctx *ctx) {
+    CHECK_READY();
+    ctx->proof_size = 0;
+    const size_t n = ctx->L.size();
+    ctx->r_u.assign(n + 1, std::vector<HFr>());
+    ctx->r_v.assign(n + 1, std::vector<HFr>());
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_vres(zk_ctx *ctx, const uint64_t *r, uint32_t output_size, uint32_t r_size, uint64_t out[4]) {
+    CHECK_READY();
+    const dev_layer &top = ctx->L.back();
+    if ((1ull << r_size) < output_size || (1ull << r_size) > top.val_len) return ZK_ERR_ARG;
+    table_pair &t = ctx->tp[0];
+    t.cur = 0;
+    t.len = 1ull << r_size;
+    ZK_HIP(hipMemcpyAsync(t.V[0], top.val, t.len * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    for (uint32_t i = 0; i < r_size; ++i) {
+        int32_t rc = fold_pair(ctx, t, H(r + 4 * i), false);
+        if (rc) return rc;
+    }
+    ZK_HIP(hipMemcpyAsync(ctx->d_result, t.V[t.cur], 32, hipMemcpyDeviceToDevice, ctx->stream));
+    int32_t rc = fetch_result(ctx, 1);
+    if (rc) return rc;
+    put(out, ctx->h_result[0]);
+    t.len = 0;
+    ctx->proof_size += 32;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_sumcheck_init_all(zk_ctx *ctx, const uint64_t *r_0, uint32_t n) {
+    CHECK_READY();
+    ctx->sumcheck_id = (int) ctx->L.size();
+    if ((int) n != ctx->L.back().d.bit_length) return ZK_ERR_ARG;
+    auto &dst = ctx->r_u[ctx->sumcheck_id];
+    dst.resize(n);
+    for (uint32_t i = 0; i < n; ++i) dst[i] = H(r_0 + 4 * i);
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_sumcheck_init(zk_ctx *ctx, const uint64_t alpha[4], const uint64_t beta[4]) {
+    CHECK_READY();
+    if (ctx->sumcheck_id < 2) return ZK_ERR_STATE;
+    ctx->alpha = H(alpha);
+    ctx->beta = H(beta);
+    ctx->r_0 = ctx->r_u[ctx->sumcheck_id].data();
+    ctx->r_1 = ctx->r_v[ctx->sumcheck_id].data();
+    --ctx->sumcheck_id;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[4]) {
+    CHECK_READY();
+    const int id = ctx->sumcheck_id;
+    if (id < 1 || id >= (int) ctx->L.size()) return ZK_ERR_STATE;
+    const dev_layer &cur = ctx->L[id], &prev = ctx->L[id - 1];
+    const zk_layer_desc &d = cur.d;
+    int32_t rc;
+    reset_pairs(ctx, d.bit_length_u[0], d.bit_length_u[1]);
+    ctx->r_u[id].assign(std::max<int>(d.max_bl_u, 0), HFr(0LL));
+    ctx->relu_rou = H(relu_rou);
+    ctx->add_term.clear();
+    ctx->round = 0;
+    const HFr scale = H(d.scale);
+
+    if (d.ty == ZK_FFT || d.ty == ZK_IFFT) {
+        const bool fwd = d.ty == ZK_FFT;
+        const int fft_bl = d.fft_bit_length, fft_blh = fft_bl - 1;
+        const int cnt_bl = fwd ? d.bit_length - fft_bl : d.bit_length - fft_blh;
+        const uint32_t cnt_len = d.size >> (fwd ? fft_bl : fft_blh);
+        fr_t *bg = ctx->beta_g[ctx->beta_g_cur];
+        if (fwd) rc = eq_table(ctx, bg, cnt_bl, ctx->r_0 + fft_bl, ctx->alpha, ctx->r_1, ctx->beta, ~0ull, HFr::one());
+        else rc = eq_table1(ctx, bg, cnt_bl, ctx->r_0 + fft_blh, ctx->alpha);
+        if (rc) return rc;
+        table_pair &t = ctx->tp[1];
+        const uint32_t len = (uint32_t) t.len;
+        if ((rc = strided_matvec(ctx, t.V[0], prev.val, bg, len, 1u << d.max_bl_u, cnt_len))) return rc;
+        if ((rc = phi_table(ctx, t.M[0], ctx->r_0, scale, fft_bl, !fwd))) return rc;
+        return ZK_OK;
+    }
+
+    for (int b = 0; b < 2; ++b)
+        if ((rc = load_v_table(ctx, ctx->tp[b].V[0], b, d.bit_length_u[b], d.size_u[b], cur.ori_u, prev))) return rc;
+
+    if (d.ty == ZK_PADDING) {
+        // beta_g[g] = beta_g_fft[g >> (n-1)] * eq(r_0[0..n-1), g & mask): the table left by the FFT layer above
+        // is expanded (reference src/prover.cpp:214-219; hidden cross-layer state)
+        const int fft_blh = d.fft_bit_length - 1;
+        if ((rc = eq_table1(ctx, ctx->beta_gs, fft_blh, ctx->r_0, HFr::one()))) return rc;
+        fr_t *src = ctx->beta_g[ctx->beta_g_cur], *dst = ctx->beta_g[ctx->beta_g_cur ^ 1];
+        hipLaunchKernelGGL(k_outer_expand, dim3(grid_for(cur.val_len)), dim3(ZK_BLOCK), 0, ctx->stream, dst, src, ctx->beta_gs,
+                           fft_blh, cur.val_len);
+        ZK_HIP(hipGetLastError());
+        ctx->beta_g_cur ^= 1;
+        if (d.zero_start_id < d.size) { ctx->err = "PADDING layer with constraint rows is not supported"; return ZK_ERR_ARG; }
+    } else {
+        const bool tail = d.zero_start_id < d.size;
+        rc = eq_table(ctx, ctx->beta_g[ctx->beta_g_cur], d.bit_length, ctx->r_0, ctx->alpha * scale, ctx->r_1, ctx->beta * scale,
+                      tail ? d.zero_start_id : ~0ull, tail ? ctx->relu_rou : HFr::one());
+        if (rc) return rc;
+    }
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        if (!t.len) continue;
+        ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
+        if ((rc = gate_scatter(ctx, t.M[0], cur.p1[b], cur.n_p1[b], 1, cur, prev))) return rc;
+    }
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
+    CHECK_READY();
+    const int id = ctx->sumcheck_id;
+    if (id < 1 || id >= (int) ctx->L.size()) return ZK_ERR_STATE;
+    const dev_layer &cur = ctx->L[id], &prev = ctx->L[id - 1];
+    const zk_layer_desc &d = cur.d;
+    if (d.ty != ZK_DOT_PROD) return ZK_ERR_STATE;
+    int32_t rc;
+    const int fft_bl = d.fft_bit_length;
+    reset_pairs(ctx, d.bit_length_u[1], d.bit_length_u[1]);       // V0 and V1 both span the whole FFT layer
+    ctx->r_u[id].assign(d.max_bl_u, HFr(0LL));
+    ctx->round = 0;
+    ctx->small_len = 1u << fft_bl;
+    ctx->small_cur = 0;
+    const uint64_t N = ctx->tp[1].len;
+    if ((rc = eq_table1(ctx, ctx->small[0], fft_bl, ctx->r_0, HFr::one()))) return rc;
+    if ((rc = load_v_table(ctx, ctx->tp[1].V[0], 1, d.bit_length_u[1], d.size_u[1], nullptr, prev))) return rc;
+    ZK_HIP(hipMemsetAsync(ctx->tp[0].V[0], 0, N * 32, ctx->stream));
+    if (cur.d1_rows) {
+        dim3 grid(((1u << fft_bl) + ZK_BLOCK - 1) / ZK_BLOCK, cur.d1_rows);
+        hipLaunchKernelGGL(k_dot_v0, grid, dim3(ZK_BLOCK), 0, ctx->stream, ctx->tp[0].V[0], prev.val, ctx->beta_g[ctx->beta_g_cur],
+                           cur.d1, cur.d1_rowptr, fft_bl);
+        ZK_HIP(hipGetLastError());
+    }
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t out_abcd[16]) {
+    CHECK_READY();
+    const int id = ctx->sumcheck_id;
+    const HFr r = H(prev_r);
+    const bool first = ctx->round == 0;
+    if (!first) ctx->r_u[id].at(ctx->round - 1) = r;
+    ++ctx->round;
+    if (!first && ctx->small_len >= 2) {
+        hipLaunchKernelGGL(k_fold, dim3(grid_for(ctx->small_len / 2)), dim3(ZK_BLOCK), 0, ctx->stream, ctx->small[ctx->small_cur],
+                           ctx->small[ctx->small_cur ^ 1], (uint64_t) ctx->small_len, to_dev(r));
+        ctx->small_cur ^= 1;
+        ctx->small_len >>= 1;
+    }
+    table_pair &t0 = ctx->tp[0], &t1 = ctx->tp[1];
+    const uint64_t n = t1.len;
+    const uint64_t npairs = first ? n / 2 : n / 4;
+    if (npairs == 0) return ZK_ERR_STATE;
+    const uint32_t g = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks);
+    hipLaunchKernelGGL(k_round_cubic, dim3(g), dim3(ZK_BLOCK), 0, ctx->stream, t0.V[t0.cur], t1.V[t1.cur], t0.V[t0.cur ^ 1],
+                       t1.V[t1.cur ^ 1], ctx->small[ctx->small_cur], ctx->small_len, n, to_dev(r), first ? 1 : 0, ctx->partials);
+    hipLaunchKernelGGL(k_sum_partials<4>, dim3(1), dim3(ZK_BLOCK), 0, ctx->stream, ctx->d_result, ctx->partials, g, 0);
+    ZK_HIP(hipGetLastError());
+    if (!first) {
+        t0.cur ^= 1; t1.cur ^= 1;
+        t0.len >>= 1; t1.len >>= 1;
+    }
+    int32_t rc = fetch_result(ctx, 4);
+    if (rc) return rc;
+    for (int k = 0; k < 4; ++k) put(out_abcd + 4 * k, ctx->h_result[k]);
+    ctx->proof_size += 32 * (3 + (ctx->h_result[0].isZero() ? 0 : 1));
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_sumcheck_dotprod_finalize1(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t claim_1[4]) {
+    CHECK_READY();
+    const int id = ctx->sumcheck_id;
+    const HFr r = H(prev_r);
+    if (ctx->round < 1) return ZK_ERR_STATE;
+    ctx->r_u[id].at(ctx->round - 1) = r;
+    table_pair &t1 = ctx->tp[1];
+    int32_t rc;
+    if (t1.len >= 2 && (rc = fold_pair(ctx, t1, r, false))) return rc;
+    if (ctx->small_len >= 2) {
+        hipLaunchKernelGGL(k_fold, dim3(1), dim3(ZK_BLOCK), 0, ctx->stream, ctx->small[ctx->small_cur], ctx->small[ctx->small_cur ^ 1],
+                           (uint64_t) ctx->small_len, to_dev(r));
+        ctx->small_cur ^= 1;
+        ctx->small_len >>= 1;
+    }
+    ZK_HIP(hipMemcpyAsync(ctx->d_result, t1.V[t1.cur], 32, hipMemcpyDeviceToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(ctx->d_result + 1, ctx->small[ctx->small_cur], 32, hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = fetch_result(ctx, 2))) return rc;
+    put(claim_1, ctx->h_result[0]);
+    ctx->V_u1 = ctx->h_result[0] * ctx->h_result[1];
+    ctx->proof_size += 32;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
+    CHECK_READY();
+    const int id = ctx->sumcheck_id;
+    if (id < 1 || id >= (int) ctx->L.size()) return ZK_ERR_STATE;
+    const dev_layer &cur = ctx->L[id], &prev = ctx->L[id - 1];
+    const zk_layer_desc &d = cur.d;
+    int32_t rc;
+    reset_pairs(ctx, d.bit_length_v[0], d.bit_length_v[1]);
+    ctx->r_v[id].assign(std::max<int>(d.max_bl_v, 0), HFr(0LL));
+    ctx->add_term.clear();
+    ctx->round = 0;
+    const HFr *ru = ctx->r_u[id].data();
+
+    if (d.ty == ZK_DOT_PROD) {
+        const int fft_bl = d.fft_bit_length, cnt_bl = d.max_bl_v;
+        if ((rc = eq_table1(ctx, ctx->beta_u, cnt_bl, ru + fft_bl, HFr::one()))) return rc;
+        if ((rc = eq_table1(ctx, ctx->beta_gs, fft_bl, ru, HFr::one()))) return rc;
+        table_pair &t = ctx->tp[1];
+        ZK_HIP(hipMemsetAsync(t.V[0], 0, t.len * 32, ctx->stream));
+        const uint32_t rows = d.size_v[1];
+        hipLaunchKernelGGL(k_row_dot, dim3((rows + 3) / 4), dim3(ZK_BLOCK), 0, ctx->stream, t.V[0], prev.val, ctx->beta_gs, rows, fft_bl);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
+        return gate_scatter(ctx, t.M[0], cur.p2[1], cur.n_p2[1], 2, cur, prev);
+    }
+
+    if ((rc = eq_table1(ctx, ctx->beta_u, d.max_bl_u, ru, HFr::one()))) return rc;
+    for (int b = 0; b < 2; ++b)
+        if ((rc = load_v_table(ctx, ctx->tp[b].V[0], b, d.bit_length_v[b], d.size_v[b], cur.ori_v, prev))) return rc;
+    if (cur.n_uni2) {
+        gate_args A;
+        A.recs = cur.uni2; A.n = cur.n_uni2;
+        A.beta_g = ctx->beta_g[ctx->beta_g_cur]; A.beta_u = ctx->beta_u;
+        A.val0 = nullptr; A.val_prev = nullptr; A.two_mul = ctx->two_mul;
+        A.Vu0 = to_dev(ctx->V_u0); A.Vu1 = to_dev(ctx->V_u1); A.phase = 2;
+        const uint32_t g = std::min<uint32_t>(grid_for(cur.n_uni2, 1024), ctx->partial_blocks);
+        hipLaunchKernelGGL(k_gate_sum2, dim3(g), dim3(ZK_BLOCK), 0, ctx->stream, ctx->partials, A);
+        hipLaunchKernelGGL(k_sum_partials<2>, dim3(1), dim3(ZK_BLOCK), 0, ctx->stream, ctx->d_result + 8, ctx->partials, g, 0);
+        ZK_HIP(hipGetLastError());
+    }
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        if (!t.len) continue;
+        ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
+        if ((rc = gate_scatter(ctx, t.M[0], cur.p2[b], cur.n_p2[b], 2, cur, prev))) return rc;
+    }
+    if (cur.n_uni2) {
+        ZK_HIP(hipMemcpyAsync(ctx->h_result + 8, ctx->d_result + 8, 64, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->add_term = ctx->V_u0 * ctx->h_result[8] + ctx->V_u1 * ctx->h_result[9];
+    }
+    return ZK_OK;
+}
+
+// One quadratic round over the live table pairs. reference src/prover.cpp:368-426.
+static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]) {
+    const bool first = ctx->round == 0;
+    ++ctx->round;
+    if (with_add_term) ctx->add_term = ctx->add_term * (HFr::one() - r);
+    uint32_t nb = 0;
+    bool collapsed[2] = {false, false};
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        if (!t.len) continue;
+        if ((first && t.len == 1) || (!first && t.len == 2)) {
+            // the reference's `total == 1` case: the table has run out of variables; its product becomes a constant
+            int32_t rc;
+            if (t.len == 2 && (rc = fold_pair(ctx, t, r, true))) return rc;
+            ZK_HIP(hipMemcpyAsync(ctx->d_result + 4 + 2 * b, t.V[t.cur], 32, hipMemcpyDeviceToDevice, ctx->stream));
+            ZK_HIP(hipMemcpyAsync(ctx->d_result + 5 + 2 * b, t.M[t.cur], 32, hipMemcpyDeviceToDevice, ctx->stream));
+            collapsed[b] = true;
+            continue;
+        }
+        const uint64_t npairs = first ? t.len / 2 : t.len / 4;
+        const uint32_t g = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks / 2);
+        hipLaunchKernelGGL(k_round_quad, dim3(g), dim3(ZK_BLOCK), 0, ctx->stream, t.V[t.cur], t.M[t.cur], t.V[t.cur ^ 1],
+                           t.M[t.cur ^ 1], t.len, to_dev(r), first ? 1 : 0, ctx->partials + 3 * (size_t) nb);
+        nb += g;
+        if (!first) { t.cur ^= 1; t.len >>= 1; }
+    }
+    if (nb) hipLaunchKernelGGL(k_sum_partials<3>, dim3(1), dim3(ZK_BLOCK), 0, ctx->stream, ctx->d_result, ctx->partials, nb, 0);
+    else ZK_HIP(hipMemsetAsync(ctx->d_result, 0, 3 * 32, ctx->stream));
+    ZK_HIP(hipGetLastError());
+    int32_t rc = fetch_result(ctx, 8);
+    if (rc) return rc;
+    HFr a = ctx->h_result[0], c = ctx->h_result[1], p1 = ctx->h_result[2];
+    HFr bcoef = p1 - a - c;
+    for (int b = 0; b < 2; ++b)
+        if (collapsed[b]) {
+            table_pair &t = ctx->tp[b];
+            t.final_v = ctx->h_result[4 + 2 * b];
+            ctx->add_term = ctx->add_term + t.final_v * ctx->h_result[5 + 2 * b];
+            t.absorbed = true;
+            t.len = 0;
+        }
+    if (with_add_term) {        // + add_term * (1 - x)
+        bcoef = bcoef - ctx->add_term;
+        c = c + ctx->add_term;
+    }
+    put(out_abc, a);
+    put(out_abc + 4, bcoef);
+    put(out_abc + 8, c);
+    ctx->proof_size += 32 * 3;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_sumcheck_update1(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t out_abc[12]) {
+    CHECK_READY();
+    if (ctx->round) ctx->r_u[ctx->sumcheck_id].at(ctx->round - 1) = H(prev_r);
+    return quad_round(ctx, H(prev_r), true, out_abc);
+}
+extern "C" int32_t zk_sumcheck_update2(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t out_abc[12]) {
+    CHECK_READY();
+    if (ctx->round) ctx->r_v[ctx->sumcheck_id].at(ctx->round - 1) = H(prev_r);
+    return quad_round(ctx, H(prev_r), true, out_abc);
+}
+extern "C" int32_t zk_sumcheck_liu_update(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t out_abc[12]) {
+    CHECK_READY();
+    return quad_round(ctx, H(prev_r), false, out_abc);
+}
+
+// final evaluations of the two V tables (reference src/prover.cpp:459-485)
+static int32_t final_claims(zk_ctx *ctx, const HFr &r, const int8_t bl[2], HFr out[2]) {
+    bool pending[2] = {false, false};
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        out[b].clear();
+        if (t.len >= 2) {
+            int32_t rc = fold_pair(ctx, t, r, false);
+            if (rc) return rc;
+        }
+        if (t.len == 1) {
+            ZK_HIP(hipMemcpyAsync(ctx->d_result + b, t.V[t.cur], 32, hipMemcpyDeviceToDevice, ctx->stream));
+            pending[b] = true;
+        } else if (t.absorbed && bl[b] >= 0) out[b] = t.final_v;
+    }
+    if (pending[0] || pending[1]) {
+        int32_t rc = fetch_result(ctx, 2);
+        if (rc) return rc;
+        for (int b = 0; b < 2; ++b) if (pending[b]) out[b] = ctx->h_result[b];
+    }
+    for (int b = 0; b < 2; ++b) ctx->tp[b].len = 0;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_sumcheck_finalize1(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t claim_0[4], uint64_t claim_1[4]) {
+    CHECK_READY();
+    const int id = ctx->sumcheck_id;
+    if (ctx->round < 1) return ZK_ERR_STATE;
+    ctx->r_u[id].at(ctx->round - 1) = H(prev_r);
+    HFr c[2];
+    int32_t rc = final_claims(ctx, H(prev_r), ctx->L[id].d.bit_length_u, c);
+    if (rc) return rc;
+    ctx->V_u0 = c[0];
+    ctx->V_u1 = c[1];
+    put(claim_0, c[0]);
+    put(claim_1, c[1]);
+    ctx->proof_size += 32 * 2;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_sumcheck_finalize2(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t claim_0[4], uint64_t claim_1[4]) {
+    CHECK_READY();
+    const int id = ctx->sumcheck_id;
+    if (ctx->round < 1) return ZK_ERR_STATE;
+    ctx->r_v[id].at(ctx->round - 1) = H(prev_r);
+    HFr c[2];
+    int32_t rc = final_claims(ctx, H(prev_r), ctx->L[id].d.bit_length_v, c);
+    if (rc) return rc;
+    put(claim_0, c[0]);
+    put(claim_1, c[1]);
+    ctx->proof_size += 32 * 2;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_sumcheck_liu_init(zk_ctx *ctx, const uint64_t *s_u, const uint64_t *s_v, uint32_t n) {
+    CHECK_READY();
+    if (n + 1 != ctx->L.size()) return ZK_ERR_ARG;
+    ctx->sumcheck_id = 0;
+    const dev_layer &L0 = ctx->L[0];
+    reset_pairs(ctx, -1, L0.d.bit_length);
+    ctx->r_u[0].assign(L0.d.bit_length, HFr(0LL));
+    ctx->add_term.clear();
+    ctx->round = 0;
+    table_pair &t = ctx->tp[1];
+    ZK_HIP(hipMemcpyAsync(t.V[0], L0.val, t.len * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
+    fr_t *bg = ctx->beta_g[ctx->beta_g_cur];
+    int32_t rc;
+    for (size_t i = 1; i < ctx->L.size(); ++i) {
+        const dev_layer &Li = ctx->L[i];
+        if (Li.d.bit_length_u[0] >= 0) {
+            if ((int) ctx->r_u[i].size() < Li.d.bit_length_u[0]) return ZK_ERR_STATE;
+            if ((rc = eq_table1(ctx, bg, Li.d.bit_length_u[0], ctx->r_u[i].data(), H(s_u + 4 * (i - 1))))) return rc;
+            if (Li.d.size_u[0])
+                hipLaunchKernelGGL(k_scatter_add_unique, dim3(grid_for(Li.d.size_u[0])), dim3(ZK_BLOCK), 0, ctx->stream, t.M[0],
+                                   Li.ori_u, bg, (uint64_t) Li.d.size_u[0]);
+        }
+        if (Li.d.bit_length_v[0] >= 0) {
+            if ((int) ctx->r_v[i].size() < Li.d.bit_length_v[0]) return ZK_ERR_STATE;
+            if ((rc = eq_table1(ctx, bg, Li.d.bit_length_v[0], ctx->r_v[i].data(), H(s_v + 4 * (i - 1))))) return rc;
+            if (Li.d.size_v[0])
+                hipLaunchKernelGGL(k_scatter_add_unique, dim3(grid_for(Li.d.size_v[0])), dim3(ZK_BLOCK), 0, ctx->stream, t.M[0],
+                                   Li.ori_v, bg, (uint64_t) Li.d.size_v[0]);
+        }
+    }
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_sumcheck_liu_finalize(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t claim_1[4]) {
+    CHECK_READY();
+    if (ctx->round < 1) return ZK_ERR_STATE;
+    ctx->r_u[0].at(ctx->round - 1) = H(prev_r);
+    HFr c[2];
+    const int8_t bl[2] = {-1, ctx->L[0].d.bit_length};
+    int32_t rc = final_claims(ctx, H(prev_r), bl, c);
+    if (rc) return rc;
+    put(claim_1, c[1]);
+    ctx->proof_size += 32;
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel-level entry points (host arrays in / out)
+// ------------------------------------------------------------------------------------------------
+#define CHECK_CTX() do { if (!ctx) return ZK_ERR_ARG; ZK_HIP(hipSetDevice(ctx->device)); } while (0)
+
+template <int OP>
+static int32_t binop(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n) {
+    CHECK_CTX();
+    int32_t rc = zk_scratch(ctx, 3 * n * 32);
+    if (rc) return rc;
+    fr_t *da = (fr_t *) ctx->scratch.p, *db = da + n, *dz = db + n;
+    ZK_HIP(hipMemcpyAsync(da, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(db, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_fr_binop<OP>, dim3(grid_for(n)), dim3(ZK_BLOCK), 0, ctx->stream, dz, da, db, n);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpyAsync(out, dz, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+extern "C" int32_t zk_k_fr_mul(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n) { return binop<0>(ctx, out, a, b, n); }
+extern "C" int32_t zk_k_fr_add(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n) { return binop<1>(ctx, out, a, b, n); }
+extern "C" int32_t zk_k_fr_sub(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n) { return binop<2>(ctx, out, a, b, n); }
+
+extern "C" int32_t zk_k_eq_table(zk_ctx *ctx, uint64_t *out, int32_t n, const uint64_t *r0, const uint64_t *r1,
+                                 const uint64_t alpha[4], const uint64_t beta[4]) {
+    CHECK_CTX();
+    if (n < 0 || n > ZK_MAX_VARS) return ZK_ERR_ARG;
+    const uint64_t len = 1ull << n;
+    int32_t rc = zk_scratch(ctx, len * 32);
+    if (rc) return rc;
+    rc = eq_table(ctx, (fr_t *) ctx->scratch.p, n, reinterpret_cast<const HFr *>(r0), H(alpha), reinterpret_cast<const HFr *>(r1),
+                  H(beta), ~0ull, HFr::one());
+    if (rc) return rc;
+    ZK_HIP(hipMemcpyAsync(out, ctx->scratch.p, len * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_k_phi_table(zk_ctx *ctx, uint64_t *out, const uint64_t *rx, const uint64_t scale[4], int32_t n,
+                                  int32_t inverse) {
+    CHECK_CTX();
+    if (n < 1 || n > 20) return ZK_ERR_ARG;
+    const uint64_t cnt = inverse ? 1ull << n : 1ull << (n - 1);
+    int32_t rc = zk_scratch(ctx, cnt * 32);
+    if (rc) return rc;
+    if ((rc = phi_table(ctx, (fr_t *) ctx->scratch.p, reinterpret_cast<const HFr *>(rx), H(scale), n, inverse != 0))) return rc;
+    ZK_HIP(hipMemcpyAsync(out, ctx->scratch.p, cnt * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_k_round_quadratic(zk_ctx *ctx, uint64_t *V, uint64_t *M, uint64_t n, const uint64_t r[4], int32_t first,
+                                        uint64_t out_abc[12], uint64_t *n_out) {
+    CHECK_CTX();
+    if (n < 2 || (n & (n - 1)) || (!first && n < 4)) return ZK_ERR_ARG;
+    int32_t rc = zk_scratch(ctx, 4 * n * 32);
+    if (rc) return rc;
+    fr_t *dV = (fr_t *) ctx->scratch.p, *dM = dV + n, *dV2 = dM + n, *dM2 = dV2 + n;
+    ZK_HIP(hipMemcpyAsync(dV, V, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(dM, M, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    const uint64_t npairs = first ? n / 2 : n / 4;
+    const uint32_t g = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks);
+    hipLaunchKernelGGL(k_round_quad, dim3(g), dim3(ZK_BLOCK), 0, ctx->stream, dV, dM, dV2, dM2, n, to_dev(H(r)), first ? 1 : 0,
+                       ctx->partials);
+    hipLaunchKernelGGL(k_sum_partials<3>, dim3(1), dim3(ZK_BLOCK), 0, ctx->stream, ctx->d_result, ctx->partials, g, 0);
+    ZK_HIP(hipGetLastError());
+    if ((rc = fetch_result(ctx, 3))) return rc;
+    const uint64_t nn = first ? n : n / 2;
+    if (!first) {
+        ZK_HIP(hipMemcpy(V, dV2, nn * 32, hipMemcpyDeviceToHost));
+        ZK_HIP(hipMemcpy(M, dM2, nn * 32, hipMemcpyDeviceToHost));
+    }
+    HFr a = ctx->h_result[0], c = ctx->h_result[1], p1 = ctx->h_result[2];
+    put(out_abc, a);
+    put(out_abc + 4, p1 - a - c);
+    put(out_abc + 8, c);
+    *n_out = nn;
+    return ZK_OK;
+}
+
+// ---- micro-benchmarks (device resident, HIP events on the context's stream) ----
+template <class Launch>
+static int32_t time_launches(zk_ctx *ctx, uint32_t iters, double *sec, Launch launch) {
+    hipEvent_t e0, e1;
+    ZK_HIP(hipEventCreate(&e0));
+    ZK_HIP(hipEventCreate(&e1));
+    launch();                                   // warm-up
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_HIP(hipEventRecord(e0, ctx->stream));
+    for (uint32_t i = 0; i < iters; ++i) launch();
+    ZK_HIP(hipEventRecord(e1, ctx->stream));
+    ZK_HIP(hipEventSynchronize(e1));
+    ZK_HIP(hipGetLastError());
+    float ms = 0;
+    ZK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *sec = (double) ms * 1e-3 / iters;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_bench_fr_mul(zk_ctx *ctx, uint64_t n_threads, uint32_t muls_per_thread, uint32_t iters, double *sec) {
+    CHECK_CTX();
+    int32_t rc = zk_scratch(ctx, 2 * n_threads * 32);
+    if (rc) return rc;
+    int lg = 0;
+    while ((2ull << lg) <= n_threads) ++lg;
+    std::vector<HFr> r(lg, HFr(0x1234567LL));
+    for (int i = 0; i < lg; ++i) r[i] = r[i] * HFr((long long) (i * 7919 + 3)) + HFr(0x9e3779b9LL);
+    ZK_HIP(hipMemsetAsync(ctx->scratch.p, 0, 2 * n_threads * 32, ctx->stream));
+    if ((rc = eq_table1(ctx, (fr_t *) ctx->scratch.p, lg, r.data(), HFr(77LL)))) return rc;
+    const uint32_t blocks = (uint32_t) ((n_threads + ZK_BLOCK - 1) / ZK_BLOCK);
+    return time_launches(ctx, iters, sec, [&] {
+        hipLaunchKernelGGL(k_bench_fr_mul, dim3(blocks), dim3(ZK_BLOCK), 0, ctx->stream, (fr_t *) ctx->scratch.p, muls_per_thread,
+                           n_threads);
+    });
+}
+
+extern "C" int32_t zk_bench_copy(zk_ctx *ctx, uint64_t bytes, uint32_t iters, double *sec) {
+    CHECK_CTX();
+    int32_t rc = zk_scratch(ctx, 2 * bytes);
+    if (rc) return rc;
+    uint4 *src = (uint4 *) ctx->scratch.p, *dst = src + bytes / 16;
+    ZK_HIP(hipMemsetAsync(src, 1, bytes, ctx->stream));
+    return time_launches(ctx, iters, sec, [&] {
+        hipLaunchKernelGGL(k_bench_copy, dim3(4096), dim3(ZK_BLOCK), 0, ctx->stream, dst, src, bytes / 16);
+    });
+}
+
+// The dominant kernel of the FFT-conv configs in isolation: one non-first quadratic round on two
+// 2^log_n-entry tables of pseudo-random elements. Algorithmic bytes = 96 * 2^log_n.
+extern "C" int32_t zk_bench_round_quadratic(zk_ctx *ctx, uint32_t log_n, uint32_t iters, double *sec_per_launch,
+                                            double *algorithmic_bytes) {
+    CHECK_CTX();
+    if (log_n < 2 || log_n > 28) return ZK_ERR_ARG;
+    const uint64_t n = 1ull << log_n;
+    int32_t rc = zk_scratch(ctx, 3 * n * 32);
+    if (rc) return rc;
+    fr_t *dV = (fr_t *) ctx->scratch.p, *dM = dV + n, *dO = dM + n;
+    // fill with field elements: eq tables of a fixed point are as good as random for timing purposes
+    std::vector<HFr> r(log_n);
+    zkff::Xoshiro g;
+    g.seed(0x5EED0002ULL);
+    for (auto &x : r) {
+        uint64_t t[4] = {g.next(), g.next(), g.next(), g.next() & 0x3fffffffffffffffULL};
+        x = HFr(zkff::MontField<zkff::FrParams>::fromCanonical(t));
+    }
+    if ((rc = eq_table1(ctx, dV, (int) log_n, r.data(), HFr(7LL)))) return rc;
+    if ((rc = eq_table1(ctx, dM, (int) log_n, r.data(), HFr(11LL)))) return rc;
+    const uint32_t gsz = std::min<uint32_t>(grid_for(n / 4, 1024), ctx->partial_blocks);
+    *algorithmic_bytes = 96.0 * (double) n;
+    return time_launches(ctx, iters, sec_per_launch, [&] {
+        hipLaunchKernelGGL(k_round_quad, dim3(gsz), dim3(ZK_BLOCK), 0, ctx->stream, dV, dM, dO, dO + n / 2, n, to_dev(r[0]), 0,
+                           ctx->partials);
+    });
+}

@@ -1,0 +1,51 @@
+// C entry points of libzkcnn_host.so (include/zkcnn_api.h): circuit + witness on the host, the
+// prover on the GPU, the reference verifier driving it.
+#include "session.hpp"
+#include "verifier_alias.hpp"
+
+struct gpuSession : public sessionT<prover> {
+    explicit gpuSession(int device) : dev(device) {}
+    int dev;
+};
+
+extern "C" {
+
+void *zkcnn_session_create(const zkcnn_model_desc *desc, int32_t device) {
+    if (!desc) return nullptr;
+    try {
+        gpuSession *s = new gpuSession(device);
+        // placement-new the prover on the requested device: sessionT owns a default-constructed one
+        s->p.~prover();
+        new (&s->p) prover(device);
+        if (!s->build(desc)) { delete s; return nullptr; }
+        s->p.init();                 // residency: circuit + witness to HBM, outside any timed region
+        return s;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkcnn_session_create: %s\n", e.what());
+        return nullptr;
+    }
+}
+
+int32_t zkcnn_session_prove(void *session, uint64_t seed, uint32_t mode, uint8_t *transcript, uint64_t cap, zkcnn_result *out) {
+    if (!session || !out) return -1;
+    gpuSession *s = (gpuSession *) session;
+    try {
+        int rc = s->prove(seed, mode, transcript, cap, out);
+        out->upload_s = s->p.uploadTime();
+        return rc;
+    } catch (const std::exception &e) {
+        std::memset(out, 0, sizeof(*out));
+        std::snprintf(out->message, sizeof(out->message), "%s", e.what());
+        return -2;
+    }
+}
+
+void zkcnn_session_destroy(void *session) { delete (gpuSession *) session; }
+
+int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap) {
+    if (!session || !cap) return -1;
+    std::snprintf(buf, cap, "%s", ((gpuSession *) session)->row.c_str());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+#include "polyProver.hpp"
+#include <stdexcept>
+#include <string>
+
+namespace hyrax_bls12_381 {
+
+static void must(zk_ctx *ctx, int rc, const char *what) {
+    if (rc != ZK_OK) throw std::runtime_error(std::string(what) + ": " + zk_last_error(ctx));
+}
+static G1 fromABI(const uint64_t *p) {
+    G1Affine a;
+    std::memcpy(&a, p, 96);
+    return G1::fromAffine(a);
+}
+
+polyProver::polyProver(zk_ctx *c, int bit_length, const std::vector<G1> &gens) : ctx(c), ps_bytes(0) {
+    pt.start();
+    const int rb = bit_length >> 1;
+    const size_t rows = (size_t) 1 << rb;
+    std::vector<G1Affine> ga;
+    zkff::batchToAffine(gens, ga);
+    std::vector<uint64_t> out(rows * 12);
+    must(ctx, zk_commit_input(ctx, reinterpret_cast<const uint64_t *>(ga.data()), ga.size(), out.data(), rows), "zk_commit_input");
+    comm.resize(rows);
+    for (size_t i = 0; i < rows; ++i) comm[i] = fromABI(&out[i * 12]);
+    ps_bytes += rows * 48;
+    pt.stop();
+}
+
+void polyProver::openInit(const std::vector<Fr> &x) {
+    pt.start();
+    must(ctx, zk_hyrax_open_init(ctx, reinterpret_cast<const uint64_t *>(x.data()), (uint32_t) x.size()), "zk_hyrax_open_init");
+    pt.stop();
+}
+
+ipaRoundMsg polyProver::openRound() {
+    pt.start();
+    uint64_t L[12], R[12];
+    ipaRoundMsg m;
+    must(ctx, zk_hyrax_open_round(ctx, L, R, reinterpret_cast<uint64_t *>(&m.yL), reinterpret_cast<uint64_t *>(&m.yR)),
+         "zk_hyrax_open_round");
+    m.L = fromABI(L);
+    m.R = fromABI(R);
+    ps_bytes += 2 * 48 + 2 * 32;
+    pt.stop();
+    return m;
+}
+
+void polyProver::openFold(const Fr &c) {
+    pt.start();
+    must(ctx, zk_hyrax_open_fold(ctx, reinterpret_cast<const uint64_t *>(&c)), "zk_hyrax_open_fold");
+    pt.stop();
+}
+
+Fr polyProver::openFinal() {
+    pt.start();
+    Fr a;
+    must(ctx, zk_hyrax_open_final(ctx, reinterpret_cast<uint64_t *>(&a)), "zk_hyrax_open_final");
+    ps_bytes += 32;
+    pt.stop();
+    return a;
+}
+
+} // namespace hyrax_bls12_381

@@ -1,0 +1,29 @@
+// hyrax_bls12_381::polyProver -- the commitment prover the reference constructs in
+// prover::commitInput (reference src/prover.cpp:509, `polyProver(val[0], gens)`), here backed by the
+// HIP multi-scalar-multiplication kernels through include/zkcnn_hip.h. The witness already lives
+// in HBM (prover::init uploaded it), so the constructor takes the context instead of the vector.
+#pragma once
+#include <hyrax-bls12-381/polyCommit.hpp>
+#include "../../../include/zkcnn_hip.h"
+
+namespace hyrax_bls12_381 {
+
+class polyProver : public polyProverBase {
+public:
+    polyProver(zk_ctx *ctx, int bit_length, const std::vector<G1> &gens);
+    const std::vector<G1> &commitment() const override { return comm; }
+    void openInit(const std::vector<Fr> &x) override;
+    ipaRoundMsg openRound() override;
+    void openFold(const Fr &c) override;
+    Fr openFinal() override;
+    double getPT() const override { return pt.elapse_sec(); }
+    double getPS() const override { return (double) ps_bytes / 1024.0; }
+
+private:
+    zk_ctx *ctx;
+    std::vector<G1> comm;
+    timer pt;
+    unsigned long long ps_bytes;
+};
+
+} // namespace hyrax_bls12_381

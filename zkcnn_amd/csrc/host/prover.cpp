@@ -1,0 +1,176 @@
+#include "prover.hpp"
+#include <stdexcept>
+
+static_assert(sizeof(uniGate) == sizeof(zk_uni_gate), "uniGate layout must match the C-ABI record");
+static_assert(sizeof(binGate) == sizeof(zk_bin_gate), "binGate layout must match the C-ABI record");
+static_assert(sizeof(F) == 32, "Fr must be 4 x u64 Montgomery limbs");
+
+static inline const uint64_t *U(const F &x) { return reinterpret_cast<const uint64_t *>(&x); }
+static inline uint64_t *U(F &x) { return reinterpret_cast<uint64_t *>(&x); }
+
+prover::prover() : ctx(nullptr), device_id(0), resident(false) {}
+prover::prover(int device) : ctx(nullptr), device_id(device), resident(false) {}
+prover::~prover() {
+    poly_p.reset();
+    if (ctx) zk_ctx_destroy(ctx);
+}
+
+void prover::check(int rc, const char *what) const {
+    if (rc != ZK_OK) throw std::runtime_error(string(what) + " failed: " + zk_last_error(ctx));
+}
+
+void prover::ensureContext() {
+    if (ctx) return;
+    int rc = zk_ctx_create(device_id, &ctx);
+    if (rc != ZK_OK) {
+        ctx = nullptr;
+        throw std::runtime_error(string("zkCNN HIP prover needs an MI355X-class GPU: ") + zk_last_error(nullptr));
+    }
+}
+
+// prover::init (reference src/prover.cpp:17-21) + residency of C and val in HBM
+void prover::init() {
+    ensureContext();
+    if (!resident) {
+        upload_timer.start();
+        // a context holds one circuit; a changed circuit gets a fresh one
+        static_assert(sizeof(layerType) == sizeof(int), "layerType is passed as int32");
+        vector<zk_layer_desc> desc(C.size);
+        for (int i = 0; i < C.size; ++i) {
+            const layer &L = C.circuit[i];
+            zk_layer_desc &d = desc[i];
+            std::memset(&d, 0, sizeof(d));
+            d.ty = (int32_t) L.ty;
+            d.size = L.size;
+            for (int b = 0; b < 2; ++b) {
+                d.size_u[b] = L.size_u[b]; d.size_v[b] = L.size_v[b];
+                d.bit_length_u[b] = L.bit_length_u[b]; d.bit_length_v[b] = L.bit_length_v[b];
+            }
+            d.bit_length = L.bit_length;
+            d.max_bl_u = L.max_bl_u; d.max_bl_v = L.max_bl_v;
+            d.fft_bit_length = L.fft_bit_length;
+            d.need_phase2 = L.need_phase2;
+            d.zero_start_id = L.zero_start_id;
+            std::memcpy(d.scale, &L.scale, 32);
+            // layer 0 only carries identity gates that the sumcheck never walks
+            d.uni_gates = i ? reinterpret_cast<const zk_uni_gate *>(L.uni_gates.data()) : nullptr;
+            d.n_uni = i ? L.uni_gates.size() : 0;
+            d.bin_gates = i ? reinterpret_cast<const zk_bin_gate *>(L.bin_gates.data()) : nullptr;
+            d.n_bin = i ? L.bin_gates.size() : 0;
+            d.ori_id_u = L.ori_id_u.data();
+            d.ori_id_v = L.ori_id_v.data();
+        }
+        if (zk_upload_circuit(ctx, desc.data(), C.size, U(C.two_mul[0]), (int) C.two_mul.size()) != ZK_OK) {
+            // the context already holds another circuit: start over with a new one
+            string first_err = zk_last_error(ctx);
+            poly_p.reset();
+            zk_ctx_destroy(ctx);
+            ctx = nullptr;
+            ensureContext();
+            if (zk_upload_circuit(ctx, desc.data(), C.size, U(C.two_mul[0]), (int) C.two_mul.size()) != ZK_OK)
+                throw std::runtime_error("zk_upload_circuit failed: " + string(zk_last_error(ctx)) + " / " + first_err);
+        }
+        for (int i = 0; i < C.size; ++i)
+            check(zk_upload_layer_values(ctx, i, val[i].empty() ? nullptr : U(val[i][0]), val[i].size()), "zk_upload_layer_values");
+        resident = true;
+        upload_timer.stop();
+    }
+    prove_timer.clear();
+    check(zk_prover_init(ctx), "zk_prover_init");
+}
+
+double prover::proofSize() const { return ctx ? (double) zk_proof_bytes(ctx) / 1024.0 : 0.0; }
+
+void prover::sumcheckInitAll(const vector<F>::const_iterator &r_0_from_v) {
+    prove_timer.start();
+    check(zk_sumcheck_init_all(ctx, U(*r_0_from_v), (u32) C.circuit[C.size - 1].bit_length), "zk_sumcheck_init_all");
+    prove_timer.stop();
+}
+void prover::sumcheckInit(const F &alpha_0, const F &beta_0) {
+    prove_timer.start();
+    check(zk_sumcheck_init(ctx, U(alpha_0), U(beta_0)), "zk_sumcheck_init");
+    prove_timer.stop();
+}
+void prover::sumcheckDotProdInitPhase1() {
+    prove_timer.start();
+    check(zk_sumcheck_dotprod_init_phase1(ctx), "zk_sumcheck_dotprod_init_phase1");
+    prove_timer.stop();
+}
+void prover::sumcheckInitPhase1(const F &relu_rou_0) {
+    prove_timer.start();
+    check(zk_sumcheck_init_phase1(ctx, U(relu_rou_0)), "zk_sumcheck_init_phase1");
+    prove_timer.stop();
+}
+void prover::sumcheckInitPhase2() {
+    prove_timer.start();
+    check(zk_sumcheck_init_phase2(ctx), "zk_sumcheck_init_phase2");
+    prove_timer.stop();
+}
+cubic_poly prover::sumcheckDotProdUpdate1(const F &previous_random) {
+    prove_timer.start();
+    F o[4];
+    check(zk_sumcheck_dotprod_update1(ctx, U(previous_random), U(o[0])), "zk_sumcheck_dotprod_update1");
+    prove_timer.stop();
+    return cubic_poly(o[0], o[1], o[2], o[3]);
+}
+quadratic_poly prover::sumcheckUpdate1(const F &previous_random) {
+    prove_timer.start();
+    F o[3];
+    check(zk_sumcheck_update1(ctx, U(previous_random), U(o[0])), "zk_sumcheck_update1");
+    prove_timer.stop();
+    return quadratic_poly(o[0], o[1], o[2]);
+}
+quadratic_poly prover::sumcheckUpdate2(const F &previous_random) {
+    prove_timer.start();
+    F o[3];
+    check(zk_sumcheck_update2(ctx, U(previous_random), U(o[0])), "zk_sumcheck_update2");
+    prove_timer.stop();
+    return quadratic_poly(o[0], o[1], o[2]);
+}
+F prover::Vres(const vector<F>::const_iterator &r, u32 output_size, u8 r_size) {
+    prove_timer.start();
+    F out;
+    F dummy = F_ZERO;
+    check(zk_vres(ctx, r_size ? U(*r) : U(dummy), output_size, r_size, U(out)), "zk_vres");
+    prove_timer.stop();
+    return out;
+}
+void prover::sumcheckDotProdFinalize1(const F &previous_random, F &claim_1) {
+    prove_timer.start();
+    check(zk_sumcheck_dotprod_finalize1(ctx, U(previous_random), U(claim_1)), "zk_sumcheck_dotprod_finalize1");
+    prove_timer.stop();
+}
+void prover::sumcheckFinalize1(const F &previous_random, F &claim_0, F &claim_1) {
+    prove_timer.start();
+    check(zk_sumcheck_finalize1(ctx, U(previous_random), U(claim_0), U(claim_1)), "zk_sumcheck_finalize1");
+    prove_timer.stop();
+}
+void prover::sumcheckFinalize2(const F &previous_random, F &claim_0, F &claim_1) {
+    prove_timer.start();
+    check(zk_sumcheck_finalize2(ctx, U(previous_random), U(claim_0), U(claim_1)), "zk_sumcheck_finalize2");
+    prove_timer.stop();
+}
+void prover::sumcheckLiuFinalize(const F &previous_random, F &claim_1) {
+    prove_timer.start();
+    check(zk_sumcheck_liu_finalize(ctx, U(previous_random), U(claim_1)), "zk_sumcheck_liu_finalize");
+    prove_timer.stop();
+}
+void prover::sumcheckLiuInit(const vector<F> &s_u, const vector<F> &s_v) {
+    prove_timer.start();
+    check(zk_sumcheck_liu_init(ctx, U(s_u[0]), U(s_v[0]), (u32) s_u.size()), "zk_sumcheck_liu_init");
+    prove_timer.stop();
+}
+quadratic_poly prover::sumcheckLiuUpdate(const F &previous_random) {
+    prove_timer.start();
+    F o[3];
+    check(zk_sumcheck_liu_update(ctx, U(previous_random), U(o[0])), "zk_sumcheck_liu_update");
+    prove_timer.stop();
+    return quadratic_poly(o[0], o[1], o[2]);
+}
+
+// reference src/prover.cpp:503-511. The HBM copy of val[0] is already zero padded to 2^bit_length.
+hyrax_bls12_381::polyProverBase &prover::commitInput(const vector<G> &gens) {
+    if (!ctx || !resident) throw std::runtime_error("prover::commitInput before prover::init");
+    poly_p.reset(new hyrax_bls12_381::polyProver(ctx, C.circuit[0].bit_length, gens));
+    return *poly_p;
+}

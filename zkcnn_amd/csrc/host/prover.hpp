@@ -1,0 +1,73 @@
+// GKR prover with the reference's public interface (reference src/prover.hpp:18-49: same method
+// names, argument meaning, return types, public data members C / val / prove_timer), implemented on
+// the GPU: every method forwards to the C-ABI of include/zkcnn_hip.h (libzkcnn_hip.so). There is
+// no CPU implementation behind it -- if the HIP library or a GPU is missing the calls throw.
+//
+// Differences a reference user sees: init() uploads C and val to HBM the first time it runs
+// (residency; timed separately as uploadTime(), not prover time), and commitInput() returns the
+// abstract polyProverBase& the verifier needs instead of the concrete class.
+#pragma once
+#include <memory>
+#include "circuit.h"
+#include "polynomial.h"
+#include "polyProver.hpp"
+
+class neuralNetwork;
+
+class prover {
+public:
+    prover();
+    explicit prover(int device);
+    ~prover();
+    prover(const prover &) = delete;
+    prover &operator=(const prover &) = delete;
+
+    void init();
+
+    void sumcheckInitAll(const vector<F>::const_iterator &r_0_from_v);
+    void sumcheckInit(const F &alpha_0, const F &beta_0);
+    void sumcheckDotProdInitPhase1();
+    void sumcheckInitPhase1(const F &relu_rou_0);
+    void sumcheckInitPhase2();
+
+    cubic_poly sumcheckDotProdUpdate1(const F &previous_random);
+    quadratic_poly sumcheckUpdate1(const F &previous_random);
+    quadratic_poly sumcheckUpdate2(const F &previous_random);
+
+    F Vres(const vector<F>::const_iterator &r, u32 output_size, u8 r_size);
+
+    void sumcheckDotProdFinalize1(const F &previous_random, F &claim_1);
+    void sumcheckFinalize1(const F &previous_random, F &claim_0, F &claim_1);
+    void sumcheckFinalize2(const F &previous_random, F &claim_0, F &claim_1);
+    void sumcheckLiuFinalize(const F &previous_random, F &claim_1);
+
+    void sumcheckLiuInit(const vector<F> &s_u, const vector<F> &s_v);
+    quadratic_poly sumcheckLiuUpdate(const F &previous_random);
+
+    hyrax_bls12_381::polyProverBase &commitInput(const vector<G> &gens);
+
+    timer prove_timer;
+    double proveTime() const { return prove_timer.elapse_sec(); }
+    double proofSize() const;                         // KB
+    double polyProverTime() const { return poly_p ? poly_p->getPT() : 0.0; }
+    double polyProofSize() const { return poly_p ? poly_p->getPS() : 0.0; }
+    double uploadTime() const { return upload_timer.elapse_sec(); }
+
+    layeredCircuit C;
+    vector<vector<F>> val;        // the output of each gate (host copy; the GPU works on its HBM copy)
+
+    // call after C / val changed on the host to force a fresh upload at the next init()
+    void invalidateDevice() { resident = false; }
+    int device() const { return device_id; }
+
+private:
+    void ensureContext();
+    void check(int rc, const char *what) const;
+
+    zk_ctx *ctx;
+    int device_id;
+    bool resident;
+    timer upload_timer;
+    std::unique_ptr<hyrax_bls12_381::polyProver> poly_p;
+    friend neuralNetwork;
+};
