@@ -25,6 +25,7 @@ typedef struct {
 #define ZKCNN_MODE_VERIFY      0u  /* full verifier (reference behaviour) */
 #define ZKCNN_MODE_DRIVE_ONLY  1u  /* same challenges and prover calls, verifier checks skipped */
 #define ZKCNN_MODE_REUSE_GENS  2u  /* keep the session's commitment generators instead of drawing new ones */
+#define ZKCNN_MODE_TAMPER      4u  /* test hook: the verifier corrupts message number (mode >> 8) before checking it */
 
 typedef struct {
     int32_t accepted;          /* 1 = "Verification pass" + Hyrax opening ok, 0 = rejected, -1 = not checked */
@@ -32,6 +33,8 @@ typedef struct {
     uint64_t input_size;       /* layer-0 size (witness size column) */
     int32_t input_bits;
     int32_t n_rounds;          /* prover round-polynomial calls */
+    int32_t n_messages;        /* sumcheck-phase messages received (round polynomials + claims); commitment messages follow */
+    int32_t reserved_;
     double prove_s;            /* prover::proveTime()            (column PT) */
     double poly_prove_s;       /* prover::polyProverTime()       (column POLY_PT); TOT_PT = sum of the two */
     double verify_s;           /* verifier time                  (column VT) */
@@ -54,6 +57,10 @@ int32_t zkcnn_session_prove(void *session, uint64_t challenge_seed, uint32_t mod
 void zkcnn_session_destroy(void *session);
 /* The reference CLI's 16-column result row of the last prove call ("a, b, c, ..."), NUL terminated. */
 int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap);
+
+/* Product library only: HIP-event profiler of the GPU kernels (see zk_profile_enable / zk_profile_report in zkcnn_hip.h). */
+int32_t zkcnn_session_profile(void *session, uint32_t class_mask);
+int32_t zkcnn_session_profile_report(void *session, char *buf, uint64_t cap, int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,13 @@ int32_t zk_hyrax_open_round(zk_ctx *ctx, uint64_t L[12], uint64_t R[12], uint64_
 int32_t zk_hyrax_open_fold(zk_ctx *ctx, const uint64_t c[4]);
 int32_t zk_hyrax_open_final(zk_ctx *ctx, uint64_t a[4]);
 
+/* ---- built-in profiler: HIP events around every launch of the selected kernel classes, on the context's stream ---- */
+/* class_mask: bit i selects class i of zk_profile_report's list; 0 switches profiling off; ~0u selects all */
+int32_t zk_profile_enable(zk_ctx *ctx, uint32_t class_mask);
+/* drains pending events and writes a JSON object {"class": {"ms": total, "launches": n, "bytes": algorithmic}, ...};
+ * reset != 0 clears the counters afterwards */
+int32_t zk_profile_report(zk_ctx *ctx, char *buf, uint64_t cap, int32_t reset);
+
 /* ---- kernel-level entry points (host arrays in/out; used by the parity tests and the micro-benches) ---- */
 int32_t zk_k_fr_mul(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n);
 int32_t zk_k_fr_add(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n);

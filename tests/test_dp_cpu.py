@@ -1,0 +1,68 @@
+"""The N > 1 path on CPU: world_size 2 over gloo. Each rank proves its shard of a batch with the CPU oracle
+standing in for the GPU prover (the sharding / packing / gather code is the product's zkcnn_amd.dp)."""
+import hashlib
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from zkcnn_amd import dp
+
+MODEL, PIC = "custom:C2:3:1:s M F4", (4, 4, 1)
+
+
+def test_shard_covers_every_image_once():
+    for n in (1, 2, 7, 8, 32):
+        for world in (1, 2, 3, 8):
+            ids = sum((dp.shard(n, world, r) for r in range(world)), [])
+            assert ids == list(range(n))
+            sizes = [len(dp.shard(n, world, r)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_roundtrip():
+    items = [(3, b"abc"), (0, b""), (9, bytes(range(200)))]
+    assert dp.unpack(dp.pack(items)) == items
+
+
+def _session(img):
+    from tests import oracle_ffi
+    return oracle_ffi.OracleSession(MODEL, PIC, 1, data_seed=1000 + img)
+
+
+def _worker(rank, world, port, n_images, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local, stats = dp.prove_images(_session, dp.shard(n_images, world, rank), challenge_seed=77)
+    assert all(s.accepted == 1 for s in stats)
+    allp = dp.gather_proofs(local, dist, "cpu")
+    if rank == 0:
+        q.put([(i, hashlib.sha256(t).hexdigest()) for i, t in allp])
+    else:
+        assert allp is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gather_equals_single_process(oracle):
+    n_images = 5
+    single, _ = dp.prove_images(_session, list(range(n_images)), challenge_seed=77)
+    want = [(i, hashlib.sha256(t).hexdigest()) for i, t in single]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_images, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == want
+    assert len({h for _, h in got}) == n_images          # different pictures give different proofs

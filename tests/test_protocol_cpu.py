@@ -1,0 +1,82 @@
+"""The CPU oracle prover against the verifier: acceptance on every layer type, determinism, sensitivity to the
+challenge stream, and the committed golden transcript hashes (tests/golden/transcripts.json, made by
+tests/golden/make_golden.py from THIS repo's oracle -- the reference itself cannot be built here)."""
+import hashlib
+import json
+import os
+
+import pytest
+
+from tests import oracle_ffi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = json.load(open(os.path.join(HERE, "golden", "transcripts.json")))
+
+SMALL = [
+    ("custom:F4", (4, 4, 1), 1),
+    ("custom:C2:3:1:s M F4", (4, 4, 1), 1),
+    ("custom:C2:3:1:n A F4", (4, 4, 2), 1),
+    ("custom:C2:3:1:f M F4", (8, 8, 1), 2),
+    ("custom:C2:3:0:f C3:3:1:f M C2:3:1:s A F5 F3", (10, 10, 2), 2),
+]
+
+
+@pytest.mark.parametrize("model,pic,pp", SMALL)
+def test_oracle_proofs_accepted_and_deterministic(oracle, model, pic, pp):
+    with oracle_ffi.OracleSession(model, pic, pp) as o:
+        r1, t1 = o.prove(seed=1)
+        r2, t2 = o.prove(seed=1)
+        r3, t3 = o.prove(seed=2)
+    assert r1.accepted == 1 and r2.accepted == 1 and r3.accepted == 1
+    assert t1 == t2 and t1 != t3
+    assert r1.transcript_len == len(t1) and r1.n_rounds > 0
+    # proof-size counter = 32 B per field element the prover returned (reference src/prover.cpp:137,152,381,...)
+    assert r1.proof_kb > 0 and r1.poly_proof_kb > 0
+
+
+@pytest.mark.parametrize("key", sorted(GOLDEN))
+def test_golden_transcripts(oracle, key):
+    g = GOLDEN[key]
+    with oracle_ffi.OracleSession(g["model"], tuple(g["pic"]), g["pic_cnt"], data_seed=g["data_seed"]) as o:
+        res, tr = o.prove(seed=g["challenge_seed"])
+    assert res.accepted == 1
+    assert res.n_layers == g["n_layers"] and res.input_size == g["input_size"] and res.n_rounds == g["n_rounds"]
+    assert len(tr) == g["transcript_len"]
+    assert hashlib.sha256(tr).hexdigest() == g["sha256"]
+
+
+def test_drive_only_makes_the_same_calls(oracle):
+    import zkcnn_amd
+    with oracle_ffi.OracleSession("custom:C2:3:1:f M F4", (8, 8, 1), 2) as o:
+        full, t_full = o.prove(seed=9)
+        drv, t_drv = o.prove(seed=9, mode=zkcnn_amd.MODE_DRIVE_ONLY)
+        reuse, t_reuse = o.prove(seed=9, mode=zkcnn_amd.MODE_REUSE_GENS)
+    assert full.accepted == 1 and drv.accepted == -1 and t_full == t_drv
+    assert reuse.accepted == 1 and t_reuse != t_full            # other generators => other commitments
+
+
+def test_result_row_has_the_reference_columns(oracle):
+    with oracle_ffi.OracleSession("custom:F8 F4", (4, 4, 1), 1) as o:
+        o.prove(seed=3)
+        cols = [c.strip() for c in o.row().split(",")]
+    assert len(cols) >= 16 and cols[0] == "custom:F8 F4" and cols[3] == "1"
+    assert cols[6].endswith(")") and "(2^" in cols[6]            # witness size column, e.g. 340(2^9)
+    for i in (7, 9, 10, 12, 13, 15):                               # times / sizes are filled
+        float(cols[i])
+
+
+def test_verifier_rejects_any_corrupted_message(oracle):
+    """soundness smoke test: perturbing ANY single prover message (round polynomial, claim, opening message)
+    must make the verifier reject (SURVEY.md 8(c) known-answer list)"""
+    import zkcnn_amd
+    with oracle_ffi.OracleSession("custom:C2:3:1:f M F4", (8, 8, 1), 2) as o:
+        ok, _ = o.prove(seed=11)
+        assert ok.accepted == 1
+        n_sum, cb = ok.n_messages, ok.input_bits - ok.input_bits // 2
+        total = n_sum + cb + 1
+        picks = sorted(set(list(range(0, total, 7)) + [0, 1, n_sum - 1, n_sum, total - 2, total - 1]))
+        for k in picks:
+            bad, _ = o.prove(seed=11, mode=zkcnn_amd.MODE_TAMPER | (k << 8))
+            assert bad.accepted == 0, f"message {k} of {total} corrupted but accepted"
+        again, _ = o.prove(seed=11, mode=zkcnn_amd.MODE_TAMPER | ((total + 5) << 8))     # out of range: nothing touched
+        assert again.accepted == 1

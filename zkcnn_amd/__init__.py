@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(ROOT, "zkcnn_amd", "lib")
 R_MOD = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 P_MOD = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 
-MODE_VERIFY, MODE_DRIVE_ONLY, MODE_REUSE_GENS = 0, 1, 2
+MODE_VERIFY, MODE_DRIVE_ONLY, MODE_REUSE_GENS, MODE_TAMPER = 0, 1, 2, 4
 
 
 class ModelDesc(ctypes.Structure):
@@ -28,7 +28,7 @@ class ModelDesc(ctypes.Structure):
 
 class Result(ctypes.Structure):
     _fields_ = [("accepted", ctypes.c_int32), ("n_layers", ctypes.c_int32), ("input_size", ctypes.c_uint64),
-                ("input_bits", ctypes.c_int32), ("n_rounds", ctypes.c_int32),
+                ("input_bits", ctypes.c_int32), ("n_rounds", ctypes.c_int32), ("n_messages", ctypes.c_int32), ("reserved_", ctypes.c_int32),
                 ("prove_s", ctypes.c_double), ("poly_prove_s", ctypes.c_double), ("verify_s", ctypes.c_double),
                 ("poly_verify_s", ctypes.c_double), ("proof_kb", ctypes.c_double), ("poly_proof_kb", ctypes.c_double),
                 ("witness_s", ctypes.c_double), ("upload_s", ctypes.c_double), ("wall_s", ctypes.c_double),
@@ -216,9 +216,33 @@ class _SessionBase:
         self.close()
 
 
+PROFILE_CLASSES = ["eq_table", "gather", "gate_reduce", "gate_fixup", "gate_sum", "sum_partials", "round_quad", "round_cubic", "fold",
+                   "matvec", "phi", "dot_prod", "liu_scatter", "msm_planes", "msm_finish", "msm_tables", "ipa", "misc"]
+
+
 class Session(_SessionBase):
     """Circuit + witness resident on one GPU; prove() runs verifier <-> HIP prover (include/zkcnn_api.h)."""
     _prefix = "zkcnn_"
 
     def __init__(self, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0):
         super().__init__(host_lib(), model, pic, pic_cnt, data_seed, device)
+
+    def profile(self, classes="all"):
+        """HIP-event timing of the selected kernel classes (list of names, "all", or None to switch off)"""
+        if classes is None:
+            mask = 0
+        elif classes == "all":
+            mask = 0xFFFFFFFF
+        else:
+            mask = sum(1 << PROFILE_CLASSES.index(c) for c in classes)
+        rc = self.lib.zkcnn_session_profile(ctypes.c_void_p(self.h), ctypes.c_uint32(mask))
+        if rc != 0:
+            raise RuntimeError("zkcnn_session_profile failed")
+
+    def profile_report(self, reset=True):
+        import json
+        buf = ctypes.create_string_buffer(8192)
+        rc = self.lib.zkcnn_session_profile_report(ctypes.c_void_p(self.h), buf, ctypes.c_uint64(8192), ctypes.c_int32(int(reset)))
+        if rc != 0:
+            raise RuntimeError("zkcnn_session_profile_report failed")
+        return json.loads(buf.value.decode())

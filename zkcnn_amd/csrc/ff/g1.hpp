@@ -118,6 +118,7 @@ public:
     G1Affine toAffine() const {
         G1Affine a;
         if (isInf()) { a.x.clear(); a.y.clear(); return a; }
+        if (Z == Fp::one()) { a.x = X; a.y = Y; return a; }       // already normalised (points that came in affine)
         Fp zi, zi2;
         Fp::invert(zi, Z);
         zi2 = zi * zi;

@@ -21,6 +21,7 @@ struct dev_layer {
     // phase-1 lists: gates whose u operand lives in table b (0: layer-0 subset, 1: previous layer), sorted by u
     gate_rec *p1[2] = {nullptr, nullptr};
     uint64_t n_p1[2] = {0, 0};
+    uint64_t n_p1_uni[2] = {0, 0};  // how many of them are uni gates (for the algorithmic byte count)
     // phase-2 lists: bin gates whose v operand lives in table b, sorted by v
     gate_rec *p2[2] = {nullptr, nullptr};
     uint64_t n_p2[2] = {0, 0};
@@ -44,6 +45,14 @@ struct table_pair {
 };
 
 struct msm_state;                  // hyrax.hip
+
+// kernel classes of the built-in profiler (HIP events on the context's stream)
+enum prof_class { PC_EQ = 0, PC_GATHER, PC_GATE, PC_GATE_FIX, PC_GATE_SUM, PC_SUM, PC_ROUND_QUAD, PC_ROUND_CUBIC, PC_FOLD, PC_MATVEC,
+                  PC_PHI, PC_DOT, PC_LIU, PC_MSM_PLANES, PC_MSM_FINISH, PC_MSM_TABLES, PC_IPA, PC_MISC, PC_COUNT };
+static const char *const prof_names[PC_COUNT] = {"eq_table", "gather", "gate_reduce", "gate_fixup", "gate_sum", "sum_partials", "round_quad",
+                                                 "round_cubic", "fold", "matvec", "phi", "dot_prod", "liu_scatter", "msm_planes",
+                                                 "msm_finish", "msm_tables", "ipa", "misc"};
+struct prof_pending { hipEvent_t e0, e1; int cls; double bytes; };
 
 struct zk_ctx {
     int device = 0;
@@ -83,7 +92,38 @@ struct zk_ctx {
     bool circuit_ready = false;
 
     msm_state *msm = nullptr;
+
+    // profiler: when a class bit is set in prof_mask every launch of that class is bracketed by events
+    uint32_t prof_mask = 0;
+    std::vector<prof_pending> prof_q;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[PC_COUNT] = {0};
+    double prof_bytes[PC_COUNT] = {0};
+    uint64_t prof_cnt[PC_COUNT] = {0};
 };
+
+static inline void prof_begin(zk_ctx *ctx, int cls, double bytes) {
+    if (!((ctx->prof_mask >> cls) & 1u)) return;
+    prof_pending p;
+    for (hipEvent_t *e : {&p.e0, &p.e1}) {
+        if (ctx->prof_pool.empty()) { if (hipEventCreate(e) != hipSuccess) return; }
+        else { *e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }
+    }
+    p.cls = cls;
+    p.bytes = bytes;
+    (void) hipEventRecord(p.e0, ctx->stream);
+    ctx->prof_q.push_back(p);
+}
+static inline void prof_end(zk_ctx *ctx, int cls) {
+    if (!((ctx->prof_mask >> cls) & 1u) || ctx->prof_q.empty()) return;
+    (void) hipEventRecord(ctx->prof_q.back().e1, ctx->stream);
+}
+#define ZK_LAUNCH(cls, bytes, kern, grid, block, ...)                                    \
+    do {                                                                                  \
+        prof_begin(ctx, cls, bytes);                                                      \
+        hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, __VA_ARGS__);               \
+        prof_end(ctx, cls);                                                               \
+    } while (0)
 
 #define ZK_HIP(call)                                                                           \
     do {                                                                                       \

@@ -215,7 +215,7 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
     if (rc) return rc;
     g1j_t *J = (g1j_t *) s->tbl_scratch;
     fp_t *pre = (fp_t *) (J + (size_t) (MSM_WINDOWS - 1) * m);
-    hipLaunchKernelGGL(k_window_tables, dim3((uint32_t) ((m + 63) / 64)), dim3(64), 0, ctx->stream, s->tables, J, pre, (uint32_t) m);
+    ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_window_tables, dim3((uint32_t) ((m + 63) / 64)), dim3(64), s->tables, J, pre, (uint32_t) m);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -239,11 +239,9 @@ static int32_t run_msm(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint
     // gridDim.z is limited to 65535 rows per launch
     for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
         const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
-        hipLaunchKernelGGL(k_msm_planes, dim3(nparts, MSM_PLANES, nr), dim3(256), 0, ctx->stream,
-                           s->partials + (size_t) r0 * MSM_PLANES * nparts, scalars + (size_t) r0 * ld, ld, idx, s->tables,
-                           (uint32_t) s->m, cols, cpt, wsplit);
+        ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, k_msm_planes, dim3(nparts, MSM_PLANES, nr), dim3(256), s->partials + (size_t) r0 * MSM_PLANES * nparts, scalars + (size_t) r0 * ld, ld, idx, s->tables, (uint32_t) s->m, cols, cpt, wsplit);
     }
-    hipLaunchKernelGGL(k_msm_finish, dim3(rows), dim3(64), 0, ctx->stream, s->rowsJ, s->partials, nparts);
+    ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_msm_finish, dim3(rows), dim3(64), s->rowsJ, s->partials, nparts);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -252,7 +250,7 @@ static int32_t run_msm(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint
 static int32_t fetch_points(zk_ctx *ctx, uint32_t rows, uint64_t *out) {
     msm_state *s = ctx->msm;
     if (rows > 8) {
-        hipLaunchKernelGGL(k_to_affine, dim3((rows + 63) / 64), dim3(64), 0, ctx->stream, s->rowsA, s->rowsJ, rows);
+        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_to_affine, dim3((rows + 63) / 64), dim3(64), s->rowsA, s->rowsJ, rows);
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipMemcpyAsync(out, s->rowsA, (size_t) rows * sizeof(g1a_t), hipMemcpyDeviceToHost, ctx->stream));
         ZK_HIP(hipStreamSynchronize(ctx->stream));
@@ -305,7 +303,7 @@ extern "C" int32_t zk_hyrax_open_init(zk_ctx *ctx, const uint64_t *x, uint32_t n
     if ((rc = zk_eq_table1_dev(ctx, s->Lrow, s->rb, xs + s->cb, HFr::one()))) return rc;
     if ((rc = zk_eq_table1_dev(ctx, s->b, s->cb, xs, HFr::one()))) return rc;
     if ((rc = zk_col_combine_dev(ctx, s->a, L0.val, s->Lrow, m, rows))) return rc;        // w = L^T Z
-    hipLaunchKernelGGL(k_fill, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, s->coef, to_dev(HFr::one()), m);
+    ZK_LAUNCH(PC_IPA, 0.0, k_fill, dim3((m + 255) / 256), dim3(256), s->coef, to_dev(HFr::one()), m);
     ZK_HIP(hipGetLastError());
     s->len = m;
     return ZK_OK;
@@ -316,9 +314,8 @@ extern "C" int32_t zk_hyrax_open_round(zk_ctx *ctx, uint64_t Lp[12], uint64_t Rp
     msm_state *s = ctx->msm;
     if (!s || s->len < 2) return ZK_ERR_STATE;
     const uint32_t m = 1u << s->cb, h = s->len >> 1;
-    hipLaunchKernelGGL(k_ipa_scalars, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, s->sL, s->idxL, s->sR, s->idxR, s->a, s->coef,
-                       m, s->len);
-    hipLaunchKernelGGL(k_ipa_dots, dim3(1), dim3(256), 0, ctx->stream, s->d_y, s->a, s->b, h);
+    ZK_LAUNCH(PC_IPA, 0.0, k_ipa_scalars, dim3((m + 255) / 256), dim3(256), s->sL, s->idxL, s->sR, s->idxR, s->a, s->coef, m, s->len);
+    ZK_LAUNCH(PC_IPA, 0.0, k_ipa_dots, dim3(1), dim3(256), s->d_y, s->a, s->b, h);
     ZK_HIP(hipGetLastError());
     // two MSMs over m/2 generators each, launched as two rows of one batch (row stride = m/2 scalars)
     // sL and sR are separate buffers; run them one after the other into rowsJ[0], rowsJ[1]
@@ -341,7 +338,7 @@ extern "C" int32_t zk_hyrax_open_fold(zk_ctx *ctx, const uint64_t c[4]) {
     msm_state *s = ctx->msm;
     if (!s || s->len < 2) return ZK_ERR_STATE;
     const uint32_t m = 1u << s->cb;
-    hipLaunchKernelGGL(k_ipa_fold, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, s->a, s->b, s->coef, to_dev(H(c)), m, s->len);
+    ZK_LAUNCH(PC_IPA, 0.0, k_ipa_fold, dim3((m + 255) / 256), dim3(256), s->a, s->b, s->coef, to_dev(H(c)), m, s->len);
     ZK_HIP(hipGetLastError());
     s->len >>= 1;
     return ZK_OK;

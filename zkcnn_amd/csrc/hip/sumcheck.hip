@@ -85,11 +85,48 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     zk_msm_destroy(ctx);
+    for (prof_pending &p : ctx->prof_q) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
+    for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
     for (void *p : ctx->owned) hipFree(p);
     if (ctx->scratch.p) hipFree(ctx->scratch.p);
     if (ctx->h_result) hipHostFree(ctx->h_result);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+extern "C" int32_t zk_profile_enable(zk_ctx *ctx, uint32_t class_mask) {
+    if (!ctx) return ZK_ERR_ARG;
+    ctx->prof_mask = class_mask;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_profile_report(zk_ctx *ctx, char *buf, uint64_t cap, int32_t reset) {
+    if (!ctx || !buf || !cap) return ZK_ERR_ARG;
+    ZK_HIP(hipSetDevice(ctx->device));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    for (prof_pending &p : ctx->prof_q) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            ctx->prof_ms[p.cls] += ms;
+            ctx->prof_bytes[p.cls] += p.bytes;
+            ++ctx->prof_cnt[p.cls];
+        }
+        ctx->prof_pool.push_back(p.e0);
+        ctx->prof_pool.push_back(p.e1);
+    }
+    ctx->prof_q.clear();
+    std::string js = "{";
+    for (int c = 0; c < PC_COUNT; ++c) {
+        char line[256];
+        std::snprintf(line, sizeof(line), "%s\"%s\": {\"ms\": %.6f, \"launches\": %llu, \"bytes\": %.0f}", c ? ", " : "", prof_names[c],
+                      ctx->prof_ms[c], (unsigned long long) ctx->prof_cnt[c], ctx->prof_bytes[c]);
+        js += line;
+    }
+    js += "}";
+    std::snprintf(buf, cap, "%s", js.c_str());
+    if (reset)
+        for (int c = 0; c < PC_COUNT; ++c) { ctx->prof_ms[c] = 0; ctx->prof_bytes[c] = 0; ctx->prof_cnt[c] = 0; }
+    return ZK_OK;
 }
 
 extern "C" const char *zk_last_error(const zk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
@@ -194,6 +231,7 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
             const uint32_t in_prev = g.lu != 0;
             gate_rec r = {g.g, g.u, 0, (uint32_t) g.sc};
             p[in_prev].push_back(r);
+            ++D.n_p1_uni[in_prev];
             gate_rec r2 = {g.g, 0, g.u, (uint32_t) g.sc | (in_prev << 10)};
             un.push_back(r2);
         }
@@ -273,10 +311,8 @@ static int32_t eq_table(zk_ctx *ctx, fr_t *out, int n, const HFr *r0, const HFr 
         ZK_HIP(hipMemsetAsync(out, 0, len * 32, ctx->stream));
         return ZK_OK;
     }
-    hipLaunchKernelGGL(k_eq_halves, dim3(1), dim3(1024), 0, ctx->stream, ctx->eq_lo, ctx->eq_hi, ctx->eq_stride,
-                       ctx->eq_stride, A);
-    hipLaunchKernelGGL(k_eq_expand, dim3(grid_for(len)), dim3(ZK_BLOCK), 0, ctx->stream, out, ctx->eq_lo, ctx->eq_hi,
-                       ctx->eq_stride, ctx->eq_stride, A.npoints, A.fh, len, tail_start, to_dev(tail_scale));
+    ZK_LAUNCH(PC_EQ, 0.0, k_eq_halves, dim3(1), dim3(1024), ctx->eq_lo, ctx->eq_hi, ctx->eq_stride, ctx->eq_stride, A);
+    ZK_LAUNCH(PC_EQ, 0.0, k_eq_expand, dim3(grid_for(len)), dim3(ZK_BLOCK), out, ctx->eq_lo, ctx->eq_hi, ctx->eq_stride, ctx->eq_stride, A.npoints, A.fh, len, tail_start, to_dev(tail_scale));
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -296,9 +332,9 @@ int32_t zk_col_combine_dev(zk_ctx *ctx, fr_t *out, const fr_t *Z, const fr_t *L,
     if (rc) return rc;
     fr_t *part = chunks == 1 ? out : (fr_t *) ctx->scratch.p;
     dim3 grid((cols + ZK_BLOCK - 1) / ZK_BLOCK, chunks);
-    hipLaunchKernelGGL(k_col_combine, grid, dim3(ZK_BLOCK), 0, ctx->stream, part, Z, L, cols, rows, per);
+    ZK_LAUNCH(PC_MATVEC, 0.0, k_col_combine, grid, dim3(ZK_BLOCK), part, Z, L, cols, rows, per);
     if (chunks > 1)
-        hipLaunchKernelGGL(k_sum_rows, dim3((cols + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), 0, ctx->stream, out, part, cols, chunks);
+        ZK_LAUNCH(PC_MATVEC, 0.0, k_sum_rows, dim3((cols + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), out, part, cols, chunks);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -310,9 +346,12 @@ static int32_t fetch_result(zk_ctx *ctx, int count) {
     return ZK_OK;
 }
 
+// algorithmic bytes of one scatter: per uni gate 12 B record + 32 B gather, per bin gate 16 B record
+// + 2 x 32 B gathers, + 32 B per output entry
 static int32_t gate_scatter(zk_ctx *ctx, fr_t *out, const gate_rec *recs, uint64_t n, int phase, const dev_layer &cur,
-                            const dev_layer &prev) {
+                            const dev_layer &prev, uint64_t n_uni_in_list, uint64_t out_len) {
     if (!n) return ZK_OK;
+    const double gate_bytes = 44.0 * (double) n_uni_in_list + 80.0 * (double) (n - n_uni_in_list) + 32.0 * (double) out_len;
     gate_args A;
     A.recs = recs;
     A.n = n;
@@ -327,9 +366,8 @@ static int32_t gate_scatter(zk_ctx *ctx, fr_t *out, const gate_rec *recs, uint64
     (void) cur;
     const uint32_t blocks = (uint32_t) ((n + ZK_BLOCK - 1) / ZK_BLOCK);
     if (2ull * blocks > ctx->carry_slots) { ctx->err = "carry buffer too small"; return ZK_ERR_STATE; }
-    hipLaunchKernelGGL(k_gate_reduce, dim3(blocks), dim3(ZK_BLOCK), 0, ctx->stream, out, ctx->carry_key, ctx->carry_val, A);
-    hipLaunchKernelGGL(k_gate_fixup, dim3(grid_for(2ull * blocks)), dim3(ZK_BLOCK), 0, ctx->stream, out, ctx->carry_key,
-                       ctx->carry_val, 2ull * blocks);
+    ZK_LAUNCH(PC_GATE, gate_bytes, k_gate_reduce, dim3(blocks), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, A);
+    ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup, dim3(grid_for(2ull * blocks)), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, 2ull * blocks);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -339,8 +377,7 @@ static int32_t load_v_table(zk_ctx *ctx, fr_t *dst, int b, int bl, uint32_t size
     if (bl < 0) return ZK_OK;
     const uint64_t len = 1ull << bl;
     if (b == 0) {
-        hipLaunchKernelGGL(k_gather, dim3(grid_for(len)), dim3(ZK_BLOCK), 0, ctx->stream, dst, ctx->L[0].val, ori,
-                           (uint64_t) size, len);
+        ZK_LAUNCH(PC_GATHER, 0.0, k_gather, dim3(grid_for(len)), dim3(ZK_BLOCK), dst, ctx->L[0].val, ori, (uint64_t) size, len);
         ZK_HIP(hipGetLastError());
     } else {
         const uint64_t have = std::min<uint64_t>(len, prev.val_len);
@@ -388,8 +425,7 @@ static int32_t phi_table(zk_ctx *ctx, fr_t *out, const HFr *rx, const HFr &scale
     const uint32_t cnt = inverse ? 1u << n : 1u << (n - 1);
     fr_vec R;
     for (int j = 0; j < vars; ++j) R.v[j] = to_dev(rx[j]);
-    hipLaunchKernelGGL(k_phi, dim3((cnt + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), 0, ctx->stream, out, pw, R, to_dev(scale),
-                       n, vars, cnt);
+    ZK_LAUNCH(PC_PHI, 0.0, k_phi, dim3((cnt + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), out, pw, R, to_dev(scale), n, vars, cnt);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -405,9 +441,9 @@ static int32_t strided_matvec(zk_ctx *ctx, fr_t *out, const fr_t *val, const fr_
     if (rc) return rc;
     fr_t *part = chunks == 1 ? out : (fr_t *) ctx->scratch.p;
     dim3 grid((len + ZK_BLOCK - 1) / ZK_BLOCK, chunks);
-    hipLaunchKernelGGL(k_strided_matvec, grid, dim3(ZK_BLOCK), 0, ctx->stream, part, val, beta, len, stride, cnt, per);
+    ZK_LAUNCH(PC_MATVEC, 0.0, k_strided_matvec, grid, dim3(ZK_BLOCK), part, val, beta, len, stride, cnt, per);
     if (chunks > 1)
-        hipLaunchKernelGGL(k_sum_rows, dim3((len + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), 0, ctx->stream, out, part, len, chunks);
+        ZK_LAUNCH(PC_MATVEC, 0.0, k_sum_rows, dim3((len + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), out, part, len, chunks);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -415,9 +451,9 @@ static int32_t strided_matvec(zk_ctx *ctx, fr_t *out, const fr_t *val, const fr_
 // folds table `b`'s V (and M if with_m) with r; len must be >= 2
 static int32_t fold_pair(zk_ctx *ctx, table_pair &t, const HFr &r, bool with_m) {
     const fr_t rr = to_dev(r);
-    hipLaunchKernelGGL(k_fold, dim3(grid_for(t.len / 2)), dim3(ZK_BLOCK), 0, ctx->stream, t.V[t.cur], t.V[t.cur ^ 1], t.len, rr);
+    ZK_LAUNCH(PC_FOLD, 0.0, k_fold, dim3(grid_for(t.len / 2)), dim3(ZK_BLOCK), t.V[t.cur], t.V[t.cur ^ 1], t.len, rr);
     if (with_m)
-        hipLaunchKernelGGL(k_fold, dim3(grid_for(t.len / 2)), dim3(ZK_BLOCK), 0, ctx->stream, t.M[t.cur], t.M[t.cur ^ 1], t.len, rr);
+        ZK_LAUNCH(PC_FOLD, 0.0, k_fold, dim3(grid_for(t.len / 2)), dim3(ZK_BLOCK), t.M[t.cur], t.M[t.cur ^ 1], t.len, rr);
     ZK_HIP(hipGetLastError());
     t.cur ^= 1;
     t.len >>= 1;
@@ -521,8 +557,7 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
         const int fft_blh = d.fft_bit_length - 1;
         if ((rc = eq_table1(ctx, ctx->beta_gs, fft_blh, ctx->r_0, HFr::one()))) return rc;
         fr_t *src = ctx->beta_g[ctx->beta_g_cur], *dst = ctx->beta_g[ctx->beta_g_cur ^ 1];
-        hipLaunchKernelGGL(k_outer_expand, dim3(grid_for(cur.val_len)), dim3(ZK_BLOCK), 0, ctx->stream, dst, src, ctx->beta_gs,
-                           fft_blh, cur.val_len);
+        ZK_LAUNCH(PC_EQ, 0.0, k_outer_expand, dim3(grid_for(cur.val_len)), dim3(ZK_BLOCK), dst, src, ctx->beta_gs, fft_blh, cur.val_len);
         ZK_HIP(hipGetLastError());
         ctx->beta_g_cur ^= 1;
         if (d.zero_start_id < d.size) { ctx->err = "PADDING layer with constraint rows is not supported"; return ZK_ERR_ARG; }
@@ -536,7 +571,7 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
         ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
-        if ((rc = gate_scatter(ctx, t.M[0], cur.p1[b], cur.n_p1[b], 1, cur, prev))) return rc;
+        if ((rc = gate_scatter(ctx, t.M[0], cur.p1[b], cur.n_p1[b], 1, cur, prev, cur.n_p1_uni[b], t.len))) return rc;
     }
     return ZK_OK;
 }
@@ -561,8 +596,7 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
     ZK_HIP(hipMemsetAsync(ctx->tp[0].V[0], 0, N * 32, ctx->stream));
     if (cur.d1_rows) {
         dim3 grid(((1u << fft_bl) + ZK_BLOCK - 1) / ZK_BLOCK, cur.d1_rows);
-        hipLaunchKernelGGL(k_dot_v0, grid, dim3(ZK_BLOCK), 0, ctx->stream, ctx->tp[0].V[0], prev.val, ctx->beta_g[ctx->beta_g_cur],
-                           cur.d1, cur.d1_rowptr, fft_bl);
+        ZK_LAUNCH(PC_DOT, 0.0, k_dot_v0, grid, dim3(ZK_BLOCK), ctx->tp[0].V[0], prev.val, ctx->beta_g[ctx->beta_g_cur], cur.d1, cur.d1_rowptr, fft_bl);
         ZK_HIP(hipGetLastError());
     }
     return ZK_OK;
@@ -576,8 +610,7 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
     if (!first) ctx->r_u[id].at(ctx->round - 1) = r;
     ++ctx->round;
     if (!first && ctx->small_len >= 2) {
-        hipLaunchKernelGGL(k_fold, dim3(grid_for(ctx->small_len / 2)), dim3(ZK_BLOCK), 0, ctx->stream, ctx->small[ctx->small_cur],
-                           ctx->small[ctx->small_cur ^ 1], (uint64_t) ctx->small_len, to_dev(r));
+        ZK_LAUNCH(PC_FOLD, 0.0, k_fold, dim3(grid_for(ctx->small_len / 2)), dim3(ZK_BLOCK), ctx->small[ctx->small_cur], ctx->small[ctx->small_cur ^ 1], (uint64_t) ctx->small_len, to_dev(r));
         ctx->small_cur ^= 1;
         ctx->small_len >>= 1;
     }
@@ -586,9 +619,8 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
     const uint64_t npairs = first ? n / 2 : n / 4;
     if (npairs == 0) return ZK_ERR_STATE;
     const uint32_t g = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks);
-    hipLaunchKernelGGL(k_round_cubic, dim3(g), dim3(ZK_BLOCK), 0, ctx->stream, t0.V[t0.cur], t1.V[t1.cur], t0.V[t0.cur ^ 1],
-                       t1.V[t1.cur ^ 1], ctx->small[ctx->small_cur], ctx->small_len, n, to_dev(r), first ? 1 : 0, ctx->partials);
-    hipLaunchKernelGGL(k_sum_partials<4>, dim3(1), dim3(ZK_BLOCK), 0, ctx->stream, ctx->d_result, ctx->partials, g, 0);
+    ZK_LAUNCH(PC_ROUND_CUBIC, (first ? 64.0 : 96.0) * (double) n, k_round_cubic, dim3(g), dim3(ZK_BLOCK), t0.V[t0.cur], t1.V[t1.cur], t0.V[t0.cur ^ 1], t1.V[t1.cur ^ 1], ctx->small[ctx->small_cur], ctx->small_len, n, to_dev(r), first ? 1 : 0, ctx->partials);
+    ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials<4>, dim3(1), dim3(ZK_BLOCK), ctx->d_result, ctx->partials, g, 0);
     ZK_HIP(hipGetLastError());
     if (!first) {
         t0.cur ^= 1; t1.cur ^= 1;
@@ -611,8 +643,7 @@ extern "C" int32_t zk_sumcheck_dotprod_finalize1(zk_ctx *ctx, const uint64_t pre
     int32_t rc;
     if (t1.len >= 2 && (rc = fold_pair(ctx, t1, r, false))) return rc;
     if (ctx->small_len >= 2) {
-        hipLaunchKernelGGL(k_fold, dim3(1), dim3(ZK_BLOCK), 0, ctx->stream, ctx->small[ctx->small_cur], ctx->small[ctx->small_cur ^ 1],
-                           (uint64_t) ctx->small_len, to_dev(r));
+        ZK_LAUNCH(PC_FOLD, 0.0, k_fold, dim3(1), dim3(ZK_BLOCK), ctx->small[ctx->small_cur], ctx->small[ctx->small_cur ^ 1], (uint64_t) ctx->small_len, to_dev(r));
         ctx->small_cur ^= 1;
         ctx->small_len >>= 1;
     }
@@ -645,10 +676,10 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         table_pair &t = ctx->tp[1];
         ZK_HIP(hipMemsetAsync(t.V[0], 0, t.len * 32, ctx->stream));
         const uint32_t rows = d.size_v[1];
-        hipLaunchKernelGGL(k_row_dot, dim3((rows + 3) / 4), dim3(ZK_BLOCK), 0, ctx->stream, t.V[0], prev.val, ctx->beta_gs, rows, fft_bl);
+        ZK_LAUNCH(PC_DOT, 0.0, k_row_dot, dim3((rows + 3) / 4), dim3(ZK_BLOCK), t.V[0], prev.val, ctx->beta_gs, rows, fft_bl);
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
-        return gate_scatter(ctx, t.M[0], cur.p2[1], cur.n_p2[1], 2, cur, prev);
+        return gate_scatter(ctx, t.M[0], cur.p2[1], cur.n_p2[1], 2, cur, prev, 0, t.len);
     }
 
     if ((rc = eq_table1(ctx, ctx->beta_u, d.max_bl_u, ru, HFr::one()))) return rc;
@@ -661,15 +692,15 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         A.val0 = nullptr; A.val_prev = nullptr; A.two_mul = ctx->two_mul;
         A.Vu0 = to_dev(ctx->V_u0); A.Vu1 = to_dev(ctx->V_u1); A.phase = 2;
         const uint32_t g = std::min<uint32_t>(grid_for(cur.n_uni2, 1024), ctx->partial_blocks);
-        hipLaunchKernelGGL(k_gate_sum2, dim3(g), dim3(ZK_BLOCK), 0, ctx->stream, ctx->partials, A);
-        hipLaunchKernelGGL(k_sum_partials<2>, dim3(1), dim3(ZK_BLOCK), 0, ctx->stream, ctx->d_result + 8, ctx->partials, g, 0);
+        ZK_LAUNCH(PC_GATE_SUM, 0.0, k_gate_sum2, dim3(g), dim3(ZK_BLOCK), ctx->partials, A);
+        ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials<2>, dim3(1), dim3(ZK_BLOCK), ctx->d_result + 8, ctx->partials, g, 0);
         ZK_HIP(hipGetLastError());
     }
     for (int b = 0; b < 2; ++b) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
         ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
-        if ((rc = gate_scatter(ctx, t.M[0], cur.p2[b], cur.n_p2[b], 2, cur, prev))) return rc;
+        if ((rc = gate_scatter(ctx, t.M[0], cur.p2[b], cur.n_p2[b], 2, cur, prev, 0, t.len))) return rc;
     }
     if (cur.n_uni2) {
         ZK_HIP(hipMemcpyAsync(ctx->h_result + 8, ctx->d_result + 8, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -700,12 +731,11 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         }
         const uint64_t npairs = first ? t.len / 2 : t.len / 4;
         const uint32_t g = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks / 2);
-        hipLaunchKernelGGL(k_round_quad, dim3(g), dim3(ZK_BLOCK), 0, ctx->stream, t.V[t.cur], t.M[t.cur], t.V[t.cur ^ 1],
-                           t.M[t.cur ^ 1], t.len, to_dev(r), first ? 1 : 0, ctx->partials + 3 * (size_t) nb);
+        ZK_LAUNCH(PC_ROUND_QUAD, (first ? 64.0 : 96.0) * (double) t.len, k_round_quad, dim3(g), dim3(ZK_BLOCK), t.V[t.cur], t.M[t.cur], t.V[t.cur ^ 1], t.M[t.cur ^ 1], t.len, to_dev(r), first ? 1 : 0, ctx->partials + 3 * (size_t) nb);
         nb += g;
         if (!first) { t.cur ^= 1; t.len >>= 1; }
     }
-    if (nb) hipLaunchKernelGGL(k_sum_partials<3>, dim3(1), dim3(ZK_BLOCK), 0, ctx->stream, ctx->d_result, ctx->partials, nb, 0);
+    if (nb) ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials<3>, dim3(1), dim3(ZK_BLOCK), ctx->d_result, ctx->partials, nb, 0);
     else ZK_HIP(hipMemsetAsync(ctx->d_result, 0, 3 * 32, ctx->stream));
     ZK_HIP(hipGetLastError());
     int32_t rc = fetch_result(ctx, 8);
@@ -820,15 +850,13 @@ extern "C" int32_t zk_sumcheck_liu_init(zk_ctx *ctx, const uint64_t *s_u, const 
             if ((int) ctx->r_u[i].size() < Li.d.bit_length_u[0]) return ZK_ERR_STATE;
             if ((rc = eq_table1(ctx, bg, Li.d.bit_length_u[0], ctx->r_u[i].data(), H(s_u + 4 * (i - 1))))) return rc;
             if (Li.d.size_u[0])
-                hipLaunchKernelGGL(k_scatter_add_unique, dim3(grid_for(Li.d.size_u[0])), dim3(ZK_BLOCK), 0, ctx->stream, t.M[0],
-                                   Li.ori_u, bg, (uint64_t) Li.d.size_u[0]);
+                ZK_LAUNCH(PC_LIU, 0.0, k_scatter_add_unique, dim3(grid_for(Li.d.size_u[0])), dim3(ZK_BLOCK), t.M[0], Li.ori_u, bg, (uint64_t) Li.d.size_u[0]);
         }
         if (Li.d.bit_length_v[0] >= 0) {
             if ((int) ctx->r_v[i].size() < Li.d.bit_length_v[0]) return ZK_ERR_STATE;
             if ((rc = eq_table1(ctx, bg, Li.d.bit_length_v[0], ctx->r_v[i].data(), H(s_v + 4 * (i - 1))))) return rc;
             if (Li.d.size_v[0])
-                hipLaunchKernelGGL(k_scatter_add_unique, dim3(grid_for(Li.d.size_v[0])), dim3(ZK_BLOCK), 0, ctx->stream, t.M[0],
-                                   Li.ori_v, bg, (uint64_t) Li.d.size_v[0]);
+                ZK_LAUNCH(PC_LIU, 0.0, k_scatter_add_unique, dim3(grid_for(Li.d.size_v[0])), dim3(ZK_BLOCK), t.M[0], Li.ori_v, bg, (uint64_t) Li.d.size_v[0]);
         }
     }
     ZK_HIP(hipGetLastError());
@@ -861,7 +889,7 @@ static int32_t binop(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64
     fr_t *da = (fr_t *) ctx->scratch.p, *db = da + n, *dz = db + n;
     ZK_HIP(hipMemcpyAsync(da, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipMemcpyAsync(db, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_fr_binop<OP>, dim3(grid_for(n)), dim3(ZK_BLOCK), 0, ctx->stream, dz, da, db, n);
+    ZK_LAUNCH(PC_MISC, 0.0, k_fr_binop<OP>, dim3(grid_for(n)), dim3(ZK_BLOCK), dz, da, db, n);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(out, dz, n * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
@@ -910,9 +938,8 @@ extern "C" int32_t zk_k_round_quadratic(zk_ctx *ctx, uint64_t *V, uint64_t *M, u
     ZK_HIP(hipMemcpyAsync(dM, M, n * 32, hipMemcpyHostToDevice, ctx->stream));
     const uint64_t npairs = first ? n / 2 : n / 4;
     const uint32_t g = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks);
-    hipLaunchKernelGGL(k_round_quad, dim3(g), dim3(ZK_BLOCK), 0, ctx->stream, dV, dM, dV2, dM2, n, to_dev(H(r)), first ? 1 : 0,
-                       ctx->partials);
-    hipLaunchKernelGGL(k_sum_partials<3>, dim3(1), dim3(ZK_BLOCK), 0, ctx->stream, ctx->d_result, ctx->partials, g, 0);
+    ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_round_quad, dim3(g), dim3(ZK_BLOCK), dV, dM, dV2, dM2, n, to_dev(H(r)), first ? 1 : 0, ctx->partials);
+    ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials<3>, dim3(1), dim3(ZK_BLOCK), ctx->d_result, ctx->partials, g, 0);
     ZK_HIP(hipGetLastError());
     if ((rc = fetch_result(ctx, 3))) return rc;
     const uint64_t nn = first ? n : n / 2;
@@ -961,8 +988,7 @@ extern "C" int32_t zk_bench_fr_mul(zk_ctx *ctx, uint64_t n_threads, uint32_t mul
     if ((rc = eq_table1(ctx, (fr_t *) ctx->scratch.p, lg, r.data(), HFr(77LL)))) return rc;
     const uint32_t blocks = (uint32_t) ((n_threads + ZK_BLOCK - 1) / ZK_BLOCK);
     return time_launches(ctx, iters, sec, [&] {
-        hipLaunchKernelGGL(k_bench_fr_mul, dim3(blocks), dim3(ZK_BLOCK), 0, ctx->stream, (fr_t *) ctx->scratch.p, muls_per_thread,
-                           n_threads);
+        ZK_LAUNCH(PC_MISC, 0.0, k_bench_fr_mul, dim3(blocks), dim3(ZK_BLOCK), (fr_t *) ctx->scratch.p, muls_per_thread, n_threads);
     });
 }
 
@@ -973,7 +999,7 @@ extern "C" int32_t zk_bench_copy(zk_ctx *ctx, uint64_t bytes, uint32_t iters, do
     uint4 *src = (uint4 *) ctx->scratch.p, *dst = src + bytes / 16;
     ZK_HIP(hipMemsetAsync(src, 1, bytes, ctx->stream));
     return time_launches(ctx, iters, sec, [&] {
-        hipLaunchKernelGGL(k_bench_copy, dim3(4096), dim3(ZK_BLOCK), 0, ctx->stream, dst, src, bytes / 16);
+        ZK_LAUNCH(PC_MISC, 0.0, k_bench_copy, dim3(4096), dim3(ZK_BLOCK), dst, src, bytes / 16);
     });
 }
 
@@ -1000,7 +1026,6 @@ extern "C" int32_t zk_bench_round_quadratic(zk_ctx *ctx, uint32_t log_n, uint32_
     const uint32_t gsz = std::min<uint32_t>(grid_for(n / 4, 1024), ctx->partial_blocks);
     *algorithmic_bytes = 96.0 * (double) n;
     return time_launches(ctx, iters, sec_per_launch, [&] {
-        hipLaunchKernelGGL(k_round_quad, dim3(gsz), dim3(ZK_BLOCK), 0, ctx->stream, dV, dM, dO, dO + n / 2, n, to_dev(r[0]), 0,
-                           ctx->partials);
+        ZK_LAUNCH(PC_ROUND_QUAD, 96.0 * (double) n, k_round_quad, dim3(gsz), dim3(ZK_BLOCK), dV, dM, dO, dO + n / 2, n, to_dev(r[0]), 0, ctx->partials);
     });
 }

@@ -48,4 +48,13 @@ int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap) {
     return 0;
 }
 
+int32_t zkcnn_session_profile(void *session, uint32_t class_mask) {
+    if (!session) return -1;
+    return zk_profile_enable(((gpuSession *) session)->p.context(), class_mask);
+}
+int32_t zkcnn_session_profile_report(void *session, char *buf, uint64_t cap, int32_t reset) {
+    if (!session) return -1;
+    return zk_profile_report(((gpuSession *) session)->p.context(), buf, cap, reset);
+}
+
 }  // extern "C"

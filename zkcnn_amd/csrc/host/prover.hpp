@@ -59,6 +59,7 @@ public:
     // call after C / val changed on the host to force a fresh upload at the next init()
     void invalidateDevice() { resident = false; }
     int device() const { return device_id; }
+    zk_ctx *context() const { return ctx; }     // for the profiler entry points of include/zkcnn_hip.h
 
 private:
     void ensureContext();

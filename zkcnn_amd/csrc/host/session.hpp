@@ -50,9 +50,11 @@ struct sessionT {
         output_tb.assign(OUT_COLUMN_CNT, "");
         output_tb[MO_INFO_OUT_ID] = model_name;
         output_tb[PCNT_OUT_ID] = std::to_string(pic_cnt);
+        output_tb[WS_OUT_ID] = std::to_string(p.C.circuit[0].size) + "(2^" + std::to_string((int) p.C.circuit[0].bit_length) + ")";
         verifierT<ProverT> v(&p, p.C);
         v.drive_only = drive;
         if (reuse) v.fixed_gens = &gens;
+        if (mode & ZKCNN_MODE_TAMPER) v.tamper_at = (long) (mode >> 8);
         bool ok = v.verify();
         out->accepted = drive ? -1 : (ok ? 1 : 0);
         out->n_layers = p.C.size;
@@ -66,6 +68,7 @@ struct sessionT {
         out->poly_proof_kb = p.polyProofSize();
         out->witness_s = witness_s;
         out->transcript_len = v.transcript.bytes.size();
+        out->n_messages = (int32_t) v.msg_count;
         if (transcript && cap) std::memcpy(transcript, v.transcript.bytes.data(), std::min<uint64_t>(cap, out->transcript_len));
         int rounds = 0;
         u64 nu = 0, nb = 0, tbl = 0;

@@ -78,6 +78,11 @@ public:
     bool drive_only = false;                 // skip the verifier's checks, keep challenges + prover calls
     const std::vector<G1> *fixed_gens = nullptr;   // re-use generators instead of drawing new ones
     proofTranscript transcript;
+    // test hook: add 1 to the k-th message received from the prover (a cheating prover); -1 = off.
+    // Messages are numbered in arrival order: Vres, every round polynomial, every finalize call, then the
+    // commitment-opening messages.
+    long tamper_at = -1;
+    long msg_count = 0;
 
     bool verify() {
         const u8 logn = C.circuit[0].bit_length;
@@ -88,7 +93,10 @@ public:
         delete poly_v;
         poly_v = new hyrax_bls12_381::polyVerifier(p->commitInput(gens), gens, &transcript);
         poly_v->drive_only = drive_only;
-        return verifyInnerLayers() && verifyFirstLayer() && verifyInput();
+        msg_count = 0;
+        if (!(verifyInnerLayers() && verifyFirstLayer())) return false;
+        poly_v->tamper_at = tamper_at < 0 ? -1 : tamper_at - msg_count;
+        return verifyInput();
     }
 
     timer total_timer, total_slow_timer;
@@ -115,6 +123,7 @@ private:
         fprintf(stderr, "Verification fail, %s\n", msg.c_str());
         return false;
     }
+    bool hit() { return msg_count++ == tamper_at; }
     static void draw(vector<F> &v, size_t n) {
         v.resize(n);
         for (auto &x : v) x.setByCSPRNG();
@@ -200,6 +209,7 @@ private:
         toc();
 
         F previousSum = p->Vres(r_0, top.size, top.bit_length);
+        if (hit()) previousSum = previousSum + F_ONE;
         transcript.put(previousSum);
         p->sumcheckInitAll(r_0);
 
@@ -220,12 +230,14 @@ private:
                 F at01, at_r;
                 if (dot) {
                     cubic_poly poly = p->sumcheckDotProdUpdate1(previousRandom);
+                    if (hit()) poly.d = poly.d + F_ONE;
                     transcript.put(poly);
                     tic();
                     at01 = poly.eval(F_ZERO) + poly.eval(F_ONE);
                     at_r = poly.eval(r_u[i][j]);
                 } else {
                     quadratic_poly poly = p->sumcheckUpdate1(previousRandom);
+                    if (hit()) poly.c = poly.c + F_ONE;
                     transcript.put(poly);
                     tic();
                     at01 = poly.eval(F_ZERO) + poly.eval(F_ONE);
@@ -239,9 +251,11 @@ private:
             }
             if (dot) {
                 p->sumcheckDotProdFinalize1(previousRandom, claim_u1);
+                if (hit()) claim_u1 = claim_u1 + F_ONE;
                 transcript.put(claim_u1);
             } else {
                 p->sumcheckFinalize1(previousRandom, final_claim_u0[i], claim_u1);
+                if (hit()) claim_u1 = claim_u1 + F_ONE;
                 transcript.put(final_claim_u0[i]);
                 transcript.put(claim_u1);
             }
@@ -259,6 +273,7 @@ private:
                 previousRandom = F_ZERO;
                 for (i8 j = 0; j < cur.max_bl_v; ++j) {
                     quadratic_poly poly = p->sumcheckUpdate2(previousRandom);
+                    if (hit()) poly.a = poly.a + F_ONE;
                     transcript.put(poly);
                     tic();
                     if (!drive_only && poly.eval(F_ZERO) + poly.eval(F_ONE) != previousSum)
@@ -268,6 +283,7 @@ private:
                     toc();
                 }
                 p->sumcheckFinalize2(previousRandom, final_claim_v0[i], claim_v1);
+                if (hit()) claim_v1 = claim_v1 + F_ONE;
                 transcript.put(final_claim_v0[i]);
                 transcript.put(claim_v1);
                 total_slow_timer.start();
@@ -321,6 +337,7 @@ private:
         F previousRandom = F_ZERO;
         for (int j = 0; j < cur.bit_length; ++j) {
             quadratic_poly poly = p->sumcheckLiuUpdate(previousRandom);
+            if (hit()) poly.b = poly.b + F_ONE;
             transcript.put(poly);
             if (!drive_only && poly.eval(F_ZERO) + poly.eval(F_ONE) != previousSum)
                 return fail("Liu, circuit 0, current bit " + std::to_string(j));
@@ -328,6 +345,7 @@ private:
             previousSum = poly.eval(previousRandom);
         }
         p->sumcheckLiuFinalize(previousRandom, eval_in);
+        if (hit()) eval_in = eval_in + F_ONE;
         transcript.put(eval_in);
 
         if (!drive_only) {

@@ -140,6 +140,7 @@ public:
         std::vector<Fr> cs(cb);
         for (int t = 0; t < cb; ++t) {
             ipaRoundMsg m = p.openRound();
+            if (tamper_at == (long) t) m.yR = m.yR + Fr::one();
             if (sink_) { sink_->put(m.L); sink_->put(m.R); sink_->put(m.yL); sink_->put(m.yR); }
             vt.start();
             cs[t].setByCSPRNG();
@@ -153,6 +154,7 @@ public:
             p.openFold(c);
         }
         Fr a = p.openFinal();
+        if (tamper_at == (long) cb) a = a + Fr::one();
         if (sink_) sink_->put(a);
 
         if (drive_only) return true;
@@ -178,6 +180,7 @@ public:
         return ok;
     }
     double getVT() const { return vt.elapse_sec(); }
+    long tamper_at = -1;       // test hook: corrupt the k-th opening message (round k, or cb = the final scalar)
     bool drive_only = false;   // make the prover calls and draw the challenges, skip the checks (bench mode)
 
 private:
