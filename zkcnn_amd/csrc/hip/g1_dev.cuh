@@ -128,7 +128,7 @@ __device__ __noinline__ fp_t fp_mul(const fp_t a, const fp_t b) {
 __device__ __forceinline__ fp_t fp_sqr(const fp_t &a) { return fp_mul(a, a); }
 
 // a^(p-2): Fermat inverse (inv(0) = 0)
-__device__ inline fp_t fp_inv(const fp_t &a) {
+__device__ __forceinline__ fp_t fp_inv(const fp_t &a) {
     const uint32_t e[12] = {0xffffaaa9u, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
                             0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
     fp_t acc = fp_one(), base = a;
@@ -154,7 +154,7 @@ __device__ __forceinline__ g1j_t g1_inf() {
 __device__ __forceinline__ bool g1_is_inf(const g1j_t &p) { return fp_is_zero(p.Z); }
 __device__ __forceinline__ bool g1a_is_inf(const g1a_t &p) { return fp_is_zero(p.x) && fp_is_zero(p.y); }
 
-__device__ inline g1j_t g1_dbl(const g1j_t &p) {
+__device__ __forceinline__ g1j_t g1_dbl(const g1j_t &p) {
     if (g1_is_inf(p)) return p;
     fp_t A = fp_sqr(p.X), B = fp_sqr(p.Y), C = fp_sqr(B);
     fp_t t = fp_add(p.X, B);
@@ -170,7 +170,7 @@ __device__ inline g1j_t g1_dbl(const g1j_t &p) {
 }
 
 // general Jacobian addition (handles infinity, doubling and inverse points)
-__device__ inline g1j_t g1_add(const g1j_t &p, const g1j_t &q) {
+__device__ __forceinline__ g1j_t g1_add(const g1j_t &p, const g1j_t &q) {
     if (g1_is_inf(p)) return q;
     if (g1_is_inf(q)) return p;
     fp_t Z1Z1 = fp_sqr(p.Z), Z2Z2 = fp_sqr(q.Z);
@@ -190,7 +190,7 @@ __device__ inline g1j_t g1_add(const g1j_t &p, const g1j_t &q) {
 }
 
 // Jacobian + affine
-__device__ inline g1j_t g1_madd(const g1j_t &p, const g1a_t &q) {
+__device__ __forceinline__ g1j_t g1_madd(const g1j_t &p, const g1a_t &q) {
     if (g1a_is_inf(q)) return p;
     if (g1_is_inf(p)) {
         g1j_t r;
@@ -212,7 +212,7 @@ __device__ inline g1j_t g1_madd(const g1j_t &p, const g1a_t &q) {
     return r;
 }
 
-__device__ inline g1a_t g1_to_affine(const g1j_t &p) {
+__device__ __forceinline__ g1a_t g1_to_affine(const g1j_t &p) {
     g1a_t a;
     if (g1_is_inf(p)) { a.x = fp_zero(); a.y = fp_zero(); return a; }
     fp_t zi = fp_inv(p.Z), zi2 = fp_sqr(zi);

@@ -31,13 +31,17 @@ struct msm_state {
     fr_t *sL = nullptr, *sR = nullptr; uint32_t *idxL = nullptr, *idxR = nullptr;
     fr_t *d_y = nullptr;               // 2 elements
     void *tbl_scratch = nullptr; size_t tbl_scratch_cap = 0;
+    // commitment fast path: digit table D[d][j] = d * g_j (d = 1..255, affine), per-row "has high bytes" flags
+    g1a_t *digit = nullptr; uint64_t digit_m = 0; bool digit_ready = false;
+    uint32_t *hi_flags = nullptr, *row_list = nullptr; size_t flags_cap = 0;
+    g1j_t *tmpJ = nullptr; size_t tmp_cap = 0;
 };
 
 void zk_msm_destroy(zk_ctx *ctx) {
     if (!ctx->msm) return;
     msm_state *s = ctx->msm;
-    void *bufs[] = {s->tables, s->partials, s->rowsJ, s->rowsA, s->a, s->b, s->coef, s->Lrow, s->sL, s->sR, s->idxL, s->idxR,
-                    s->d_y, s->tbl_scratch};
+    void *bufs[] = {s->tables, s->partials, s->rowsJ, s->rowsA, s->a, s->b, s->coef, s->Lrow, s->sL, s->idxL, s->d_y, s->tbl_scratch,
+                    s->digit, s->hi_flags, s->row_list, s->tmpJ};
     for (void *p : bufs) if (p) hipFree(p);
     delete s;
     ctx->msm = nullptr;
@@ -89,12 +93,14 @@ __global__ void k_window_tables(g1a_t *T, g1j_t *J, fp_t *pre, uint32_t m) {
 // One block = (row, bit plane, column chunk x window group). Each thread walks `cpt` columns
 // (stride 256: coalesced scalar and table reads), adds the selected table points, then the block
 // tree-reduces through LDS. out[(row * 8 + plane) * nparts + part]
-__global__ void __launch_bounds__(256) k_msm_planes(g1j_t *out, const fr_t *scalars, uint64_t ld, const uint32_t *idx,
-                                                     const g1a_t *T, uint32_t m, uint32_t cols, uint32_t cpt, uint32_t wsplit) {
+__global__ void __launch_bounds__(256) k_msm_planes(g1j_t *out, const fr_t *scalars, uint64_t ld, const uint32_t *idx_base,
+                                                     const g1a_t *T, uint32_t m, uint32_t cols, uint32_t cpt, uint32_t wsplit,
+                                                     const uint32_t *row_map, uint32_t w_lo) {
     __shared__ g1j_t sm[256];
-    const uint32_t plane = blockIdx.y, row = blockIdx.z;
+    const uint32_t plane = blockIdx.y, row = row_map ? row_map[blockIdx.z] : blockIdx.z;
     const uint32_t wg = blockIdx.x % wsplit, chunk = blockIdx.x / wsplit;
-    const uint32_t wpg = MSM_WINDOWS / wsplit, w0 = wg * wpg;
+    const uint32_t wpg = MSM_WINDOWS / wsplit, w0 = max(wg * wpg, w_lo);
+    const uint32_t *idx = idx_base ? idx_base + (size_t) row * ld : nullptr;     // index rows are laid out like the scalar rows
     g1j_t acc = g1_inf();
     for (uint32_t i = 0; i < cpt; ++i) {
         const uint32_t c = chunk * (256 * cpt) + i * 256 + threadIdx.x;
@@ -102,7 +108,7 @@ __global__ void __launch_bounds__(256) k_msm_planes(g1j_t *out, const fr_t *scal
         bool neg;
         const fr_t s = fr_signed_magnitude(fr_load(scalars + (size_t) row * ld + c), neg);
         const uint32_t j = idx ? idx[c] : c;
-        for (uint32_t w = w0; w < w0 + wpg; ++w) {
+        for (uint32_t w = w0; w < (wg + 1) * wpg; ++w) {
             const uint32_t byte = (s.v[w >> 2] >> ((w & 3) * 8)) & 0xffu;
             if ((byte >> plane) & 1u) {
                 g1a_t pt = T[(size_t) w * m + j];
@@ -117,28 +123,139 @@ __global__ void __launch_bounds__(256) k_msm_planes(g1j_t *out, const fr_t *scal
         if (threadIdx.x < s) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[((size_t) row * MSM_PLANES + plane) * gridDim.x + blockIdx.x] = sm[0];
+    if (threadIdx.x == 0) out[((size_t) blockIdx.z * MSM_PLANES + plane) * gridDim.x + blockIdx.x] = sm[0];
 }
 
-// one wave per row: sums the partial points of every plane and combines the planes, R = sum_k 2^k S_k
-__global__ void __launch_bounds__(64) k_msm_finish(g1j_t *outJ, const g1j_t *partials, uint32_t nparts) {
-    __shared__ g1j_t sm[64];
-    const uint32_t row = blockIdx.x, lane = threadIdx.x;
-    g1j_t R = g1_inf();
-    for (int k = MSM_PLANES - 1; k >= 0; --k) {
-        g1j_t acc = g1_inf();
-        const g1j_t *src = partials + ((size_t) row * MSM_PLANES + k) * nparts;
-        for (uint32_t p = lane; p < nparts; p += 64) acc = g1_add(acc, src[p]);
-        sm[lane] = acc;
-        __syncthreads();
-        for (uint32_t s = 32; s >= 1; s >>= 1) {
-            if (lane < s) sm[lane] = g1_add(sm[lane], sm[lane + s]);
-            __syncthreads();
+// ---- commitment fast path -------------------------------------------------------------------------
+// digit table by levels: D[1] = g, D[d] = 2 D[d/2] (+ g if d is odd); every entry of a level is independent
+__global__ void k_digit_level(g1j_t *J, const g1a_t *G, uint32_t m, uint32_t level) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t cnt = 1u << level;
+    if (tid >= cnt * m) return;
+    const uint32_t j = tid % m, d = cnt + tid / m;
+    const g1a_t g = G[j];
+    g1j_t P;
+    if (level == 0) {
+        if (g1a_is_inf(g)) P = g1_inf();
+        else { P.X = g.x; P.Y = g.y; P.Z = fp_one(); }
+    } else {
+        P = g1_dbl(J[(size_t) (d >> 1) * m + j]);
+        if (d & 1) P = g1_madd(P, g);
+    }
+    J[(size_t) d * m + j] = P;
+}
+// Jacobian -> affine for 16 consecutive digits of one generator with one inversion (Montgomery's trick)
+__global__ void k_digit_affine(g1a_t *D, const g1j_t *J, fp_t *pre, uint32_t m) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= 16 * m) return;
+    const uint32_t j = tid % m, d0 = (tid / m) * 16;
+    fp_t run = fp_one();
+    for (uint32_t d = d0; d < d0 + 16; ++d) {
+        if (d == 0) continue;
+        const fp_t z = J[(size_t) d * m + j].Z;
+        pre[(size_t) d * m + j] = run;
+        if (!fp_is_zero(z)) run = fp_mul(run, z);
+    }
+    fp_t inv = fp_inv(run);
+    for (uint32_t d = d0 + 16; d-- > d0;) {
+        if (d == 0) continue;
+        const g1j_t Q = J[(size_t) d * m + j];
+        g1a_t a;
+        if (fp_is_zero(Q.Z)) { a.x = fp_zero(); a.y = fp_zero(); }
+        else {
+            const fp_t zi = fp_mul(inv, pre[(size_t) d * m + j]);
+            inv = fp_mul(inv, Q.Z);
+            const fp_t zi2 = fp_sqr(zi);
+            a.x = fp_mul(Q.X, zi2);
+            a.y = fp_mul(fp_mul(Q.Y, zi2), zi);
         }
-        if (lane == 0) R = g1_add(g1_dbl(R), sm[0]);
+        D[(size_t) d * m + j] = a;
+    }
+}
+
+// Row commitment when (almost) every scalar is a signed byte: ONE mixed addition per non-zero scalar, taken
+// from the digit table. Scalars with higher bytes only contribute their low byte here and flag the row; the
+// caller adds their remaining windows with k_msm_planes(w_lo = 1). out[row * gridDim.x + chunk]
+__global__ void __launch_bounds__(256) k_msm_digit(g1j_t *out, uint32_t *hi_flags, const fr_t *scalars, uint64_t ld,
+                                                    const g1a_t *D, uint32_t m, uint32_t cols, uint32_t cpt) {
+    __shared__ g1j_t sm[256];
+    const uint32_t row = blockIdx.y, chunk = blockIdx.x;
+    g1j_t acc = g1_inf();
+    bool hi = false;
+    for (uint32_t i = 0; i < cpt; ++i) {
+        const uint32_t c = chunk * (256 * cpt) + i * 256 + threadIdx.x;
+        if (c >= cols) break;
+        const fr_t raw = fr_load(scalars + (size_t) row * ld + c);
+        if (fr_is_zero(raw)) continue;
+        bool neg;
+        const fr_t s = fr_signed_magnitude(raw, neg);
+        uint32_t rest = s.v[0] >> 8;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) rest |= s.v[k];
+        hi |= rest != 0;
+        const uint32_t d = s.v[0] & 0xffu;
+        if (d) {
+            g1a_t pt = D[(size_t) d * m + c];
+            if (neg) pt.y = fp_neg(pt.y);
+            acc = g1_madd(acc, pt);
+        }
+    }
+    if (hi) hi_flags[row] = 1;
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = 128; s >= 1; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + s]);
         __syncthreads();
     }
-    if (lane == 0) outJ[row] = R;
+    if (threadIdx.x == 0) out[(size_t) row * gridDim.x + chunk] = sm[0];
+}
+// rows[r] = sum of its `nparts` chunk sums
+__global__ void k_sum_parts(g1j_t *rows, const g1j_t *parts, uint32_t nparts, uint32_t n) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    g1j_t acc = parts[(size_t) r * nparts];
+    for (uint32_t p = 1; p < nparts; ++p) acc = g1_add(acc, parts[(size_t) r * nparts + p]);
+    rows[r] = acc;
+}
+// rows[list[i]] += extra[i]
+__global__ void k_add_rows(g1j_t *rows, const g1j_t *extra, const uint32_t *list, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rows[list[i]] = g1_add(rows[list[i]], extra[i]);
+}
+
+// One block per row, one wave per bit plane: wave k sums the partial points of plane k (lane-strided, then a
+// tree through LDS) and pre-multiplies by 2^k (k doublings, the waves run concurrently); a final 3-level tree
+// adds the 8 weighted plane sums. Sequential depth: ceil(nparts/64) + 6 + 7 + 3 point operations.
+__global__ void __launch_bounds__(512) k_msm_finish(g1j_t *outJ, const g1j_t *partials, uint32_t nparts) {
+    __shared__ g1j_t sm[MSM_PLANES][32];
+    const uint32_t row = blockIdx.x, lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+    g1j_t acc = g1_inf();
+    const g1j_t *src = partials + ((size_t) row * MSM_PLANES + k) * nparts;
+    for (uint32_t p = lane; p < nparts; p += 64) acc = g1_add(acc, src[p]);
+    const uint32_t live = nparts < 64 ? nparts : 64;          // lanes beyond this hold the point at infinity
+    if (lane >= 32) sm[k][lane - 32] = acc;
+    __syncthreads();
+    if (lane < 32) {
+        if (lane + 32 < live) acc = g1_add(acc, sm[k][lane]);
+    }
+    __syncthreads();
+    if (lane < 32) sm[k][lane] = acc;
+    __syncthreads();
+    for (uint32_t s = 16; s >= 1; s >>= 1) {
+        if (lane < s && lane + s < live) sm[k][lane] = g1_add(sm[k][lane], sm[k][lane + s]);
+        __syncthreads();
+    }
+    if (lane == 0) {
+        g1j_t R = sm[k][0];
+        for (uint32_t d = 0; d < k; ++d) R = g1_dbl(R);
+        sm[k][0] = R;
+    }
+    __syncthreads();
+    for (uint32_t s = MSM_PLANES / 2; s >= 1; s >>= 1) {
+        if (lane == 0 && k < s) sm[k][0] = g1_add(sm[k][0], sm[k + s][0]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) outJ[row] = sm[0][0];
 }
 
 __global__ void k_to_affine(g1a_t *out, const g1j_t *in, uint32_t n) {
@@ -149,7 +266,7 @@ __global__ void k_to_affine(g1a_t *out, const g1j_t *in, uint32_t n) {
 // scalars of the two cross terms of one inner-product round, expressed over the ORIGINAL generators:
 //   g^(k)_i = sum_{j = i mod len} coef[j] g_j, so  L = <a_lo, g_hi> = sum_{j: (j mod len) >= h} a[(j mod len) - h] coef[j] g_j
 __global__ void k_ipa_scalars(fr_t *sL, uint32_t *idxL, fr_t *sR, uint32_t *idxR, const fr_t *a, const fr_t *coef, uint32_t m,
-                              uint32_t len) {
+                              uint32_t len) {      // sL/sR and idxL/idxR are the two rows of one (2 x m/2) batch
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const uint32_t h = len >> 1, i = j & (len - 1), pos = (j / len) * h + (i & (h - 1));
@@ -209,6 +326,7 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
         s->m = m;
     }
     s->gens_host.assign(gens, gens + m * 12);
+    s->digit_ready = false;
     ZK_HIP(hipMemcpyAsync(s->tables, gens, m * sizeof(g1a_t), hipMemcpyHostToDevice, ctx->stream));
     const size_t need = (size_t) (MSM_WINDOWS - 1) * m * (sizeof(g1j_t) + sizeof(fp_t));
     int32_t rc = regrow(ctx, &s->tbl_scratch, &s->tbl_scratch_cap, need);
@@ -221,7 +339,8 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
 }
 
 // rows independent MSMs over the cached generator tables; results (Jacobian) in s->rowsJ[0..rows)
-static int32_t run_msm(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint32_t *idx, uint32_t rows, uint32_t cols) {
+static int32_t run_msm(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint32_t *idx, uint32_t rows, uint32_t cols,
+                       const uint32_t *row_map = nullptr, uint32_t w_lo = 0, g1j_t *outJ = nullptr) {
     msm_state *s = ctx->msm;
     uint32_t wsplit, cpt;
     if (rows >= 64) { wsplit = 1; cpt = std::min<uint32_t>(16, (cols + 255) / 256); }
@@ -239,9 +358,80 @@ static int32_t run_msm(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint
     // gridDim.z is limited to 65535 rows per launch
     for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
         const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
-        ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, k_msm_planes, dim3(nparts, MSM_PLANES, nr), dim3(256), s->partials + (size_t) r0 * MSM_PLANES * nparts, scalars + (size_t) r0 * ld, ld, idx, s->tables, (uint32_t) s->m, cols, cpt, wsplit);
+        ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, k_msm_planes, dim3(nparts, MSM_PLANES, nr), dim3(256), s->partials + (size_t) r0 * MSM_PLANES * nparts, scalars + (row_map ? 0 : (size_t) r0 * ld), ld, idx, s->tables, (uint32_t) s->m, cols, cpt, wsplit, row_map ? row_map + r0 : nullptr, w_lo);
     }
-    ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_msm_finish, dim3(rows), dim3(64), s->rowsJ, s->partials, nparts);
+    ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_msm_finish, dim3(rows), dim3(512), outJ ? outJ : s->rowsJ, s->partials, nparts);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+// digit table D[d][j] = d g_j for the cached generators
+static int32_t ensure_digit_table(zk_ctx *ctx) {
+    msm_state *s = ctx->msm;
+    if (s->digit_ready && s->digit_m == s->m) return ZK_OK;
+    const uint32_t m = (uint32_t) s->m;
+    if (s->digit_m != s->m) {
+        if (s->digit) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->digit)); s->digit = nullptr; }
+        ZK_HIP(hipMalloc((void **) &s->digit, (size_t) 256 * m * sizeof(g1a_t)));
+        s->digit_m = s->m;
+    }
+    int32_t rc = regrow(ctx, &s->tbl_scratch, &s->tbl_scratch_cap, (size_t) 256 * m * (sizeof(g1j_t) + sizeof(fp_t)));
+    if (rc) return rc;
+    g1j_t *J = (g1j_t *) s->tbl_scratch;
+    fp_t *pre = (fp_t *) (J + (size_t) 256 * m);
+    for (uint32_t level = 0; level < 8; ++level) {
+        const uint32_t work = (1u << level) * m;
+        ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_digit_level, dim3((work + 63) / 64), dim3(64), J, s->tables, m, level);
+    }
+    ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_digit_affine, dim3((16 * m + 63) / 64), dim3(64), s->digit, J, pre, m);
+    ZK_HIP(hipGetLastError());
+    s->digit_ready = true;
+    return ZK_OK;
+}
+
+// commitments of `rows` rows of `cols` scalars (cols == number of cached generators): digit-table pass for the low
+// byte of every scalar, then the bit-plane path for the remaining windows of the (few) rows that have any
+static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32_t rows, uint32_t cols) {
+    msm_state *s = ctx->msm;
+    int32_t rc;
+    if ((rc = ensure_digit_table(ctx))) return rc;
+    const uint32_t cpt = std::max<uint32_t>(1, std::min<uint32_t>(16, (cols + 255) / 256));
+    const uint32_t chunks = (cols + 256 * cpt - 1) / (256 * cpt);
+    if (s->rows_cap < rows) {
+        if (s->rowsJ) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->rowsJ)); ZK_HIP(hipFree(s->rowsA)); }
+        ZK_HIP(hipMalloc((void **) &s->rowsJ, (size_t) rows * sizeof(g1j_t)));
+        ZK_HIP(hipMalloc((void **) &s->rowsA, (size_t) rows * sizeof(g1a_t)));
+        s->rows_cap = rows;
+    }
+    if (s->flags_cap < rows) {
+        if (s->hi_flags) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->hi_flags)); ZK_HIP(hipFree(s->row_list)); }
+        ZK_HIP(hipMalloc((void **) &s->hi_flags, (size_t) rows * 4));
+        ZK_HIP(hipMalloc((void **) &s->row_list, (size_t) rows * 4));
+        s->flags_cap = rows;
+    }
+    ZK_HIP(hipMemsetAsync(s->hi_flags, 0, (size_t) rows * 4, ctx->stream));
+    g1j_t *dst = s->rowsJ;
+    if (chunks > 1) {
+        if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * chunks * sizeof(g1j_t)))) return rc;
+        dst = s->partials;
+    }
+    for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
+        const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
+        ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, k_msm_digit, dim3(chunks, nr), dim3(256),
+                  dst + (size_t) r0 * chunks, s->hi_flags + r0, scalars + (size_t) r0 * ld, ld, s->digit, (uint32_t) s->m, cols, cpt);
+    }
+    if (chunks > 1) ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_sum_parts, dim3((rows + 63) / 64), dim3(64), s->rowsJ, s->partials, chunks, rows);
+    ZK_HIP(hipGetLastError());
+    std::vector<uint32_t> flags(rows), list;
+    ZK_HIP(hipMemcpyAsync(flags.data(), s->hi_flags, (size_t) rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    for (uint32_t r = 0; r < rows; ++r) if (flags[r]) list.push_back(r);
+    if (list.empty()) return ZK_OK;
+    const uint32_t nl = (uint32_t) list.size();
+    ZK_HIP(hipMemcpyAsync(s->row_list, list.data(), (size_t) nl * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = regrow(ctx, (void **) &s->tmpJ, &s->tmp_cap, (size_t) nl * sizeof(g1j_t)))) return rc;
+    if ((rc = run_msm(ctx, scalars, ld, nullptr, nl, cols, s->row_list, 1, s->tmpJ))) return rc;
+    ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_add_rows, dim3((nl + 63) / 64), dim3(64), s->rowsJ, s->tmpJ, s->row_list, nl);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -280,7 +470,7 @@ extern "C" int32_t zk_commit_input(zk_ctx *ctx, const uint64_t *gens, uint64_t n
     if ((rc = ensure_state(ctx)) || (rc = ensure_tables(ctx, gens, n_gens))) return rc;
     ctx->msm->rb = rb;
     ctx->msm->cb = cb;
-    if ((rc = run_msm(ctx, L0.val, n_gens, nullptr, (uint32_t) n_rows, (uint32_t) n_gens))) return rc;
+    if ((rc = commit_rows(ctx, L0.val, n_gens, (uint32_t) n_rows, (uint32_t) n_gens))) return rc;
     return fetch_points(ctx, (uint32_t) n_rows, out_comm);
 }
 
@@ -294,8 +484,10 @@ extern "C" int32_t zk_hyrax_open_init(zk_ctx *ctx, const uint64_t *x, uint32_t n
     if (!s->a) {
         ZK_HIP(hipMalloc((void **) &s->a, (size_t) m * 32)); ZK_HIP(hipMalloc((void **) &s->b, (size_t) m * 32));
         ZK_HIP(hipMalloc((void **) &s->coef, (size_t) m * 32)); ZK_HIP(hipMalloc((void **) &s->Lrow, (size_t) rows * 32));
-        ZK_HIP(hipMalloc((void **) &s->sL, (size_t) m * 16)); ZK_HIP(hipMalloc((void **) &s->sR, (size_t) m * 16));
-        ZK_HIP(hipMalloc((void **) &s->idxL, (size_t) m * 2)); ZK_HIP(hipMalloc((void **) &s->idxR, (size_t) m * 2));
+        ZK_HIP(hipMalloc((void **) &s->sL, (size_t) m * 32));          // rows: sL | sR
+        ZK_HIP(hipMalloc((void **) &s->idxL, (size_t) m * 4));         // rows: idxL | idxR
+        s->sR = s->sL + m / 2;
+        s->idxR = s->idxL + m / 2;
         ZK_HIP(hipMalloc((void **) &s->d_y, 64));
     }
     const HFr *xs = reinterpret_cast<const HFr *>(x);
@@ -317,14 +509,11 @@ extern "C" int32_t zk_hyrax_open_round(zk_ctx *ctx, uint64_t Lp[12], uint64_t Rp
     ZK_LAUNCH(PC_IPA, 0.0, k_ipa_scalars, dim3((m + 255) / 256), dim3(256), s->sL, s->idxL, s->sR, s->idxR, s->a, s->coef, m, s->len);
     ZK_LAUNCH(PC_IPA, 0.0, k_ipa_dots, dim3(1), dim3(256), s->d_y, s->a, s->b, h);
     ZK_HIP(hipGetLastError());
-    // two MSMs over m/2 generators each, launched as two rows of one batch (row stride = m/2 scalars)
-    // sL and sR are separate buffers; run them one after the other into rowsJ[0], rowsJ[1]
+    // two MSMs over m/2 generators each = the two rows of one batch (row stride m/2 for scalars and indices)
     int32_t rc;
     uint64_t pts[24];
-    if ((rc = run_msm(ctx, s->sL, m / 2, s->idxL, 1, m / 2))) return rc;
-    if ((rc = fetch_points(ctx, 1, pts))) return rc;
-    if ((rc = run_msm(ctx, s->sR, m / 2, s->idxR, 1, m / 2))) return rc;
-    if ((rc = fetch_points(ctx, 1, pts + 12))) return rc;
+    if ((rc = run_msm(ctx, s->sL, m / 2, s->idxL, 2, m / 2))) return rc;
+    if ((rc = fetch_points(ctx, 2, pts))) return rc;
     ZK_HIP(hipMemcpy(ctx->h_result, s->d_y, 64, hipMemcpyDeviceToHost));
     std::memcpy(Lp, pts, 96);
     std::memcpy(Rp, pts + 12, 96);
