@@ -100,3 +100,22 @@ def test_msm_matches_cpu_pippenger(hip, oracle, n, kind):
     g = hip.msm(sc, bases)
     assert np.array_equal(g, oracle.msm(sc, bases))
     assert oracle.g1_on_curve(g)
+
+
+def test_commit_rows_digit_table_and_high_byte_rows(hip, oracle):
+    """the commitInput data path: signed-byte witnesses through the digit table, rows with larger scalars through the
+    bit-plane path for their remaining windows; every row against the CPU Pippenger"""
+    rows, cols = 12, 512
+    rng = np.random.default_rng(7)
+    vals = rng.integers(-255, 256, size=(rows, cols)).astype(object)
+    vals[3, :] = rng.integers(0, 2, cols)                          # bit row
+    vals[5, 10:40] = [int(x) for x in rng.integers(-(1 << 20), 1 << 20, 30)]   # a few wide scalars (biases / maxima)
+    vals[7, :] = 0                                                 # empty row -> point at infinity
+    sc = to_mont([int(v) % R_MOD for v in vals.reshape(-1)])
+    big = oracle.random(cols, 99)
+    sc[8 * cols:9 * cols] = big                                    # a full-width random row
+    bases = oracle.generators(cols, 4242)
+    got = hip.commit_rows(sc, bases, rows, cols)
+    for r in range(rows):
+        assert np.array_equal(got[r], oracle.msm(sc[r * cols:(r + 1) * cols], bases)), f"row {r}"
+    assert not got[7].any()

@@ -156,6 +156,21 @@ class HipContext:
         self._check(self.lib.zk_k_msm(self.ctx, u64p(out), u64p(scalars), u64p(bases), ctypes.c_uint64(scalars.shape[0])), "zk_k_msm")
         return out
 
+    def commit_rows(self, scalars, bases, rows, cols):
+        out = np.zeros((rows, 12), dtype=np.uint64)
+        self._check(self.lib.zk_k_commit_rows(self.ctx, u64p(out), u64p(scalars), u64p(bases), ctypes.c_uint64(rows), ctypes.c_uint64(cols)),
+                    "zk_k_commit_rows")
+        return out
+
+    def profile(self, mask):
+        self._check(self.lib.zk_profile_enable(self.ctx, ctypes.c_uint32(mask)), "zk_profile_enable")
+
+    def profile_report(self, reset=True):
+        import json
+        buf = ctypes.create_string_buffer(8192)
+        self._check(self.lib.zk_profile_report(self.ctx, buf, ctypes.c_uint64(8192), ctypes.c_int32(int(reset))), "zk_profile_report")
+        return json.loads(buf.value.decode())
+
     def bench_fr_mul(self, n_threads, muls, iters=5):
         sec = ctypes.c_double()
         self._check(self.lib.zk_bench_fr_mul(self.ctx, ctypes.c_uint64(n_threads), ctypes.c_uint32(muls), ctypes.c_uint32(iters),

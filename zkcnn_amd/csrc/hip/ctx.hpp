@@ -78,6 +78,11 @@ struct zk_ctx {
     fr_t *partials = nullptr; uint32_t partial_blocks = 0;
     fr_t *d_result = nullptr;      // 32 elements
     HFr *h_result = nullptr;       // pinned, 32 elements
+    // per-round hand-over: mapped pinned host slot written by the last block of a fused round kernel
+    struct host_slot_h { HFr v[12]; volatile unsigned long long seq; } *h_slot = nullptr;
+    void *d_slot = nullptr;        // device address of h_slot
+    uint32_t *d_counter = nullptr; // arrival counter of the grid-wide reduction
+    unsigned long long slot_seq = 0;
     uint32_t *carry_key = nullptr; fr_t *carry_val = nullptr; uint64_t carry_slots = 0;
     dev_buf scratch;               // growable (mat-vec partial sums, ...)
     std::vector<fr_t *> root_pw[2];  // [inverse][n] powers of the 2^n-th root of unity

@@ -117,6 +117,11 @@ __global__ void __launch_bounds__(256) k_msm_planes(g1j_t *out, const fr_t *scal
             }
         }
     }
+    // blocks that selected no point at all (high windows of small scalars) skip the reduction tree
+    if (!__syncthreads_or(!g1_is_inf(acc))) {
+        if (threadIdx.x == 0) out[((size_t) blockIdx.z * MSM_PLANES + plane) * gridDim.x + blockIdx.x] = acc;
+        return;
+    }
     sm[threadIdx.x] = acc;
     __syncthreads();
     for (uint32_t s = 128; s >= 1; s >>= 1) {
@@ -340,10 +345,11 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
 
 // rows independent MSMs over the cached generator tables; results (Jacobian) in s->rowsJ[0..rows)
 static int32_t run_msm(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint32_t *idx, uint32_t rows, uint32_t cols,
-                       const uint32_t *row_map = nullptr, uint32_t w_lo = 0, g1j_t *outJ = nullptr) {
+                       const uint32_t *row_map = nullptr, uint32_t w_lo = 0, g1j_t *outJ = nullptr, bool sparse_windows = false) {
     msm_state *s = ctx->msm;
     uint32_t wsplit, cpt;
     if (rows >= 64) { wsplit = 1; cpt = std::min<uint32_t>(16, (cols + 255) / 256); }
+    else if (sparse_windows) { wsplit = 1; cpt = std::min<uint32_t>(2, (cols + 255) / 256); }   // few non-zero windows: one block walks them all
     else { wsplit = MSM_WINDOWS; cpt = std::min<uint32_t>(4, (cols + 255) / 256); }
     cpt = std::max<uint32_t>(cpt, 1);
     const uint32_t chunks = (cols + 256 * cpt - 1) / (256 * cpt), nparts = chunks * wsplit;
@@ -430,7 +436,7 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
     const uint32_t nl = (uint32_t) list.size();
     ZK_HIP(hipMemcpyAsync(s->row_list, list.data(), (size_t) nl * 4, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = regrow(ctx, (void **) &s->tmpJ, &s->tmp_cap, (size_t) nl * sizeof(g1j_t)))) return rc;
-    if ((rc = run_msm(ctx, scalars, ld, nullptr, nl, cols, s->row_list, 1, s->tmpJ))) return rc;
+    if ((rc = run_msm(ctx, scalars, ld, nullptr, nl, cols, s->row_list, 1, s->tmpJ, true))) return rc;
     ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_add_rows, dim3((nl + 63) / 64), dim3(64), s->rowsJ, s->tmpJ, s->row_list, nl);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
@@ -552,4 +558,17 @@ extern "C" int32_t zk_k_msm(zk_ctx *ctx, uint64_t out[12], const uint64_t *scala
     ZK_HIP(hipMemcpyAsync(ctx->scratch.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = run_msm(ctx, (const fr_t *) ctx->scratch.p, n, nullptr, 1, (uint32_t) n))) return rc;
     return fetch_points(ctx, 1, out);
+}
+
+// rows x cols row commitments over `cols` arbitrary bases: the commitInput data path on caller-supplied data
+extern "C" int32_t zk_k_commit_rows(zk_ctx *ctx, uint64_t *out, const uint64_t *scalars, const uint64_t *bases, uint64_t rows,
+                                    uint64_t cols) {
+    if (!ctx || !rows || !cols || rows * cols > (1ull << 26)) return ZK_ERR_ARG;
+    ZK_HIP(hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = ensure_state(ctx)) || (rc = ensure_tables(ctx, bases, cols))) return rc;
+    if ((rc = zk_scratch(ctx, rows * cols * 32))) return rc;
+    ZK_HIP(hipMemcpyAsync(ctx->scratch.p, scalars, rows * cols * 32, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = commit_rows(ctx, (const fr_t *) ctx->scratch.p, cols, (uint32_t) rows, (uint32_t) cols))) return rc;
+    return fetch_points(ctx, (uint32_t) rows, out);
 }

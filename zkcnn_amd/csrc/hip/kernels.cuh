@@ -302,6 +302,142 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad(const fr_t *Vin, const 
         for (int k = 0; k < 3; ++k) fr_store(partials + 3 * blockIdx.x + k, acc[k]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused round kernels of the interactive loop. One launch per sumcheck round: both live table pairs, the grid-wide
+// reduction (last block to arrive sums the per-block partials) and the hand-over to the host (the result goes
+// straight into a mapped, pinned host slot followed by a sequence number the host spins on) -- no separate
+// reduction kernel, no device-to-host copy, no stream synchronisation on the critical path of a round.
+// ------------------------------------------------------------------------------------------------
+struct host_slot {
+    fr_t v[12];                 // [0..3] round sums, [4 + 2b], [5 + 2b] values of a table pair that just collapsed
+    unsigned long long seq;     // written last
+};
+
+template <int K>
+__device__ __forceinline__ void grid_finish(fr_t (&acc)[K], fr_t *partials, uint32_t *counter, host_slot *slot,
+                                            unsigned long long seq, fr_t *smem) {
+    __shared__ int s_last;
+    if (gridDim.x == 1) {                                // small tables: this block already holds the grid total
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) fr_store(&slot->v[k], acc[k]);
+            __threadfence_system();
+            *((volatile unsigned long long *) &slot->seq) = seq;
+        }
+        return;
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) fr_store(partials + (size_t) K * blockIdx.x + k, acc[k]);
+        __threadfence_system();                          // release: partials (and any slot values) before the ticket
+        const uint32_t t = atomicAdd(counter, 1u);
+        s_last = (t == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                     // acquire: this CU's L1 may hold last round's partials
+    fr_t tot[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) tot[k] = fr_zero();
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += blockDim.x)
+#pragma unroll
+        for (int k = 0; k < K; ++k) tot[k] = fr_add(tot[k], fr_load(partials + (size_t) K * b + k));
+    fr_block_sum<K>(tot, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) fr_store(&slot->v[k], tot[k]);
+        *counter = 0;
+        __threadfence_system();
+        *((volatile unsigned long long *) &slot->seq) = seq;
+    }
+}
+
+struct round2_args {
+    const fr_t *Vin[2], *Min[2];
+    fr_t *Vout[2], *Mout[2];
+    uint64_t n[2];              // pre-fold length of each pair; 0 = absent
+    uint32_t blocks[2];         // blocks working on each pair (grid.x = blocks[0] + blocks[1])
+    fr_t r;
+    int32_t first;
+    fr_t *partials;
+    uint32_t *counter;
+    host_slot *slot;
+    unsigned long long seq;
+};
+
+// reference src/prover.cpp:368-426 for both table pairs of a layer in one launch
+__global__ void __launch_bounds__(ZK_BLOCK) k_round_quad2(round2_args a) {
+    __shared__ fr_t smem[3 * ZK_BLOCK / 64];
+    const int b = blockIdx.x < a.blocks[0] ? 0 : 1;
+    const uint32_t lb = b ? blockIdx.x - a.blocks[0] : blockIdx.x, nblk = a.blocks[b];
+    const fr_t *Vin = a.Vin[b], *Min = a.Min[b];
+    fr_t *Vout = a.Vout[b], *Mout = a.Mout[b];
+    const uint64_t n = a.n[b];
+    fr_t acc[3] = {fr_zero(), fr_zero(), fr_zero()};       // a, c, p(1)
+    const bool collapse = a.first ? n == 1 : n == 2;        // the reference's `total == 1` case (prover.cpp:400-404)
+    if (collapse) {
+        if (threadIdx.x == 0) {
+            fr_t v = fr_load(Vin), m = fr_load(Min);
+            if (!a.first) {
+                v = fr_lerp(v, fr_load(Vin + 1), a.r);
+                m = fr_lerp(m, fr_load(Min + 1), a.r);
+                fr_store(Vout, v);
+                fr_store(Mout, m);
+            }
+            fr_store(&a.slot->v[4 + 2 * b], v);
+            fr_store(&a.slot->v[5 + 2 * b], m);
+        }
+    } else {
+        const uint64_t tid = lb * (uint64_t) ZK_BLOCK + threadIdx.x, stride = (uint64_t) nblk * ZK_BLOCK;
+        if (a.first) {
+            for (uint64_t p = tid; p < n / 2; p += stride) {
+                fr_t v0 = fr_load(Vin + 2 * p), v1 = fr_load(Vin + 2 * p + 1);
+                fr_t m0 = fr_load(Min + 2 * p), m1 = fr_load(Min + 2 * p + 1);
+                acc[0] = fr_add(acc[0], fr_mul(fr_sub(v1, v0), fr_sub(m1, m0)));
+                acc[1] = fr_add(acc[1], fr_mul(v0, m0));
+                acc[2] = fr_add(acc[2], fr_mul(v1, m1));
+            }
+        } else {
+            for (uint64_t q = tid; q < n / 4; q += stride) {
+                fr_t a0 = fr_load(Vin + 4 * q), a1 = fr_load(Vin + 4 * q + 1), a2 = fr_load(Vin + 4 * q + 2), a3 = fr_load(Vin + 4 * q + 3);
+                fr_t v0 = fr_lerp(a0, a1, a.r), v1 = fr_lerp(a2, a3, a.r);
+                fr_store(Vout + 2 * q, v0);
+                fr_store(Vout + 2 * q + 1, v1);
+                a0 = fr_load(Min + 4 * q); a1 = fr_load(Min + 4 * q + 1); a2 = fr_load(Min + 4 * q + 2); a3 = fr_load(Min + 4 * q + 3);
+                fr_t m0 = fr_lerp(a0, a1, a.r), m1 = fr_lerp(a2, a3, a.r);
+                fr_store(Mout + 2 * q, m0);
+                fr_store(Mout + 2 * q + 1, m1);
+                acc[0] = fr_add(acc[0], fr_mul(fr_sub(v1, v0), fr_sub(m1, m0)));
+                acc[1] = fr_add(acc[1], fr_mul(v0, m0));
+                acc[2] = fr_add(acc[2], fr_mul(v1, m1));
+            }
+        }
+    }
+    fr_block_sum<3>(acc, smem);
+    __syncthreads();
+    grid_finish<3>(acc, a.partials, a.counter, a.slot, a.seq, smem);
+}
+
+// up to four "evaluate the last variable" requests in one tiny launch: out[i] = n == 2 ? lerp(p[0], p[1], r) : p[0]
+struct eval_args {
+    const fr_t *p[4];
+    uint32_t n[4];              // 0 = unused
+    fr_t r;
+    host_slot *slot;
+    unsigned long long seq;
+};
+__global__ void k_eval_pairs(eval_args a) {
+    if (threadIdx.x < 4 && a.n[threadIdx.x]) {
+        const fr_t *p = a.p[threadIdx.x];
+        fr_t v = fr_load(p);
+        if (a.n[threadIdx.x] == 2) v = fr_lerp(v, fr_load(p + 1), a.r);
+        fr_store(&a.slot->v[threadIdx.x], v);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *((volatile unsigned long long *) &a.slot->seq) = a.seq;
+}
+
 // plain fold (tables shorter than one quad, the periodic table of the cubic rounds, Vres)
 __global__ void k_fold(const fr_t *in, fr_t *out, uint64_t n, fr_t r) {
     for (uint64_t j = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; j < n / 2; j += (uint64_t) gridDim.x * blockDim.x)
@@ -316,7 +452,8 @@ __global__ void k_fold(const fr_t *in, fr_t *out, uint64_t n, fr_t r) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, const fr_t *V1in, fr_t *V0out, fr_t *V1out,
                                                           const fr_t *Ms, uint32_t ls, uint64_t n, fr_t r, int first,
-                                                          fr_t *partials) {
+                                                          fr_t *partials, uint32_t *counter, host_slot *slot,
+                                                          unsigned long long seq) {
     __shared__ fr_t smem[4 * ZK_BLOCK / 64];
     fr_t acc[4] = {fr_zero(), fr_zero(), fr_zero(), fr_zero()};      // c3, c2, c1, c0
     const uint64_t tid = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x, stride = (uint64_t) gridDim.x * ZK_BLOCK;
@@ -353,9 +490,8 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, cons
         acc[3] = fr_add(acc[3], fr_mul(q0, m0));
     }
     fr_block_sum<4>(acc, smem);
-    if (threadIdx.x == 0)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) fr_store(partials + 4 * blockIdx.x + k, acc[k]);
+    __syncthreads();
+    grid_finish<4>(acc, partials, counter, slot, seq, smem);
 }
 
 // ------------------------------------------------------------------------------------------------

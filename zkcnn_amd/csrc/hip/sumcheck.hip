@@ -71,11 +71,16 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
         zk_dev_alloc(ctx, (void **) &ctx->eq_hi, 2 * (size_t) ctx->eq_stride * 32) ||
         zk_dev_alloc(ctx, (void **) &ctx->partials, (size_t) ctx->partial_blocks * 4 * 32) ||
         zk_dev_alloc(ctx, (void **) &ctx->d_result, 32 * 32) ||
+        zk_dev_alloc(ctx, (void **) &ctx->d_counter, 64) ||
+        hipHostMalloc((void **) &ctx->h_slot, sizeof(*ctx->h_slot), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&ctx->d_slot, ctx->h_slot, 0) != hipSuccess ||
+        hipMemset(ctx->d_counter, 0, 64) != hipSuccess ||
         hipHostMalloc((void **) &ctx->h_result, 32 * 32) != hipSuccess) {
         g_create_err = ctx->err.empty() ? "allocation failed" : ctx->err;
         zk_ctx_destroy(ctx);
         return ZK_ERR_NOMEM;
     }
+    std::memset((void *) ctx->h_slot, 0, sizeof(*ctx->h_slot));
     *out = ctx;
     return ZK_OK;
 }
@@ -90,6 +95,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     for (void *p : ctx->owned) hipFree(p);
     if (ctx->scratch.p) hipFree(ctx->scratch.p);
     if (ctx->h_result) hipHostFree(ctx->h_result);
+    if (ctx->h_slot) hipHostFree((void *) ctx->h_slot);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -348,6 +354,23 @@ static int32_t fetch_result(zk_ctx *ctx, int count) {
 
 // algorithmic bytes of one scatter: per uni gate 12 B record + 32 B gather, per bin gate 16 B record
 // + 2 x 32 B gathers, + 32 B per output entry
+// Waits until the fused round kernel has published sequence number `seq` in the mapped host slot. Spinning on the
+// slot keeps a stream synchronisation (and a D2H copy) off the critical path of every round; if the value does not
+// show up quickly the stream is synchronised instead (long kernels, or host memory that is not fine-grained).
+static int32_t wait_slot(zk_ctx *ctx, unsigned long long seq) {
+    volatile unsigned long long *p = &ctx->h_slot->seq;
+    for (uint64_t spins = 0; *p != seq; ++spins) {
+        if (spins > (1ull << 21)) {
+            ZK_HIP(hipStreamSynchronize(ctx->stream));
+            if (*p != seq) { ctx->err = "round result was not published"; return ZK_ERR_STATE; }
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return ZK_OK;
+}
+
 static int32_t gate_scatter(zk_ctx *ctx, fr_t *out, const gate_rec *recs, uint64_t n, int phase, const dev_layer &cur,
                             const dev_layer &prev, uint64_t n_uni_in_list, uint64_t out_len) {
     if (!n) return ZK_OK;
@@ -619,15 +642,18 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
     const uint64_t npairs = first ? n / 2 : n / 4;
     if (npairs == 0) return ZK_ERR_STATE;
     const uint32_t g = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks);
-    ZK_LAUNCH(PC_ROUND_CUBIC, (first ? 64.0 : 96.0) * (double) n, k_round_cubic, dim3(g), dim3(ZK_BLOCK), t0.V[t0.cur], t1.V[t1.cur], t0.V[t0.cur ^ 1], t1.V[t1.cur ^ 1], ctx->small[ctx->small_cur], ctx->small_len, n, to_dev(r), first ? 1 : 0, ctx->partials);
-    ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials<4>, dim3(1), dim3(ZK_BLOCK), ctx->d_result, ctx->partials, g, 0);
+    const unsigned long long seq = ++ctx->slot_seq;
+    ZK_LAUNCH(PC_ROUND_CUBIC, (first ? 64.0 : 96.0) * (double) n, k_round_cubic, dim3(g), dim3(ZK_BLOCK), t0.V[t0.cur], t1.V[t1.cur],
+              t0.V[t0.cur ^ 1], t1.V[t1.cur ^ 1], ctx->small[ctx->small_cur], ctx->small_len, n, to_dev(r), first ? 1 : 0, ctx->partials,
+              ctx->d_counter, (host_slot *) ctx->d_slot, seq);
     ZK_HIP(hipGetLastError());
     if (!first) {
         t0.cur ^= 1; t1.cur ^= 1;
         t0.len >>= 1; t1.len >>= 1;
     }
-    int32_t rc = fetch_result(ctx, 4);
+    int32_t rc = wait_slot(ctx, seq);
     if (rc) return rc;
+    for (int k = 0; k < 4; ++k) ctx->h_result[k] = ctx->h_slot->v[k];
     for (int k = 0; k < 4; ++k) put(out_abcd + 4 * k, ctx->h_result[k]);
     ctx->proof_size += 32 * (3 + (ctx->h_result[0].isZero() ? 0 : 1));
     return ZK_OK;
@@ -641,15 +667,21 @@ extern "C" int32_t zk_sumcheck_dotprod_finalize1(zk_ctx *ctx, const uint64_t pre
     ctx->r_u[id].at(ctx->round - 1) = r;
     table_pair &t1 = ctx->tp[1];
     int32_t rc;
-    if (t1.len >= 2 && (rc = fold_pair(ctx, t1, r, false))) return rc;
-    if (ctx->small_len >= 2) {
-        ZK_LAUNCH(PC_FOLD, 0.0, k_fold, dim3(1), dim3(ZK_BLOCK), ctx->small[ctx->small_cur], ctx->small[ctx->small_cur ^ 1], (uint64_t) ctx->small_len, to_dev(r));
-        ctx->small_cur ^= 1;
-        ctx->small_len >>= 1;
-    }
-    ZK_HIP(hipMemcpyAsync(ctx->d_result, t1.V[t1.cur], 32, hipMemcpyDeviceToDevice, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(ctx->d_result + 1, ctx->small[ctx->small_cur], 32, hipMemcpyDeviceToDevice, ctx->stream));
-    if ((rc = fetch_result(ctx, 2))) return rc;
+    eval_args E;
+    std::memset(&E, 0, sizeof(E));
+    E.p[0] = t1.V[t1.cur]; E.n[0] = (uint32_t) std::min<uint64_t>(t1.len, 2);
+    E.p[1] = ctx->small[ctx->small_cur]; E.n[1] = std::min<uint32_t>(ctx->small_len, 2);
+    if (t1.len > 2 || ctx->small_len > 2) return ZK_ERR_STATE;
+    E.r = to_dev(r);
+    E.slot = (host_slot *) ctx->d_slot;
+    E.seq = ++ctx->slot_seq;
+    ZK_LAUNCH(PC_FOLD, 0.0, k_eval_pairs, dim3(1), dim3(64), E);
+    ZK_HIP(hipGetLastError());
+    if ((rc = wait_slot(ctx, E.seq))) return rc;
+    ctx->h_result[0] = ctx->h_slot->v[0];
+    ctx->h_result[1] = ctx->h_slot->v[1];
+    t1.len = 0;
+    ctx->small_len = 1;
     put(claim_1, ctx->h_result[0]);
     ctx->V_u1 = ctx->h_result[0] * ctx->h_result[1];
     ctx->proof_size += 32;
@@ -715,31 +747,40 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
     const bool first = ctx->round == 0;
     ++ctx->round;
     if (with_add_term) ctx->add_term = ctx->add_term * (HFr::one() - r);
-    uint32_t nb = 0;
     bool collapsed[2] = {false, false};
+    round2_args A;
+    std::memset(&A, 0, sizeof(A));
+    double alg_bytes = 0;
     for (int b = 0; b < 2; ++b) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
-        if ((first && t.len == 1) || (!first && t.len == 2)) {
-            // the reference's `total == 1` case: the table has run out of variables; its product becomes a constant
-            int32_t rc;
-            if (t.len == 2 && (rc = fold_pair(ctx, t, r, true))) return rc;
-            ZK_HIP(hipMemcpyAsync(ctx->d_result + 4 + 2 * b, t.V[t.cur], 32, hipMemcpyDeviceToDevice, ctx->stream));
-            ZK_HIP(hipMemcpyAsync(ctx->d_result + 5 + 2 * b, t.M[t.cur], 32, hipMemcpyDeviceToDevice, ctx->stream));
-            collapsed[b] = true;
-            continue;
-        }
+        A.Vin[b] = t.V[t.cur]; A.Min[b] = t.M[t.cur];
+        A.Vout[b] = t.V[t.cur ^ 1]; A.Mout[b] = t.M[t.cur ^ 1];
+        A.n[b] = t.len;
+        collapsed[b] = (first && t.len == 1) || (!first && t.len == 2);     // the reference's `total == 1` case
         const uint64_t npairs = first ? t.len / 2 : t.len / 4;
-        const uint32_t g = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks / 2);
-        ZK_LAUNCH(PC_ROUND_QUAD, (first ? 64.0 : 96.0) * (double) t.len, k_round_quad, dim3(g), dim3(ZK_BLOCK), t.V[t.cur], t.M[t.cur], t.V[t.cur ^ 1], t.M[t.cur ^ 1], t.len, to_dev(r), first ? 1 : 0, ctx->partials + 3 * (size_t) nb);
-        nb += g;
-        if (!first) { t.cur ^= 1; t.len >>= 1; }
+        A.blocks[b] = collapsed[b] ? 1 : std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks / 2);
+        alg_bytes += (first ? 64.0 : 96.0) * (double) t.len;
     }
-    if (nb) ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials<3>, dim3(1), dim3(ZK_BLOCK), ctx->d_result, ctx->partials, nb, 0);
-    else ZK_HIP(hipMemsetAsync(ctx->d_result, 0, 3 * 32, ctx->stream));
-    ZK_HIP(hipGetLastError());
-    int32_t rc = fetch_result(ctx, 8);
-    if (rc) return rc;
+    if (A.blocks[0] + A.blocks[1] == 0) {
+        for (int k = 0; k < 3; ++k) ctx->h_result[k].clear();
+    } else {
+        A.r = to_dev(r);
+        A.first = first ? 1 : 0;
+        A.partials = ctx->partials;
+        A.counter = ctx->d_counter;
+        A.slot = (host_slot *) ctx->d_slot;
+        A.seq = ++ctx->slot_seq;
+        ZK_LAUNCH(PC_ROUND_QUAD, alg_bytes, k_round_quad2, dim3(A.blocks[0] + A.blocks[1]), dim3(ZK_BLOCK), A);
+        ZK_HIP(hipGetLastError());
+        for (int b = 0; b < 2; ++b) {
+            table_pair &t = ctx->tp[b];
+            if (t.len && !first) { t.cur ^= 1; t.len >>= 1; }
+        }
+        int32_t rc = wait_slot(ctx, A.seq);
+        if (rc) return rc;
+        for (int k = 0; k < 8; ++k) ctx->h_result[k] = ctx->h_slot->v[k];
+    }
     HFr a = ctx->h_result[0], c = ctx->h_result[1], p1 = ctx->h_result[2];
     HFr bcoef = p1 - a - c;
     for (int b = 0; b < 2; ++b)
@@ -779,22 +820,27 @@ extern "C" int32_t zk_sumcheck_liu_update(zk_ctx *ctx, const uint64_t prev_r[4],
 // final evaluations of the two V tables (reference src/prover.cpp:459-485)
 static int32_t final_claims(zk_ctx *ctx, const HFr &r, const int8_t bl[2], HFr out[2]) {
     bool pending[2] = {false, false};
+    eval_args E;
+    std::memset(&E, 0, sizeof(E));
     for (int b = 0; b < 2; ++b) {
         table_pair &t = ctx->tp[b];
         out[b].clear();
-        if (t.len >= 2) {
-            int32_t rc = fold_pair(ctx, t, r, false);
-            if (rc) return rc;
-        }
-        if (t.len == 1) {
-            ZK_HIP(hipMemcpyAsync(ctx->d_result + b, t.V[t.cur], 32, hipMemcpyDeviceToDevice, ctx->stream));
+        if (t.len > 2) return ZK_ERR_STATE;
+        if (t.len >= 1) {
+            E.p[b] = t.V[t.cur];
+            E.n[b] = (uint32_t) t.len;
             pending[b] = true;
         } else if (t.absorbed && bl[b] >= 0) out[b] = t.final_v;
     }
     if (pending[0] || pending[1]) {
-        int32_t rc = fetch_result(ctx, 2);
+        E.r = to_dev(r);
+        E.slot = (host_slot *) ctx->d_slot;
+        E.seq = ++ctx->slot_seq;
+        ZK_LAUNCH(PC_FOLD, 0.0, k_eval_pairs, dim3(1), dim3(64), E);
+        ZK_HIP(hipGetLastError());
+        int32_t rc = wait_slot(ctx, E.seq);
         if (rc) return rc;
-        for (int b = 0; b < 2; ++b) if (pending[b]) out[b] = ctx->h_result[b];
+        for (int b = 0; b < 2; ++b) if (pending[b]) out[b] = ctx->h_slot->v[b];
     }
     for (int b = 0; b < 2; ++b) ctx->tp[b].len = 0;
     return ZK_OK;
