@@ -45,38 +45,24 @@ struct eq_args {
     int32_t npoints, fh, sh;
 };
 
-// single block: lo[p] = init_p * eq(r_p[0..fh), .),  hi[p] = eq(r_p[fh..fh+sh), .)
-// lo tables are `lo_stride` apart, hi tables `hi_stride` apart.
+// one block per (point, half): lo[p] = init_p * eq(r_p[0..fh), .),  hi[p] = eq(r_p[fh..fh+sh), .)
+// lo tables are `lo_stride` apart, hi tables `hi_stride` apart. The four doubling chains are independent.
 __global__ void __launch_bounds__(1024) k_eq_halves(fr_t *lo, fr_t *hi, uint32_t lo_stride, uint32_t hi_stride, eq_args a) {
-    for (int p = 0; p < a.npoints; ++p) {
-        fr_t *L = lo + (size_t) p * lo_stride, *H = hi + (size_t) p * hi_stride;
-        if (threadIdx.x == 0) {
-            fr_store(L, a.init[p]);
-            fr_store(H, fr_one());
+    const int p = blockIdx.x >> 1, is_hi = blockIdx.x & 1;
+    fr_t *T = is_hi ? hi + (size_t) p * hi_stride : lo + (size_t) p * lo_stride;
+    const int steps = is_hi ? a.sh : a.fh, base = is_hi ? a.fh : 0;
+    if (threadIdx.x == 0) fr_store(T, is_hi ? fr_one() : a.init[p]);
+    __syncthreads();
+    for (int i = 0; i < steps; ++i) {
+        const uint32_t half = 1u << i;
+        const fr_t ri = a.r[p].v[base + i];
+        for (uint32_t j = threadIdx.x; j < half; j += blockDim.x) {
+            fr_t cur = fr_load(T + j);
+            fr_t t = fr_mul(cur, ri);
+            fr_store(T + (j | half), t);
+            fr_store(T + j, fr_sub(cur, t));
         }
         __syncthreads();
-        for (int i = 0; i < a.fh; ++i) {
-            const uint32_t half = 1u << i;
-            const fr_t ri = a.r[p].v[i];
-            for (uint32_t j = threadIdx.x; j < half; j += blockDim.x) {
-                fr_t cur = fr_load(L + j);
-                fr_t t = fr_mul(cur, ri);
-                fr_store(L + (j | half), t);
-                fr_store(L + j, fr_sub(cur, t));
-            }
-            __syncthreads();
-        }
-        for (int i = 0; i < a.sh; ++i) {
-            const uint32_t half = 1u << i;
-            const fr_t ri = a.r[p].v[a.fh + i];
-            for (uint32_t j = threadIdx.x; j < half; j += blockDim.x) {
-                fr_t cur = fr_load(H + j);
-                fr_t t = fr_mul(cur, ri);
-                fr_store(H + (j | half), t);
-                fr_store(H + j, fr_sub(cur, t));
-            }
-            __syncthreads();
-        }
     }
 }
 
@@ -315,8 +301,9 @@ struct host_slot {
 
 template <int K>
 __device__ __forceinline__ void grid_finish(fr_t (&acc)[K], fr_t *partials, uint32_t *counter, host_slot *slot,
-                                            unsigned long long seq, fr_t *smem) {
+                                            unsigned long long seq, fr_t *smem, bool wrote_slot = false) {
     __shared__ int s_last;
+    (void) smem;
     if (gridDim.x == 1) {                                // small tables: this block already holds the grid total
         if (threadIdx.x == 0) {
 #pragma unroll
@@ -329,23 +316,25 @@ __device__ __forceinline__ void grid_finish(fr_t (&acc)[K], fr_t *partials, uint
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < K; ++k) fr_store(partials + (size_t) K * blockIdx.x + k, acc[k]);
-        __threadfence_system();                          // release: partials (and any slot values) before the ticket
+        if (wrote_slot) __threadfence_system();          // release (host-visible values were written by this block)
+        else __threadfence();                            // release: partials before the ticket
         const uint32_t t = atomicAdd(counter, 1u);
         s_last = (t == gridDim.x - 1);
     }
     __syncthreads();
     if (!s_last) return;
     __threadfence();                                     // acquire: this CU's L1 may hold last round's partials
-    fr_t tot[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) tot[k] = fr_zero();
-    for (uint32_t b = threadIdx.x; b < gridDim.x; b += blockDim.x)
-#pragma unroll
-        for (int k = 0; k < K; ++k) tot[k] = fr_add(tot[k], fr_load(partials + (size_t) K * b + k));
-    fr_block_sum<K>(tot, smem);
+    // wave k sums accumulator k over all blocks (lane-strided), one 6-step butterfly each
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave < K) {
+        fr_t tot = fr_zero();
+        for (uint32_t b = lane; b < gridDim.x; b += 64) tot = fr_add(tot, fr_load(partials + (size_t) K * b + wave));
+        tot = fr_wave_sum(tot);
+        if (lane == 0) fr_store(&slot->v[wave], tot);
+    }
+    __threadfence_system();
+    __syncthreads();
     if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) fr_store(&slot->v[k], tot[k]);
         *counter = 0;
         __threadfence_system();
         *((volatile unsigned long long *) &slot->seq) = seq;
@@ -359,6 +348,7 @@ struct round2_args {
     uint32_t blocks[2];         // blocks working on each pair (grid.x = blocks[0] + blocks[1])
     fr_t r;
     int32_t first;
+    int32_t fine;               // small tables: 4 lanes per quad so that the dependent chain is 2 multiplications, not 7
     fr_t *partials;
     uint32_t *counter;
     host_slot *slot;
@@ -415,7 +405,89 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad2(round2_args a) {
     }
     fr_block_sum<3>(acc, smem);
     __syncthreads();
-    grid_finish<3>(acc, a.partials, a.counter, a.slot, a.seq, smem);
+    grid_finish<3>(acc, a.partials, a.counter, a.slot, a.seq, smem, collapse);
+}
+
+// Latency-oriented variant for the many small rounds of the interactive loop (tables up to 2^16 entries).
+// Items of both table pairs are concatenated; lane = 4 * item + role:
+//   fold     role 0: v0 = lerp(V[4q], V[4q+1])   1: v1 = lerp(V[4q+2], V[4q+3])   2: m0   3: m1     (one multiply deep)
+//   product  role 0: c = v0 m0                   1: p1 = v1 m1                    2: a = (v1 - v0)(m1 - m0)  (one more)
+// followed by a 4-step butterfly over lanes of equal role. A pair that collapses this round is one item whose
+// roles 0 and 2 produce the final V and M values (the reference's `total == 1` case).
+__global__ void __launch_bounds__(ZK_BLOCK) k_round_quad_fine(round2_args a) {
+    __shared__ fr_t smem[3 * ZK_BLOCK / 64];
+    __shared__ fr_t s_role[3][ZK_BLOCK / 64];
+    uint64_t items[2];
+    bool collapse[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        collapse[b] = a.n[b] && (a.first ? a.n[b] == 1 : a.n[b] == 2);
+        items[b] = !a.n[b] ? 0 : collapse[b] ? 1 : (a.first ? a.n[b] / 2 : a.n[b] / 4);
+    }
+    const uint64_t gi = blockIdx.x * (uint64_t) (ZK_BLOCK / 4) + (threadIdx.x >> 2);
+    const uint32_t role = threadIdx.x & 3;
+    const bool live = gi < items[0] + items[1];
+    const int b = (live && gi >= items[0]) ? 1 : 0;
+    const uint64_t q = b ? gi - items[0] : gi;
+    const fr_t *Vin = a.Vin[b], *Min = a.Min[b];
+    fr_t X = fr_zero(), opA = fr_zero(), opB = fr_zero();
+    const bool special = live && collapse[b];
+    if (special) {
+        if (role == 0 || role == 2) {
+            const fr_t *src = role == 0 ? Vin : Min;
+            fr_t v = fr_load(src);
+            if (!a.first) {
+                v = fr_lerp(v, fr_load(src + 1), a.r);
+                fr_store(role == 0 ? a.Vout[b] : a.Mout[b], v);
+            }
+            fr_store(&a.slot->v[4 + 2 * b + (role >> 1)], v);
+        }
+    } else if (a.first) {
+        if (live && role < 3) {
+            const fr_t v0 = fr_load(Vin + 2 * q), v1 = fr_load(Vin + 2 * q + 1), m0 = fr_load(Min + 2 * q), m1 = fr_load(Min + 2 * q + 1);
+            opA = role == 0 ? v0 : role == 1 ? v1 : fr_sub(v1, v0);
+            opB = role == 0 ? m0 : role == 1 ? m1 : fr_sub(m1, m0);
+        }
+    } else if (live) {
+        const fr_t *src = (role < 2 ? Vin : Min) + 4 * q + 2 * (role & 1);
+        X = fr_lerp(fr_load(src), fr_load(src + 1), a.r);
+        fr_store((role < 2 ? a.Vout[b] : a.Mout[b]) + 2 * q + (role & 1), X);
+    }
+    if (!a.first) {
+        fr_t y1, y2, y3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            y1.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 2, 64);
+            y2.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 1, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y3.v[i] = (uint32_t) __shfl_xor((int) y1.v[i], 1, 64);
+        // role 0: X = v0, y1 = m0;  role 1: X = v1, y1 = m1;  role 2: X = m0, y1 = v0, y2 = m1, y3 = v1
+        opA = role == 2 ? fr_sub(y3, y1) : X;
+        opB = role == 2 ? fr_sub(y2, X) : y1;
+        if (role == 3 || !live || special) { opA = fr_zero(); opB = fr_zero(); }
+    }
+    fr_t prod = fr_mul(opA, opB);
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) {
+        fr_t o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.v[i] = (uint32_t) __shfl_xor((int) prod.v[i], off, 64);
+        prod = fr_add(prod, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 3) s_role[lane][wave] = prod;
+    __syncthreads();
+    fr_t acc[3] = {fr_zero(), fr_zero(), fr_zero()};       // a, c, p(1)
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < ZK_BLOCK / 64; ++w) {
+            acc[1] = fr_add(acc[1], s_role[0][w]);
+            acc[2] = fr_add(acc[2], s_role[1][w]);
+            acc[0] = fr_add(acc[0], s_role[2][w]);
+        }
+    }
+    grid_finish<3>(acc, a.partials, a.counter, a.slot, a.seq, smem, collapse[0] || collapse[1]);
 }
 
 // up to four "evaluate the last variable" requests in one tiny launch: out[i] = n == 2 ? lerp(p[0], p[1], r) : p[0]

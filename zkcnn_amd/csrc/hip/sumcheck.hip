@@ -317,7 +317,7 @@ static int32_t eq_table(zk_ctx *ctx, fr_t *out, int n, const HFr *r0, const HFr 
         ZK_HIP(hipMemsetAsync(out, 0, len * 32, ctx->stream));
         return ZK_OK;
     }
-    ZK_LAUNCH(PC_EQ, 0.0, k_eq_halves, dim3(1), dim3(1024), ctx->eq_lo, ctx->eq_hi, ctx->eq_stride, ctx->eq_stride, A);
+    ZK_LAUNCH(PC_EQ, 0.0, k_eq_halves, dim3(2 * A.npoints), dim3(1024), ctx->eq_lo, ctx->eq_hi, ctx->eq_stride, ctx->eq_stride, A);
     ZK_LAUNCH(PC_EQ, 0.0, k_eq_expand, dim3(grid_for(len)), dim3(ZK_BLOCK), out, ctx->eq_lo, ctx->eq_hi, ctx->eq_stride, ctx->eq_stride, A.npoints, A.fh, len, tail_start, to_dev(tail_scale));
     ZK_HIP(hipGetLastError());
     return ZK_OK;
@@ -751,6 +751,10 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
     round2_args A;
     std::memset(&A, 0, sizeof(A));
     double alg_bytes = 0;
+    // small tables are latency bound: spread each quad over 4 lanes (k_round_quad2, `fine`)
+    const bool fine = std::max(ctx->tp[0].len, ctx->tp[1].len) <= (1ull << 18);
+    A.fine = fine ? 1 : 0;
+    uint64_t fine_items = 0;
     for (int b = 0; b < 2; ++b) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
@@ -760,6 +764,7 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         collapsed[b] = (first && t.len == 1) || (!first && t.len == 2);     // the reference's `total == 1` case
         const uint64_t npairs = first ? t.len / 2 : t.len / 4;
         A.blocks[b] = collapsed[b] ? 1 : std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks / 2);
+        fine_items += collapsed[b] ? 1 : npairs;
         alg_bytes += (first ? 64.0 : 96.0) * (double) t.len;
     }
     if (A.blocks[0] + A.blocks[1] == 0) {
@@ -771,7 +776,10 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         A.counter = ctx->d_counter;
         A.slot = (host_slot *) ctx->d_slot;
         A.seq = ++ctx->slot_seq;
-        ZK_LAUNCH(PC_ROUND_QUAD, alg_bytes, k_round_quad2, dim3(A.blocks[0] + A.blocks[1]), dim3(ZK_BLOCK), A);
+        if (fine) {
+            const uint32_t blocks = (uint32_t) ((fine_items + ZK_BLOCK / 4 - 1) / (ZK_BLOCK / 4));
+            ZK_LAUNCH(PC_ROUND_QUAD, alg_bytes, k_round_quad_fine, dim3(blocks), dim3(ZK_BLOCK), A);
+        } else ZK_LAUNCH(PC_ROUND_QUAD, alg_bytes, k_round_quad2, dim3(A.blocks[0] + A.blocks[1]), dim3(ZK_BLOCK), A);
         ZK_HIP(hipGetLastError());
         for (int b = 0; b < 2; ++b) {
             table_pair &t = ctx->tp[b];
