@@ -87,7 +87,8 @@ int32_t zk_commit_input(zk_ctx *ctx, const uint64_t *gens, uint64_t n_gens, uint
 int32_t zk_hyrax_open_init(zk_ctx *ctx, const uint64_t *x, uint32_t n);
 int32_t zk_hyrax_open_round(zk_ctx *ctx, uint64_t L[12], uint64_t R[12], uint64_t yL[4], uint64_t yR[4]);
 int32_t zk_hyrax_open_fold(zk_ctx *ctx, const uint64_t c[4]);
-int32_t zk_hyrax_open_final(zk_ctx *ctx, uint64_t a[4]);
+/* the vector left when the recursion stops (at most `cap` elements are written; *n = its length) */
+int32_t zk_hyrax_open_final(zk_ctx *ctx, uint64_t *a, uint32_t cap, uint32_t *n);
 
 /* ---- built-in profiler: HIP events around every launch of the selected kernel classes, on the context's stream ---- */
 /* class_mask: bit i selects class i of zk_profile_report's list; 0 switches profiling off; ~0u selects all */

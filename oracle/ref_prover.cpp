@@ -432,9 +432,9 @@ void polyProverCPU::openFold(const Fr &c) {
     pt.stop();
 }
 
-Fr polyProverCPU::openFinal() {
-    ps_bytes += 32;
-    return a[0];
+std::vector<Fr> polyProverCPU::openFinal() {
+    ps_bytes += 32 * a.size();
+    return a;
 }
 
 } // namespace oracle

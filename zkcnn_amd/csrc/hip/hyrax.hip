@@ -539,12 +539,14 @@ extern "C" int32_t zk_hyrax_open_fold(zk_ctx *ctx, const uint64_t c[4]) {
     return ZK_OK;
 }
 
-extern "C" int32_t zk_hyrax_open_final(zk_ctx *ctx, uint64_t a[4]) {
+extern "C" int32_t zk_hyrax_open_final(zk_ctx *ctx, uint64_t *a, uint32_t cap, uint32_t *n) {
     CHECK_READY();
     msm_state *s = ctx->msm;
-    if (!s || s->len != 1) return ZK_ERR_STATE;
-    ZK_HIP(hipMemcpyAsync(a, s->a, 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (!s || !s->len || !a || !n) return ZK_ERR_STATE;
+    if (s->len > cap) { ctx->err = "open_final: buffer too small"; return ZK_ERR_ARG; }
+    ZK_HIP(hipMemcpyAsync(a, s->a, (size_t) s->len * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
+    *n = s->len;
     return ZK_OK;
 }
 

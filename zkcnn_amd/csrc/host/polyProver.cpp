@@ -52,11 +52,13 @@ void polyProver::openFold(const Fr &c) {
     pt.stop();
 }
 
-Fr polyProver::openFinal() {
+std::vector<Fr> polyProver::openFinal() {
     pt.start();
-    Fr a;
-    must(ctx, zk_hyrax_open_final(ctx, reinterpret_cast<uint64_t *>(&a)), "zk_hyrax_open_final");
-    ps_bytes += 32;
+    std::vector<Fr> a(IPA_STOP_LEN);
+    uint32_t n = 0;
+    must(ctx, zk_hyrax_open_final(ctx, reinterpret_cast<uint64_t *>(a.data()), (uint32_t) a.size(), &n), "zk_hyrax_open_final");
+    a.resize(n);
+    ps_bytes += 32ull * n;
     pt.stop();
     return a;
 }

@@ -15,7 +15,7 @@ public:
     void openInit(const std::vector<Fr> &x) override;
     ipaRoundMsg openRound() override;
     void openFold(const Fr &c) override;
-    Fr openFinal() override;
+    std::vector<Fr> openFinal() override;
     double getPT() const override { return pt.elapse_sec(); }
     double getPS() const override { return (double) ps_bytes / 1024.0; }
 
