@@ -29,6 +29,8 @@ WORKLOADS = {
     "vgg11": ("vgg11", (32, 32, 3), 1),
     "lenet": ("lenet", (32, 32, 1), 1),
     "vgg16": ("vgg16", (32, 32, 3), 1),
+    "vgg11_pp8": ("vgg11", (32, 32, 3), 8),      # 8 pictures folded into ONE circuit (the reference's pic_cnt = 8; FFT convolutions)
+    "vgg16_pp4": ("vgg16", (32, 32, 3), 4),
     # bounded CPU sample: vgg11 with every channel width divided by 4 (1/16 of the multiplication gates)
     "vgg11_quarter": ("vgg:16 M 32 M 64 64 M 128 128 M 128 128 M", (32, 32, 3), 1),
 }

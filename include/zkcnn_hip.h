@@ -90,6 +90,16 @@ int32_t zk_hyrax_open_fold(zk_ctx *ctx, const uint64_t c[4]);
 /* the vector left when the recursion stops (at most `cap` elements are written; *n = its length) */
 int32_t zk_hyrax_open_final(zk_ctx *ctx, uint64_t *a, uint32_t cap, uint32_t *n);
 
+/* ---- witness side of the FFT convolution (reference src/neuralNetwork.cpp:937-965, src/utils.cpp:105-145) ------------ */
+/* `count` transforms of length 2^logn. Forward (inverse = 0): every input block has in_len = 2^(logn-1) elements and is zero
+ * padded, all 2^logn outputs are written. Inverse: 2^logn inputs, scaled by 1/2^logn, the first 2^(logn-1) outputs are written.
+ * src / dst are host arrays (calcFFTLayer's val[layer-1] / val[layer]). */
+int32_t zk_witness_ntt(zk_ctx *ctx, uint64_t *dst, const uint64_t *src, int32_t logn, int32_t inverse, uint64_t count);
+/* calcDotProdLayer: out[(g, t)] = sum over the layer's bin gates (g, u, v) of F[(u, t)] * F[(v, t)], t < 2^fft_bl.
+ * F = val[layer-1] (n_in vectors), out = val[layer] (n_out vectors), host arrays. */
+int32_t zk_witness_dotprod(zk_ctx *ctx, uint64_t *out, uint64_t n_out, const uint64_t *F, uint64_t n_in, const zk_bin_gate *gates,
+                           uint64_t n_gates, int32_t fft_bl);
+
 /* ---- built-in profiler: HIP events around every launch of the selected kernel classes, on the context's stream ---- */
 /* class_mask: bit i selects class i of zk_profile_report's list; 0 switches profiling off; ~0u selects all */
 int32_t zk_profile_enable(zk_ctx *ctx, uint32_t class_mask);

@@ -119,3 +119,22 @@ def test_commit_rows_digit_table_and_high_byte_rows(hip, oracle):
     for r in range(rows):
         assert np.array_equal(got[r], oracle.msm(sc[r * cols:(r + 1) * cols], bases)), f"row {r}"
     assert not got[7].any()
+
+
+@pytest.mark.parametrize("logn", [1, 2, 5, 9, 12])
+def test_batched_ntt_matches_reference_fft(hip, oracle, logn):
+    """K9 against the oracle's restatement of reference src/utils.cpp:105-145, used as calcFFTLayer uses it:
+    forward = zero-padded half-length inputs, inverse = scaled, first half kept; and inverse(forward(x)) == x"""
+    length, count = 1 << logn, 7 if logn < 12 else 3
+    half = length // 2
+    x = oracle.random(count * half, 400 + logn)
+    padded = np.zeros((count * length, 4), dtype=np.uint64)
+    for c in range(count):
+        padded[c * length:c * length + half] = x[c * half:(c + 1) * half]
+    fwd = hip.witness_ntt(x, logn, False, count)
+    assert np.array_equal(fwd, oracle.ntt(padded, logn, False))
+    back = hip.witness_ntt(fwd, logn, True, count)
+    full_back = oracle.ntt(fwd, logn, True)
+    for c in range(count):
+        assert np.array_equal(back[c * half:(c + 1) * half], full_back[c * length:c * length + half])
+    assert np.array_equal(back, x)

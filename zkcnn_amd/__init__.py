@@ -156,6 +156,15 @@ class HipContext:
         self._check(self.lib.zk_k_msm(self.ctx, u64p(out), u64p(scalars), u64p(bases), ctypes.c_uint64(scalars.shape[0])), "zk_k_msm")
         return out
 
+    def witness_ntt(self, src, logn, inverse, count):
+        """count transforms of length 2^logn (forward: half-length inputs zero padded; inverse: first half kept)"""
+        length = 1 << logn
+        out_len = length // 2 if inverse else length
+        dst = np.zeros((count * out_len, 4), dtype=np.uint64)
+        self._check(self.lib.zk_witness_ntt(self.ctx, u64p(dst), u64p(src), ctypes.c_int32(logn), ctypes.c_int32(int(inverse)),
+                                            ctypes.c_uint64(count)), "zk_witness_ntt")
+        return dst
+
     def commit_rows(self, scalars, bases, rows, cols):
         out = np.zeros((rows, 12), dtype=np.uint64)
         self._check(self.lib.zk_k_commit_rows(self.ctx, u64p(out), u64p(scalars), u64p(bases), ctypes.c_uint64(rows), ctypes.c_uint64(cols)),

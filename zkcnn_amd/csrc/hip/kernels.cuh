@@ -643,3 +643,50 @@ __global__ void k_col_combine(fr_t *out, const fr_t *Z, const fr_t *L, uint32_t 
     for (uint32_t i = i0; i < i1; ++i) acc = fr_add(acc, fr_mul(fr_load(Z + (size_t) i * cols + j), fr_load(L + i)));
     fr_store(out + (size_t) blockIdx.y * cols + j, acc);
 }
+
+// ------------------------------------------------------------------------------------------------
+// K9: batched NTT / inverse NTT, one transform per block, LDS resident (2^12 x 32 B = 128 KiB <= 160 KiB).
+// reference src/utils.cpp:105-145 (`fft`) as used by calcFFTLayer, src/neuralNetwork.cpp:950-965:
+//   forward: `in_len` = len/2 input elements are zero padded to len, all len outputs are kept;
+//   inverse: len inputs, multiplied by 1/len, the first `out_len` = len/2 outputs are kept.
+// pw = powers of the 2^logn-th root of unity (or of its inverse). Radix-2 decimation in time:
+// bit-reversed load, then logn butterfly stages separated by workgroup barriers.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_ntt_batch(fr_t *dst, const fr_t *src, const fr_t *pw, int logn, uint32_t in_len, uint32_t out_len, fr_t scale,
+                            int apply_scale) {
+    extern __shared__ __align__(16) unsigned char ntt_lds_raw[];
+    fr_t *buf = reinterpret_cast<fr_t *>(ntt_lds_raw);
+    const uint32_t len = 1u << logn;
+    const fr_t *in = src + (size_t) blockIdx.x * in_len;
+    fr_t *out = dst + (size_t) blockIdx.x * out_len;
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+        const uint32_t rev = __brev(i) >> (32 - logn);
+        buf[rev] = i < in_len ? fr_load(in + i) : fr_zero();
+    }
+    __syncthreads();
+    for (int s = 0; s < logn; ++s) {
+        const uint32_t half = 1u << s, step = len >> (s + 1);
+        for (uint32_t k = threadIdx.x; k < (len >> 1); k += blockDim.x) {
+            const uint32_t j = k & (half - 1), base = (k >> s) << (s + 1);
+            const fr_t lo = buf[base + j];
+            const fr_t hi = fr_mul(buf[base + j + half], fr_load(pw + (size_t) step * j));
+            buf[base + j] = fr_add(lo, hi);
+            buf[base + j + half] = fr_sub(lo, hi);
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < out_len; i += blockDim.x) fr_store(out + i, apply_scale ? fr_mul(buf[i], scale) : buf[i]);
+}
+
+// K10: witness of the DOT_PROD layer, out[(g, t)] = sum_{gates of g} F[(u, t)] * F[(v, t)]
+// reference src/neuralNetwork.cpp:937-948 (calcDotProdLayer). Gates sorted by g with CSR row pointers.
+__global__ void k_dot_witness(fr_t *out, const fr_t *F, const gate_rec *recs, const uint32_t *row_ptr, int fft_bl) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (t >= (1u << fft_bl)) return;
+    fr_t acc = fr_zero();
+    for (uint32_t e = row_ptr[g]; e < row_ptr[g + 1]; ++e) {
+        const gate_rec rc = recs[e];
+        acc = fr_add(acc, fr_mul(fr_load(F + (((size_t) rc.key) << fft_bl) + t), fr_load(F + (((size_t) rc.aux) << fft_bl) + t)));
+    }
+    fr_store(out + (((size_t) g) << fft_bl) + t, acc);
+}

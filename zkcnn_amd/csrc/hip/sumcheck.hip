@@ -1009,6 +1009,80 @@ extern "C" int32_t zk_k_round_quadratic(zk_ctx *ctx, uint64_t *V, uint64_t *M, u
     return ZK_OK;
 }
 
+// ---- witness kernels of the FFT convolution (host arrays in / out) ----
+extern "C" int32_t zk_witness_ntt(zk_ctx *ctx, uint64_t *dst, const uint64_t *src, int32_t logn, int32_t inverse, uint64_t count) {
+    CHECK_CTX();
+    if (logn < 1 || logn > 12 || !count) return ZK_ERR_ARG;        // 2^12 x 32 B = 128 KiB is what fits in LDS
+    const uint32_t len = 1u << logn, in_len = inverse ? len : len / 2, out_len = inverse ? len / 2 : len;
+    fr_t *pw = powers_of_root(ctx, logn, inverse != 0);
+    if (!pw) { ctx->err = "root table allocation failed"; return ZK_ERR_NOMEM; }
+    const size_t in_bytes = (size_t) count * in_len * 32, out_bytes = (size_t) count * out_len * 32;
+    int32_t rc = zk_scratch(ctx, in_bytes + out_bytes);
+    if (rc) return rc;
+    fr_t *d_in = (fr_t *) ctx->scratch.p, *d_out = d_in + (size_t) count * in_len;
+    ZK_HIP(hipMemcpyAsync(d_in, src, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HFr ilen;
+    HFr::inv(ilen, HFr((unsigned long long) len));
+    const size_t lds = (size_t) len * 32;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_batch), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+    }
+    const uint32_t threads = std::min<uint32_t>(1024, std::max<uint32_t>(64, len / 2));
+    for (uint64_t b0 = 0; b0 < count; b0 += 1u << 30) {
+        const uint32_t nb = (uint32_t) std::min<uint64_t>(1u << 30, count - b0);
+        prof_begin(ctx, PC_MISC, 64.0 * len * nb);
+        hipLaunchKernelGGL(k_ntt_batch, dim3(nb), dim3(threads), lds, ctx->stream, d_out + b0 * out_len, d_in + b0 * in_len, pw, logn, in_len,
+                           out_len, to_dev(ilen), inverse ? 1 : 0);
+        prof_end(ctx, PC_MISC);
+    }
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpyAsync(dst, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_witness_dotprod(zk_ctx *ctx, uint64_t *out, uint64_t n_out, const uint64_t *F, uint64_t n_in,
+                                      const zk_bin_gate *gates, uint64_t n_gates, int32_t fft_bl) {
+    CHECK_CTX();
+    if (fft_bl < 1 || fft_bl > 20 || !n_out || !n_in) return ZK_ERR_ARG;
+    std::vector<gate_rec> recs(n_gates);
+    for (uint64_t k = 0; k < n_gates; ++k) {
+        if (gates[k].g >= n_out || gates[k].u >= n_in || gates[k].v >= n_in) { ctx->err = "dot-prod gate out of range"; return ZK_ERR_ARG; }
+        gate_rec r = {gates[k].g, gates[k].u, gates[k].v, 0};      // key = u, aux = v for this kernel
+        recs[k] = r;
+    }
+    // CSR by output vector g (stable: order inside a row does not matter, the sum is exact)
+    std::vector<uint32_t> ptr(n_out + 1, 0);
+    for (const gate_rec &r : recs) ++ptr[r.g + 1];
+    for (uint64_t g = 0; g < n_out; ++g) ptr[g + 1] += ptr[g];
+    std::vector<gate_rec> sorted(n_gates);
+    {
+        std::vector<uint32_t> pos(ptr.begin(), ptr.end() - 1);
+        for (const gate_rec &r : recs) sorted[pos[r.g]++] = r;
+    }
+    const size_t len = (size_t) 1 << fft_bl;
+    const size_t bytes = (n_in + n_out) * len * 32 + n_gates * sizeof(gate_rec) + (n_out + 1) * 4 + 64;
+    int32_t rc = zk_scratch(ctx, bytes);
+    if (rc) return rc;
+    fr_t *dF = (fr_t *) ctx->scratch.p, *dO = dF + n_in * len;
+    gate_rec *dR = (gate_rec *) (dO + n_out * len);
+    uint32_t *dP = (uint32_t *) (dR + n_gates);
+    ZK_HIP(hipMemcpyAsync(dF, F, n_in * len * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(dR, sorted.data(), n_gates * sizeof(gate_rec), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(dP, ptr.data(), (n_out + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    for (uint64_t g0 = 0; g0 < n_out; g0 += 32768) {
+        const uint32_t ng = (uint32_t) std::min<uint64_t>(32768, n_out - g0);
+        dim3 grid((uint32_t) ((len + ZK_BLOCK - 1) / ZK_BLOCK), ng);
+        ZK_LAUNCH(PC_DOT, 0.0, k_dot_witness, grid, dim3(ZK_BLOCK), dO + g0 * len, dF, dR, dP + g0, fft_bl);
+    }
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpyAsync(out, dO, n_out * len * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
 // ---- micro-benchmarks (device resident, HIP events on the context's stream) ----
 template <class Launch>
 static int32_t time_launches(zk_ctx *ctx, uint32_t iters, double *sec, Launch launch) {

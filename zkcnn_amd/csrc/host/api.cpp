@@ -1,7 +1,31 @@
 // C entry points of libzkcnn_host.so (include/zkcnn_api.h): circuit + witness on the host, the
 // prover on the GPU, the reference verifier driving it.
+#include <stdexcept>
 #include "session.hpp"
 #include "verifier_alias.hpp"
+
+// witness kernels of the FFT convolution on the GPU (include/zkcnn_hip.h: zk_witness_ntt / zk_witness_dotprod)
+class hipWitnessAccel : public witnessAccel {
+public:
+    explicit hipWitnessAccel(int device) : ctx(nullptr) {
+        if (zk_ctx_create(device, &ctx) != ZK_OK) throw std::runtime_error(string("zk_ctx_create: ") + zk_last_error(nullptr));
+    }
+    ~hipWitnessAccel() override { if (ctx) zk_ctx_destroy(ctx); }
+    bool ntt(F *dst, const F *src, int logn, bool inverse, size_t count) override {
+        if (logn > 12) return false;                 // longer transforms do not fit in LDS; the host loop takes them
+        int rc = zk_witness_ntt(ctx, reinterpret_cast<uint64_t *>(dst), reinterpret_cast<const uint64_t *>(src), logn, inverse, count);
+        if (rc != ZK_OK) throw std::runtime_error(string("zk_witness_ntt: ") + zk_last_error(ctx));
+        return true;
+    }
+    bool dotProd(F *out, size_t n_out, const F *in, size_t n_in, const binGate *gates, size_t n_gates, int fft_bl) override {
+        int rc = zk_witness_dotprod(ctx, reinterpret_cast<uint64_t *>(out), n_out, reinterpret_cast<const uint64_t *>(in), n_in,
+                                    reinterpret_cast<const zk_bin_gate *>(gates), n_gates, fft_bl);
+        if (rc != ZK_OK) throw std::runtime_error(string("zk_witness_dotprod: ") + zk_last_error(ctx));
+        return true;
+    }
+private:
+    zk_ctx *ctx;
+};
 
 struct gpuSession : public sessionT<prover> {
     explicit gpuSession(int device) : dev(device) {}
@@ -17,7 +41,13 @@ void *zkcnn_session_create(const zkcnn_model_desc *desc, int32_t device) {
         // placement-new the prover on the requested device: sessionT owns a default-constructed one
         s->p.~prover();
         new (&s->p) prover(device);
-        if (!s->build(desc)) { delete s; return nullptr; }
+        {
+            hipWitnessAccel accel(device);
+            s->accel = &accel;
+            bool ok = s->build(desc);
+            s->accel = nullptr;
+            if (!ok) { delete s; return nullptr; }
+        }
         s->p.init();                 // residency: circuit + witness to HBM, outside any timed region
         return s;
     } catch (const std::exception &e) {

@@ -303,6 +303,8 @@ void neuralNetwork::evalDotProd(const layer &L, i64 layer_id) {
     const int fb = L.fft_bit_length;
     const u32 len = 1u << fb;
     const auto &prev = val[layer_id - 1];
+    if (accel && accel->dotProd(out.data(), out.size() >> fb, prev.data(), prev.size() >> fb, L.bin_gates.data(), L.bin_gates.size(), fb))
+        return;
     for (const binGate &gt : L.bin_gates) {
         F *o = &out[(size_t) gt.g << fb];
         const F *a = &prev[(size_t) gt.u << fb], *b = &prev[(size_t) gt.v << fb];
@@ -318,6 +320,11 @@ void neuralNetwork::evalTransform(const layer &L, i64 layer_id) {
     auto &out = val[layer_id];
     const auto &prev = val[layer_id - 1];
     out.assign(L.size, F_ZERO);
+    if (accel) {
+        const bool inv = L.ty == layerType::IFFT;
+        const size_t count = inv ? L.size / lenh : L.size / len;
+        if (prev.size() >= count * (inv ? len : lenh) && accel->ntt(out.data(), prev.data(), L.fft_bit_length, inv, count)) return;
+    }
     vector<F> arr(len);
     if (L.ty == layerType::FFT) {
         for (size_t c = 0, d = 0; d < L.size; c += lenh, d += len) {

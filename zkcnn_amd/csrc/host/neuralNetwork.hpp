@@ -41,6 +41,18 @@ public:
     virtual double next(kind k, i64 fan_in) = 0;
 };
 
+// Optional offload of the two witness loops that belong to the FFT-convolution hot path:
+// the batched NTT of the FFT / IFFT layers and the per-frequency channel contraction of the DOT_PROD layer.
+// Without one the host loops run (that is what the CPU oracle session uses). Results are exact field
+// elements either way.
+class witnessAccel {
+public:
+    virtual ~witnessAccel() {}
+    // count transforms of length 2^logn; forward: half-length inputs, full outputs; inverse: full inputs, half outputs
+    virtual bool ntt(F *dst, const F *src, int logn, bool inverse, size_t count) = 0;
+    virtual bool dotProd(F *out, size_t n_out, const F *in, size_t n_in, const binGate *gates, size_t n_gates, int fft_bl) = 0;
+};
+
 class neuralNetwork {
 public:
     neuralNetwork(i64 psize_x, i64 psize_y, i64 pchannel, i64 pparallel, const string &i_filename,
@@ -50,6 +62,7 @@ public:
     // replace the input file by a seeded synthetic stream (picture ~ U[0,1), weights/biases ~ U(-k,k),
     // k = 1/sqrt(fan_in)); must be called before create()
     void useSyntheticData(u64 seed);
+    void setWitnessAccel(witnessAccel *a) { accel = a; }
 
     // Fills pr.C (circuit) and pr.val (value of every gate). Works for any prover type exposing those two.
     template <class P>
@@ -75,6 +88,7 @@ protected:
 
 private:
     std::unique_ptr<dataSource> src;
+    witnessAccel *accel = nullptr;
     string out_filename;
     vector<int> infer_result;
 

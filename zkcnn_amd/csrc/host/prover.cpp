@@ -5,6 +5,32 @@ static_assert(sizeof(uniGate) == sizeof(zk_uni_gate), "uniGate layout must match
 static_assert(sizeof(binGate) == sizeof(zk_bin_gate), "binGate layout must match the C-ABI record");
 static_assert(sizeof(F) == 32, "Fr must be 4 x u64 Montgomery limbs");
 
+// optional wall-clock breakdown per prover method (ZKCNN_TIMING=1): printed when the prover is destroyed
+#include <chrono>
+#include <map>
+namespace {
+struct methodTimes {
+    std::map<string, std::pair<double, long>> t;
+    bool on = std::getenv("ZKCNN_TIMING") != nullptr;
+    ~methodTimes() {
+        if (!on) return;
+        for (auto &kv : t) fprintf(stderr, "[zkcnn timing] %-28s %9.3f ms %7ld calls\n", kv.first.c_str(), 1e3 * kv.second.first, kv.second.second);
+    }
+} g_times;
+struct scopeTimer {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    explicit scopeTimer(const char *n) : name(n) { if (g_times.on) t0 = std::chrono::steady_clock::now(); }
+    ~scopeTimer() {
+        if (!g_times.on) return;
+        auto &e = g_times.t[name];
+        e.first += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        ++e.second;
+    }
+};
+}
+#define TIMED() scopeTimer st_(__func__)
+
 static inline const uint64_t *U(const F &x) { return reinterpret_cast<const uint64_t *>(&x); }
 static inline uint64_t *U(F &x) { return reinterpret_cast<uint64_t *>(&x); }
 
@@ -82,31 +108,37 @@ void prover::init() {
 double prover::proofSize() const { return ctx ? (double) zk_proof_bytes(ctx) / 1024.0 : 0.0; }
 
 void prover::sumcheckInitAll(const vector<F>::const_iterator &r_0_from_v) {
+    TIMED();
     prove_timer.start();
     check(zk_sumcheck_init_all(ctx, U(*r_0_from_v), (u32) C.circuit[C.size - 1].bit_length), "zk_sumcheck_init_all");
     prove_timer.stop();
 }
 void prover::sumcheckInit(const F &alpha_0, const F &beta_0) {
+    TIMED();
     prove_timer.start();
     check(zk_sumcheck_init(ctx, U(alpha_0), U(beta_0)), "zk_sumcheck_init");
     prove_timer.stop();
 }
 void prover::sumcheckDotProdInitPhase1() {
+    TIMED();
     prove_timer.start();
     check(zk_sumcheck_dotprod_init_phase1(ctx), "zk_sumcheck_dotprod_init_phase1");
     prove_timer.stop();
 }
 void prover::sumcheckInitPhase1(const F &relu_rou_0) {
+    TIMED();
     prove_timer.start();
     check(zk_sumcheck_init_phase1(ctx, U(relu_rou_0)), "zk_sumcheck_init_phase1");
     prove_timer.stop();
 }
 void prover::sumcheckInitPhase2() {
+    TIMED();
     prove_timer.start();
     check(zk_sumcheck_init_phase2(ctx), "zk_sumcheck_init_phase2");
     prove_timer.stop();
 }
 cubic_poly prover::sumcheckDotProdUpdate1(const F &previous_random) {
+    TIMED();
     prove_timer.start();
     F o[4];
     check(zk_sumcheck_dotprod_update1(ctx, U(previous_random), U(o[0])), "zk_sumcheck_dotprod_update1");
@@ -114,6 +146,7 @@ cubic_poly prover::sumcheckDotProdUpdate1(const F &previous_random) {
     return cubic_poly(o[0], o[1], o[2], o[3]);
 }
 quadratic_poly prover::sumcheckUpdate1(const F &previous_random) {
+    TIMED();
     prove_timer.start();
     F o[3];
     check(zk_sumcheck_update1(ctx, U(previous_random), U(o[0])), "zk_sumcheck_update1");
@@ -121,6 +154,7 @@ quadratic_poly prover::sumcheckUpdate1(const F &previous_random) {
     return quadratic_poly(o[0], o[1], o[2]);
 }
 quadratic_poly prover::sumcheckUpdate2(const F &previous_random) {
+    TIMED();
     prove_timer.start();
     F o[3];
     check(zk_sumcheck_update2(ctx, U(previous_random), U(o[0])), "zk_sumcheck_update2");
@@ -128,6 +162,7 @@ quadratic_poly prover::sumcheckUpdate2(const F &previous_random) {
     return quadratic_poly(o[0], o[1], o[2]);
 }
 F prover::Vres(const vector<F>::const_iterator &r, u32 output_size, u8 r_size) {
+    TIMED();
     prove_timer.start();
     F out;
     F dummy = F_ZERO;
@@ -136,31 +171,37 @@ F prover::Vres(const vector<F>::const_iterator &r, u32 output_size, u8 r_size) {
     return out;
 }
 void prover::sumcheckDotProdFinalize1(const F &previous_random, F &claim_1) {
+    TIMED();
     prove_timer.start();
     check(zk_sumcheck_dotprod_finalize1(ctx, U(previous_random), U(claim_1)), "zk_sumcheck_dotprod_finalize1");
     prove_timer.stop();
 }
 void prover::sumcheckFinalize1(const F &previous_random, F &claim_0, F &claim_1) {
+    TIMED();
     prove_timer.start();
     check(zk_sumcheck_finalize1(ctx, U(previous_random), U(claim_0), U(claim_1)), "zk_sumcheck_finalize1");
     prove_timer.stop();
 }
 void prover::sumcheckFinalize2(const F &previous_random, F &claim_0, F &claim_1) {
+    TIMED();
     prove_timer.start();
     check(zk_sumcheck_finalize2(ctx, U(previous_random), U(claim_0), U(claim_1)), "zk_sumcheck_finalize2");
     prove_timer.stop();
 }
 void prover::sumcheckLiuFinalize(const F &previous_random, F &claim_1) {
+    TIMED();
     prove_timer.start();
     check(zk_sumcheck_liu_finalize(ctx, U(previous_random), U(claim_1)), "zk_sumcheck_liu_finalize");
     prove_timer.stop();
 }
 void prover::sumcheckLiuInit(const vector<F> &s_u, const vector<F> &s_v) {
+    TIMED();
     prove_timer.start();
     check(zk_sumcheck_liu_init(ctx, U(s_u[0]), U(s_v[0]), (u32) s_u.size()), "zk_sumcheck_liu_init");
     prove_timer.stop();
 }
 quadratic_poly prover::sumcheckLiuUpdate(const F &previous_random) {
+    TIMED();
     prove_timer.start();
     F o[3];
     check(zk_sumcheck_liu_update(ctx, U(previous_random), U(o[0])), "zk_sumcheck_liu_update");
@@ -170,6 +211,7 @@ quadratic_poly prover::sumcheckLiuUpdate(const F &previous_random) {
 
 // reference src/prover.cpp:503-511. The HBM copy of val[0] is already zero padded to 2^bit_length.
 hyrax_bls12_381::polyProverBase &prover::commitInput(const vector<G> &gens) {
+    TIMED();
     if (!ctx || !resident) throw std::runtime_error("prover::commitInput before prover::init");
     poly_p.reset(new hyrax_bls12_381::polyProver(ctx, C.circuit[0].bit_length, gens));
     return *poly_p;

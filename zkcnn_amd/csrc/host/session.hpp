@@ -17,6 +17,7 @@ struct sessionT {
     int pic_cnt = 1;
     double witness_s = 0;
     string row;
+    witnessAccel *accel = nullptr;     // set by the product driver while the witness is generated
 
     static double now() {
         return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -28,6 +29,7 @@ struct sessionT {
         nn.reset(makeModel(model_name, d->pic_x, d->pic_y, d->pic_channel, d->pic_cnt));
         if (!nn) return false;
         nn->useSyntheticData(d->data_seed);
+        nn->setWitnessAccel(accel);
         double t0 = now();
         nn->create(p, false);
         witness_s = now() - t0;
