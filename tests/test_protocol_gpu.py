@@ -20,6 +20,10 @@ CASES = [
     ("custom:C2:3:1:f M F4", (8, 8, 1), 2),
     ("custom:C2:3:0:f C3:3:1:f M C2:3:1:s A F5 F3", (10, 10, 2), 2),
     ("lenet", (32, 32, 1), 1),
+    ("custom:C3:3:1:f A C2:3:1:f M F6 F3", (8, 8, 1), 3),          # ragged batch (3 pictures), FFT conv + avg + max pool
+    ("lenetCifar", (32, 32, 3), 1),                                 # three FFT conv blocks, 28 layers
+    ("lenet.avg", (28, 28, 1), 1),                                  # MNIST-size input, padded first conv, average pooling
+    ("vgg:16 M 32 M 64 64 M 128 128 M 128 128 M", (32, 32, 3), 1),  # vgg11 at quarter width: 8e6 mul gates, 2^21 inputs
 ]
 
 

@@ -25,6 +25,7 @@ struct dev_layer {
     // phase-2 lists: bin gates whose v operand lives in table b, sorted by v
     gate_rec *p2[2] = {nullptr, nullptr};
     uint64_t n_p2[2] = {0, 0};
+    int p2_uniform[2] = {-1, -1};   // every gate of the list has its u operand in the same layer: 0 = layer 0, 1 = previous, -1 = mixed
     gate_rec *uni2 = nullptr;      // uni gates for the phase-2 constant term (aux = u, bit 10 = u in previous layer)
     uint64_t n_uni2 = 0;
     uint32_t *ori_u = nullptr, *ori_v = nullptr;

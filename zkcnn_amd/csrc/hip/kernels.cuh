@@ -122,6 +122,8 @@ struct gate_args {
     const fr_t *two_mul;
     fr_t Vu0, Vu1;           // phase 2: claimed values of the u operands
     int32_t phase;           // 1 or 2
+    int32_t post_scale;      // phase 2, all gates of the list take the same Vu: multiply once per output, not per gate
+    fr_t post;
 };
 
 __device__ __forceinline__ fr_t gate_term(const gate_rec &rc, const gate_args &a) {
@@ -130,7 +132,7 @@ __device__ __forceinline__ fr_t gate_term(const gate_rec &rc, const gate_args &a
         if (GATE_HAS_VAL(rc.meta)) t = fr_mul(t, fr_load((GATE_IN_PREV(rc.meta) ? a.val_prev : a.val0) + rc.aux));
     } else {
         t = fr_mul(t, fr_load(a.beta_u + rc.aux));
-        t = fr_mul(t, GATE_IN_PREV(rc.meta) ? a.Vu1 : a.Vu0);
+        if (!a.post_scale) t = fr_mul(t, GATE_IN_PREV(rc.meta) ? a.Vu1 : a.Vu0);
     }
     const uint32_t sc = GATE_SC(rc.meta);
     if (sc) t = fr_mul(t, fr_load(a.two_mul + sc));
@@ -175,6 +177,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_gate_reduce(fr_t *out, uint32_t *c
     uint32_t next_key = (uint32_t) __shfl_down((int) key, 1, 64);
     if (lane == 63) next_key = (wave + 1 < ZK_BLOCK / 64) ? s_head[wave + 1] : GATE_NOKEY;
     const uint32_t kf = s_head[0];
+    if (a.post_scale && (idx == blk_last || next_key != key)) val = fr_mul(val, a.post);   // segment (or block-partial) total
     if (idx == blk_last) {
         const int slot = (key == kf) ? 0 : 1;
         carry_key[2 * blockIdx.x + slot] = key;

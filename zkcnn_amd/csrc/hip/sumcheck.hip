@@ -207,6 +207,12 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
             if (S.bit_length_v[b] < 0) { ctx->err = "bin gate refers to an absent v table"; return ZK_ERR_ARG; }
             counting_sort(q[b], 1u << S.bit_length_v[b]);
             D.n_p2[b] = q[b].size();
+            {
+                const uint32_t f0 = GATE_IN_PREV(q[b][0].meta);
+                bool same = true;
+                for (const gate_rec &r : q[b]) if (GATE_IN_PREV(r.meta) != f0) { same = false; break; }
+                D.p2_uniform[b] = same ? (int) f0 : -1;
+            }
             max_list = std::max<uint64_t>(max_list, q[b].size());
             if ((rc = upload(ctx, &D.p2[b], q[b]))) return rc;
             std::vector<gate_rec>().swap(q[b]);
@@ -372,7 +378,7 @@ static int32_t wait_slot(zk_ctx *ctx, unsigned long long seq) {
 }
 
 static int32_t gate_scatter(zk_ctx *ctx, fr_t *out, const gate_rec *recs, uint64_t n, int phase, const dev_layer &cur,
-                            const dev_layer &prev, uint64_t n_uni_in_list, uint64_t out_len) {
+                            const dev_layer &prev, uint64_t n_uni_in_list, uint64_t out_len, int uniform_u = -1) {
     if (!n) return ZK_OK;
     const double gate_bytes = 44.0 * (double) n_uni_in_list + 80.0 * (double) (n - n_uni_in_list) + 32.0 * (double) out_len;
     gate_args A;
@@ -386,6 +392,8 @@ static int32_t gate_scatter(zk_ctx *ctx, fr_t *out, const gate_rec *recs, uint64
     A.Vu0 = to_dev(ctx->V_u0);
     A.Vu1 = to_dev(ctx->V_u1);
     A.phase = phase;
+    A.post_scale = (phase == 2 && uniform_u >= 0) ? 1 : 0;
+    A.post = uniform_u == 1 ? A.Vu1 : A.Vu0;
     (void) cur;
     const uint32_t blocks = (uint32_t) ((n + ZK_BLOCK - 1) / ZK_BLOCK);
     if (2ull * blocks > ctx->carry_slots) { ctx->err = "carry buffer too small"; return ZK_ERR_STATE; }
@@ -711,7 +719,7 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         ZK_LAUNCH(PC_DOT, 0.0, k_row_dot, dim3((rows + 3) / 4), dim3(ZK_BLOCK), t.V[0], prev.val, ctx->beta_gs, rows, fft_bl);
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
-        return gate_scatter(ctx, t.M[0], cur.p2[1], cur.n_p2[1], 2, cur, prev, 0, t.len);
+        return gate_scatter(ctx, t.M[0], cur.p2[1], cur.n_p2[1], 2, cur, prev, 0, t.len, cur.p2_uniform[1]);
     }
 
     if ((rc = eq_table1(ctx, ctx->beta_u, d.max_bl_u, ru, HFr::one()))) return rc;
@@ -722,7 +730,7 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         A.recs = cur.uni2; A.n = cur.n_uni2;
         A.beta_g = ctx->beta_g[ctx->beta_g_cur]; A.beta_u = ctx->beta_u;
         A.val0 = nullptr; A.val_prev = nullptr; A.two_mul = ctx->two_mul;
-        A.Vu0 = to_dev(ctx->V_u0); A.Vu1 = to_dev(ctx->V_u1); A.phase = 2;
+        A.Vu0 = to_dev(ctx->V_u0); A.Vu1 = to_dev(ctx->V_u1); A.phase = 2; A.post_scale = 0; A.post = A.Vu0;
         const uint32_t g = std::min<uint32_t>(grid_for(cur.n_uni2, 1024), ctx->partial_blocks);
         ZK_LAUNCH(PC_GATE_SUM, 0.0, k_gate_sum2, dim3(g), dim3(ZK_BLOCK), ctx->partials, A);
         ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials<2>, dim3(1), dim3(ZK_BLOCK), ctx->d_result + 8, ctx->partials, g, 0);
@@ -732,7 +740,7 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
         ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
-        if ((rc = gate_scatter(ctx, t.M[0], cur.p2[b], cur.n_p2[b], 2, cur, prev, 0, t.len))) return rc;
+        if ((rc = gate_scatter(ctx, t.M[0], cur.p2[b], cur.n_p2[b], 2, cur, prev, 0, t.len, cur.p2_uniform[b]))) return rc;
     }
     if (cur.n_uni2) {
         ZK_HIP(hipMemcpyAsync(ctx->h_result + 8, ctx->d_result + 8, 64, hipMemcpyDeviceToHost, ctx->stream));
