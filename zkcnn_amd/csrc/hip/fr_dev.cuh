@@ -42,68 +42,38 @@ __device__ __forceinline__ bool fr_eq(const fr_t &a, const fr_t &b) {
     return acc == 0;
 }
 
-// t >= r ?  (t has 8 limbs)
-__device__ __forceinline__ bool fr_ge_mod(const uint32_t *t) {
-    const uint32_t m[8] = FR_MOD_INIT;
-    // compute t - r and look at the borrow
-    uint64_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t d = (uint64_t) t[i] - m[i] - borrow;
-        borrow = (d >> 32) & 1;
-    }
-    return borrow == 0;
-}
-
-// z = t - r if t >= r else t
+// z = t - r if t >= r else t   (extra_carry: a ninth limb of t is set)
 __device__ __forceinline__ void fr_cond_sub(fr_t &z, const uint32_t *t, uint32_t extra_carry) {
     const uint32_t m[8] = FR_MOD_INIT;
     uint32_t d[8];
-    uint64_t borrow = 0;
+    unsigned bo = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t x = (uint64_t) t[i] - m[i] - borrow;
-        d[i] = (uint32_t) x;
-        borrow = (x >> 32) & 1;
-    }
-    const bool use_d = extra_carry || !borrow;
+    for (int i = 0; i < 8; ++i) d[i] = __builtin_subc(t[i], m[i], bo, &bo);
+    const bool use_d = extra_carry || !bo;
 #pragma unroll
     for (int i = 0; i < 8; ++i) z.v[i] = use_d ? d[i] : t[i];
 }
 
 __device__ __forceinline__ fr_t fr_add(const fr_t &a, const fr_t &b) {
     uint32_t t[8];
-    uint64_t c = 0;
+    unsigned c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        c += (uint64_t) a.v[i] + b.v[i];
-        t[i] = (uint32_t) c;
-        c >>= 32;
-    }
+    for (int i = 0; i < 8; ++i) t[i] = __builtin_addc(a.v[i], b.v[i], c, &c);
     fr_t z;
-    fr_cond_sub(z, t, (uint32_t) c);       // r < 2^255, so c is always 0 here; kept for safety
+    fr_cond_sub(z, t, c);                  // r < 2^255, so c is always 0 here; kept for safety
     return z;
 }
 
 __device__ __forceinline__ fr_t fr_sub(const fr_t &a, const fr_t &b) {
     const uint32_t m[8] = FR_MOD_INIT;
     uint32_t t[8];
-    uint64_t borrow = 0;
+    unsigned bo = 0, c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t x = (uint64_t) a.v[i] - b.v[i] - borrow;
-        t[i] = (uint32_t) x;
-        borrow = (x >> 32) & 1;
-    }
-    const uint32_t mask = borrow ? 0xffffffffu : 0u;
+    for (int i = 0; i < 8; ++i) t[i] = __builtin_subc(a.v[i], b.v[i], bo, &bo);
+    const uint32_t mask = bo ? 0xffffffffu : 0u;
     fr_t z;
-    uint64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        c += (uint64_t) t[i] + (m[i] & mask);
-        z.v[i] = (uint32_t) c;
-        c >>= 32;
-    }
+    for (int i = 0; i < 8; ++i) z.v[i] = __builtin_addc(t[i], m[i] & mask, c, &c);
     return z;
 }
 
@@ -111,50 +81,62 @@ __device__ __forceinline__ fr_t fr_neg(const fr_t &a) {
     const uint32_t m[8] = FR_MOD_INIT;
     const uint32_t mask = fr_is_zero(a) ? 0u : 0xffffffffu;
     fr_t z;
-    uint64_t borrow = 0;
+    unsigned bo = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t x = (uint64_t) m[i] - a.v[i] - borrow;
-        z.v[i] = (uint32_t) x & mask;
-        borrow = (x >> 32) & 1;
-    }
+    for (int i = 0; i < 8; ++i) z.v[i] = __builtin_subc(m[i], a.v[i], bo, &bo) & mask;
     return z;
 }
 
-// Montgomery product, CIOS over 32-bit limbs: 8 x (8 MADs for a*b_i + 7 MADs for the reduction row).
+// 96-bit column accumulator step: acc (64-bit VGPR pair) += x * y, carries out of the pair counted in ovf.
+// v_mad_u64_u32 is the widest integer MAD of gfx950 and returns its carry in VCC; the s_nop covers the
+// VALU-writes-VCC -> v_addc wait state (hipcc inserts the same nop in its own code for this pair).
+#define ZK_MAC(acc, ovf, x, y)                                                                            \
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"          \
+        : "+v"(acc), "+v"(ovf) : "v"(x), "v"(y) : "vcc")
+
+// Montgomery product by product scanning (finely integrated: multiplication and reduction columns interleaved)
+// with ONE 96-bit accumulator: 2 instructions per 32x32 partial product, no carry ripple inside a column.
+template <int N, bool INV_IS_MINUS1>
+__device__ __forceinline__ void mont_mul_comba(uint32_t *z, const uint32_t *a, const uint32_t *b, const uint32_t *m, uint32_t inv) {
+    uint32_t q[N], r[N + 1];
+    uint64_t acc = 0;
+    uint32_t ovf = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) ZK_MAC(acc, ovf, a[i], b[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; ++i) ZK_MAC(acc, ovf, q[i], m[k - i]);
+        q[k] = INV_IS_MINUS1 ? 0u - (uint32_t) acc : (uint32_t) acc * inv;
+        ZK_MAC(acc, ovf, q[k], m[0]);
+        acc = (acc >> 32) | ((uint64_t) ovf << 32);
+        ovf = 0;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N; ++k) {
+#pragma unroll
+        for (int i = k - N + 1; i < N; ++i) ZK_MAC(acc, ovf, a[i], b[k - i]);
+#pragma unroll
+        for (int i = k - N + 1; i < N; ++i) ZK_MAC(acc, ovf, q[i], m[k - i]);
+        r[k - N] = (uint32_t) acc;
+        acc = (acc >> 32) | ((uint64_t) ovf << 32);
+        ovf = 0;
+    }
+    r[N] = (uint32_t) acc;
+    uint32_t d[N];
+    unsigned bo = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) d[i] = __builtin_subc(r[i], m[i], bo, &bo);
+    const bool use_d = r[N] || !bo;
+#pragma unroll
+    for (int i = 0; i < N; ++i) z[i] = use_d ? d[i] : r[i];
+}
+
+// Montgomery product (R = 2^256). r = 1 (mod 2^32): the quotient digit is the negated low word.
 __device__ __forceinline__ fr_t fr_mul(const fr_t &a, const fr_t &b) {
     const uint32_t m[8] = FR_MOD_INIT;
-    uint32_t t[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            c += (uint64_t) a.v[j] * b.v[i] + t[j];
-            t[j] = (uint32_t) c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[8] = (uint32_t) c;
-        t[9] = (uint32_t) (c >> 32);
-
-        const uint32_t q = 0u - t[0];               // q = t0 * (-r^-1) mod 2^32
-        // q * r[0] + t[0] = q + t0 = 0 (mod 2^32), carry = (t0 != 0)
-        c = (t[0] != 0) ? 1 : 0;
-#pragma unroll
-        for (int j = 1; j < 8; ++j) {
-            c += (uint64_t) q * m[j] + t[j];
-            t[j - 1] = (uint32_t) c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[7] = (uint32_t) c;
-        t[8] = t[9] + (uint32_t) (c >> 32);
-    }
     fr_t z;
-    fr_cond_sub(z, t, t[8]);
+    mont_mul_comba<8, true>(z.v, a.v, b.v, m, 0xffffffffu);
     return z;
 }
 

@@ -43,25 +43,17 @@ __device__ __forceinline__ bool fp_eq(const fp_t &a, const fp_t &b) {
 __device__ __forceinline__ void fp_cond_sub(fp_t &z, const uint32_t *t) {
     const uint32_t m[12] = FP_MOD_INIT;
     uint32_t d[12];
-    uint64_t borrow = 0;
+    unsigned bo = 0;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        uint64_t x = (uint64_t) t[i] - m[i] - borrow;
-        d[i] = (uint32_t) x;
-        borrow = (x >> 32) & 1;
-    }
+    for (int i = 0; i < 12; ++i) d[i] = __builtin_subc(t[i], m[i], bo, &bo);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) z.v[i] = borrow ? t[i] : d[i];
+    for (int i = 0; i < 12; ++i) z.v[i] = bo ? t[i] : d[i];
 }
 __device__ __forceinline__ fp_t fp_add(const fp_t &a, const fp_t &b) {
     uint32_t t[12];
-    uint64_t c = 0;
+    unsigned c = 0;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        c += (uint64_t) a.v[i] + b.v[i];
-        t[i] = (uint32_t) c;
-        c >>= 32;
-    }
+    for (int i = 0; i < 12; ++i) t[i] = __builtin_addc(a.v[i], b.v[i], c, &c);
     fp_t z;
     fp_cond_sub(z, t);          // p < 2^381: no carry out of the top limb
     return z;
@@ -69,60 +61,23 @@ __device__ __forceinline__ fp_t fp_add(const fp_t &a, const fp_t &b) {
 __device__ __forceinline__ fp_t fp_sub(const fp_t &a, const fp_t &b) {
     const uint32_t m[12] = FP_MOD_INIT;
     uint32_t t[12];
-    uint64_t borrow = 0;
+    unsigned bo = 0, c = 0;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        uint64_t x = (uint64_t) a.v[i] - b.v[i] - borrow;
-        t[i] = (uint32_t) x;
-        borrow = (x >> 32) & 1;
-    }
-    const uint32_t mask = borrow ? 0xffffffffu : 0u;
+    for (int i = 0; i < 12; ++i) t[i] = __builtin_subc(a.v[i], b.v[i], bo, &bo);
+    const uint32_t mask = bo ? 0xffffffffu : 0u;
     fp_t z;
-    uint64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        c += (uint64_t) t[i] + (m[i] & mask);
-        z.v[i] = (uint32_t) c;
-        c >>= 32;
-    }
+    for (int i = 0; i < 12; ++i) z.v[i] = __builtin_addc(t[i], m[i] & mask, c, &c);
     return z;
 }
 __device__ __forceinline__ fp_t fp_neg(const fp_t &a) { return fp_sub(fp_zero(), a); }
 __device__ __forceinline__ fp_t fp_dbl(const fp_t &a) { return fp_add(a, a); }
 
-// CIOS Montgomery product over 12 limbs (288 32x32 MADs)
+// Montgomery product over 12 limbs: 288 MAC steps of the 96-bit column accumulator (fr_dev.cuh: mont_mul_comba)
 __device__ __noinline__ fp_t fp_mul(const fp_t a, const fp_t b) {
     const uint32_t m[12] = FP_MOD_INIT;
-    uint32_t t[14];
-#pragma unroll
-    for (int i = 0; i < 14; ++i) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            c += (uint64_t) a.v[j] * b.v[i] + t[j];
-            t[j] = (uint32_t) c;
-            c >>= 32;
-        }
-        c += t[12];
-        t[12] = (uint32_t) c;
-        t[13] = (uint32_t) (c >> 32);
-        const uint32_t q = t[0] * FP_INV32;
-        c = (uint64_t) q * m[0] + t[0];
-        c >>= 32;
-#pragma unroll
-        for (int j = 1; j < 12; ++j) {
-            c += (uint64_t) q * m[j] + t[j];
-            t[j - 1] = (uint32_t) c;
-            c >>= 32;
-        }
-        c += t[12];
-        t[11] = (uint32_t) c;
-        t[12] = t[13] + (uint32_t) (c >> 32);
-    }
     fp_t z;
-    fp_cond_sub(z, t);
+    mont_mul_comba<12, false>(z.v, a.v, b.v, m, FP_INV32);
     return z;
 }
 __device__ __forceinline__ fp_t fp_sqr(const fp_t &a) { return fp_mul(a, a); }

@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_sum_partials(fr_t *out, const fr_t
 //   2. accumulates, over pairs of the folded tables,  c = sum v0 m0,  a = sum dv dm,  p1 = sum v1 m1
 // (b = p1 - a - c is recovered by the caller). Algorithmic traffic: read 2n, write n elements.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(ZK_BLOCK) k_round_quad(const fr_t *Vin, const fr_t *Min, fr_t *Vout, fr_t *Mout, uint64_t n,
+__global__ void __launch_bounds__(ZK_BLOCK, 4) k_round_quad(const fr_t *Vin, const fr_t *Min, fr_t *Vout, fr_t *Mout, uint64_t n,
                                                          fr_t r, int first, fr_t *partials) {
     __shared__ fr_t smem[3 * ZK_BLOCK / 64];
     fr_t acc[3] = {fr_zero(), fr_zero(), fr_zero()};       // a, c, p1
