@@ -88,10 +88,12 @@ __device__ __forceinline__ fr_t fr_neg(const fr_t &a) {
 }
 
 // 96-bit column accumulator step: acc (64-bit VGPR pair) += x * y, carries out of the pair counted in ovf.
-// v_mad_u64_u32 is the widest integer MAD of gfx950 and returns its carry in VCC; the s_nop covers the
-// VALU-writes-VCC -> v_addc wait state (hipcc inserts the same nop in its own code for this pair).
+// v_mad_u64_u32 is the widest integer MAD of gfx950 and returns its carry in VCC. gfx950 needs TWO wait states
+// between a VALU write of VCC and a VALU read of it as carry-in (hipcc emits `s_nop 1` in its own add/addc
+// chains); inline asm is opaque to the hazard recogniser, so the wait states are part of the string.
+// (Pairing two MACs on two SGPR carry registers so that they share wait states measured no faster.)
 #define ZK_MAC(acc, ovf, x, y)                                                                            \
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"          \
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"          \
         : "+v"(acc), "+v"(ovf) : "v"(x), "v"(y) : "vcc")
 
 // Montgomery product by product scanning (finely integrated: multiplication and reduction columns interleaved)
