@@ -131,6 +131,22 @@ def main():
                     "algorithmic_bytes_per_launch": prof["bytes"] / prof["launches"],
                     "share_of_prover_time": round(prof["ms"] * 1e-3 / max(prove_s + poly_s, 1e-12), 3)}
 
+    # the same kernel family on one large streaming launch (two 2^24-entry tables, device resident): this is the figure
+    # to read against the HBM roof; the whole-proof average above is dominated by ~1.1 k tiny latency-bound rounds
+    if roofline is not None and rank == 0:
+        try:
+            hc = zkcnn_amd.HipContext(local_rank)
+            sec, nbytes = hc.bench_round_quadratic(24, 10)
+            mul_sec = hc.bench_fr_mul(1 << 20, 256, 3)
+            hc.close()
+            roofline["streaming_launch"] = {"kernel": "k_round_quad, 2 x 2^24 entries", "ms": round(sec * 1e3, 4),
+                                            "algorithmic_bytes": nbytes, "achieved": round(nbytes / sec / 1e9, 1),
+                                            "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                            "traffic_pmc_bytes": 1.7037e9,      # profiles/r01_round_quad_kernel.md (FETCH_SIZE x2 + WRITE_SIZE)
+                                            "fr_mul_ceiling_G_per_s": round((1 << 20) * 256 / mul_sec / 1e9, 1)}
+        except Exception as e:      # the headline numbers do not depend on this extra measurement
+            roofline["streaming_launch"] = {"error": str(e)}
+
     if rank != 0:
         sess.close()
         if dist is not None:
