@@ -60,7 +60,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:        # launched by torch.distributed.run (also with one rank: same code path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -101,15 +101,18 @@ def main():
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     prove_s = poly_s = 0.0
+    gatherer = dp.AsyncGather(dist, "cuda", 1 << 20) if dist is not None else None
     for k in range(args.steps):
         res, tr = sess.prove(seed=0x5EED1000 + k, mode=drive, want_transcript=dist is not None)
         prove_s += res.prove_s
         poly_s += res.poly_prove_s
-        if dist is not None:
-            # the step's only exchange: per-image proofs to rank 0 over RCCL (zkcnn_amd/dp.py)
-            gathered = dp.gather_proofs([(rank, tr)], dist, "cuda")
-            if rank == 0:
-                assert len(gathered) == world
+        if gatherer is not None:
+            # the step's only exchange: this image's proof to rank 0 over RCCL, overlapped with the next proof (zkcnn_amd/dp.py)
+            gatherer.submit(rank, tr)
+    if gatherer is not None:
+        gathered = gatherer.wait()
+        if rank == 0:
+            assert len(gathered) == args.steps and all(len(g) == world for g in gathered)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -66,3 +66,35 @@ def test_two_ranks_gather_equals_single_process(oracle):
         assert p.exitcode == 0
     assert got == want
     assert len({h for _, h in got}) == n_images          # different pictures give different proofs
+
+
+def _async_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = dp.AsyncGather(dist, "cpu", 4096)
+    for step in range(3):
+        g.submit(rank, bytes([rank, step]) * (10 + step))
+    res = g.wait()
+    if rank == 0:
+        q.put(res)
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_gather_keeps_steps_and_ranks_apart():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_async_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [[(0, bytes([0, s]) * (10 + s)), (1, bytes([1, s]) * (10 + s))] for s in range(3)]

@@ -41,3 +41,18 @@ def test_gpu_transcript_identical_to_oracle(built, model, pic, pp):
         assert ores.accepted == 1
     assert len(gpu) == len(cpu) and hashlib.sha256(gpu).hexdigest() == hashlib.sha256(cpu).hexdigest()
     assert abs(res.proof_kb - ores.proof_kb) < 1e-9 and abs(res.poly_proof_kb - ores.poly_proof_kb) < 1e-9
+
+
+def test_full_size_vgg11_accepted_and_deterministic(built):
+    """BASELINE.json configs[2] at full size (1.16e8 multiplication gates, 2^24 inputs): the verifier -- which checks the sumcheck
+    round identity p(0) + p(1) == claim in every one of the 1129 rounds, every layer's wiring predicate and the Hyrax opening --
+    accepts the GPU proof, and proving twice under one seed gives the same bytes (size-independent properties; the byte-for-byte
+    comparison with the CPU oracle at this size takes ~1 min of CPU and is run by scripts/, see profiles/r01_summary.md)."""
+    with zkcnn_amd.Session("vgg11", (32, 32, 3), 1) as s:
+        res, t1 = s.prove(seed=0x5EED0001)
+        assert res.accepted == 1, res.message.decode()
+        assert res.n_layers == 37 and res.input_bits == 24 and res.gate_cnt_bin == 115904256
+        res2, t2 = s.prove(seed=0x5EED0001, mode=zkcnn_amd.MODE_DRIVE_ONLY)
+        assert t1 == t2
+        bad, _ = s.prove(seed=0x5EED0001, mode=zkcnn_amd.MODE_TAMPER | (700 << 8))
+        assert bad.accepted == 0

@@ -213,14 +213,21 @@ class _SessionBase:
             raise RuntimeError(f"{self._prefix}session_create({model}) failed")
 
     def prove(self, seed=0x5EED0001, mode=MODE_VERIFY, want_transcript=True):
-        cap = (1 << 24) if want_transcript else 0
-        buf = (ctypes.c_uint8 * max(cap, 1))()
+        cap = 0
+        if want_transcript:
+            if getattr(self, "_tbuf", None) is None:
+                self._tbuf = (ctypes.c_uint8 * (4 << 20))()       # re-used across proofs; grown if a proof is larger
+            cap = len(self._tbuf)
+        buf = self._tbuf if want_transcript else (ctypes.c_uint8 * 1)()
         res = Result()
         rc = self._fn("session_prove")(ctypes.c_void_p(self.h), ctypes.c_uint64(seed), ctypes.c_uint32(mode), buf,
                                        ctypes.c_uint64(cap), ctypes.byref(res))
         if rc != 0:
             raise RuntimeError(f"{self._prefix}session_prove failed ({rc}): {res.message.decode(errors='replace')}")
-        data = bytes(buf[:min(res.transcript_len, cap)]) if want_transcript else b""
+        if want_transcript and res.transcript_len > cap:
+            self._tbuf = (ctypes.c_uint8 * int(res.transcript_len + (1 << 20)))()
+            return self.prove(seed, mode, True)                     # deterministic: the same seed gives the same proof
+        data = ctypes.string_at(buf, res.transcript_len) if want_transcript else b""
         return res, data
 
     def row(self):

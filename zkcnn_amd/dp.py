@@ -61,6 +61,44 @@ def gather_proofs(local, dist=None, device="cpu"):
     return None
 
 
+class AsyncGather:
+    """Per-step gather that overlaps with the next proof: the transcript goes to a device buffer and an asynchronous
+    RCCL gather is queued on the collective stream; wait() drains everything before the final barrier."""
+
+    def __init__(self, dist, device, cap_bytes):
+        import torch
+        self.dist, self.device, self.cap = dist, device, int(cap_bytes)
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.pending = []          # (work handle, send buffer, receive buffers)
+        self.torch = torch
+
+    def submit(self, image_id, transcript):
+        torch = self.torch
+        blob = struct.pack("<IQ", image_id, len(transcript)) + transcript
+        if len(blob) > self.cap:
+            raise ValueError("proof larger than the gather capacity")
+        host = torch.frombuffer(bytearray(blob.ljust(self.cap, b"\0")), dtype=torch.uint8)
+        send = host.to(self.device, non_blocking=False)
+        recv = [torch.empty_like(send) for _ in range(self.world)] if self.rank == 0 else None
+        work = self.dist.gather(send, recv, dst=0, async_op=True)
+        self.pending.append((work, send, recv))
+
+    def wait(self):
+        """returns list[list[(image_id, bytes)]] per step on rank 0, None elsewhere"""
+        out = []
+        for work, _, recv in self.pending:
+            work.wait()
+            if recv is not None:
+                step = []
+                for t in recv:
+                    raw = t.cpu().numpy().tobytes()
+                    img, ln = struct.unpack_from("<IQ", raw, 0)
+                    step.append((img, raw[12:12 + ln]))
+                out.append(sorted(step))
+        self.pending = []
+        return out if self.rank == 0 else None
+
+
 def prove_images(make_session, image_ids, challenge_seed, mode=0):
     """proves the given images one after the other on this rank; make_session(image_id) -> session object"""
     out, stats = [], []
