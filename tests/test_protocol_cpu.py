@@ -73,7 +73,7 @@ def test_verifier_rejects_any_corrupted_message(oracle):
         ok, _ = o.prove(seed=11)
         assert ok.accepted == 1
         n_sum, cb = ok.n_messages, ok.input_bits - ok.input_bits // 2
-        rounds = max(0, cb - 6)                 # the inner-product recursion stops at length 64
+        rounds = max(0, cb - 8)                 # the inner-product recursion stops at length 256
         total = n_sum + rounds + 1
         picks = sorted(set(list(range(0, total, 7)) + [0, 1, n_sum - 1, n_sum, total - 2, total - 1]))
         for k in picks:
@@ -81,3 +81,16 @@ def test_verifier_rejects_any_corrupted_message(oracle):
             assert bad.accepted == 0, f"message {k} of {total} corrupted but accepted"
         again, _ = o.prove(seed=11, mode=zkcnn_amd.MODE_TAMPER | ((total + 5) << 8))     # out of range: nothing touched
         assert again.accepted == 1
+
+
+def test_verifier_rejects_corrupted_opening_round(oracle):
+    """LeNet5's commitment has 512 generators, so its opening runs one inner-product round before the 256-element tail:
+    corrupting that round's message, or the tail, must be caught by the final P* / y* check"""
+    import zkcnn_amd
+    with oracle_ffi.OracleSession("lenet", (32, 32, 1), 1) as o:
+        ok, _ = o.prove(seed=21, mode=zkcnn_amd.MODE_REUSE_GENS)
+        assert ok.accepted == 1
+        n_sum = ok.n_messages
+        for k in (n_sum, n_sum + 1):           # the round message, then the tail vector
+            bad, _ = o.prove(seed=21, mode=zkcnn_amd.MODE_REUSE_GENS | zkcnn_amd.MODE_TAMPER | (k << 8))
+            assert bad.accepted == 0, k

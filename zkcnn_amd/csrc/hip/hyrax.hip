@@ -17,6 +17,10 @@
 
 #define MSM_WINDOWS 32
 #define MSM_PLANES 8
+// threads per MSM block: one wave. The kernels are chains of dependent Fp products, so what matters is how many
+// independent chains are resident (2 waves/SIMD at ~200 VGPRs) and how short each is: one wave per block keeps the
+// reduction tree at 6 levels and lets 8 blocks share a CU.
+#define MSM_BLOCK 64
 
 struct msm_state {
     g1a_t *tables = nullptr;           // [MSM_WINDOWS][m]
@@ -91,19 +95,19 @@ __global__ void k_window_tables(g1a_t *T, g1j_t *J, fp_t *pre, uint32_t m) {
 }
 
 // One block = (row, bit plane, column chunk x window group). Each thread walks `cpt` columns
-// (stride 256: coalesced scalar and table reads), adds the selected table points, then the block
+// (stride MSM_BLOCK: coalesced scalar and table reads), adds the selected table points, then the block
 // tree-reduces through LDS. out[(row * 8 + plane) * nparts + part]
-__global__ void __launch_bounds__(256) k_msm_planes(g1j_t *out, const fr_t *scalars, uint64_t ld, const uint32_t *idx_base,
+__global__ void __launch_bounds__(MSM_BLOCK) k_msm_planes(g1j_t *out, const fr_t *scalars, uint64_t ld, const uint32_t *idx_base,
                                                      const g1a_t *T, uint32_t m, uint32_t cols, uint32_t cpt, uint32_t wsplit,
                                                      const uint32_t *row_map, uint32_t w_lo) {
-    __shared__ g1j_t sm[256];
+    __shared__ g1j_t sm[MSM_BLOCK];
     const uint32_t plane = blockIdx.y, row = row_map ? row_map[blockIdx.z] : blockIdx.z;
     const uint32_t wg = blockIdx.x % wsplit, chunk = blockIdx.x / wsplit;
     const uint32_t wpg = MSM_WINDOWS / wsplit, w0 = max(wg * wpg, w_lo);
     const uint32_t *idx = idx_base ? idx_base + (size_t) row * ld : nullptr;     // index rows are laid out like the scalar rows
     g1j_t acc = g1_inf();
     for (uint32_t i = 0; i < cpt; ++i) {
-        const uint32_t c = chunk * (256 * cpt) + i * 256 + threadIdx.x;
+        const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + threadIdx.x;
         if (c >= cols) break;
         bool neg;
         const fr_t s = fr_signed_magnitude(fr_load(scalars + (size_t) row * ld + c), neg);
@@ -124,7 +128,7 @@ __global__ void __launch_bounds__(256) k_msm_planes(g1j_t *out, const fr_t *scal
     }
     sm[threadIdx.x] = acc;
     __syncthreads();
-    for (uint32_t s = 128; s >= 1; s >>= 1) {
+    for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
         if (threadIdx.x < s) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + s]);
         __syncthreads();
     }
@@ -181,14 +185,14 @@ __global__ void k_digit_affine(g1a_t *D, const g1j_t *J, fp_t *pre, uint32_t m) 
 // Row commitment when (almost) every scalar is a signed byte: ONE mixed addition per non-zero scalar, taken
 // from the digit table. Scalars with higher bytes only contribute their low byte here and flag the row; the
 // caller adds their remaining windows with k_msm_planes(w_lo = 1). out[row * gridDim.x + chunk]
-__global__ void __launch_bounds__(256) k_msm_digit(g1j_t *out, uint32_t *hi_flags, const fr_t *scalars, uint64_t ld,
+__global__ void __launch_bounds__(MSM_BLOCK) k_msm_digit(g1j_t *out, uint32_t *hi_flags, const fr_t *scalars, uint64_t ld,
                                                     const g1a_t *D, uint32_t m, uint32_t cols, uint32_t cpt) {
-    __shared__ g1j_t sm[256];
+    __shared__ g1j_t sm[MSM_BLOCK];
     const uint32_t row = blockIdx.y, chunk = blockIdx.x;
     g1j_t acc = g1_inf();
     bool hi = false;
     for (uint32_t i = 0; i < cpt; ++i) {
-        const uint32_t c = chunk * (256 * cpt) + i * 256 + threadIdx.x;
+        const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + threadIdx.x;
         if (c >= cols) break;
         const fr_t raw = fr_load(scalars + (size_t) row * ld + c);
         if (fr_is_zero(raw)) continue;
@@ -208,7 +212,7 @@ __global__ void __launch_bounds__(256) k_msm_digit(g1j_t *out, uint32_t *hi_flag
     if (hi) hi_flags[row] = 1;
     sm[threadIdx.x] = acc;
     __syncthreads();
-    for (uint32_t s = 128; s >= 1; s >>= 1) {
+    for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
         if (threadIdx.x < s) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + s]);
         __syncthreads();
     }
@@ -348,11 +352,12 @@ static int32_t run_msm(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint
                        const uint32_t *row_map = nullptr, uint32_t w_lo = 0, g1j_t *outJ = nullptr, bool sparse_windows = false) {
     msm_state *s = ctx->msm;
     uint32_t wsplit, cpt;
-    if (rows >= 64) { wsplit = 1; cpt = std::min<uint32_t>(16, (cols + 255) / 256); }
-    else if (sparse_windows) { wsplit = 1; cpt = std::min<uint32_t>(2, (cols + 255) / 256); }   // few non-zero windows: one block walks them all
-    else { wsplit = MSM_WINDOWS; cpt = std::min<uint32_t>(4, (cols + 255) / 256); }
+    const uint32_t per = (cols + MSM_BLOCK - 1) / MSM_BLOCK;
+    if (rows >= 64) { wsplit = 1; cpt = std::min<uint32_t>(64, per); }
+    else if (sparse_windows) { wsplit = 1; cpt = std::min<uint32_t>(8, per); }   // few non-zero windows: one block walks them all
+    else { wsplit = MSM_WINDOWS; cpt = std::min<uint32_t>(8, per); }
     cpt = std::max<uint32_t>(cpt, 1);
-    const uint32_t chunks = (cols + 256 * cpt - 1) / (256 * cpt), nparts = chunks * wsplit;
+    const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt), nparts = chunks * wsplit;
     int32_t rc;
     if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * MSM_PLANES * nparts * sizeof(g1j_t)))) return rc;
     if (s->rows_cap < rows) {
@@ -364,7 +369,7 @@ static int32_t run_msm(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint
     // gridDim.z is limited to 65535 rows per launch
     for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
         const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
-        ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, k_msm_planes, dim3(nparts, MSM_PLANES, nr), dim3(256), s->partials + (size_t) r0 * MSM_PLANES * nparts, scalars + (row_map ? 0 : (size_t) r0 * ld), ld, idx, s->tables, (uint32_t) s->m, cols, cpt, wsplit, row_map ? row_map + r0 : nullptr, w_lo);
+        ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, k_msm_planes, dim3(nparts, MSM_PLANES, nr), dim3(MSM_BLOCK), s->partials + (size_t) r0 * MSM_PLANES * nparts, scalars + (row_map ? 0 : (size_t) r0 * ld), ld, idx, s->tables, (uint32_t) s->m, cols, cpt, wsplit, row_map ? row_map + r0 : nullptr, w_lo);
     }
     ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_msm_finish, dim3(rows), dim3(512), outJ ? outJ : s->rowsJ, s->partials, nparts);
     ZK_HIP(hipGetLastError());
@@ -401,8 +406,8 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
     msm_state *s = ctx->msm;
     int32_t rc;
     if ((rc = ensure_digit_table(ctx))) return rc;
-    const uint32_t cpt = std::max<uint32_t>(1, std::min<uint32_t>(16, (cols + 255) / 256));
-    const uint32_t chunks = (cols + 256 * cpt - 1) / (256 * cpt);
+    const uint32_t cpt = std::max<uint32_t>(1, std::min<uint32_t>(64, (cols + MSM_BLOCK - 1) / MSM_BLOCK));
+    const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt);
     if (s->rows_cap < rows) {
         if (s->rowsJ) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->rowsJ)); ZK_HIP(hipFree(s->rowsA)); }
         ZK_HIP(hipMalloc((void **) &s->rowsJ, (size_t) rows * sizeof(g1j_t)));
@@ -423,7 +428,7 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
     }
     for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
         const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
-        ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, k_msm_digit, dim3(chunks, nr), dim3(256),
+        ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, k_msm_digit, dim3(chunks, nr), dim3(MSM_BLOCK),
                   dst + (size_t) r0 * chunks, s->hi_flags + r0, scalars + (size_t) r0 * ld, ld, s->digit, (uint32_t) s->m, cols, cpt);
     }
     if (chunks > 1) ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_sum_parts, dim3((rows + 63) / 64), dim3(64), s->rowsJ, s->partials, chunks, rows);

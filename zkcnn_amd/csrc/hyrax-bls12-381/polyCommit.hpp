@@ -14,9 +14,9 @@
 //     round: prover sends  Lk = <a_lo, g_hi>, Rk = <a_hi, g_lo>, yL = <a_lo, b_hi>, yR = <a_hi, b_lo>
 //            verifier sends c;   a' = a_lo + c a_hi,  g' = c g_lo + g_hi,  b' = c b_lo + b_hi
 //            P' = Lk + c P + c^2 Rk,   y' = yL + c y + c^2 yR
-//     the recursion stops at length IPA_STOP_LEN (64): the prover sends the remaining vector a* and the verifier
+//     the recursion stops at length IPA_STOP_LEN (256): the prover sends the remaining vector a* and the verifier
 //     checks  P* == <a*, g*>  and  y* == <a*, b*>  (g*, b* = generators / eq table folded with the challenges).
-//     Stopping early trades 2 KB of proof for 6 latency-bound rounds.
+//     Stopping early trades 8 KB of proof for 8 latency-bound rounds (each round is two MSMs over half of the generators).
 // Message order/format of the upstream library is unknowable here ("parity unpinned").
 #pragma once
 #include <chrono>
@@ -86,7 +86,7 @@ inline void eqTable(std::vector<Fr> &out, const Fr *r, int n, const Fr &init) {
     }
 }
 
-enum { IPA_STOP_LEN = 64 };
+enum { IPA_STOP_LEN = 256 };
 inline int ipaRounds(int cb) { int t = 0; while (((size_t) 1 << (cb - t)) > IPA_STOP_LEN) ++t; return t; }
 
 struct ipaRoundMsg {
