@@ -39,13 +39,14 @@ struct msm_state {
     g1a_t *digit = nullptr; uint64_t digit_m = 0; bool digit_ready = false;
     uint32_t *hi_flags = nullptr, *row_list = nullptr; size_t flags_cap = 0;
     g1j_t *tmpJ = nullptr; size_t tmp_cap = 0;
+    void *aff_scratch = nullptr; size_t aff_cap = 0;
 };
 
 void zk_msm_destroy(zk_ctx *ctx) {
     if (!ctx->msm) return;
     msm_state *s = ctx->msm;
     void *bufs[] = {s->tables, s->partials, s->rowsJ, s->rowsA, s->a, s->b, s->coef, s->Lrow, s->sL, s->idxL, s->d_y, s->tbl_scratch,
-                    s->digit, s->hi_flags, s->row_list, s->tmpJ};
+                    s->digit, s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch};
     for (void *p : bufs) if (p) hipFree(p);
     delete s;
     ctx->msm = nullptr;
@@ -267,6 +268,63 @@ __global__ void __launch_bounds__(512) k_msm_finish(g1j_t *outJ, const g1j_t *pa
     if (threadIdx.x == 0) outJ[row] = sm[0][0];
 }
 
+// ---- batched Jacobian -> affine: ONE field inversion for all rows (Montgomery's trick), and that single inversion -- a
+// chain of ~570 dependent products, 1 ms on one GPU lane -- is done by the host between two small kernels (27 us on a CPU core).
+#define AFF_SEG 16
+// per thread: running products inside its segment of AFF_SEG points; seg[t] = product of the segment's Z (infinity counts as 1)
+__global__ void k_aff_prefix(fp_t *pre, fp_t *seg, const g1j_t *in, uint32_t n) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t * AFF_SEG >= n) return;
+    fp_t run = fp_one();
+    for (uint32_t i = t * AFF_SEG; i < min(n, (t + 1) * AFF_SEG); ++i) {
+        pre[i] = run;
+        const fp_t z = in[i].Z;
+        if (!fp_is_zero(z)) run = fp_mul(run, z);
+    }
+    seg[t] = run;
+}
+// single block: exclusive prefix and suffix products over the nseg segment products (in place), total product to *total
+__global__ void __launch_bounds__(1024) k_aff_scan(fp_t *seg_pre, fp_t *seg_suf, fp_t *total, const fp_t *seg, uint32_t nseg) {
+    __shared__ fp_t a[1024], b[1024];
+    const uint32_t t = threadIdx.x;
+    a[t] = t < nseg ? seg[t] : fp_one();                      // inclusive prefix
+    b[t] = t < nseg ? seg[nseg - 1 - t] : fp_one();           // inclusive prefix of the reversed sequence = suffix
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        fp_t x, y;
+        const bool on = t >= d;
+        if (on) { x = fp_mul(a[t], a[t - d]); y = fp_mul(b[t], b[t - d]); }
+        __syncthreads();
+        if (on) { a[t] = x; b[t] = y; }
+        __syncthreads();
+    }
+    if (t < nseg) {
+        seg_pre[t] = t ? a[t - 1] : fp_one();
+        seg_suf[t] = (nseg - 1 - t) ? b[nseg - 2 - t] : fp_one();
+    }
+    if (t == 0) *total = a[nseg - 1];
+}
+__global__ void k_aff_finish(g1a_t *out, const g1j_t *in, const fp_t *pre, const fp_t *seg_pre, const fp_t *seg_suf, const fp_t *total_inv,
+                             uint32_t n) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t * AFF_SEG >= n) return;
+    fp_t inv = fp_mul(fp_mul(*total_inv, seg_pre[t]), seg_suf[t]);        // 1 / (product of this segment's Z)
+    const uint32_t lo = t * AFF_SEG, hi = min(n, (t + 1) * AFF_SEG);
+    for (uint32_t i = hi; i-- > lo;) {
+        const g1j_t Q = in[i];
+        g1a_t r;
+        if (fp_is_zero(Q.Z)) { r.x = fp_zero(); r.y = fp_zero(); }
+        else {
+            const fp_t zi = fp_mul(inv, pre[i]);
+            inv = fp_mul(inv, Q.Z);
+            const fp_t zi2 = fp_sqr(zi);
+            r.x = fp_mul(Q.X, zi2);
+            r.y = fp_mul(fp_mul(Q.Y, zi2), zi);
+        }
+        out[i] = r;
+    }
+}
+
 __global__ void k_to_affine(g1a_t *out, const g1j_t *in, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = g1_to_affine(in[i]);
@@ -450,6 +508,25 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
 // few points: Jacobian -> affine on the host (one inversion each); many: on the device
 static int32_t fetch_points(zk_ctx *ctx, uint32_t rows, uint64_t *out) {
     msm_state *s = ctx->msm;
+    const uint32_t nseg = (rows + AFF_SEG - 1) / AFF_SEG;
+    if (rows > 8 && nseg <= 1024) {
+        int32_t rc = regrow(ctx, &s->aff_scratch, &s->aff_cap, ((size_t) rows + 3 * (size_t) nseg + 2) * sizeof(fp_t));
+        if (rc) return rc;
+        fp_t *pre = (fp_t *) s->aff_scratch, *seg = pre + rows, *seg_pre = seg + nseg, *seg_suf = seg_pre + nseg, *tot = seg_suf + nseg;
+        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_aff_prefix, dim3((nseg + 63) / 64), dim3(64), pre, seg, s->rowsJ, rows);
+        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_aff_scan, dim3(1), dim3(1024), seg_pre, seg_suf, tot, seg, nseg);
+        ZK_HIP(hipGetLastError());
+        zkff::Fp total, inv;
+        ZK_HIP(hipMemcpyAsync(&total, tot, sizeof(fp_t), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        zkff::Fp::invert(inv, total);                      // the one sequential inversion: O(1) host work, like add_term
+        ZK_HIP(hipMemcpyAsync(tot + 1, &inv, sizeof(fp_t), hipMemcpyHostToDevice, ctx->stream));
+        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_aff_finish, dim3((nseg + 63) / 64), dim3(64), s->rowsA, s->rowsJ, pre, seg_pre, seg_suf, tot + 1, rows);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipMemcpyAsync(out, s->rowsA, (size_t) rows * sizeof(g1a_t), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        return ZK_OK;
+    }
     if (rows > 8) {
         ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_to_affine, dim3((rows + 63) / 64), dim3(64), s->rowsA, s->rowsJ, rows);
         ZK_HIP(hipGetLastError());
