@@ -100,6 +100,19 @@ int32_t zk_witness_ntt(zk_ctx *ctx, uint64_t *dst, const uint64_t *src, int32_t 
 int32_t zk_witness_dotprod(zk_ctx *ctx, uint64_t *out, uint64_t n_out, const uint64_t *F, uint64_t n_in, const zk_bin_gate *gates,
                            uint64_t n_gates, int32_t fft_bl);
 
+/* ---- witness of a generic layer (reference src/neuralNetwork.cpp:918-935, calcNormalLayer) -------------------------------- */
+/* Layer 0 is built piecewise while the circuit is generated (weights, then the bit / sign / max witnesses of every RELU and pooling
+ * layer): the context keeps a device copy; call this with every span the host has written since the last call (no holes:
+ * offset <= entries held so far; offset 0 starts a new layer 0). */
+int32_t zk_witness_input(zk_ctx *ctx, uint64_t offset, const uint64_t *values, uint64_t n);
+/* out[g] = scale * ( sum over uni gates in_lu[u] * two_mul[sc]  +  sum over bin gates in_U[u] * in_V[v] * two_mul[sc] ), g < n_out.
+ * Operands in layer 0 are read from the device copy above, operands in the previous layer from `prev` (host, n_prev entries);
+ * uni.lu != 0 means "previous layer", bin.l as in reference src/circuit.h:31-32; prev == NULL: the previous layer is layer 0 itself
+ * (layer 1). out is a host array. */
+int32_t zk_witness_gates(zk_ctx *ctx, uint64_t *out, uint64_t n_out, const zk_uni_gate *uni, uint64_t n_uni, const zk_bin_gate *bin,
+                         uint64_t n_bin, const uint64_t *prev, uint64_t n_prev, const uint64_t *two_mul, uint32_t n_two_mul,
+                         const uint64_t scale[4]);
+
 /* ---- built-in profiler: HIP events around every launch of the selected kernel classes, on the context's stream ---- */
 /* class_mask: bit i selects class i of zk_profile_report's list; 0 switches profiling off; ~0u selects all */
 int32_t zk_profile_enable(zk_ctx *ctx, uint32_t class_mask);

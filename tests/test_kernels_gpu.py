@@ -138,3 +138,70 @@ def test_batched_ntt_matches_reference_fft(hip, oracle, logn):
     for c in range(count):
         assert np.array_equal(back[c * half:(c + 1) * half], full_back[c * length:c * length + half])
     assert np.array_equal(back, x)
+
+
+def _gates_expected(n_out, uni, bin_, v0, vp, tm, scale):
+    """calcNormalLayer (reference src/neuralNetwork.cpp:918-935) on Python integers"""
+    out = [0] * n_out
+    for gt in uni:
+        x = (vp if gt["lu"] else v0)[gt["u"]]
+        out[gt["g"]] = (out[gt["g"]] + x * tm[gt["sc"]]) % R_MOD
+    for gt in bin_:
+        x = (v0 if gt["l"] == 0 else vp)[gt["u"]]
+        y = (vp if (gt["l"] & 1) else v0)[gt["v"]]
+        out[gt["g"]] = (out[gt["g"]] + x * y * tm[gt["sc"]]) % R_MOD
+    return [o * scale % R_MOD for o in out]
+
+
+@pytest.mark.parametrize("case", ["grouped", "shuffled", "layer1", "uni_only", "long_runs"])
+def test_witness_gates(hip, oracle, case):
+    """zk_witness_gates: every gate of a generic layer, against big-int arithmetic; layer 0 uploaded in two overlapping spans"""
+    rng = np.random.default_rng(7)
+    n0, n_prev, n_out = 3000, 2000, 700
+    v0m, vpm = _rand(oracle, n0, 71), _rand(oracle, n_prev, 72)
+    q = 20
+    tm = [pow(2, k, R_MOD) for k in range(q + 1)] + [(-pow(2, k, R_MOD)) % R_MOD for k in range(q + 1)]
+    tmm = to_mont(tm)
+    scale = 1 if case in ("grouped", "long_runs") else pow(49, -1, R_MOD)
+    if case == "long_runs":                 # segments longer than a block (conv: thousands of products per output), outputs without gates
+        gs = np.sort(rng.choice(np.array([3, 4, 5, 250, 699]), size=6000))
+    else:
+        gs = np.sort(rng.integers(0, n_out, size=6000))
+    n_uni = 0 if case == "layer1" else 2500
+    uni = np.zeros(n_uni, dtype=zkcnn_amd.HipContext.UNI_GATE)
+    uni["g"] = np.sort(rng.integers(0, n_out, size=n_uni)) if case != "long_runs" else np.sort(rng.choice(np.array([3, 5, 699]), size=n_uni))
+    uni["lu"] = rng.integers(0, 2, size=n_uni) * 9
+    uni["u"] = [rng.integers(0, n_prev if lu else n0) for lu in uni["lu"]]
+    uni["sc"] = rng.integers(0, len(tm), size=n_uni) * (rng.integers(0, 2, size=n_uni))
+    n_bin = 0 if case == "uni_only" else gs.shape[0]
+    bin_ = np.zeros(n_bin, dtype=zkcnn_amd.HipContext.BIN_GATE)
+    bin_["g"] = gs[:n_bin]
+    bin_["l"] = rng.integers(0, 3, size=n_bin)
+    bin_["u"] = [rng.integers(0, n0 if l == 0 else n_prev) for l in bin_["l"]]
+    bin_["v"] = [rng.integers(0, n_prev if (l & 1) else n0) for l in bin_["l"]]
+    bin_["sc"] = rng.integers(0, len(tm), size=n_bin) * (rng.integers(0, 2, size=n_bin))
+    if case == "shuffled":                  # equal outputs no longer adjacent: the entry point regroups
+        bin_ = bin_[rng.permutation(n_bin)]
+        uni = uni[rng.permutation(n_uni)]
+    prev = vpm
+    if case == "layer1":                    # previous layer == layer 0 (prev = NULL)
+        prev, n_prev_eff = None, n0
+        bin_["u"] %= n0
+        bin_["v"] %= n0
+        vp_int = from_mont(v0m)
+    else:
+        vp_int = from_mont(vpm)
+    hip.witness_input(0, v0m[:2000])
+    hip.witness_input(1500, v0m[1500:])     # overlapping second span, as after a resize of layer 0
+    got = hip.witness_gates(n_out, uni, bin_, prev, tmm, to_mont([scale]))
+    want = _gates_expected(n_out, uni, bin_, from_mont(v0m), vp_int, tm, scale)
+    assert from_mont(got) == want
+
+
+def test_witness_gates_rejects_out_of_range(hip, oracle):
+    v0m = _rand(oracle, 10, 5)
+    hip.witness_input(0, v0m)
+    uni = np.zeros(1, dtype=zkcnn_amd.HipContext.UNI_GATE)
+    uni["u"] = 10                            # one past the end of layer 0
+    with pytest.raises(RuntimeError):
+        hip.witness_gates(4, uni, np.zeros(0, dtype=zkcnn_amd.HipContext.BIN_GATE), None, to_mont([1]), to_mont([1]))

@@ -165,6 +165,28 @@ class HipContext:
                                             ctypes.c_uint64(count)), "zk_witness_ntt")
         return dst
 
+    UNI_GATE = np.dtype([("g", "<u4"), ("u", "<u4"), ("lu", "u1"), ("sc", "u1"), ("pad", "u1", (2,))])               # zk_uni_gate
+    BIN_GATE = np.dtype([("g", "<u4"), ("u", "<u4"), ("v", "<u4"), ("sc", "u1"), ("l", "u1"), ("pad", "u1", (2,))])   # zk_bin_gate
+
+    def witness_input(self, offset, values):
+        """(re)writes entries [offset, offset + len) of the device copy of layer 0 (zk_witness_input)"""
+        values = np.ascontiguousarray(values, dtype=np.uint64)
+        self._check(self.lib.zk_witness_input(self.ctx, ctypes.c_uint64(offset), u64p(values), ctypes.c_uint64(values.shape[0])),
+                    "zk_witness_input")
+
+    def witness_gates(self, n_out, uni, bin_, prev, two_mul, scale):
+        """value of every gate of a generic layer (zk_witness_gates); uni / bin_ are UNI_GATE / BIN_GATE record arrays"""
+        out = np.zeros((n_out, 4), dtype=np.uint64)
+        uni = np.ascontiguousarray(uni, dtype=self.UNI_GATE)
+        bin_ = np.ascontiguousarray(bin_, dtype=self.BIN_GATE)
+        two_mul = np.ascontiguousarray(two_mul, dtype=np.uint64)
+        pp = u64p(prev) if prev is not None else None
+        self._check(self.lib.zk_witness_gates(self.ctx, u64p(out), ctypes.c_uint64(n_out), uni.ctypes.data_as(ctypes.c_void_p),
+                                              ctypes.c_uint64(uni.shape[0]), bin_.ctypes.data_as(ctypes.c_void_p),
+                                              ctypes.c_uint64(bin_.shape[0]), pp, ctypes.c_uint64(0 if prev is None else prev.shape[0]),
+                                              u64p(two_mul), ctypes.c_uint32(two_mul.shape[0]), u64p(scale)), "zk_witness_gates")
+        return out
+
     def commit_rows(self, scalars, bases, rows, cols):
         out = np.zeros((rows, 12), dtype=np.uint64)
         self._check(self.lib.zk_k_commit_rows(self.ctx, u64p(out), u64p(scalars), u64p(bases), ctypes.c_uint64(rows), ctypes.c_uint64(cols)),

@@ -99,6 +99,10 @@ struct zk_ctx {
 
     msm_state *msm = nullptr;
 
+    // witness generation (zk_witness_input / zk_witness_gates): device copy of layer 0 while it is being built + staging
+    dev_buf w_val0, w_stage[5];
+    uint64_t w_val0_len = 0;
+
     // profiler: when a class bit is set in prof_mask every launch of that class is bracketed by events
     uint32_t prof_mask = 0;
     std::vector<prof_pending> prof_q;

@@ -142,20 +142,11 @@ __device__ __forceinline__ fr_t gate_term(const gate_rec &rc, const gate_args &a
 // One gate per thread. Wave-level segmented scan with cross-lane moves, cross-wave carry through
 // LDS. Segments that lie inside a block are stored straight to `out`; the block's first and last
 // segment go to `carry` (2 slots per block) and are combined by k_gate_fixup.
-__global__ void __launch_bounds__(ZK_BLOCK) k_gate_reduce(fr_t *out, uint32_t *carry_key, fr_t *carry_val, gate_args a) {
+__device__ __forceinline__ void gate_segment_store(uint32_t key, fr_t val, bool live, uint64_t idx, uint64_t n, fr_t *out,
+                                                   uint32_t *carry_key, fr_t *carry_val, bool post_scale, const fr_t &post) {
     __shared__ uint32_t s_head[ZK_BLOCK / 64], s_tail[ZK_BLOCK / 64];
     __shared__ fr_t s_tailval[ZK_BLOCK / 64];
-    const uint64_t idx = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool live = idx < a.n;
-
-    uint32_t key = GATE_NOKEY;
-    fr_t val = fr_zero();
-    if (live) {
-        gate_rec rc = a.recs[idx];
-        key = rc.key;
-        val = gate_term(rc, a);
-    }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         uint32_t k2 = (uint32_t) __shfl_up((int) key, d, 64);
@@ -173,11 +164,11 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_gate_reduce(fr_t *out, uint32_t *c
         }
     }
     if (!live) return;
-    const uint64_t blk_last = min(a.n, (blockIdx.x + 1) * (uint64_t) ZK_BLOCK) - 1;
+    const uint64_t blk_last = min(n, (blockIdx.x + 1) * (uint64_t) ZK_BLOCK) - 1;
     uint32_t next_key = (uint32_t) __shfl_down((int) key, 1, 64);
     if (lane == 63) next_key = (wave + 1 < ZK_BLOCK / 64) ? s_head[wave + 1] : GATE_NOKEY;
     const uint32_t kf = s_head[0];
-    if (a.post_scale && (idx == blk_last || next_key != key)) val = fr_mul(val, a.post);   // segment (or block-partial) total
+    if (post_scale && (idx == blk_last || next_key != key)) val = fr_mul(val, post);   // segment (or block-partial) total
     if (idx == blk_last) {
         const int slot = (key == kf) ? 0 : 1;
         carry_key[2 * blockIdx.x + slot] = key;
@@ -188,6 +179,62 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_gate_reduce(fr_t *out, uint32_t *c
             carry_key[2 * blockIdx.x] = key;
             fr_store(carry_val + 2 * blockIdx.x, val);
         } else fr_store(out + key, val);
+    }
+}
+
+__global__ void __launch_bounds__(ZK_BLOCK) k_gate_reduce(fr_t *out, uint32_t *carry_key, fr_t *carry_val, gate_args a) {
+    const uint64_t idx = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x;
+    const bool live = idx < a.n;
+    uint32_t key = GATE_NOKEY;
+    fr_t val = fr_zero();
+    if (live) {
+        gate_rec rc = a.recs[idx];
+        key = rc.key;
+        val = gate_term(rc, a);
+    }
+    gate_segment_store(key, val, live, idx, a.n, out, carry_key, carry_val, a.post_scale != 0, a.post);
+}
+
+// ---- witness: value of every gate of a generic layer (reference src/neuralNetwork.cpp:918-935, calcNormalLayer) ----
+// Gate lists exactly as the circuit stores them; gates of one output must be adjacent (the generator emits them so; the
+// entry point regroups a list that is not). out[g] = sum of the list's terms; outputs without a gate are not written.
+struct uni_gate_dev { uint32_t g, u; uint8_t lu, sc, pad_[2]; };
+struct bin_gate_dev { uint32_t g, u, v; uint8_t sc, l, pad_[2]; };
+__global__ void __launch_bounds__(ZK_BLOCK) k_eval_uni(fr_t *out, uint32_t *carry_key, fr_t *carry_val, const uni_gate_dev *gates, uint64_t n,
+                                                       const fr_t *val0, const fr_t *val_prev, const fr_t *two_mul) {
+    const uint64_t idx = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x;
+    const bool live = idx < n;
+    uint32_t key = GATE_NOKEY;
+    fr_t val = fr_zero();
+    if (live) {
+        const uni_gate_dev gt = gates[idx];
+        key = gt.g;
+        val = fr_load((gt.lu ? val_prev : val0) + gt.u);
+        if (gt.sc) val = fr_mul(val, fr_load(two_mul + gt.sc));
+    }
+    gate_segment_store(key, val, live, idx, n, out, carry_key, carry_val, false, val);
+}
+__global__ void __launch_bounds__(ZK_BLOCK) k_eval_bin(fr_t *out, uint32_t *carry_key, fr_t *carry_val, const bin_gate_dev *gates, uint64_t n,
+                                                       const fr_t *val0, const fr_t *val_prev, const fr_t *two_mul) {
+    const uint64_t idx = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x;
+    const bool live = idx < n;
+    uint32_t key = GATE_NOKEY;
+    fr_t val = fr_zero();
+    if (live) {
+        const bin_gate_dev gt = gates[idx];
+        key = gt.g;
+        // l == 0: both operands in layer 0; l == 1: both in the previous layer; l == 2: u previous, v layer 0
+        val = fr_mul(fr_load((gt.l == 0 ? val0 : val_prev) + gt.u), fr_load(((gt.l & 1) ? val_prev : val0) + gt.v));
+        if (gt.sc) val = fr_mul(val, fr_load(two_mul + gt.sc));
+    }
+    gate_segment_store(key, val, live, idx, n, out, carry_key, carry_val, false, val);
+}
+// out = (a + b) * scale
+__global__ void k_eval_combine(fr_t *out, const fr_t *a, const fr_t *b, fr_t scale, int scaled, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        fr_t v = fr_add(fr_load(a + i), fr_load(b + i));
+        if (scaled) v = fr_mul(v, scale);
+        fr_store(out + i, v);
     }
 }
 

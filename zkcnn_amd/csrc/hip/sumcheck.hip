@@ -94,6 +94,8 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
     for (void *p : ctx->owned) hipFree(p);
     if (ctx->scratch.p) hipFree(ctx->scratch.p);
+    if (ctx->w_val0.p) hipFree(ctx->w_val0.p);
+    for (dev_buf &b : ctx->w_stage) if (b.p) hipFree(b.p);
     if (ctx->h_result) hipHostFree(ctx->h_result);
     if (ctx->h_slot) hipHostFree((void *) ctx->h_slot);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -1087,6 +1089,116 @@ extern "C" int32_t zk_witness_dotprod(zk_ctx *ctx, uint64_t *out, uint64_t n_out
     }
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(out, dO, n_out * len * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+// ---- witness of a generic layer: every gate evaluated on the GPU (reference src/neuralNetwork.cpp:918-935) ----
+static int32_t grow_buf(zk_ctx *ctx, dev_buf &b, size_t bytes, size_t keep = 0) {
+    if (b.bytes >= bytes) return ZK_OK;
+    size_t want = std::max(bytes, b.bytes + b.bytes / 2);
+    void *np = nullptr;
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (hipMalloc(&np, want) != hipSuccess) {
+        (void) hipGetLastError();
+        want = bytes;
+        ZK_HIP(hipMalloc(&np, want));
+    }
+    if (keep && b.p) ZK_HIP(hipMemcpy(np, b.p, keep, hipMemcpyDeviceToDevice));
+    if (b.p) ZK_HIP(hipFree(b.p));
+    b.p = np;
+    b.bytes = want;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_witness_input(zk_ctx *ctx, uint64_t offset, const uint64_t *values, uint64_t n) {
+    CHECK_CTX();
+    if (offset == 0) ctx->w_val0_len = 0;                            // a new layer 0 starts
+    if (offset > ctx->w_val0_len) return ZK_ERR_ARG;                 // the copy has no holes
+    int32_t rc = grow_buf(ctx, ctx->w_val0, (offset + n) * 32, ctx->w_val0_len * 32);
+    if (rc) return rc;
+    if (n) ZK_HIP(hipMemcpyAsync((fr_t *) ctx->w_val0.p + offset, values, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    ctx->w_val0_len = std::max<uint64_t>(ctx->w_val0_len, offset + n);
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+// true when equal g are adjacent; range-checks the list on the way
+template <class G, class Check>
+static int grouped_by_output(const G *gates, uint64_t n, uint64_t n_out, std::vector<uint8_t> &seen, Check in_range) {
+    std::fill(seen.begin(), seen.end(), 0);
+    bool grouped = true;
+    uint32_t prev = 0xffffffffu;
+    for (uint64_t k = 0; k < n; ++k) {
+        const G &gt = gates[k];
+        if (gt.g >= n_out || !in_range(gt)) return -1;
+        if (gt.g != prev) {
+            if (seen[gt.g]) grouped = false;
+            seen[gt.g] = 1;
+            prev = gt.g;
+        }
+    }
+    return grouped ? 1 : 0;
+}
+template <class G>
+static void regroup(std::vector<G> &dst, const G *gates, uint64_t n, uint64_t n_out) {
+    std::vector<uint64_t> pos(n_out + 1, 0);
+    for (uint64_t k = 0; k < n; ++k) ++pos[gates[k].g + 1];
+    for (uint64_t g = 0; g < n_out; ++g) pos[g + 1] += pos[g];
+    dst.resize(n);
+    for (uint64_t k = 0; k < n; ++k) dst[pos[gates[k].g]++] = gates[k];
+}
+
+extern "C" int32_t zk_witness_gates(zk_ctx *ctx, uint64_t *out, uint64_t n_out, const zk_uni_gate *uni, uint64_t n_uni,
+                                    const zk_bin_gate *bin, uint64_t n_bin, const uint64_t *prev, uint64_t n_prev,
+                                    const uint64_t *two_mul, uint32_t n_two_mul, const uint64_t scale[4]) {
+    CHECK_CTX();
+    if (!n_out || n_out > 0xfffffffeull || !n_two_mul) return ZK_ERR_ARG;
+    static_assert(sizeof(uni_gate_dev) == sizeof(zk_uni_gate) && sizeof(bin_gate_dev) == sizeof(zk_bin_gate), "gate layout");
+    const uint64_t n0 = ctx->w_val0_len;
+    if (!prev) n_prev = n0;                                          // layer 1: the previous layer IS layer 0
+    std::vector<uint8_t> seen(n_out);
+    std::vector<zk_uni_gate> uni_sorted;
+    std::vector<zk_bin_gate> bin_sorted;
+    int g1 = grouped_by_output(uni, n_uni, n_out, seen, [&](const zk_uni_gate &gt) {
+        return gt.sc < n_two_mul && gt.u < (gt.lu ? n_prev : n0); });
+    int g2 = g1 < 0 ? -1 : grouped_by_output(bin, n_bin, n_out, seen, [&](const zk_bin_gate &gt) {
+        return gt.sc < n_two_mul && gt.l <= 2 && gt.u < (gt.l == 0 ? n0 : n_prev) && gt.v < ((gt.l & 1) ? n_prev : n0); });
+    if (g1 < 0 || g2 < 0) { ctx->err = "witness gate operand out of range"; return ZK_ERR_ARG; }
+    if (!g1) { regroup(uni_sorted, uni, n_uni, n_out); uni = uni_sorted.data(); }
+    if (!g2) { regroup(bin_sorted, bin, n_bin, n_out); bin = bin_sorted.data(); }
+
+    const uint64_t blocks_u = (n_uni + ZK_BLOCK - 1) / ZK_BLOCK, blocks_b = (n_bin + ZK_BLOCK - 1) / ZK_BLOCK;
+    const uint64_t slots = 2 * std::max<uint64_t>(std::max(blocks_u, blocks_b), 1);
+    int32_t rc;
+    dev_buf &bG = ctx->w_stage[0], &bP = ctx->w_stage[1], &bO = ctx->w_stage[2], &bC = ctx->w_stage[3], &bT = ctx->w_stage[4];
+    if ((rc = grow_buf(ctx, bG, std::max<size_t>(n_uni * sizeof(zk_uni_gate), n_bin * sizeof(zk_bin_gate)) + 16)) ||
+        (rc = grow_buf(ctx, bP, (prev ? std::max<uint64_t>(n_prev, 1) : 1) * 32)) || (rc = grow_buf(ctx, bO, 3 * n_out * 32)) ||
+        (rc = grow_buf(ctx, bC, slots * (32 + 4))) || (rc = grow_buf(ctx, bT, (size_t) n_two_mul * 32)))
+        return rc;
+    fr_t *dA = (fr_t *) bO.p, *dB = dA + n_out, *dO = dB + n_out;
+    fr_t *carry_val = (fr_t *) bC.p;
+    uint32_t *carry_key = (uint32_t *) (carry_val + slots);
+    const fr_t *v0 = (const fr_t *) ctx->w_val0.p, *vp = prev ? (const fr_t *) bP.p : v0, *tm = (const fr_t *) bT.p;
+    if (prev && n_prev) ZK_HIP(hipMemcpyAsync(bP.p, prev, n_prev * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(bT.p, two_mul, (size_t) n_two_mul * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemsetAsync(dA, 0, 2 * n_out * 32, ctx->stream));
+    if (n_uni) {
+        ZK_HIP(hipMemcpyAsync(bG.p, uni, n_uni * sizeof(zk_uni_gate), hipMemcpyHostToDevice, ctx->stream));
+        ZK_LAUNCH(PC_GATE, 44.0 * (double) n_uni, k_eval_uni, dim3((uint32_t) blocks_u), dim3(ZK_BLOCK), dA, carry_key, carry_val,
+                  (const uni_gate_dev *) bG.p, n_uni, v0, vp, tm);
+        ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup, dim3(grid_for(2 * blocks_u)), dim3(ZK_BLOCK), dA, carry_key, carry_val, 2 * blocks_u);
+    }
+    if (n_bin) {
+        ZK_HIP(hipMemcpyAsync(bG.p, bin, n_bin * sizeof(zk_bin_gate), hipMemcpyHostToDevice, ctx->stream));
+        ZK_LAUNCH(PC_GATE, 80.0 * (double) n_bin, k_eval_bin, dim3((uint32_t) blocks_b), dim3(ZK_BLOCK), dB, carry_key, carry_val,
+                  (const bin_gate_dev *) bG.p, n_bin, v0, vp, tm);
+        ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup, dim3(grid_for(2 * blocks_b)), dim3(ZK_BLOCK), dB, carry_key, carry_val, 2 * blocks_b);
+    }
+    const HFr sc = H(scale);
+    ZK_LAUNCH(PC_MISC, 0.0, k_eval_combine, dim3(grid_for(n_out)), dim3(ZK_BLOCK), dO, dA, dB, to_dev(sc), sc == HFr::one() ? 0 : 1, n_out);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpyAsync(out, dO, n_out * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     return ZK_OK;
 }

@@ -23,6 +23,20 @@ public:
         if (rc != ZK_OK) throw std::runtime_error(string("zk_witness_dotprod: ") + zk_last_error(ctx));
         return true;
     }
+    bool input(size_t offset, const F *values, size_t n) override {
+        int rc = zk_witness_input(ctx, offset, reinterpret_cast<const uint64_t *>(values), n);
+        if (rc != ZK_OK) throw std::runtime_error(string("zk_witness_input: ") + zk_last_error(ctx));
+        return true;
+    }
+    bool gates(F *out, size_t n_out, const uniGate *uni, size_t n_uni, const binGate *bin, size_t n_bin, const F *prev, size_t n_prev,
+               const F *two_mul, size_t n_two_mul, const F &scale) override {
+        static_assert(sizeof(uniGate) == sizeof(zk_uni_gate) && sizeof(binGate) == sizeof(zk_bin_gate), "gate records cross the C-ABI as they are");
+        int rc = zk_witness_gates(ctx, reinterpret_cast<uint64_t *>(out), n_out, reinterpret_cast<const zk_uni_gate *>(uni), n_uni,
+                                  reinterpret_cast<const zk_bin_gate *>(bin), n_bin, reinterpret_cast<const uint64_t *>(prev), n_prev,
+                                  reinterpret_cast<const uint64_t *>(two_mul), (uint32_t) n_two_mul, reinterpret_cast<const uint64_t *>(&scale));
+        if (rc != ZK_OK) throw std::runtime_error(string("zk_witness_gates: ") + zk_last_error(ctx));
+        return true;
+    }
 private:
     zk_ctx *ctx;
 };

@@ -136,6 +136,8 @@ void neuralNetwork::build(layeredCircuit &C, vector<vector<F>> &val, bool only_c
     val.assign(SIZE, vector<F>());
     vals = &val;
     two_mul = C.two_mul.data();
+    n_two_mul = C.two_mul.size();
+    in_dirty_lo = 0;
 
     i64 layer_id = 0;
     emitInput(C.circuit[layer_id++]);
@@ -210,6 +212,7 @@ int neuralNetwork::quantBits(double mx, double mn) const {
 void neuralNetwork::loadPicture(layer &L) {
     auto &v0 = (*vals)[0];
     v0.assign(L.size, F_ZERO);
+    touch0(0);
     const i64 n = pic_channel * pic_size_x * pic_size_y;
     vector<double> dat(n);
     double mx = -10000, mn = 10000;
@@ -235,6 +238,7 @@ void neuralNetwork::loadConvWeight(i64 first_id) {
     }
     w_bit = quantBits(mx, mn);
     auto &v0 = (*vals)[0];
+    touch0(first_id);
     for (i64 i = 0; i < n; ++i) v0[first_id + i] = F((i64) (dat[i] * std::exp2(w_bit)));
 }
 
@@ -249,11 +253,13 @@ void neuralNetwork::loadFcWeight(i64 first_id) {
     }
     w_bit = quantBits(mx, mn);
     auto &v0 = (*vals)[0];
+    touch0(first_id);
     for (i64 i = 0; i < n; ++i) v0[first_id + i] = F((i64) (dat[i] * std::exp2(w_bit)));
 }
 
 void neuralNetwork::loadBias(i64 first_id) {
     auto &v0 = (*vals)[0];
+    touch0(first_id);
     for (i64 co = 0; co < channel_out; ++co) {
         double b = src->next(dataSource::BIAS, channel_in * m * m);
         v0[first_id + co] = F((i64) (b * std::exp2(w_bit + x_bit)));
@@ -262,18 +268,22 @@ void neuralNetwork::loadBias(i64 first_id) {
 
 void neuralNetwork::putBit(i64 layer_id, i64 idx, i64 dst, i64 shift) {
     i64 mag = std::llabs((*vals)[layer_id].at(idx).getInt64());
+    touch0(dst);
     (*vals)[0].at(dst) = F((i64) ((mag >> shift) & 1));
 }
 void neuralNetwork::putFieldBit(const F &data, i64 dst, i64 shift) {
     i64 mag = std::llabs(data.getInt64());
+    touch0(dst);
     (*vals)[0].at(dst) = F((i64) ((mag >> shift) & 1));
 }
 void neuralNetwork::putSign(i64 layer_id, i64 idx, i64 dst) {
+    touch0(dst);
     (*vals)[0].at(dst) = (*vals)[layer_id].at(idx).isNegative() ? F_ONE : F_ZERO;
 }
 void neuralNetwork::putMax(i64 layer_id, i64 idx, i64 dst) {
     const F &x = (*vals)[layer_id].at(idx);
     F clamped = x.isNegative() ? F_ZERO : x;
+    touch0(dst);
     if (clamped > (*vals)[0].at(dst)) (*vals)[0].at(dst) = clamped;
 }
 
@@ -282,6 +292,17 @@ void neuralNetwork::evalGates(const layer &L, i64 layer_id) {
     auto &val = *vals;
     auto &out = val[layer_id];
     out.assign(L.size, F_ZERO);
+    if (accel && layer_id >= 1) {
+        auto &v0 = val[0];
+        const auto &prev = val[layer_id - 1];
+        const i64 lo = std::min<i64>(in_dirty_lo, (i64) v0.size());
+        if (accel->input((size_t) lo, v0.data() + lo, v0.size() - (size_t) lo) &&
+            accel->gates(out.data(), out.size(), L.uni_gates.data(), L.uni_gates.size(), L.bin_gates.data(), L.bin_gates.size(),
+                         layer_id > 1 ? prev.data() : nullptr, layer_id > 1 ? prev.size() : 0, two_mul, n_two_mul, L.scale)) {
+            in_dirty_lo = (i64) v0.size();
+            return;
+        }
+    }
     for (const uniGate &gt : L.uni_gates) {
         const F &x = val[gt.lu].at(gt.u);
         if (gt.sc == 0) out[gt.g] = out[gt.g] + x;
@@ -529,6 +550,7 @@ void neuralNetwork::emitRelu(layer &L, i64 &layer_id, i64 block_len) {
 
     auto &v0 = (*vals)[0];
     const i64 first_dcmp_id = (i64) v0.size();
+    touch0(first_dcmp_id);
     v0.resize(v0.size() + block_len * Q_MAX, F_ZERO);
     total_relu_in_size += block_len * Q_MAX;
     const u8 lcode = (u8) (2 * (layer_id > 1));
@@ -570,6 +592,7 @@ void neuralNetwork::emitAvgPool(layer &L, i64 &layer_id) {
 
     auto &val = *vals;
     const i64 first_gate_id = (i64) val[0].size();
+    touch0(first_gate_id);
     val[0].resize(val[0].size() + zero_start * dbl, F_ZERO);
     total_ave_in_size += zero_start * dbl;
 
@@ -609,6 +632,7 @@ void neuralNetwork::emitMaxPool(layeredCircuit &C, i64 &layer_id) {
     const i64 ksq = sqr(pool_sz);
 
     const i64 first_dcmp_id = (i64) val[0].size();
+    touch0(first_dcmp_id);
     const i64 dcmp_cnt = poolAuxSize();
     val[0].resize(val[0].size() + dcmp_cnt, F_ZERO);
     const i64 first_max_id = (i64) val[0].size();

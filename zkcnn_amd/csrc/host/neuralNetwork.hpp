@@ -51,6 +51,11 @@ public:
     // count transforms of length 2^logn; forward: half-length inputs, full outputs; inverse: full inputs, half outputs
     virtual bool ntt(F *dst, const F *src, int logn, bool inverse, size_t count) = 0;
     virtual bool dotProd(F *out, size_t n_out, const F *in, size_t n_in, const binGate *gates, size_t n_gates, int fft_bl) = 0;
+    // layer 0 grows while the circuit is generated: entries [offset, offset + n) were (re)written by the host
+    virtual bool input(size_t offset, const F *values, size_t n) = 0;
+    // value of every gate of a generic layer; operands in layer 0 come from the spans passed to input()
+    virtual bool gates(F *out, size_t n_out, const uniGate *uni, size_t n_uni, const binGate *bin, size_t n_bin, const F *prev,
+                       size_t n_prev, const F *two_mul, size_t n_two_mul, const F &scale) = 0;
 };
 
 class neuralNetwork {
@@ -100,6 +105,9 @@ private:
     int x_bit, w_bit, x_next_bit;
 
     vector<vector<F>> *vals;       // == &pr.val while building
+    i64 in_dirty_lo = 0;           // layer-0 entries from here on are newer than the accelerator's copy
+    size_t n_two_mul = 0;
+    void touch0(i64 idx) { if (idx < in_dirty_lo) in_dirty_lo = idx; }
     const F *two_mul;
 
     void planLayout();
