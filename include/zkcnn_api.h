@@ -26,6 +26,8 @@ typedef struct {
 #define ZKCNN_MODE_DRIVE_ONLY  1u  /* same challenges and prover calls, verifier checks skipped */
 #define ZKCNN_MODE_REUSE_GENS  2u  /* keep the session's commitment generators instead of drawing new ones */
 #define ZKCNN_MODE_TAMPER      4u  /* test hook: the verifier corrupts message number (mode >> 8) before checking it */
+#define ZKCNN_MODE_HOST_PRED   8u  /* verifier's wiring predicates on the host (reference src/verifier.cpp:89-116) instead of the GPU */
+#define ZKCNN_MODE_CROSS_PRED 16u  /* both, and the verifier rejects if they differ (parity check of zk_verifier_*) */
 
 typedef struct {
     int32_t accepted;          /* 1 = "Verification pass" + Hyrax opening ok, 0 = rejected, -1 = not checked */

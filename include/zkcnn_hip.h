@@ -100,6 +100,19 @@ int32_t zk_witness_ntt(zk_ctx *ctx, uint64_t *dst, const uint64_t *src, int32_t 
 int32_t zk_witness_dotprod(zk_ctx *ctx, uint64_t *out, uint64_t n_out, const uint64_t *F, uint64_t n_in, const zk_bin_gate *gates,
                            uint64_t n_gates, int32_t fft_bl);
 
+/* ---- verifier side: wiring predicates over the resident gate lists (reference src/verifier.cpp:36-116) --------------------- */
+/* Everything betaInitPhase1/2 + predicatePhase1/2 produce for layer `layer`: uni[0..1] (already multiplied by beta_v[0] when the
+ * layer has a phase 2) and bin[0..2] (indexed by binGate::l). r_0 / r_1 / alpha / beta: the layer's incoming claim; r_u / r_v: this
+ * layer's sumcheck points; r_u2 / r_v2: the points of layer + 2 (PADDING and DOT_PROD only, may be NULL otherwise). The tables
+ * are rebuilt from these arguments in verifier-owned buffers; nothing of the prover's state is read except the circuit. */
+int32_t zk_verifier_predicates(zk_ctx *ctx, int32_t layer, const uint64_t *r_0, const uint64_t *r_1, const uint64_t alpha[4],
+                               const uint64_t beta[4], const uint64_t relu_rou[4], const uint64_t *r_u, const uint64_t *r_v,
+                               const uint64_t *r_u2, const uint64_t *r_v2, uint64_t uni[8], uint64_t bin[12]);
+/* Layer-0 check (reference src/verifier.cpp:304-325): out = sum over layers i = 1..n of
+ * sum_j eq(r_u0, ori_id_u[j]) sig_u[i-1] eq(r_u[i], j) + the same for v. r_u / r_v: n + 1 pointers indexed by layer (entry 0 unused). */
+int32_t zk_verifier_input_predicate(zk_ctx *ctx, const uint64_t *r_u0, const uint64_t *const *r_u, const uint64_t *const *r_v,
+                                    const uint64_t *sig_u, const uint64_t *sig_v, uint32_t n, uint64_t out[4]);
+
 /* ---- witness of a generic layer (reference src/neuralNetwork.cpp:918-935, calcNormalLayer) -------------------------------- */
 /* Layer 0 is built piecewise while the circuit is generated (weights, then the bit / sign / max witnesses of every RELU and pooling
  * layer): the context keeps a device copy; call this with every span the host has written since the last call (no holes:

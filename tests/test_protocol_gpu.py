@@ -36,6 +36,11 @@ def test_gpu_transcript_identical_to_oracle(built, model, pic, pp):
         assert res2.accepted == 1 and gpu2 != gpu
         res3, gpu3 = s.prove(seed=0x5EED0001, mode=zkcnn_amd.MODE_DRIVE_ONLY)
         assert res3.accepted == -1 and gpu3 == gpu       # drive-only makes the same calls with the same challenges
+        # verifier's wiring predicates: GPU (default) == host loops of the reference verifier, value for value, in every layer
+        res4, gpu4 = s.prove(seed=0x5EED0003, mode=zkcnn_amd.MODE_CROSS_PRED)
+        assert res4.accepted == 1, res4.message.decode()
+        res5, gpu5 = s.prove(seed=0x5EED0003, mode=zkcnn_amd.MODE_HOST_PRED)
+        assert res5.accepted == 1 and gpu5 == gpu4
     with oracle_ffi.OracleSession(model, pic, pp) as o:
         ores, cpu = o.prove(seed=0x5EED0001)
         assert ores.accepted == 1
@@ -56,3 +61,20 @@ def test_full_size_vgg11_accepted_and_deterministic(built):
         assert t1 == t2
         bad, _ = s.prove(seed=0x5EED0001, mode=zkcnn_amd.MODE_TAMPER | (700 << 8))
         assert bad.accepted == 0
+        cross, _ = s.prove(seed=0x5EED0004, mode=zkcnn_amd.MODE_CROSS_PRED)     # GPU predicates == host predicates on 1.3e8 gates
+        assert cross.accepted == 1, cross.message.decode()
+        print(f"verifier: GPU predicates {res.verify_s:.3f} s, host predicates {cross.verify_s - res.verify_s:.3f} s more")
+
+
+def test_gpu_verifier_rejects_any_corrupted_message(built):
+    """soundness smoke test with the verifier's predicates on the GPU: perturbing any single prover message must be rejected, and
+    the abandoned proofs must leave the session usable (the next proof is accepted)"""
+    with zkcnn_amd.Session("custom:C2:3:1:f M F4", (8, 8, 1), 2) as s:
+        ok, _ = s.prove(seed=11)
+        assert ok.accepted == 1
+        n_sum = ok.n_messages
+        for k in sorted(set(list(range(0, n_sum, 5)) + [n_sum - 1, n_sum])):
+            bad, _ = s.prove(seed=11, mode=zkcnn_amd.MODE_TAMPER | (k << 8))
+            assert bad.accepted == 0, f"message {k} of {n_sum} corrupted but accepted"
+        again, _ = s.prove(seed=12)
+        assert again.accepted == 1

@@ -99,6 +99,9 @@ struct zk_ctx {
 
     msm_state *msm = nullptr;
 
+    // verifier-side tables (zk_verifier_*): kept apart from the prover's, whose beta_g carries state from layer to layer
+    fr_t *v_bg = nullptr, *v_bu = nullptr, *v_bv = nullptr, *v_gs = nullptr;
+
     // witness generation (zk_witness_input / zk_witness_gates): device copy of layer 0 while it is being built + staging
     dev_buf w_val0, w_stage[5];
     uint64_t w_val0_len = 0;

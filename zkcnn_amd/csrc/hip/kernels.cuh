@@ -281,6 +281,36 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_gate_sum2(fr_t *partials, gate_arg
     }
 }
 
+// ---- verifier side: wiring predicates (reference src/verifier.cpp:89-116) ----
+// partial sums of beta_g[g] * beta_u[u] * beta_v[v] * two_mul[sc] over one phase-2 list, split by where u lives
+__global__ void __launch_bounds__(ZK_BLOCK) k_pred_bin(fr_t *partials, const gate_rec *recs, uint64_t n, const fr_t *bg, const fr_t *bu,
+                                                       const fr_t *bv, const fr_t *two_mul, int use_tm) {
+    __shared__ fr_t smem[2 * ZK_BLOCK / 64];
+    fr_t acc[2] = {fr_zero(), fr_zero()};
+    for (uint64_t i = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x; i < n; i += (uint64_t) gridDim.x * ZK_BLOCK) {
+        const gate_rec rc = recs[i];                                   // key = v, aux = u
+        fr_t t = fr_mul(fr_mul(fr_load(bg + rc.g), fr_load(bu + rc.aux)), fr_load(bv + rc.key));
+        const uint32_t sc = GATE_SC(rc.meta);
+        if (use_tm && sc) t = fr_mul(t, fr_load(two_mul + sc));
+        if (GATE_IN_PREV(rc.meta)) acc[1] = fr_add(acc[1], t);
+        else acc[0] = fr_add(acc[0], t);
+    }
+    fr_block_sum<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        fr_store(partials + 2 * blockIdx.x, acc[0]);
+        fr_store(partials + 2 * blockIdx.x + 1, acc[1]);
+    }
+}
+// partial sums of a[idx ? idx[j] : j] * b[j]
+__global__ void __launch_bounds__(ZK_BLOCK) k_dot_indexed(fr_t *partials, const fr_t *a, const uint32_t *idx, const fr_t *b, uint64_t n) {
+    __shared__ fr_t smem[ZK_BLOCK / 64];
+    fr_t acc[1] = {fr_zero()};
+    for (uint64_t j = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x; j < n; j += (uint64_t) gridDim.x * ZK_BLOCK)
+        acc[0] = fr_add(acc[0], fr_mul(fr_load(a + (idx ? idx[j] : j)), fr_load(b + j)));
+    fr_block_sum<1>(acc, smem);
+    if (threadIdx.x == 0) fr_store(partials + blockIdx.x, acc[0]);
+}
+
 // out[k] (+)= sum_b partials[b * K + k]; single block
 template <int K>
 __global__ void __launch_bounds__(ZK_BLOCK) k_sum_partials(fr_t *out, const fr_t *partials, uint32_t nblocks, int accumulate) {

@@ -41,9 +41,40 @@ private:
     zk_ctx *ctx;
 };
 
+// wiring predicates of the verifier on the prover's GPU context (include/zkcnn_hip.h: zk_verifier_*)
+class hipVerifierAccel : public verifierAccel {
+public:
+    explicit hipVerifierAccel(prover *pr) : p(pr) {}
+    void predicates(u8 layer, const F *r_0, const F *r_1, const F &alpha, const F &beta, const F &relu_rou, const F *r_u, const F *r_v,
+                    const F *r_u2, const F *r_v2, F uni[2], F bin[3]) override {
+        auto q = [](const F *x) { return reinterpret_cast<const uint64_t *>(x); };
+        int rc = zk_verifier_predicates(p->context(), layer, q(r_0), q(r_1), q(&alpha), q(&beta), q(&relu_rou), q(r_u), q(r_v), q(r_u2), q(r_v2),
+                                        reinterpret_cast<uint64_t *>(uni), reinterpret_cast<uint64_t *>(bin));
+        if (rc != ZK_OK) throw std::runtime_error(string("zk_verifier_predicates: ") + zk_last_error(p->context()));
+    }
+    F inputPredicate(const vector<F> &r_u0, const vector<vector<F>> &r_u, const vector<vector<F>> &r_v, const vector<F> &sig_u,
+                     const vector<F> &sig_v) override {
+        const size_t n = sig_u.size();
+        vector<const uint64_t *> pu(n + 1, nullptr), pv(n + 1, nullptr);
+        for (size_t i = 1; i <= n; ++i) {
+            pu[i] = reinterpret_cast<const uint64_t *>(r_u[i].data());
+            pv[i] = reinterpret_cast<const uint64_t *>(r_v[i].data());
+        }
+        F out;
+        int rc = zk_verifier_input_predicate(p->context(), reinterpret_cast<const uint64_t *>(r_u0.data()), pu.data(), pv.data(),
+                                             reinterpret_cast<const uint64_t *>(sig_u.data()), reinterpret_cast<const uint64_t *>(sig_v.data()),
+                                             (uint32_t) n, reinterpret_cast<uint64_t *>(&out));
+        if (rc != ZK_OK) throw std::runtime_error(string("zk_verifier_input_predicate: ") + zk_last_error(p->context()));
+        return out;
+    }
+private:
+    prover *p;
+};
+
 struct gpuSession : public sessionT<prover> {
-    explicit gpuSession(int device) : dev(device) {}
+    explicit gpuSession(int device) : dev(device), va(&p) { vaccel = &va; }
     int dev;
+    hipVerifierAccel va;
 };
 
 extern "C" {

@@ -18,6 +18,7 @@ struct sessionT {
     double witness_s = 0;
     string row;
     witnessAccel *accel = nullptr;     // set by the product driver while the witness is generated
+    verifierAccel *vaccel = nullptr;   // set by the product driver: wiring predicates on the GPU
 
     static double now() {
         return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -57,6 +58,8 @@ struct sessionT {
         v.drive_only = drive;
         if (reuse) v.fixed_gens = &gens;
         if (mode & ZKCNN_MODE_TAMPER) v.tamper_at = (long) (mode >> 8);
+        if (vaccel && !(mode & ZKCNN_MODE_HOST_PRED)) v.accel = vaccel;
+        v.cross_check = (mode & ZKCNN_MODE_CROSS_PRED) != 0;
         bool ok = v.verify();
         out->accepted = drive ? -1 : (ok ? 1 : 0);
         out->n_layers = p.C.size;

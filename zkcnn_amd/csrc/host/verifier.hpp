@@ -59,6 +59,17 @@ inline void drawGenerators(std::vector<G1> &gens, size_t count) {
     }
 }
 
+// Optional accelerator for the verifier's wiring predicates (the only part of the verifier that walks every gate:
+// reference src/verifier.cpp:36-116 and :304-325, `total_slow_timer`). The product driver plugs the HIP implementation
+// in (include/zkcnn_hip.h: zk_verifier_*); without one the loops below run on the host as in the reference.
+struct verifierAccel {
+    virtual ~verifierAccel() {}
+    virtual void predicates(u8 layer, const F *r_0, const F *r_1, const F &alpha, const F &beta, const F &relu_rou, const F *r_u,
+                            const F *r_v, const F *r_u2, const F *r_v2, F uni[2], F bin[3]) = 0;
+    virtual F inputPredicate(const vector<F> &r_u0, const vector<vector<F>> &r_u, const vector<vector<F>> &r_v, const vector<F> &sig_u,
+                             const vector<F> &sig_v) = 0;
+};
+
 template <class ProverT>
 class verifierT {
 public:
@@ -99,6 +110,8 @@ public:
         return verifyInput();
     }
 
+    verifierAccel *accel = nullptr;     // wiring predicates on the GPU
+    bool cross_check = false;           // with an accelerator: also run the host loops and require identical values
     timer total_timer, total_slow_timer;
     double verifierTime() const { return total_timer.elapse_sec(); }
     double verifierSlowTime() const { return total_slow_timer.elapse_sec(); }
@@ -261,7 +274,8 @@ private:
             }
 
             total_slow_timer.start();
-            if (!drive_only) {
+            const bool host_pred = !drive_only && (!accel || cross_check);
+            if (host_pred) {
                 betaInitPhase1(i, alpha, beta, r_0, r_1, relu_rou);
                 predicatePhase1(i);
             }
@@ -287,10 +301,24 @@ private:
                 transcript.put(final_claim_v0[i]);
                 transcript.put(claim_v1);
                 total_slow_timer.start();
-                if (!drive_only) {
+                if (host_pred) {
                     betaInitPhase2(i);
                     predicatePhase2(i);
                 }
+                total_timer.start();
+            }
+            if (!drive_only && accel) {
+                total_slow_timer.start();
+                F uni[2], bin[3];
+                // r_u / r_v hold C.size + 2 entries: PADDING / DOT_PROD look two layers up
+                accel->predicates(i, r_u[i + 1].data(), r_v[i + 1].data(), alpha, beta, relu_rou, r_u[i].data(), r_v[i].data(),
+                                  r_u[i + 2].data(), r_v[i + 2].data(), uni, bin);
+                if (cross_check)
+                    for (int k = 0; k < 3; ++k)
+                        if ((k < 2 && uni[k] != uni_value[k]) || bin[k] != bin_value[k])
+                            return fail("predicate mismatch between host and accelerator, circuit level " + std::to_string(i));
+                uni_value[0] = uni[0]; uni_value[1] = uni[1];
+                bin_value[0] = bin[0]; bin_value[1] = bin[1]; bin_value[2] = bin[2];
                 total_timer.start();
             }
             if (!drive_only) {
@@ -351,9 +379,12 @@ private:
         if (!drive_only) {
             total_slow_timer.start();
             F gr = F_ZERO;
+            const bool host_pred = !accel || cross_check;
+            if (host_pred) {
             beta_g.resize((size_t) 1 << cur.bit_length);
             initBetaTable(beta_g, cur.bit_length, r_u[0].begin(), F_ONE);
-            for (int i = 1; i < C.size; ++i) {
+            }
+            for (int i = 1; host_pred && i < C.size; ++i) {
                 const layer &L = C.circuit[i];
                 if (~L.bit_length_u[0]) {
                     beta_u.resize((size_t) 1 << L.bit_length_u[0]);
@@ -365,6 +396,11 @@ private:
                     initBetaTable(beta_v, L.bit_length_v[0], r_v[i].begin(), sig_v[i - 1]);
                     for (u32 j = 0; j < L.size_v[0]; ++j) gr = gr + beta_g[L.ori_id_v[j]] * beta_v[j];
                 }
+            }
+            if (accel) {
+                F g2 = accel->inputPredicate(r_u[0], r_u, r_v, sig_u, sig_v);
+                if (cross_check && g2 != gr) return fail("layer-0 predicate mismatch between host and accelerator");
+                gr = g2;
             }
             total_timer.start();
             if (eval_in * gr != previousSum) return fail("Liu, semi final, circuit 0");
