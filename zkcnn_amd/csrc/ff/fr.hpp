@@ -71,7 +71,7 @@ struct Xoshiro {
 };
 
 inline Xoshiro &challengeStream() {
-    static Xoshiro g = [] {
+    static thread_local Xoshiro g = [] {       // one stream per thread: concurrent sessions (one per host thread) stay deterministic
         Xoshiro x;
         std::random_device rd;
         x.seed(((uint64_t) rd() << 32) ^ rd());

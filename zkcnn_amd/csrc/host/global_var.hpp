@@ -30,7 +30,7 @@ using std::string;
 using std::vector;
 
 // one row per process, filled by neuralNetwork / verifier (defined in utils.cpp)
-extern vector<string> output_tb;
+extern thread_local vector<string> output_tb;     // per thread: sessions on different host threads do not share the row
 
 template <typename T>
 inline string to_string_wp(const T value, const int digits = 4) {

@@ -1,7 +1,7 @@
 #include "utils.hpp"
 #include <map>
 
-vector<string> output_tb(OUT_COLUMN_CNT, "");
+thread_local vector<string> output_tb(OUT_COLUMN_CNT, "");
 
 // Bit length of the next power of two >= n, -1 for n == 0. The reference computes this in double
 // precision (reference src/utils.cpp:23-25), which over-counts by one at n = 2^29 and 2^31; the same
@@ -50,7 +50,7 @@ void initBetaTable(vector<F> &beta_g, u8 gLength, const vector<F>::const_iterato
 // primitive 2^n-th root of unity: n-1 successive square roots of -1 (reference src/utils.cpp:224-232).
 // Which root each squareRoot call returns is this library's convention (ff/fr.hpp).
 F getRootOfUnit(int n) {
-    static std::map<int, F> cache;
+    static thread_local std::map<int, F> cache;
     auto it = cache.find(n);
     if (it != cache.end()) return it->second;
     F res = F_ONE;
@@ -95,7 +95,7 @@ void phiGInit(vector<F> &phi_g, const vector<F>::const_iterator &rx, const F &sc
 void fft(vector<F> &arr, int logn, bool flag) {
     const size_t len = (size_t) 1 << logn;
     assert(arr.size() == len);
-    static std::map<int, vector<F>> tw_cache;       // key: logn * 2 + inverse
+    static thread_local std::map<int, vector<F>> tw_cache;       // key: logn * 2 + inverse
     vector<F> &tw = tw_cache[logn * 2 + (flag ? 1 : 0)];
     if (tw.empty()) rootPowers(tw, logn, flag);
 

@@ -31,7 +31,7 @@ struct proofTranscript : public hyrax_bls12_381::transcriptSink {
 
 // random multiples of the base point (reference src/verifier.cpp:121-126), via a fixed-base table
 inline void drawGenerators(std::vector<G1> &gens, size_t count) {
-    static std::vector<G1Affine> table;      // table[w * 16 + d] = d * 16^w * G
+    static thread_local std::vector<G1Affine> table;      // table[w * 16 + d] = d * 16^w * G
     if (table.empty()) {
         std::vector<G1> jac(64 * 16);
         G1 base = G1::generator();
