@@ -94,3 +94,27 @@ def test_verifier_rejects_corrupted_opening_round(oracle):
         for k in (n_sum, n_sum + 1):           # the round message, then the tail vector
             bad, _ = o.prove(seed=21, mode=zkcnn_amd.MODE_REUSE_GENS | zkcnn_amd.MODE_TAMPER | (k << 8))
             assert bad.accepted == 0, k
+
+
+def test_concurrent_sessions_are_deterministic(oracle):
+    """two sessions proving at the same time on two host threads (what bench.py --streams does on the GPU): the challenge stream
+    is per thread, so each transcript equals the one produced alone"""
+    import hashlib
+    import threading
+    models = [("custom:C2:3:1:f M F4", (8, 8, 1), 2), ("custom:C2:3:1:s A F4", (4, 4, 1), 1)]
+    alone = []
+    for m in models:
+        with oracle_ffi.OracleSession(*m) as o:
+            alone.append(hashlib.sha256(o.prove(seed=31)[1]).hexdigest())
+    got = [None, None]
+
+    def work(i):
+        with oracle_ffi.OracleSession(*models[i]) as o:
+            for _ in range(3):
+                res, tr = o.prove(seed=31)
+                assert res.accepted == 1
+            got[i] = hashlib.sha256(tr).hexdigest()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert got == alone

@@ -78,3 +78,26 @@ def test_gpu_verifier_rejects_any_corrupted_message(built):
             assert bad.accepted == 0, f"message {k} of {n_sum} corrupted but accepted"
         again, _ = s.prove(seed=12)
         assert again.accepted == 1
+
+
+def test_concurrent_gpu_sessions_are_deterministic(built):
+    """three proofs in flight on one GPU (own session, host thread and HIP stream each): same bytes as one at a time"""
+    import threading
+    model, pic, pp = "custom:C2:3:0:f C3:3:1:f M C2:3:1:s A F5 F3", (10, 10, 2), 2
+    sessions = [zkcnn_amd.Session(model, pic, pp, data_seed=100 + i) for i in range(3)]
+    try:
+        alone = [s.prove(seed=5)[1] for s in sessions]
+        got = [None] * 3
+
+        def work(i):
+            for _ in range(4):
+                res, tr = sessions[i].prove(seed=5)
+                assert res.accepted == 1
+            got[i] = tr
+        th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert got == alone and len(set(alone)) == 3
+    finally:
+        for s in sessions:
+            s.close()
