@@ -762,7 +762,8 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
     std::memset(&A, 0, sizeof(A));
     double alg_bytes = 0;
     // small tables are latency bound: spread each quad over 4 lanes (k_round_quad2, `fine`)
-    const bool fine = std::max(ctx->tp[0].len, ctx->tp[1].len) <= (1ull << 18);
+    static const int fine_log = getenv("ZKCNN_FINE_LOG") ? atoi(getenv("ZKCNN_FINE_LOG")) : 16;
+    const bool fine = std::max(ctx->tp[0].len, ctx->tp[1].len) <= (1ull << fine_log);
     A.fine = fine ? 1 : 0;
     uint64_t fine_items = 0;
     for (int b = 0; b < 2; ++b) {
