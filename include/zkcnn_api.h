@@ -27,6 +27,7 @@ typedef struct {
 #define ZKCNN_MODE_REUSE_GENS  2u  /* keep the session's commitment generators instead of drawing new ones */
 #define ZKCNN_MODE_TAMPER      4u  /* test hook: the verifier corrupts message number (mode >> 8) before checking it */
 #define ZKCNN_MODE_HOST_PRED   8u  /* verifier's wiring predicates on the host (reference src/verifier.cpp:89-116) instead of the GPU */
+#define ZKCNN_MODE_FIAT_SHAMIR 32u /* non-interactive: challenges are SHA-256 of the statement and of every message so far (the seed is ignored) */
 #define ZKCNN_MODE_CROSS_PRED 16u  /* both, and the verifier rejects if they differ (parity check of zk_verifier_*) */
 
 typedef struct {
@@ -56,6 +57,11 @@ void *zkcnn_session_create(const zkcnn_model_desc *desc, int32_t device);
 /* One proof. `transcript` may be NULL; at most `cap` bytes are written, the full length is reported. */
 int32_t zkcnn_session_prove(void *session, uint64_t challenge_seed, uint32_t mode, uint8_t *transcript,
                             uint64_t cap, zkcnn_result *out);
+/* Checks a serialized proof (the transcript zkcnn_session_prove returned) without running the prover: the verifier replays the
+ * bytes against this session's circuit. challenge_seed and the ZKCNN_MODE_REUSE_GENS / ZKCNN_MODE_FIAT_SHAMIR bits must be the
+ * ones the proof was made with. out->accepted = 1 / 0, out->message = the reason for a rejection. */
+int32_t zkcnn_session_verify(void *session, uint64_t challenge_seed, uint32_t mode, const uint8_t *proof, uint64_t len,
+                             zkcnn_result *out);
 void zkcnn_session_destroy(void *session);
 /* The reference CLI's 16-column result row of the last prove call ("a, b, c, ..."), NUL terminated. */
 int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap);

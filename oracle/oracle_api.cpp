@@ -1,6 +1,7 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (PARITY UNPINNED, see ref_tables.hpp).
 // C entry points of liboracle.so: the whole-proof driver of include/zkcnn_api.h backed by the CPU
 // restatement, plus array-level reference functions the kernel parity tests compare against.
+#include "../zkcnn_amd/csrc/ff/sha256.hpp"
 #include "ref_prover.hpp"
 #include "session.hpp"
 
@@ -20,6 +21,9 @@ void *oracle_session_create(const zkcnn_model_desc *desc, int32_t) {
 int32_t oracle_session_prove(void *session, uint64_t seed, uint32_t mode, uint8_t *transcript, uint64_t cap,
                              zkcnn_result *out) {
     return ((oracleSession *) session)->prove(seed, mode, transcript, cap, out);
+}
+int32_t oracle_session_verify(void *session, uint64_t seed, uint32_t mode, const uint8_t *proof, uint64_t len, zkcnn_result *out) {
+    return ((oracleSession *) session)->verifyProof(proof, len, seed, mode, out);
 }
 void oracle_session_destroy(void *session) { delete (oracleSession *) session; }
 int32_t oracle_session_row(void *session, char *buf, uint64_t cap) {
@@ -122,6 +126,20 @@ void oracle_msm(uint64_t *out_affine, const uint64_t *scalars, const uint64_t *b
 void oracle_g1_serialize(uint8_t *out48, const uint64_t *affine) {
     G1 p = G1::fromAffine(*reinterpret_cast<const G1Affine *>(affine));
     p.serialize(out48);
+}
+// 1 = accepted (affine point written), 0 = rejected encoding
+int32_t oracle_g1_deserialize(uint64_t *out_affine, const uint8_t *in48, int32_t check_subgroup) {
+    G1 p;
+    if (!G1::deserialize(p, in48, check_subgroup != 0)) return 0;
+    G1Affine a = p.toAffine();
+    std::memcpy(out_affine, &a, 96);
+    return 1;
+}
+void oracle_sha256(uint8_t *out32, const uint8_t *in, uint64_t n, uint64_t split) {
+    zkff::Sha256 h;                       // absorbed in two pieces to exercise the buffering
+    h.update(in, split < n ? split : n);
+    if (split < n) h.update(in + split, n - split);
+    h.digest(out32);
 }
 int32_t oracle_g1_on_curve(const uint64_t *affine) {
     return G1::fromAffine(*reinterpret_cast<const G1Affine *>(affine)).isOnCurve() ? 1 : 0;

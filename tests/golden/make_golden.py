@@ -29,9 +29,11 @@ out = {}
 for key, (model, pic, pp) in CASES.items():
     with oracle_ffi.OracleSession(model, pic, pp, data_seed=20260928) as o:
         res, tr = o.prove(seed=0x5EED0001)
-    assert res.accepted == 1, key
+        fres, ftr = o.prove(seed=0, mode=32)           # ZKCNN_MODE_FIAT_SHAMIR: challenges = SHA-256 of statement + messages
+    assert res.accepted == 1 and fres.accepted == 1, key
     out[key] = {"model": model, "pic": list(pic), "pic_cnt": pp, "data_seed": 20260928, "challenge_seed": 0x5EED0001,
                 "n_layers": res.n_layers, "input_size": res.input_size, "n_rounds": res.n_rounds,
-                "transcript_len": len(tr), "sha256": hashlib.sha256(tr).hexdigest()}
+                "transcript_len": len(tr), "sha256": hashlib.sha256(tr).hexdigest(),
+                "fiat_shamir_sha256": hashlib.sha256(ftr).hexdigest()}
     print(key, out[key]["sha256"][:16], len(tr))
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "transcripts.json"), "w"), indent=1, sort_keys=True)

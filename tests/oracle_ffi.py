@@ -108,6 +108,18 @@ class Oracle:
         self.lib.oracle_g1_serialize(buf, u64p(p))
         return bytes(buf)
 
+    def g1_deserialize(self, data, check_subgroup=True):
+        out = np.zeros(12, dtype=np.uint64)
+        buf = (ctypes.c_uint8 * 48).from_buffer_copy(data)
+        ok = self.lib.oracle_g1_deserialize(u64p(out), buf, ctypes.c_int32(int(check_subgroup)))
+        return out if ok else None
+
+    def sha256(self, data, split=0):
+        out = (ctypes.c_uint8 * 32)()
+        buf = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+        self.lib.oracle_sha256(out, buf, ctypes.c_uint64(len(data)), ctypes.c_uint64(split))
+        return bytes(out)
+
     def fp_to_canonical(self, a):
         a = np.ascontiguousarray(a.reshape(-1, 6))
         out = np.zeros_like(a)

@@ -43,6 +43,10 @@ def test_golden_transcripts(oracle, key):
     assert res.n_layers == g["n_layers"] and res.input_size == g["input_size"] and res.n_rounds == g["n_rounds"]
     assert len(tr) == g["transcript_len"]
     assert hashlib.sha256(tr).hexdigest() == g["sha256"]
+    if key != "lenet5_pic1":            # the non-interactive form of the same proof (kept out of the largest case for time)
+        with oracle_ffi.OracleSession(g["model"], tuple(g["pic"]), g["pic_cnt"], data_seed=g["data_seed"]) as o:
+            fres, ftr = o.prove(seed=123, mode=32)
+        assert fres.accepted == 1 and hashlib.sha256(ftr).hexdigest() == g["fiat_shamir_sha256"]
 
 
 def test_drive_only_makes_the_same_calls(oracle):

@@ -1,0 +1,107 @@
+"""Serialized proofs and the optional Fiat-Shamir mode on the CPU: SHA-256 and point decompression against
+known answers, replay verification of transcripts (interactive seed and Fiat-Shamir), rejection of every kind of damage."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import zkcnn_amd
+from zkcnn_amd import proof_io
+from tests import oracle_ffi
+
+MODEL = ("custom:C2:3:1:f M F4", (8, 8, 1), 2)      # FFT conv + max pool + FC: every message type occurs
+FS = zkcnn_amd.MODE_FIAT_SHAMIR
+
+
+def test_sha256_matches_hashlib(oracle):
+    rng = np.random.default_rng(1)
+    for n in [0, 1, 3, 55, 56, 57, 63, 64, 65, 119, 120, 128, 1000, 4097]:
+        data = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        for split in (0, 1, 64, n // 2):
+            assert oracle.sha256(data, split) == hashlib.sha256(data).digest(), (n, split)
+    assert oracle.sha256(b"abc").hex() == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad"
+
+
+def test_g1_compression_round_trip_and_rejections(oracle):
+    base = oracle.g1_base()
+    ks = oracle.random(6, 99)
+    for i in range(6):
+        p = oracle.g1_mul(base, ks[i:i + 1])
+        enc = oracle.g1_serialize(p)
+        back = oracle.g1_deserialize(enc)
+        assert back is not None and np.array_equal(back, p)
+        flipped = bytes([enc[0] ^ 0x20]) + enc[1:]                  # the other root: still a valid point, the negated one
+        neg = oracle.g1_deserialize(flipped)
+        assert neg is not None and not np.array_equal(neg, p) and oracle.g1_serialize(neg) == flipped
+        assert oracle.g1_deserialize(bytes([enc[0] & 0x7f]) + enc[1:]) is None          # compression flag missing
+    # generator of BLS12-381 G1 in the standard compressed form (the value every implementation publishes)
+    g = bytes.fromhex("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb")
+    assert oracle.g1_serialize(base) == g and np.array_equal(oracle.g1_deserialize(g), base)
+    inf = bytes([0xc0]) + bytes(47)
+    assert oracle.g1_deserialize(inf) is not None and oracle.g1_deserialize(bytes([0xc0]) + bytes(46) + b"\x01") is None
+    p_mod = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+    too_big = (p_mod + 1).to_bytes(48, "big")
+    assert oracle.g1_deserialize(bytes([too_big[0] | 0x80]) + too_big[1:]) is None     # x >= p
+    # points on the curve but outside the order-r subgroup (almost every curve point: the cofactor is ~2^126), and x with no y
+    on_curve = off_curve = 0
+    for x in range(1, 40):
+        enc = x.to_bytes(48, "big")
+        enc = bytes([enc[0] | 0x80]) + enc[1:]
+        if oracle.g1_deserialize(enc, check_subgroup=False) is None:
+            off_curve += 1
+        else:
+            on_curve += 1
+            assert oracle.g1_deserialize(enc, check_subgroup=True) is None
+    assert on_curve > 5 and off_curve > 5
+
+
+@pytest.mark.parametrize("mode", [0, zkcnn_amd.MODE_REUSE_GENS, FS, FS | zkcnn_amd.MODE_REUSE_GENS])
+def test_replay_accepts_and_rejects(oracle, mode):
+    with oracle_ffi.OracleSession(*MODEL) as o:
+        res, tr = o.prove(seed=41, mode=mode)
+        assert res.accepted == 1
+        ok = o.verify(tr, seed=41, mode=mode)
+        assert ok.accepted == 1, ok.message
+        assert ok.n_messages == res.n_messages
+        # challenges of another run do not fit the proof
+        other = o.verify(tr, seed=42, mode=mode)
+        assert other.accepted == (1 if mode & FS else 0)                   # Fiat-Shamir ignores the seed
+        assert o.verify(tr, seed=41, mode=mode ^ FS).accepted == 0          # wrong challenge derivation
+        # damage: any flipped bit, truncation, extension
+        rng = np.random.default_rng(5)
+        for pos in sorted(set([0, 47, 48, len(tr) - 1] + list(rng.integers(0, len(tr), size=24)))):
+            bad = bytearray(tr)
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+            r = o.verify(bytes(bad), seed=41, mode=mode)
+            assert r.accepted == 0, f"byte {pos} of {len(tr)} damaged but accepted"
+        assert o.verify(tr[:-32], seed=41, mode=mode).accepted == 0
+        assert o.verify(tr + bytes(32), seed=41, mode=mode).accepted == 0
+        assert o.verify(b"", seed=41, mode=mode).accepted == 0
+
+
+def test_fiat_shamir_is_deterministic_and_binds_the_statement(oracle):
+    with oracle_ffi.OracleSession(*MODEL) as o:
+        _, a = o.prove(seed=1, mode=FS)
+        _, b = o.prove(seed=2, mode=FS)
+        _, c = o.prove(seed=1)
+        assert a == b and a != c                    # no dependence on the seed; differs from the interactive transcript
+    with oracle_ffi.OracleSession(MODEL[0], MODEL[1], MODEL[2], data_seed=7) as o2:
+        _, d = o2.prove(seed=1, mode=FS)
+        assert d != a                               # other picture and weights: other commitment, other challenges
+    with oracle_ffi.OracleSession("custom:C2:3:1:f M F5", MODEL[1], MODEL[2]) as o3:
+        assert o3.verify(a, mode=FS).accepted == 0  # the statement (circuit) is hashed into every challenge
+
+
+def test_proof_file_round_trip(oracle, tmp_path):
+    with oracle_ffi.OracleSession(*MODEL) as o:
+        for mode, seed in ((FS, 0), (zkcnn_amd.MODE_REUSE_GENS, 77)):
+            _, tr = o.prove(seed=seed, mode=mode)
+            path = tmp_path / f"proof_{mode}.zkp"
+            proof_io.save(path, tr, MODEL[0], MODEL[1], MODEL[2], 20260928, seed, mode)
+            header, back = proof_io.load(path)
+            assert back == tr and header["model"] == MODEL[0]
+            assert proof_io.verify_with(o, path.read_bytes()).accepted == 1
+            blob = bytearray(path.read_bytes())
+            blob[len(blob) // 2] ^= 0x40
+            with pytest.raises(ValueError):
+                proof_io.loads(bytes(blob))

@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(ROOT, "zkcnn_amd", "lib")
 R_MOD = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 P_MOD = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 
-MODE_VERIFY, MODE_DRIVE_ONLY, MODE_REUSE_GENS, MODE_TAMPER, MODE_HOST_PRED, MODE_CROSS_PRED = 0, 1, 2, 4, 8, 16
+MODE_VERIFY, MODE_DRIVE_ONLY, MODE_REUSE_GENS, MODE_TAMPER, MODE_HOST_PRED, MODE_CROSS_PRED, MODE_FIAT_SHAMIR = 0, 1, 2, 4, 8, 16, 32
 
 
 class ModelDesc(ctypes.Structure):
@@ -251,6 +251,16 @@ class _SessionBase:
             return self.prove(seed, mode, True)                     # deterministic: the same seed gives the same proof
         data = ctypes.string_at(buf, res.transcript_len) if want_transcript else b""
         return res, data
+
+    def verify(self, proof, seed=0x5EED0001, mode=MODE_VERIFY):
+        """checks a serialized proof (bytes returned by prove) without the prover; returns the Result (accepted = 1 / 0)"""
+        res = Result()
+        buf = (ctypes.c_uint8 * max(len(proof), 1)).from_buffer_copy(proof if proof else b"\0")
+        rc = self._fn("session_verify")(ctypes.c_void_p(self.h), ctypes.c_uint64(seed), ctypes.c_uint32(mode), buf,
+                                        ctypes.c_uint64(len(proof)), ctypes.byref(res))
+        if rc != 0:
+            raise RuntimeError(f"{self._prefix}session_verify failed ({rc}): {res.message.decode(errors='replace')}")
+        return res
 
     def row(self):
         buf = ctypes.create_string_buffer(1024)

@@ -70,6 +70,17 @@ struct Xoshiro {
     double nextUnit() { return (double) (next() >> 11) * (1.0 / 9007199254740992.0); }
 };
 
+// Per-thread replacement of the seeded stream: when set, every challenge is taken from it (Fiat-Shamir: a hash of the
+// transcript so far, host/replay.hpp) instead of the xoshiro stream.
+struct ChallengeSource {
+    virtual ~ChallengeSource() {}
+    virtual void words(uint64_t out[4]) = 0;     // 256 fresh pseudo-random bits
+};
+inline ChallengeSource *&challengeOverride() {
+    static thread_local ChallengeSource *src = nullptr;
+    return src;
+}
+
 inline Xoshiro &challengeStream() {
     static thread_local Xoshiro g = [] {       // one stream per thread: concurrent sessions (one per host thread) stay deterministic
         Xoshiro x;
@@ -104,15 +115,26 @@ public:
     // (multiplying a uniform value by the constant R^{-1} keeps it uniform).
     void setByCSPRNG() {
         Xoshiro &g = challengeStream();
+        ChallengeSource *src = challengeOverride();
         for (;;) {
             uint64_t t[4];
-            for (int i = 0; i < 4; ++i) t[i] = g.next();
+            if (src) src->words(t);
+            else for (int i = 0; i < 4; ++i) t[i] = g.next();
             t[3] &= 0x7fffffffffffffffULL;
             if (!Base::geMod(t)) {
                 *this = Fr(Base::fromCanonical(t));
                 return;
             }
         }
+    }
+
+    // 32 little-endian canonical bytes -> element; false when the value is not below r (non-canonical encoding)
+    static bool fromBytesLE(Fr &out, const uint8_t in[32]) {
+        uint64_t t[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 32; ++i) t[i >> 3] |= (uint64_t) in[i] << (8 * (i & 7));
+        if (Base::geMod(t)) return false;
+        out = Fr(Base::fromCanonical(t));
+        return true;
     }
 
     bool isNegative() const {

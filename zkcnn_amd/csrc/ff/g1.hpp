@@ -155,6 +155,50 @@ public:
         out[0] |= 0x80;
         if (Fp::cmpCanonical(a.y, ny) > 0) out[0] |= 0x20;
     }
+    // inverse of serialize(): rejects non-canonical encodings (x >= p, stray flag bits, a non-residue x^3 + 4) and, with
+    // check_subgroup, points outside the order-r subgroup (r * P != O).
+    static bool deserialize(G1 &out, const uint8_t in[48], bool check_subgroup = true) {
+        const uint8_t flags = in[0] & 0xe0;
+        if (!(flags & 0x80)) return false;                       // only the compressed form is canonical here
+        if (flags & 0x40) {                                      // infinity: everything else must be zero
+            if (in[0] != 0xc0) return false;
+            for (int i = 1; i < 48; ++i) if (in[i]) return false;
+            out = G1();
+            return true;
+        }
+        uint64_t cx[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 6; ++i)
+            for (int b = 0; b < 8; ++b) {
+                uint8_t byte = in[47 - (i * 8 + b)];
+                if (i == 5 && b == 7) byte &= 0x1f;
+                cx[i] |= (uint64_t) byte << (8 * b);
+            }
+        if (Fp::geMod(cx)) return false;
+        const Fp x = Fp::fromCanonical(cx);
+        const Fp rhs = x * x * x + Fp::fromU64(4);
+        // p = 3 (mod 4): sqrt = rhs^((p + 1) / 4)
+        static const uint64_t e[6] = {0xee7fbfffffffeaabULL, 0x07aaffffac54ffffULL, 0xd9cc34a83dac3d89ULL,
+                                      0xd91dd2e13ce144afULL, 0x92c6e9ed90d2eb35ULL, 0x0680447a8e5ff9a6ULL};
+        Fp y;
+        Fp::powLimbs(y, rhs, e, 6);
+        if (!(y * y == rhs)) return false;
+        Fp ny = -y;
+        const bool y_is_larger = Fp::cmpCanonical(y, ny) > 0;
+        if (y_is_larger != ((flags & 0x20) != 0)) y = ny;
+        G1Affine a;
+        a.x = x; a.y = y;
+        out = fromAffine(a);
+        if (check_subgroup) {
+            static const uint64_t rr[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+            G1 acc;                                              // r * P by double-and-add over the 255 bits of r
+            for (int i = 254; i >= 0; --i) {
+                dbl(acc, acc);
+                if ((rr[i >> 6] >> (i & 63)) & 1) addMixed(acc, acc, a);
+            }
+            if (!acc.isInf()) return false;
+        }
+        return true;
+    }
 };
 
 // many Jacobian -> affine conversions with one field inversion

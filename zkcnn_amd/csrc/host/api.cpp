@@ -115,6 +115,17 @@ int32_t zkcnn_session_prove(void *session, uint64_t seed, uint32_t mode, uint8_t
     }
 }
 
+int32_t zkcnn_session_verify(void *session, uint64_t seed, uint32_t mode, const uint8_t *proof, uint64_t len, zkcnn_result *out) {
+    if (!session || !out || !proof) return -1;
+    try {
+        return ((gpuSession *) session)->verifyProof(proof, len, seed, mode, out);
+    } catch (const std::exception &e) {
+        std::memset(out, 0, sizeof(*out));
+        std::snprintf(out->message, sizeof(out->message), "%s", e.what());
+        return -2;
+    }
+}
+
 void zkcnn_session_destroy(void *session) { delete (gpuSession *) session; }
 
 int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap) {

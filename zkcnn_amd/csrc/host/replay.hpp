@@ -1,0 +1,140 @@
+// Serialized proofs: the canonical transcript the verifier records (verifier.hpp: proofTranscript) is the wire
+// form of a proof. Two pieces make it checkable without the prover:
+//   * replayProver: an object with the `prover` interface whose answers are parsed, in order, from a transcript. The unchanged
+//     verifier template runs against it (verifierT<replayProver>), so every check of the interactive protocol is applied to the
+//     bytes; the challenges come from the same seeded stream (interactive mode) or from the transcript itself:
+//   * fiatShamir: a ChallengeSource that hashes everything the verifier has received so far (SHA-256, counter mode), which
+//     turns the same protocol into a non-interactive proof. Optional; the interactive path is untouched.
+// The reference has neither (its proof never leaves the process); nothing here is on the hot path.
+#pragma once
+#include <stdexcept>
+#include "../ff/sha256.hpp"
+#include "verifier.hpp"
+
+class fiatShamir : public zkff::ChallengeSource, public transcriptTap {
+public:
+    fiatShamir() { absorb("zkcnn-amd/fiat-shamir/v1", 24); }
+    void absorb(const void *data, size_t n) override { st.update(data, n); }
+    // binds the statement: model descriptor and the shape of every layer of the circuit
+    void absorbStatement(const string &model, const layeredCircuit &C) {
+        absorb(model.data(), model.size());
+        for (int i = 0; i < C.size; ++i) {
+            const layer &L = C.circuit[i];
+            uint64_t rec[4] = {(uint64_t) L.ty, L.size, L.uni_gates.size(), L.bin_gates.size()};
+            absorb(rec, sizeof(rec));
+        }
+    }
+    void words(uint64_t out[4]) override {
+        zkff::Sha256 c = st;
+        uint8_t tag[12] = {'c', 'h', 'a', 'l'};
+        for (int i = 0; i < 8; ++i) tag[4 + i] = (uint8_t) (ctr >> (8 * i));
+        ++ctr;
+        c.update(tag, sizeof(tag));
+        uint8_t d[32];
+        c.digest(d);
+        for (int i = 0; i < 4; ++i) {
+            out[i] = 0;
+            for (int b = 0; b < 8; ++b) out[i] |= (uint64_t) d[8 * i + b] << (8 * b);
+        }
+    }
+private:
+    zkff::Sha256 st;
+    uint64_t ctr = 0;
+};
+
+// RAII: installs a challenge source for the current thread
+struct challengeScope {
+    zkff::ChallengeSource *prev;
+    explicit challengeScope(zkff::ChallengeSource *s) : prev(zkff::challengeOverride()) { zkff::challengeOverride() = s; }
+    ~challengeScope() { zkff::challengeOverride() = prev; }
+};
+
+class proofReader {
+public:
+    proofReader(const u8 *data, size_t n) : p(data), end(data + n) {}
+    Fr fr() {
+        need(32);
+        Fr x;
+        if (!Fr::fromBytesLE(x, p)) throw std::runtime_error("proof: field element not in canonical form");
+        p += 32;
+        return x;
+    }
+    G1 g1() {
+        need(48);
+        G1 x;
+        if (!G1::deserialize(x, p, true)) throw std::runtime_error("proof: invalid group element");
+        p += 48;
+        return x;
+    }
+    bool done() const { return p == end; }
+private:
+    const u8 *p, *end;
+    void need(size_t n) const { if ((size_t) (end - p) < n) throw std::runtime_error("proof: truncated"); }
+};
+
+class replayPolyProver : public hyrax_bls12_381::polyProverBase {
+public:
+    replayPolyProver(proofReader &reader, int input_bits) : rd(reader) {
+        const int rb = input_bits >> 1;
+        cb = input_bits - rb;
+        comm.resize((size_t) 1 << rb);
+        for (auto &c : comm) c = rd.g1();
+    }
+    const std::vector<G1> &commitment() const override { return comm; }
+    void openInit(const std::vector<Fr> &) override {}
+    hyrax_bls12_381::ipaRoundMsg openRound() override {
+        hyrax_bls12_381::ipaRoundMsg m;
+        m.L = rd.g1(); m.R = rd.g1(); m.yL = rd.fr(); m.yR = rd.fr();
+        ++rounds;
+        return m;
+    }
+    void openFold(const Fr &) override {}
+    std::vector<Fr> openFinal() override {
+        std::vector<Fr> a((size_t) 1 << (cb - rounds));
+        for (auto &x : a) x = rd.fr();
+        return a;
+    }
+    double getPT() const override { return 0; }
+    double getPS() const override { return 0; }
+private:
+    proofReader &rd;
+    std::vector<G1> comm;
+    int cb = 0, rounds = 0;
+};
+
+// the `prover` interface (reference src/prover.hpp:18-49) answered from a transcript
+class replayProver {
+public:
+    replayProver(const u8 *data, size_t n, const layeredCircuit *statement) : C(statement), rd(data, n) {}
+
+    void init() {}
+    F Vres(const vector<F>::const_iterator &, u32, u8) { return rd.fr(); }
+    void sumcheckInitAll(const vector<F>::const_iterator &) {}
+    void sumcheckInit(const F &, const F &) {}
+    void sumcheckDotProdInitPhase1() {}
+    void sumcheckInitPhase1(const F &) {}
+    void sumcheckInitPhase2() {}
+    cubic_poly sumcheckDotProdUpdate1(const F &) { F a = rd.fr(), b = rd.fr(), c = rd.fr(), d = rd.fr(); return cubic_poly(a, b, c, d); }
+    quadratic_poly sumcheckUpdate1(const F &) { return quad(); }
+    quadratic_poly sumcheckUpdate2(const F &) { return quad(); }
+    void sumcheckDotProdFinalize1(const F &, F &claim_1) { claim_1 = rd.fr(); }
+    void sumcheckFinalize1(const F &, F &claim_0, F &claim_1) { claim_0 = rd.fr(); claim_1 = rd.fr(); }
+    void sumcheckFinalize2(const F &, F &claim_0, F &claim_1) { claim_0 = rd.fr(); claim_1 = rd.fr(); }
+    void sumcheckLiuInit(const vector<F> &, const vector<F> &) {}
+    quadratic_poly sumcheckLiuUpdate(const F &) { return quad(); }
+    void sumcheckLiuFinalize(const F &, F &claim_1) { claim_1 = rd.fr(); }
+    hyrax_bls12_381::polyProverBase &commitInput(const std::vector<G1> &) {
+        pp.reset(new replayPolyProver(rd, C->circuit[0].bit_length));
+        return *pp;
+    }
+    double proveTime() const { return 0; }
+    double proofSize() const { return 0; }
+    double polyProverTime() const { return 0; }
+    double polyProofSize() const { return 0; }
+    bool consumedAll() const { return rd.done(); }
+private:
+    const layeredCircuit *C;                  // the statement (only the size of the input layer is needed here)
+    proofReader rd;
+    std::unique_ptr<replayPolyProver> pp;
+    quadratic_poly quad() { F a = rd.fr(), b = rd.fr(), c = rd.fr(); return quadratic_poly(a, b, c); }
+};

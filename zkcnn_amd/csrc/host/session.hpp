@@ -6,7 +6,7 @@
 #include <memory>
 #include "../../../include/zkcnn_api.h"
 #include "models.hpp"
-#include "verifier.hpp"
+#include "replay.hpp"
 
 template <class ProverT>
 struct sessionT {
@@ -37,30 +37,49 @@ struct sessionT {
         return true;
     }
 
-    int prove(uint64_t challenge_seed, uint32_t mode, uint8_t *transcript, uint64_t cap, zkcnn_result *out) {
-        std::memset(out, 0, sizeof(*out));
-        double t0 = now();
-        Fr::seedCSPRNG(challenge_seed);
-        const bool drive = mode & ZKCNN_MODE_DRIVE_ONLY, reuse = mode & ZKCNN_MODE_REUSE_GENS;
+    // common set-up of a verifier run: challenge source (seeded stream, or the transcript itself), generators, options
+    template <class V>
+    void configure(V &v, uint64_t challenge_seed, uint32_t mode, fiatShamir &fs, std::unique_ptr<challengeScope> &scope) {
+        const bool reuse = mode & ZKCNN_MODE_REUSE_GENS;
         const u8 logn = p.C.circuit[0].bit_length;
         const size_t n_sqrt = (size_t) 1 << (logn - (logn >> 1));
+        Fr::seedCSPRNG(challenge_seed);
         if (reuse && gens.size() != n_sqrt) {
             // session generators come from their own stream so that they do not depend on the proof seed
             Fr::seedCSPRNG(0x67656e73ULL);
             drawGenerators(gens, n_sqrt);
             Fr::seedCSPRNG(challenge_seed);
         }
+        v.drive_only = (mode & ZKCNN_MODE_DRIVE_ONLY) != 0;
+        if (reuse) v.fixed_gens = &gens;
+        if (mode & ZKCNN_MODE_TAMPER) v.tamper_at = (long) (mode >> 8);
+        if (vaccel && !(mode & ZKCNN_MODE_HOST_PRED)) v.accel = vaccel;
+        v.cross_check = (mode & ZKCNN_MODE_CROSS_PRED) != 0;
+        if (mode & ZKCNN_MODE_FIAT_SHAMIR) {
+            // non-interactive: every challenge (and, unless the session's are re-used, every generator) is a hash of the
+            // statement and of all messages received so far
+            fs.absorbStatement(model_name, p.C);
+            if (reuse) for (const G1 &g : gens) { u8 b[48]; g.serialize(b); fs.absorb(b, 48); }
+            v.transcript.tap = &fs;
+            v.lazy_challenges = true;
+            scope.reset(new challengeScope(&fs));
+        }
+    }
+
+    int prove(uint64_t challenge_seed, uint32_t mode, uint8_t *transcript, uint64_t cap, zkcnn_result *out) {
+        std::memset(out, 0, sizeof(*out));
+        double t0 = now();
+        const bool drive = mode & ZKCNN_MODE_DRIVE_ONLY;
         output_tb.assign(OUT_COLUMN_CNT, "");
         output_tb[MO_INFO_OUT_ID] = model_name;
         output_tb[PCNT_OUT_ID] = std::to_string(pic_cnt);
         output_tb[WS_OUT_ID] = std::to_string(p.C.circuit[0].size) + "(2^" + std::to_string((int) p.C.circuit[0].bit_length) + ")";
         verifierT<ProverT> v(&p, p.C);
-        v.drive_only = drive;
-        if (reuse) v.fixed_gens = &gens;
-        if (mode & ZKCNN_MODE_TAMPER) v.tamper_at = (long) (mode >> 8);
-        if (vaccel && !(mode & ZKCNN_MODE_HOST_PRED)) v.accel = vaccel;
-        v.cross_check = (mode & ZKCNN_MODE_CROSS_PRED) != 0;
+        fiatShamir fs;
+        std::unique_ptr<challengeScope> scope;
+        configure(v, challenge_seed, mode, fs, scope);
         bool ok = v.verify();
+        scope.reset();
         out->accepted = drive ? -1 : (ok ? 1 : 0);
         out->n_layers = p.C.size;
         out->input_size = p.C.circuit[0].size;
@@ -89,6 +108,46 @@ struct sessionT {
         std::snprintf(out->message, sizeof(out->message), "%s", ok ? "" : v.failure());
         row.clear();
         for (auto &s : output_tb) { row += s; row += ", "; }
+        out->wall_s = now() - t0;
+        return 0;
+    }
+
+    // Checks a serialized proof (the canonical transcript prove() returns) WITHOUT the prover: the same verifier runs against a
+    // replayProver that parses its answers from the bytes. challenge_seed / mode must be the ones the proof was made with
+    // (the seed is ignored under ZKCNN_MODE_FIAT_SHAMIR). Uses this session's circuit as the statement.
+    int verifyProof(const uint8_t *proof, uint64_t len, uint64_t challenge_seed, uint32_t mode, zkcnn_result *out) {
+        std::memset(out, 0, sizeof(*out));
+        double t0 = now();
+        mode &= ~(uint32_t) (ZKCNN_MODE_DRIVE_ONLY | ZKCNN_MODE_TAMPER);
+        bool ok = false;
+        string why;
+        try {
+            replayProver rp(proof, len, &p.C);
+            verifierT<replayProver> v(&rp, p.C);
+            fiatShamir fs;
+            std::unique_ptr<challengeScope> scope;
+            configure(v, challenge_seed, mode, fs, scope);
+            ok = v.verify();
+            scope.reset();
+            if (!ok) why = v.failure();
+            else if (!rp.consumedAll()) { ok = false; why = "trailing bytes after the last message"; }
+            else if (v.transcript.bytes.size() != len || std::memcmp(v.transcript.bytes.data(), proof, len) != 0) {
+                ok = false;
+                why = "proof is not in canonical form";
+            }
+            out->verify_s = v.verifierTime();
+            out->poly_verify_s = v.polyVerifierTime();
+            out->n_messages = (int32_t) v.msg_count;
+        } catch (const std::exception &e) {
+            ok = false;
+            why = e.what();
+        }
+        out->accepted = ok ? 1 : 0;
+        out->n_layers = p.C.size;
+        out->input_size = p.C.circuit[0].size;
+        out->input_bits = p.C.circuit[0].bit_length;
+        out->transcript_len = len;
+        std::snprintf(out->message, sizeof(out->message), "%s", why.c_str());
         out->wall_s = now() - t0;
         return 0;
     }

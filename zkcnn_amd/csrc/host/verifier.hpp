@@ -13,17 +13,26 @@
 #include "polynomial.h"
 #include "utils.hpp"
 
+// anything that wants to see every serialized message as it is recorded (the Fiat-Shamir state of replay.hpp)
+struct transcriptTap {
+    virtual ~transcriptTap() {}
+    virtual void absorb(const void *data, size_t n) = 0;
+};
+
 struct proofTranscript : public hyrax_bls12_381::transcriptSink {
     std::vector<u8> bytes;
+    transcriptTap *tap = nullptr;
     void put(const Fr &x) override {
         size_t o = bytes.size();
         bytes.resize(o + 32);
         x.toBytesLE(&bytes[o]);
+        if (tap) tap->absorb(&bytes[o], 32);
     }
     void put(const G1 &p) override {
         size_t o = bytes.size();
         bytes.resize(o + 48);
         p.serialize(&bytes[o]);
+        if (tap) tap->absorb(&bytes[o], 48);
     }
     void put(const quadratic_poly &p) { put(p.a); put(p.b); put(p.c); }
     void put(const cubic_poly &p) { put(p.a); put(p.b); put(p.c); put(p.d); }
@@ -87,6 +96,9 @@ public:
 
     // options (all default to reference behaviour)
     bool drive_only = false;                 // skip the verifier's checks, keep challenges + prover calls
+    // Fiat-Shamir needs every round challenge to depend on that round's message: draw r[j] after round j's polynomial has been
+    // recorded instead of all of a phase's challenges up front as the reference does (src/verifier.cpp:155,207,279)
+    bool lazy_challenges = false;
     const std::vector<G1> *fixed_gens = nullptr;   // re-use generators instead of drawing new ones
     proofTranscript transcript;
     // test hook: add 1 to the k-th message received from the prover (a cheating prover); -1 = off.
@@ -246,6 +258,7 @@ private:
                     if (hit()) poly.d = poly.d + F_ONE;
                     transcript.put(poly);
                     tic();
+                    if (lazy_challenges) r_u[i][j].setByCSPRNG();
                     at01 = poly.eval(F_ZERO) + poly.eval(F_ONE);
                     at_r = poly.eval(r_u[i][j]);
                 } else {
@@ -253,6 +266,7 @@ private:
                     if (hit()) poly.c = poly.c + F_ONE;
                     transcript.put(poly);
                     tic();
+                    if (lazy_challenges) r_u[i][j].setByCSPRNG();
                     at01 = poly.eval(F_ZERO) + poly.eval(F_ONE);
                     at_r = poly.eval(r_u[i][j]);
                 }
@@ -290,6 +304,7 @@ private:
                     if (hit()) poly.a = poly.a + F_ONE;
                     transcript.put(poly);
                     tic();
+                    if (lazy_challenges) r_v[i][j].setByCSPRNG();
                     if (!drive_only && poly.eval(F_ZERO) + poly.eval(F_ONE) != previousSum)
                         return fail("phase2, circuit level " + std::to_string(i) + ", current bit " + std::to_string(j));
                     previousRandom = r_v[i][j];
@@ -367,6 +382,7 @@ private:
             quadratic_poly poly = p->sumcheckLiuUpdate(previousRandom);
             if (hit()) poly.b = poly.b + F_ONE;
             transcript.put(poly);
+            if (lazy_challenges) r_u[0][j].setByCSPRNG();
             if (!drive_only && poly.eval(F_ZERO) + poly.eval(F_ONE) != previousSum)
                 return fail("Liu, circuit 0, current bit " + std::to_string(j));
             previousRandom = r_u[0][j];

@@ -1,0 +1,53 @@
+"""On-disk / wire form of a proof. The proof proper is the canonical transcript the verifier records
+(Fr: 32 bytes little-endian canonical, G1: 48 bytes compressed, in protocol order); this module wraps it with what a verifier
+needs to replay it: the statement (model descriptor) and how the challenges were made.
+
+  magic "ZKCNNPF1" | u32 header length | header (UTF-8 JSON) | u64 transcript length | transcript | sha256(all of the above)
+"""
+import hashlib
+import json
+import struct
+
+MAGIC = b"ZKCNNPF1"
+
+
+def dumps(transcript, model, pic, pic_cnt, data_seed, challenge_seed, mode):
+    from . import MODE_FIAT_SHAMIR, MODE_REUSE_GENS
+    header = {"model": model, "pic": list(pic), "pic_cnt": pic_cnt, "data_seed": data_seed,
+              "challenges": "fiat-shamir/sha256" if mode & MODE_FIAT_SHAMIR else "seeded-stream",
+              "challenge_seed": None if mode & MODE_FIAT_SHAMIR else challenge_seed,
+              "session_generators": bool(mode & MODE_REUSE_GENS), "mode": mode & (MODE_FIAT_SHAMIR | MODE_REUSE_GENS)}
+    h = json.dumps(header, sort_keys=True).encode()
+    body = MAGIC + struct.pack("<I", len(h)) + h + struct.pack("<Q", len(transcript)) + bytes(transcript)
+    return body + hashlib.sha256(body).digest()
+
+
+def loads(blob):
+    """-> (header dict, transcript bytes); raises ValueError on a damaged file"""
+    if len(blob) < len(MAGIC) + 4 + 8 + 32 or blob[:8] != MAGIC:
+        raise ValueError("not a zkcnn proof file")
+    if hashlib.sha256(blob[:-32]).digest() != blob[-32:]:
+        raise ValueError("proof file checksum mismatch")
+    (hl,) = struct.unpack_from("<I", blob, 8)
+    header = json.loads(blob[12:12 + hl].decode())
+    (tl,) = struct.unpack_from("<Q", blob, 12 + hl)
+    tr = blob[20 + hl:20 + hl + tl]
+    if len(tr) != tl or 20 + hl + tl + 32 != len(blob):
+        raise ValueError("proof file length mismatch")
+    return header, tr
+
+
+def save(path, *args, **kw):
+    with open(path, "wb") as f:
+        f.write(dumps(*args, **kw))
+
+
+def load(path):
+    with open(path, "rb") as f:
+        return loads(f.read())
+
+
+def verify_with(session, blob):
+    """replays a proof file against `session` (whose circuit must be the file's statement); returns the Result"""
+    header, tr = loads(blob)
+    return session.verify(tr, seed=header["challenge_seed"] or 0, mode=header["mode"])
