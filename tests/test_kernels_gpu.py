@@ -97,9 +97,15 @@ def test_msm_matches_cpu_pippenger(hip, oracle, n, kind):
         sc[::3] = 0
         sc[1::7] = to_mont([R_MOD - 1])[0]
         bases[5] = 0             # point at infinity among the bases
+    want = oracle.msm(sc, bases)
     g = hip.msm(sc, bases)
-    assert np.array_equal(g, oracle.msm(sc, bases))
+    assert np.array_equal(g, want)
     assert oracle.g1_on_curve(g)
+    # the same generators again: the context now builds the full byte table (one mixed addition per non-zero scalar byte,
+    # 64-wide reduction trees, last partial sums on the host) -- same point
+    assert np.array_equal(hip.msm(sc, bases), want)
+    sc2 = oracle.random(n, 77 + n)
+    assert np.array_equal(hip.msm(sc2, bases), oracle.msm(sc2, bases))
 
 
 def test_commit_rows_digit_table_and_high_byte_rows(hip, oracle):
@@ -119,6 +125,24 @@ def test_commit_rows_digit_table_and_high_byte_rows(hip, oracle):
     for r in range(rows):
         assert np.array_equal(got[r], oracle.msm(sc[r * cols:(r + 1) * cols], bases)), f"row {r}"
     assert not got[7].any()
+
+
+def test_commit_rows_byte_table_path(hip, oracle):
+    """many rows over generators that are used again: every row through the full byte table (no bit planes, no high-byte pass)"""
+    rows, cols = 80, 128
+    rng = np.random.default_rng(11)
+    vals = rng.integers(-255, 256, size=(rows, cols)).astype(object)
+    vals[2, :] = rng.integers(0, 2, cols)
+    vals[4, 3:9] = [int(x) for x in rng.integers(-(1 << 40), 1 << 40, 6)]
+    vals[6, :] = 0
+    sc = to_mont([int(v) % R_MOD for v in vals.reshape(-1)])
+    sc[9 * cols:10 * cols] = oracle.random(cols, 5)
+    bases = oracle.generators(cols, 777)
+    first = hip.commit_rows(sc, bases, rows, cols)          # first use of the generators: digit table + bit planes
+    again = hip.commit_rows(sc, bases, rows, cols)          # second use: byte table
+    assert np.array_equal(first, again)
+    for r in range(rows):
+        assert np.array_equal(again[r], oracle.msm(sc[r * cols:(r + 1) * cols], bases)), f"row {r}"
 
 
 @pytest.mark.parametrize("logn", [1, 2, 5, 9, 12])

@@ -40,13 +40,21 @@ struct msm_state {
     uint32_t *hi_flags = nullptr, *row_list = nullptr; size_t flags_cap = 0;
     g1j_t *tmpJ = nullptr; size_t tmp_cap = 0;
     void *aff_scratch = nullptr; size_t aff_cap = 0;
+    // generators seen again: full byte table F[w][d][j] = d * 2^(8w) * g_j (d = 1..255), so that EVERY non-zero scalar byte is
+    // one mixed addition and no bit planes / doublings are left (3.2 GB for 4096 generators; built on the second use of a set)
+    g1a_t *full = nullptr; uint64_t full_m = 0; bool full_ready = false, full_failed = false;
+    uint32_t gens_hits = 0;
+    g1j_t *parts2 = nullptr; size_t parts2_cap = 0;
+    bool host_rows_valid = false;      // few-row MSMs end with a short sum on the host (like the single inversion of fetch_points)
+    zkff::G1 host_rows[8];
 };
+#define MSM_FULL_MAX_M 16384u
 
 void zk_msm_destroy(zk_ctx *ctx) {
     if (!ctx->msm) return;
     msm_state *s = ctx->msm;
     void *bufs[] = {s->tables, s->partials, s->rowsJ, s->rowsA, s->a, s->b, s->coef, s->Lrow, s->sL, s->idxL, s->d_y, s->tbl_scratch,
-                    s->digit, s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch};
+                    s->digit, s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch, s->full, s->parts2};
     for (void *p : bufs) if (p) hipFree(p);
     delete s;
     ctx->msm = nullptr;
@@ -233,6 +241,61 @@ __global__ void k_add_rows(g1j_t *rows, const g1j_t *extra, const uint32_t *list
     if (i < n) rows[list[i]] = g1_add(rows[list[i]], extra[i]);
 }
 
+// ---- byte-table path: every non-zero byte of every scalar is ONE mixed addition from F[w][d][j] ----
+// grid (chunks * wsplit, rows). A thread walks `cpt` columns and the windows of its group; out[row * gridDim.x + part].
+__global__ void __launch_bounds__(MSM_BLOCK) k_msm_bytes(g1j_t *out, const fr_t *scalars, uint64_t ld, const uint32_t *idx_base,
+                                                         const g1a_t *F, uint32_t m, uint32_t cols, uint32_t cpt, uint32_t wsplit) {
+    __shared__ g1j_t sm[MSM_BLOCK];
+    const uint32_t row = blockIdx.y;
+    const uint32_t wg = blockIdx.x % wsplit, chunk = blockIdx.x / wsplit;
+    const uint32_t wpg = MSM_WINDOWS / wsplit, w0 = wg * wpg, w1 = w0 + wpg;
+    const uint32_t *idx = idx_base ? idx_base + (size_t) row * ld : nullptr;
+    g1j_t acc = g1_inf();
+    for (uint32_t i = 0; i < cpt; ++i) {
+        const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + threadIdx.x;
+        if (c >= cols) break;
+        const fr_t raw = fr_load(scalars + (size_t) row * ld + c);
+        if (fr_is_zero(raw)) continue;
+        bool neg;
+        const fr_t s = fr_signed_magnitude(raw, neg);
+        const uint32_t j = idx ? idx[c] : c;
+        int top = 7;                                  // highest non-zero limb: small scalars leave after their last byte
+        while (top > 0 && s.v[top] == 0) --top;
+        const uint32_t wend = min(w1, (uint32_t) (4 * top + 4));
+        for (uint32_t w = w0; w < wend; ++w) {
+            const uint32_t byte = (s.v[w >> 2] >> ((w & 3) * 8)) & 0xffu;
+            if (byte) {
+                g1a_t pt = F[((size_t) w * 256 + byte) * m + j];
+                if (neg) pt.y = fp_neg(pt.y);
+                acc = g1_madd(acc, pt);
+            }
+        }
+    }
+    if (!__syncthreads_or(!g1_is_inf(acc))) {
+        if (threadIdx.x == 0) out[(size_t) row * gridDim.x + blockIdx.x] = acc;
+        return;
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t) row * gridDim.x + blockIdx.x] = sm[0];
+}
+// out[row * gridDim.x + b] = sum of in[row * nin + 64 b .. 64 b + 63]  (one tree level of width 64 per launch)
+__global__ void __launch_bounds__(MSM_BLOCK) k_tree_reduce(g1j_t *out, const g1j_t *in, uint32_t nin) {
+    __shared__ g1j_t sm[MSM_BLOCK];
+    const uint32_t row = blockIdx.y, p = blockIdx.x * MSM_BLOCK + threadIdx.x;
+    sm[threadIdx.x] = p < nin ? in[(size_t) row * nin + p] : g1_inf();
+    __syncthreads();
+    for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t) row * gridDim.x + blockIdx.x] = sm[0];
+}
+
 // One block per row, one wave per bit plane: wave k sums the partial points of plane k (lane-strided, then a
 // tree through LDS) and pre-multiplies by 2^k (k doublings, the waves run concurrently); a final 3-level tree
 // adds the 8 weighted plane sums. Sequential depth: ceil(nparts/64) + 6 + 7 + 3 point operations.
@@ -386,7 +449,12 @@ static int32_t ensure_state(zk_ctx *ctx) {
 // window tables for `m` affine generators (host pointer, C-ABI layout); cached while the generators stay the same
 static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
     msm_state *s = ctx->msm;
-    if (s->m == m && s->gens_host.size() == m * 12 && std::memcmp(s->gens_host.data(), gens, m * 96) == 0) return ZK_OK;
+    if (s->m == m && s->gens_host.size() == m * 12 && std::memcmp(s->gens_host.data(), gens, m * 96) == 0) {
+        ++s->gens_hits;
+        return ZK_OK;
+    }
+    s->gens_hits = 0;
+    s->full_ready = false;
     if (s->m != m) {
         if (s->tables) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->tables)); s->tables = nullptr; }
         ZK_HIP(hipMalloc((void **) &s->tables, (size_t) MSM_WINDOWS * m * sizeof(g1a_t)));
@@ -405,10 +473,116 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
     return ZK_OK;
 }
 
+static int32_t ensure_rows(zk_ctx *ctx, uint32_t rows) {
+    msm_state *s = ctx->msm;
+    if (s->rows_cap >= rows) return ZK_OK;
+    if (s->rowsJ) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->rowsJ)); ZK_HIP(hipFree(s->rowsA)); s->rowsJ = nullptr; }
+    ZK_HIP(hipMalloc((void **) &s->rowsJ, (size_t) rows * sizeof(g1j_t)));
+    ZK_HIP(hipMalloc((void **) &s->rowsA, (size_t) rows * sizeof(g1a_t)));
+    s->rows_cap = rows;
+    return ZK_OK;
+}
+
+// full byte table for a generator set that is being used again (ZKCNN_MSM_FULL=0 keeps the bit-plane path)
+static int32_t ensure_full_table(zk_ctx *ctx) {
+    msm_state *s = ctx->msm;
+    static const bool enabled = !(getenv("ZKCNN_MSM_FULL") && atoi(getenv("ZKCNN_MSM_FULL")) == 0);
+    if (!enabled || s->full_ready || s->full_failed || s->gens_hits < 1 || s->m > MSM_FULL_MAX_M) return ZK_OK;
+    const uint32_t m = (uint32_t) s->m;
+    if (s->full_m != s->m) {
+        if (s->full) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->full)); s->full = nullptr; s->full_m = 0; }
+        if (hipMalloc((void **) &s->full, (size_t) MSM_WINDOWS * 256 * m * sizeof(g1a_t)) != hipSuccess) {
+            (void) hipGetLastError();
+            s->full = nullptr;
+            s->full_failed = true;             // not enough memory for the table: stay on the bit-plane path
+            return ZK_OK;
+        }
+        s->full_m = s->m;
+    }
+    int32_t rc = regrow(ctx, &s->tbl_scratch, &s->tbl_scratch_cap, (size_t) 256 * m * (sizeof(g1j_t) + sizeof(fp_t)));
+    if (rc) return rc;
+    g1j_t *J = (g1j_t *) s->tbl_scratch;
+    fp_t *pre = (fp_t *) (J + (size_t) 256 * m);
+    for (uint32_t w = 0; w < MSM_WINDOWS; ++w) {
+        for (uint32_t level = 0; level < 8; ++level) {
+            const uint32_t work = (1u << level) * m;
+            ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_digit_level, dim3((work + 63) / 64), dim3(64), J, s->tables + (size_t) w * m, m, level);
+        }
+        ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_digit_affine, dim3((16 * m + 63) / 64), dim3(64), s->full + (size_t) w * 256 * m, J, pre, m);
+    }
+    ZK_HIP(hipGetLastError());
+    s->full_ready = true;
+    return ZK_OK;
+}
+
+// MSMs through the byte table. Many rows: one block per row chunk walks all windows (small scalars stop early). Few rows
+// (the two cross terms of an inner-product round): one (column, window) term per thread, then 64-wide trees; the last
+// <= 64 partial points per row are summed on the host, where the result is needed anyway.
+static int32_t run_msm_bytes(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint32_t *idx, uint32_t rows, uint32_t cols) {
+    msm_state *s = ctx->msm;
+    int32_t rc;
+    if ((rc = ensure_rows(ctx, rows))) return rc;
+    const uint32_t per = (cols + MSM_BLOCK - 1) / MSM_BLOCK;
+    if (rows >= 64) {
+        const uint32_t cpt = std::max<uint32_t>(1, std::min<uint32_t>(64, per));
+        const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt);
+        g1j_t *dst = s->rowsJ;
+        if (chunks > 1) {
+            if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * chunks * sizeof(g1j_t)))) return rc;
+            dst = s->partials;
+        }
+        for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
+            const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
+            ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, k_msm_bytes, dim3(chunks, nr), dim3(MSM_BLOCK), dst + (size_t) r0 * chunks,
+                      scalars + (size_t) r0 * ld, ld, idx ? idx + (size_t) r0 * ld : nullptr, s->full, (uint32_t) s->m, cols, cpt, 1u);
+        }
+        if (chunks > 1) ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_sum_parts, dim3((rows + 63) / 64), dim3(64), s->rowsJ, s->partials, chunks, rows);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+    // few rows: spread (column, window) terms over the whole GPU
+    uint32_t cpt = 1;
+    while ((uint64_t) ((cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt)) * MSM_WINDOWS > 4096) cpt *= 2;
+    const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt);
+    uint32_t n = chunks * MSM_WINDOWS;
+    if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * n * sizeof(g1j_t)))) return rc;
+    if ((rc = regrow(ctx, (void **) &s->parts2, &s->parts2_cap, (size_t) rows * ((n + 63) / 64) * sizeof(g1j_t)))) return rc;
+    ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) rows * (double) cols, k_msm_bytes, dim3(n, rows), dim3(MSM_BLOCK), s->partials, scalars, ld, idx,
+              s->full, (uint32_t) s->m, cols, cpt, (uint32_t) MSM_WINDOWS);
+    g1j_t *cur = s->partials, *nxt = s->parts2;
+    while (n > 64 || (rows > 8 && n > 1)) {
+        const uint32_t n2 = (n + 63) / 64;
+        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_tree_reduce, dim3(n2, rows), dim3(MSM_BLOCK), nxt, cur, n);
+        std::swap(cur, nxt);
+        n = n2;
+    }
+    ZK_HIP(hipGetLastError());
+    if (rows > 8) {
+        ZK_HIP(hipMemcpyAsync(s->rowsJ, cur, (size_t) rows * sizeof(g1j_t), hipMemcpyDeviceToDevice, ctx->stream));
+        return ZK_OK;
+    }
+    std::vector<zkff::G1> part((size_t) rows * n);
+    ZK_HIP(hipMemcpyAsync(part.data(), cur, part.size() * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    for (uint32_t r = 0; r < rows; ++r) {
+        zkff::G1 acc = part[(size_t) r * n];
+        for (uint32_t k = 1; k < n; ++k) zkff::G1::add(acc, acc, part[(size_t) r * n + k]);
+        s->host_rows[r] = acc;
+    }
+    s->host_rows_valid = true;
+    return ZK_OK;
+}
+
 // rows independent MSMs over the cached generator tables; results (Jacobian) in s->rowsJ[0..rows)
 static int32_t run_msm(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint32_t *idx, uint32_t rows, uint32_t cols,
                        const uint32_t *row_map = nullptr, uint32_t w_lo = 0, g1j_t *outJ = nullptr, bool sparse_windows = false) {
     msm_state *s = ctx->msm;
+    s->host_rows_valid = false;
+    if (!row_map && !outJ && w_lo == 0) {
+        int32_t rc0 = ensure_full_table(ctx);
+        if (rc0) return rc0;
+        if (s->full_ready) return run_msm_bytes(ctx, scalars, ld, idx, rows, cols);
+    }
     uint32_t wsplit, cpt;
     const uint32_t per = (cols + MSM_BLOCK - 1) / MSM_BLOCK;
     if (rows >= 64) { wsplit = 1; cpt = std::min<uint32_t>(64, per); }
@@ -463,6 +637,9 @@ static int32_t ensure_digit_table(zk_ctx *ctx) {
 static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32_t rows, uint32_t cols) {
     msm_state *s = ctx->msm;
     int32_t rc;
+    s->host_rows_valid = false;
+    if ((rc = ensure_full_table(ctx))) return rc;
+    if (s->full_ready && rows >= 64) return run_msm_bytes(ctx, scalars, ld, nullptr, rows, cols);
     if ((rc = ensure_digit_table(ctx))) return rc;
     const uint32_t cpt = std::max<uint32_t>(1, std::min<uint32_t>(64, (cols + MSM_BLOCK - 1) / MSM_BLOCK));
     const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt);
@@ -535,8 +712,12 @@ static int32_t fetch_points(zk_ctx *ctx, uint32_t rows, uint64_t *out) {
         return ZK_OK;
     }
     zkff::G1 pj[8];
-    ZK_HIP(hipMemcpyAsync(pj, s->rowsJ, (size_t) rows * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (s->host_rows_valid) {
+        for (uint32_t i = 0; i < rows; ++i) pj[i] = s->host_rows[i];
+    } else {
+        ZK_HIP(hipMemcpyAsync(pj, s->rowsJ, (size_t) rows * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    }
     for (uint32_t i = 0; i < rows; ++i) {
         zkff::G1Affine a = pj[i].toAffine();
         std::memcpy(out + 12 * i, &a, 96);
