@@ -1,0 +1,19 @@
+#!/bin/bash
+# bench.py over the BASELINE.json configurations -> gpurun_out/<tag>_configs.jsonl (one JSON line per run)
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+TAG=${1:-configs}
+OUT=$ROOT/gpurun_out/${TAG}_configs.jsonl
+mkdir -p $ROOT/gpurun_out; : > $OUT
+cd $ROOT
+for spec in "lenet 1" "lenet 4" "vgg11 1" "vgg11 4" "vgg16 1" "vgg16 4" "vgg11_pp8 1" "vgg16_pp4 1"; do
+  set -- $spec
+  timeout 900 python bench.py --workload $1 --streams $2 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT
+done
+python3 - <<PY
+import json
+for l in open("$OUT"):
+    try: d = json.loads(l)
+    except Exception: print("bad line", l[:80]); continue
+    c = d["config"]
+    print(f'{c["workload"][:60]:60s} streams {c["streams_per_gpu"]} | {d["value"]:8.2f} proofs/s | latency {d["prover_ms_per_image"]:8.1f} ms (sumcheck {d["prover_ms_sumcheck"]:.1f} + commit {d["prover_ms_commit"]:.1f}) | layers {c["layers"]} rounds {c["rounds"]} input 2^{(c["input_size"]-1).bit_length()} mul {c["mul_gates"]:.2e} | proof {d["proof_kb"]} KB | setup {d["setup_s"]} s | pass {d["verifier_pass"]}')
+PY

@@ -8,7 +8,9 @@ static_assert(sizeof(F) == 32, "Fr must be 4 x u64 Montgomery limbs");
 // optional wall-clock breakdown per prover method (ZKCNN_TIMING=1): printed when the prover is destroyed
 #include <chrono>
 #include <map>
+#include <mutex>
 namespace {
+std::mutex g_times_mu;
 struct methodTimes {
     std::map<string, std::pair<double, long>> t;
     bool on = std::getenv("ZKCNN_TIMING") != nullptr;
@@ -23,6 +25,7 @@ struct scopeTimer {
     explicit scopeTimer(const char *n) : name(n) { if (g_times.on) t0 = std::chrono::steady_clock::now(); }
     ~scopeTimer() {
         if (!g_times.on) return;
+        std::lock_guard<std::mutex> lk(g_times_mu);
         auto &e = g_times.t[name];
         e.first += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         ++e.second;
