@@ -25,6 +25,7 @@ struct dev_layer {
     // phase-2 lists: bin gates whose v operand lives in table b, sorted by v
     gate_rec *p2[2] = {nullptr, nullptr};
     uint64_t n_p2[2] = {0, 0};
+    uint32_t p1_cov[2] = {0, 0}, p2_cov[2] = {0, 0};   // keys [0, cov) all have a gate: the scatter writes them, only the rest is zeroed
     int p2_uniform[2] = {-1, -1};   // every gate of the list has its u operand in the same layer: 0 = layer 0, 1 = previous, -1 = mixed
     gate_rec *uni2 = nullptr;      // uni gates for the phase-2 constant term (aux = u, bit 10 = u in previous layer)
     uint64_t n_uni2 = 0;
@@ -40,6 +41,7 @@ struct table_pair {
     fr_t *V[2] = {nullptr, nullptr};
     fr_t *M[2] = {nullptr, nullptr};
     int cur = 0;
+    const fr_t *Vsrc = nullptr;    // until the first fold the V input is read straight from a layer's values (no copy into V[cur])
     uint64_t len = 0;              // current (pre-fold) length; 0 = absent or already absorbed
     bool absorbed = false;         // collapsed to a constant whose product went into add_term
     HFr final_v;                   // value of V when it collapsed

@@ -660,12 +660,20 @@ __global__ void k_strided_matvec(fr_t *out, const fr_t *val, const fr_t *beta, u
     fr_store(out + (size_t) blockIdx.y * len + u, acc);
 }
 // out[u] = sum_c part[c * len + u]
-__global__ void k_sum_rows(fr_t *out, const fr_t *part, uint32_t len, uint32_t chunks) {
-    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= len) return;
-    fr_t acc = fr_load(part + u);
-    for (uint32_t c = 1; c < chunks; ++c) acc = fr_add(acc, fr_load(part + (size_t) c * len + u));
-    fr_store(out + u, acc);
+// block = 64 columns x 16 chunk lanes (1024 threads): a lane sums every 16th chunk row, an LDS tree adds the 16 lanes
+__global__ void __launch_bounds__(1024) k_sum_rows(fr_t *out, const fr_t *part, uint32_t len, uint32_t chunks) {
+    __shared__ fr_t sm[16][64];
+    const uint32_t tx = threadIdx.x & 63, cl = threadIdx.x >> 6, u = blockIdx.x * 64 + tx;
+    fr_t acc = fr_zero();
+    if (u < len)
+        for (uint32_t c = cl; c < chunks; c += 16) acc = fr_add(acc, fr_load(part + (size_t) c * len + u));
+    sm[cl][tx] = acc;
+    __syncthreads();
+    for (uint32_t s = 8; s >= 1; s >>= 1) {
+        if (cl < s) sm[cl][tx] = fr_add(sm[cl][tx], sm[cl + s][tx]);
+        __syncthreads();
+    }
+    if (cl == 0 && u < len) fr_store(out + u, sm[0][tx]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -143,6 +143,15 @@ extern "C" uint64_t zk_proof_bytes(const zk_ctx *ctx) { return ctx->proof_size; 
 // ------------------------------------------------------------------------------------------------
 // residency
 // ------------------------------------------------------------------------------------------------
+// number of leading keys 0, 1, 2, ... that occur in a list sorted by key
+static uint32_t covered_prefix(const std::vector<gate_rec> &recs) {
+    uint32_t k = 0;
+    for (const gate_rec &r : recs) {
+        if (r.key == k) ++k;
+        else if (r.key > k) break;
+    }
+    return k;
+}
 static void counting_sort(std::vector<gate_rec> &recs, uint32_t nkeys) {
     std::vector<uint32_t> cnt((size_t) nkeys + 1, 0);
     for (const gate_rec &r : recs) ++cnt[r.key + 1];
@@ -209,6 +218,7 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
             if (S.bit_length_v[b] < 0) { ctx->err = "bin gate refers to an absent v table"; return ZK_ERR_ARG; }
             counting_sort(q[b], 1u << S.bit_length_v[b]);
             D.n_p2[b] = q[b].size();
+            D.p2_cov[b] = covered_prefix(q[b]);
             {
                 const uint32_t f0 = GATE_IN_PREV(q[b][0].meta);
                 bool same = true;
@@ -261,6 +271,7 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
             if (S.bit_length_u[b] < 0) { ctx->err = "gate refers to an absent u table"; return ZK_ERR_ARG; }
             counting_sort(p[b], 1u << S.bit_length_u[b]);
             D.n_p1[b] = p[b].size();
+            D.p1_cov[b] = covered_prefix(p[b]);
             max_list = std::max<uint64_t>(max_list, p[b].size());
             if ((rc = upload(ctx, &D.p1[b], p[b]))) return rc;
             std::vector<gate_rec>().swap(p[b]);
@@ -348,7 +359,7 @@ int32_t zk_col_combine_dev(zk_ctx *ctx, fr_t *out, const fr_t *Z, const fr_t *L,
     dim3 grid((cols + ZK_BLOCK - 1) / ZK_BLOCK, chunks);
     ZK_LAUNCH(PC_MATVEC, 0.0, k_col_combine, grid, dim3(ZK_BLOCK), part, Z, L, cols, rows, per);
     if (chunks > 1)
-        ZK_LAUNCH(PC_MATVEC, 0.0, k_sum_rows, dim3((cols + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), out, part, cols, chunks);
+        ZK_LAUNCH(PC_MATVEC, 0.0, k_sum_rows, dim3((cols + 63) / 64), dim3(1024), out, part, cols, chunks);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -406,9 +417,16 @@ static int32_t gate_scatter(zk_ctx *ctx, fr_t *out, const gate_rec *recs, uint64
 }
 
 // V-table of one side: layer-0 subset through ori ids, or the previous layer as it is
-static int32_t load_v_table(zk_ctx *ctx, fr_t *dst, int b, int bl, uint32_t size, const uint32_t *ori, const dev_layer &prev) {
+static inline const fr_t *vin(const table_pair &t) { return t.Vsrc ? t.Vsrc : t.V[t.cur]; }
+
+static int32_t load_v_table(zk_ctx *ctx, table_pair &t, int b, int bl, uint32_t size, const uint32_t *ori, const dev_layer &prev) {
     if (bl < 0) return ZK_OK;
     const uint64_t len = 1ull << bl;
+    fr_t *dst = t.V[0];
+    if (b == 1 && prev.val_len >= len) {            // the previous layer as it is: read in place until the first fold
+        t.Vsrc = prev.val;
+        return ZK_OK;
+    }
     if (b == 0) {
         ZK_LAUNCH(PC_GATHER, 0.0, k_gather, dim3(grid_for(len)), dim3(ZK_BLOCK), dst, ctx->L[0].val, ori, (uint64_t) size, len);
         ZK_HIP(hipGetLastError());
@@ -424,6 +442,7 @@ static void reset_pairs(zk_ctx *ctx, int bl0, int bl1) {
     const int bl[2] = {bl0, bl1};
     for (int b = 0; b < 2; ++b) {
         ctx->tp[b].cur = 0;
+        ctx->tp[b].Vsrc = nullptr;
         ctx->tp[b].len = bl[b] >= 0 ? 1ull << bl[b] : 0;
         ctx->tp[b].absorbed = false;
         ctx->tp[b].final_v.clear();
@@ -476,7 +495,7 @@ static int32_t strided_matvec(zk_ctx *ctx, fr_t *out, const fr_t *val, const fr_
     dim3 grid((len + ZK_BLOCK - 1) / ZK_BLOCK, chunks);
     ZK_LAUNCH(PC_MATVEC, 0.0, k_strided_matvec, grid, dim3(ZK_BLOCK), part, val, beta, len, stride, cnt, per);
     if (chunks > 1)
-        ZK_LAUNCH(PC_MATVEC, 0.0, k_sum_rows, dim3((len + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), out, part, len, chunks);
+        ZK_LAUNCH(PC_MATVEC, 0.0, k_sum_rows, dim3((len + 63) / 64), dim3(1024), out, part, len, chunks);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -484,7 +503,8 @@ static int32_t strided_matvec(zk_ctx *ctx, fr_t *out, const fr_t *val, const fr_
 // folds table `b`'s V (and M if with_m) with r; len must be >= 2
 static int32_t fold_pair(zk_ctx *ctx, table_pair &t, const HFr &r, bool with_m) {
     const fr_t rr = to_dev(r);
-    ZK_LAUNCH(PC_FOLD, 0.0, k_fold, dim3(grid_for(t.len / 2)), dim3(ZK_BLOCK), t.V[t.cur], t.V[t.cur ^ 1], t.len, rr);
+    ZK_LAUNCH(PC_FOLD, 0.0, k_fold, dim3(grid_for(t.len / 2)), dim3(ZK_BLOCK), vin(t), t.V[t.cur ^ 1], t.len, rr);
+    t.Vsrc = nullptr;
     if (with_m)
         ZK_LAUNCH(PC_FOLD, 0.0, k_fold, dim3(grid_for(t.len / 2)), dim3(ZK_BLOCK), t.M[t.cur], t.M[t.cur ^ 1], t.len, rr);
     ZK_HIP(hipGetLastError());
@@ -516,12 +536,13 @@ extern "C" int32_t zk_vres(zk_ctx *ctx, const uint64_t *r, uint32_t output_size,
     table_pair &t = ctx->tp[0];
     t.cur = 0;
     t.len = 1ull << r_size;
-    ZK_HIP(hipMemcpyAsync(t.V[0], top.val, t.len * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    t.Vsrc = top.val;
     for (uint32_t i = 0; i < r_size; ++i) {
         int32_t rc = fold_pair(ctx, t, H(r + 4 * i), false);
         if (rc) return rc;
     }
-    ZK_HIP(hipMemcpyAsync(ctx->d_result, t.V[t.cur], 32, hipMemcpyDeviceToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(ctx->d_result, vin(t), 32, hipMemcpyDeviceToDevice, ctx->stream));
+    t.Vsrc = nullptr;
     int32_t rc = fetch_result(ctx, 1);
     if (rc) return rc;
     put(out, ctx->h_result[0]);
@@ -582,7 +603,7 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
     }
 
     for (int b = 0; b < 2; ++b)
-        if ((rc = load_v_table(ctx, ctx->tp[b].V[0], b, d.bit_length_u[b], d.size_u[b], cur.ori_u, prev))) return rc;
+        if ((rc = load_v_table(ctx, ctx->tp[b], b, d.bit_length_u[b], d.size_u[b], cur.ori_u, prev))) return rc;
 
     if (d.ty == ZK_PADDING) {
         // beta_g[g] = beta_g_fft[g >> (n-1)] * eq(r_0[0..n-1), g & mask): the table left by the FFT layer above
@@ -603,7 +624,7 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
     for (int b = 0; b < 2; ++b) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
-        ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
+        if (cur.p1_cov[b] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p1_cov[b], 0, (t.len - cur.p1_cov[b]) * 32, ctx->stream));
         if ((rc = gate_scatter(ctx, t.M[0], cur.p1[b], cur.n_p1[b], 1, cur, prev, cur.n_p1_uni[b], t.len))) return rc;
     }
     return ZK_OK;
@@ -625,7 +646,7 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
     ctx->small_cur = 0;
     const uint64_t N = ctx->tp[1].len;
     if ((rc = eq_table1(ctx, ctx->small[0], fft_bl, ctx->r_0, HFr::one()))) return rc;
-    if ((rc = load_v_table(ctx, ctx->tp[1].V[0], 1, d.bit_length_u[1], d.size_u[1], nullptr, prev))) return rc;
+    if ((rc = load_v_table(ctx, ctx->tp[1], 1, d.bit_length_u[1], d.size_u[1], nullptr, prev))) return rc;
     ZK_HIP(hipMemsetAsync(ctx->tp[0].V[0], 0, N * 32, ctx->stream));
     if (cur.d1_rows) {
         dim3 grid(((1u << fft_bl) + ZK_BLOCK - 1) / ZK_BLOCK, cur.d1_rows);
@@ -653,13 +674,14 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
     if (npairs == 0) return ZK_ERR_STATE;
     const uint32_t g = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks);
     const unsigned long long seq = ++ctx->slot_seq;
-    ZK_LAUNCH(PC_ROUND_CUBIC, (first ? 64.0 : 96.0) * (double) n, k_round_cubic, dim3(g), dim3(ZK_BLOCK), t0.V[t0.cur], t1.V[t1.cur],
+    ZK_LAUNCH(PC_ROUND_CUBIC, (first ? 64.0 : 96.0) * (double) n, k_round_cubic, dim3(g), dim3(ZK_BLOCK), t0.V[t0.cur], vin(t1),
               t0.V[t0.cur ^ 1], t1.V[t1.cur ^ 1], ctx->small[ctx->small_cur], ctx->small_len, n, to_dev(r), first ? 1 : 0, ctx->partials,
               ctx->d_counter, (host_slot *) ctx->d_slot, seq);
     ZK_HIP(hipGetLastError());
     if (!first) {
         t0.cur ^= 1; t1.cur ^= 1;
         t0.len >>= 1; t1.len >>= 1;
+        t1.Vsrc = nullptr;
     }
     int32_t rc = wait_slot(ctx, seq);
     if (rc) return rc;
@@ -679,7 +701,7 @@ extern "C" int32_t zk_sumcheck_dotprod_finalize1(zk_ctx *ctx, const uint64_t pre
     int32_t rc;
     eval_args E;
     std::memset(&E, 0, sizeof(E));
-    E.p[0] = t1.V[t1.cur]; E.n[0] = (uint32_t) std::min<uint64_t>(t1.len, 2);
+    E.p[0] = vin(t1); E.n[0] = (uint32_t) std::min<uint64_t>(t1.len, 2);
     E.p[1] = ctx->small[ctx->small_cur]; E.n[1] = std::min<uint32_t>(ctx->small_len, 2);
     if (t1.len > 2 || ctx->small_len > 2) return ZK_ERR_STATE;
     E.r = to_dev(r);
@@ -720,13 +742,13 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         const uint32_t rows = d.size_v[1];
         ZK_LAUNCH(PC_DOT, 0.0, k_row_dot, dim3((rows + 3) / 4), dim3(ZK_BLOCK), t.V[0], prev.val, ctx->beta_gs, rows, fft_bl);
         ZK_HIP(hipGetLastError());
-        ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
+        if (cur.p2_cov[1] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p2_cov[1], 0, (t.len - cur.p2_cov[1]) * 32, ctx->stream));
         return gate_scatter(ctx, t.M[0], cur.p2[1], cur.n_p2[1], 2, cur, prev, 0, t.len, cur.p2_uniform[1]);
     }
 
     if ((rc = eq_table1(ctx, ctx->beta_u, d.max_bl_u, ru, HFr::one()))) return rc;
     for (int b = 0; b < 2; ++b)
-        if ((rc = load_v_table(ctx, ctx->tp[b].V[0], b, d.bit_length_v[b], d.size_v[b], cur.ori_v, prev))) return rc;
+        if ((rc = load_v_table(ctx, ctx->tp[b], b, d.bit_length_v[b], d.size_v[b], cur.ori_v, prev))) return rc;
     if (cur.n_uni2) {
         gate_args A;
         A.recs = cur.uni2; A.n = cur.n_uni2;
@@ -741,7 +763,7 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
     for (int b = 0; b < 2; ++b) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
-        ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
+        if (cur.p2_cov[b] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p2_cov[b], 0, (t.len - cur.p2_cov[b]) * 32, ctx->stream));
         if ((rc = gate_scatter(ctx, t.M[0], cur.p2[b], cur.n_p2[b], 2, cur, prev, 0, t.len, cur.p2_uniform[b]))) return rc;
     }
     if (cur.n_uni2) {
@@ -769,7 +791,7 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
     for (int b = 0; b < 2; ++b) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
-        A.Vin[b] = t.V[t.cur]; A.Min[b] = t.M[t.cur];
+        A.Vin[b] = vin(t); A.Min[b] = t.M[t.cur];
         A.Vout[b] = t.V[t.cur ^ 1]; A.Mout[b] = t.M[t.cur ^ 1];
         A.n[b] = t.len;
         collapsed[b] = (first && t.len == 1) || (!first && t.len == 2);     // the reference's `total == 1` case
@@ -794,7 +816,7 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         ZK_HIP(hipGetLastError());
         for (int b = 0; b < 2; ++b) {
             table_pair &t = ctx->tp[b];
-            if (t.len && !first) { t.cur ^= 1; t.len >>= 1; }
+            if (t.len && !first) { t.cur ^= 1; t.len >>= 1; t.Vsrc = nullptr; }
         }
         int32_t rc = wait_slot(ctx, A.seq);
         if (rc) return rc;
@@ -846,7 +868,7 @@ static int32_t final_claims(zk_ctx *ctx, const HFr &r, const int8_t bl[2], HFr o
         out[b].clear();
         if (t.len > 2) return ZK_ERR_STATE;
         if (t.len >= 1) {
-            E.p[b] = t.V[t.cur];
+            E.p[b] = vin(t);
             E.n[b] = (uint32_t) t.len;
             pending[b] = true;
         } else if (t.absorbed && bl[b] >= 0) out[b] = t.final_v;
@@ -905,7 +927,7 @@ extern "C" int32_t zk_sumcheck_liu_init(zk_ctx *ctx, const uint64_t *s_u, const 
     ctx->add_term.clear();
     ctx->round = 0;
     table_pair &t = ctx->tp[1];
-    ZK_HIP(hipMemcpyAsync(t.V[0], L0.val, t.len * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    t.Vsrc = L0.val;
     ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
     fr_t *bg = ctx->beta_g[ctx->beta_g_cur];
     int32_t rc;
