@@ -38,6 +38,10 @@ WORKLOADS = {
     # bounded CPU sample: vgg11 with every channel width divided by 4 (1/16 of the multiplication gates)
     "vgg11_quarter": ("vgg:16 M 32 M 64 64 M 128 128 M 128 128 M", (32, 32, 3), 1),
 }
+# HBM bytes per launch of a kernel class from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, separate passes,
+# scripts/pmc_proof.sh): r01g_vgg11_pmc_traffic.md: (5.03 + 1.76 + 69.18 + 23.58) GB over 7976 + 1056 launches of k_round_quad_fine / 2;
+# r01g_vgg11_pp8_pmc_traffic.md likewise. None where no PMC pass exists for the (workload, class).
+PMC_TRAFFIC_PER_LAUNCH = {("vgg11", "round_quad"): 11.02e6, ("vgg11_pp8", "round_quad"): (6.50 + 2.55 + 299.46 + 105.63) * 1e9 / (10000 + 2312)}
 # kernel classes whose algorithmic byte count is defined; the dominant one is reported
 ROOFLINE_CLASSES = ["gate_reduce", "round_quad", "round_cubic", "msm_planes"]
 
@@ -193,7 +197,7 @@ def main():
         sec = prof["ms"] * 1e-3 / prof["launches"]
         achieved = prof["bytes"] / prof["launches"] / sec / 1e9
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_PER_LAUNCH.get((args.workload, dominant)),
                     "avg_launch_ms": round(sec * 1e3, 4), "launches_per_step": prof["launches"] / args.steps,
                     "note": f"HIP events with {K} proofs in flight on the GPU: launch durations include contention between the streams",
                     "algorithmic_bytes_per_launch": prof["bytes"] / prof["launches"],
