@@ -81,6 +81,14 @@ __device__ __noinline__ fp_t fp_mul(const fp_t a, const fp_t b) {
     return z;
 }
 __device__ __forceinline__ fp_t fp_sqr(const fp_t &a) { return fp_mul(a, a); }
+// inlined copy for the one hot loop that keeps a whole point in registers across the products (k_msm_bytes: g1_madd)
+__device__ __forceinline__ fp_t fp_mul_i(const fp_t &a, const fp_t &b) {
+    const uint32_t m[12] = FP_MOD_INIT;
+    fp_t z;
+    mont_mul_comba<12, false>(z.v, a.v, b.v, m, FP_INV32);
+    return z;
+}
+__device__ __forceinline__ fp_t fp_sqr_i(const fp_t &a) { return fp_mul_i(a, a); }
 
 // a^(p-2): Fermat inverse (inv(0) = 0)
 __device__ __forceinline__ fp_t fp_inv(const fp_t &a) {
@@ -164,6 +172,62 @@ __device__ __forceinline__ g1j_t g1_madd(const g1j_t &p, const g1a_t &q) {
     r.X = fp_sub(fp_sub(fp_sqr(Rr), HHH), fp_dbl(V));
     r.Y = fp_sub(fp_mul(Rr, fp_sub(V, r.X)), fp_mul(p.Y, HHH));
     r.Z = fp_mul(p.Z, H);
+    return r;
+}
+
+// g1_madd with every product inlined (no calls: nothing is spilled around them)
+__device__ __forceinline__ g1j_t g1_madd_i(const g1j_t &p, const g1a_t &q) {
+    if (g1a_is_inf(q)) return p;
+    if (g1_is_inf(p)) {
+        g1j_t r;
+        r.X = q.x; r.Y = q.y; r.Z = fp_one();
+        return r;
+    }
+    fp_t Z1Z1 = fp_sqr_i(p.Z);
+    fp_t U2 = fp_mul_i(q.x, Z1Z1), S2 = fp_mul_i(fp_mul_i(q.y, p.Z), Z1Z1);
+    if (fp_eq(p.X, U2)) {
+        if (fp_eq(p.Y, S2)) return g1_dbl(p);
+        return g1_inf();
+    }
+    fp_t H = fp_sub(U2, p.X), Rr = fp_sub(S2, p.Y);
+    fp_t HH = fp_sqr_i(H), HHH = fp_mul_i(H, HH), V = fp_mul_i(p.X, HH);
+    g1j_t r;
+    r.X = fp_sub(fp_sub(fp_sqr_i(Rr), HHH), fp_dbl(V));
+    r.Y = fp_sub(fp_mul_i(Rr, fp_sub(V, r.X)), fp_mul_i(p.Y, HHH));
+    r.Z = fp_mul_i(p.Z, H);
+    return r;
+}
+
+__device__ __forceinline__ g1j_t g1_dbl_i(const g1j_t &p) {
+    if (g1_is_inf(p)) return p;
+    fp_t A = fp_sqr_i(p.X), B = fp_sqr_i(p.Y), C = fp_sqr_i(B);
+    fp_t t = fp_add(p.X, B);
+    fp_t D = fp_sub(fp_sub(fp_sqr_i(t), A), C);
+    D = fp_dbl(D);
+    fp_t E = fp_add(fp_dbl(A), A), F = fp_sqr_i(E);
+    g1j_t r;
+    r.X = fp_sub(F, fp_dbl(D));
+    fp_t C8 = fp_dbl(fp_dbl(fp_dbl(C)));
+    r.Y = fp_sub(fp_mul_i(E, fp_sub(D, r.X)), C8);
+    r.Z = fp_dbl(fp_mul_i(p.Y, p.Z));
+    return r;
+}
+__device__ __forceinline__ g1j_t g1_add_i(const g1j_t &p, const g1j_t &q) {
+    if (g1_is_inf(p)) return q;
+    if (g1_is_inf(q)) return p;
+    fp_t Z1Z1 = fp_sqr_i(p.Z), Z2Z2 = fp_sqr_i(q.Z);
+    fp_t U1 = fp_mul_i(p.X, Z2Z2), U2 = fp_mul_i(q.X, Z1Z1);
+    fp_t S1 = fp_mul_i(fp_mul_i(p.Y, q.Z), Z2Z2), S2 = fp_mul_i(fp_mul_i(q.Y, p.Z), Z1Z1);
+    if (fp_eq(U1, U2)) {
+        if (fp_eq(S1, S2)) return g1_dbl(p);
+        return g1_inf();
+    }
+    fp_t H = fp_sub(U2, U1), Rr = fp_sub(S2, S1);
+    fp_t HH = fp_sqr_i(H), HHH = fp_mul_i(H, HH), V = fp_mul_i(U1, HH);
+    g1j_t r;
+    r.X = fp_sub(fp_sub(fp_sqr_i(Rr), HHH), fp_dbl(V));
+    r.Y = fp_sub(fp_mul_i(Rr, fp_sub(V, r.X)), fp_mul_i(S1, HHH));
+    r.Z = fp_mul_i(fp_mul_i(p.Z, q.Z), H);
     return r;
 }
 

@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_bytes(g1j_t *out, const fr_t 
             if (byte) {
                 g1a_t pt = F[((size_t) w * 256 + byte) * m + j];
                 if (neg) pt.y = fp_neg(pt.y);
-                acc = g1_madd(acc, pt);
+                acc = g1_madd_i(acc, pt);
             }
         }
     }
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_bytes(g1j_t *out, const fr_t 
     sm[threadIdx.x] = acc;
     __syncthreads();
     for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
-        if (threadIdx.x < s) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + s]);
+        if (threadIdx.x < s) sm[threadIdx.x] = g1_add_i(sm[threadIdx.x], sm[threadIdx.x + s]);
         __syncthreads();
     }
     if (threadIdx.x == 0) out[(size_t) row * gridDim.x + blockIdx.x] = sm[0];
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_tree_reduce(g1j_t *out, const g1j
     sm[threadIdx.x] = p < nin ? in[(size_t) row * nin + p] : g1_inf();
     __syncthreads();
     for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
-        if (threadIdx.x < s) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + s]);
+        if (threadIdx.x < s) sm[threadIdx.x] = g1_add_i(sm[threadIdx.x], sm[threadIdx.x + s]);
         __syncthreads();
     }
     if (threadIdx.x == 0) out[(size_t) row * gridDim.x + blockIdx.x] = sm[0];
