@@ -783,7 +783,8 @@ extern "C" int32_t zk_hyrax_open_round(zk_ctx *ctx, uint64_t Lp[12], uint64_t Rp
     uint64_t pts[24];
     if ((rc = run_msm(ctx, s->sL, m / 2, s->idxL, 2, m / 2))) return rc;
     if ((rc = fetch_points(ctx, 2, pts))) return rc;
-    ZK_HIP(hipMemcpy(ctx->h_result, s->d_y, 64, hipMemcpyDeviceToHost));
+    ZK_HIP(hipMemcpyAsync(ctx->h_result, s->d_y, 64, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
     std::memcpy(Lp, pts, 96);
     std::memcpy(Rp, pts + 12, 96);
     std::memcpy(yL, &ctx->h_result[0], 32);

@@ -59,7 +59,7 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
     if (device < 0 || device >= n) { g_create_err = "device index out of range"; return ZK_ERR_ARG; }
     zk_ctx *ctx = new zk_ctx();
     ctx->device = device;
-    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
         g_create_err = hipGetErrorString(e);
         delete ctx;
         return ZK_ERR_HIP;
@@ -74,7 +74,7 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
         zk_dev_alloc(ctx, (void **) &ctx->d_counter, 64) ||
         hipHostMalloc((void **) &ctx->h_slot, sizeof(*ctx->h_slot), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer(&ctx->d_slot, ctx->h_slot, 0) != hipSuccess ||
-        hipMemset(ctx->d_counter, 0, 64) != hipSuccess ||
+        hipMemsetAsync(ctx->d_counter, 0, 64, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
         hipHostMalloc((void **) &ctx->h_result, 32 * 32) != hipSuccess) {
         g_create_err = ctx->err.empty() ? "allocation failed" : ctx->err;
         zk_ctx_destroy(ctx);
@@ -181,7 +181,7 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
         if (S.bit_length < 0 || S.bit_length > ZK_MAX_VARS) { ctx->err = "layer bit length out of range"; return ZK_ERR_ARG; }
         D.val_len = 1ull << S.bit_length;
         if ((rc = zk_dev_alloc(ctx, (void **) &D.val, D.val_len * 32))) return rc;
-        ZK_HIP(hipMemset(D.val, 0, D.val_len * 32));
+        ZK_HIP(hipMemsetAsync(D.val, 0, D.val_len * 32, ctx->stream));
         max_table = std::max<uint64_t>(max_table, D.val_len);
         if (i == 0) continue;
         max_bg = std::max<uint64_t>(max_bg, D.val_len);
@@ -297,6 +297,7 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
     if ((rc = zk_dev_alloc(ctx, (void **) &ctx->carry_key, ctx->carry_slots * 4))) return rc;
     if ((rc = zk_dev_alloc(ctx, (void **) &ctx->carry_val, ctx->carry_slots * 32))) return rc;
     if ((rc = zk_scratch(ctx, (size_t) 1 << 24))) return rc;
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->circuit_ready = true;
     return ZK_OK;
 }
@@ -306,8 +307,9 @@ extern "C" int32_t zk_upload_layer_values(zk_ctx *ctx, int32_t layer, const uint
     dev_layer &D = ctx->L[layer];
     if (n > D.val_len) { ctx->err = "more values than the layer holds"; return ZK_ERR_ARG; }
     ZK_HIP(hipSetDevice(ctx->device));
-    ZK_HIP(hipMemcpy(D.val, values, n * 32, hipMemcpyHostToDevice));
-    if (n < D.val_len) ZK_HIP(hipMemset(D.val + n, 0, (D.val_len - n) * 32));
+    ZK_HIP(hipMemcpyAsync(D.val, values, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (n < D.val_len) ZK_HIP(hipMemsetAsync(D.val + n, 0, (D.val_len - n) * 32, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
     return ZK_OK;
 }
 
@@ -1250,7 +1252,10 @@ static int32_t grow_buf(zk_ctx *ctx, dev_buf &b, size_t bytes, size_t keep = 0) 
         want = bytes;
         ZK_HIP(hipMalloc(&np, want));
     }
-    if (keep && b.p) ZK_HIP(hipMemcpy(np, b.p, keep, hipMemcpyDeviceToDevice));
+    if (keep && b.p) {
+        ZK_HIP(hipMemcpyAsync(np, b.p, keep, hipMemcpyDeviceToDevice, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    }
     if (b.p) ZK_HIP(hipFree(b.p));
     b.p = np;
     b.bytes = want;
