@@ -379,11 +379,76 @@ struct host_slot {
     unsigned long long seq;     // written last
 };
 
+// Hand-over without cache-wide fences (default; ZKCNN_FINISH_LIGHT=0 at context creation restores the fence version below): the per-block partial sums and the
+// host slot are written with scope-qualified atomic stores (write-through past the XCD's L2 / uncached to the host), ordered by
+// waiting for their acknowledgement (s_waitcnt vmcnt(0)) before the ticket / the sequence number; the last block reads the
+// partials with agent-scope loads. A release / acquire fence here would write back or invalidate the whole L2 of the XCD --
+// which holds the table halves this kernel has just written -- once per block.
+__device__ int g_finish_light = 1;
+__device__ __forceinline__ void fr_store_scoped(fr_t *p, const fr_t &a, bool system) {
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const unsigned long long x = ((unsigned long long) a.v[2 * w + 1] << 32) | a.v[2 * w];
+        if (system) __hip_atomic_store(q + w, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else __hip_atomic_store(q + w, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ fr_t fr_load_agent(const fr_t *p) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+    fr_t z;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const unsigned long long x = __hip_atomic_load(q + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        z.v[2 * w] = (uint32_t) x;
+        z.v[2 * w + 1] = (uint32_t) (x >> 32);
+    }
+    return z;
+}
+#define ZK_WAIT_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
 template <int K>
 __device__ __forceinline__ void grid_finish(fr_t (&acc)[K], fr_t *partials, uint32_t *counter, host_slot *slot,
                                             unsigned long long seq, fr_t *smem, bool wrote_slot = false) {
     __shared__ int s_last;
     (void) smem;
+    if (g_finish_light) {
+        if (gridDim.x == 1) {
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) fr_store_scoped(&slot->v[k], acc[k], true);
+                if (wrote_slot) __threadfence_system();
+                ZK_WAIT_STORES();
+                __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) fr_store_scoped(partials + (size_t) K * blockIdx.x + k, acc[k], false);
+            if (wrote_slot) __threadfence_system();
+            ZK_WAIT_STORES();
+            const uint32_t t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (t == gridDim.x - 1);
+        }
+        __syncthreads();
+        if (!s_last) return;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (wave < K) {
+            fr_t tot = fr_zero();
+            for (uint32_t b = lane; b < gridDim.x; b += 64) tot = fr_add(tot, fr_load_agent(partials + (size_t) K * b + wave));
+            tot = fr_wave_sum(tot);
+            if (lane == 0) fr_store_scoped(&slot->v[wave], tot, true);
+            ZK_WAIT_STORES();
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ZK_WAIT_STORES();
+            __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     if (gridDim.x == 1) {                                // small tables: this block already holds the grid total
         if (threadIdx.x == 0) {
 #pragma unroll

@@ -81,6 +81,14 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
         return ZK_ERR_NOMEM;
     }
     std::memset((void *) ctx->h_slot, 0, sizeof(*ctx->h_slot));
+    {
+        const int light = getenv("ZKCNN_FINISH_LIGHT") ? atoi(getenv("ZKCNN_FINISH_LIGHT")) : 1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_finish_light), &light, sizeof(int)) != hipSuccess) {
+            g_create_err = "finish switch";
+            zk_ctx_destroy(ctx);
+            return ZK_ERR_HIP;
+        }
+    }
     *out = ctx;
     return ZK_OK;
 }
