@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="vgg11", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=4, help="proofs in flight per GPU (one session, host thread and HIP stream each)")
+    ap.add_argument("--streams", type=int, default=8, help="proofs in flight per GPU (one session, host thread and HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="vgg11_quarter", choices=sorted(WORKLOADS))
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel-class table of one extra proof to stderr")
