@@ -417,7 +417,6 @@ __device__ __forceinline__ void grid_finish(fr_t (&acc)[K], fr_t *partials, uint
             if (threadIdx.x == 0) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) fr_store_scoped(&slot->v[k], acc[k], true);
-                if (wrote_slot) __threadfence_system();
                 ZK_WAIT_STORES();
                 __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -426,7 +425,6 @@ __device__ __forceinline__ void grid_finish(fr_t (&acc)[K], fr_t *partials, uint
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int k = 0; k < K; ++k) fr_store_scoped(partials + (size_t) K * blockIdx.x + k, acc[k], false);
-            if (wrote_slot) __threadfence_system();
             ZK_WAIT_STORES();
             const uint32_t t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = (t == gridDim.x - 1);
@@ -519,8 +517,14 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad2(round2_args a) {
                 fr_store(Vout, v);
                 fr_store(Mout, m);
             }
-            fr_store(&a.slot->v[4 + 2 * b], v);
-            fr_store(&a.slot->v[5 + 2 * b], m);
+            if (g_finish_light) {
+                fr_store_scoped(&a.slot->v[4 + 2 * b], v, true);
+                fr_store_scoped(&a.slot->v[5 + 2 * b], m, true);
+                ZK_WAIT_STORES();
+            } else {
+                fr_store(&a.slot->v[4 + 2 * b], v);
+                fr_store(&a.slot->v[5 + 2 * b], m);
+            }
         }
     } else {
         const uint64_t tid = lb * (uint64_t) ZK_BLOCK + threadIdx.x, stride = (uint64_t) nblk * ZK_BLOCK;
@@ -585,7 +589,10 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad_fine(round2_args a) {
                 v = fr_lerp(v, fr_load(src + 1), a.r);
                 fr_store(role == 0 ? a.Vout[b] : a.Mout[b], v);
             }
-            fr_store(&a.slot->v[4 + 2 * b + (role >> 1)], v);
+            if (g_finish_light) {
+                fr_store_scoped(&a.slot->v[4 + 2 * b + (role >> 1)], v, true);
+                ZK_WAIT_STORES();
+            } else fr_store(&a.slot->v[4 + 2 * b + (role >> 1)], v);
         }
     } else if (a.first) {
         if (live && role < 3) {
@@ -648,11 +655,17 @@ __global__ void k_eval_pairs(eval_args a) {
         const fr_t *p = a.p[threadIdx.x];
         fr_t v = fr_load(p);
         if (a.n[threadIdx.x] == 2) v = fr_lerp(v, fr_load(p + 1), a.r);
-        fr_store(&a.slot->v[threadIdx.x], v);
+        if (g_finish_light) {
+            fr_store_scoped(&a.slot->v[threadIdx.x], v, true);
+            ZK_WAIT_STORES();
+        } else fr_store(&a.slot->v[threadIdx.x], v);
     }
-    __threadfence_system();
+    if (!g_finish_light) __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) *((volatile unsigned long long *) &a.slot->seq) = a.seq;
+    if (threadIdx.x == 0) {
+        if (g_finish_light) __hip_atomic_store(&a.slot->seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else *((volatile unsigned long long *) &a.slot->seq) = a.seq;
+    }
 }
 
 // plain fold (tables shorter than one quad, the periodic table of the cubic rounds, Vres)
