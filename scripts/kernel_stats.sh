@@ -7,7 +7,7 @@ TAG=${1:-prof}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for S in 1 4; do
+for S in 1 8; do
   D=$OUT/${TAG}_s$S
   rm -rf $D
   rocprofv3 --kernel-trace --stats -d $D -o trace -- python $ROOT/bench.py --steps 5 --warmup 2 --streams $S --no-cpu-baseline > $OUT/${TAG}_s$S.log 2>&1 || true
