@@ -29,6 +29,7 @@ print("single-stream prover ms:", [round(x[1], 1) for x in ref])
 for k in ks:
     out = [None] * k
     def work(i, steps):
+        time.sleep(i * float(os.environ.get("STAGGER_MS", "0")) * 1e-3)
         for _ in range(steps):
             out[i] = sessions[i].prove(seed=8, mode=mode)
     steps = 6
