@@ -47,23 +47,34 @@ struct eq_args {
 
 // one block per (point, half): lo[p] = init_p * eq(r_p[0..fh), .),  hi[p] = eq(r_p[fh..fh+sh), .)
 // lo tables are `lo_stride` apart, hi tables `hi_stride` apart. The four doubling chains are independent.
+// The table of `steps` variables is the outer product of two quarter tables (variables [0, qa) and [qa, steps)) that the two halves
+// of the block build side by side in LDS by doubling: the dependent chain is ceil(steps / 2) + 1 products instead of `steps`.
 __global__ void __launch_bounds__(1024) k_eq_halves(fr_t *lo, fr_t *hi, uint32_t lo_stride, uint32_t hi_stride, eq_args a) {
+    __shared__ fr_t q[2][256];
     const int p = blockIdx.x >> 1, is_hi = blockIdx.x & 1;
     fr_t *T = is_hi ? hi + (size_t) p * hi_stride : lo + (size_t) p * lo_stride;
     const int steps = is_hi ? a.sh : a.fh, base = is_hi ? a.fh : 0;
-    if (threadIdx.x == 0) fr_store(T, is_hi ? fr_one() : a.init[p]);
+    const int qa = (steps + 1) >> 1, qb = steps - qa;              // qa <= 8 for the 2^15-entry tables this kernel is sized for
+    const int side = threadIdx.x >> 9, t = threadIdx.x & 511;      // threads 0..511 build quarter 0, 512..1023 quarter 1
+    const int nq = side ? qb : qa, qbase = base + (side ? qa : 0);
+    if (t == 0) q[side][0] = side ? fr_one() : (is_hi ? fr_one() : a.init[p]);
     __syncthreads();
-    for (int i = 0; i < steps; ++i) {
+    for (int i = 0; i < qa; ++i) {                                 // qa >= qb: both sides run qa barrier steps
         const uint32_t half = 1u << i;
-        const fr_t ri = a.r[p].v[base + i];
-        for (uint32_t j = threadIdx.x; j < half; j += blockDim.x) {
-            fr_t cur = fr_load(T + j);
-            fr_t t = fr_mul(cur, ri);
-            fr_store(T + (j | half), t);
-            fr_store(T + j, fr_sub(cur, t));
+        if (i < nq && (uint32_t) t < half) {
+            const fr_t cur = q[side][t];
+            const fr_t x = fr_mul(cur, a.r[p].v[qbase + i]);
+            q[side][t | half] = x;
+            q[side][t] = fr_sub(cur, x);
         }
         __syncthreads();
     }
+    const uint32_t n = 1u << steps, ma = (1u << qa) - 1;
+    if (qb == 0) {
+        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) fr_store(T + j, q[0][j]);
+        return;
+    }
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) fr_store(T + j, fr_mul(q[0][j & ma], q[1][j >> qa]));
 }
 
 // out[i] = sum_p lo_p[i & mask] * hi_p[i >> fh]; entries >= tail_start are additionally scaled
