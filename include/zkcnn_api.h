@@ -62,6 +62,13 @@ int32_t zkcnn_session_prove(void *session, uint64_t challenge_seed, uint32_t mod
  * ones the proof was made with. out->accepted = 1 / 0, out->message = the reason for a rejection. */
 int32_t zkcnn_session_verify(void *session, uint64_t challenge_seed, uint32_t mode, const uint8_t *proof, uint64_t len,
                              zkcnn_result *out);
+/* The statement of a session's circuit besides the model descriptor: the quantisation scales (bits kept per layer) the circuit's
+ * shape depends on. Returns their number (also when it exceeds `cap`; at most `cap` are written). */
+int64_t zkcnn_session_statement(void *session, int32_t *scales, uint64_t cap);
+/* A verifier-only session: the circuit rebuilt from the model descriptor (data_seed ignored) and a statement, without picture,
+ * weights or witness; zkcnn_session_verify works on it, zkcnn_session_prove fails. Returns NULL on error (also on a statement
+ * that does not fit the model). */
+void *zkcnn_verifier_create(const zkcnn_model_desc *desc, const int32_t *scales, uint64_t n_scales, int32_t device);
 void zkcnn_session_destroy(void *session);
 /* The reference CLI's 16-column result row of the last prove call ("a, b, c, ..."), NUL terminated. */
 int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap);

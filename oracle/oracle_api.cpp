@@ -22,6 +22,18 @@ int32_t oracle_session_prove(void *session, uint64_t seed, uint32_t mode, uint8_
                              zkcnn_result *out) {
     return ((oracleSession *) session)->prove(seed, mode, transcript, cap, out);
 }
+int64_t oracle_session_statement(void *session, int32_t *scales, uint64_t cap) {
+    const vector<int> &v = ((oracleSession *) session)->statementScales();
+    for (size_t i = 0; i < v.size() && i < cap; ++i) scales[i] = v[i];
+    return (int64_t) v.size();
+}
+void *oracle_verifier_create(const zkcnn_model_desc *desc, const int32_t *scales, uint64_t n_scales, int32_t) {
+    oracleSession *s = new oracleSession();
+    try {
+        if (!s->buildStatement(desc, scales, n_scales)) { delete s; return nullptr; }
+    } catch (const std::exception &) { delete s; return nullptr; }
+    return s;
+}
 int32_t oracle_session_verify(void *session, uint64_t seed, uint32_t mode, const uint8_t *proof, uint64_t len, zkcnn_result *out) {
     return ((oracleSession *) session)->verifyProof(proof, len, seed, mode, out);
 }

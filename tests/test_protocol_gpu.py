@@ -121,3 +121,23 @@ def test_gpu_matches_golden_transcripts(built, key):
         bad = bytearray(ftr)
         bad[len(bad) // 3] ^= 4
         assert s.verify(bytes(bad), mode=zkcnn_amd.MODE_FIAT_SHAMIR).accepted == 0
+
+
+def test_standalone_gpu_verifier_from_proof_file(built):
+    """a proof file made by one session verifies in a verifier-only session built from the file alone (circuit from model descriptor +
+    statement, wiring predicates on the GPU, no witness anywhere); LeNet5 and a proof made by the CPU oracle as well"""
+    from zkcnn_amd import proof_io
+    for model, pic, pp in (("lenet", (32, 32, 1), 1), ("custom:C2:3:0:f C3:3:1:f M C2:3:1:s A F5 F3", (10, 10, 2), 2)):
+        with zkcnn_amd.Session(model, pic, pp) as s:
+            _, tr = s.prove(seed=0, mode=zkcnn_amd.MODE_FIAT_SHAMIR)
+            blob = proof_io.dumps_from(s, tr, 0, zkcnn_amd.MODE_FIAT_SHAMIR)
+            stmt = s.statement()
+        res = proof_io.verify_standalone(blob, zkcnn_amd.Session)
+        assert res.accepted == 1, res.message.decode()
+        with oracle_ffi.OracleSession(model, pic, pp) as o:
+            assert o.statement() == stmt
+            _, otr = o.prove(seed=3)
+            oblob = proof_io.dumps_from(o, otr, 3, 0)
+        assert proof_io.verify_standalone(oblob, zkcnn_amd.Session).accepted == 1
+        damaged = proof_io.dumps(tr[:200] + bytes([tr[200] ^ 2]) + tr[201:], model, pic, pp, 20260928, 0, zkcnn_amd.MODE_FIAT_SHAMIR, stmt)
+        assert proof_io.verify_standalone(damaged, zkcnn_amd.Session).accepted == 0

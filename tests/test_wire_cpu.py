@@ -105,3 +105,35 @@ def test_proof_file_round_trip(oracle, tmp_path):
             blob[len(blob) // 2] ^= 0x40
             with pytest.raises(ValueError):
                 proof_io.loads(bytes(blob))
+
+
+@pytest.mark.parametrize("model", [MODEL, ("custom:C2:3:0:f C3:3:1:f M C2:3:1:s A F5 F3", (10, 10, 2), 2), ("custom:C2:3:1:n A F4", (4, 4, 2), 1)])
+def test_standalone_verifier_needs_only_the_proof_file(oracle, model):
+    """the circuit is rebuilt from the model descriptor + the recorded quantisation scales (no picture, weights or witness) and the
+    proof file verifies against it; a verifier-only session cannot prove; a wrong statement does not verify"""
+    with oracle_ffi.OracleSession(*model) as o:
+        stmt = o.statement()
+        assert len(stmt) >= 2
+        _, tr = o.prove(seed=5, mode=FS)
+        blob = proof_io.dumps_from(o, tr, 5, FS)
+        _, tr2 = o.prove(seed=6)
+        blob2 = proof_io.dumps_from(o, tr2, 6, 0)
+    assert proof_io.verify_standalone(blob, oracle_ffi.OracleSession).accepted == 1
+    assert proof_io.verify_standalone(blob2, oracle_ffi.OracleSession).accepted == 1
+    with oracle_ffi.OracleSession(*model, statement=stmt) as v:
+        assert v.statement() == stmt
+        with pytest.raises(RuntimeError):
+            v.prove(seed=1)
+        bad = bytearray(tr)
+        bad[100] ^= 1
+        assert v.verify(bytes(bad), mode=FS).accepted == 0
+    # a statement with another scale: the circuit (shift constants of the re-quantisation gates) differs, the proof does not fit;
+    # a statement of the wrong length is refused outright
+    wrong = list(stmt)
+    wrong[0] += 1                       # the picture's scale: one more bit is cut by the first re-quantisation, its layers grow
+    with oracle_ffi.OracleSession(*model, statement=wrong) as v2:
+        assert v2.verify(tr, mode=FS).accepted == 0
+    with pytest.raises(RuntimeError):
+        oracle_ffi.OracleSession(*model, statement=stmt[:-1])
+    with pytest.raises(RuntimeError):
+        oracle_ffi.OracleSession(*model, statement=stmt + [3])

@@ -226,13 +226,30 @@ class _SessionBase:
     def _fn(self, name):
         return getattr(self.lib, self._prefix + name)
 
-    def __init__(self, lib, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0):
+    def __init__(self, lib, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0, statement=None):
+        """statement=None: circuit + witness from the (synthetic) data. statement=[ints]: a verifier-only session whose circuit is
+        rebuilt from the model descriptor and the quantisation scales of a prover's session (no witness; prove() fails)."""
         self.lib = lib
-        self._fn("session_create").restype = ctypes.c_void_p
+        self.model, self.pic, self.pic_cnt, self.data_seed = model, tuple(pic), pic_cnt, data_seed
         self.desc = ModelDesc(model.encode(), pic[0], pic[1], pic[2], pic_cnt, data_seed)
-        self.h = self._fn("session_create")(ctypes.byref(self.desc), ctypes.c_int32(device))
+        if statement is None:
+            self._fn("session_create").restype = ctypes.c_void_p
+            self.h = self._fn("session_create")(ctypes.byref(self.desc), ctypes.c_int32(device))
+        else:
+            arr = (ctypes.c_int32 * max(len(statement), 1))(*statement)
+            self._fn("verifier_create").restype = ctypes.c_void_p
+            self.h = self._fn("verifier_create")(ctypes.byref(self.desc), arr, ctypes.c_uint64(len(statement)), ctypes.c_int32(device))
         if not self.h:
             raise RuntimeError(f"{self._prefix}session_create({model}) failed")
+
+    def statement(self):
+        """quantisation scales the circuit's shape depends on (together with the model descriptor: the public statement)"""
+        fn = self._fn("session_statement")
+        fn.restype = ctypes.c_int64
+        n = fn(ctypes.c_void_p(self.h), None, ctypes.c_uint64(0))
+        arr = (ctypes.c_int32 * max(n, 1))()
+        fn(ctypes.c_void_p(self.h), arr, ctypes.c_uint64(n))
+        return [int(x) for x in arr[:n]]
 
     def prove(self, seed=0x5EED0001, mode=MODE_VERIFY, want_transcript=True):
         cap = 0
@@ -287,8 +304,8 @@ class Session(_SessionBase):
     """Circuit + witness resident on one GPU; prove() runs verifier <-> HIP prover (include/zkcnn_api.h)."""
     _prefix = "zkcnn_"
 
-    def __init__(self, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0):
-        super().__init__(host_lib(), model, pic, pic_cnt, data_seed, device)
+    def __init__(self, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0, statement=None):
+        super().__init__(host_lib(), model, pic, pic_cnt, data_seed, device, statement)
 
     def profile(self, classes="all"):
         """HIP-event timing of the selected kernel classes (list of names, "all", or None to switch off)"""

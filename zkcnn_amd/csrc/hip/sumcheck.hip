@@ -315,7 +315,7 @@ extern "C" int32_t zk_upload_layer_values(zk_ctx *ctx, int32_t layer, const uint
     dev_layer &D = ctx->L[layer];
     if (n > D.val_len) { ctx->err = "more values than the layer holds"; return ZK_ERR_ARG; }
     ZK_HIP(hipSetDevice(ctx->device));
-    ZK_HIP(hipMemcpyAsync(D.val, values, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (n) ZK_HIP(hipMemcpyAsync(D.val, values, n * 32, hipMemcpyHostToDevice, ctx->stream));
     if (n < D.val_len) ZK_HIP(hipMemsetAsync(D.val + n, 0, (D.val_len - n) * 32, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     return ZK_OK;

@@ -115,6 +115,28 @@ int32_t zkcnn_session_prove(void *session, uint64_t seed, uint32_t mode, uint8_t
     }
 }
 
+int64_t zkcnn_session_statement(void *session, int32_t *scales, uint64_t cap) {
+    if (!session) return -1;
+    const vector<int> &v = ((gpuSession *) session)->statementScales();
+    for (size_t i = 0; i < v.size() && i < cap; ++i) scales[i] = v[i];
+    return (int64_t) v.size();
+}
+
+void *zkcnn_verifier_create(const zkcnn_model_desc *desc, const int32_t *scales, uint64_t n_scales, int32_t device) {
+    if (!desc || (!scales && n_scales)) return nullptr;
+    try {
+        gpuSession *s = new gpuSession(device);
+        s->p.~prover();
+        new (&s->p) prover(device);
+        if (!s->buildStatement(desc, scales, n_scales)) { delete s; return nullptr; }
+        s->p.init();                 // the circuit goes to the GPU for the wiring predicates; there are no values to upload
+        return s;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkcnn_verifier_create: %s\n", e.what());
+        return nullptr;
+    }
+}
+
 int32_t zkcnn_session_verify(void *session, uint64_t seed, uint32_t mode, const uint8_t *proof, uint64_t len, zkcnn_result *out) {
     if (!session || !out || !proof) return -1;
     try {

@@ -128,7 +128,9 @@ void neuralNetwork::planLayout() {
 // driver
 // ---------------------------------------------------------------------------------------------
 void neuralNetwork::build(layeredCircuit &C, vector<vector<F>> &val, bool only_compute) {
-    assert(src && "no data source: pass an input file or call useSyntheticData()");
+    assert((src || structure_only) && "no data source: pass an input file or call useSyntheticData()");
+    if (!structure_only) scale_log.clear();
+    scale_pos = 0;
     assert(pool.size() + 1 >= conv_section.size());
     planLayout();
     assert(SIZE > 0 && SIZE < 256);
@@ -213,6 +215,7 @@ void neuralNetwork::loadPicture(layer &L) {
     auto &v0 = (*vals)[0];
     v0.assign(L.size, F_ZERO);
     touch0(0);
+    if (structure_only) { x_next_bit = logged(0); return; }
     const i64 n = pic_channel * pic_size_x * pic_size_y;
     vector<double> dat(n);
     double mx = -10000, mn = 10000;
@@ -221,13 +224,14 @@ void neuralNetwork::loadPicture(layer &L) {
         mx = std::max(mx, dat[i]);
         mn = std::min(mn, dat[i]);
     }
-    x_next_bit = quantBits(mx, mn);
+    x_next_bit = logged(quantBits(mx, mn));
     i64 pos = 0;
     for (i64 p = 0; p < pic_parallel; ++p)          // the single picture is replicated pic_parallel times
         for (i64 i = 0; i < n; ++i) v0[pos++] = F((i64) (dat[i] * std::exp2(x_next_bit)));
 }
 
 void neuralNetwork::loadConvWeight(i64 first_id) {
+    if (structure_only) { w_bit = logged(0); return; }
     const i64 n = channel_out * channel_in * m * m;
     vector<double> dat(n);
     double mx = -10000, mn = 10000;
@@ -236,13 +240,14 @@ void neuralNetwork::loadConvWeight(i64 first_id) {
         mx = std::max(mx, dat[i]);
         mn = std::min(mn, dat[i]);
     }
-    w_bit = quantBits(mx, mn);
+    w_bit = logged(quantBits(mx, mn));
     auto &v0 = (*vals)[0];
     touch0(first_id);
     for (i64 i = 0; i < n; ++i) v0[first_id + i] = F((i64) (dat[i] * std::exp2(w_bit)));
 }
 
 void neuralNetwork::loadFcWeight(i64 first_id) {
+    if (structure_only) { w_bit = logged(0); return; }
     const i64 n = channel_out * channel_in;
     vector<double> dat(n);
     double mx = -10000, mn = 10000;
@@ -251,13 +256,14 @@ void neuralNetwork::loadFcWeight(i64 first_id) {
         mx = std::max(mx, dat[i]);
         mn = std::min(mn, dat[i]);
     }
-    w_bit = quantBits(mx, mn);
+    w_bit = logged(quantBits(mx, mn));
     auto &v0 = (*vals)[0];
     touch0(first_id);
     for (i64 i = 0; i < n; ++i) v0[first_id + i] = F((i64) (dat[i] * std::exp2(w_bit)));
 }
 
 void neuralNetwork::loadBias(i64 first_id) {
+    if (structure_only) return;
     auto &v0 = (*vals)[0];
     touch0(first_id);
     for (i64 co = 0; co < channel_out; ++co) {
@@ -267,20 +273,24 @@ void neuralNetwork::loadBias(i64 first_id) {
 }
 
 void neuralNetwork::putBit(i64 layer_id, i64 idx, i64 dst, i64 shift) {
+    if (structure_only) return;
     i64 mag = std::llabs((*vals)[layer_id].at(idx).getInt64());
     touch0(dst);
     (*vals)[0].at(dst) = F((i64) ((mag >> shift) & 1));
 }
 void neuralNetwork::putFieldBit(const F &data, i64 dst, i64 shift) {
+    if (structure_only) return;
     i64 mag = std::llabs(data.getInt64());
     touch0(dst);
     (*vals)[0].at(dst) = F((i64) ((mag >> shift) & 1));
 }
 void neuralNetwork::putSign(i64 layer_id, i64 idx, i64 dst) {
+    if (structure_only) return;
     touch0(dst);
     (*vals)[0].at(dst) = (*vals)[layer_id].at(idx).isNegative() ? F_ONE : F_ZERO;
 }
 void neuralNetwork::putMax(i64 layer_id, i64 idx, i64 dst) {
+    if (structure_only) return;
     const F &x = (*vals)[layer_id].at(idx);
     F clamped = x.isNegative() ? F_ZERO : x;
     touch0(dst);
@@ -289,6 +299,7 @@ void neuralNetwork::putMax(i64 layer_id, i64 idx, i64 dst) {
 
 // value of every gate of a generic layer (reference src/neuralNetwork.cpp:918-935)
 void neuralNetwork::evalGates(const layer &L, i64 layer_id) {
+    if (structure_only) return;
     auto &val = *vals;
     auto &out = val[layer_id];
     out.assign(L.size, F_ZERO);
@@ -318,6 +329,7 @@ void neuralNetwork::evalGates(const layer &L, i64 layer_id) {
 
 // per-frequency channel contraction (reference src/neuralNetwork.cpp:937-948)
 void neuralNetwork::evalDotProd(const layer &L, i64 layer_id) {
+    if (structure_only) return;
     auto &val = *vals;
     auto &out = val[layer_id];
     out.assign(L.size, F_ZERO);
@@ -336,6 +348,7 @@ void neuralNetwork::evalDotProd(const layer &L, i64 layer_id) {
 // FFT layer: each half-length block is zero-padded and transformed; IFFT layer: inverse transform
 // and keep the first half (reference src/neuralNetwork.cpp:950-965)
 void neuralNetwork::evalTransform(const layer &L, i64 layer_id) {
+    if (structure_only) return;
     auto &val = *vals;
     const size_t len = (size_t) 1 << L.fft_bit_length, lenh = len >> 1;
     auto &out = val[layer_id];
@@ -366,6 +379,7 @@ void neuralNetwork::evalTransform(const layer &L, i64 layer_id) {
 // scale (in bits) of the next activation so that its range fits Q-1 bits
 // (reference src/neuralNetwork.cpp:967-977)
 int neuralNetwork::nextScaleBits(i64 layer_id) {
+    if (structure_only) return logged(0);
     F mx = F_ZERO, mn = F_ZERO;
     for (const F &x : (*vals)[layer_id]) {
         if (!x.isNegative()) { if (x > mx) mx = x; }
@@ -373,7 +387,7 @@ int neuralNetwork::nextScaleBits(i64 layer_id) {
     }
     i64 range = (mx + mn).getInt64();
     double real_scale = range / std::exp2(x_bit + w_bit);
-    return (int) std::log2(((1 << (Q - 1)) - 1) / real_scale);
+    return logged((int) std::log2(((1 << (Q - 1)) - 1) / real_scale));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -606,7 +620,7 @@ void neuralNetwork::emitAvgPool(layer &L, i64 &layer_id) {
                         for (i64 ty = y; ty < y + pool_sz; ++ty) {
                             i64 u = tesIdx(p, co, tx, ty, channel_out, nx_out, ny_out);
                             L.uni_gates.emplace_back((u32) g, (u32) u, (u8) (layer_id - 1), (u8) 0);
-                            sum = sum + val[layer_id - 1][u];
+                            if (!structure_only) sum = sum + val[layer_id - 1][u];
                         }
                     // subtract the remainder bits so that the division by pool_sz^2 is exact
                     for (i64 k = 0; k < dbl; ++k) {
@@ -753,7 +767,7 @@ void neuralNetwork::emitFC(layer &L, i64 &layer_id, i64 first_fc_id, i64 first_b
 // arg-max class per picture over the non-negative logits (reference src/neuralNetwork.cpp:994-1016)
 void neuralNetwork::reportInference(const layeredCircuit &C) {
     infer_result.clear();
-    if (!full_conn.empty()) {
+    if (!full_conn.empty() && !structure_only) {
         const int n_class = (int) full_conn.back().channel_out;
         const auto &outv = (*vals)[SIZE - 1];
         for (int p = 0; p < pic_parallel; ++p) {

@@ -4,6 +4,7 @@
 // data files are absent (data.tar.gz is a missing blob), so next to the file reader there is a
 // seeded synthetic source that produces the same value counts in the same order.
 #pragma once
+#include <stdexcept>
 #include <memory>
 #include "circuit.h"
 #include "utils.hpp"
@@ -69,6 +70,13 @@ public:
     void useSyntheticData(u64 seed);
     void setWitnessAccel(witnessAccel *a) { accel = a; }
 
+    // The circuit's shape depends on the data only through the quantisation scales (bits kept per layer): a build records them,
+    // and a build in structure-only mode replays them to produce the SAME circuit without picture, weights or witness --
+    // what a verifier that has nothing but the proof needs (host/replay.hpp, zkcnn_verifier_create).
+    const vector<int> &scales() const { return scale_log; }
+    bool scalesConsumed() const { return scale_pos == scale_log.size(); }
+    void setStructureOnly(const vector<int> &recorded) { structure_only = true; scale_log = recorded; scale_pos = 0; }
+
     // Fills pr.C (circuit) and pr.val (value of every gate). Works for any prover type exposing those two.
     template <class P>
     void create(P &pr, bool only_compute) { build(pr.C, pr.val, only_compute); }
@@ -104,6 +112,14 @@ private:
     i64 total_in_size, total_para_size, total_relu_in_size, total_ave_in_size, total_max_in_size;
     int x_bit, w_bit, x_next_bit;
 
+    bool structure_only = false;
+    vector<int> scale_log;
+    size_t scale_pos = 0;
+    int logged(int computed) {       // record in a normal build, replay in a structure-only build
+        if (!structure_only) { scale_log.push_back(computed); return computed; }
+        if (scale_pos >= scale_log.size()) throw std::runtime_error("statement: too few quantisation scales");
+        return scale_log[scale_pos++];
+    }
     vector<vector<F>> *vals;       // == &pr.val while building
     i64 in_dirty_lo = 0;           // layer-0 entries from here on are newer than the accelerator's copy
     size_t n_two_mul = 0;

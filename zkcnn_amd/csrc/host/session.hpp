@@ -24,6 +24,23 @@ struct sessionT {
         return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     }
 
+    bool has_witness = true;           // false: a verifier-only session (circuit rebuilt from a statement, nothing to prove)
+
+    // statement = the quantisation scales recorded while the circuit was built; with them, buildStatement() reproduces the circuit
+    // from the model descriptor alone (no picture, weights or witness)
+    const vector<int> &statementScales() const { return nn->scales(); }
+    bool buildStatement(const zkcnn_model_desc *d, const int32_t *scales, uint64_t n) {
+        model_name = d->model ? d->model : "";
+        pic_cnt = d->pic_cnt;
+        nn.reset(makeModel(model_name, d->pic_x, d->pic_y, d->pic_channel, d->pic_cnt));
+        if (!nn) return false;
+        nn->setStructureOnly(vector<int>(scales, scales + n));
+        nn->create(p, false);
+        if (!nn->scalesConsumed()) return false;           // a statement with more scales than the model asks for is malformed
+        has_witness = false;
+        return true;
+    }
+
     bool build(const zkcnn_model_desc *d) {
         model_name = d->model ? d->model : "";
         pic_cnt = d->pic_cnt;
@@ -68,6 +85,10 @@ struct sessionT {
 
     int prove(uint64_t challenge_seed, uint32_t mode, uint8_t *transcript, uint64_t cap, zkcnn_result *out) {
         std::memset(out, 0, sizeof(*out));
+        if (!has_witness) {
+            std::snprintf(out->message, sizeof(out->message), "verifier-only session: nothing to prove");
+            return -3;
+        }
         double t0 = now();
         const bool drive = mode & ZKCNN_MODE_DRIVE_ONLY;
         output_tb.assign(OUT_COLUMN_CNT, "");

@@ -11,9 +11,9 @@ import struct
 MAGIC = b"ZKCNNPF1"
 
 
-def dumps(transcript, model, pic, pic_cnt, data_seed, challenge_seed, mode):
+def dumps(transcript, model, pic, pic_cnt, data_seed, challenge_seed, mode, statement=None):
     from . import MODE_FIAT_SHAMIR, MODE_REUSE_GENS
-    header = {"model": model, "pic": list(pic), "pic_cnt": pic_cnt, "data_seed": data_seed,
+    header = {"model": model, "pic": list(pic), "pic_cnt": pic_cnt, "data_seed": data_seed, "statement": statement,
               "challenges": "fiat-shamir/sha256" if mode & MODE_FIAT_SHAMIR else "seeded-stream",
               "challenge_seed": None if mode & MODE_FIAT_SHAMIR else challenge_seed,
               "session_generators": bool(mode & MODE_REUSE_GENS), "mode": mode & (MODE_FIAT_SHAMIR | MODE_REUSE_GENS)}
@@ -45,6 +45,21 @@ def save(path, *args, **kw):
 def load(path):
     with open(path, "rb") as f:
         return loads(f.read())
+
+
+def dumps_from(session, transcript, challenge_seed, mode):
+    """proof file of a proof made by `session`, carrying the statement a stand-alone verifier needs"""
+    return dumps(transcript, session.model, session.pic, session.pic_cnt, session.data_seed, challenge_seed, mode, session.statement())
+
+
+def verify_standalone(blob, session_cls, **kw):
+    """verifies a proof file with nothing but the file: the circuit is rebuilt from the header's model descriptor + statement
+    (session_cls: zkcnn_amd.Session for GPU predicates, or the oracle's session class in tests). Returns the Result."""
+    header, tr = loads(blob)
+    if header.get("statement") is None:
+        raise ValueError("proof file carries no statement")
+    with session_cls(header["model"], tuple(header["pic"]), header["pic_cnt"], statement=header["statement"], **kw) as v:
+        return v.verify(tr, seed=header["challenge_seed"] or 0, mode=header["mode"])
 
 
 def verify_with(session, blob):
