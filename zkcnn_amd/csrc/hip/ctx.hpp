@@ -20,7 +20,8 @@ struct dev_layer {
     uint64_t val_len = 0;
     // phase-1 lists: gates whose u operand lives in table b (0: layer-0 subset, 1: previous layer), sorted by u
     gate_rec *p1[2] = {nullptr, nullptr};
-    uint64_t n_p1[2] = {0, 0};
+    uint64_t n_p1[2] = {0, 0};      // records incl. padding (runs of equal keys padded to multiples of GATE_GROUP)
+    uint64_t n_p1_real[2] = {0, 0}, n_p2_real[2] = {0, 0};
     uint64_t n_p1_uni[2] = {0, 0};  // how many of them are uni gates (for the algorithmic byte count)
     // phase-2 lists: bin gates whose v operand lives in table b, sorted by v
     gate_rec *p2[2] = {nullptr, nullptr};

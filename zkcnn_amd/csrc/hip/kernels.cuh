@@ -138,6 +138,7 @@ struct gate_args {
 };
 
 __device__ __forceinline__ fr_t gate_term(const gate_rec &rc, const gate_args &a) {
+    if (GATE_DUMMY(rc.meta)) return fr_zero();
     fr_t t = fr_load(a.beta_g + rc.g);
     if (a.phase == 1) {
         if (GATE_HAS_VAL(rc.meta)) t = fr_mul(t, fr_load((GATE_IN_PREV(rc.meta) ? a.val_prev : a.val0) + rc.aux));
@@ -193,15 +194,21 @@ __device__ __forceinline__ void gate_segment_store(uint32_t key, fr_t val, bool 
     }
 }
 
+// GATE_GROUP consecutive records per thread: the upload pads every run of equal keys to a multiple of GATE_GROUP, so the records
+// of one thread always share their key and are summed before the (comparatively expensive) cross-lane scan. a.n counts groups.
 __global__ void __launch_bounds__(ZK_BLOCK) k_gate_reduce(fr_t *out, uint32_t *carry_key, fr_t *carry_val, gate_args a) {
     const uint64_t idx = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x;
     const bool live = idx < a.n;
     uint32_t key = GATE_NOKEY;
     fr_t val = fr_zero();
     if (live) {
-        gate_rec rc = a.recs[idx];
-        key = rc.key;
-        val = gate_term(rc, a);
+        const gate_rec *rp = a.recs + idx * GATE_GROUP;
+        key = rp[0].key;
+#pragma unroll
+        for (uint32_t k = 0; k < GATE_GROUP; ++k) {
+            const gate_rec rc = rp[k];
+            val = fr_add(val, gate_term(rc, a));
+        }
     }
     gate_segment_store(key, val, live, idx, a.n, out, carry_key, carry_val, a.post_scale != 0, a.post);
 }
@@ -300,6 +307,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_pred_bin(fr_t *partials, const gat
     fr_t acc[2] = {fr_zero(), fr_zero()};
     for (uint64_t i = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x; i < n; i += (uint64_t) gridDim.x * ZK_BLOCK) {
         const gate_rec rc = recs[i];                                   // key = v, aux = u
+        if (GATE_DUMMY(rc.meta)) continue;
         fr_t t = fr_mul(fr_mul(fr_load(bg + rc.g), fr_load(bu + rc.aux)), fr_load(bv + rc.key));
         const uint32_t sc = GATE_SC(rc.meta);
         if (use_tm && sc) t = fr_mul(t, fr_load(two_mul + sc));

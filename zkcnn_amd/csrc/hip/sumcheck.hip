@@ -160,6 +160,23 @@ static uint32_t covered_prefix(const std::vector<gate_rec> &recs) {
     }
     return k;
 }
+// pads every run of equal keys (list sorted by key) to a multiple of GATE_GROUP records with padding records of the same key
+static void pad_runs(std::vector<gate_rec> &recs) {
+    std::vector<gate_rec> out;
+    out.reserve(recs.size() + recs.size() / 8 + GATE_GROUP);
+    size_t i = 0;
+    while (i < recs.size()) {
+        size_t j = i;
+        while (j < recs.size() && recs[j].key == recs[i].key) ++j;
+        out.insert(out.end(), recs.begin() + i, recs.begin() + j);
+        for (size_t k = j - i; k % GATE_GROUP; ++k) {
+            gate_rec d = {0, recs[i].key, 0, 1u << 11};
+            out.push_back(d);
+        }
+        i = j;
+    }
+    recs.swap(out);
+}
 static void counting_sort(std::vector<gate_rec> &recs, uint32_t nkeys) {
     std::vector<uint32_t> cnt((size_t) nkeys + 1, 0);
     for (const gate_rec &r : recs) ++cnt[r.key + 1];
@@ -225,7 +242,6 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
             if (q[b].empty()) continue;
             if (S.bit_length_v[b] < 0) { ctx->err = "bin gate refers to an absent v table"; return ZK_ERR_ARG; }
             counting_sort(q[b], 1u << S.bit_length_v[b]);
-            D.n_p2[b] = q[b].size();
             D.p2_cov[b] = covered_prefix(q[b]);
             {
                 const uint32_t f0 = GATE_IN_PREV(q[b][0].meta);
@@ -233,6 +249,9 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
                 for (const gate_rec &r : q[b]) if (GATE_IN_PREV(r.meta) != f0) { same = false; break; }
                 D.p2_uniform[b] = same ? (int) f0 : -1;
             }
+            D.n_p2_real[b] = q[b].size();
+            pad_runs(q[b]);
+            D.n_p2[b] = q[b].size();
             max_list = std::max<uint64_t>(max_list, q[b].size());
             if ((rc = upload(ctx, &D.p2[b], q[b]))) return rc;
             std::vector<gate_rec>().swap(q[b]);
@@ -278,8 +297,10 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
             if (p[b].empty()) continue;
             if (S.bit_length_u[b] < 0) { ctx->err = "gate refers to an absent u table"; return ZK_ERR_ARG; }
             counting_sort(p[b], 1u << S.bit_length_u[b]);
-            D.n_p1[b] = p[b].size();
             D.p1_cov[b] = covered_prefix(p[b]);
+            D.n_p1_real[b] = p[b].size();
+            pad_runs(p[b]);
+            D.n_p1[b] = p[b].size();
             max_list = std::max<uint64_t>(max_list, p[b].size());
             if ((rc = upload(ctx, &D.p1[b], p[b]))) return rc;
             std::vector<gate_rec>().swap(p[b]);
@@ -400,13 +421,14 @@ static int32_t wait_slot(zk_ctx *ctx, unsigned long long seq) {
     return ZK_OK;
 }
 
-static int32_t gate_scatter(zk_ctx *ctx, fr_t *out, const gate_rec *recs, uint64_t n, int phase, const dev_layer &cur,
+// n = records in the padded list (a multiple of GATE_GROUP), n_real = gates among them
+static int32_t gate_scatter(zk_ctx *ctx, fr_t *out, const gate_rec *recs, uint64_t n, uint64_t n_real, int phase, const dev_layer &cur,
                             const dev_layer &prev, uint64_t n_uni_in_list, uint64_t out_len, int uniform_u = -1) {
     if (!n) return ZK_OK;
-    const double gate_bytes = 44.0 * (double) n_uni_in_list + 80.0 * (double) (n - n_uni_in_list) + 32.0 * (double) out_len;
+    const double gate_bytes = 44.0 * (double) n_uni_in_list + 80.0 * (double) (n_real - n_uni_in_list) + 32.0 * (double) out_len;
     gate_args A;
     A.recs = recs;
-    A.n = n;
+    A.n = n / GATE_GROUP;
     A.beta_g = ctx->beta_g[ctx->beta_g_cur];
     A.beta_u = ctx->beta_u;
     A.val0 = ctx->L[0].val;
@@ -418,7 +440,7 @@ static int32_t gate_scatter(zk_ctx *ctx, fr_t *out, const gate_rec *recs, uint64
     A.post_scale = (phase == 2 && uniform_u >= 0) ? 1 : 0;
     A.post = uniform_u == 1 ? A.Vu1 : A.Vu0;
     (void) cur;
-    const uint32_t blocks = (uint32_t) ((n + ZK_BLOCK - 1) / ZK_BLOCK);
+    const uint32_t blocks = (uint32_t) ((A.n + ZK_BLOCK - 1) / ZK_BLOCK);
     if (2ull * blocks > ctx->carry_slots) { ctx->err = "carry buffer too small"; return ZK_ERR_STATE; }
     ZK_LAUNCH(PC_GATE, gate_bytes, k_gate_reduce, dim3(blocks), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, A);
     ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup, dim3(grid_for(2ull * blocks)), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, 2ull * blocks);
@@ -635,7 +657,7 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
         if (cur.p1_cov[b] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p1_cov[b], 0, (t.len - cur.p1_cov[b]) * 32, ctx->stream));
-        if ((rc = gate_scatter(ctx, t.M[0], cur.p1[b], cur.n_p1[b], 1, cur, prev, cur.n_p1_uni[b], t.len))) return rc;
+        if ((rc = gate_scatter(ctx, t.M[0], cur.p1[b], cur.n_p1[b], cur.n_p1_real[b], 1, cur, prev, cur.n_p1_uni[b], t.len))) return rc;
     }
     return ZK_OK;
 }
@@ -753,7 +775,7 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         ZK_LAUNCH(PC_DOT, 0.0, k_row_dot, dim3((rows + 3) / 4), dim3(ZK_BLOCK), t.V[0], prev.val, ctx->beta_gs, rows, fft_bl);
         ZK_HIP(hipGetLastError());
         if (cur.p2_cov[1] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p2_cov[1], 0, (t.len - cur.p2_cov[1]) * 32, ctx->stream));
-        return gate_scatter(ctx, t.M[0], cur.p2[1], cur.n_p2[1], 2, cur, prev, 0, t.len, cur.p2_uniform[1]);
+        return gate_scatter(ctx, t.M[0], cur.p2[1], cur.n_p2[1], cur.n_p2_real[1], 2, cur, prev, 0, t.len, cur.p2_uniform[1]);
     }
 
     if ((rc = eq_table1(ctx, ctx->beta_u, d.max_bl_u, ru, HFr::one()))) return rc;
@@ -774,7 +796,7 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
         if (cur.p2_cov[b] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p2_cov[b], 0, (t.len - cur.p2_cov[b]) * 32, ctx->stream));
-        if ((rc = gate_scatter(ctx, t.M[0], cur.p2[b], cur.n_p2[b], 2, cur, prev, 0, t.len, cur.p2_uniform[b]))) return rc;
+        if ((rc = gate_scatter(ctx, t.M[0], cur.p2[b], cur.n_p2[b], cur.n_p2_real[b], 2, cur, prev, 0, t.len, cur.p2_uniform[b]))) return rc;
     }
     if (cur.n_uni2) {
         ZK_HIP(hipMemcpyAsync(ctx->h_result + 8, ctx->d_result + 8, 64, hipMemcpyDeviceToHost, ctx->stream));

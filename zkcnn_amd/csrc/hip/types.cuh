@@ -14,10 +14,12 @@ struct __align__(16) gate_rec {
     uint32_t key;      // destination table entry (sorted, non-decreasing)
     uint32_t aux;      // phase 1: resolved index of the OTHER operand's value; phase 2: u (index into beta_u)
     uint32_t meta;     // bits 0..8: two_mul index; bit 9: has value operand (bin gate, phase 1);
-                       // bit 10: operand lives in the previous layer (else layer 0)
+                       // bit 10: operand lives in the previous layer (else layer 0); bit 11: padding record
 };
 #define GATE_SC(m) ((m) & 0x1ffu)
 #define GATE_HAS_VAL(m) (((m) >> 9) & 1u)
 #define GATE_IN_PREV(m) (((m) >> 10) & 1u)
+#define GATE_DUMMY(m) (((m) >> 11) & 1u)     // padding record: contributes nothing (runs of equal keys are padded to multiples of GATE_GROUP)
+#define GATE_GROUP 4u
 #define GATE_NOKEY 0xffffffffu
 
