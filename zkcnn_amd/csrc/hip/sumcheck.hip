@@ -817,7 +817,9 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
     double alg_bytes = 0;
     // small tables are latency bound: spread each quad over 4 lanes (k_round_quad2, `fine`)
     static const int fine_log = getenv("ZKCNN_FINE_LOG") ? atoi(getenv("ZKCNN_FINE_LOG")) : 16;
-    const bool fine = std::max(ctx->tp[0].len, ctx->tp[1].len) <= (1ull << fine_log);
+    // (one block per 64 quads and 3 partial sums per block: both pairs together must stay within the partials buffer)
+    const uint64_t longest = std::max(ctx->tp[0].len, ctx->tp[1].len);
+    const bool fine = longest <= (1ull << fine_log) && 2 * (longest / 4 / (ZK_BLOCK / 4) + 1) <= ctx->partial_blocks;
     A.fine = fine ? 1 : 0;
     uint64_t fine_items = 0;
     for (int b = 0; b < 2; ++b) {
