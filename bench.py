@@ -77,6 +77,11 @@ def main():
 
     model, pic, pp = WORKLOADS[args.workload]
     K = max(1, args.streams)
+    try:                                # a session keeps ~8 GB of host memory (circuit + witness): do not overcommit a small node
+        import psutil
+        K = max(1, min(K, int(psutil.virtual_memory().available / (10e9 * max(world, 1)))))
+    except ImportError:
+        pass
     drive = zkcnn_amd.MODE_DRIVE_ONLY | zkcnn_amd.MODE_REUSE_GENS
 
     def in_threads(fn):
