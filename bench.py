@@ -128,6 +128,7 @@ def main():
     sess.prove(seed=0x5EED00FF, mode=drive, want_transcript=False)
     table = sess.profile_report(reset=True)
     dominant = max(ROOFLINE_CLASSES, key=lambda c: table[c]["ms"])
+    alg_bytes_per_proof = sum(table[c]["bytes"] for c in ROOFLINE_CLASSES)     # every class with a defined byte count, one proof
     if args.profile_all and rank == 0:
         for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
             if v["launches"]:
@@ -234,6 +235,12 @@ def main():
         except Exception as e:      # the headline numbers do not depend on this extra measurement
             roofline["streaming_launch"] = {"error": str(e)}
 
+    if roofline is not None:
+        # whole-GPU view of the multi-stream regime: algorithmic bytes of one proof (all byte-counted classes) x proofs/s of this GPU
+        per_gpu = K * args.steps / elapsed
+        roofline["whole_gpu"] = {"algorithmic_GB_per_proof": round(alg_bytes_per_proof / 1e9, 2), "achieved": round(alg_bytes_per_proof * per_gpu / 1e9, 1),
+                                 "frac": round(alg_bytes_per_proof * per_gpu / 1e9 / HBM_PEAK_GBS, 4),
+                                 "note": "gate_reduce + round_quad + round_cubic + msm algorithmic bytes of one proof times proofs/s per GPU"}
     if rank != 0:
         sess.close()
         if dist is not None:
