@@ -101,6 +101,8 @@ struct zk_ctx {
     bool circuit_ready = false;
 
     msm_state *msm = nullptr;
+    // ZKCNN_TIMING: host view of a round call: time between calls (verifier + wrappers), before / in / after the wait for the result
+    double t_seg[4] = {0, 0, 0, 0}; uint64_t n_seg = 0; double t_last_exit = 0;
 
     // verifier-side tables (zk_verifier_*): kept apart from the prover's, whose beta_g carries state from layer to layer
     fr_t *v_bg = nullptr, *v_bu = nullptr, *v_bv = nullptr, *v_gs = nullptr;

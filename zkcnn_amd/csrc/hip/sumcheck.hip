@@ -2,6 +2,7 @@
 // Each extern "C" function is the binding of one reference prover method (see include/zkcnn_hip.h);
 // the O(1)-per-round scalar bookkeeping (add_term, round counters, proof-size counter) stays in
 // host code here exactly as in the reference, everything that is O(table) or O(gates) is a kernel.
+#include <chrono>
 #include <algorithm>
 #include <cstring>
 #include "ctx.hpp"
@@ -97,6 +98,8 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->n_seg) fprintf(stderr, "[zkcnn timing] quadratic round call: %.2f us between calls (verifier + wrappers), %.2f plan + launch, %.2f waiting for the result, %.2f after (averages over %llu rounds)\n",
+                            1e6 * ctx->t_seg[0] / ctx->n_seg, 1e6 * ctx->t_seg[1] / ctx->n_seg, 1e6 * ctx->t_seg[2] / ctx->n_seg, 1e6 * ctx->t_seg[3] / ctx->n_seg, (unsigned long long) ctx->n_seg);
     zk_msm_destroy(ctx);
     for (prof_pending &p : ctx->prof_q) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
     for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
@@ -807,7 +810,11 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
 }
 
 // One quadratic round over the live table pairs. reference src/prover.cpp:368-426.
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]) {
+    static const bool seg_timing = getenv("ZKCNN_TIMING") != nullptr;
+    const double ts_enter = seg_timing ? now_s() : 0;
+    double ts_wait0 = 0, ts_wait1 = 0;
     const bool first = ctx->round == 0;
     ++ctx->round;
     if (with_add_term) ctx->add_term = ctx->add_term * (HFr::one() - r);
@@ -852,8 +859,10 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
             table_pair &t = ctx->tp[b];
             if (t.len && !first) { t.cur ^= 1; t.len >>= 1; t.Vsrc = nullptr; }
         }
+        if (seg_timing) ts_wait0 = now_s();
         int32_t rc = wait_slot(ctx, A.seq);
         if (rc) return rc;
+        if (seg_timing) ts_wait1 = now_s();
         for (int k = 0; k < 8; ++k) ctx->h_result[k] = ctx->h_slot->v[k];
     }
     HFr a = ctx->h_result[0], c = ctx->h_result[1], p1 = ctx->h_result[2];
@@ -874,6 +883,14 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
     put(out_abc + 4, bcoef);
     put(out_abc + 8, c);
     ctx->proof_size += 32 * 3;
+    if (seg_timing && ts_wait0 > 0) {
+        const double ts_exit = now_s();
+        if (!first && ctx->t_last_exit > 0) { ctx->t_seg[0] += ts_enter - ctx->t_last_exit; ++ctx->n_seg; }
+        ctx->t_seg[1] += ts_wait0 - ts_enter;
+        ctx->t_seg[2] += ts_wait1 - ts_wait0;
+        ctx->t_seg[3] += ts_exit - ts_wait1;
+        ctx->t_last_exit = ts_exit;
+    }
     return ZK_OK;
 }
 
