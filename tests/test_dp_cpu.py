@@ -98,3 +98,59 @@ def test_async_gather_keeps_steps_and_ranks_apart():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == [[(0, bytes([0, s]) * (10 + s)), (1, bytes([1, s]) * (10 + s))] for s in range(3)]
+
+
+def _streams_worker(rank, world, port, q):
+    """what bench.py does per rank: K sessions proving on K host threads, one packed asynchronous gather per step"""
+    import threading
+    from tests import oracle_ffi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    K, steps = 2, 2
+    sessions = [oracle_ffi.OracleSession(MODEL, PIC, 1, data_seed=2000 + rank * K + i) for i in range(K)]
+    g = dp.AsyncGather(dist, "cpu", K << 16)
+    out = [[None] * K for _ in range(steps)]
+
+    def stream(i):
+        for k in range(steps):
+            out[k][i] = sessions[i].prove(seed=500 + k)[1]
+    th = [threading.Thread(target=stream, args=(i,)) for i in range(K)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(steps):
+        g.submit(rank, dp.pack([(rank * K + i, out[k][i]) for i in range(K)]))
+    res = g.wait()
+    if rank == 0:
+        # every gathered proof is checked without its prover: replayed against a verifier-only session built from the statement
+        ok = []
+        stmts = {}
+        for step, per_rank in enumerate(res):
+            for r, blob in per_rank:
+                for img, tr in dp.unpack(blob):
+                    if img not in stmts:
+                        with oracle_ffi.OracleSession(MODEL, PIC, 1, data_seed=2000 + img) as tmp:
+                            stmts[img] = tmp.statement()
+                    with oracle_ffi.OracleSession(MODEL, PIC, 1, statement=stmts[img]) as v:
+                        ok.append((step, img, v.verify(tr, seed=500 + step).accepted))
+        q.put(ok)
+    for s in sessions:
+        s.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_two_streams_each_all_proofs_verify(oracle):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_streams_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(got) == [(step, img, 1) for step in range(2) for img in range(4)]
