@@ -105,7 +105,24 @@ def main():
 
     def build(i):
         sessions[i] = zkcnn_amd.Session(model, pic, pp, data_seed=20260928 + rank * K + i, device=local_rank)
-    in_threads(build)
+    # the first session alone, to see what one costs in HBM (tables + circuit now; the MSM byte table and scratch come with the
+    # first proofs, hence the margin): large single-circuit workloads do not fit 8 times
+    free0, _ = torch.cuda.mem_get_info(local_rank)
+    build(0)
+    free1, _ = torch.cuda.mem_get_info(local_rank)
+    per_session = max(free0 - free1, 1) * 1.6 + 4e9
+    K_fit = max(1, int(0.9 * free0 / per_session))
+    if K_fit < K:
+        K = K_fit
+        sessions = sessions[:K]
+
+    def in_rest(fn):
+        th = [threading.Thread(target=fn, args=(i,)) for i in range(1, K)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    in_rest(build)
+    if any(x is None for x in sessions):
+        raise SystemExit("a session could not be built")
     setup_s = time.time() - t0
     sess = sessions[0]
 
