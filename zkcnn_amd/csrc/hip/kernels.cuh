@@ -708,6 +708,45 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, cons
     const uint64_t tid = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x, stride = (uint64_t) gridDim.x * ZK_BLOCK;
     const uint64_t npairs = first ? n / 2 : n / 4;
     const uint32_t mpairs = ls >> 1;
+    // The periodic factor depends on the pair only through p mod mpairs. When the grid stride is a multiple of mpairs, all pairs
+    // of a thread share it: the thread accumulates the QUADRATIC sum_p X_p(t) Y_p(t) (3 products per pair) and multiplies by its
+    // one periodic factor at the end -- 7 products per pair instead of 13.
+    if (mpairs == 0 || stride % mpairs == 0) {
+        fr_t s00 = fr_zero(), s11 = fr_zero(), sdd = fr_zero();     // sum x0 y0, sum x1 y1, sum dx dy
+        for (uint64_t p = tid; p < npairs; p += stride) {
+            fr_t x0, x1, y0, y1;
+            if (first) {
+                x0 = fr_load(V0in + 2 * p); x1 = fr_load(V0in + 2 * p + 1);
+                y0 = fr_load(V1in + 2 * p); y1 = fr_load(V1in + 2 * p + 1);
+            } else {
+                x0 = fr_lerp(fr_load(V0in + 4 * p), fr_load(V0in + 4 * p + 1), r);
+                x1 = fr_lerp(fr_load(V0in + 4 * p + 2), fr_load(V0in + 4 * p + 3), r);
+                y0 = fr_lerp(fr_load(V1in + 4 * p), fr_load(V1in + 4 * p + 1), r);
+                y1 = fr_lerp(fr_load(V1in + 4 * p + 2), fr_load(V1in + 4 * p + 3), r);
+                fr_store(V0out + 2 * p, x0); fr_store(V0out + 2 * p + 1, x1);
+                fr_store(V1out + 2 * p, y0); fr_store(V1out + 2 * p + 1, y1);
+            }
+            sdd = fr_add(sdd, fr_mul(fr_sub(x1, x0), fr_sub(y1, y0)));
+            s00 = fr_add(s00, fr_mul(x0, y0));
+            s11 = fr_add(s11, fr_mul(x1, y1));
+        }
+        if (tid < npairs) {
+            fr_t m0, dm;
+            if (mpairs) {
+                const uint32_t mi = (uint32_t) (tid & (mpairs - 1));
+                m0 = fr_load(Ms + 2 * mi);
+                dm = fr_sub(fr_load(Ms + 2 * mi + 1), m0);
+            } else {
+                m0 = fr_load(Ms);
+                dm = fr_zero();
+            }
+            const fr_t q1 = fr_sub(fr_sub(s11, sdd), s00);
+            acc[0] = fr_mul(sdd, dm);
+            acc[1] = fr_add(fr_mul(sdd, m0), fr_mul(q1, dm));
+            acc[2] = fr_add(fr_mul(q1, m0), fr_mul(s00, dm));
+            acc[3] = fr_mul(s00, m0);
+        }
+    } else
     for (uint64_t p = tid; p < npairs; p += stride) {
         fr_t x0, x1, y0, y1;
         if (first) {
