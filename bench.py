@@ -46,6 +46,26 @@ PMC_TRAFFIC_PER_LAUNCH = {("vgg11", "round_quad"): 11.02e6, ("vgg11_pp8", "round
 ROOFLINE_CLASSES = ["gate_reduce", "round_quad", "round_cubic", "msm_planes"]
 
 
+def pin_to_gpu_numa_node(torch, local_rank):
+    """best effort: the host threads of a rank spin on a slot their GPU writes over PCIe; keep them on the GPU's NUMA node"""
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf.lower()}"
+        node = int(open(base + "/numa_node").read())
+        if node < 0:
+            return
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if len(cpus) >= 16:
+            os.sched_setaffinity(0, cpus)
+    except Exception:       # noqa: BLE001 - placement is an optimisation only
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +88,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    pin_to_gpu_numa_node(torch, local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:        # launched by torch.distributed.run (also with one rank: same code path)
         import torch.distributed as dist
