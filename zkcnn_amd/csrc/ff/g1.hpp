@@ -151,9 +151,15 @@ public:
         a.x.toCanonical(cx);
         for (int i = 0; i < 6; ++i)
             for (int b = 0; b < 8; ++b) out[47 - (i * 8 + b)] = (uint8_t) (cx[i] >> (8 * b));
-        Fp ny = -a.y;
         out[0] |= 0x80;
-        if (Fp::cmpCanonical(a.y, ny) > 0) out[0] |= 0x20;
+        // y is the larger of the two roots iff y > (p - 1) / 2 (one canonical conversion instead of two)
+        static const uint64_t half[6] = {0xdcff7fffffffd555ULL, 0x0f55ffff58a9ffffULL, 0xb39869507b587b12ULL,
+                                         0xb23ba5c279c2895fULL, 0x258dd3db21a5d66bULL, 0x0d0088f51cbff34dULL};
+        uint64_t cy[6];
+        a.y.toCanonical(cy);
+        for (int i = 5; i >= 0; --i) {
+            if (cy[i] != half[i]) { if (cy[i] > half[i]) out[0] |= 0x20; break; }
+        }
     }
     // inverse of serialize(): rejects non-canonical encodings (x >= p, stray flag bits, a non-residue x^3 + 4) and, with
     // check_subgroup, points outside the order-r subgroup (r * P != O).

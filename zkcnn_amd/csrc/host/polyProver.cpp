@@ -13,12 +13,18 @@ static G1 fromABI(const uint64_t *p) {
     return G1::fromAffine(a);
 }
 
-polyProver::polyProver(zk_ctx *c, int bit_length, const std::vector<G1> &gens) : ctx(c), ps_bytes(0) {
+polyProver::polyProver(zk_ctx *c, int bit_length, const std::vector<G1> &gens, gensCache *cache) : ctx(c), ps_bytes(0) {
     pt.start();
     const int rb = bit_length >> 1;
     const size_t rows = (size_t) 1 << rb;
-    std::vector<G1Affine> ga;
-    zkff::batchToAffine(gens, ga);
+    std::vector<G1Affine> local;
+    const bool hit = cache && cache->gens.size() == gens.size() && !gens.empty() &&
+                     std::memcmp(cache->gens.data(), gens.data(), gens.size() * sizeof(G1)) == 0;
+    std::vector<G1Affine> &ga = cache ? cache->affine : local;
+    if (!hit) {
+        zkff::batchToAffine(gens, ga);
+        if (cache) cache->gens = gens;
+    }
     std::vector<uint64_t> out(rows * 12);
     must(ctx, zk_commit_input(ctx, reinterpret_cast<const uint64_t *>(ga.data()), ga.size(), out.data(), rows), "zk_commit_input");
     comm.resize(rows);

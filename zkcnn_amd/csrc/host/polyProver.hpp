@@ -10,7 +10,10 @@ namespace hyrax_bls12_381 {
 
 class polyProver : public polyProverBase {
 public:
-    polyProver(zk_ctx *ctx, int bit_length, const std::vector<G1> &gens);
+    // `affine_cache` (optional, owned by the caller): the affine form of the generators of the previous commitment; re-used when the
+    // same generators come again (one batched inversion + 6 products per generator saved), refreshed otherwise
+    struct gensCache { std::vector<G1> gens; std::vector<G1Affine> affine; };
+    polyProver(zk_ctx *ctx, int bit_length, const std::vector<G1> &gens, gensCache *affine_cache = nullptr);
     const std::vector<G1> &commitment() const override { return comm; }
     void openInit(const std::vector<Fr> &x) override;
     ipaRoundMsg openRound() override;

@@ -216,6 +216,6 @@ quadratic_poly prover::sumcheckLiuUpdate(const F &previous_random) {
 hyrax_bls12_381::polyProverBase &prover::commitInput(const vector<G> &gens) {
     TIMED();
     if (!ctx || !resident) throw std::runtime_error("prover::commitInput before prover::init");
-    poly_p.reset(new hyrax_bls12_381::polyProver(ctx, C.circuit[0].bit_length, gens));
+    poly_p.reset(new hyrax_bls12_381::polyProver(ctx, C.circuit[0].bit_length, gens, &gens_cache));
     return *poly_p;
 }

@@ -70,5 +70,6 @@ private:
     bool resident;
     timer upload_timer;
     std::unique_ptr<hyrax_bls12_381::polyProver> poly_p;
+    hyrax_bls12_381::polyProver::gensCache gens_cache;      // affine form of the last generator set (re-used generators)
     friend neuralNetwork;
 };
