@@ -202,11 +202,12 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_gate_reduce(fr_t *out, uint32_t *c
     uint32_t key = GATE_NOKEY;
     fr_t val = fr_zero();
     if (live) {
-        const gate_rec *rp = a.recs + idx * GATE_GROUP;
+        // records of one wave are stored lane-interleaved: the k-th record of lane l sits at slot k * 64 + l of the wave's chunk
+        const gate_rec *rp = a.recs + (idx >> 6) * (64 * GATE_GROUP) + (idx & 63);
         key = rp[0].key;
 #pragma unroll
         for (uint32_t k = 0; k < GATE_GROUP; ++k) {
-            const gate_rec rc = rp[k];
+            const gate_rec rc = rp[k * 64];
             val = fr_add(val, gate_term(rc, a));
         }
     }

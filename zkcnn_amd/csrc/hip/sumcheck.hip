@@ -178,7 +178,18 @@ static void pad_runs(std::vector<gate_rec> &recs) {
         }
         i = j;
     }
-    recs.swap(out);
+    // whole waves: the list is padded to a multiple of 64 groups with records of the last key, and inside every chunk of
+    // 64 x GATE_GROUP records the k-th record of lane l is stored at slot k * 64 + l, so that each of the kernel's GATE_GROUP
+    // loads is one contiguous 1 KB access of the wave
+    const size_t chunk = 64 * GATE_GROUP;
+    while (!out.empty() && out.size() % chunk) {
+        gate_rec d = {0, out.back().key, 0, 1u << 11};
+        out.push_back(d);
+    }
+    recs.resize(out.size());
+    for (size_t base = 0; base < out.size(); base += chunk)
+        for (size_t l = 0; l < 64; ++l)
+            for (size_t k = 0; k < GATE_GROUP; ++k) recs[base + k * 64 + l] = out[base + l * GATE_GROUP + k];
 }
 static void counting_sort(std::vector<gate_rec> &recs, uint32_t nkeys) {
     std::vector<uint32_t> cnt((size_t) nkeys + 1, 0);
