@@ -132,8 +132,9 @@ def main():
         sessions[i] = zkcnn_amd.Session(model, pic, pp, data_seed=20260928 + rank * K + i, device=local_rank)
     # Large single-circuit workloads do not fit 8 times: a probe session measures what one costs in HBM (tables + circuit now; the MSM
     # byte table and scratch come with the first proofs, hence the margin) and is closed again. All K sessions are then built side by
-    # side -- with the sessions created one after the other the same 8 streams reach 51 instead of 59 proofs/s (the order in which
-    # streams are created decides how HIP maps them to hardware queues; scripts/exp/bench_variants.py).
+    # side -- with the sessions created one after the other the same 8 streams reach 51 instead of 59 proofs/s, reproducibly
+    # (scripts/exp/bench_variants.py: plain vs allseq; GPU_MAX_HW_QUEUES = 1 / 2 / 3 / 4 / 8 gives 28 / 44 / 51 / 59 / 45-51, so how
+    # HIP maps the streams to hardware queues matters, but the creation-order effect itself is not explained).
     if pp > 1 or "vgg16" in model:
         free0, _ = torch.cuda.mem_get_info(local_rank)
         build(0)

@@ -126,6 +126,9 @@ int32_t zk_witness_gates(zk_ctx *ctx, uint64_t *out, uint64_t n_out, const zk_un
                          uint64_t n_bin, const uint64_t *prev, uint64_t n_prev, const uint64_t *two_mul, uint32_t n_two_mul,
                          const uint64_t scale[4]);
 
+/* frees the device copy of layer 0 and the staging buffers of zk_witness_* (the witness is complete) */
+int32_t zk_witness_release(zk_ctx *ctx);
+
 /* ---- built-in profiler: HIP events around every launch of the selected kernel classes, on the context's stream ---- */
 /* class_mask: bit i selects class i of zk_profile_report's list; 0 switches profiling off; ~0u selects all */
 int32_t zk_profile_enable(zk_ctx *ctx, uint32_t class_mask);

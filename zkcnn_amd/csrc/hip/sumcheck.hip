@@ -1322,6 +1322,15 @@ static int32_t grow_buf(zk_ctx *ctx, dev_buf &b, size_t bytes, size_t keep = 0) 
     return ZK_OK;
 }
 
+extern "C" int32_t zk_witness_release(zk_ctx *ctx) {
+    CHECK_CTX();
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->w_val0.p) { ZK_HIP(hipFree(ctx->w_val0.p)); ctx->w_val0 = dev_buf(); }
+    for (dev_buf &b : ctx->w_stage) if (b.p) { ZK_HIP(hipFree(b.p)); b = dev_buf(); }
+    ctx->w_val0_len = 0;
+    return ZK_OK;
+}
+
 extern "C" int32_t zk_witness_input(zk_ctx *ctx, uint64_t offset, const uint64_t *values, uint64_t n) {
     CHECK_CTX();
     if (offset == 0) ctx->w_val0_len = 0;                            // a new layer 0 starts

@@ -7,10 +7,10 @@
 // witness kernels of the FFT convolution on the GPU (include/zkcnn_hip.h: zk_witness_ntt / zk_witness_dotprod)
 class hipWitnessAccel : public witnessAccel {
 public:
-    explicit hipWitnessAccel(int device) : ctx(nullptr) {
-        if (zk_ctx_create(device, &ctx) != ZK_OK) throw std::runtime_error(string("zk_ctx_create: ") + zk_last_error(nullptr));
-    }
-    ~hipWitnessAccel() override { if (ctx) zk_ctx_destroy(ctx); }
+    // Runs on the session's OWN context and stream (the circuit is uploaded to it afterwards): one context, one HIP stream and one set
+    // of scratch buffers per session; the witness buffers are released when the witness is complete
+    explicit hipWitnessAccel(zk_ctx *session_ctx) : ctx(session_ctx) {}
+    ~hipWitnessAccel() override { if (ctx) zk_witness_release(ctx); }
     bool ntt(F *dst, const F *src, int logn, bool inverse, size_t count) override {
         if (logn > 12) return false;                 // longer transforms do not fit in LDS; the host loop takes them
         int rc = zk_witness_ntt(ctx, reinterpret_cast<uint64_t *>(dst), reinterpret_cast<const uint64_t *>(src), logn, inverse, count);
@@ -87,7 +87,8 @@ void *zkcnn_session_create(const zkcnn_model_desc *desc, int32_t device) {
         s->p.~prover();
         new (&s->p) prover(device);
         {
-            hipWitnessAccel accel(device);
+            s->p.ensureContext();
+            hipWitnessAccel accel(s->p.context());
             s->accel = &accel;
             bool ok = s->build(desc);
             s->accel = nullptr;

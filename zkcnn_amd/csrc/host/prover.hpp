@@ -61,8 +61,8 @@ public:
     int device() const { return device_id; }
     zk_ctx *context() const { return ctx; }     // for the profiler entry points of include/zkcnn_hip.h
 
+    void ensureContext();                       // creates the GPU context (and its stream) without uploading anything
 private:
-    void ensureContext();
     void check(int rc, const char *what) const;
 
     zk_ctx *ctx;
