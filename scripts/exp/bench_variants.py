@@ -1,7 +1,7 @@
 import hashlib, os, sys, threading, time, queue
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import zkcnn_amd
-K = 8
+K = int(os.environ.get("KSTREAMS", "8"))
 variant = sys.argv[1]
 sessions = [None] * K
 def build(i): sessions[i] = zkcnn_amd.Session("vgg11", (32, 32, 3), 1, data_seed=20260928 + i)
