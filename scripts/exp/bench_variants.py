@@ -5,8 +5,33 @@ K = int(os.environ.get("KSTREAMS", "8"))
 variant = sys.argv[1]
 sessions = [None] * K
 def build(i): sessions[i] = zkcnn_amd.Session("vgg11", (32, 32, 3), 1, data_seed=20260928 + i)
-if variant == "allseq":
+import numpy as np
+def prewarm(n):
+    """n contexts created and used side by side, then closed: the hardware queues exist before the sessions' streams are made"""
+    def one(_):
+        hc = zkcnn_amd.HipContext(0)
+        a = np.ones((64, 4), dtype=np.uint64)
+        hc.fr_binop("add", a, a)
+        time.sleep(0.2)
+        hc.close()
+    tt = [threading.Thread(target=one, args=(j,)) for j in range(n)]
+    [t.start() for t in tt]; [t.join() for t in tt]
+if variant == "prewarm_allseq":
+    prewarm(8)
     for i in range(K): build(i)
+    th = []
+elif variant == "allseq":
+    for i in range(K): build(i)
+    th = []
+elif variant == "seqthreads":          # one builder thread per session, but one after the other
+    for i in range(K):
+        t = threading.Thread(target=build, args=(i,)); t.start(); t.join()
+    th = []
+elif variant in ("pairs", "quads"):    # two / four at a time
+    g = 2 if variant == "pairs" else 4
+    for i in range(0, K, g):
+        tt = [threading.Thread(target=build, args=(j,)) for j in range(i, min(K, i + g))]
+        [t.start() for t in tt]; [t.join() for t in tt]
     th = []
 elif variant in ("seqfirst", "queue", "notranscript"):
     build(0)
