@@ -45,6 +45,8 @@ struct table_pair {
     const fr_t *Vsrc = nullptr;    // until the first fold the V input is read straight from a layer's values (no copy into V[cur])
     uint64_t len = 0;              // current (pre-fold) length; 0 = absent or already absorbed
     bool absorbed = false;         // collapsed to a constant whose product went into add_term
+    bool tail_valid = false;       // the two entries left in V are known on the host (sent along with the last round)
+    HFr tail_v[2];
     HFr final_v;                   // value of V when it collapsed
 };
 

@@ -625,6 +625,16 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad_fine(round2_args a) {
         X = fr_lerp(fr_load(src), fr_load(src + 1), a.r);
         fr_store((role < 2 ? a.Vout[b] : a.Mout[b]) + 2 * q + (role & 1), X);
     }
+    // the last pair of a V table (two entries left after this round) also goes to the host slot: the phase's final evaluation
+    // V(r) = v0 + r (v1 - v0) is then one host multiplication instead of one more launch and hand-over
+    const bool tail = live && !special && items[b] == 1 && role < 2;
+    if (tail) {
+        const fr_t tv = a.first ? opA : X;
+        if (g_finish_light) {
+            fr_store_scoped(&a.slot->v[8 + 2 * b + role], tv, true);
+            ZK_WAIT_STORES();
+        } else fr_store(&a.slot->v[8 + 2 * b + role], tv);
+    }
     if (!a.first) {
         fr_t y1, y2, y3;
 #pragma unroll
@@ -659,7 +669,8 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad_fine(round2_args a) {
             acc[0] = fr_add(acc[0], s_role[2][w]);
         }
     }
-    grid_finish<3>(acc, a.partials, a.counter, a.slot, a.seq, smem, collapse[0] || collapse[1]);
+    grid_finish<3>(acc, a.partials, a.counter, a.slot, a.seq, smem,
+                   collapse[0] || collapse[1] || (items[0] == 1 && a.n[0]) || (items[1] == 1 && a.n[1]));
 }
 
 // up to four "evaluate the last variable" requests in one tiny launch: out[i] = n == 2 ? lerp(p[0], p[1], r) : p[0]

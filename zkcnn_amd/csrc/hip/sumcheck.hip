@@ -488,6 +488,7 @@ static void reset_pairs(zk_ctx *ctx, int bl0, int bl1) {
     const int bl[2] = {bl0, bl1};
     for (int b = 0; b < 2; ++b) {
         ctx->tp[b].cur = 0;
+        ctx->tp[b].tail_valid = false;
         ctx->tp[b].Vsrc = nullptr;
         ctx->tp[b].len = bl[b] >= 0 ? 1ull << bl[b] : 0;
         ctx->tp[b].absorbed = false;
@@ -875,6 +876,14 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         if (rc) return rc;
         if (seg_timing) ts_wait1 = now_s();
         for (int k = 0; k < 8; ++k) ctx->h_result[k] = ctx->h_slot->v[k];
+        for (int b = 0; b < 2; ++b) {          // a V table that is down to its last pair came along (k_round_quad_fine)
+            table_pair &t = ctx->tp[b];
+            if (fine && !collapsed[b] && t.len == 2) {
+                t.tail_v[0] = ctx->h_slot->v[8 + 2 * b];
+                t.tail_v[1] = ctx->h_slot->v[9 + 2 * b];
+                t.tail_valid = true;
+            }
+        }
     }
     HFr a = ctx->h_result[0], c = ctx->h_result[1], p1 = ctx->h_result[2];
     HFr bcoef = p1 - a - c;
@@ -929,7 +938,9 @@ static int32_t final_claims(zk_ctx *ctx, const HFr &r, const int8_t bl[2], HFr o
         table_pair &t = ctx->tp[b];
         out[b].clear();
         if (t.len > 2) return ZK_ERR_STATE;
-        if (t.len >= 1) {
+        if (t.len == 2 && t.tail_valid) {
+            out[b] = t.tail_v[0] + r * (t.tail_v[1] - t.tail_v[0]);       // O(1): the pair arrived with the last round
+        } else if (t.len >= 1) {
             E.p[b] = vin(t);
             E.n[b] = (uint32_t) t.len;
             pending[b] = true;
