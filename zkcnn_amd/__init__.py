@@ -187,6 +187,16 @@ class HipContext:
                                               u64p(two_mul), ctypes.c_uint32(two_mul.shape[0]), u64p(scale)), "zk_witness_gates")
         return out
 
+    def witness_dotprod(self, F, n_in, n_out, gates, fft_bl):
+        """witness of a DOT_PROD layer (zk_witness_dotprod): out[(g, t)] = sum over the gates of g of F[(u, t)] * F[(v, t)]"""
+        out = np.zeros((n_out << fft_bl, 4), dtype=np.uint64)
+        F = np.ascontiguousarray(F, dtype=np.uint64)
+        gates = np.ascontiguousarray(gates, dtype=self.BIN_GATE)
+        self._check(self.lib.zk_witness_dotprod(self.ctx, u64p(out), ctypes.c_uint64(n_out), u64p(F), ctypes.c_uint64(n_in),
+                                                gates.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(gates.shape[0]),
+                                                ctypes.c_int32(fft_bl)), "zk_witness_dotprod")
+        return out
+
     def commit_rows(self, scalars, bases, rows, cols):
         out = np.zeros((rows, 12), dtype=np.uint64)
         self._check(self.lib.zk_k_commit_rows(self.ctx, u64p(out), u64p(scalars), u64p(bases), ctypes.c_uint64(rows), ctypes.c_uint64(cols)),
