@@ -12,6 +12,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_runtime_first():
+    """On a GPU box, bring PyTorch's HIP runtime up before libzkcnn_hip.so creates its first context -- the order bench.py uses.
+    (torch ships its own libamdhip64; initialising it after another copy of the runtime has been active in the process was seen to
+    report `No HIP GPUs are available`.) Nothing happens on a CPU-only box."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:       # noqa: BLE001 - the CPU suite does not need torch's GPU side
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def built():
     """native libraries, built once per test session (hipcc cross-compiles without a GPU)"""

@@ -96,6 +96,12 @@ __device__ __forceinline__ fr_t fr_neg(const fr_t &a) {
     asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"          \
         : "+v"(acc), "+v"(ovf) : "v"(x), "v"(y) : "vcc")
 
+// same step with the second factor in a scalar register: the modulus limbs are compile-time constants, one s_mov each instead of a
+// VGPR held across the whole product (VOP3 reads one SGPR operand per instruction)
+#define ZK_MAC_S(acc, ovf, x, y)                                                                          \
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"          \
+        : "+v"(acc), "+v"(ovf) : "v"(x), "s"(y) : "vcc")
+
 // Montgomery product by product scanning (finely integrated: multiplication and reduction columns interleaved)
 // with ONE 96-bit accumulator: 2 instructions per 32x32 partial product, no carry ripple inside a column.
 template <int N, bool INV_IS_MINUS1>
@@ -108,9 +114,9 @@ __device__ __forceinline__ void mont_mul_comba(uint32_t *z, const uint32_t *a, c
 #pragma unroll
         for (int i = 0; i <= k; ++i) ZK_MAC(acc, ovf, a[i], b[k - i]);
 #pragma unroll
-        for (int i = 0; i < k; ++i) ZK_MAC(acc, ovf, q[i], m[k - i]);
+        for (int i = 0; i < k; ++i) ZK_MAC_S(acc, ovf, q[i], m[k - i]);
         q[k] = INV_IS_MINUS1 ? 0u - (uint32_t) acc : (uint32_t) acc * inv;
-        ZK_MAC(acc, ovf, q[k], m[0]);
+        ZK_MAC_S(acc, ovf, q[k], m[0]);
         acc = (acc >> 32) | ((uint64_t) ovf << 32);
         ovf = 0;
     }
@@ -119,7 +125,7 @@ __device__ __forceinline__ void mont_mul_comba(uint32_t *z, const uint32_t *a, c
 #pragma unroll
         for (int i = k - N + 1; i < N; ++i) ZK_MAC(acc, ovf, a[i], b[k - i]);
 #pragma unroll
-        for (int i = k - N + 1; i < N; ++i) ZK_MAC(acc, ovf, q[i], m[k - i]);
+        for (int i = k - N + 1; i < N; ++i) ZK_MAC_S(acc, ovf, q[i], m[k - i]);
         r[k - N] = (uint32_t) acc;
         acc = (acc >> 32) | ((uint64_t) ovf << 32);
         ovf = 0;

@@ -73,22 +73,39 @@ __device__ __forceinline__ fp_t fp_sub(const fp_t &a, const fp_t &b) {
 __device__ __forceinline__ fp_t fp_neg(const fp_t &a) { return fp_sub(fp_zero(), a); }
 __device__ __forceinline__ fp_t fp_dbl(const fp_t &a) { return fp_add(a, a); }
 
-// Montgomery product over 12 limbs: 288 MAC steps of the 96-bit column accumulator (fr_dev.cuh: mont_mul_comba)
-__device__ __noinline__ fp_t fp_mul(const fp_t a, const fp_t b) {
+// Montgomery product over 12 limbs: 300 MAC steps of the 96-bit column accumulator (fr_dev.cuh: mont_mul_comba).
+// ONE copy of the code per translation unit, reached by a call whose 24 operand limbs and 12 result limbs travel in VGPRs
+// (scalar arguments: the AMDGPU calling convention passes a by-value struct of this size on the stack, i.e. through scratch
+// memory -- the round-1 kernels had a 144..688-byte private segment for exactly that reason). With inter-procedural register
+// allocation the caller keeps its live points in the registers the callee does not touch, so nothing is spilled around the call,
+// and a mixed addition is 11 calls + a few hundred add / sub instructions (~7 KB of code) instead of 11 inlined products (~60 KB,
+// the size of the instruction cache two CUs share).
+struct fp_regs { uint32_t v[12]; };
+__device__ __noinline__ fp_regs fp_mul_r(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7,
+                                         uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3,
+                                         uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8, uint32_t b9, uint32_t b10, uint32_t b11) {
     const uint32_t m[12] = FP_MOD_INIT;
+    const uint32_t a[12] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11}, b[12] = {b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11};
+    fp_regs z;
+    mont_mul_comba<12, false>(z.v, a, b, m, FP_INV32);
+    return z;
+}
+__device__ __forceinline__ fp_t fp_mul(const fp_t &a, const fp_t &b) {
+    const fp_regs r = fp_mul_r(a.v[0], a.v[1], a.v[2], a.v[3], a.v[4], a.v[5], a.v[6], a.v[7], a.v[8], a.v[9], a.v[10], a.v[11],
+                               b.v[0], b.v[1], b.v[2], b.v[3], b.v[4], b.v[5], b.v[6], b.v[7], b.v[8], b.v[9], b.v[10], b.v[11]);
     fp_t z;
-    mont_mul_comba<12, false>(z.v, a.v, b.v, m, FP_INV32);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) z.v[i] = r.v[i];
     return z;
 }
 __device__ __forceinline__ fp_t fp_sqr(const fp_t &a) { return fp_mul(a, a); }
-// inlined copy for the one hot loop that keeps a whole point in registers across the products (k_msm_bytes: g1_madd)
+// inlined copy (micro-benchmarks only)
 __device__ __forceinline__ fp_t fp_mul_i(const fp_t &a, const fp_t &b) {
     const uint32_t m[12] = FP_MOD_INIT;
     fp_t z;
     mont_mul_comba<12, false>(z.v, a.v, b.v, m, FP_INV32);
     return z;
 }
-__device__ __forceinline__ fp_t fp_sqr_i(const fp_t &a) { return fp_mul_i(a, a); }
 
 // a^(p-2): Fermat inverse (inv(0) = 0)
 __device__ __forceinline__ fp_t fp_inv(const fp_t &a) {
@@ -172,62 +189,6 @@ __device__ __forceinline__ g1j_t g1_madd(const g1j_t &p, const g1a_t &q) {
     r.X = fp_sub(fp_sub(fp_sqr(Rr), HHH), fp_dbl(V));
     r.Y = fp_sub(fp_mul(Rr, fp_sub(V, r.X)), fp_mul(p.Y, HHH));
     r.Z = fp_mul(p.Z, H);
-    return r;
-}
-
-// g1_madd with every product inlined (no calls: nothing is spilled around them)
-__device__ __forceinline__ g1j_t g1_madd_i(const g1j_t &p, const g1a_t &q) {
-    if (g1a_is_inf(q)) return p;
-    if (g1_is_inf(p)) {
-        g1j_t r;
-        r.X = q.x; r.Y = q.y; r.Z = fp_one();
-        return r;
-    }
-    fp_t Z1Z1 = fp_sqr_i(p.Z);
-    fp_t U2 = fp_mul_i(q.x, Z1Z1), S2 = fp_mul_i(fp_mul_i(q.y, p.Z), Z1Z1);
-    if (fp_eq(p.X, U2)) {
-        if (fp_eq(p.Y, S2)) return g1_dbl(p);
-        return g1_inf();
-    }
-    fp_t H = fp_sub(U2, p.X), Rr = fp_sub(S2, p.Y);
-    fp_t HH = fp_sqr_i(H), HHH = fp_mul_i(H, HH), V = fp_mul_i(p.X, HH);
-    g1j_t r;
-    r.X = fp_sub(fp_sub(fp_sqr_i(Rr), HHH), fp_dbl(V));
-    r.Y = fp_sub(fp_mul_i(Rr, fp_sub(V, r.X)), fp_mul_i(p.Y, HHH));
-    r.Z = fp_mul_i(p.Z, H);
-    return r;
-}
-
-__device__ __forceinline__ g1j_t g1_dbl_i(const g1j_t &p) {
-    if (g1_is_inf(p)) return p;
-    fp_t A = fp_sqr_i(p.X), B = fp_sqr_i(p.Y), C = fp_sqr_i(B);
-    fp_t t = fp_add(p.X, B);
-    fp_t D = fp_sub(fp_sub(fp_sqr_i(t), A), C);
-    D = fp_dbl(D);
-    fp_t E = fp_add(fp_dbl(A), A), F = fp_sqr_i(E);
-    g1j_t r;
-    r.X = fp_sub(F, fp_dbl(D));
-    fp_t C8 = fp_dbl(fp_dbl(fp_dbl(C)));
-    r.Y = fp_sub(fp_mul_i(E, fp_sub(D, r.X)), C8);
-    r.Z = fp_dbl(fp_mul_i(p.Y, p.Z));
-    return r;
-}
-__device__ __forceinline__ g1j_t g1_add_i(const g1j_t &p, const g1j_t &q) {
-    if (g1_is_inf(p)) return q;
-    if (g1_is_inf(q)) return p;
-    fp_t Z1Z1 = fp_sqr_i(p.Z), Z2Z2 = fp_sqr_i(q.Z);
-    fp_t U1 = fp_mul_i(p.X, Z2Z2), U2 = fp_mul_i(q.X, Z1Z1);
-    fp_t S1 = fp_mul_i(fp_mul_i(p.Y, q.Z), Z2Z2), S2 = fp_mul_i(fp_mul_i(q.Y, p.Z), Z1Z1);
-    if (fp_eq(U1, U2)) {
-        if (fp_eq(S1, S2)) return g1_dbl(p);
-        return g1_inf();
-    }
-    fp_t H = fp_sub(U2, U1), Rr = fp_sub(S2, S1);
-    fp_t HH = fp_sqr_i(H), HHH = fp_mul_i(H, HH), V = fp_mul_i(U1, HH);
-    g1j_t r;
-    r.X = fp_sub(fp_sub(fp_sqr_i(Rr), HHH), fp_dbl(V));
-    r.Y = fp_sub(fp_mul_i(Rr, fp_sub(V, r.X)), fp_mul_i(S1, HHH));
-    r.Z = fp_mul_i(fp_mul_i(p.Z, q.Z), H);
     return r;
 }
 

@@ -12,15 +12,8 @@
 #include <algorithm>
 #include <cstring>
 #include "ctx.hpp"
-#include "g1_dev.cuh"
+#include "msm_kernels.cuh"
 #include "../ff/g1.hpp"
-
-#define MSM_WINDOWS 32
-#define MSM_PLANES 8
-// threads per MSM block: one wave. The kernels are chains of dependent Fp products, so what matters is how many
-// independent chains are resident (2 waves/SIMD at ~200 VGPRs) and how short each is: one wave per block keeps the
-// reduction tree at 6 levels and lets 8 blocks share a CU.
-#define MSM_BLOCK 64
 
 struct msm_state {
     g1a_t *tables = nullptr;           // [MSM_WINDOWS][m]
@@ -35,7 +28,7 @@ struct msm_state {
     fr_t *sL = nullptr, *sR = nullptr; uint32_t *idxL = nullptr, *idxR = nullptr;
     fr_t *d_y = nullptr;               // 2 elements
     void *tbl_scratch = nullptr; size_t tbl_scratch_cap = 0;
-    // commitment fast path: digit table D[d][j] = d * g_j (d = 1..255, affine), per-row "has high bytes" flags
+    // commitment fast path: digit table D[d][j] = d * g_j (d = 1..255, affine), per-row "has wide scalars" flags (+ the exception word)
     g1a_t *digit = nullptr; uint64_t digit_m = 0; bool digit_ready = false;
     uint32_t *hi_flags = nullptr, *row_list = nullptr; size_t flags_cap = 0;
     g1j_t *tmpJ = nullptr; size_t tmp_cap = 0;
@@ -47,14 +40,20 @@ struct msm_state {
     g1j_t *parts2 = nullptr; size_t parts2_cap = 0;
     bool host_rows_valid = false;      // few-row MSMs end with a short sum on the host (like the single inversion of fetch_points)
     zkff::G1 host_rows[8];
+    // scalar pre-pass outputs: 16-bit codes of a whole matrix, canonical signed magnitudes of the rows that need every window
+    uint16_t *codes = nullptr, *codes_v = nullptr; size_t codes_cap = 0, codes_v_cap = 0;   // codes of a matrix; of the virtual rows (higher windows of wide rows)
+    fr_t *mag = nullptr; size_t mag_cap = 0;
+    uint32_t *exc = nullptr;           // device word set by a fast-variant kernel that met P = +-Q
+    bool safe = false;                 // run the SAFE kernel variants (after a flagged batch)
 };
 #define MSM_FULL_MAX_M 16384u
+#define ZK_RETRY_SAFE 0x5afe       // internal status: repeat the batch with the SAFE kernels
 
 void zk_msm_destroy(zk_ctx *ctx) {
     if (!ctx->msm) return;
     msm_state *s = ctx->msm;
     void *bufs[] = {s->tables, s->partials, s->rowsJ, s->rowsA, s->a, s->b, s->coef, s->Lrow, s->sL, s->idxL, s->d_y, s->tbl_scratch,
-                    s->digit, s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch, s->full, s->parts2};
+                    s->digit, s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch, s->full, s->parts2, s->codes, s->mag, s->exc, s->codes_v};
     for (void *p : bufs) if (p) hipFree(p);
     delete s;
     ctx->msm = nullptr;
@@ -69,380 +68,15 @@ static int32_t regrow(zk_ctx *ctx, void **p, size_t *cap, size_t bytes) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// kernels
-// ------------------------------------------------------------------------------------------------
-// T[0][j] = g_j is already in place; fills T[w][j] = 2^(8w) g_j for w >= 1, converted to affine with
-// one field inversion per generator (Montgomery's trick over the 31 Jacobian points of that thread).
-__global__ void k_window_tables(g1a_t *T, g1j_t *J, fp_t *pre, uint32_t m) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const g1a_t g = T[j];
-    if (g1a_is_inf(g)) {
-        for (int w = 1; w < MSM_WINDOWS; ++w) T[(size_t) w * m + j] = g;
-        return;
-    }
-    g1j_t P;
-    P.X = g.x; P.Y = g.y; P.Z = fp_one();
-    fp_t run = fp_one();
-    for (int w = 1; w < MSM_WINDOWS; ++w) {
-        for (int d = 0; d < 8; ++d) P = g1_dbl(P);
-        J[(size_t) (w - 1) * m + j] = P;
-        pre[(size_t) (w - 1) * m + j] = run;
-        run = fp_mul(run, P.Z);
-    }
-    fp_t inv = fp_inv(run);
-    for (int w = MSM_WINDOWS - 1; w >= 1; --w) {
-        const g1j_t Q = J[(size_t) (w - 1) * m + j];
-        const fp_t zi = fp_mul(inv, pre[(size_t) (w - 1) * m + j]);
-        inv = fp_mul(inv, Q.Z);
-        const fp_t zi2 = fp_sqr(zi);
-        g1a_t a;
-        a.x = fp_mul(Q.X, zi2);
-        a.y = fp_mul(fp_mul(Q.Y, zi2), zi);
-        T[(size_t) w * m + j] = a;
-    }
-}
-
-// One block = (row, bit plane, column chunk x window group). Each thread walks `cpt` columns
-// (stride MSM_BLOCK: coalesced scalar and table reads), adds the selected table points, then the block
-// tree-reduces through LDS. out[(row * 8 + plane) * nparts + part]
-__global__ void __launch_bounds__(MSM_BLOCK) k_msm_planes(g1j_t *out, const fr_t *scalars, uint64_t ld, const uint32_t *idx_base,
-                                                     const g1a_t *T, uint32_t m, uint32_t cols, uint32_t cpt, uint32_t wsplit,
-                                                     const uint32_t *row_map, uint32_t w_lo) {
-    __shared__ g1j_t sm[MSM_BLOCK];
-    const uint32_t plane = blockIdx.y, row = row_map ? row_map[blockIdx.z] : blockIdx.z;
-    const uint32_t wg = blockIdx.x % wsplit, chunk = blockIdx.x / wsplit;
-    const uint32_t wpg = MSM_WINDOWS / wsplit, w0 = max(wg * wpg, w_lo);
-    const uint32_t *idx = idx_base ? idx_base + (size_t) row * ld : nullptr;     // index rows are laid out like the scalar rows
-    g1j_t acc = g1_inf();
-    for (uint32_t i = 0; i < cpt; ++i) {
-        const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + threadIdx.x;
-        if (c >= cols) break;
-        bool neg;
-        const fr_t s = fr_signed_magnitude(fr_load(scalars + (size_t) row * ld + c), neg);
-        const uint32_t j = idx ? idx[c] : c;
-        for (uint32_t w = w0; w < (wg + 1) * wpg; ++w) {
-            const uint32_t byte = (s.v[w >> 2] >> ((w & 3) * 8)) & 0xffu;
-            if ((byte >> plane) & 1u) {
-                g1a_t pt = T[(size_t) w * m + j];
-                if (neg) pt.y = fp_neg(pt.y);
-                acc = g1_madd(acc, pt);
-            }
-        }
-    }
-    // blocks that selected no point at all (high windows of small scalars) skip the reduction tree
-    if (!__syncthreads_or(!g1_is_inf(acc))) {
-        if (threadIdx.x == 0) out[((size_t) blockIdx.z * MSM_PLANES + plane) * gridDim.x + blockIdx.x] = acc;
-        return;
-    }
-    sm[threadIdx.x] = acc;
-    __syncthreads();
-    for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
-        if (threadIdx.x < s) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + s]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[((size_t) blockIdx.z * MSM_PLANES + plane) * gridDim.x + blockIdx.x] = sm[0];
-}
-
-// ---- commitment fast path -------------------------------------------------------------------------
-// digit table by levels: D[1] = g, D[d] = 2 D[d/2] (+ g if d is odd); every entry of a level is independent
-__global__ void k_digit_level(g1j_t *J, const g1a_t *G, uint32_t m, uint32_t level) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t cnt = 1u << level;
-    if (tid >= cnt * m) return;
-    const uint32_t j = tid % m, d = cnt + tid / m;
-    const g1a_t g = G[j];
-    g1j_t P;
-    if (level == 0) {
-        if (g1a_is_inf(g)) P = g1_inf();
-        else { P.X = g.x; P.Y = g.y; P.Z = fp_one(); }
-    } else {
-        P = g1_dbl(J[(size_t) (d >> 1) * m + j]);
-        if (d & 1) P = g1_madd(P, g);
-    }
-    J[(size_t) d * m + j] = P;
-}
-// Jacobian -> affine for 16 consecutive digits of one generator with one inversion (Montgomery's trick)
-__global__ void k_digit_affine(g1a_t *D, const g1j_t *J, fp_t *pre, uint32_t m) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= 16 * m) return;
-    const uint32_t j = tid % m, d0 = (tid / m) * 16;
-    fp_t run = fp_one();
-    for (uint32_t d = d0; d < d0 + 16; ++d) {
-        if (d == 0) continue;
-        const fp_t z = J[(size_t) d * m + j].Z;
-        pre[(size_t) d * m + j] = run;
-        if (!fp_is_zero(z)) run = fp_mul(run, z);
-    }
-    fp_t inv = fp_inv(run);
-    for (uint32_t d = d0 + 16; d-- > d0;) {
-        if (d == 0) continue;
-        const g1j_t Q = J[(size_t) d * m + j];
-        g1a_t a;
-        if (fp_is_zero(Q.Z)) { a.x = fp_zero(); a.y = fp_zero(); }
-        else {
-            const fp_t zi = fp_mul(inv, pre[(size_t) d * m + j]);
-            inv = fp_mul(inv, Q.Z);
-            const fp_t zi2 = fp_sqr(zi);
-            a.x = fp_mul(Q.X, zi2);
-            a.y = fp_mul(fp_mul(Q.Y, zi2), zi);
-        }
-        D[(size_t) d * m + j] = a;
-    }
-}
-
-// Row commitment when (almost) every scalar is a signed byte: ONE mixed addition per non-zero scalar, taken
-// from the digit table. Scalars with higher bytes only contribute their low byte here and flag the row; the
-// caller adds their remaining windows with k_msm_planes(w_lo = 1). out[row * gridDim.x + chunk]
-__global__ void __launch_bounds__(MSM_BLOCK) k_msm_digit(g1j_t *out, uint32_t *hi_flags, const fr_t *scalars, uint64_t ld,
-                                                    const g1a_t *D, uint32_t m, uint32_t cols, uint32_t cpt) {
-    __shared__ g1j_t sm[MSM_BLOCK];
-    const uint32_t row = blockIdx.y, chunk = blockIdx.x;
-    g1j_t acc = g1_inf();
-    bool hi = false;
-    for (uint32_t i = 0; i < cpt; ++i) {
-        const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + threadIdx.x;
-        if (c >= cols) break;
-        const fr_t raw = fr_load(scalars + (size_t) row * ld + c);
-        if (fr_is_zero(raw)) continue;
-        bool neg;
-        const fr_t s = fr_signed_magnitude(raw, neg);
-        uint32_t rest = s.v[0] >> 8;
-#pragma unroll
-        for (int k = 1; k < 8; ++k) rest |= s.v[k];
-        hi |= rest != 0;
-        const uint32_t d = s.v[0] & 0xffu;
-        if (d) {
-            g1a_t pt = D[(size_t) d * m + c];
-            if (neg) pt.y = fp_neg(pt.y);
-            acc = g1_madd(acc, pt);
-        }
-    }
-    if (hi) hi_flags[row] = 1;
-    sm[threadIdx.x] = acc;
-    __syncthreads();
-    for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
-        if (threadIdx.x < s) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + s]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[(size_t) row * gridDim.x + chunk] = sm[0];
-}
-// rows[r] = sum of its `nparts` chunk sums
-__global__ void k_sum_parts(g1j_t *rows, const g1j_t *parts, uint32_t nparts, uint32_t n) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    g1j_t acc = parts[(size_t) r * nparts];
-    for (uint32_t p = 1; p < nparts; ++p) acc = g1_add(acc, parts[(size_t) r * nparts + p]);
-    rows[r] = acc;
-}
-// rows[list[i]] += extra[i]
-__global__ void k_add_rows(g1j_t *rows, const g1j_t *extra, const uint32_t *list, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) rows[list[i]] = g1_add(rows[list[i]], extra[i]);
-}
-
-// ---- byte-table path: every non-zero byte of every scalar is ONE mixed addition from F[w][d][j] ----
-// grid (chunks * wsplit, rows). A thread walks `cpt` columns and the windows of its group; out[row * gridDim.x + part].
-__global__ void __launch_bounds__(MSM_BLOCK) k_msm_bytes(g1j_t *out, const fr_t *scalars, uint64_t ld, const uint32_t *idx_base,
-                                                         const g1a_t *F, uint32_t m, uint32_t cols, uint32_t cpt, uint32_t wsplit) {
-    __shared__ g1j_t sm[MSM_BLOCK];
-    const uint32_t row = blockIdx.y;
-    const uint32_t wg = blockIdx.x % wsplit, chunk = blockIdx.x / wsplit;
-    const uint32_t wpg = MSM_WINDOWS / wsplit, w0 = wg * wpg, w1 = w0 + wpg;
-    const uint32_t *idx = idx_base ? idx_base + (size_t) row * ld : nullptr;
-    g1j_t acc = g1_inf();
-    for (uint32_t i = 0; i < cpt; ++i) {
-        const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + threadIdx.x;
-        if (c >= cols) break;
-        const fr_t raw = fr_load(scalars + (size_t) row * ld + c);
-        if (fr_is_zero(raw)) continue;
-        bool neg;
-        const fr_t s = fr_signed_magnitude(raw, neg);
-        const uint32_t j = idx ? idx[c] : c;
-        int top = 7;                                  // highest non-zero limb: small scalars leave after their last byte
-        while (top > 0 && s.v[top] == 0) --top;
-        const uint32_t wend = min(w1, (uint32_t) (4 * top + 4));
-        for (uint32_t w = w0; w < wend; ++w) {
-            const uint32_t byte = (s.v[w >> 2] >> ((w & 3) * 8)) & 0xffu;
-            if (byte) {
-                g1a_t pt = F[((size_t) w * 256 + byte) * m + j];
-                if (neg) pt.y = fp_neg(pt.y);
-                acc = g1_madd_i(acc, pt);
-            }
-        }
-    }
-    if (!__syncthreads_or(!g1_is_inf(acc))) {
-        if (threadIdx.x == 0) out[(size_t) row * gridDim.x + blockIdx.x] = acc;
-        return;
-    }
-    sm[threadIdx.x] = acc;
-    __syncthreads();
-    for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
-        if (threadIdx.x < s) sm[threadIdx.x] = g1_add_i(sm[threadIdx.x], sm[threadIdx.x + s]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[(size_t) row * gridDim.x + blockIdx.x] = sm[0];
-}
-// out[row * gridDim.x + b] = sum of in[row * nin + 64 b .. 64 b + 63]  (one tree level of width 64 per launch)
-__global__ void __launch_bounds__(MSM_BLOCK) k_tree_reduce(g1j_t *out, const g1j_t *in, uint32_t nin) {
-    __shared__ g1j_t sm[MSM_BLOCK];
-    const uint32_t row = blockIdx.y, p = blockIdx.x * MSM_BLOCK + threadIdx.x;
-    sm[threadIdx.x] = p < nin ? in[(size_t) row * nin + p] : g1_inf();
-    __syncthreads();
-    for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
-        if (threadIdx.x < s) sm[threadIdx.x] = g1_add_i(sm[threadIdx.x], sm[threadIdx.x + s]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[(size_t) row * gridDim.x + blockIdx.x] = sm[0];
-}
-
-// One block per row, one wave per bit plane: wave k sums the partial points of plane k (lane-strided, then a
-// tree through LDS) and pre-multiplies by 2^k (k doublings, the waves run concurrently); a final 3-level tree
-// adds the 8 weighted plane sums. Sequential depth: ceil(nparts/64) + 6 + 7 + 3 point operations.
-__global__ void __launch_bounds__(512) k_msm_finish(g1j_t *outJ, const g1j_t *partials, uint32_t nparts) {
-    __shared__ g1j_t sm[MSM_PLANES][32];
-    const uint32_t row = blockIdx.x, lane = threadIdx.x & 63, k = threadIdx.x >> 6;
-    g1j_t acc = g1_inf();
-    const g1j_t *src = partials + ((size_t) row * MSM_PLANES + k) * nparts;
-    for (uint32_t p = lane; p < nparts; p += 64) acc = g1_add(acc, src[p]);
-    const uint32_t live = nparts < 64 ? nparts : 64;          // lanes beyond this hold the point at infinity
-    if (lane >= 32) sm[k][lane - 32] = acc;
-    __syncthreads();
-    if (lane < 32) {
-        if (lane + 32 < live) acc = g1_add(acc, sm[k][lane]);
-    }
-    __syncthreads();
-    if (lane < 32) sm[k][lane] = acc;
-    __syncthreads();
-    for (uint32_t s = 16; s >= 1; s >>= 1) {
-        if (lane < s && lane + s < live) sm[k][lane] = g1_add(sm[k][lane], sm[k][lane + s]);
-        __syncthreads();
-    }
-    if (lane == 0) {
-        g1j_t R = sm[k][0];
-        for (uint32_t d = 0; d < k; ++d) R = g1_dbl(R);
-        sm[k][0] = R;
-    }
-    __syncthreads();
-    for (uint32_t s = MSM_PLANES / 2; s >= 1; s >>= 1) {
-        if (lane == 0 && k < s) sm[k][0] = g1_add(sm[k][0], sm[k + s][0]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) outJ[row] = sm[0][0];
-}
-
-// ---- batched Jacobian -> affine: ONE field inversion for all rows (Montgomery's trick), and that single inversion -- a
-// chain of ~570 dependent products, 1 ms on one GPU lane -- is done by the host between two small kernels (27 us on a CPU core).
-#define AFF_SEG 16
-// per thread: running products inside its segment of AFF_SEG points; seg[t] = product of the segment's Z (infinity counts as 1)
-__global__ void k_aff_prefix(fp_t *pre, fp_t *seg, const g1j_t *in, uint32_t n) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t * AFF_SEG >= n) return;
-    fp_t run = fp_one();
-    for (uint32_t i = t * AFF_SEG; i < min(n, (t + 1) * AFF_SEG); ++i) {
-        pre[i] = run;
-        const fp_t z = in[i].Z;
-        if (!fp_is_zero(z)) run = fp_mul(run, z);
-    }
-    seg[t] = run;
-}
-// single block: exclusive prefix and suffix products over the nseg segment products (in place), total product to *total
-__global__ void __launch_bounds__(1024) k_aff_scan(fp_t *seg_pre, fp_t *seg_suf, fp_t *total, const fp_t *seg, uint32_t nseg) {
-    __shared__ fp_t a[1024], b[1024];
-    const uint32_t t = threadIdx.x;
-    a[t] = t < nseg ? seg[t] : fp_one();                      // inclusive prefix
-    b[t] = t < nseg ? seg[nseg - 1 - t] : fp_one();           // inclusive prefix of the reversed sequence = suffix
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        fp_t x, y;
-        const bool on = t >= d;
-        if (on) { x = fp_mul(a[t], a[t - d]); y = fp_mul(b[t], b[t - d]); }
-        __syncthreads();
-        if (on) { a[t] = x; b[t] = y; }
-        __syncthreads();
-    }
-    if (t < nseg) {
-        seg_pre[t] = t ? a[t - 1] : fp_one();
-        seg_suf[t] = (nseg - 1 - t) ? b[nseg - 2 - t] : fp_one();
-    }
-    if (t == 0) *total = a[nseg - 1];
-}
-__global__ void k_aff_finish(g1a_t *out, const g1j_t *in, const fp_t *pre, const fp_t *seg_pre, const fp_t *seg_suf, const fp_t *total_inv,
-                             uint32_t n) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t * AFF_SEG >= n) return;
-    fp_t inv = fp_mul(fp_mul(*total_inv, seg_pre[t]), seg_suf[t]);        // 1 / (product of this segment's Z)
-    const uint32_t lo = t * AFF_SEG, hi = min(n, (t + 1) * AFF_SEG);
-    for (uint32_t i = hi; i-- > lo;) {
-        const g1j_t Q = in[i];
-        g1a_t r;
-        if (fp_is_zero(Q.Z)) { r.x = fp_zero(); r.y = fp_zero(); }
-        else {
-            const fp_t zi = fp_mul(inv, pre[i]);
-            inv = fp_mul(inv, Q.Z);
-            const fp_t zi2 = fp_sqr(zi);
-            r.x = fp_mul(Q.X, zi2);
-            r.y = fp_mul(fp_mul(Q.Y, zi2), zi);
-        }
-        out[i] = r;
-    }
-}
-
-__global__ void k_to_affine(g1a_t *out, const g1j_t *in, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = g1_to_affine(in[i]);
-}
-
-// scalars of the two cross terms of one inner-product round, expressed over the ORIGINAL generators:
-//   g^(k)_i = sum_{j = i mod len} coef[j] g_j, so  L = <a_lo, g_hi> = sum_{j: (j mod len) >= h} a[(j mod len) - h] coef[j] g_j
-__global__ void k_ipa_scalars(fr_t *sL, uint32_t *idxL, fr_t *sR, uint32_t *idxR, const fr_t *a, const fr_t *coef, uint32_t m,
-                              uint32_t len) {      // sL/sR and idxL/idxR are the two rows of one (2 x m/2) batch
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const uint32_t h = len >> 1, i = j & (len - 1), pos = (j / len) * h + (i & (h - 1));
-    const fr_t cj = fr_load(coef + j);
-    if (i >= h) {
-        fr_store(sL + pos, fr_mul(fr_load(a + i - h), cj));
-        idxL[pos] = j;
-    } else {
-        fr_store(sR + pos, fr_mul(fr_load(a + i + h), cj));
-        idxR[pos] = j;
-    }
-}
-
-// y[0] = <a_lo, b_hi>, y[1] = <a_hi, b_lo>; single block
-__global__ void __launch_bounds__(256) k_ipa_dots(fr_t *y, const fr_t *a, const fr_t *b, uint32_t h) {
-    __shared__ fr_t smem[2 * 256 / 64];
-    fr_t acc[2] = {fr_zero(), fr_zero()};
-    for (uint32_t i = threadIdx.x; i < h; i += 256) {
-        acc[0] = fr_add(acc[0], fr_mul(fr_load(a + i), fr_load(b + i + h)));
-        acc[1] = fr_add(acc[1], fr_mul(fr_load(a + i + h), fr_load(b + i)));
-    }
-    fr_block_sum<2>(acc, smem);
-    if (threadIdx.x == 0) { fr_store(y, acc[0]); fr_store(y + 1, acc[1]); }
-}
-
-// a' = a_lo + c a_hi, b' = c b_lo + b_hi (in place), coef[j] *= c for generators in the low half
-__global__ void k_ipa_fold(fr_t *a, fr_t *b, fr_t *coef, fr_t c, uint32_t m, uint32_t len) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t h = len >> 1;
-    if (j < m && (j & (len - 1)) < h) fr_store(coef + j, fr_mul(fr_load(coef + j), c));
-    if (j < h) {
-        fr_store(a + j, fr_add(fr_load(a + j), fr_mul(c, fr_load(a + j + h))));
-        fr_store(b + j, fr_add(fr_mul(c, fr_load(b + j)), fr_load(b + j + h)));
-    }
-}
-
-__global__ void k_fill(fr_t *dst, fr_t v, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) fr_store(dst + i, v);
-}
-
-// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static int32_t ensure_state(zk_ctx *ctx) {
     if (!ctx->msm) ctx->msm = new msm_state();
+    msm_state *s = ctx->msm;
+    if (!s->exc) {
+        ZK_HIP(hipMalloc((void **) &s->exc, 64));
+        ZK_HIP(hipMemsetAsync(s->exc, 0, 64, ctx->stream));
+    }
     return ZK_OK;
 }
 
@@ -483,6 +117,22 @@ static int32_t ensure_rows(zk_ctx *ctx, uint32_t rows) {
     return ZK_OK;
 }
 
+// d * base_j for d = 1..255 of `m` affine points (levels of doubling / adding, then a batched conversion to affine)
+static int32_t build_digit_table(zk_ctx *ctx, g1a_t *dst, const g1a_t *base, uint32_t m) {
+    msm_state *s = ctx->msm;
+    int32_t rc = regrow(ctx, &s->tbl_scratch, &s->tbl_scratch_cap, (size_t) 256 * m * (sizeof(g1j_t) + sizeof(fp_t)));
+    if (rc) return rc;
+    g1j_t *J = (g1j_t *) s->tbl_scratch;
+    fp_t *pre = (fp_t *) (J + (size_t) 256 * m);
+    for (uint32_t level = 0; level < 8; ++level) {
+        const uint32_t work = (1u << level) * m;
+        ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_digit_level, dim3((work + 63) / 64), dim3(64), J, base, m, level);
+    }
+    ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_digit_affine, dim3((16 * m + 63) / 64), dim3(64), dst, J, pre, m);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
 // full byte table for a generator set that is being used again (ZKCNN_MSM_FULL=0 keeps the bit-plane path)
 static int32_t ensure_full_table(zk_ctx *ctx) {
     msm_state *s = ctx->msm;
@@ -499,112 +149,11 @@ static int32_t ensure_full_table(zk_ctx *ctx) {
         }
         s->full_m = s->m;
     }
-    int32_t rc = regrow(ctx, &s->tbl_scratch, &s->tbl_scratch_cap, (size_t) 256 * m * (sizeof(g1j_t) + sizeof(fp_t)));
-    if (rc) return rc;
-    g1j_t *J = (g1j_t *) s->tbl_scratch;
-    fp_t *pre = (fp_t *) (J + (size_t) 256 * m);
     for (uint32_t w = 0; w < MSM_WINDOWS; ++w) {
-        for (uint32_t level = 0; level < 8; ++level) {
-            const uint32_t work = (1u << level) * m;
-            ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_digit_level, dim3((work + 63) / 64), dim3(64), J, s->tables + (size_t) w * m, m, level);
-        }
-        ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_digit_affine, dim3((16 * m + 63) / 64), dim3(64), s->full + (size_t) w * 256 * m, J, pre, m);
+        int32_t rc = build_digit_table(ctx, s->full + (size_t) w * 256 * m, s->tables + (size_t) w * m, m);
+        if (rc) return rc;
     }
-    ZK_HIP(hipGetLastError());
     s->full_ready = true;
-    return ZK_OK;
-}
-
-// MSMs through the byte table. Many rows: one block per row chunk walks all windows (small scalars stop early). Few rows
-// (the two cross terms of an inner-product round): one (column, window) term per thread, then 64-wide trees; the last
-// <= 64 partial points per row are summed on the host, where the result is needed anyway.
-static int32_t run_msm_bytes(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint32_t *idx, uint32_t rows, uint32_t cols) {
-    msm_state *s = ctx->msm;
-    int32_t rc;
-    if ((rc = ensure_rows(ctx, rows))) return rc;
-    const uint32_t per = (cols + MSM_BLOCK - 1) / MSM_BLOCK;
-    if (rows >= 64) {
-        const uint32_t cpt = std::max<uint32_t>(1, std::min<uint32_t>(64, per));
-        const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt);
-        g1j_t *dst = s->rowsJ;
-        if (chunks > 1) {
-            if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * chunks * sizeof(g1j_t)))) return rc;
-            dst = s->partials;
-        }
-        for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
-            const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
-            ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, k_msm_bytes, dim3(chunks, nr), dim3(MSM_BLOCK), dst + (size_t) r0 * chunks,
-                      scalars + (size_t) r0 * ld, ld, idx ? idx + (size_t) r0 * ld : nullptr, s->full, (uint32_t) s->m, cols, cpt, 1u);
-        }
-        if (chunks > 1) ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_sum_parts, dim3((rows + 63) / 64), dim3(64), s->rowsJ, s->partials, chunks, rows);
-        ZK_HIP(hipGetLastError());
-        return ZK_OK;
-    }
-    // few rows: spread (column, window) terms over the whole GPU
-    uint32_t cpt = 1;
-    while ((uint64_t) ((cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt)) * MSM_WINDOWS > 4096) cpt *= 2;
-    const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt);
-    uint32_t n = chunks * MSM_WINDOWS;
-    if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * n * sizeof(g1j_t)))) return rc;
-    if ((rc = regrow(ctx, (void **) &s->parts2, &s->parts2_cap, (size_t) rows * ((n + 63) / 64) * sizeof(g1j_t)))) return rc;
-    ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) rows * (double) cols, k_msm_bytes, dim3(n, rows), dim3(MSM_BLOCK), s->partials, scalars, ld, idx,
-              s->full, (uint32_t) s->m, cols, cpt, (uint32_t) MSM_WINDOWS);
-    g1j_t *cur = s->partials, *nxt = s->parts2;
-    while (n > 64 || (rows > 8 && n > 1)) {
-        const uint32_t n2 = (n + 63) / 64;
-        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_tree_reduce, dim3(n2, rows), dim3(MSM_BLOCK), nxt, cur, n);
-        std::swap(cur, nxt);
-        n = n2;
-    }
-    ZK_HIP(hipGetLastError());
-    if (rows > 8) {
-        ZK_HIP(hipMemcpyAsync(s->rowsJ, cur, (size_t) rows * sizeof(g1j_t), hipMemcpyDeviceToDevice, ctx->stream));
-        return ZK_OK;
-    }
-    std::vector<zkff::G1> part((size_t) rows * n);
-    ZK_HIP(hipMemcpyAsync(part.data(), cur, part.size() * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    for (uint32_t r = 0; r < rows; ++r) {
-        zkff::G1 acc = part[(size_t) r * n];
-        for (uint32_t k = 1; k < n; ++k) zkff::G1::add(acc, acc, part[(size_t) r * n + k]);
-        s->host_rows[r] = acc;
-    }
-    s->host_rows_valid = true;
-    return ZK_OK;
-}
-
-// rows independent MSMs over the cached generator tables; results (Jacobian) in s->rowsJ[0..rows)
-static int32_t run_msm(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint32_t *idx, uint32_t rows, uint32_t cols,
-                       const uint32_t *row_map = nullptr, uint32_t w_lo = 0, g1j_t *outJ = nullptr, bool sparse_windows = false) {
-    msm_state *s = ctx->msm;
-    s->host_rows_valid = false;
-    if (!row_map && !outJ && w_lo == 0) {
-        int32_t rc0 = ensure_full_table(ctx);
-        if (rc0) return rc0;
-        if (s->full_ready) return run_msm_bytes(ctx, scalars, ld, idx, rows, cols);
-    }
-    uint32_t wsplit, cpt;
-    const uint32_t per = (cols + MSM_BLOCK - 1) / MSM_BLOCK;
-    if (rows >= 64) { wsplit = 1; cpt = std::min<uint32_t>(64, per); }
-    else if (sparse_windows) { wsplit = 1; cpt = std::min<uint32_t>(8, per); }   // few non-zero windows: one block walks them all
-    else { wsplit = MSM_WINDOWS; cpt = std::min<uint32_t>(8, per); }
-    cpt = std::max<uint32_t>(cpt, 1);
-    const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt), nparts = chunks * wsplit;
-    int32_t rc;
-    if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * MSM_PLANES * nparts * sizeof(g1j_t)))) return rc;
-    if (s->rows_cap < rows) {
-        if (s->rowsJ) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->rowsJ)); ZK_HIP(hipFree(s->rowsA)); }
-        ZK_HIP(hipMalloc((void **) &s->rowsJ, (size_t) rows * sizeof(g1j_t)));
-        ZK_HIP(hipMalloc((void **) &s->rowsA, (size_t) rows * sizeof(g1a_t)));
-        s->rows_cap = rows;
-    }
-    // gridDim.z is limited to 65535 rows per launch
-    for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
-        const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
-        ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, k_msm_planes, dim3(nparts, MSM_PLANES, nr), dim3(MSM_BLOCK), s->partials + (size_t) r0 * MSM_PLANES * nparts, scalars + (row_map ? 0 : (size_t) r0 * ld), ld, idx, s->tables, (uint32_t) s->m, cols, cpt, wsplit, row_map ? row_map + r0 : nullptr, w_lo);
-    }
-    ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_msm_finish, dim3(rows), dim3(512), outJ ? outJ : s->rowsJ, s->partials, nparts);
-    ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
 
@@ -618,65 +167,195 @@ static int32_t ensure_digit_table(zk_ctx *ctx) {
         ZK_HIP(hipMalloc((void **) &s->digit, (size_t) 256 * m * sizeof(g1a_t)));
         s->digit_m = s->m;
     }
-    int32_t rc = regrow(ctx, &s->tbl_scratch, &s->tbl_scratch_cap, (size_t) 256 * m * (sizeof(g1j_t) + sizeof(fp_t)));
+    int32_t rc = build_digit_table(ctx, s->digit, s->tables, m);
     if (rc) return rc;
-    g1j_t *J = (g1j_t *) s->tbl_scratch;
-    fp_t *pre = (fp_t *) (J + (size_t) 256 * m);
-    for (uint32_t level = 0; level < 8; ++level) {
-        const uint32_t work = (1u << level) * m;
-        ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_digit_level, dim3((work + 63) / 64), dim3(64), J, s->tables, m, level);
-    }
-    ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_digit_affine, dim3((16 * m + 63) / 64), dim3(64), s->digit, J, pre, m);
-    ZK_HIP(hipGetLastError());
     s->digit_ready = true;
     return ZK_OK;
 }
 
-// commitments of `rows` rows of `cols` scalars (cols == number of cached generators): digit-table pass for the low
-// byte of every scalar, then the bit-plane path for the remaining windows of the (few) rows that have any
+// sums the `n` partial points of every row (row-major in `src`) into dst[row]
+static int32_t reduce_rows(zk_ctx *ctx, const g1j_t *src, uint32_t n, uint32_t rows, g1j_t *dst) {
+    if (n == 1) {
+        ZK_HIP(hipMemcpyAsync(dst, src, (size_t) rows * sizeof(g1j_t), hipMemcpyDeviceToDevice, ctx->stream));
+        return ZK_OK;
+    }
+    ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_reduce_rows16, dim3((rows + 3) / 4), dim3(MSM_BLOCK), dst, src, n, rows);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+// canonical signed magnitudes of the listed rows (all rows if row_map is null) into s->mag, dense rows of `cols` entries
+static int32_t scalar_mags(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint32_t *row_map, uint32_t rows, uint32_t cols) {
+    msm_state *s = ctx->msm;
+    int32_t rc = regrow(ctx, (void **) &s->mag, &s->mag_cap, (size_t) rows * cols * sizeof(fr_t));
+    if (rc) return rc;
+    for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
+        const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
+        ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_scalar_mags, dim3(std::min<uint32_t>((cols + 255) / 256, 64), nr), dim3(256), s->mag + (size_t) r0 * cols,
+                  row_map ? scalars : scalars + (size_t) r0 * ld, ld, row_map ? row_map + r0 : nullptr, cols);
+    }
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+// rows independent MSMs over the cached generator tables, every window >= w_lo of every scalar; scalars are read from s->mag
+// (scalar_mags ran before). idx (optional): generator index of every column, rows `ld` apart. Results (Jacobian) in `outJ` or, for
+// at most 8 rows without outJ, as short lists that fetch_points sums on the host.
+static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32_t rows, uint32_t cols, uint32_t w_lo, g1j_t *outJ) {
+    msm_state *s = ctx->msm;
+    int32_t rc;
+    const uint32_t nwin = MSM_WINDOWS - w_lo;
+    const uint32_t per = (cols + MSM_BLOCK - 1) / MSM_BLOCK;
+    if (s->full_ready) {
+        // spread (column chunk, window) blocks over the whole GPU: at most ~4096 blocks per row for few rows, one chunk per row for many
+        uint32_t cpt = rows >= 64 ? std::min<uint32_t>(64, per) : 1;
+        while (rows < 64 && (uint64_t) ((cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt)) * nwin > 4096) cpt *= 2;
+        cpt = std::max<uint32_t>(cpt, 1);
+        const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt);
+        uint32_t n = chunks * nwin;
+        if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * n * sizeof(g1j_t)))) return rc;
+        if ((rc = regrow(ctx, (void **) &s->parts2, &s->parts2_cap, (size_t) rows * ((n + 63) / 64) * sizeof(g1j_t)))) return rc;
+        for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
+            const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
+            const double bytes = 32.0 * (double) nr * (double) cols;
+            if (s->safe)
+                ZK_LAUNCH(PC_MSM_PLANES, bytes, k_msm_windows<true>, dim3(n, nr), dim3(MSM_BLOCK), s->partials + (size_t) r0 * n, s->exc, s->mag + (size_t) r0 * cols,
+                          ld, idx ? idx + (size_t) r0 * ld : nullptr, s->full, (uint32_t) s->m, cols, cpt, w_lo, nwin);
+            else
+                ZK_LAUNCH(PC_MSM_PLANES, bytes, k_msm_windows<false>, dim3(n, nr), dim3(MSM_BLOCK), s->partials + (size_t) r0 * n, s->exc, s->mag + (size_t) r0 * cols,
+                          ld, idx ? idx + (size_t) r0 * ld : nullptr, s->full, (uint32_t) s->m, cols, cpt, w_lo, nwin);
+        }
+        ZK_HIP(hipGetLastError());
+        if (outJ || rows > 8) {
+            // few rows with thousands of (mostly empty) partial points each: one 64-wide tree level first
+            g1j_t *cur = s->partials;
+            if (n > 256) {
+                const uint32_t n2 = (n + 63) / 64;
+                ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_tree_reduce, dim3(n2, rows), dim3(MSM_BLOCK), s->parts2, cur, n);
+                cur = s->parts2;
+                n = n2;
+            }
+            return reduce_rows(ctx, cur, n, rows, outJ ? outJ : s->rowsJ);
+        }
+        // few rows: 64-wide trees, the last <= 64 partial points per row are summed on the host, where the result is needed anyway
+        g1j_t *cur = s->partials, *nxt = s->parts2;
+        while (n > 64) {
+            const uint32_t n2 = (n + 63) / 64;
+            ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_tree_reduce, dim3(n2, rows), dim3(MSM_BLOCK), nxt, cur, n);
+            std::swap(cur, nxt);
+            n = n2;
+        }
+        ZK_HIP(hipGetLastError());
+        std::vector<zkff::G1> part((size_t) rows * n);
+        uint32_t exc = 0;
+        ZK_HIP(hipMemcpyAsync(part.data(), cur, part.size() * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(&exc, s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        if (exc && !s->safe) return ZK_RETRY_SAFE;
+        for (uint32_t r = 0; r < rows; ++r) {
+            zkff::G1 acc = part[(size_t) r * n];
+            for (uint32_t k = 1; k < n; ++k) zkff::G1::add(acc, acc, part[(size_t) r * n + k]);
+            s->host_rows[r] = acc;
+        }
+        s->host_rows_valid = true;
+        return ZK_OK;
+    }
+    // first use of the generators: bit planes over the window tables
+    uint32_t wsplit, cpt;
+    if (rows >= 64 || w_lo) { wsplit = 1; cpt = std::min<uint32_t>(rows >= 64 ? 64 : 8, per); }   // wide rows of a commitment: few non-zero windows, one block walks them all
+    else { wsplit = MSM_WINDOWS; cpt = std::min<uint32_t>(8, per); }
+    cpt = std::max<uint32_t>(cpt, 1);
+    const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt), nparts = chunks * wsplit;
+    if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * MSM_PLANES * nparts * sizeof(g1j_t)))) return rc;
+    for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {      // gridDim.z is limited to 65535
+        const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
+        ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, k_msm_planes, dim3(nparts, MSM_PLANES, nr), dim3(MSM_BLOCK),
+                  s->partials + (size_t) r0 * MSM_PLANES * nparts, s->mag + (size_t) r0 * cols, ld, idx ? idx + (size_t) r0 * ld : nullptr, s->tables,
+                  (uint32_t) s->m, cols, cpt, wsplit, w_lo);
+    }
+    ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_msm_finish, dim3(rows), dim3(512), outJ ? outJ : s->rowsJ, s->partials, nparts);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+// rows independent MSMs with full-width scalars (Montgomery form, rows `ld` apart); results in s->rowsJ / s->host_rows
+static int32_t run_msm(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint32_t *idx, uint32_t rows, uint32_t cols) {
+    msm_state *s = ctx->msm;
+    s->host_rows_valid = false;
+    int32_t rc;
+    if ((rc = ensure_full_table(ctx)) || (rc = ensure_rows(ctx, rows)) || (rc = scalar_mags(ctx, scalars, ld, nullptr, rows, cols))) return rc;
+    return msm_windows(ctx, idx, ld, rows, cols, 0, nullptr);
+}
+
+// commitments of `rows` rows of `cols` scalars (cols == number of cached generators): every scalar's low byte through the digit
+// table (k_msm_codes), then the remaining windows of the (few) rows that hold wider scalars
 static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32_t rows, uint32_t cols) {
     msm_state *s = ctx->msm;
     int32_t rc;
     s->host_rows_valid = false;
     if ((rc = ensure_full_table(ctx))) return rc;
-    if (s->full_ready && rows >= 64) return run_msm_bytes(ctx, scalars, ld, nullptr, rows, cols);
-    if ((rc = ensure_digit_table(ctx))) return rc;
-    const uint32_t cpt = std::max<uint32_t>(1, std::min<uint32_t>(64, (cols + MSM_BLOCK - 1) / MSM_BLOCK));
-    const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt);
-    if (s->rows_cap < rows) {
-        if (s->rowsJ) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->rowsJ)); ZK_HIP(hipFree(s->rowsA)); }
-        ZK_HIP(hipMalloc((void **) &s->rowsJ, (size_t) rows * sizeof(g1j_t)));
-        ZK_HIP(hipMalloc((void **) &s->rowsA, (size_t) rows * sizeof(g1a_t)));
-        s->rows_cap = rows;
+    const g1a_t *D = s->full;                               // F[0][d][j] = d g_j
+    if (!s->full_ready) {
+        if ((rc = ensure_digit_table(ctx))) return rc;
+        D = s->digit;
     }
-    if (s->flags_cap < rows) {
+    if ((rc = ensure_rows(ctx, rows))) return rc;
+    if (s->flags_cap < rows + 1) {
         if (s->hi_flags) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->hi_flags)); ZK_HIP(hipFree(s->row_list)); }
-        ZK_HIP(hipMalloc((void **) &s->hi_flags, (size_t) rows * 4));
-        ZK_HIP(hipMalloc((void **) &s->row_list, (size_t) rows * 4));
-        s->flags_cap = rows;
+        ZK_HIP(hipMalloc((void **) &s->hi_flags, ((size_t) rows + 1) * 4));
+        ZK_HIP(hipMalloc((void **) &s->row_list, ((size_t) rows + 1) * 4));
+        s->flags_cap = rows + 1;
     }
-    ZK_HIP(hipMemsetAsync(s->hi_flags, 0, (size_t) rows * 4, ctx->stream));
-    g1j_t *dst = s->rowsJ;
-    if (chunks > 1) {
-        if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * chunks * sizeof(g1j_t)))) return rc;
-        dst = s->partials;
-    }
+    ZK_HIP(hipMemsetAsync(s->hi_flags, 0, ((size_t) rows + 1) * 4, ctx->stream));
+    if ((rc = regrow(ctx, (void **) &s->codes, &s->codes_cap, (size_t) rows * cols * 2))) return rc;
+    const uint32_t cpt = std::max<uint32_t>(1, std::min<uint32_t>(64, (cols + MSM_BLOCK - 1) / MSM_BLOCK));
+    const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt), n = chunks * MSM_BLOCK;
+    if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * n * sizeof(g1j_t)))) return rc;
     for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
         const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
-        ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, k_msm_digit, dim3(chunks, nr), dim3(MSM_BLOCK),
-                  dst + (size_t) r0 * chunks, s->hi_flags + r0, scalars + (size_t) r0 * ld, ld, s->digit, (uint32_t) s->m, cols, cpt);
+        ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_scalar_codes, dim3(std::min<uint32_t>((cols + 255) / 256, 64), nr), dim3(256), s->codes + (size_t) r0 * cols,
+                  s->hi_flags + r0, scalars + (size_t) r0 * ld, ld, cols);
+        const double bytes = 32.0 * (double) nr * (double) cols;
+        if (s->safe)
+            ZK_LAUNCH(PC_MSM_PLANES, bytes, k_msm_codes<true>, dim3(chunks, nr), dim3(MSM_BLOCK), s->partials + (size_t) r0 * n, s->exc,
+                      s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, 0u);
+        else
+            ZK_LAUNCH(PC_MSM_PLANES, bytes, k_msm_codes<false>, dim3(chunks, nr), dim3(MSM_BLOCK), s->partials + (size_t) r0 * n, s->exc,
+                      s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, 0u);
     }
-    if (chunks > 1) ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_sum_parts, dim3((rows + 63) / 64), dim3(64), s->rowsJ, s->partials, chunks, rows);
     ZK_HIP(hipGetLastError());
-    std::vector<uint32_t> flags(rows), list;
+    if ((rc = reduce_rows(ctx, s->partials, n, rows, s->rowsJ))) return rc;
+    std::vector<uint32_t> flags((size_t) rows + 1), list;
     ZK_HIP(hipMemcpyAsync(flags.data(), s->hi_flags, (size_t) rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(&flags[rows], s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (flags[rows] && !s->safe) return ZK_RETRY_SAFE;
     for (uint32_t r = 0; r < rows; ++r) if (flags[r]) list.push_back(r);
     if (list.empty()) return ZK_OK;
     const uint32_t nl = (uint32_t) list.size();
     ZK_HIP(hipMemcpyAsync(s->row_list, list.data(), (size_t) nl * 4, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = regrow(ctx, (void **) &s->tmpJ, &s->tmp_cap, (size_t) nl * sizeof(g1j_t)))) return rc;
-    if ((rc = run_msm(ctx, scalars, ld, nullptr, nl, cols, s->row_list, 1, s->tmpJ, true))) return rc;
+    if (s->full_ready) {
+        // windows 1..31 of the wide rows as 31 virtual rows each of the same hot kernel, then 31 -> 1 per wide row
+        const uint32_t nv = nl * (MSM_WINDOWS - 1);
+        if (nv > 65535) { ctx->err = "commit: too many rows with wide scalars"; return ZK_ERR_ARG; }
+        if ((rc = regrow(ctx, (void **) &s->codes_v, &s->codes_v_cap, (size_t) nv * cols * 2))) return rc;
+        if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) nv * n * sizeof(g1j_t)))) return rc;
+        if ((rc = regrow(ctx, (void **) &s->parts2, &s->parts2_cap, (size_t) nv * sizeof(g1j_t)))) return rc;
+        ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_scalar_codes_wide, dim3(std::min<uint32_t>((cols + 255) / 256, 64), nl), dim3(256), s->codes_v, scalars, ld, s->row_list, cols);
+        if (s->safe)
+            ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_msm_codes<true>, dim3(chunks, nv), dim3(MSM_BLOCK), s->partials, s->exc, s->codes_v, s->full, (uint32_t) s->m, cols, cpt,
+                      (uint32_t) (MSM_WINDOWS - 1));
+        else
+            ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_msm_codes<false>, dim3(chunks, nv), dim3(MSM_BLOCK), s->partials, s->exc, s->codes_v, s->full, (uint32_t) s->m, cols, cpt,
+                      (uint32_t) (MSM_WINDOWS - 1));
+        ZK_HIP(hipGetLastError());
+        if ((rc = reduce_rows(ctx, s->partials, n, nv, s->parts2))) return rc;
+        if ((rc = reduce_rows(ctx, s->parts2, MSM_WINDOWS - 1, nl, s->tmpJ))) return rc;
+    } else {
+        if ((rc = scalar_mags(ctx, scalars, ld, s->row_list, nl, cols))) return rc;
+        if ((rc = msm_windows(ctx, nullptr, cols, nl, cols, 1, s->tmpJ))) return rc;
+    }
     ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_add_rows, dim3((nl + 63) / 64), dim3(64), s->rowsJ, s->tmpJ, s->row_list, nl);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
@@ -685,12 +364,14 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
 // few points: Jacobian -> affine on the host (one inversion each); many: on the device
 static int32_t fetch_points(zk_ctx *ctx, uint32_t rows, uint64_t *out) {
     msm_state *s = ctx->msm;
+    const uint32_t AFF_SEG = std::max<uint32_t>(4, (rows + 1023) / 1024);      // short per-thread chains; the single-block scan takes up to 1024 segments
     const uint32_t nseg = (rows + AFF_SEG - 1) / AFF_SEG;
+    uint32_t exc = 0;                    // set by a fast-variant kernel that met P = +-Q: the caller repeats the batch with the SAFE kernels
     if (rows > 8 && nseg <= 1024) {
         int32_t rc = regrow(ctx, &s->aff_scratch, &s->aff_cap, ((size_t) rows + 3 * (size_t) nseg + 2) * sizeof(fp_t));
         if (rc) return rc;
         fp_t *pre = (fp_t *) s->aff_scratch, *seg = pre + rows, *seg_pre = seg + nseg, *seg_suf = seg_pre + nseg, *tot = seg_suf + nseg;
-        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_aff_prefix, dim3((nseg + 63) / 64), dim3(64), pre, seg, s->rowsJ, rows);
+        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_aff_prefix, dim3((nseg + 63) / 64), dim3(64), pre, seg, s->rowsJ, rows, AFF_SEG);
         ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_aff_scan, dim3(1), dim3(1024), seg_pre, seg_suf, tot, seg, nseg);
         ZK_HIP(hipGetLastError());
         zkff::Fp total, inv;
@@ -698,31 +379,50 @@ static int32_t fetch_points(zk_ctx *ctx, uint32_t rows, uint64_t *out) {
         ZK_HIP(hipStreamSynchronize(ctx->stream));
         zkff::Fp::invert(inv, total);                      // the one sequential inversion: O(1) host work, like add_term
         ZK_HIP(hipMemcpyAsync(tot + 1, &inv, sizeof(fp_t), hipMemcpyHostToDevice, ctx->stream));
-        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_aff_finish, dim3((nseg + 63) / 64), dim3(64), s->rowsA, s->rowsJ, pre, seg_pre, seg_suf, tot + 1, rows);
+        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_aff_finish, dim3((nseg + 63) / 64), dim3(64), s->rowsA, s->rowsJ, pre, seg_pre, seg_suf, tot + 1, rows, AFF_SEG);
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipMemcpyAsync(out, s->rowsA, (size_t) rows * sizeof(g1a_t), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(&exc, s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
         ZK_HIP(hipStreamSynchronize(ctx->stream));
-        return ZK_OK;
+        return exc && !s->safe ? ZK_RETRY_SAFE : ZK_OK;
     }
     if (rows > 8) {
         ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_to_affine, dim3((rows + 63) / 64), dim3(64), s->rowsA, s->rowsJ, rows);
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipMemcpyAsync(out, s->rowsA, (size_t) rows * sizeof(g1a_t), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(&exc, s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
         ZK_HIP(hipStreamSynchronize(ctx->stream));
-        return ZK_OK;
+        return exc && !s->safe ? ZK_RETRY_SAFE : ZK_OK;
     }
     zkff::G1 pj[8];
     if (s->host_rows_valid) {
         for (uint32_t i = 0; i < rows; ++i) pj[i] = s->host_rows[i];
     } else {
         ZK_HIP(hipMemcpyAsync(pj, s->rowsJ, (size_t) rows * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(&exc, s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
         ZK_HIP(hipStreamSynchronize(ctx->stream));
+        if (exc && !s->safe) return ZK_RETRY_SAFE;
     }
     for (uint32_t i = 0; i < rows; ++i) {
         zkff::G1Affine a = pj[i].toAffine();
         std::memcpy(out + 12 * i, &a, 96);
     }
     return ZK_OK;
+}
+
+// runs `body` with the fast kernels; if one of them flagged an exceptional addition, once more with the SAFE variants
+template <class Body>
+static int32_t with_safe_retry(zk_ctx *ctx, Body body) {
+    msm_state *s = ctx->msm;
+    s->safe = false;
+    ZK_HIP(hipMemsetAsync(s->exc, 0, 4, ctx->stream));
+    int32_t rc = body();
+    if (rc != ZK_RETRY_SAFE) return rc;
+    s->safe = true;
+    ZK_HIP(hipMemsetAsync(s->exc, 0, 4, ctx->stream));
+    rc = body();
+    s->safe = false;
+    return rc;
 }
 
 static_assert(sizeof(zkff::G1) == sizeof(g1j_t) && sizeof(zkff::G1Affine) == sizeof(g1a_t), "host / device point layouts must agree");
@@ -739,8 +439,10 @@ extern "C" int32_t zk_commit_input(zk_ctx *ctx, const uint64_t *gens, uint64_t n
     if ((rc = ensure_state(ctx)) || (rc = ensure_tables(ctx, gens, n_gens))) return rc;
     ctx->msm->rb = rb;
     ctx->msm->cb = cb;
-    if ((rc = commit_rows(ctx, L0.val, n_gens, (uint32_t) n_rows, (uint32_t) n_gens))) return rc;
-    return fetch_points(ctx, (uint32_t) n_rows, out_comm);
+    return with_safe_retry(ctx, [&]() -> int32_t {
+        int32_t r = commit_rows(ctx, L0.val, n_gens, (uint32_t) n_rows, (uint32_t) n_gens);
+        return r ? r : fetch_points(ctx, (uint32_t) n_rows, out_comm);
+    });
 }
 
 extern "C" int32_t zk_hyrax_open_init(zk_ctx *ctx, const uint64_t *x, uint32_t n) {
@@ -781,8 +483,11 @@ extern "C" int32_t zk_hyrax_open_round(zk_ctx *ctx, uint64_t Lp[12], uint64_t Rp
     // two MSMs over m/2 generators each = the two rows of one batch (row stride m/2 for scalars and indices)
     int32_t rc;
     uint64_t pts[24];
-    if ((rc = run_msm(ctx, s->sL, m / 2, s->idxL, 2, m / 2))) return rc;
-    if ((rc = fetch_points(ctx, 2, pts))) return rc;
+    rc = with_safe_retry(ctx, [&]() -> int32_t {
+        int32_t r = run_msm(ctx, s->sL, m / 2, s->idxL, 2, m / 2);
+        return r ? r : fetch_points(ctx, 2, pts);
+    });
+    if (rc) return rc;
     ZK_HIP(hipMemcpyAsync(ctx->h_result, s->d_y, 64, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     std::memcpy(Lp, pts, 96);
@@ -822,8 +527,10 @@ extern "C" int32_t zk_k_msm(zk_ctx *ctx, uint64_t out[12], const uint64_t *scala
     if ((rc = ensure_state(ctx)) || (rc = ensure_tables(ctx, bases, n))) return rc;
     if ((rc = zk_scratch(ctx, n * 32))) return rc;
     ZK_HIP(hipMemcpyAsync(ctx->scratch.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = run_msm(ctx, (const fr_t *) ctx->scratch.p, n, nullptr, 1, (uint32_t) n))) return rc;
-    return fetch_points(ctx, 1, out);
+    return with_safe_retry(ctx, [&]() -> int32_t {
+        int32_t r = run_msm(ctx, (const fr_t *) ctx->scratch.p, n, nullptr, 1, (uint32_t) n);
+        return r ? r : fetch_points(ctx, 1, out);
+    });
 }
 
 // rows x cols row commitments over `cols` arbitrary bases: the commitInput data path on caller-supplied data
@@ -835,6 +542,8 @@ extern "C" int32_t zk_k_commit_rows(zk_ctx *ctx, uint64_t *out, const uint64_t *
     if ((rc = ensure_state(ctx)) || (rc = ensure_tables(ctx, bases, cols))) return rc;
     if ((rc = zk_scratch(ctx, rows * cols * 32))) return rc;
     ZK_HIP(hipMemcpyAsync(ctx->scratch.p, scalars, rows * cols * 32, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = commit_rows(ctx, (const fr_t *) ctx->scratch.p, cols, (uint32_t) rows, (uint32_t) cols))) return rc;
-    return fetch_points(ctx, (uint32_t) rows, out);
+    return with_safe_retry(ctx, [&]() -> int32_t {
+        int32_t r = commit_rows(ctx, (const fr_t *) ctx->scratch.p, cols, (uint32_t) rows, (uint32_t) cols);
+        return r ? r : fetch_points(ctx, (uint32_t) rows, out);
+    });
 }

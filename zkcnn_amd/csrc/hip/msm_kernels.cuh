@@ -1,0 +1,612 @@
+// Multi-scalar-multiplication kernels of the Hyrax commitment (K13 / K14 in SURVEY.md) for gfx950.
+// They replace the Pedersen row commitments and the inner-product-argument cross terms of the absent upstream library
+// hyrax-bls12-381 (call sites: reference src/prover.cpp:503-511, src/verifier.cpp:128,360).
+//
+// Shape of the work: MANY MSMs over ONE generator vector (4096 rows x 4096 generators for vgg11), scalars almost all tiny and
+// signed (bits, 9-bit quantised weights), a few rows with wide scalars, and -- in the opening -- two MSMs per round with
+// full-width scalars. Tables remove every doubling: D[d][j] = d g_j (first use of a generator set) and, once a set is used
+// again, F[w][d][j] = d 2^(8w) g_j, so every non-zero scalar BYTE is one mixed addition.
+//
+// Pipeline of a commitment:
+//   k_scalar_codes   scalar (Montgomery) -> 16-bit code: low byte of |s|, sign, "wide" flag; per-row wide flag      (HBM bound)
+//   k_msm_codes      one wave per row chunk; a lane walks ITS non-zero codes only (bit mask built up front), the next table point
+//                    is fetched while the current mixed addition runs; every lane leaves one Jacobian partial sum   (integer ALU)
+//   k_sum_groups     partial sums of a row, 4 at a time per thread, full lanes (no half-empty reduction tree in the hot kernel)
+//   k_scalar_mags + k_msm_windows   rows flagged wide: their windows >= 1 through F (or the bit-plane kernel on first use)
+// Mixed additions are written for register pressure: 11 calls of the one shared Fp product (g1_dev.cuh: fp_mul_r), at most six Fp
+// values live across a call, exceptional cases (P = +-Q, negligible for random generators) only flagged in the fast variant; the
+// host re-runs a flagged batch with the SAFE variant that handles them in place. No scratch memory in any of these kernels.
+#pragma once
+#include "g1_dev.cuh"
+
+#define MSM_WINDOWS 32
+#define MSM_PLANES 8
+#define MSM_BLOCK 64                 // one wave per block: reduction trees of 6 levels, many blocks per CU
+#define MSM_CODE_NEG 0x100u
+#define MSM_CODE_WIDE 0x200u
+
+// ---- exceptional-case aware in-place point operations on separate coordinate registers ----
+// doubling, a = 0 (dbl-2009-l); Z == 0 stays Z == 0
+__device__ __forceinline__ void g1_dbl_ip(fp_t &X, fp_t &Y, fp_t &Z) {
+    Z = fp_mul(Y, Z);
+    Z = fp_dbl(Z);                         // Z3 = 2 Y Z
+    fp_t A = fp_sqr(X), B = fp_sqr(Y);
+    fp_t C = fp_sqr(B);
+    B = fp_add(X, B);
+    B = fp_sqr(B);
+    B = fp_sub(fp_sub(B, A), C);
+    B = fp_dbl(B);                         // D = 2 ((X + B)^2 - A - C)
+    A = fp_add(fp_dbl(A), A);              // E = 3 A
+    X = fp_sqr(A);
+    X = fp_sub(X, fp_dbl(B));              // X3 = E^2 - 2 D
+    B = fp_sub(B, X);
+    B = fp_mul(A, B);
+    C = fp_dbl(fp_dbl(fp_dbl(C)));
+    Y = fp_sub(B, C);                      // Y3 = E (D - X3) - 8 C
+}
+
+// (X, Y, Z) += (px, py) for a finite accumulator and a finite affine point. px / py are clobbered. Returns false -- and leaves the
+// accumulator untouched -- when the two points have equal x (P = +-Q); *same then tells which.
+// Order chosen so that at most six field elements are live across any call (7 M + 4 S, madd-2007-bl without the doubling trick).
+__device__ __forceinline__ bool g1_madd_ip(fp_t &X, fp_t &Y, fp_t &Z, fp_t &px, fp_t &py, bool *same) {
+    fp_t A = fp_sqr(Z);                    // Z1Z1
+    px = fp_mul(px, A);                    // U2
+    py = fp_mul(py, Z);
+    py = fp_mul(py, A);                    // S2
+    px = fp_sub(px, X);                    // H
+    py = fp_sub(py, Y);                    // R
+    if (fp_is_zero(px)) {
+        *same = fp_is_zero(py);
+        return false;
+    }
+    Z = fp_mul(Z, px);                     // Z3 = Z1 H
+    A = fp_sqr(px);                        // HH
+    px = fp_mul(px, A);                    // HHH
+    A = fp_mul(X, A);                      // V
+    X = fp_sqr(py);
+    X = fp_sub(fp_sub(X, px), fp_dbl(A));  // X3 = R^2 - HHH - 2 V
+    A = fp_sub(A, X);
+    A = fp_mul(py, A);                     // R (V - X3)
+    Y = fp_mul(Y, px);                     // Y1 HHH
+    Y = fp_sub(A, Y);
+    return true;
+}
+
+__device__ __forceinline__ void g1a_load(fp_t &x, fp_t &y, const g1a_t *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
+    x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w; x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
+    x.v[8] = c.x; x.v[9] = c.y; x.v[10] = c.z; x.v[11] = c.w;
+    y.v[0] = d.x; y.v[1] = d.y; y.v[2] = d.z; y.v[3] = d.w; y.v[4] = e.x; y.v[5] = e.y; y.v[6] = e.z; y.v[7] = e.w;
+    y.v[8] = f.x; y.v[9] = f.y; y.v[10] = f.z; y.v[11] = f.w;
+}
+__device__ __forceinline__ void fp_store16(fp_t *p, const fp_t &a) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+    q[2] = make_uint4(a.v[8], a.v[9], a.v[10], a.v[11]);
+}
+__device__ __forceinline__ void g1j_store(g1j_t *p, const fp_t &X, const fp_t &Y, const fp_t &Z, bool empty) {
+    fp_store16(&p->X, empty ? fp_zero() : X);
+    fp_store16(&p->Y, empty ? fp_one() : Y);
+    fp_store16(&p->Z, empty ? fp_zero() : Z);
+}
+
+// one accumulation step shared by the MSM kernels: acc += +-pt, with the first point, infinity and P = +-Q handled
+template <bool SAFE>
+__device__ __forceinline__ void g1_accumulate(fp_t &X, fp_t &Y, fp_t &Z, bool &empty, fp_t &px, fp_t &py, bool neg, bool &exc) {
+    if (fp_is_zero(px) && fp_is_zero(py)) return;          // (0, 0) = the point at infinity (a generator may be)
+    if (neg) py = fp_neg(py);
+    if (empty) {
+        X = px; Y = py; Z = fp_one();
+        empty = false;
+        return;
+    }
+    bool same = false;
+    if (!g1_madd_ip(X, Y, Z, px, py, &same)) {
+        if (SAFE) {
+            if (same) g1_dbl_ip(X, Y, Z);
+            else empty = true;             // P + (-P)
+        } else exc = true;                 // the host repeats the batch with SAFE = true
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalar pre-passes
+// ------------------------------------------------------------------------------------------------
+// codes[row * cols + c]: bits 0..7 low byte of |s| (|s| <= (r-1)/2), MSM_CODE_NEG, MSM_CODE_WIDE when |s| >= 256;
+// row_flags[row] = 1 if the row holds a wide scalar (the caller then adds that row's higher windows, see k_scalar_codes_wide)
+__global__ void __launch_bounds__(256) k_scalar_codes(uint16_t *codes, uint32_t *row_flags, const fr_t *scalars, uint64_t ld, uint32_t cols) {
+    const uint32_t row = blockIdx.y;
+    bool wide = false;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
+        const fr_t raw = fr_load(scalars + (size_t) row * ld + c);
+        uint32_t code = 0;
+        if (!fr_is_zero(raw)) {
+            bool neg;
+            const fr_t s = fr_signed_magnitude(raw, neg);
+            uint32_t rest = s.v[0] >> 8;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) rest |= s.v[k];
+            code = (s.v[0] & 0xffu) | (neg ? MSM_CODE_NEG : 0u) | (rest ? MSM_CODE_WIDE : 0u);
+            wide |= rest != 0;
+        }
+        codes[(size_t) row * cols + c] = (uint16_t) code;
+    }
+    if (wide) row_flags[row] = 1;
+}
+
+// The higher windows of the rows that hold wide scalars (biases, maxima, the picture: whole rows of 2..4-byte values), as VIRTUAL rows
+// of the same hot kernel: codes[(ri * 31 + w - 1) * cols + c] = byte w of |scalars[row_list[ri]][c]| with its sign, w = 1..31.
+// k_msm_codes takes virtual row v through window table 1 + v % 31; windows no scalar reaches are rows of zeros that cost nothing.
+__global__ void __launch_bounds__(256) k_scalar_codes_wide(uint16_t *codes, const fr_t *scalars, uint64_t ld, const uint32_t *row_list, uint32_t cols) {
+    const uint32_t ri = blockIdx.y, row = row_list[ri];
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
+        const fr_t raw = fr_load(scalars + (size_t) row * ld + c);
+        fr_t s = raw;
+        bool neg = false;
+        if (!fr_is_zero(raw)) s = fr_signed_magnitude(raw, neg);
+        const uint32_t sign = neg ? MSM_CODE_NEG : 0u;
+#pragma unroll
+        for (uint32_t w = 1; w < MSM_WINDOWS; ++w) {
+            const uint32_t byte = (s.v[w >> 2] >> ((w & 3) * 8)) & 0xffu;
+            codes[((size_t) ri * (MSM_WINDOWS - 1) + (w - 1)) * cols + c] = (uint16_t) (byte ? (byte | sign) : 0u);
+        }
+    }
+}
+
+// mag[ri * cols + c] = |s| of scalars[row][c] as a canonical integer, sign in bit 255 (|s| < 2^254); row = row_map ? row_map[ri] : ri
+__global__ void __launch_bounds__(256) k_scalar_mags(fr_t *mag, const fr_t *scalars, uint64_t ld, const uint32_t *row_map, uint32_t cols) {
+    const uint32_t ri = blockIdx.y, row = row_map ? row_map[ri] : ri;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
+        const fr_t raw = fr_load(scalars + (size_t) row * ld + c);
+        fr_t s = raw;
+        if (!fr_is_zero(raw)) {
+            bool neg;
+            s = fr_signed_magnitude(raw, neg);
+            if (neg) s.v[7] |= 0x80000000u;
+        }
+        fr_store(mag + (size_t) ri * cols + c, s);
+    }
+}
+__device__ __forceinline__ uint32_t mag_byte(const fr_t *mag, size_t i, uint32_t w) {     // w-th byte of the magnitude (sign bit masked)
+    const uint32_t limb = reinterpret_cast<const uint32_t *>(mag + i)[w >> 2];
+    const uint32_t b = (limb >> ((w & 3) * 8)) & 0xffu;
+    return w == 31 ? (b & 0x7fu) : b;
+}
+__device__ __forceinline__ bool mag_neg(const fr_t *mag, size_t i) { return (reinterpret_cast<const uint32_t *>(mag + i)[7] >> 31) != 0; }
+
+// ------------------------------------------------------------------------------------------------
+// the commitment's hot kernel: signed-byte codes through a digit table. grid (chunks, rows), one wave per block; lane l owns columns
+// base + 64 i + l, i < cpt <= 64. out[(row * chunks + chunk) * 64 + lane] = the lane's partial sum.
+// vwin == 0: every row uses D[d][j] = d g_j.  vwin == 31: the rows are virtual rows (k_scalar_codes_wide), row v uses window
+// 1 + v % 31 of the full byte table F[w][d][j] = d 2^(8w) g_j, of which D is window 0.
+// ------------------------------------------------------------------------------------------------
+template <bool SAFE>
+__global__ void __launch_bounds__(MSM_BLOCK) k_msm_codes(g1j_t *out, uint32_t *exc_flag, const uint16_t *codes, const g1a_t *D, uint32_t m, uint32_t cols,
+                                                         uint32_t cpt, uint32_t vwin) {
+    const uint32_t row = blockIdx.y, lane = threadIdx.x;
+    const uint32_t base = blockIdx.x * (MSM_BLOCK * cpt) + lane;
+    const uint16_t *rc = codes + (size_t) row * cols;
+    if (vwin) D += (size_t) (1 + row % vwin) * 256 * m;
+    // which of this lane's columns carry a non-zero byte: cpt independent 2-byte loads, then the loop below visits set bits only,
+    // so a lane of a half-empty bit row is done after its ~cpt/2 additions instead of idling through cpt iterations
+    unsigned long long mask = 0;
+    for (uint32_t i = 0; i < cpt; ++i) {
+        const uint32_t c = base + i * MSM_BLOCK;
+        if (c < cols && (rc[c] & 0xffu)) mask |= 1ull << i;
+    }
+    fp_t X = fp_zero(), Y = fp_zero(), Z = fp_zero();
+    bool empty = true, exc = false;
+    // the code of the NEXT column is fetched one addition ahead (one register); the table point itself is loaded where it is used: its
+    // latency (an L2 / Infinity-Cache hit: the digit table of 4096 generators is 100 MB) is a few percent of the ~14 us addition and the
+    // other waves of the SIMD run meanwhile -- holding a second point in registers would cost the third wave per SIMD
+    uint32_t c_next = 0, code_next = 0;
+    bool have = mask != 0;
+    if (have) {
+        c_next = base + (uint32_t) (__ffsll((long long) mask) - 1) * MSM_BLOCK;
+        mask &= mask - 1;
+        code_next = rc[c_next];
+    }
+    while (__any(have)) {
+        const bool cur = have;
+        const uint32_t c = c_next, code = code_next;
+        have = mask != 0;
+        if (have) {
+            c_next = base + (uint32_t) (__ffsll((long long) mask) - 1) * MSM_BLOCK;
+            mask &= mask - 1;
+            code_next = rc[c_next];
+        }
+        if (cur) {
+            fp_t px, py;
+            g1a_load(px, py, D + (size_t) (code & 0xffu) * m + c);
+            g1_accumulate<SAFE>(X, Y, Z, empty, px, py, (code & MSM_CODE_NEG) != 0, exc);
+        }
+    }
+    g1j_store(out + ((size_t) row * gridDim.x + blockIdx.x) * MSM_BLOCK + lane, X, Y, Z, empty);
+    if (!SAFE && exc) *exc_flag = 1;
+}
+
+// general Jacobian addition with every special case (infinity, doubling, inverse), operands in memory order
+__device__ __forceinline__ g1j_t g1_add_any(const g1j_t &p, const g1j_t &q) {
+    if (g1_is_inf(p)) return q;
+    if (g1_is_inf(q)) return p;
+    g1j_t r;
+    fp_t Z1Z1 = fp_sqr(p.Z), Z2Z2 = fp_sqr(q.Z);
+    fp_t U1 = fp_mul(p.X, Z2Z2), U2 = fp_mul(q.X, Z1Z1);
+    fp_t S1 = fp_mul(p.Y, q.Z), S2 = fp_mul(q.Y, p.Z);
+    S1 = fp_mul(S1, Z2Z2);
+    S2 = fp_mul(S2, Z1Z1);
+    U2 = fp_sub(U2, U1);                   // H
+    S2 = fp_sub(S2, S1);                   // R
+    if (fp_is_zero(U2)) {
+        if (!fp_is_zero(S2)) return g1_inf();
+        r = p;
+        g1_dbl_ip(r.X, r.Y, r.Z);
+        return r;
+    }
+    r.Z = fp_mul(p.Z, q.Z);
+    r.Z = fp_mul(r.Z, U2);
+    Z1Z1 = fp_sqr(U2);                     // HH
+    U2 = fp_mul(U2, Z1Z1);                 // HHH
+    U1 = fp_mul(U1, Z1Z1);                 // V
+    r.X = fp_sqr(S2);
+    r.X = fp_sub(fp_sub(r.X, U2), fp_dbl(U1));
+    U1 = fp_sub(U1, r.X);
+    U1 = fp_mul(S2, U1);
+    S1 = fp_mul(S1, U2);
+    r.Y = fp_sub(U1, S1);
+    return r;
+}
+
+// out[row] = sum of the n partial points in[row * n ..]: 16 lanes per row (4 rows per wave), lane l adds partials l, l + 16, ...
+// one after the other, then a 4-level tree through LDS. One launch instead of log(n) dependent ones: the chain is n / 16 - 1 + 4
+// additions deep (7 for the 64 lane sums of a commitment row) and all 64 lanes of a wave work until the tree starts.
+__global__ void __launch_bounds__(MSM_BLOCK) k_reduce_rows16(g1j_t *out, const g1j_t *in, uint32_t n, uint32_t rows) {
+    __shared__ g1j_t sm[MSM_BLOCK];
+    const uint32_t l = threadIdx.x & 15, row = blockIdx.x * 4 + (threadIdx.x >> 4);
+    g1j_t acc = g1_inf();
+    if (row < rows) {
+        const g1j_t *src = in + (size_t) row * n;
+        if (l < n) acc = src[l];
+        for (uint32_t k = l + 16; k < n; k += 16) acc = g1_add_any(acc, src[k]);
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = 8; s >= 1; s >>= 1) {
+        if (l < s) sm[threadIdx.x] = g1_add_any(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (l == 0 && row < rows) out[row] = sm[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic kernel: one block = (row, column chunk, window); byte w of every scalar of the chunk through the full table
+// F[w][d][j] = d 2^(8w) g_j. grid (chunks * nwin, rows). The block's 64 lane sums are added by an LDS tree (this kernel serves the
+// few-row, latency-bound MSMs of the opening and the rare wide rows of a commitment). out[row * gridDim.x + blockIdx.x]
+// ------------------------------------------------------------------------------------------------
+template <bool SAFE>
+__global__ void __launch_bounds__(MSM_BLOCK) k_msm_windows(g1j_t *out, uint32_t *exc_flag, const fr_t *mag, uint64_t ld, const uint32_t *idx_base,
+                                                           const g1a_t *F, uint32_t m, uint32_t cols, uint32_t cpt, uint32_t w_lo, uint32_t nwin) {
+    __shared__ g1j_t sm[MSM_BLOCK];
+    const uint32_t row = blockIdx.y, lane = threadIdx.x;
+    const uint32_t w = w_lo + blockIdx.x % nwin, chunk = blockIdx.x / nwin;
+    const uint32_t *idx = idx_base ? idx_base + (size_t) row * ld : nullptr;
+    const g1a_t *Fw = F + (size_t) w * 256 * m;
+    fp_t X = fp_zero(), Y = fp_zero(), Z = fp_zero();
+    bool empty = true, exc = false;
+    for (uint32_t i = 0; i < cpt; ++i) {
+        const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + lane;
+        if (c >= cols) break;
+        const size_t si = (size_t) row * cols + c;              // magnitudes are dense rows of `cols`; index rows are `ld` apart
+        const uint32_t byte = mag_byte(mag, si, w);
+        if (!byte) continue;
+        const uint32_t j = idx ? idx[c] : c;
+        fp_t px, py;
+        g1a_load(px, py, Fw + (size_t) byte * m + j);
+        g1_accumulate<SAFE>(X, Y, Z, empty, px, py, mag_neg(mag, si), exc);
+    }
+    if (!SAFE && exc) *exc_flag = 1;
+    // blocks that selected no point at all (high windows of small scalars) skip the tree
+    if (!__syncthreads_or(!empty)) {
+        if (lane == 0) g1j_store(out + (size_t) row * gridDim.x + blockIdx.x, X, Y, Z, true);
+        return;
+    }
+    g1j_store(&sm[lane], X, Y, Z, empty);
+    __syncthreads();
+    for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
+        if (lane < s) sm[lane] = g1_add_any(sm[lane], sm[lane + s]);
+        __syncthreads();
+    }
+    if (lane == 0) out[(size_t) row * gridDim.x + blockIdx.x] = sm[0];
+}
+
+// out[row * gridDim.x + b] = sum of in[row * nin + 64 b .. 64 b + 63]  (one tree level of width 64 per launch)
+__global__ void __launch_bounds__(MSM_BLOCK) k_tree_reduce(g1j_t *out, const g1j_t *in, uint32_t nin) {
+    __shared__ g1j_t sm[MSM_BLOCK];
+    const uint32_t row = blockIdx.y, p = blockIdx.x * MSM_BLOCK + threadIdx.x;
+    sm[threadIdx.x] = p < nin ? in[(size_t) row * nin + p] : g1_inf();
+    __syncthreads();
+    for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] = g1_add_any(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t) row * gridDim.x + blockIdx.x] = sm[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// first use of a generator set (no byte table yet): window tables T[w][j] = 2^(8w) g_j only. Digit d of window w contributes
+// d T[w][j] = sum_k bit_k(d) 2^k T[w][j]: for each of the 8 bit planes one block sums the selected table points, and the row
+// result is sum_k 2^k S_k (k_msm_finish). One block = (row, bit plane, column chunk x window group).
+// out[(row * 8 + plane) * nparts + part]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(MSM_BLOCK) k_msm_planes(g1j_t *out, const fr_t *mag, uint64_t ld, const uint32_t *idx_base, const g1a_t *T,
+                                                          uint32_t m, uint32_t cols, uint32_t cpt, uint32_t wsplit, uint32_t w_lo) {
+    __shared__ g1j_t sm[MSM_BLOCK];
+    const uint32_t plane = blockIdx.y, row = blockIdx.z, lane = threadIdx.x;
+    const uint32_t wg = blockIdx.x % wsplit, chunk = blockIdx.x / wsplit;
+    const uint32_t wpg = MSM_WINDOWS / wsplit, w0 = max(wg * wpg, w_lo), w1 = (wg + 1) * wpg;
+    const uint32_t *idx = idx_base ? idx_base + (size_t) row * ld : nullptr;
+    fp_t X = fp_zero(), Y = fp_zero(), Z = fp_zero();
+    bool empty = true, exc = false;
+    for (uint32_t i = 0; i < cpt; ++i) {
+        const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + lane;
+        if (c >= cols) break;
+        const size_t si = (size_t) row * cols + c;
+        const uint32_t j = idx ? idx[c] : c;
+        const bool neg = mag_neg(mag, si);
+        for (uint32_t w = w0; w < w1; ++w) {
+            if (!((mag_byte(mag, si, w) >> plane) & 1u)) continue;
+            fp_t px, py;
+            g1a_load(px, py, T + (size_t) w * m + j);
+            g1_accumulate<true>(X, Y, Z, empty, px, py, neg, exc);
+        }
+    }
+    const size_t o = ((size_t) row * MSM_PLANES + plane) * gridDim.x + blockIdx.x;
+    if (!__syncthreads_or(!empty)) {
+        if (lane == 0) g1j_store(out + o, X, Y, Z, true);
+        return;
+    }
+    g1j_store(&sm[lane], X, Y, Z, empty);
+    __syncthreads();
+    for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
+        if (lane < s) sm[lane] = g1_add_any(sm[lane], sm[lane + s]);
+        __syncthreads();
+    }
+    if (lane == 0) out[o] = sm[0];
+}
+
+// One block per row, one wave per bit plane: wave k sums the partial points of plane k (lane-strided, then a tree through LDS) and
+// pre-multiplies by 2^k (k doublings, the waves run concurrently); a final 3-level tree adds the 8 weighted plane sums.
+__global__ void __launch_bounds__(512) k_msm_finish(g1j_t *outJ, const g1j_t *partials, uint32_t nparts) {
+    __shared__ g1j_t sm[MSM_PLANES][32];
+    const uint32_t row = blockIdx.x, lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+    g1j_t acc = g1_inf();
+    const g1j_t *src = partials + ((size_t) row * MSM_PLANES + k) * nparts;
+    for (uint32_t p = lane; p < nparts; p += 64) acc = g1_add_any(acc, src[p]);
+    const uint32_t live = nparts < 64 ? nparts : 64;          // lanes beyond this hold the point at infinity
+    if (lane >= 32) sm[k][lane - 32] = acc;
+    __syncthreads();
+    if (lane < 32) {
+        if (lane + 32 < live) acc = g1_add_any(acc, sm[k][lane]);
+    }
+    __syncthreads();
+    if (lane < 32) sm[k][lane] = acc;
+    __syncthreads();
+    for (uint32_t s = 16; s >= 1; s >>= 1) {
+        if (lane < s && lane + s < live) sm[k][lane] = g1_add_any(sm[k][lane], sm[k][lane + s]);
+        __syncthreads();
+    }
+    if (lane == 0) {
+        g1j_t R = sm[k][0];
+        for (uint32_t d = 0; d < k; ++d) g1_dbl_ip(R.X, R.Y, R.Z);
+        sm[k][0] = R;
+    }
+    __syncthreads();
+    for (uint32_t s = MSM_PLANES / 2; s >= 1; s >>= 1) {
+        if (lane == 0 && k < s) sm[k][0] = g1_add_any(sm[k][0], sm[k + s][0]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) outJ[row] = sm[0][0];
+}
+
+// rows[list[i]] += extra[i]
+__global__ void __launch_bounds__(MSM_BLOCK) k_add_rows(g1j_t *rows, const g1j_t *extra, const uint32_t *list, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rows[list[i]] = g1_add_any(rows[list[i]], extra[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tables
+// ------------------------------------------------------------------------------------------------
+// T[0][j] = g_j is already in place; fills T[w][j] = 2^(8w) g_j for w >= 1, converted to affine with
+// one field inversion per generator (Montgomery's trick over the 31 Jacobian points of that thread).
+__global__ void __launch_bounds__(MSM_BLOCK) k_window_tables(g1a_t *T, g1j_t *J, fp_t *pre, uint32_t m) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const g1a_t g = T[j];
+    if (g1a_is_inf(g)) {
+        for (int w = 1; w < MSM_WINDOWS; ++w) T[(size_t) w * m + j] = g;
+        return;
+    }
+    fp_t X = g.x, Y = g.y, Z = fp_one();
+    fp_t run = fp_one();
+    for (int w = 1; w < MSM_WINDOWS; ++w) {
+        for (int d = 0; d < 8; ++d) g1_dbl_ip(X, Y, Z);
+        g1j_store(J + (size_t) (w - 1) * m + j, X, Y, Z, false);
+        pre[(size_t) (w - 1) * m + j] = run;
+        run = fp_mul(run, Z);
+    }
+    fp_t inv = fp_inv(run);
+    for (int w = MSM_WINDOWS - 1; w >= 1; --w) {
+        const g1j_t Q = J[(size_t) (w - 1) * m + j];
+        const fp_t zi = fp_mul(inv, pre[(size_t) (w - 1) * m + j]);
+        inv = fp_mul(inv, Q.Z);
+        const fp_t zi2 = fp_sqr(zi);
+        g1a_t a;
+        a.x = fp_mul(Q.X, zi2);
+        a.y = fp_mul(fp_mul(Q.Y, zi2), zi);
+        T[(size_t) w * m + j] = a;
+    }
+}
+
+// digit table by levels: D[1] = g, D[d] = 2 D[d/2] (+ g if d is odd); every entry of a level is independent
+__global__ void __launch_bounds__(MSM_BLOCK) k_digit_level(g1j_t *J, const g1a_t *G, uint32_t m, uint32_t level) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t cnt = 1u << level;
+    if (tid >= cnt * m) return;
+    const uint32_t j = tid % m, d = cnt + tid / m;
+    fp_t gx, gy;
+    g1a_load(gx, gy, G + j);
+    const bool ginf = fp_is_zero(gx) && fp_is_zero(gy);
+    fp_t X, Y, Z;
+    bool empty = ginf, exc = false;
+    if (level == 0) {
+        X = gx; Y = gy; Z = fp_one();
+    } else {
+        const g1j_t P = J[(size_t) (d >> 1) * m + j];
+        X = P.X; Y = P.Y; Z = P.Z;
+        empty = fp_is_zero(Z);
+        if (!empty) g1_dbl_ip(X, Y, Z);
+        empty = empty || fp_is_zero(Z);
+        if ((d & 1) && !ginf) g1_accumulate<true>(X, Y, Z, empty, gx, gy, false, exc);
+    }
+    g1j_store(J + (size_t) d * m + j, X, Y, Z, empty);
+}
+// Jacobian -> affine for 16 consecutive digits of one generator with one inversion (Montgomery's trick)
+__global__ void __launch_bounds__(MSM_BLOCK) k_digit_affine(g1a_t *D, const g1j_t *J, fp_t *pre, uint32_t m) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= 16 * m) return;
+    const uint32_t j = tid % m, d0 = (tid / m) * 16;
+    fp_t run = fp_one();
+    for (uint32_t d = d0; d < d0 + 16; ++d) {
+        if (d == 0) continue;
+        const fp_t z = J[(size_t) d * m + j].Z;
+        pre[(size_t) d * m + j] = run;
+        if (!fp_is_zero(z)) run = fp_mul(run, z);
+    }
+    fp_t inv = fp_inv(run);
+    for (uint32_t d = d0 + 16; d-- > d0;) {
+        if (d == 0) continue;
+        const g1j_t Q = J[(size_t) d * m + j];
+        g1a_t a;
+        if (fp_is_zero(Q.Z)) { a.x = fp_zero(); a.y = fp_zero(); }
+        else {
+            const fp_t zi = fp_mul(inv, pre[(size_t) d * m + j]);
+            inv = fp_mul(inv, Q.Z);
+            const fp_t zi2 = fp_sqr(zi);
+            a.x = fp_mul(Q.X, zi2);
+            a.y = fp_mul(fp_mul(Q.Y, zi2), zi);
+        }
+        D[(size_t) d * m + j] = a;
+    }
+}
+
+// ---- batched Jacobian -> affine: ONE field inversion for all rows (Montgomery's trick), and that single inversion -- a
+// chain of ~570 dependent products, 1 ms on one GPU lane -- is done by the host between two small kernels (27 us on a CPU core).
+// per thread: running products inside its segment of AFF_SEG points (4 for up to 4096 points: short chains, the scan takes 1024 segments); seg[t] = product of the segment's Z (infinity counts as 1)
+__global__ void __launch_bounds__(MSM_BLOCK) k_aff_prefix(fp_t *pre, fp_t *seg, const g1j_t *in, uint32_t n, uint32_t AFF_SEG) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t * AFF_SEG >= n) return;
+    fp_t run = fp_one();
+    for (uint32_t i = t * AFF_SEG; i < min(n, (t + 1) * AFF_SEG); ++i) {
+        pre[i] = run;
+        const fp_t z = in[i].Z;
+        if (!fp_is_zero(z)) run = fp_mul(run, z);
+    }
+    seg[t] = run;
+}
+// single block: exclusive prefix and suffix products over the nseg segment products (in place), total product to *total
+__global__ void __launch_bounds__(1024) k_aff_scan(fp_t *seg_pre, fp_t *seg_suf, fp_t *total, const fp_t *seg, uint32_t nseg) {
+    __shared__ fp_t a[1024], b[1024];
+    const uint32_t t = threadIdx.x;
+    a[t] = t < nseg ? seg[t] : fp_one();                      // inclusive prefix
+    b[t] = t < nseg ? seg[nseg - 1 - t] : fp_one();           // inclusive prefix of the reversed sequence = suffix
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        fp_t x, y;
+        const bool on = t >= d;
+        if (on) { x = fp_mul(a[t], a[t - d]); y = fp_mul(b[t], b[t - d]); }
+        __syncthreads();
+        if (on) { a[t] = x; b[t] = y; }
+        __syncthreads();
+    }
+    if (t < nseg) {
+        seg_pre[t] = t ? a[t - 1] : fp_one();
+        seg_suf[t] = (nseg - 1 - t) ? b[nseg - 2 - t] : fp_one();
+    }
+    if (t == 0) *total = a[nseg - 1];
+}
+__global__ void __launch_bounds__(MSM_BLOCK) k_aff_finish(g1a_t *out, const g1j_t *in, const fp_t *pre, const fp_t *seg_pre, const fp_t *seg_suf,
+                                                          const fp_t *total_inv, uint32_t n, uint32_t AFF_SEG) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t * AFF_SEG >= n) return;
+    fp_t inv = fp_mul(fp_mul(*total_inv, seg_pre[t]), seg_suf[t]);        // 1 / (product of this segment's Z)
+    const uint32_t lo = t * AFF_SEG, hi = min(n, (t + 1) * AFF_SEG);
+    for (uint32_t i = hi; i-- > lo;) {
+        const g1j_t Q = in[i];
+        g1a_t r;
+        if (fp_is_zero(Q.Z)) { r.x = fp_zero(); r.y = fp_zero(); }
+        else {
+            const fp_t zi = fp_mul(inv, pre[i]);
+            inv = fp_mul(inv, Q.Z);
+            const fp_t zi2 = fp_sqr(zi);
+            r.x = fp_mul(Q.X, zi2);
+            r.y = fp_mul(fp_mul(Q.Y, zi2), zi);
+        }
+        out[i] = r;
+    }
+}
+
+__global__ void __launch_bounds__(MSM_BLOCK) k_to_affine(g1a_t *out, const g1j_t *in, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = g1_to_affine(in[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// inner-product argument (scalar side)
+// ------------------------------------------------------------------------------------------------
+// scalars of the two cross terms of one round, expressed over the ORIGINAL generators:
+//   g^(k)_i = sum_{j = i mod len} coef[j] g_j, so  L = <a_lo, g_hi> = sum_{j: (j mod len) >= h} a[(j mod len) - h] coef[j] g_j
+__global__ void k_ipa_scalars(fr_t *sL, uint32_t *idxL, fr_t *sR, uint32_t *idxR, const fr_t *a, const fr_t *coef, uint32_t m,
+                              uint32_t len) {      // sL/sR and idxL/idxR are the two rows of one (2 x m/2) batch
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t h = len >> 1, i = j & (len - 1), pos = (j / len) * h + (i & (h - 1));
+    const fr_t cj = fr_load(coef + j);
+    if (i >= h) {
+        fr_store(sL + pos, fr_mul(fr_load(a + i - h), cj));
+        idxL[pos] = j;
+    } else {
+        fr_store(sR + pos, fr_mul(fr_load(a + i + h), cj));
+        idxR[pos] = j;
+    }
+}
+
+// y[0] = <a_lo, b_hi>, y[1] = <a_hi, b_lo>; single block
+__global__ void __launch_bounds__(256) k_ipa_dots(fr_t *y, const fr_t *a, const fr_t *b, uint32_t h) {
+    __shared__ fr_t smem[2 * 256 / 64];
+    fr_t acc[2] = {fr_zero(), fr_zero()};
+    for (uint32_t i = threadIdx.x; i < h; i += 256) {
+        acc[0] = fr_add(acc[0], fr_mul(fr_load(a + i), fr_load(b + i + h)));
+        acc[1] = fr_add(acc[1], fr_mul(fr_load(a + i + h), fr_load(b + i)));
+    }
+    fr_block_sum<2>(acc, smem);
+    if (threadIdx.x == 0) { fr_store(y, acc[0]); fr_store(y + 1, acc[1]); }
+}
+
+// a' = a_lo + c a_hi, b' = c b_lo + b_hi (in place), coef[j] *= c for generators in the low half
+__global__ void k_ipa_fold(fr_t *a, fr_t *b, fr_t *coef, fr_t c, uint32_t m, uint32_t len) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t h = len >> 1;
+    if (j < m && (j & (len - 1)) < h) fr_store(coef + j, fr_mul(fr_load(coef + j), c));
+    if (j < h) {
+        fr_store(a + j, fr_add(fr_load(a + j), fr_mul(c, fr_load(a + j + h))));
+        fr_store(b + j, fr_add(fr_mul(c, fr_load(b + j)), fr_load(b + j + h)));
+    }
+}
+
+__global__ void k_fill(fr_t *dst, fr_t v, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fr_store(dst + i, v);
+}
