@@ -22,12 +22,17 @@ typedef struct {
     uint64_t data_seed;    /* synthetic picture / weights / biases (reference data.tar.gz is absent) */
 } zkcnn_model_desc;
 
-#define ZKCNN_MODE_VERIFY      0u  /* full verifier (reference behaviour) */
+#define ZKCNN_MODE_VERIFY      0u  /* full verifier (reference behaviour): challenges from the operating system's CSPRNG, fresh random generators */
 #define ZKCNN_MODE_DRIVE_ONLY  1u  /* same challenges and prover calls, verifier checks skipped */
-#define ZKCNN_MODE_REUSE_GENS  2u  /* keep the session's commitment generators instead of drawing new ones */
+#define ZKCNN_MODE_REUSE_GENS  2u  /* public commitment generators (hash-to-curve, nobody knows a discrete log) instead of fresh random multiples of G */
 #define ZKCNN_MODE_TAMPER      4u  /* test hook: the verifier corrupts message number (mode >> 8) before checking it */
 #define ZKCNN_MODE_HOST_PRED   8u  /* verifier's wiring predicates on the host (reference src/verifier.cpp:89-116) instead of the GPU */
-#define ZKCNN_MODE_FIAT_SHAMIR 32u /* non-interactive: challenges are SHA-256 of the statement and of every message so far (the seed is ignored) */
+#define ZKCNN_MODE_FIAT_SHAMIR 32u /* non-interactive: challenges are SHA-256 of the statement and of every message so far (the seed is ignored);
+                                     always on the public hash-to-curve generators, whose digest is part of the hashed statement */
+#define ZKCNN_MODE_SEEDED      64u /* reproducible run for parity tests / benches: challenges (and, without REUSE_GENS, generator scalars) come from a
+                                     xoshiro stream seeded with challenge_seed. NOT secure -- every challenge is predictable from the seed.
+                                     zkcnn_session_verify accepts an interactive (non-Fiat-Shamir) transcript only with this bit: a replay against a
+                                     known challenge stream is a debugging aid, never evidence that a statement is true */
 #define ZKCNN_MODE_CROSS_PRED 16u  /* both, and the verifier rejects if they differ (parity check of zk_verifier_*) */
 
 typedef struct {
@@ -58,8 +63,9 @@ void *zkcnn_session_create(const zkcnn_model_desc *desc, int32_t device);
 int32_t zkcnn_session_prove(void *session, uint64_t challenge_seed, uint32_t mode, uint8_t *transcript,
                             uint64_t cap, zkcnn_result *out);
 /* Checks a serialized proof (the transcript zkcnn_session_prove returned) without running the prover: the verifier replays the
- * bytes against this session's circuit. challenge_seed and the ZKCNN_MODE_REUSE_GENS / ZKCNN_MODE_FIAT_SHAMIR bits must be the
- * ones the proof was made with. out->accepted = 1 / 0, out->message = the reason for a rejection. */
+ * bytes against this session's circuit. Only Fiat-Shamir proofs (ZKCNN_MODE_FIAT_SHAMIR) are PROOFS off line; an interactive
+ * transcript is rejected unless ZKCNN_MODE_SEEDED says "replay it against the seeded stream it was driven with" (parity / debugging).
+ * out->accepted = 1 / 0, out->message = the reason for a rejection. */
 int32_t zkcnn_session_verify(void *session, uint64_t challenge_seed, uint32_t mode, const uint8_t *proof, uint64_t len,
                              zkcnn_result *out);
 /* The statement of a session's circuit besides the model descriptor: the quantisation scales (bits kept per layer) the circuit's

@@ -45,6 +45,16 @@ int32_t oracle_session_row(void *session, char *buf, uint64_t cap) {
     return 0;
 }
 
+// public commitment generators (ff/hash_to_curve.hpp): affine points in the C-ABI layout + the digest a transcript absorbs
+void oracle_public_generators(uint64_t *out, uint8_t digest[32], uint64_t n) {
+    const zkff::publicGenerators &pg = zkff::publicGeneratorSet(n);
+    for (size_t i = 0; i < n; ++i) {
+        G1Affine a = pg.gens[i].toAffine();
+        std::memcpy(out + 12 * i, &a, 96);
+    }
+    std::memcpy(digest, pg.digest, 32);
+}
+
 // ---- field (4 x u64 Montgomery limbs per element, the C-ABI form) ----
 
 void oracle_fr_from_canonical(uint64_t *out, const uint64_t *in, uint64_t n) {

@@ -80,6 +80,16 @@ class Oracle:
         self.lib.oracle_g1_generators(u64p(out), ctypes.c_uint64(n), ctypes.c_uint64(seed))
         return out
 
+    def public_generators(self, n):
+        out = np.zeros((n, 12), dtype=np.uint64)
+        dig = (ctypes.c_uint8 * 32)()
+        self.lib.oracle_public_generators(u64p(out), dig, ctypes.c_uint64(n))
+        return out, bytes(dig)
+
+    def g1_in_subgroup(self, p):
+        """r * P == O, through the compressed round trip with the subgroup check on"""
+        return self.g1_deserialize(self.g1_serialize(p), check_subgroup=True) is not None
+
     def msm(self, scalars, bases):
         out = np.zeros(12, dtype=np.uint64)
         self.lib.oracle_msm(u64p(out), u64p(scalars), u64p(bases), ctypes.c_uint64(scalars.shape[0]))

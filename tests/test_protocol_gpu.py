@@ -138,6 +138,8 @@ def test_standalone_gpu_verifier_from_proof_file(built):
             assert o.statement() == stmt
             _, otr = o.prove(seed=3)
             oblob = proof_io.dumps_from(o, otr, 3, 0)
-        assert proof_io.verify_standalone(oblob, zkcnn_amd.Session).accepted == 1
+        with pytest.raises(proof_io.NotAProofError):
+            proof_io.verify_standalone(oblob, zkcnn_amd.Session)       # an interactive transcript: a replay must be asked for
+        assert proof_io.verify_standalone(oblob, zkcnn_amd.Session, allow_seeded_replay=True).accepted == 1
         damaged = proof_io.dumps(tr[:200] + bytes([tr[200] ^ 2]) + tr[201:], model, pic, pp, 20260928, 0, zkcnn_amd.MODE_FIAT_SHAMIR, stmt)
         assert proof_io.verify_standalone(damaged, zkcnn_amd.Session).accepted == 0

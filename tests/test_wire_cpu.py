@@ -100,7 +100,12 @@ def test_proof_file_round_trip(oracle, tmp_path):
             proof_io.save(path, tr, MODEL[0], MODEL[1], MODEL[2], 20260928, seed, mode)
             header, back = proof_io.load(path)
             assert back == tr and header["model"] == MODEL[0]
-            assert proof_io.verify_with(o, path.read_bytes()).accepted == 1
+            if mode & FS:
+                assert proof_io.verify_with(o, path.read_bytes()).accepted == 1
+            else:           # an interactive transcript is not a proof off line: refused unless a replay is asked for explicitly
+                with pytest.raises(proof_io.NotAProofError):
+                    proof_io.verify_with(o, path.read_bytes())
+                assert proof_io.verify_with(o, path.read_bytes(), allow_seeded_replay=True).accepted == 1
             blob = bytearray(path.read_bytes())
             blob[len(blob) // 2] ^= 0x40
             with pytest.raises(ValueError):
@@ -119,7 +124,9 @@ def test_standalone_verifier_needs_only_the_proof_file(oracle, model):
         _, tr2 = o.prove(seed=6)
         blob2 = proof_io.dumps_from(o, tr2, 6, 0)
     assert proof_io.verify_standalone(blob, oracle_ffi.OracleSession).accepted == 1
-    assert proof_io.verify_standalone(blob2, oracle_ffi.OracleSession).accepted == 1
+    with pytest.raises(proof_io.NotAProofError):            # an interactive transcript names its own challenge seed: not a proof
+        proof_io.verify_standalone(blob2, oracle_ffi.OracleSession)
+    assert proof_io.verify_standalone(blob2, oracle_ffi.OracleSession, allow_seeded_replay=True).accepted == 1
     with oracle_ffi.OracleSession(*model, statement=stmt) as v:
         assert v.statement() == stmt
         with pytest.raises(RuntimeError):
@@ -137,3 +144,83 @@ def test_standalone_verifier_needs_only_the_proof_file(oracle, model):
         oracle_ffi.OracleSession(*model, statement=stmt[:-1])
     with pytest.raises(RuntimeError):
         oracle_ffi.OracleSession(*model, statement=stmt + [3])
+
+
+def test_interactive_transcripts_are_not_proofs_off_line(oracle):
+    """zkcnn_session_verify (here: the oracle's twin of it) refuses a transcript whose challenges it cannot re-derive; with OS randomness
+    (the default: no seed) two runs differ, both are accepted in process, and neither verifies off line"""
+    with oracle_ffi.OracleSession(*MODEL) as o:
+        r1, t1 = o.prove()                       # challenges from getrandom(2)
+        r2, t2 = o.prove()
+        assert r1.accepted == 1 and r2.accepted == 1 and t1 != t2
+        res = o.verify(t1)                       # no Fiat-Shamir, no seeded replay
+        assert res.accepted == 0 and b"Fiat-Shamir" in res.message
+        assert o.verify(t1, seed=1).accepted == 0          # replaying against some seeded stream does not fit either
+        _, t3 = o.prove(mode=zkcnn_amd.MODE_REUSE_GENS)
+        _, t4 = o.prove(mode=zkcnn_amd.MODE_REUSE_GENS)
+        assert t3 != t4 and t3[:48] == t4[:48]   # same witness, same public generators: same commitment, other challenges
+
+
+def test_public_generators_are_hash_to_curve_points(oracle):
+    """session / Fiat-Shamir generators: on the curve, in the order-r subgroup, pairwise distinct, prefix-stable, and not multiples of G
+    by a scalar anybody chose (they are a function of the index alone: recomputed here from the definition for the first point)"""
+    g64, dig64 = oracle.public_generators(64)
+    g16, dig16 = oracle.public_generators(16)
+    assert np.array_equal(g64[:16], g16) and dig16 != dig64
+    assert len({g.tobytes() for g in g64}) == 64
+    for g in g64[:8]:
+        assert oracle.g1_on_curve(g) and oracle.g1_in_subgroup(g)
+    enc = b"".join(oracle.g1_serialize(g) for g in g16)
+    assert hashlib.sha256(enc).digest() == dig16
+    # definition: x = (H(d || i || ctr || 1) mod 2^255) * 2^256 + H(d || i || ctr || 0) mod p, first ctr with a square x^3 + 4, times h_eff
+    p_mod = zkcnn_amd.P_MOD
+    dom, i = b"zkcnn-amd/generators/v1", 0
+    ctr = 0
+    while True:
+        tail = i.to_bytes(8, "little") + ctr.to_bytes(4, "little")
+        lo = int.from_bytes(hashlib.sha256(dom + tail + b"\x00").digest(), "little")
+        hi = int.from_bytes(hashlib.sha256(dom + tail + b"\x01").digest(), "little")
+        pick_larger, hi = hi >> 255, hi & ((1 << 255) - 1)
+        x = (hi * (1 << 256) + lo) % p_mod
+        rhs = (x * x * x + 4) % p_mod
+        y = pow(rhs, (p_mod + 1) // 4, p_mod)
+        if y * y % p_mod == rhs:
+            break
+        ctr += 1
+    if (y > p_mod - y) != bool(pick_larger):
+        y = p_mod - y
+
+    def add(P, Q):                                # affine short Weierstrass, a = 0
+        if P is None:
+            return Q
+        if Q is None:
+            return P
+        if P[0] == Q[0]:
+            if (P[1] + Q[1]) % p_mod == 0:
+                return None
+            lam = 3 * P[0] * P[0] * pow(2 * P[1], -1, p_mod) % p_mod
+        else:
+            lam = (Q[1] - P[1]) * pow(Q[0] - P[0], -1, p_mod) % p_mod
+        x3 = (lam * lam - P[0] - Q[0]) % p_mod
+        return x3, (lam * (P[0] - x3) - P[1]) % p_mod
+    acc = None
+    for bit in bin(0xd201000000010001)[2:]:
+        acc = add(acc, acc)
+        if bit == "1":
+            acc = add(acc, (x, y))
+    got = oracle.fp_to_canonical(g64[0])
+    assert zkcnn_amd.from_limbs(got) == [acc[0], acc[1]]
+
+
+def test_statement_with_out_of_range_scales_is_refused(oracle):
+    """quantisation scales size layers and index two_mul; a statement (proof file) is untrusted input: out-of-range values must fail
+    cleanly instead of building giant or negative-sized layers"""
+    with oracle_ffi.OracleSession(*MODEL) as o:
+        stmt = o.statement()
+    for k, v in ((0, -3), (0, 200), (1, 70), (len(stmt) - 1, -1), (len(stmt) - 1, 10 ** 6)):
+        bad = list(stmt)
+        bad[k] = v
+        with pytest.raises(RuntimeError):
+            oracle_ffi.OracleSession(*MODEL, statement=bad)
+    with pytest.raises(RuntimeError):
+        oracle_ffi.OracleSession(MODEL[0], (1 << 20, 4, 1), 1, statement=stmt)      # absurd picture shape

@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(ROOT, "zkcnn_amd", "lib")
 R_MOD = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 P_MOD = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 
-MODE_VERIFY, MODE_DRIVE_ONLY, MODE_REUSE_GENS, MODE_TAMPER, MODE_HOST_PRED, MODE_CROSS_PRED, MODE_FIAT_SHAMIR = 0, 1, 2, 4, 8, 16, 32
+MODE_VERIFY, MODE_DRIVE_ONLY, MODE_REUSE_GENS, MODE_TAMPER, MODE_HOST_PRED, MODE_CROSS_PRED, MODE_FIAT_SHAMIR, MODE_SEEDED = 0, 1, 2, 4, 8, 16, 32, 64
 
 
 class ModelDesc(ctypes.Structure):
@@ -261,7 +261,13 @@ class _SessionBase:
         fn(ctypes.c_void_p(self.h), arr, ctypes.c_uint64(n))
         return [int(x) for x in arr[:n]]
 
-    def prove(self, seed=0x5EED0001, mode=MODE_VERIFY, want_transcript=True):
+    def prove(self, seed=None, mode=MODE_VERIFY, want_transcript=True):
+        """one proof. seed=None (default): the verifier's challenges come from the operating system's CSPRNG, as in the reference.
+        An integer seed asks for a REPRODUCIBLE run (MODE_SEEDED: parity tests, benches) -- predictable challenges, not secure."""
+        if seed is not None:
+            mode |= MODE_SEEDED
+        else:
+            seed = 0
         cap = 0
         if want_transcript:
             if getattr(self, "_tbuf", None) is None:
@@ -275,12 +281,20 @@ class _SessionBase:
             raise RuntimeError(f"{self._prefix}session_prove failed ({rc}): {res.message.decode(errors='replace')}")
         if want_transcript and res.transcript_len > cap:
             self._tbuf = (ctypes.c_uint8 * int(res.transcript_len + (1 << 20)))()
+            if not mode & (MODE_SEEDED | MODE_FIAT_SHAMIR):
+                raise RuntimeError("transcript buffer too small for a proof with fresh randomness; call prove() again")
             return self.prove(seed, mode, True)                     # deterministic: the same seed gives the same proof
         data = ctypes.string_at(buf, res.transcript_len) if want_transcript else b""
         return res, data
 
-    def verify(self, proof, seed=0x5EED0001, mode=MODE_VERIFY):
-        """checks a serialized proof (bytes returned by prove) without the prover; returns the Result (accepted = 1 / 0)"""
+    def verify(self, proof, seed=None, mode=MODE_VERIFY):
+        """checks a serialized proof (bytes returned by prove) without the prover; returns the Result (accepted = 1 / 0).
+        Only Fiat-Shamir proofs are proofs off line. An interactive transcript verifies only as a REPLAY against the seeded challenge
+        stream it was driven with (pass that seed): a parity / debugging aid, not evidence -- the library rejects it otherwise."""
+        if seed is not None:
+            mode |= MODE_SEEDED
+        else:
+            seed = 0
         res = Result()
         buf = (ctypes.c_uint8 * max(len(proof), 1)).from_buffer_copy(proof if proof else b"\0")
         rc = self._fn("session_verify")(ctypes.c_void_p(self.h), ctypes.c_uint64(seed), ctypes.c_uint32(mode), buf,

@@ -8,6 +8,10 @@
 //   getInt64() returns the signed representative;  < and > compare canonical integers;
 //   setByCSPRNG() draws from a process-wide stream that tests can seed (parity needs that).
 #pragma once
+#include <sys/random.h>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
 #include "mont.hpp"
 #include <ostream>
 #include <random>
@@ -81,6 +85,39 @@ inline ChallengeSource *&challengeOverride() {
     return src;
 }
 
+// The default source of randomness: the operating system's CSPRNG (getrandom(2), buffered 4 KB at a time per thread).
+// The reference draws every challenge with mcl's OS-backed setByCSPRNG (reference src/verifier.cpp:124...279); a seeded xoshiro
+// stream is NOT a CSPRNG and is only used when a caller asks for a reproducible run (Fr::seedCSPRNG: parity tests, benches).
+struct OsRandom {
+    uint8_t buf[4096];
+    size_t pos = sizeof(buf);
+    void words(uint64_t out[4]) {
+        if (pos + 32 > sizeof(buf)) {
+            size_t got = 0;
+            while (got < sizeof(buf)) {
+                ssize_t r = ::getrandom(buf + got, sizeof(buf) - got, 0);
+                if (r < 0) {
+                    if (errno == EINTR) continue;
+                    std::perror("getrandom");
+                    std::abort();                      // no randomness, no challenges: never fall back to something predictable
+                }
+                got += (size_t) r;
+            }
+            pos = 0;
+        }
+        std::memcpy(out, buf + pos, 32);
+        pos += 32;
+    }
+};
+inline OsRandom &osRandom() {
+    static thread_local OsRandom r;
+    return r;
+}
+inline bool &challengeSeeded() {                   // per thread: a seeded (reproducible, NOT secure) stream is active
+    static thread_local bool on = false;
+    return on;
+}
+
 inline Xoshiro &challengeStream() {
     static thread_local Xoshiro g = [] {       // one stream per thread: concurrent sessions (one per host thread) stay deterministic
         Xoshiro x;
@@ -110,16 +147,19 @@ public:
     }
     static int getByteSize() { return 32; }
 
-    static void seedCSPRNG(uint64_t seed) { challengeStream().seed(seed); }
+    // reproducible challenges for parity tests and benches: NOT cryptographically secure (xoshiro256**, 64-bit seed)
+    static void seedCSPRNG(uint64_t seed) { challengeStream().seed(seed); challengeSeeded() = true; }
+    // back to the operating system's CSPRNG (the default)
+    static void useOsRandom() { challengeSeeded() = false; }
     // uniform in [0, r) by rejection on 255-bit draws; stored as-is in Montgomery form
     // (multiplying a uniform value by the constant R^{-1} keeps it uniform).
     void setByCSPRNG() {
-        Xoshiro &g = challengeStream();
         ChallengeSource *src = challengeOverride();
         for (;;) {
             uint64_t t[4];
             if (src) src->words(t);
-            else for (int i = 0; i < 4; ++i) t[i] = g.next();
+            else if (challengeSeeded()) { Xoshiro &g = challengeStream(); for (int i = 0; i < 4; ++i) t[i] = g.next(); }
+            else osRandom().words(t);
             t[3] &= 0x7fffffffffffffffULL;
             if (!Base::geMod(t)) {
                 *this = Fr(Base::fromCanonical(t));

@@ -41,19 +41,20 @@ struct msm_state {
     bool host_rows_valid = false;      // few-row MSMs end with a short sum on the host (like the single inversion of fetch_points)
     zkff::G1 host_rows[8];
     // scalar pre-pass outputs: 16-bit codes of a whole matrix, canonical signed magnitudes of the rows that need every window
-    uint16_t *codes = nullptr, *codes_v = nullptr; size_t codes_cap = 0, codes_v_cap = 0;   // codes of a matrix; of the virtual rows (higher windows of wide rows)
+    uint16_t *codes = nullptr; size_t codes_cap = 0;          // 16-bit codes of a matrix, followed by those of the virtual rows (higher windows of wide rows)
     fr_t *mag = nullptr; size_t mag_cap = 0;
     uint32_t *exc = nullptr;           // device word set by a fast-variant kernel that met P = +-Q
     bool safe = false;                 // run the SAFE kernel variants (after a flagged batch)
 };
 #define MSM_FULL_MAX_M 16384u
+#define MSM_WIDE_CAP 128u          // rows with wide scalars whose higher windows ride along as virtual rows of the commitment's launches
 #define ZK_RETRY_SAFE 0x5afe       // internal status: repeat the batch with the SAFE kernels
 
 void zk_msm_destroy(zk_ctx *ctx) {
     if (!ctx->msm) return;
     msm_state *s = ctx->msm;
     void *bufs[] = {s->tables, s->partials, s->rowsJ, s->rowsA, s->a, s->b, s->coef, s->Lrow, s->sL, s->idxL, s->d_y, s->tbl_scratch,
-                    s->digit, s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch, s->full, s->parts2, s->codes, s->mag, s->exc, s->codes_v};
+                    s->digit, s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch, s->full, s->parts2, s->codes, s->mag, s->exc};
     for (void *p : bufs) if (p) hipFree(p);
     delete s;
     ctx->msm = nullptr;
@@ -299,64 +300,66 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
         if ((rc = ensure_digit_table(ctx))) return rc;
         D = s->digit;
     }
-    if ((rc = ensure_rows(ctx, rows))) return rc;
+    // Rows that hold wide scalars (biases, maxima, the picture: a few whole rows) get their windows 1..31 as 31 virtual rows each of
+    // the SAME launches -- found on the device (flags -> compacted list), so nothing waits for the host; MSM_WIDE_CAP bounds the list,
+    // more wide rows than that (or no byte table yet) take the separate pass below.
+    const uint32_t wide_cap = s->full_ready ? std::min<uint32_t>(MSM_WIDE_CAP, (65535u - std::min<uint32_t>(rows, 65535u)) / (MSM_WINDOWS - 1)) : 0;
+    const uint32_t nv = wide_cap * (MSM_WINDOWS - 1), rows_all = rows + nv;
+    if ((rc = ensure_rows(ctx, rows_all))) return rc;
     if (s->flags_cap < rows + 1) {
         if (s->hi_flags) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->hi_flags)); ZK_HIP(hipFree(s->row_list)); }
-        ZK_HIP(hipMalloc((void **) &s->hi_flags, ((size_t) rows + 1) * 4));
+        ZK_HIP(hipMalloc((void **) &s->hi_flags, ((size_t) rows + 1) * 4));                  // [rows] = number of flagged rows
         ZK_HIP(hipMalloc((void **) &s->row_list, ((size_t) rows + 1) * 4));
         s->flags_cap = rows + 1;
     }
     ZK_HIP(hipMemsetAsync(s->hi_flags, 0, ((size_t) rows + 1) * 4, ctx->stream));
-    if ((rc = regrow(ctx, (void **) &s->codes, &s->codes_cap, (size_t) rows * cols * 2))) return rc;
+    if ((rc = regrow(ctx, (void **) &s->codes, &s->codes_cap, (size_t) rows_all * cols * 2))) return rc;
     const uint32_t cpt = std::max<uint32_t>(1, std::min<uint32_t>(64, (cols + MSM_BLOCK - 1) / MSM_BLOCK));
     const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt), n = chunks * MSM_BLOCK;
-    if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * n * sizeof(g1j_t)))) return rc;
-    for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
-        const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
-        ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_scalar_codes, dim3(std::min<uint32_t>((cols + 255) / 256, 64), nr), dim3(256), s->codes + (size_t) r0 * cols,
+    if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows_all * n * sizeof(g1j_t)))) return rc;
+    if ((rc = regrow(ctx, (void **) &s->tmpJ, &s->tmp_cap, (size_t) std::max<uint32_t>(wide_cap, 1) * sizeof(g1j_t)))) return rc;
+    uint32_t *n_wide = s->hi_flags + rows;
+    const dim3 cgrid(std::min<uint32_t>((cols + 255) / 256, 64), 1);
+    for (uint32_t r0 = 0; r0 < rows; r0 += 32768)
+        ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_scalar_codes, dim3(cgrid.x, std::min<uint32_t>(32768, rows - r0)), dim3(256), s->codes + (size_t) r0 * cols,
                   s->hi_flags + r0, scalars + (size_t) r0 * ld, ld, cols);
-        const double bytes = 32.0 * (double) nr * (double) cols;
+    if (wide_cap) {
+        ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_compact_flags, dim3(1), dim3(1024), s->row_list, n_wide, s->hi_flags, rows, wide_cap);
+        ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_scalar_codes_wide, dim3(cgrid.x, wide_cap), dim3(256), s->codes + (size_t) rows * cols, scalars, ld, s->row_list, n_wide, cols);
+    }
+    for (uint32_t r0 = 0; r0 < rows_all; r0 += 65535) {           // one launch whenever rows + virtual rows <= 65535 (always, for the circuits here)
+        const uint32_t nr = std::min<uint32_t>(65535, rows_all - r0), n_real = std::min<uint32_t>(nr, r0 < rows ? rows - r0 : 0);
+        const double bytes = 32.0 * (double) std::min(nr, n_real) * (double) cols;
         if (s->safe)
             ZK_LAUNCH(PC_MSM_PLANES, bytes, k_msm_codes<true>, dim3(chunks, nr), dim3(MSM_BLOCK), s->partials + (size_t) r0 * n, s->exc,
-                      s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, 0u);
+                      s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, n_real, n_wide);
         else
             ZK_LAUNCH(PC_MSM_PLANES, bytes, k_msm_codes<false>, dim3(chunks, nr), dim3(MSM_BLOCK), s->partials + (size_t) r0 * n, s->exc,
-                      s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, 0u);
+                      s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, n_real, n_wide);
     }
     ZK_HIP(hipGetLastError());
-    if ((rc = reduce_rows(ctx, s->partials, n, rows, s->rowsJ))) return rc;
-    std::vector<uint32_t> flags((size_t) rows + 1), list;
-    ZK_HIP(hipMemcpyAsync(flags.data(), s->hi_flags, (size_t) rows * 4, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(&flags[rows], s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = reduce_rows(ctx, s->partials, n, rows_all, s->rowsJ))) return rc;         // rowsJ[rows + v] = sum of virtual row v
+    if (wide_cap) {
+        if ((rc = reduce_rows(ctx, s->rowsJ + rows, MSM_WINDOWS - 1, wide_cap, s->tmpJ))) return rc;
+        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_add_rows, dim3((wide_cap + 63) / 64), dim3(64), s->rowsJ, s->tmpJ, s->row_list, wide_cap, n_wide);
+        ZK_HIP(hipGetLastError());
+    }
+    std::vector<uint32_t> flags((size_t) rows + 2), list;
+    ZK_HIP(hipMemcpyAsync(flags.data(), s->hi_flags, ((size_t) rows + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(&flags[rows + 1], s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
-    if (flags[rows] && !s->safe) return ZK_RETRY_SAFE;
+    if (flags[rows + 1] && !s->safe) return ZK_RETRY_SAFE;
+    if (wide_cap && flags[rows] <= wide_cap) return ZK_OK;       // every wide row went through the virtual rows
     for (uint32_t r = 0; r < rows; ++r) if (flags[r]) list.push_back(r);
     if (list.empty()) return ZK_OK;
+    // separate pass: all wide rows when there was no byte table, the ones beyond the list otherwise (list rows are ascending on both sides)
+    if (wide_cap) list.erase(list.begin(), list.begin() + wide_cap);
     const uint32_t nl = (uint32_t) list.size();
     ZK_HIP(hipMemcpyAsync(s->row_list, list.data(), (size_t) nl * 4, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = regrow(ctx, (void **) &s->tmpJ, &s->tmp_cap, (size_t) nl * sizeof(g1j_t)))) return rc;
-    if (s->full_ready) {
-        // windows 1..31 of the wide rows as 31 virtual rows each of the same hot kernel, then 31 -> 1 per wide row
-        const uint32_t nv = nl * (MSM_WINDOWS - 1);
-        if (nv > 65535) { ctx->err = "commit: too many rows with wide scalars"; return ZK_ERR_ARG; }
-        if ((rc = regrow(ctx, (void **) &s->codes_v, &s->codes_v_cap, (size_t) nv * cols * 2))) return rc;
-        if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) nv * n * sizeof(g1j_t)))) return rc;
-        if ((rc = regrow(ctx, (void **) &s->parts2, &s->parts2_cap, (size_t) nv * sizeof(g1j_t)))) return rc;
-        ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_scalar_codes_wide, dim3(std::min<uint32_t>((cols + 255) / 256, 64), nl), dim3(256), s->codes_v, scalars, ld, s->row_list, cols);
-        if (s->safe)
-            ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_msm_codes<true>, dim3(chunks, nv), dim3(MSM_BLOCK), s->partials, s->exc, s->codes_v, s->full, (uint32_t) s->m, cols, cpt,
-                      (uint32_t) (MSM_WINDOWS - 1));
-        else
-            ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_msm_codes<false>, dim3(chunks, nv), dim3(MSM_BLOCK), s->partials, s->exc, s->codes_v, s->full, (uint32_t) s->m, cols, cpt,
-                      (uint32_t) (MSM_WINDOWS - 1));
-        ZK_HIP(hipGetLastError());
-        if ((rc = reduce_rows(ctx, s->partials, n, nv, s->parts2))) return rc;
-        if ((rc = reduce_rows(ctx, s->parts2, MSM_WINDOWS - 1, nl, s->tmpJ))) return rc;
-    } else {
-        if ((rc = scalar_mags(ctx, scalars, ld, s->row_list, nl, cols))) return rc;
-        if ((rc = msm_windows(ctx, nullptr, cols, nl, cols, 1, s->tmpJ))) return rc;
-    }
-    ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_add_rows, dim3((nl + 63) / 64), dim3(64), s->rowsJ, s->tmpJ, s->row_list, nl);
+    if ((rc = scalar_mags(ctx, scalars, ld, s->row_list, nl, cols))) return rc;
+    if ((rc = msm_windows(ctx, nullptr, cols, nl, cols, 1, s->tmpJ))) return rc;
+    ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_add_rows, dim3((nl + 63) / 64), dim3(64), s->rowsJ, s->tmpJ, s->row_list, nl, (const uint32_t *) nullptr);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }

@@ -425,6 +425,11 @@ __device__ __forceinline__ fr_t fr_load_agent(const fr_t *p) {
     }
     return z;
 }
+// Outside the HIP memory model: correct where vector-memory STORES are counted by vmcnt, i.e. the gfx9 family this library is built for
+// (gfx10+ counts them in vscnt, where this wait would order nothing). Any other target must use the fence path (g_finish_light = 0).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "grid_finish: the light hand-over relies on s_waitcnt vmcnt(0) ordering stores (gfx9 family only)"
+#endif
 #define ZK_WAIT_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 template <int K>

@@ -136,11 +136,38 @@ __global__ void __launch_bounds__(256) k_scalar_codes(uint16_t *codes, uint32_t 
     if (wide) row_flags[row] = 1;
 }
 
+// row_list[0 .. *count) = the rows whose flag is set, ascending (single block; rows <= a few 10^4); *count may exceed `cap`: the
+// list then holds the first `cap` of them and the caller takes its slow path
+__global__ void __launch_bounds__(1024) k_compact_flags(uint32_t *row_list, uint32_t *count, const uint32_t *flags, uint32_t rows, uint32_t cap) {
+    __shared__ uint32_t s_wave[16], s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (uint32_t r0 = 0; r0 < rows; r0 += 1024) {
+        const uint32_t r = r0 + threadIdx.x;
+        const bool on = r < rows && flags[r] != 0;
+        const unsigned long long b = __ballot(on);
+        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) s_wave[wave] = (uint32_t) __popcll(b);
+        __syncthreads();
+        uint32_t off = s_base;
+        for (uint32_t w = 0; w < wave; ++w) off += s_wave[w];
+        const uint32_t pos = off + (uint32_t) __popcll(b & ((1ull << lane) - 1));
+        if (on && pos < cap) row_list[pos] = r;
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < 16; ++w) t += s_wave[w]; s_base += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = s_base;
+}
+
 // The higher windows of the rows that hold wide scalars (biases, maxima, the picture: whole rows of 2..4-byte values), as VIRTUAL rows
 // of the same hot kernel: codes[(ri * 31 + w - 1) * cols + c] = byte w of |scalars[row_list[ri]][c]| with its sign, w = 1..31.
 // k_msm_codes takes virtual row v through window table 1 + v % 31; windows no scalar reaches are rows of zeros that cost nothing.
-__global__ void __launch_bounds__(256) k_scalar_codes_wide(uint16_t *codes, const fr_t *scalars, uint64_t ld, const uint32_t *row_list, uint32_t cols) {
-    const uint32_t ri = blockIdx.y, row = row_list[ri];
+__global__ void __launch_bounds__(256) k_scalar_codes_wide(uint16_t *codes, const fr_t *scalars, uint64_t ld, const uint32_t *row_list,
+                                                           const uint32_t *count, uint32_t cols) {
+    const uint32_t ri = blockIdx.y;
+    if (ri >= *count) return;                           // the grid covers the list's capacity
+    const uint32_t row = row_list[ri];
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
         const fr_t raw = fr_load(scalars + (size_t) row * ld + c);
         fr_t s = raw;
@@ -179,16 +206,27 @@ __device__ __forceinline__ bool mag_neg(const fr_t *mag, size_t i) { return (rei
 // ------------------------------------------------------------------------------------------------
 // the commitment's hot kernel: signed-byte codes through a digit table. grid (chunks, rows), one wave per block; lane l owns columns
 // base + 64 i + l, i < cpt <= 64. out[(row * chunks + chunk) * 64 + lane] = the lane's partial sum.
-// vwin == 0: every row uses D[d][j] = d g_j.  vwin == 31: the rows are virtual rows (k_scalar_codes_wide), row v uses window
-// 1 + v % 31 of the full byte table F[w][d][j] = d 2^(8w) g_j, of which D is window 0.
+// Rows < n_real use D[d][j] = d g_j. Rows >= n_real are virtual rows (k_scalar_codes_wide): virtual row v uses window 1 + v % 31 of
+// the full byte table F[w][d][j] = d 2^(8w) g_j, of which D is window 0; only the first 31 * *n_wide of them exist.
 // ------------------------------------------------------------------------------------------------
 template <bool SAFE>
 __global__ void __launch_bounds__(MSM_BLOCK) k_msm_codes(g1j_t *out, uint32_t *exc_flag, const uint16_t *codes, const g1a_t *D, uint32_t m, uint32_t cols,
-                                                         uint32_t cpt, uint32_t vwin) {
-    const uint32_t row = blockIdx.y, lane = threadIdx.x;
+                                                         uint32_t cpt, uint32_t n_real, const uint32_t *n_wide) {
+    // the virtual rows come FIRST in the grid (their few long chains then run alongside the heavy rows instead of forming a tail);
+    // `row` is the logical row: real rows 0 .. n_real - 1, virtual rows behind them
+    const uint32_t n_virtual = gridDim.y - n_real;
+    const uint32_t row = blockIdx.y < n_virtual ? n_real + blockIdx.y : blockIdx.y - n_virtual, lane = threadIdx.x;
     const uint32_t base = blockIdx.x * (MSM_BLOCK * cpt) + lane;
     const uint16_t *rc = codes + (size_t) row * cols;
-    if (vwin) D += (size_t) (1 + row % vwin) * 256 * m;
+    g1j_t *dst = out + ((size_t) row * gridDim.x + blockIdx.x) * MSM_BLOCK + lane;
+    if (row >= n_real) {
+        const uint32_t v = row - n_real;
+        if (v >= *n_wide * (MSM_WINDOWS - 1)) {          // beyond the list: an empty partial sum, nothing to read
+            g1j_store(dst, fp_zero(), fp_zero(), fp_zero(), true);
+            return;
+        }
+        D += (size_t) (1 + v % (MSM_WINDOWS - 1)) * 256 * m;
+    }
     // which of this lane's columns carry a non-zero byte: cpt independent 2-byte loads, then the loop below visits set bits only,
     // so a lane of a half-empty bit row is done after its ~cpt/2 additions instead of idling through cpt iterations
     unsigned long long mask = 0;
@@ -223,7 +261,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_codes(g1j_t *out, uint32_t *e
             g1_accumulate<SAFE>(X, Y, Z, empty, px, py, (code & MSM_CODE_NEG) != 0, exc);
         }
     }
-    g1j_store(out + ((size_t) row * gridDim.x + blockIdx.x) * MSM_BLOCK + lane, X, Y, Z, empty);
+    g1j_store(dst, X, Y, Z, empty);
     if (!SAFE && exc) *exc_flag = 1;
 }
 
@@ -410,10 +448,10 @@ __global__ void __launch_bounds__(512) k_msm_finish(g1j_t *outJ, const g1j_t *pa
     if (threadIdx.x == 0) outJ[row] = sm[0][0];
 }
 
-// rows[list[i]] += extra[i]
-__global__ void __launch_bounds__(MSM_BLOCK) k_add_rows(g1j_t *rows, const g1j_t *extra, const uint32_t *list, uint32_t n) {
+// rows[list[i]] += extra[i], i < min(n, *count)
+__global__ void __launch_bounds__(MSM_BLOCK) k_add_rows(g1j_t *rows, const g1j_t *extra, const uint32_t *list, uint32_t n, const uint32_t *count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) rows[list[i]] = g1_add_any(rows[list[i]], extra[i]);
+    if (i < n && (!count || i < *count)) rows[list[i]] = g1_add_any(rows[list[i]], extra[i]);
 }
 
 // ------------------------------------------------------------------------------------------------

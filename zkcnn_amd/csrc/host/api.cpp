@@ -72,7 +72,7 @@ private:
 };
 
 struct gpuSession : public sessionT<prover> {
-    explicit gpuSession(int device) : dev(device), va(&p) { vaccel = &va; }
+    explicit gpuSession(int device) : sessionT<prover>(device), dev(device), va(&p) { vaccel = &va; }
     int dev;
     hipVerifierAccel va;
 };
@@ -82,20 +82,17 @@ extern "C" {
 void *zkcnn_session_create(const zkcnn_model_desc *desc, int32_t device) {
     if (!desc) return nullptr;
     try {
-        gpuSession *s = new gpuSession(device);
-        // placement-new the prover on the requested device: sessionT owns a default-constructed one
-        s->p.~prover();
-        new (&s->p) prover(device);
+        std::unique_ptr<gpuSession> s(new gpuSession(device));      // owns the session until it is complete: nothing leaks when a step throws
         {
             s->p.ensureContext();
             hipWitnessAccel accel(s->p.context());
             s->accel = &accel;
             bool ok = s->build(desc);
             s->accel = nullptr;
-            if (!ok) { delete s; return nullptr; }
+            if (!ok) return nullptr;
         }
         s->p.init();                 // residency: circuit + witness to HBM, outside any timed region
-        return s;
+        return s.release();
     } catch (const std::exception &e) {
         fprintf(stderr, "zkcnn_session_create: %s\n", e.what());
         return nullptr;
@@ -126,12 +123,10 @@ int64_t zkcnn_session_statement(void *session, int32_t *scales, uint64_t cap) {
 void *zkcnn_verifier_create(const zkcnn_model_desc *desc, const int32_t *scales, uint64_t n_scales, int32_t device) {
     if (!desc || (!scales && n_scales)) return nullptr;
     try {
-        gpuSession *s = new gpuSession(device);
-        s->p.~prover();
-        new (&s->p) prover(device);
-        if (!s->buildStatement(desc, scales, n_scales)) { delete s; return nullptr; }
+        std::unique_ptr<gpuSession> s(new gpuSession(device));
+        if (!s->buildStatement(desc, scales, n_scales)) return nullptr;
         s->p.init();                 // the circuit goes to the GPU for the wiring predicates; there are no values to upload
-        return s;
+        return s.release();
     } catch (const std::exception &e) {
         fprintf(stderr, "zkcnn_verifier_create: %s\n", e.what());
         return nullptr;

@@ -69,3 +69,60 @@ void layeredCircuit::initSubset() {
         cur.updateSize();
     }
 }
+
+// ---- wiring digest (Fiat-Shamir statement binding; not on any timed path) ----
+#include <thread>
+#include "../ff/sha256.hpp"
+
+namespace {
+struct leafJob { const uint8_t *p; size_t n; uint8_t out[32]; };
+}
+
+const uint8_t *layeredCircuit::wiringDigest() const {
+    if (wiring_digest_ok) return wiring_digest;
+    // leaves: consecutive spans of at most 2^20 records of each list, in layer order: uni gates (12 B), bin gates (16 B), ori_id_u, ori_id_v (4 B)
+    std::vector<leafJob> jobs;
+    auto add = [&](const void *base, size_t count, size_t rec) {
+        const uint8_t *b = static_cast<const uint8_t *>(base);
+        const size_t span = (size_t) 1 << 20;
+        for (size_t i = 0; i < count; i += span) {
+            leafJob j;
+            j.p = b + i * rec;
+            j.n = std::min(span, count - i) * rec;
+            jobs.push_back(j);
+        }
+    };
+    static_assert(sizeof(uniGate) == 12 && sizeof(binGate) == 16, "gate records are hashed as they lie in memory");
+    for (int i = 0; i < size; ++i) {
+        const layer &L = circuit[i];
+        add(L.uni_gates.data(), L.uni_gates.size(), sizeof(uniGate));
+        add(L.bin_gates.data(), L.bin_gates.size(), sizeof(binGate));
+        add(L.ori_id_u.data(), L.ori_id_u.size(), 4);
+        add(L.ori_id_v.data(), L.ori_id_v.size(), 4);
+    }
+    // (the records carry explicit zero padding bytes, circuit.h, so raw memory is a canonical encoding)
+    unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (jobs.size() < 4) nthreads = 1;
+    auto work = [&](unsigned t) {
+        for (size_t k = t; k < jobs.size(); k += nthreads) {
+            zkff::Sha256 h;
+            h.update(jobs[k].p, jobs[k].n);
+            h.digest(jobs[k].out);
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    zkff::Sha256 top;
+    const uint64_t header[2] = {(uint64_t) size, (uint64_t) jobs.size()};
+    top.update(header, sizeof(header));
+    for (const leafJob &j : jobs) {
+        const uint64_t n = j.n;
+        top.update(&n, 8);
+        top.update(j.out, 32);
+    }
+    top.digest(wiring_digest);
+    wiring_digest_ok = true;
+    return wiring_digest;
+}

@@ -11,12 +11,14 @@
 struct uniGate {
     u32 g, u;
     u8 lu, sc;
+    u8 pad_[2] = {0, 0};                 // explicit zero padding: records are uploaded and hashed as they lie in memory (12 bytes)
     uniGate(u32 out, u32 in, u8 in_layer, u8 scale_id) : g(out), u(in), lu(in_layer), sc(scale_id) {}
 };
 
 struct binGate {
     u32 g, u, v;
     u8 sc, l;
+    u8 pad_[2] = {0, 0};                 // 16 bytes
     binGate(u32 out, u32 in_u, u32 in_v, u8 scale_id, u8 layers) : g(out), u(in_u), v(in_v), sc(scale_id), l(layers) {}
     u8 getLayerIdU(u8 layer_id) const { return l == 0 ? 0 : (u8) (layer_id - 1); }
     u8 getLayerIdV(u8 layer_id) const { return (l & 1) ? (u8) (layer_id - 1) : 0; }
@@ -59,4 +61,10 @@ public:
 
     void init(u8 q_bit_size, u8 layer_cnt);
     void initSubset();
+    // SHA-256 tree over the gate lists and subset maps of every layer (leaves of 2^20 records, hashed on several host threads);
+    // computed on first use and kept: what a Fiat-Shamir transcript absorbs as "the wiring"
+    const uint8_t *wiringDigest() const;
+private:
+    mutable uint8_t wiring_digest[32];
+    mutable bool wiring_digest_ok = false;
 };

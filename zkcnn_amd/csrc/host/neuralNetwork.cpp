@@ -167,8 +167,7 @@ void neuralNetwork::build(layeredCircuit &C, vector<vector<F>> &val, bool only_c
             }
             // re-quantise: keep Q bits of the accumulator, T = bits dropped
             x_next_bit = nextScaleBits(layer_id - 1);
-            T = x_bit + w_bit - x_next_bit;
-            Q_MAX = Q + T;
+            setTruncation();
             if (pool_ty != MAX)
                 emitRelu(C.circuit[layer_id], layer_id, nx_out * ny_out * channel_out * pic_parallel);
         }
@@ -186,8 +185,7 @@ void neuralNetwork::build(layeredCircuit &C, vector<vector<F>> &val, bool only_c
         emitFC(C.circuit[layer_id], layer_id, fc.weight_start_id, fc.bias_start_id);
         if (i + 1 == full_conn.size()) break;
         x_next_bit = nextScaleBits(layer_id - 1);
-        T = x_bit + w_bit - x_next_bit;
-        Q_MAX = Q + T;
+        setTruncation();
         emitRelu(C.circuit[layer_id], layer_id, channel_out * pic_parallel);
     }
     assert(SIZE == layer_id);
@@ -374,6 +372,16 @@ void neuralNetwork::evalTransform(const layer &L, i64 layer_id) {
             for (size_t j = 0; j < lenh; ++j) out[c + j] = arr[j];
         }
     }
+}
+
+// T = bits dropped by the re-quantisation, Q_MAX = width of the value that is decomposed into bits. The scales may come from an
+// untrusted statement (proof file): they size layers (block_len * Q_MAX rows) and index two_mul, so they are bounded here -- in
+// every build, the NDEBUG asserts elsewhere are not a defence.
+void neuralNetwork::setTruncation() {
+    T = x_bit + w_bit - x_next_bit;
+    Q_MAX = Q + T;
+    if (x_bit < 0 || x_bit > 62 || w_bit < 0 || w_bit > 62 || x_next_bit < 0 || x_next_bit > 62 || T < 0 || Q_MAX < Q || Q_MAX > 64)
+        throw std::runtime_error("statement: quantisation scale out of range");
 }
 
 // scale (in bits) of the next activation so that its range fits Q-1 bits

@@ -118,7 +118,9 @@ private:
     int logged(int computed) {       // record in a normal build, replay in a structure-only build
         if (!structure_only) { scale_log.push_back(computed); return computed; }
         if (scale_pos >= scale_log.size()) throw std::runtime_error("statement: too few quantisation scales");
-        return scale_log[scale_pos++];
+        const int v = scale_log[scale_pos++];
+        if (v < 0 || v > 62) throw std::runtime_error("statement: quantisation scale out of range");      // untrusted input (proof file)
+        return v;
     }
     vector<vector<F>> *vals;       // == &pr.val while building
     i64 in_dirty_lo = 0;           // layer-0 entries from here on are newer than the accelerator's copy
@@ -126,6 +128,7 @@ private:
     void touch0(i64 idx) { if (idx < in_dirty_lo) in_dirty_lo = idx; }
     const F *two_mul;
 
+    void setTruncation();
     void planLayout();
     void setConv(i64 nx, i64 ny, const convKernel &conv);
     void setFC(const fconKernel &fc);

@@ -9,20 +9,37 @@
 #pragma once
 #include <stdexcept>
 #include "../ff/sha256.hpp"
+#include "../../../include/zkcnn_api.h"
 #include "verifier.hpp"
 
 class fiatShamir : public zkff::ChallengeSource, public transcriptTap {
 public:
     fiatShamir() { absorb("zkcnn-amd/fiat-shamir/v1", 24); }
     void absorb(const void *data, size_t n) override { st.update(data, n); }
-    // binds the statement: model descriptor and the shape of every layer of the circuit
-    void absorbStatement(const string &model, const layeredCircuit &C) {
-        absorb(model.data(), model.size());
+    // binds the statement: the whole model descriptor, every quantisation scale (they fix gate exponents, layer sizes and Q_MAX), the
+    // shape of every layer and a digest of the wiring (gate lists, subset maps): statements that differ anywhere get unrelated challenges
+    void absorbStatement(const zkcnn_model_desc &d, const vector<int> &scales, const layeredCircuit &C) {
+        const uint64_t ml = d.model ? std::strlen(d.model) : 0;
+        absorb(&ml, 8);
+        if (ml) absorb(d.model, ml);
+        const int64_t shape[4] = {d.pic_x, d.pic_y, d.pic_channel, d.pic_cnt};
+        absorb(shape, sizeof(shape));
+        const uint64_t ns = scales.size();
+        absorb(&ns, 8);
+        for (int sc : scales) { const int64_t v = sc; absorb(&v, 8); }
+        const uint64_t nl = C.size;
+        absorb(&nl, 8);
         for (int i = 0; i < C.size; ++i) {
             const layer &L = C.circuit[i];
-            uint64_t rec[4] = {(uint64_t) L.ty, L.size, L.uni_gates.size(), L.bin_gates.size()};
+            int64_t rec[16] = {(int64_t) L.ty, L.size, L.bit_length, L.fft_bit_length, L.zero_start_id, (int64_t) L.uni_gates.size(),
+                               (int64_t) L.bin_gates.size(), L.size_u[0], L.size_u[1], L.size_v[0], L.size_v[1], L.bit_length_u[0],
+                               L.bit_length_u[1], L.bit_length_v[0], L.bit_length_v[1], L.need_phase2};
             absorb(rec, sizeof(rec));
+            uint8_t sb[32];
+            L.scale.toBytesLE(sb);
+            absorb(sb, 32);
         }
+        absorb(C.wiringDigest(), 32);
     }
     void words(uint64_t out[4]) override {
         zkff::Sha256 c = st;

@@ -7,14 +7,17 @@
 #include "../../../include/zkcnn_api.h"
 #include "models.hpp"
 #include "replay.hpp"
+#include "../ff/hash_to_curve.hpp"
 
 template <class ProverT>
 struct sessionT {
+    sessionT() {}
+    template <class A> explicit sessionT(const A &prover_arg) : p(prover_arg) {}      // e.g. the GPU index of the HIP-backed prover
     ProverT p;
     std::unique_ptr<neuralNetwork> nn;
     std::vector<G1> gens;
     string model_name;
-    int pic_cnt = 1;
+    int pic_cnt = 1, pic_x = 0, pic_y = 0, pic_channel = 0;
     double witness_s = 0;
     string row;
     witnessAccel *accel = nullptr;     // set by the product driver while the witness is generated
@@ -24,6 +27,12 @@ struct sessionT {
         return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     }
 
+    // a model descriptor may come from an untrusted proof file: bound it before anything is sized from it
+    static bool sane(const zkcnn_model_desc *d) {
+        return d->pic_x >= 1 && d->pic_x <= 1024 && d->pic_y >= 1 && d->pic_y <= 1024 && d->pic_channel >= 1 && d->pic_channel <= 64 &&
+               d->pic_cnt >= 1 && d->pic_cnt <= 256;
+    }
+
     bool has_witness = true;           // false: a verifier-only session (circuit rebuilt from a statement, nothing to prove)
 
     // statement = the quantisation scales recorded while the circuit was built; with them, buildStatement() reproduces the circuit
@@ -31,7 +40,8 @@ struct sessionT {
     const vector<int> &statementScales() const { return nn->scales(); }
     bool buildStatement(const zkcnn_model_desc *d, const int32_t *scales, uint64_t n) {
         model_name = d->model ? d->model : "";
-        pic_cnt = d->pic_cnt;
+        pic_cnt = d->pic_cnt; pic_x = d->pic_x; pic_y = d->pic_y; pic_channel = d->pic_channel;
+        if (!sane(d)) return false;
         nn.reset(makeModel(model_name, d->pic_x, d->pic_y, d->pic_channel, d->pic_cnt));
         if (!nn) return false;
         nn->setStructureOnly(vector<int>(scales, scales + n));
@@ -43,7 +53,8 @@ struct sessionT {
 
     bool build(const zkcnn_model_desc *d) {
         model_name = d->model ? d->model : "";
-        pic_cnt = d->pic_cnt;
+        pic_cnt = d->pic_cnt; pic_x = d->pic_x; pic_y = d->pic_y; pic_channel = d->pic_channel;
+        if (!sane(d)) return false;
         nn.reset(makeModel(model_name, d->pic_x, d->pic_y, d->pic_channel, d->pic_cnt));
         if (!nn) return false;
         nn->useSyntheticData(d->data_seed);
@@ -54,29 +65,35 @@ struct sessionT {
         return true;
     }
 
-    // common set-up of a verifier run: challenge source (seeded stream, or the transcript itself), generators, options
+    // common set-up of a verifier run: challenge source (OS CSPRNG, seeded stream, or the transcript itself), generators, options
     template <class V>
     void configure(V &v, uint64_t challenge_seed, uint32_t mode, fiatShamir &fs, std::unique_ptr<challengeScope> &scope) {
-        const bool reuse = mode & ZKCNN_MODE_REUSE_GENS;
+        const bool fiat = (mode & ZKCNN_MODE_FIAT_SHAMIR) != 0;
+        // generators both sides know in advance must not have a known discrete logarithm: hash-to-curve (ff/hash_to_curve.hpp).
+        // Only the in-process interactive run keeps the reference's k_i * G, with k_i drawn by the verifier and never shown to the prover.
+        const bool public_gens = fiat || (mode & ZKCNN_MODE_REUSE_GENS);
         const u8 logn = p.C.circuit[0].bit_length;
         const size_t n_sqrt = (size_t) 1 << (logn - (logn >> 1));
-        Fr::seedCSPRNG(challenge_seed);
-        if (reuse && gens.size() != n_sqrt) {
-            // session generators come from their own stream so that they do not depend on the proof seed
-            Fr::seedCSPRNG(0x67656e73ULL);
-            drawGenerators(gens, n_sqrt);
-            Fr::seedCSPRNG(challenge_seed);
+        if (mode & ZKCNN_MODE_SEEDED) Fr::seedCSPRNG(challenge_seed);
+        else Fr::useOsRandom();
+        const zkff::publicGenerators *pg = nullptr;
+        if (public_gens) {
+            pg = &zkff::publicGeneratorSet(n_sqrt);
+            if (gens.size() != n_sqrt) gens = pg->gens;
         }
         v.drive_only = (mode & ZKCNN_MODE_DRIVE_ONLY) != 0;
-        if (reuse) v.fixed_gens = &gens;
+        if (public_gens) v.fixed_gens = &gens;
         if (mode & ZKCNN_MODE_TAMPER) v.tamper_at = (long) (mode >> 8);
         if (vaccel && !(mode & ZKCNN_MODE_HOST_PRED)) v.accel = vaccel;
         v.cross_check = (mode & ZKCNN_MODE_CROSS_PRED) != 0;
-        if (mode & ZKCNN_MODE_FIAT_SHAMIR) {
-            // non-interactive: every challenge (and, unless the session's are re-used, every generator) is a hash of the
-            // statement and of all messages received so far
-            fs.absorbStatement(model_name, p.C);
-            if (reuse) for (const G1 &g : gens) { u8 b[48]; g.serialize(b); fs.absorb(b, 48); }
+        if (fiat) {
+            // non-interactive: every challenge is a hash of the statement (model, picture shape, quantisation scales, every layer's
+            // shape, a digest of the wiring, the generators) and of all messages received so far
+            zkcnn_model_desc d;
+            d.model = model_name.c_str();
+            d.pic_x = pic_x; d.pic_y = pic_y; d.pic_channel = pic_channel; d.pic_cnt = pic_cnt; d.data_seed = 0;
+            fs.absorbStatement(d, nn->scales(), p.C);
+            fs.absorb(pg->digest, 32);
             v.transcript.tap = &fs;
             v.lazy_challenges = true;
             scope.reset(new challengeScope(&fs));
@@ -142,6 +159,13 @@ struct sessionT {
         mode &= ~(uint32_t) (ZKCNN_MODE_DRIVE_ONLY | ZKCNN_MODE_TAMPER);
         bool ok = false;
         string why;
+        if (!(mode & (ZKCNN_MODE_FIAT_SHAMIR | ZKCNN_MODE_SEEDED))) {
+            // the challenges of an interactive transcript were the verifier's own coins; off line there is nothing to check them against
+            out->accepted = 0;
+            std::snprintf(out->message, sizeof(out->message), "not a non-interactive proof: only Fiat-Shamir proofs verify off line (seeded replay: ZKCNN_MODE_SEEDED)");
+            out->wall_s = now() - t0;
+            return 0;
+        }
         try {
             replayProver rp(proof, len, &p.C);
             verifierT<replayProver> v(&rp, p.C);

@@ -52,17 +52,37 @@ def dumps_from(session, transcript, challenge_seed, mode):
     return dumps(transcript, session.model, session.pic, session.pic_cnt, session.data_seed, challenge_seed, mode, session.statement())
 
 
-def verify_standalone(blob, session_cls, **kw):
+class NotAProofError(ValueError):
+    """the file holds an interactive transcript: its challenges were the verifier's private coins, off line it proves nothing"""
+
+
+def _replay_args(header, allow_seeded_replay):
+    """(seed, mode) for Session.verify. A header is prover-controlled input: a file that says "seeded-stream" names the very seed its
+    challenges came from, so whoever wrote it knew every challenge before sending a single message. Such a file is only ever
+    replayed on request (parity / debugging), never accepted as a proof."""
+    from . import MODE_FIAT_SHAMIR, MODE_REUSE_GENS
+    mode = int(header["mode"]) & (MODE_FIAT_SHAMIR | MODE_REUSE_GENS)
+    if mode & MODE_FIAT_SHAMIR:
+        return None, mode
+    if not allow_seeded_replay:
+        raise NotAProofError("interactive transcript (seeded challenge stream): not a proof; pass allow_seeded_replay=True to replay it for debugging")
+    return int(header["challenge_seed"] or 0), mode
+
+
+def verify_standalone(blob, session_cls, allow_seeded_replay=False, **kw):
     """verifies a proof file with nothing but the file: the circuit is rebuilt from the header's model descriptor + statement
-    (session_cls: zkcnn_amd.Session for GPU predicates, or the oracle's session class in tests). Returns the Result."""
+    (session_cls: zkcnn_amd.Session for GPU predicates, or the oracle's session class in tests). Returns the Result.
+    Only Fiat-Shamir proofs are accepted; see _replay_args."""
     header, tr = loads(blob)
     if header.get("statement") is None:
         raise ValueError("proof file carries no statement")
+    seed, mode = _replay_args(header, allow_seeded_replay)
     with session_cls(header["model"], tuple(header["pic"]), header["pic_cnt"], statement=header["statement"], **kw) as v:
-        return v.verify(tr, seed=header["challenge_seed"] or 0, mode=header["mode"])
+        return v.verify(tr, seed=seed, mode=mode)
 
 
-def verify_with(session, blob):
-    """replays a proof file against `session` (whose circuit must be the file's statement); returns the Result"""
+def verify_with(session, blob, allow_seeded_replay=False):
+    """checks a proof file against `session` (whose circuit must be the file's statement); returns the Result"""
     header, tr = loads(blob)
-    return session.verify(tr, seed=header["challenge_seed"] or 0, mode=header["mode"])
+    seed, mode = _replay_args(header, allow_seeded_replay)
+    return session.verify(tr, seed=seed, mode=mode)
