@@ -14,7 +14,13 @@ step runs the full verifier and must print acceptance.
 One JSON line on rank 0:
   value        whole-job proofs/s over all N GPUs (weak scaling: --streams images per GPU per step)
   roofline     dominant kernel: algorithmic bytes / HIP-event time measured inside the timed steps
-  cpu_baseline the CPU oracle (port of the reference prover) on a bounded sample, 1 core
+  cpu_baseline the CPU oracle (port of the reference prover) on the SAME workload, one core, plus the aggregate of several
+               independent single-threaded provers running side by side on the host cores (the reference has no threads)
+
+Modes of the timed proofs (stated in `metric`): SEEDED (reproducible challenges) | DRIVE_ONLY | REUSE_GENS (public hash-to-curve
+generators; their byte table is built once per session outside the clock) with the inner-product argument cut at 256. The
+conservative companions are reported next to it: prover_ms_fresh_gens_full_ipa (new random generators for the proof, argument run
+down to length 1, nothing pre-built) and upload_sort_s (gate sort + upload, which the reference pays inside its prover timer).
 """
 import argparse
 import json
@@ -48,7 +54,19 @@ WORKLOADS = {
 # r01g_vgg11_pp8_pmc_traffic.md likewise. None where no PMC pass exists for the (workload, class).
 PMC_TRAFFIC_PER_LAUNCH = {("vgg11", "round_quad"): 11.02e6, ("vgg11_pp8", "round_quad"): (6.50 + 2.55 + 299.46 + 105.63) * 1e9 / (10000 + 2312)}
 # kernel classes whose algorithmic byte count is defined; the dominant one is reported
+STREAMING_PMC_BYTES = 1.7037e9      # profiles/r01_round_quad_kernel.md (FETCH_SIZE x2 + WRITE_SIZE) for 2 x 2^24 entries
 ROOFLINE_CLASSES = ["gate_reduce", "round_quad", "round_cubic", "msm_planes"]
+
+
+def _cpu_prover_worker(args):
+    """one single-threaded CPU prover (the oracle) on the workload: returns (prover seconds, wall seconds incl. circuit + witness)"""
+    model, pic, pp, seed, mode = args
+    sys.path.insert(0, ROOT)
+    from tests import oracle_ffi
+    t0 = time.time()
+    with oracle_ffi.OracleSession(model, pic, pp, data_seed=seed) as o:
+        res, _ = o.prove(seed=0x5EED0001, mode=mode, want_transcript=False)
+    return res.prove_s + res.poly_prove_s, time.time() - t0, int(res.gate_cnt_bin), res.prove_s, res.poly_prove_s
 
 
 def pin_to_gpu_numa_node(torch, local_rank):
@@ -81,7 +99,8 @@ def main():
     ap.add_argument("--workload", default="vgg11", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=8, help="proofs in flight per GPU (one session, host thread and HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="vgg11_half", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample", default=None, choices=sorted(WORKLOADS), help="CPU baseline workload (default: the bench workload itself)")
+    ap.add_argument("--cpu-procs", type=int, default=8, help="independent CPU provers run side by side for the host throughput figure (0 = skip)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel-class table of one extra proof to stderr")
     args = ap.parse_args()
 
@@ -107,7 +126,10 @@ def main():
     K = max(1, args.streams)
     try:                                # a session keeps ~8 GB of host memory (circuit + witness): do not overcommit a small node
         import psutil
-        K = max(1, min(K, int(psutil.virtual_memory().available / (10e9 * max(world, 1)))))
+        K_ram = max(1, int(psutil.virtual_memory().available / (10e9 * max(world, 1))))
+        if K_ram < K:
+            print(f"[bench] host memory allows {K_ram} sessions per rank, not the {K} asked for", file=sys.stderr)
+            K = K_ram
     except ImportError:
         pass
     drive = zkcnn_amd.MODE_DRIVE_ONLY | zkcnn_amd.MODE_REUSE_GENS
@@ -263,6 +285,7 @@ def main():
         achieved = prof["bytes"] / prof["launches"] / sec / 1e9
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_PER_LAUNCH.get((args.workload, dominant)),
+                    "traffic_source": "PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; see PMC_TRAFFIC_PER_LAUNCH) -- a constant from that pass, not measured in this run",
                     "avg_launch_ms": round(sec * 1e3, 4), "launches_per_step": prof["launches"] / EVENT_STEPS,
                     "note": f"HIP events on stream 0 of {K} streams during its first {EVENT_STEPS} timed proofs: launch durations include contention between the streams",
                     "algorithmic_bytes_per_launch": prof["bytes"] / prof["launches"],
@@ -281,10 +304,10 @@ def main():
             sec, nbytes = hc.bench_round_quadratic(24, 10)
             mul_sec = hc.bench_fr_mul(1 << 20, 256, 3)
             hc.close()
-            roofline["streaming_launch"] = {"kernel": "k_round_quad, 2 x 2^24 entries", "ms": round(sec * 1e3, 4),
+            roofline["streaming_launch"] = {"kernel": "k_round_quad2 (the product round kernel: fold + sums + grid finish + host slot), V and M of 2^24 entries", "ms": round(sec * 1e3, 4),
                                             "algorithmic_bytes": nbytes, "achieved": round(nbytes / sec / 1e9, 1),
                                             "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
-                                            "traffic_pmc_bytes": 1.7037e9,      # profiles/r01_round_quad_kernel.md (FETCH_SIZE x2 + WRITE_SIZE)
+                                            "traffic_pmc_bytes": STREAMING_PMC_BYTES, "traffic_source": "profiles/ PMC pass of this launch (constant, not measured in this run)",
                                             "fr_mul_ceiling_G_per_s": round((1 << 20) * 256 / mul_sec / 1e9, 1)}
         except Exception as e:      # the headline numbers do not depend on this extra measurement
             roofline["streaming_launch"] = {"error": str(e)}
@@ -294,36 +317,69 @@ def main():
         per_gpu = K * args.steps / elapsed
         roofline["whole_gpu"] = {"algorithmic_GB_per_proof": round(alg_bytes_per_proof / 1e9, 2), "achieved": round(alg_bytes_per_proof * per_gpu / 1e9, 1),
                                  "frac": round(alg_bytes_per_proof * per_gpu / 1e9 / HBM_PEAK_GBS, 4),
-                                 "note": "gate_reduce + round_quad + round_cubic + msm algorithmic bytes of one proof times proofs/s per GPU"}
+                                 "note": "ALGORITHMIC bytes (SURVEY 8(d)) of gate_reduce + round_quad + round_cubic + msm of one proof times proofs/s per GPU; "
+                                         "most gate_reduce gathers hit L2, so this is NOT HBM traffic (PMC: see profiles/)"}
     if rank != 0:
         sess.close()
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    # ---- CPU baseline: the oracle (port of the reference prover), 1 core, bounded sample ----
+    # ---- conservative companions of the headline (not timed steps): nothing pre-built, nothing cut ----
+    extras = {}
+    try:
+        fresh = []
+        for k in range(2):          # new random generators per proof (no REUSE_GENS): tables rebuilt inside the prover's clock; IPA down to length 1
+            r, _ = sess.prove(seed=0x5EED0200 + k, mode=zkcnn_amd.MODE_DRIVE_ONLY | zkcnn_amd.MODE_FULL_IPA, want_transcript=False)
+            fresh.append(1e3 * (r.prove_s + r.poly_prove_s))
+        extras["prover_ms_fresh_gens_full_ipa"] = round(min(fresh), 3)
+        r, _ = sess.prove(seed=0x5EED0210, mode=drive, want_transcript=False)      # back on the session generators (tables are rebuilt once)
+        r, _ = sess.prove(seed=0x5EED0211, mode=drive, want_transcript=False)
+        r, _ = sess.prove(seed=0x5EED0212, mode=drive | zkcnn_amd.MODE_FULL_IPA, want_transcript=False)
+        extras["prover_ms_session_gens_full_ipa"] = round(1e3 * (r.prove_s + r.poly_prove_s), 3)
+    except Exception as e:          # noqa: BLE001 - the headline does not depend on these
+        extras["companions_error"] = str(e)
+    sess.close()
+    sess = None
+
+    # ---- CPU baseline: the oracle (port of the reference prover) on the same workload ----
     cpu = None
-    if not args.no_cpu_baseline:
-        from tests import oracle_ffi
-        cm, cpic, cpp = WORKLOADS[args.cpu_sample]
-        with oracle_ffi.OracleSession(cm, cpic, cpp, data_seed=20260928) as o:
-            ores, _ = o.prove(seed=0x5EED0001, mode=drive, want_transcript=False)
-        cpu_ms = 1e3 * (ores.prove_s + ores.poly_prove_s)
-        # the GPU on the same sample, for a like-for-like ratio
-        with zkcnn_amd.Session(cm, cpic, cpp, data_seed=20260928, device=local_rank) as gs:
-            for _ in range(2):           # the second proof builds the MSM byte table of the session's generators
-                gs.prove(seed=0x5EED0001, mode=drive, want_transcript=False)
-            gres, _ = gs.prove(seed=0x5EED0001, mode=drive, want_transcript=False)
-        gpu_ms = 1e3 * (gres.prove_s + gres.poly_prove_s)
-        cpu = {"value": round(cpu_ms, 1), "unit": "prover ms/image", "cores": 1, "kind": "port",
-               "sample": f"{args.cpu_sample} ({cm}), pic_cnt=1, {ores.gate_cnt_bin} mul gates: CPU oracle prover time "
-                         f"(sumcheck {1e3 * ores.prove_s:.0f} ms + Hyrax {1e3 * ores.poly_prove_s:.0f} ms); full vgg11 measured offline: see BASELINE.md",
-               "gpu_same_sample_ms": round(gpu_ms, 2), "gpu_speedup_same_sample": round(cpu_ms / gpu_ms, 1),
+    if not args.no_cpu_baseline and world == 1:        # the host baseline belongs to the single-GPU line (rank 0, N = 1)
+        import multiprocessing as mp
+        cm, cpic, cpp = WORKLOADS[args.cpu_sample or args.workload]
+        job = (cm, cpic, cpp, 20260928, drive)
+        ctx = mp.get_context("spawn")
+        with ctx.Pool(1) as pool:                          # (i) one core, nothing else running
+            one_s, one_wall, gates, one_sum, one_poly = pool.map(_cpu_prover_worker, [job])[0]
+        cpu = {"value": round(1e3 * one_s, 1), "unit": "prover ms/image", "cores": 1, "kind": "port",
+               "sample": f"{args.cpu_sample or args.workload} ({cm}), pic_cnt={cpp}, {gates} mul gates -- the full bench workload: CPU oracle prover time "
+                         f"(sumcheck {1e3 * one_sum:.0f} ms + Hyrax {1e3 * one_poly:.0f} ms), same modes as the timed GPU proofs",
+               "gpu_speedup_vs_one_core": round(1e3 * one_s / max(1e3 * (lat_prove + lat_poly), 1e-9), 1),
                "host_cores_available": os.cpu_count()}
+        n_proc = max(0, min(args.cpu_procs, (os.cpu_count() or 1)))
+        try:
+            import psutil
+            n_proc = min(n_proc, int(psutil.virtual_memory().available / 14e9))
+        except ImportError:
+            pass
+        if n_proc >= 2:                                    # (ii) independent single-threaded provers side by side
+            t0 = time.time()
+            with ctx.Pool(n_proc) as pool:
+                rs = pool.map(_cpu_prover_worker, [(cm, cpic, cpp, 20260928 + i, drive) for i in range(n_proc)])
+            wall = time.time() - t0
+            per = sum(r[0] for r in rs) / n_proc
+            cores = os.cpu_count() or 1
+            cpu["multi_process"] = {"processes": n_proc, "prover_s_each": round(per, 2), "wall_s_incl_witness": round(wall, 1),
+                                    "proofs_per_s_measured": round(n_proc / per, 3),
+                                    "proofs_per_s_if_every_core_ran_one": round(cores / per, 2),
+                                    "gpu_proofs_per_s_over_that": round((world * K * args.steps / elapsed) / max(cores / per, 1e-9), 2),
+                                    "note": f"{n_proc} independent oracle processes at once (prover time only, contention included); the all-cores figure "
+                                            f"extrapolates to {cores} processes and needs ~{cores * 10} GB of host memory -- an upper bound for the host"}
 
     steps = args.steps
     out = {
-        "metric": "proofs/s (prover, vgg11 pic_cnt=1 proofs); prover_ms_per_image (single-stream latency) alongside",
+        "metric": f"proofs/s (GKR prover, {args.workload} pic_cnt={pp} proofs, {K} in flight per GPU; modes SEEDED|DRIVE_ONLY|REUSE_GENS: public generators "
+                  "with a resident byte table, IPA cut at 256); prover_ms_per_image = single-stream latency; conservative companions alongside",
         "value": round(world * K * steps / elapsed, 4),
         "unit": "proofs/s",
         "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -338,11 +394,11 @@ def main():
         "prover_ms_sumcheck": round(1e3 * lat_prove, 3), "prover_ms_commit": round(1e3 * lat_poly, 3),
         "prover_ms_per_image_in_flight": round(1e3 * (prove_s + poly_s) / (steps * K), 3),
         "verifier_pass": bool(accepted), "timed_proofs_replay_verified": K, "proof_kb": round(first.proof_kb + first.poly_proof_kb, 1),
-        "setup_s": round(setup_s, 1), "witness_s": round(first.witness_s, 1), "upload_s": round(first.upload_s, 2),
+        "setup_s": round(setup_s, 1), "witness_s": round(first.witness_s, 1), "upload_sort_s": round(first.upload_s, 2),
         "roofline": roofline, "cpu_baseline": cpu,
     }
+    out.update(extras)
     print(json.dumps(out), flush=True)
-    sess.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -25,7 +25,7 @@ typedef struct {
 #define ZKCNN_MODE_VERIFY      0u  /* full verifier (reference behaviour): challenges from the operating system's CSPRNG, fresh random generators */
 #define ZKCNN_MODE_DRIVE_ONLY  1u  /* same challenges and prover calls, verifier checks skipped */
 #define ZKCNN_MODE_REUSE_GENS  2u  /* public commitment generators (hash-to-curve, nobody knows a discrete log) instead of fresh random multiples of G */
-#define ZKCNN_MODE_TAMPER      4u  /* test hook: the verifier corrupts message number (mode >> 8) before checking it */
+#define ZKCNN_MODE_TAMPER      4u  /* test hook: the verifier corrupts message number ((mode >> 8) & 0xffff) before checking it; flags continue at bit 24 */
 #define ZKCNN_MODE_HOST_PRED   8u  /* verifier's wiring predicates on the host (reference src/verifier.cpp:89-116) instead of the GPU */
 #define ZKCNN_MODE_FIAT_SHAMIR 32u /* non-interactive: challenges are SHA-256 of the statement and of every message so far (the seed is ignored);
                                      always on the public hash-to-curve generators, whose digest is part of the hashed statement */
@@ -33,6 +33,7 @@ typedef struct {
                                      xoshiro stream seeded with challenge_seed. NOT secure -- every challenge is predictable from the seed.
                                      zkcnn_session_verify accepts an interactive (non-Fiat-Shamir) transcript only with this bit: a replay against a
                                      known challenge stream is a debugging aid, never evidence that a statement is true */
+#define ZKCNN_MODE_FULL_IPA  128u  /* inner-product argument down to length 1 (log2(m) rounds) instead of sending the last 256 scalars in the clear */
 #define ZKCNN_MODE_CROSS_PRED 16u  /* both, and the verifier rejects if they differ (parity check of zk_verifier_*) */
 
 typedef struct {

@@ -7,6 +7,7 @@ import os
 
 import pytest
 
+import zkcnn_amd
 from tests import oracle_ffi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -122,3 +123,21 @@ def test_concurrent_sessions_are_deterministic(oracle):
     [t.start() for t in th]
     [t.join() for t in th]
     assert got == alone
+
+
+def test_full_length_inner_product_argument(oracle):
+    """ZKCNN_MODE_FULL_IPA: log2(m) rounds and ONE scalar at the end instead of the last 256 in the clear; accepted, every opening message
+    still matters, and the sumcheck part of the transcript is the one of the default mode (same seed, same challenges up to the opening)"""
+    with oracle_ffi.OracleSession("lenet", (32, 32, 1), 1) as o:
+        r0, t0 = o.prove(seed=21)
+        r1, t1 = o.prove(seed=21, mode=zkcnn_amd.MODE_FULL_IPA)
+        assert r0.accepted == 1 and r1.accepted == 1
+        m = 1 << (r0.input_bits - r0.input_bits // 2)            # generators = columns of the witness matrix: 512 for LeNet5
+        rounds0, rounds1 = 1, 9                                   # 512 -> 256;  512 -> 1
+        assert m == 512 and len(t1) - len(t0) == (rounds1 - rounds0) * (2 * 48 + 2 * 32) - (256 - 1) * 32
+        n = r1.n_messages
+        for k in (n, n + 4, n + 8, n + 9):                        # first / middle / last round, the final scalar
+            bad, _ = o.prove(seed=21, mode=zkcnn_amd.MODE_FULL_IPA | zkcnn_amd.MODE_TAMPER | (k << 8))
+            assert bad.accepted == 0, k
+        assert o.verify(t1, seed=21, mode=zkcnn_amd.MODE_FULL_IPA).accepted == 1
+        assert o.verify(t1, seed=21).accepted == 0                # the replay must know how long the argument ran

@@ -20,7 +20,8 @@ from tests import oracle_ffi
 
 pytestmark = pytest.mark.gpu
 
-REUSE, DRIVE, CROSS, TAMPER = zkcnn_amd.MODE_REUSE_GENS, zkcnn_amd.MODE_DRIVE_ONLY, zkcnn_amd.MODE_CROSS_PRED, zkcnn_amd.MODE_TAMPER
+REUSE, DRIVE, CROSS, TAMPER, FULL_IPA = (zkcnn_amd.MODE_REUSE_GENS, zkcnn_amd.MODE_DRIVE_ONLY, zkcnn_amd.MODE_CROSS_PRED, zkcnn_amd.MODE_TAMPER,
+                                           zkcnn_amd.MODE_FULL_IPA)
 
 TIMED_CASES = [
     ("lenet", (32, 32, 1), 1),
@@ -49,11 +50,18 @@ def test_reused_generators_byte_table_path_identical_to_oracle(built, model, pic
         for k, sd in enumerate(seeds):                    # bench mode: same calls, same challenges, verifier checks skipped
             res, tr = s.prove(seed=sd, mode=REUSE | DRIVE)
             assert res.accepted == -1 and tr == want[k], f"drive-only proof {k} differs"
+        # the inner-product argument run down to length 1 (bench.py's conservative companion), on the byte table and on fresh generators
+        res, full_reuse = s.prove(seed=seeds[1], mode=REUSE | FULL_IPA)
+        assert res.accepted == 1 and len(full_reuse) != len(want[1])
         # fresh generators on a session whose byte table is live: the cache must notice the change
         res, tr = s.prove(seed=seeds[0])
         assert res.accepted == 1
+        res, full_fresh = s.prove(seed=seeds[2], mode=FULL_IPA)
+        assert res.accepted == 1
     with oracle_ffi.OracleSession(model, pic, pp) as o:
         assert o.prove(seed=seeds[0])[1] == tr
+        assert o.prove(seed=seeds[1], mode=REUSE | FULL_IPA)[1] == full_reuse
+        assert o.prove(seed=seeds[2], mode=FULL_IPA)[1] == full_fresh
 
 
 REDUCED = [

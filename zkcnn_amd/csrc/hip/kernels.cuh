@@ -354,40 +354,6 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_sum_partials(fr_t *out, const fr_t
 //   2. accumulates, over pairs of the folded tables,  c = sum v0 m0,  a = sum dv dm,  p1 = sum v1 m1
 // (b = p1 - a - c is recovered by the caller). Algorithmic traffic: read 2n, write n elements.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(ZK_BLOCK, 4) k_round_quad(const fr_t *Vin, const fr_t *Min, fr_t *Vout, fr_t *Mout, uint64_t n,
-                                                         fr_t r, int first, fr_t *partials) {
-    __shared__ fr_t smem[3 * ZK_BLOCK / 64];
-    fr_t acc[3] = {fr_zero(), fr_zero(), fr_zero()};       // a, c, p1
-    const uint64_t tid = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x, stride = (uint64_t) gridDim.x * ZK_BLOCK;
-    if (first) {
-        for (uint64_t p = tid; p < n / 2; p += stride) {
-            fr_t v0 = fr_load(Vin + 2 * p), v1 = fr_load(Vin + 2 * p + 1);
-            fr_t m0 = fr_load(Min + 2 * p), m1 = fr_load(Min + 2 * p + 1);
-            acc[0] = fr_add(acc[0], fr_mul(fr_sub(v1, v0), fr_sub(m1, m0)));
-            acc[1] = fr_add(acc[1], fr_mul(v0, m0));
-            acc[2] = fr_add(acc[2], fr_mul(v1, m1));
-        }
-    } else {
-        for (uint64_t q = tid; q < n / 4; q += stride) {
-            fr_t a0 = fr_load(Vin + 4 * q), a1 = fr_load(Vin + 4 * q + 1), a2 = fr_load(Vin + 4 * q + 2), a3 = fr_load(Vin + 4 * q + 3);
-            fr_t v0 = fr_lerp(a0, a1, r), v1 = fr_lerp(a2, a3, r);
-            fr_store(Vout + 2 * q, v0);
-            fr_store(Vout + 2 * q + 1, v1);
-            a0 = fr_load(Min + 4 * q); a1 = fr_load(Min + 4 * q + 1); a2 = fr_load(Min + 4 * q + 2); a3 = fr_load(Min + 4 * q + 3);
-            fr_t m0 = fr_lerp(a0, a1, r), m1 = fr_lerp(a2, a3, r);
-            fr_store(Mout + 2 * q, m0);
-            fr_store(Mout + 2 * q + 1, m1);
-            acc[0] = fr_add(acc[0], fr_mul(fr_sub(v1, v0), fr_sub(m1, m0)));
-            acc[1] = fr_add(acc[1], fr_mul(v0, m0));
-            acc[2] = fr_add(acc[2], fr_mul(v1, m1));
-        }
-    }
-    fr_block_sum<3>(acc, smem);
-    if (threadIdx.x == 0)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) fr_store(partials + 3 * blockIdx.x + k, acc[k]);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Fused round kernels of the interactive loop. One launch per sumcheck round: both live table pairs, the grid-wide
 // reduction (last block to arrive sums the per-block partials) and the hand-over to the host (the result goes

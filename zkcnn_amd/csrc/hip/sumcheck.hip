@@ -1096,12 +1096,23 @@ extern "C" int32_t zk_k_round_quadratic(zk_ctx *ctx, uint64_t *V, uint64_t *M, u
     fr_t *dV = (fr_t *) ctx->scratch.p, *dM = dV + n, *dV2 = dM + n, *dM2 = dV2 + n;
     ZK_HIP(hipMemcpyAsync(dV, V, n * 32, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipMemcpyAsync(dM, M, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    // the PRODUCT kernel (k_round_quad2 as quad_round launches it for tables above the fine-grained limit), one table pair
     const uint64_t npairs = first ? n / 2 : n / 4;
-    const uint32_t g = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks);
-    ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_round_quad, dim3(g), dim3(ZK_BLOCK), dV, dM, dV2, dM2, n, to_dev(H(r)), first ? 1 : 0, ctx->partials);
-    ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials<3>, dim3(1), dim3(ZK_BLOCK), ctx->d_result, ctx->partials, g, 0);
+    round2_args A;
+    std::memset(&A, 0, sizeof(A));
+    A.Vin[0] = dV; A.Min[0] = dM; A.Vout[0] = dV2; A.Mout[0] = dM2;
+    A.n[0] = n;
+    A.blocks[0] = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks / 2);
+    A.r = to_dev(H(r));
+    A.first = first ? 1 : 0;
+    A.partials = ctx->partials;
+    A.counter = ctx->d_counter;
+    A.slot = (host_slot *) ctx->d_slot;
+    A.seq = ++ctx->slot_seq;
+    ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_round_quad2, dim3(A.blocks[0]), dim3(ZK_BLOCK), A);
     ZK_HIP(hipGetLastError());
-    if ((rc = fetch_result(ctx, 3))) return rc;
+    if ((rc = wait_slot(ctx, A.seq))) return rc;
+    for (int k = 0; k < 3; ++k) ctx->h_result[k] = ctx->h_slot->v[k];
     const uint64_t nn = first ? n : n / 2;
     if (!first) {
         ZK_HIP(hipMemcpy(V, dV2, nn * 32, hipMemcpyDeviceToHost));
@@ -1482,7 +1493,7 @@ extern "C" int32_t zk_bench_copy(zk_ctx *ctx, uint64_t bytes, uint32_t iters, do
     });
 }
 
-// The dominant kernel of the FFT-conv configs in isolation: one non-first quadratic round on two
+// The dominant kernel of the FFT-conv configs in isolation: one non-first quadratic round (k_round_quad2, the product kernel) on two
 // 2^log_n-entry tables of pseudo-random elements. Algorithmic bytes = 96 * 2^log_n.
 extern "C" int32_t zk_bench_round_quadratic(zk_ctx *ctx, uint32_t log_n, uint32_t iters, double *sec_per_launch,
                                             double *algorithmic_bytes) {
@@ -1502,9 +1513,21 @@ extern "C" int32_t zk_bench_round_quadratic(zk_ctx *ctx, uint32_t log_n, uint32_
     }
     if ((rc = eq_table1(ctx, dV, (int) log_n, r.data(), HFr(7LL)))) return rc;
     if ((rc = eq_table1(ctx, dM, (int) log_n, r.data(), HFr(11LL)))) return rc;
-    const uint32_t gsz = std::min<uint32_t>(grid_for(n / 4, 1024), ctx->partial_blocks);
+    // the product kernel exactly as quad_round launches it for one large table pair (fold + round sums + grid finish + host slot)
+    round2_args A;
+    std::memset(&A, 0, sizeof(A));
+    A.Vin[0] = dV; A.Min[0] = dM; A.Vout[0] = dO; A.Mout[0] = dO + n / 2;
+    A.n[0] = n;
+    A.blocks[0] = std::min<uint32_t>(grid_for(n / 4, 1024), ctx->partial_blocks / 2);
+    A.r = to_dev(r[0]);
+    A.partials = ctx->partials;
+    A.counter = ctx->d_counter;
+    A.slot = (host_slot *) ctx->d_slot;
     *algorithmic_bytes = 96.0 * (double) n;
-    return time_launches(ctx, iters, sec_per_launch, [&] {
-        ZK_LAUNCH(PC_ROUND_QUAD, 96.0 * (double) n, k_round_quad, dim3(gsz), dim3(ZK_BLOCK), dV, dM, dO, dO + n / 2, n, to_dev(r[0]), 0, ctx->partials);
+    rc = time_launches(ctx, iters, sec_per_launch, [&] {
+        A.seq = ++ctx->slot_seq;
+        ZK_LAUNCH(PC_ROUND_QUAD, 96.0 * (double) n, k_round_quad2, dim3(A.blocks[0]), dim3(ZK_BLOCK), A);
     });
+    if (rc) return rc;
+    return wait_slot(ctx, ctx->slot_seq);
 }

@@ -60,7 +60,7 @@ void polyProver::openFold(const Fr &c) {
 
 std::vector<Fr> polyProver::openFinal() {
     pt.start();
-    std::vector<Fr> a(IPA_STOP_LEN);
+    std::vector<Fr> a(IPA_STOP_LEN);          // the vector is at most this long (shorter when the verifier asked for more rounds)
     uint32_t n = 0;
     must(ctx, zk_hyrax_open_final(ctx, reinterpret_cast<uint64_t *>(a.data()), (uint32_t) a.size(), &n), "zk_hyrax_open_final");
     a.resize(n);

@@ -83,9 +83,10 @@ struct sessionT {
         }
         v.drive_only = (mode & ZKCNN_MODE_DRIVE_ONLY) != 0;
         if (public_gens) v.fixed_gens = &gens;
-        if (mode & ZKCNN_MODE_TAMPER) v.tamper_at = (long) (mode >> 8);
+        if (mode & ZKCNN_MODE_TAMPER) v.tamper_at = (long) ((mode >> 8) & 0xffffu);
         if (vaccel && !(mode & ZKCNN_MODE_HOST_PRED)) v.accel = vaccel;
         v.cross_check = (mode & ZKCNN_MODE_CROSS_PRED) != 0;
+        v.full_ipa = (mode & ZKCNN_MODE_FULL_IPA) != 0;
         if (fiat) {
             // non-interactive: every challenge is a hash of the statement (model, picture shape, quantisation scales, every layer's
             // shape, a digest of the wiring, the generators) and of all messages received so far

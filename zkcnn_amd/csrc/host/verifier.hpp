@@ -100,6 +100,7 @@ public:
     // recorded instead of all of a phase's challenges up front as the reference does (src/verifier.cpp:155,207,279)
     bool lazy_challenges = false;
     const std::vector<G1> *fixed_gens = nullptr;   // re-use generators instead of drawing new ones
+    bool full_ipa = false;                   // run the inner-product argument down to length 1 instead of stopping at IPA_STOP_LEN
     proofTranscript transcript;
     // test hook: add 1 to the k-th message received from the prover (a cheating prover); -1 = off.
     // Messages are numbered in arrival order: Vres, every round polynomial, every finalize call, then the
@@ -116,6 +117,7 @@ public:
         delete poly_v;
         poly_v = new hyrax_bls12_381::polyVerifier(p->commitInput(gens), gens, &transcript);
         poly_v->drive_only = drive_only;
+        poly_v->stop_len = full_ipa ? 1 : (size_t) hyrax_bls12_381::IPA_STOP_LEN;
         msg_count = 0;
         if (!(verifyInnerLayers() && verifyFirstLayer())) return false;
         poly_v->tamper_at = tamper_at < 0 ? -1 : tamper_at - msg_count;

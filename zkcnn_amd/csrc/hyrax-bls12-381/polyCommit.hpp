@@ -87,7 +87,7 @@ inline void eqTable(std::vector<Fr> &out, const Fr *r, int n, const Fr &init) {
 }
 
 enum { IPA_STOP_LEN = 256 };
-inline int ipaRounds(int cb) { int t = 0; while (((size_t) 1 << (cb - t)) > IPA_STOP_LEN) ++t; return t; }
+inline int ipaRounds(int cb, size_t stop_len = IPA_STOP_LEN) { int t = 0; while (((size_t) 1 << (cb - t)) > stop_len) ++t; return t; }
 
 struct ipaRoundMsg {
     G1 L, R;
@@ -142,7 +142,7 @@ public:
         vt.stop();
 
         p.openInit(x);
-        const int rounds = ipaRounds(cb);
+        const int rounds = ipaRounds(cb, stop_len);
         const int kb = cb - rounds;                      // bits of the vector that is sent in the clear
         std::vector<Fr> cs(rounds);
         for (int t = 0; t < rounds; ++t) {
@@ -195,6 +195,7 @@ public:
     double getVT() const { return vt.elapse_sec(); }
     long tamper_at = -1;       // test hook: corrupt the k-th opening message (round k, or ipaRounds = the final vector)
     bool drive_only = false;   // make the prover calls and draw the challenges, skip the checks (bench mode)
+    size_t stop_len = IPA_STOP_LEN;   // 1 = the textbook argument: log2(m) rounds, a single scalar at the end (ZKCNN_MODE_FULL_IPA)
 
 private:
     polyProverBase &p;
