@@ -34,6 +34,7 @@ typedef struct {
                                      zkcnn_session_verify accepts an interactive (non-Fiat-Shamir) transcript only with this bit: a replay against a
                                      known challenge stream is a debugging aid, never evidence that a statement is true */
 #define ZKCNN_MODE_FULL_IPA  128u  /* inner-product argument down to length 1 (log2(m) rounds) instead of sending the last 256 scalars in the clear */
+#define ZKCNN_MODE_ZK  (1u << 24)  /* zero-knowledge masking: blinded commitments, masked round polynomials, proofs of dot product */
 #define ZKCNN_MODE_CROSS_PRED 16u  /* both, and the verifier rejects if they differ (parity check of zk_verifier_*) */
 
 typedef struct {

@@ -100,6 +100,16 @@ int32_t zk_witness_ntt(zk_ctx *ctx, uint64_t *dst, const uint64_t *src, int32_t 
 int32_t zk_witness_dotprod(zk_ctx *ctx, uint64_t *out, uint64_t n_out, const uint64_t *F, uint64_t n_in, const zk_bin_gate *gates,
                            uint64_t n_gates, int32_t fft_bl);
 
+/* ---- zero-knowledge mode of the commitment (no reference counterpart: reference README.md:5 "not fully
+ * zero-knowledge"): the generator set has one more entry H = gens[n_gens - 1] and every commitment is blinded, Com(v; s) = <v, g> + s H -- */
+/* zk_commit_input with n_gens = 2^cb + 1 generators and one blinding factor per row: out_comm[i] = <row_i, g> + blinds[i] H */
+int32_t zk_commit_input_blinded(zk_ctx *ctx, const uint64_t *gens, uint64_t n_gens, const uint64_t *blinds, uint64_t *out_comm, uint64_t n_rows);
+/* blinded row commitments of a HOST matrix (n_rows x cols scalars) over the generators of the last zk_commit_input[_blinded] call
+ * (cols = their number without H): masking-polynomial coefficients, the random vector of a proof of dot product. blinds may be NULL. */
+int32_t zk_commit_vector(zk_ctx *ctx, const uint64_t *scalars, uint64_t n_rows, uint64_t cols, const uint64_t *blinds, uint64_t *out);
+/* w = L^T Z of the committed input, L = eq(x[cb..n)): the vector a proof of dot product opens (2^cb elements to the host) */
+int32_t zk_hyrax_combine_rows(zk_ctx *ctx, const uint64_t *x, uint32_t n, uint64_t *out_w);
+
 /* ---- verifier side: wiring predicates over the resident gate lists (reference src/verifier.cpp:36-116) --------------------- */
 /* Everything betaInitPhase1/2 + predicatePhase1/2 produce for layer `layer`: uni[0..1] (already multiplied by beta_v[0] when the
  * layer has a phase 2) and bin[0..2] (indexed by binGate::l). r_0 / r_1 / alpha / beta: the layer's incoming claim; r_u / r_v: this

@@ -58,6 +58,7 @@ void prover::sumcheckDotProdInitPhase1() {                                    //
             V_mult[0][iu].b = V_mult[0][iu].b + beta_g[gate.g] * prev[iv];
         }
     round = 0;
+    zkBeginInstance();            // zero-knowledge mode: the next masking polynomial (zk_mask.hpp); a no-op otherwise
     prove_timer.stop();
 }
 
@@ -86,6 +87,7 @@ cubic_poly prover::sumcheckDotProdUpdate1(const F &previous_random) {        // 
     proof_size += F_BYTE_SIZE * (3 + (!ret.a.isZero()));
     total[1] >>= 1;
     total_size[1] = (total_size[1] + 1) >> 1;
+    zkMask(ret, previous_random);
     prove_timer.stop();
     return ret;
 }
@@ -163,6 +165,7 @@ void prover::sumcheckInitPhase1(const F &relu_rou_0) {                        //
         }
     }
     round = 0;
+    zkBeginInstance();            // zero-knowledge mode: the next masking polynomial (zk_mask.hpp); a no-op otherwise
     prove_timer.stop();
 }
 
@@ -217,6 +220,7 @@ void prover::sumcheckInitPhase2() {                                           //
         }
     }
     round = 0;
+    zkBeginInstance();            // zero-knowledge mode: the next masking polynomial (zk_mask.hpp); a no-op otherwise
     prove_timer.stop();
 }
 
@@ -255,6 +259,7 @@ void prover::sumcheckLiuInit(const vector<F> &s_u, const vector<F> &s_v) {    //
         }
     }
     round = 0;
+    zkBeginInstance();            // zero-knowledge mode: the next masking polynomial (zk_mask.hpp); a no-op otherwise
     prove_timer.stop();
 }
 
@@ -269,6 +274,7 @@ quadratic_poly prover::update(const F &previous_random, vector<F> &r_arr) {   //
     add_term = add_term * (Fr::one() - previous_random);
     for (int b = 0; b < 2; ++b) ret = ret + updateEach(previous_random, b);
     ret = ret + quadratic_poly(F_ZERO, -add_term, add_term);
+    zkMask(ret, previous_random);
     prove_timer.stop();
     proof_size += F_BYTE_SIZE * 3;
     return ret;
@@ -278,6 +284,7 @@ quadratic_poly prover::sumcheckLiuUpdate(const F &previous_random) {          //
     prove_timer.start();
     ++round;
     quadratic_poly ret = updateEach(previous_random, true);
+    zkMask(ret, previous_random);
     prove_timer.stop();
     proof_size += F_BYTE_SIZE * 3;
     return ret;
@@ -360,14 +367,24 @@ void prover::sumcheckLiuFinalize(const F &previous_random, F &claim_1) {      //
 hyrax_bls12_381::polyProverBase &prover::commitInput(const vector<G> &gens) { // prover.cpp:503-511
     if (C.circuit[0].size != (1ULL << C.circuit[0].bit_length))
         val[0].resize((size_t) 1 << C.circuit[0].bit_length, F_ZERO);
+    zkReset();
     poly_p.reset(new polyProverCPU(val[0], gens));
+    return *poly_p;
+}
+
+hyrax_bls12_381::polyProverBase &prover::commitInputZk(const vector<G> &gens) {
+    if (C.circuit[0].size != (1ULL << C.circuit[0].bit_length))
+        val[0].resize((size_t) 1 << C.circuit[0].bit_length, F_ZERO);
+    zkReset();
+    const vector<F> blinds = zkDrawBlinds((size_t) 1 << (C.circuit[0].bit_length >> 1));
+    poly_p.reset(new polyProverCPU(val[0], gens, &blinds));
     return *poly_p;
 }
 
 // ---------------------------------------------------------------------------------------------
 // CPU Hyrax prover: the protocol documented in zkcnn_amd/csrc/hyrax-bls12-381/polyCommit.hpp
 // ---------------------------------------------------------------------------------------------
-polyProverCPU::polyProverCPU(const std::vector<Fr> &Z_, const std::vector<G1> &gens) : Z(Z_), ps_bytes(0) {
+polyProverCPU::polyProverCPU(const std::vector<Fr> &Z_, const std::vector<G1> &gens, const std::vector<Fr> *blinds) : Z(Z_), ps_bytes(0) {
     pt.start();
     int n = 0;
     while (((size_t) 1 << n) < Z.size()) ++n;
@@ -377,8 +394,41 @@ polyProverCPU::polyProverCPU(const std::vector<Fr> &Z_, const std::vector<G1> &g
     const size_t rows = (size_t) 1 << rb, cols = (size_t) 1 << cb;
     comm.resize(rows);
     for (size_t i = 0; i < rows; ++i) comm[i] = zkff::msmCPU(&Z[i * cols], g0.data(), cols);
+    if (blinds) {                          // zero-knowledge mode: gens = (g_0 .. g_{cols-1}, H), row i gets + blinds[i] H
+        input_blinds = *blinds;
+        zk_m = cols;
+        const G1 H = G1::fromAffine(g0[cols]);
+        for (size_t i = 0; i < rows; ++i) comm[i] = comm[i] + H * (*blinds)[i];
+    }
     ps_bytes += rows * 48;
     pt.stop();
+}
+
+std::vector<G1> polyProverCPU::commitHostVector(const std::vector<Fr> &v, const std::vector<Fr> &blinds) {
+    pt.start();
+    const size_t rows = blinds.size(), cols = zk_m;
+    std::vector<Fr> padded(rows * cols, Fr(0LL));
+    std::copy(v.begin(), v.end(), padded.begin());
+    const G1 H = G1::fromAffine(g0[cols]);
+    std::vector<G1> out(rows);
+    for (size_t i = 0; i < rows; ++i) out[i] = zkff::msmCPU(&padded[i * cols], g0.data(), cols) + H * blinds[i];
+    pt.stop();
+    return out;
+}
+
+std::vector<Fr> polyProverCPU::combineRows(const std::vector<Fr> &x) {
+    pt.start();
+    const size_t rows = (size_t) 1 << rb, cols = (size_t) 1 << cb;
+    std::vector<Fr> Lrow, w(cols, Fr(0LL));
+    hyrax_bls12_381::eqTable(Lrow, x.data() + cb, rb, Fr::one());
+    for (size_t i = 0; i < rows; ++i) {
+        if (Lrow[i].isZero()) continue;
+        const Fr *row = &Z[i * cols];
+        for (size_t j = 0; j < cols; ++j)
+            if (!row[j].isZero()) w[j] = w[j] + Lrow[i] * row[j];
+    }
+    pt.stop();
+    return w;
 }
 
 void polyProverCPU::openInit(const std::vector<Fr> &x) {

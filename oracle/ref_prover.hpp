@@ -10,13 +10,17 @@
 #include "circuit.h"
 #include "polynomial.h"
 #include "ref_tables.hpp"
+#include "zk_mask.hpp"
 
 namespace oracle {
 
 // CPU Hyrax prover (restates the protocol in hyrax-bls12-381/polyCommit.hpp on host cores)
 class polyProverCPU : public hyrax_bls12_381::polyProverBase {
 public:
-    polyProverCPU(const std::vector<Fr> &Z, const std::vector<G1> &gens);
+    polyProverCPU(const std::vector<Fr> &Z, const std::vector<G1> &gens, const std::vector<Fr> *blinds = nullptr);
+    std::vector<G1> commitHostVector(const std::vector<Fr> &v, const std::vector<Fr> &blinds) override;
+    std::vector<Fr> combineRows(const std::vector<Fr> &x) override;
+    void addProofBytes(size_t n) override { ps_bytes += n; }
     const std::vector<G1> &commitment() const override { return comm; }
     void openInit(const std::vector<Fr> &x) override;
     hyrax_bls12_381::ipaRoundMsg openRound() override;
@@ -35,7 +39,7 @@ private:
     u64 ps_bytes;
 };
 
-class prover {
+class prover : public zkmask::proverMixin {
 public:
     void init();                                                              // prover.cpp:17-21
     void sumcheckInitAll(const vector<F>::const_iterator &r_0_from_v);        // :28-36
@@ -54,6 +58,7 @@ public:
     void sumcheckLiuInit(const vector<F> &s_u, const vector<F> &s_v);         // :312-358
     quadratic_poly sumcheckLiuUpdate(const F &previous_random);               // :385-394
     hyrax_bls12_381::polyProverBase &commitInput(const vector<G> &gens);      // :503-511
+    hyrax_bls12_381::polyProverBase &commitInputZk(const vector<G> &gens);    // zero-knowledge mode (no reference counterpart), see zk_mask.hpp
 
     timer prove_timer;
     double proveTime() const { return prove_timer.elapse_sec(); }
@@ -65,6 +70,8 @@ public:
     vector<vector<F>> val;
 
 private:
+    hyrax_bls12_381::polyProverBase &zkBackend() override { return *poly_p; }
+    const layeredCircuit &zkCircuit() const override { return C; }
     quadratic_poly updateEach(const F &previous_random, bool idx);            // :396-426
     quadratic_poly update(const F &previous_random, vector<F> &r_arr);        // :368-383
     F cirValue(u8 layer_id, const vector<u32> &ori, u32 u) const {            // :499-501

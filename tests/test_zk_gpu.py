@@ -1,0 +1,54 @@
+"""Zero-knowledge mode on the GPU: under a seed (challenges and prover coins reproducible) the HIP prover's
+transcript -- blinded row commitments (k_msm_codes + blinding column through the window kernels), masked round polynomials, the proofs of
+dot product whose commitments go through zk_commit_vector -- is byte-identical to the CPU oracle's; full-size vgg11 is accepted."""
+import pytest
+
+import zkcnn_amd
+from tests import oracle_ffi
+
+pytestmark = pytest.mark.gpu
+ZK, FS, REUSE, DRIVE, TAMPER = zkcnn_amd.MODE_ZK, zkcnn_amd.MODE_FIAT_SHAMIR, zkcnn_amd.MODE_REUSE_GENS, zkcnn_amd.MODE_DRIVE_ONLY, zkcnn_amd.MODE_TAMPER
+
+CASES = [
+    ("custom:F8 F4", (4, 4, 1), 1),
+    ("custom:C2:3:1:f M F4", (8, 8, 1), 2),
+    ("custom:C2:3:0:f C3:3:1:f M C2:3:1:s A F5 F3", (10, 10, 2), 2),
+    ("lenet", (32, 32, 1), 1),
+    ("vgg:16 M 32 M 64 64 M 128 128 M 128 128 M", (32, 32, 3), 1),
+]
+
+
+@pytest.mark.parametrize("model,pic,pp", CASES)
+def test_zero_knowledge_transcripts_identical_to_oracle(built, model, pic, pp):
+    modes = [ZK, ZK | REUSE, ZK | REUSE, ZK | FS]          # REUSE twice: the second proof runs on the byte table of (g, H)
+    with oracle_ffi.OracleSession(model, pic, pp) as o:
+        want = [o.prove(seed=0x5EED0001 + k, mode=m)[1] for k, m in enumerate(modes)]
+    with zkcnn_amd.Session(model, pic, pp) as s:
+        for k, m in enumerate(modes):
+            res, tr = s.prove(seed=0x5EED0001 + k, mode=m)
+            assert res.accepted == 1, res.message.decode()
+            assert tr == want[k], f"zero-knowledge transcript {k} (mode {m:#x}) differs from the oracle"
+        res, tr = s.prove(seed=0x5EED0002, mode=ZK | REUSE | DRIVE)
+        assert res.accepted == -1 and tr == want[1]
+        assert s.verify(want[3], mode=ZK | FS).accepted == 1
+        plain, t_plain = s.prove(seed=0x5EED0001)             # the plain mode still works on the same session afterwards
+        assert plain.accepted == 1
+        n = res.n_messages
+        for k in (n // 2, n - 1, n, n + 1, n + 2):
+            bad, _ = s.prove(seed=3, mode=ZK | TAMPER | (k << 8))
+            assert bad.accepted == 0, k
+    with oracle_ffi.OracleSession(model, pic, pp) as o:
+        assert o.prove(seed=0x5EED0001)[1] == t_plain
+
+
+def test_full_size_vgg11_zero_knowledge(built):
+    with zkcnn_amd.Session("vgg11", (32, 32, 3), 1) as s:
+        a, ta = s.prove(mode=ZK | REUSE)                      # OS randomness
+        b, tb = s.prove(mode=ZK | REUSE)
+        assert a.accepted == 1 and b.accepted == 1 and ta[:4096 * 48] != tb[:4096 * 48]
+        c, tc = s.prove(seed=9, mode=ZK | REUSE | DRIVE)
+        d, td = s.prove(seed=9, mode=ZK | REUSE | DRIVE)
+        assert tc == td
+        print(f"vgg11 zero-knowledge: prover {1e3 * (d.prove_s + d.poly_prove_s):.1f} ms (sumcheck {1e3 * d.prove_s:.1f} + commitments / openings "
+              f"{1e3 * d.poly_prove_s:.1f}), proof {d.proof_kb + d.poly_proof_kb:.0f} KB")
+        assert s.verify(tc, seed=9, mode=ZK | REUSE).accepted == 1

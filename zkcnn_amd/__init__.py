@@ -19,6 +19,7 @@ R_MOD = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 P_MOD = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 
 MODE_VERIFY, MODE_DRIVE_ONLY, MODE_REUSE_GENS, MODE_TAMPER, MODE_HOST_PRED, MODE_CROSS_PRED, MODE_FIAT_SHAMIR, MODE_SEEDED, MODE_FULL_IPA = 0, 1, 2, 4, 8, 16, 32, 64, 128
+MODE_ZK = 1 << 24
 
 
 class ModelDesc(ctypes.Structure):

@@ -247,4 +247,27 @@ public:
 
 inline std::ostream &operator<<(std::ostream &os, const Fr &x) { return os << x.toHex(); }
 
+// A prover's PRIVATE coins (blinding factors, masking polynomials of the zero-knowledge mode): the operating system's CSPRNG, or -- for
+// reproducible parity runs only -- a seeded stream that is separate from the verifier's challenge stream. One per thread, like the
+// challenge stream, so that concurrent sessions stay deterministic under a seed.
+struct PrivateCoins {
+    Xoshiro g;
+    bool seeded = false;
+    void seed(uint64_t s) { g.seed(s ^ 0x70726f7665722121ULL); seeded = true; }
+    void useOsRandom() { seeded = false; }
+    Fr next() {
+        for (;;) {
+            uint64_t t[4];
+            if (seeded) for (int i = 0; i < 4; ++i) t[i] = g.next();
+            else osRandom().words(t);
+            t[3] &= 0x7fffffffffffffffULL;
+            if (!MontField<FrParams>::geMod(t)) return Fr(MontField<FrParams>::fromCanonical(t));
+        }
+    }
+};
+inline PrivateCoins &privateCoins() {
+    static thread_local PrivateCoins c;
+    return c;
+}
+
 } // namespace zkff

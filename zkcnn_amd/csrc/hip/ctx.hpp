@@ -22,6 +22,7 @@ struct dev_layer {
     gate_rec *p1[2] = {nullptr, nullptr};
     uint64_t n_p1[2] = {0, 0};      // records incl. padding (runs of equal keys padded to multiples of GATE_GROUP)
     uint64_t n_p1_real[2] = {0, 0}, n_p2_real[2] = {0, 0};
+    uint32_t p1_G[2] = {4, 4}, p2_G[2] = {4, 4};       // records per thread of the scatter kernel (runs are padded to multiples of it)
     uint64_t n_p1_uni[2] = {0, 0};  // how many of them are uni gates (for the algorithmic byte count)
     // phase-2 lists: bin gates whose v operand lives in table b, sorted by v
     gate_rec *p2[2] = {nullptr, nullptr};

@@ -433,19 +433,91 @@ static_assert(sizeof(zkff::G1) == sizeof(g1j_t) && sizeof(zkff::G1Affine) == siz
 #define CHECK_READY() do { if (!ctx || !ctx->circuit_ready) return ZK_ERR_STATE; ZK_HIP(hipSetDevice(ctx->device)); } while (0)
 static inline const HFr &H(const uint64_t *p) { return *reinterpret_cast<const HFr *>(p); }
 
-extern "C" int32_t zk_commit_input(zk_ctx *ctx, const uint64_t *gens, uint64_t n_gens, uint64_t *out_comm, uint64_t n_rows) {
+// rowsJ[i] += blinds[i] * H for i < rows, H = generator number h_index of the cached set (zero-knowledge mode). The blinds are host
+// scalars; they go through the generic window kernels as a one-column matrix whose only column is H.
+static int32_t add_blinds(zk_ctx *ctx, const uint64_t *blinds, uint32_t rows, uint32_t h_index) {
+    msm_state *s = ctx->msm;
+    if (h_index >= s->m) { ctx->err = "blinding generator is not part of the cached generator set"; return ZK_ERR_ARG; }
+    int32_t rc;
+    if ((rc = zk_scratch(ctx, (size_t) rows * 36))) return rc;
+    fr_t *d_bl = (fr_t *) ctx->scratch.p;
+    uint32_t *d_idx = (uint32_t *) (d_bl + rows);
+    std::vector<uint32_t> idx(rows, h_index);
+    ZK_HIP(hipMemcpyAsync(d_bl, blinds, (size_t) rows * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync(d_idx, idx.data(), (size_t) rows * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));          // idx is a local
+    if ((rc = regrow(ctx, (void **) &s->tmpJ, &s->tmp_cap, (size_t) rows * sizeof(g1j_t)))) return rc;
+    if ((rc = scalar_mags(ctx, d_bl, 1, nullptr, rows, 1))) return rc;
+    if ((rc = msm_windows(ctx, d_idx, 1, rows, 1, 0, s->tmpJ))) return rc;
+    ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_add_rows, dim3((rows + 63) / 64), dim3(64), s->rowsJ, s->tmpJ, (const uint32_t *) nullptr, rows, (const uint32_t *) nullptr);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
+static int32_t commit_input_impl(zk_ctx *ctx, const uint64_t *gens, uint64_t n_gens, const uint64_t *blinds, uint64_t *out_comm, uint64_t n_rows) {
     CHECK_READY();
     const dev_layer &L0 = ctx->L[0];
     const int n = L0.d.bit_length, rb = n >> 1, cb = n - rb;
-    if (n_gens != (1ull << cb) || n_rows != (1ull << rb) || !gens || !out_comm) { ctx->err = "commit: wrong generator / row count"; return ZK_ERR_ARG; }
+    const uint64_t cols = 1ull << cb;
+    if (n_gens != cols + (blinds ? 1 : 0) || n_rows != (1ull << rb) || !gens || !out_comm) { ctx->err = "commit: wrong generator / row count"; return ZK_ERR_ARG; }
     int32_t rc;
     if ((rc = ensure_state(ctx)) || (rc = ensure_tables(ctx, gens, n_gens))) return rc;
     ctx->msm->rb = rb;
     ctx->msm->cb = cb;
     return with_safe_retry(ctx, [&]() -> int32_t {
-        int32_t r = commit_rows(ctx, L0.val, n_gens, (uint32_t) n_rows, (uint32_t) n_gens);
+        int32_t r = commit_rows(ctx, L0.val, cols, (uint32_t) n_rows, (uint32_t) cols);
+        if (!r && blinds) r = add_blinds(ctx, blinds, (uint32_t) n_rows, (uint32_t) cols);
         return r ? r : fetch_points(ctx, (uint32_t) n_rows, out_comm);
     });
+}
+
+extern "C" int32_t zk_commit_input(zk_ctx *ctx, const uint64_t *gens, uint64_t n_gens, uint64_t *out_comm, uint64_t n_rows) {
+    return commit_input_impl(ctx, gens, n_gens, nullptr, out_comm, n_rows);
+}
+extern "C" int32_t zk_commit_input_blinded(zk_ctx *ctx, const uint64_t *gens, uint64_t n_gens, const uint64_t *blinds, uint64_t *out_comm, uint64_t n_rows) {
+    if (!blinds) return ZK_ERR_ARG;
+    return commit_input_impl(ctx, gens, n_gens, blinds, out_comm, n_rows);
+}
+
+extern "C" int32_t zk_commit_vector(zk_ctx *ctx, const uint64_t *scalars, uint64_t n_rows, uint64_t cols, const uint64_t *blinds, uint64_t *out) {
+    CHECK_READY();
+    msm_state *s = ctx->msm;
+    if (!s || !s->tables || !scalars || !out || !n_rows || n_rows > 65535 || cols + (blinds ? 1 : 0) > s->m || !cols) {
+        ctx->err = "commit_vector: no cached generators for this shape";
+        return ZK_ERR_ARG;
+    }
+    int32_t rc;
+    ++s->gens_hits;                                   // the cached set is in use again: worth its byte table
+    fr_t *d_v = nullptr;                              // its own buffer: commit_rows and add_blinds use the context's scratch
+    ZK_HIP(hipMalloc((void **) &d_v, (size_t) n_rows * cols * 32));
+    hipError_t e = hipMemcpyAsync(d_v, scalars, (size_t) n_rows * cols * 32, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { hipFree(d_v); ctx->err = hipGetErrorString(e); return ZK_ERR_HIP; }
+    rc = with_safe_retry(ctx, [&]() -> int32_t {
+        int32_t r = commit_rows(ctx, d_v, cols, (uint32_t) n_rows, (uint32_t) cols);
+        if (!r && blinds) r = add_blinds(ctx, blinds, (uint32_t) n_rows, (uint32_t) cols);
+        return r ? r : fetch_points(ctx, (uint32_t) n_rows, out);
+    });
+    hipStreamSynchronize(ctx->stream);
+    hipFree(d_v);
+    return rc;
+}
+
+extern "C" int32_t zk_hyrax_combine_rows(zk_ctx *ctx, const uint64_t *x, uint32_t n, uint64_t *out_w) {
+    CHECK_READY();
+    msm_state *s = ctx->msm;
+    if (!s || !s->tables) { ctx->err = "open before commit"; return ZK_ERR_STATE; }
+    const dev_layer &L0 = ctx->L[0];
+    if ((int) n != L0.d.bit_length || !out_w) return ZK_ERR_ARG;
+    const uint32_t rows = 1u << s->rb, m = 1u << s->cb;
+    int32_t rc;
+    if ((rc = regrow(ctx, (void **) &s->mag, &s->mag_cap, ((size_t) rows + m) * sizeof(fr_t)))) return rc;
+    fr_t *Lrow = s->mag, *w = s->mag + rows;
+    const HFr *xs = reinterpret_cast<const HFr *>(x);
+    if ((rc = zk_eq_table1_dev(ctx, Lrow, s->rb, xs + s->cb, HFr::one()))) return rc;
+    if ((rc = zk_col_combine_dev(ctx, w, L0.val, Lrow, m, rows))) return rc;
+    ZK_HIP(hipMemcpyAsync(out_w, w, (size_t) m * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
 }
 
 extern "C" int32_t zk_hyrax_open_init(zk_ctx *ctx, const uint64_t *x, uint32_t n) {

@@ -194,8 +194,42 @@ __device__ __forceinline__ void gate_segment_store(uint32_t key, fr_t val, bool 
     }
 }
 
-// GATE_GROUP consecutive records per thread: the upload pads every run of equal keys to a multiple of GATE_GROUP, so the records
-// of one thread always share their key and are summed before the (comparatively expensive) cross-lane scan. a.n counts groups.
+// Sum of up to 32 field elements without a modular reduction per addition: 9 limbs (32 r < 2^260), one carry chain per term,
+// then log2(G) + 1 conditional subtractions of r << k at the end.
+struct fr_wide { uint32_t v[9]; };
+__device__ __forceinline__ void frw_add(fr_wide &a, const fr_t &x) {
+    unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.v[i] = __builtin_addc(a.v[i], x.v[i], c, &c);
+    a.v[8] += c;
+}
+template <int LOG2G>
+__device__ __forceinline__ fr_t frw_reduce(fr_wide a) {          // a < 2^LOG2G r
+    const uint32_t m[8] = FR_MOD_INIT;
+#pragma unroll
+    for (int k = LOG2G - 1; k >= 0; --k) {
+        uint32_t d[9];
+        unsigned bo = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            // limb i of r << k
+            const uint32_t lo = i < 8 ? m[i] << k : 0u, hi = (k && i > 0) ? m[i - 1] >> (32 - k) : 0u;
+            d[i] = __builtin_subc(a.v[i], lo | hi, bo, &bo);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a.v[i] = bo ? a.v[i] : d[i];
+    }
+    fr_t z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z.v[i] = a.v[i];
+    return z;
+}
+
+// G consecutive records per thread: the upload pads every run of equal keys to a multiple of G, so the records of one thread always
+// share their key and are summed (lazily reduced) before the comparatively expensive cross-lane scan. a.n counts groups. G is chosen
+// per list at upload: lists whose runs are long (a convolution's gates per input pixel or per weight) take 32 terms per thread, which
+// leaves ~10 VALU instructions per term around the Montgomery product instead of ~180 with 4.
+template <int G>
 __global__ void __launch_bounds__(ZK_BLOCK) k_gate_reduce(fr_t *out, uint32_t *carry_key, fr_t *carry_val, gate_args a) {
     const uint64_t idx = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x;
     const bool live = idx < a.n;
@@ -203,13 +237,18 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_gate_reduce(fr_t *out, uint32_t *c
     fr_t val = fr_zero();
     if (live) {
         // records of one wave are stored lane-interleaved: the k-th record of lane l sits at slot k * 64 + l of the wave's chunk
-        const gate_rec *rp = a.recs + (idx >> 6) * (64 * GATE_GROUP) + (idx & 63);
+        const gate_rec *rp = a.recs + (idx >> 6) * (64 * G) + (idx & 63);
         key = rp[0].key;
+        fr_wide acc;
 #pragma unroll
-        for (uint32_t k = 0; k < GATE_GROUP; ++k) {
+        for (int i = 0; i < 9; ++i) acc.v[i] = 0;
+#pragma unroll 4
+        for (uint32_t k = 0; k < G; ++k) {
             const gate_rec rc = rp[k * 64];
-            val = fr_add(val, gate_term(rc, a));
+            frw_add(acc, gate_term(rc, a));
         }
+        constexpr int LOG2G = G == 4 ? 2 : G == 8 ? 3 : G == 16 ? 4 : 5;
+        val = frw_reduce<LOG2G>(acc);
     }
     gate_segment_store(key, val, live, idx, a.n, out, carry_key, carry_val, a.post_scale != 0, a.post);
 }

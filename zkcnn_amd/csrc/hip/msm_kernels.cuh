@@ -448,10 +448,13 @@ __global__ void __launch_bounds__(512) k_msm_finish(g1j_t *outJ, const g1j_t *pa
     if (threadIdx.x == 0) outJ[row] = sm[0][0];
 }
 
-// rows[list[i]] += extra[i], i < min(n, *count)
+// rows[list[i]] += extra[i], i < min(n, *count)   (list == NULL: rows[i] += extra[i])
 __global__ void __launch_bounds__(MSM_BLOCK) k_add_rows(g1j_t *rows, const g1j_t *extra, const uint32_t *list, uint32_t n, const uint32_t *count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && (!count || i < *count)) rows[list[i]] = g1_add_any(rows[list[i]], extra[i]);
+    if (i < n && (!count || i < *count)) {
+        const uint32_t r = list ? list[i] : i;
+        rows[r] = g1_add_any(rows[r], extra[i]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -163,25 +163,45 @@ static uint32_t covered_prefix(const std::vector<gate_rec> &recs) {
     }
     return k;
 }
-// pads every run of equal keys (list sorted by key) to a multiple of GATE_GROUP records with padding records of the same key
-static void pad_runs(std::vector<gate_rec> &recs) {
+// records after padding every run of equal keys (list sorted by key) to a multiple of G
+static uint64_t padded_size(const std::vector<gate_rec> &recs, uint32_t G) {
+    uint64_t total = 0;
+    size_t i = 0;
+    while (i < recs.size()) {
+        size_t j = i;
+        while (j < recs.size() && recs[j].key == recs[i].key) ++j;
+        total += ((j - i + G - 1) / G) * G;
+        i = j;
+    }
+    return total;
+}
+// records per thread for a list: the largest of 32 / 16 / 8 / 4 whose padding costs less than 1/8 of the list
+static uint32_t choose_group(const std::vector<gate_rec> &recs) {
+    static const int forced = getenv("ZKCNN_GATE_GROUP") ? atoi(getenv("ZKCNN_GATE_GROUP")) : 0;
+    if (forced == 4 || forced == 8 || forced == 16 || forced == 32) return (uint32_t) forced;
+    for (uint32_t G = 32; G > GATE_GROUP; G >>= 1)
+        if (padded_size(recs, G) <= recs.size() + recs.size() / 8) return G;
+    return GATE_GROUP;
+}
+// pads every run of equal keys (list sorted by key) to a multiple of G records with padding records of the same key
+static void pad_runs(std::vector<gate_rec> &recs, uint32_t G) {
     std::vector<gate_rec> out;
-    out.reserve(recs.size() + recs.size() / 8 + GATE_GROUP);
+    out.reserve(recs.size() + recs.size() / 8 + 64 * G);
     size_t i = 0;
     while (i < recs.size()) {
         size_t j = i;
         while (j < recs.size() && recs[j].key == recs[i].key) ++j;
         out.insert(out.end(), recs.begin() + i, recs.begin() + j);
-        for (size_t k = j - i; k % GATE_GROUP; ++k) {
+        for (size_t k = j - i; k % G; ++k) {
             gate_rec d = {0, recs[i].key, 0, 1u << 11};
             out.push_back(d);
         }
         i = j;
     }
     // whole waves: the list is padded to a multiple of 64 groups with records of the last key, and inside every chunk of
-    // 64 x GATE_GROUP records the k-th record of lane l is stored at slot k * 64 + l, so that each of the kernel's GATE_GROUP
-    // loads is one contiguous 1 KB access of the wave
-    const size_t chunk = 64 * GATE_GROUP;
+    // 64 x G records the k-th record of lane l is stored at slot k * 64 + l, so that each of the kernel's G loads is one
+    // contiguous 1 KB access of the wave
+    const size_t chunk = 64 * (size_t) G;
     while (!out.empty() && out.size() % chunk) {
         gate_rec d = {0, out.back().key, 0, 1u << 11};
         out.push_back(d);
@@ -189,7 +209,7 @@ static void pad_runs(std::vector<gate_rec> &recs) {
     recs.resize(out.size());
     for (size_t base = 0; base < out.size(); base += chunk)
         for (size_t l = 0; l < 64; ++l)
-            for (size_t k = 0; k < GATE_GROUP; ++k) recs[base + k * 64 + l] = out[base + l * GATE_GROUP + k];
+            for (size_t k = 0; k < G; ++k) recs[base + k * 64 + l] = out[base + l * G + k];
 }
 static void counting_sort(std::vector<gate_rec> &recs, uint32_t nkeys) {
     std::vector<uint32_t> cnt((size_t) nkeys + 1, 0);
@@ -264,7 +284,8 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
                 D.p2_uniform[b] = same ? (int) f0 : -1;
             }
             D.n_p2_real[b] = q[b].size();
-            pad_runs(q[b]);
+            D.p2_G[b] = choose_group(q[b]);
+            pad_runs(q[b], D.p2_G[b]);
             D.n_p2[b] = q[b].size();
             max_list = std::max<uint64_t>(max_list, q[b].size());
             if ((rc = upload(ctx, &D.p2[b], q[b]))) return rc;
@@ -313,7 +334,8 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
             counting_sort(p[b], 1u << S.bit_length_u[b]);
             D.p1_cov[b] = covered_prefix(p[b]);
             D.n_p1_real[b] = p[b].size();
-            pad_runs(p[b]);
+            D.p1_G[b] = choose_group(p[b]);
+            pad_runs(p[b], D.p1_G[b]);
             D.n_p1[b] = p[b].size();
             max_list = std::max<uint64_t>(max_list, p[b].size());
             if ((rc = upload(ctx, &D.p1[b], p[b]))) return rc;
@@ -437,12 +459,12 @@ static int32_t wait_slot(zk_ctx *ctx, unsigned long long seq) {
 
 // n = records in the padded list (a multiple of GATE_GROUP), n_real = gates among them
 static int32_t gate_scatter(zk_ctx *ctx, fr_t *out, const gate_rec *recs, uint64_t n, uint64_t n_real, int phase, const dev_layer &cur,
-                            const dev_layer &prev, uint64_t n_uni_in_list, uint64_t out_len, int uniform_u = -1) {
+                            const dev_layer &prev, uint64_t n_uni_in_list, uint64_t out_len, uint32_t G, int uniform_u = -1) {
     if (!n) return ZK_OK;
     const double gate_bytes = 44.0 * (double) n_uni_in_list + 80.0 * (double) (n_real - n_uni_in_list) + 32.0 * (double) out_len;
     gate_args A;
     A.recs = recs;
-    A.n = n / GATE_GROUP;
+    A.n = n / G;
     A.beta_g = ctx->beta_g[ctx->beta_g_cur];
     A.beta_u = ctx->beta_u;
     A.val0 = ctx->L[0].val;
@@ -456,7 +478,12 @@ static int32_t gate_scatter(zk_ctx *ctx, fr_t *out, const gate_rec *recs, uint64
     (void) cur;
     const uint32_t blocks = (uint32_t) ((A.n + ZK_BLOCK - 1) / ZK_BLOCK);
     if (2ull * blocks > ctx->carry_slots) { ctx->err = "carry buffer too small"; return ZK_ERR_STATE; }
-    ZK_LAUNCH(PC_GATE, gate_bytes, k_gate_reduce, dim3(blocks), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, A);
+    switch (G) {
+        case 32: ZK_LAUNCH(PC_GATE, gate_bytes, k_gate_reduce<32>, dim3(blocks), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, A); break;
+        case 16: ZK_LAUNCH(PC_GATE, gate_bytes, k_gate_reduce<16>, dim3(blocks), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, A); break;
+        case 8: ZK_LAUNCH(PC_GATE, gate_bytes, k_gate_reduce<8>, dim3(blocks), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, A); break;
+        default: ZK_LAUNCH(PC_GATE, gate_bytes, k_gate_reduce<4>, dim3(blocks), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, A); break;
+    }
     ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup, dim3(grid_for(2ull * blocks)), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, 2ull * blocks);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
@@ -672,7 +699,7 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
         if (cur.p1_cov[b] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p1_cov[b], 0, (t.len - cur.p1_cov[b]) * 32, ctx->stream));
-        if ((rc = gate_scatter(ctx, t.M[0], cur.p1[b], cur.n_p1[b], cur.n_p1_real[b], 1, cur, prev, cur.n_p1_uni[b], t.len))) return rc;
+        if ((rc = gate_scatter(ctx, t.M[0], cur.p1[b], cur.n_p1[b], cur.n_p1_real[b], 1, cur, prev, cur.n_p1_uni[b], t.len, cur.p1_G[b]))) return rc;
     }
     return ZK_OK;
 }
@@ -790,7 +817,7 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         ZK_LAUNCH(PC_DOT, 0.0, k_row_dot, dim3((rows + 3) / 4), dim3(ZK_BLOCK), t.V[0], prev.val, ctx->beta_gs, rows, fft_bl);
         ZK_HIP(hipGetLastError());
         if (cur.p2_cov[1] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p2_cov[1], 0, (t.len - cur.p2_cov[1]) * 32, ctx->stream));
-        return gate_scatter(ctx, t.M[0], cur.p2[1], cur.n_p2[1], cur.n_p2_real[1], 2, cur, prev, 0, t.len, cur.p2_uniform[1]);
+        return gate_scatter(ctx, t.M[0], cur.p2[1], cur.n_p2[1], cur.n_p2_real[1], 2, cur, prev, 0, t.len, cur.p2_G[1], cur.p2_uniform[1]);
     }
 
     if ((rc = eq_table1(ctx, ctx->beta_u, d.max_bl_u, ru, HFr::one()))) return rc;
@@ -811,7 +838,7 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
         if (cur.p2_cov[b] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p2_cov[b], 0, (t.len - cur.p2_cov[b]) * 32, ctx->stream));
-        if ((rc = gate_scatter(ctx, t.M[0], cur.p2[b], cur.n_p2[b], cur.n_p2_real[b], 2, cur, prev, 0, t.len, cur.p2_uniform[b]))) return rc;
+        if ((rc = gate_scatter(ctx, t.M[0], cur.p2[b], cur.n_p2[b], cur.n_p2_real[b], 2, cur, prev, 0, t.len, cur.p2_G[b], cur.p2_uniform[b]))) return rc;
     }
     if (cur.n_uni2) {
         ZK_HIP(hipMemcpyAsync(ctx->h_result + 8, ctx->d_result + 8, 64, hipMemcpyDeviceToHost, ctx->stream));

@@ -13,7 +13,11 @@ public:
     // `affine_cache` (optional, owned by the caller): the affine form of the generators of the previous commitment; re-used when the
     // same generators come again (one batched inversion + 6 products per generator saved), refreshed otherwise
     struct gensCache { std::vector<G1> gens; std::vector<G1Affine> affine; };
-    polyProver(zk_ctx *ctx, int bit_length, const std::vector<G1> &gens, gensCache *affine_cache = nullptr);
+    // `blinds` (zero-knowledge mode): gens holds one more generator H and row i is committed as <row_i, g> + (*blinds)[i] H
+    polyProver(zk_ctx *ctx, int bit_length, const std::vector<G1> &gens, gensCache *affine_cache = nullptr, const std::vector<Fr> *blinds = nullptr);
+    std::vector<G1> commitHostVector(const std::vector<Fr> &v, const std::vector<Fr> &blinds) override;
+    std::vector<Fr> combineRows(const std::vector<Fr> &x) override;
+    void addProofBytes(size_t n) override { ps_bytes += n; }
     const std::vector<G1> &commitment() const override { return comm; }
     void openInit(const std::vector<Fr> &x) override;
     ipaRoundMsg openRound() override;

@@ -126,18 +126,21 @@ void prover::sumcheckDotProdInitPhase1() {
     TIMED();
     prove_timer.start();
     check(zk_sumcheck_dotprod_init_phase1(ctx), "zk_sumcheck_dotprod_init_phase1");
+    zkBeginInstance();
     prove_timer.stop();
 }
 void prover::sumcheckInitPhase1(const F &relu_rou_0) {
     TIMED();
     prove_timer.start();
     check(zk_sumcheck_init_phase1(ctx, U(relu_rou_0)), "zk_sumcheck_init_phase1");
+    zkBeginInstance();
     prove_timer.stop();
 }
 void prover::sumcheckInitPhase2() {
     TIMED();
     prove_timer.start();
     check(zk_sumcheck_init_phase2(ctx), "zk_sumcheck_init_phase2");
+    zkBeginInstance();
     prove_timer.stop();
 }
 cubic_poly prover::sumcheckDotProdUpdate1(const F &previous_random) {
@@ -145,24 +148,30 @@ cubic_poly prover::sumcheckDotProdUpdate1(const F &previous_random) {
     prove_timer.start();
     F o[4];
     check(zk_sumcheck_dotprod_update1(ctx, U(previous_random), U(o[0])), "zk_sumcheck_dotprod_update1");
+    cubic_poly poly(o[0], o[1], o[2], o[3]);
+    zkMask(poly, previous_random);
     prove_timer.stop();
-    return cubic_poly(o[0], o[1], o[2], o[3]);
+    return poly;
 }
 quadratic_poly prover::sumcheckUpdate1(const F &previous_random) {
     TIMED();
     prove_timer.start();
     F o[3];
     check(zk_sumcheck_update1(ctx, U(previous_random), U(o[0])), "zk_sumcheck_update1");
+    quadratic_poly poly(o[0], o[1], o[2]);
+    zkMask(poly, previous_random);
     prove_timer.stop();
-    return quadratic_poly(o[0], o[1], o[2]);
+    return poly;
 }
 quadratic_poly prover::sumcheckUpdate2(const F &previous_random) {
     TIMED();
     prove_timer.start();
     F o[3];
     check(zk_sumcheck_update2(ctx, U(previous_random), U(o[0])), "zk_sumcheck_update2");
+    quadratic_poly poly(o[0], o[1], o[2]);
+    zkMask(poly, previous_random);
     prove_timer.stop();
-    return quadratic_poly(o[0], o[1], o[2]);
+    return poly;
 }
 F prover::Vres(const vector<F>::const_iterator &r, u32 output_size, u8 r_size) {
     TIMED();
@@ -201,6 +210,7 @@ void prover::sumcheckLiuInit(const vector<F> &s_u, const vector<F> &s_v) {
     TIMED();
     prove_timer.start();
     check(zk_sumcheck_liu_init(ctx, U(s_u[0]), U(s_v[0]), (u32) s_u.size()), "zk_sumcheck_liu_init");
+    zkBeginInstance();
     prove_timer.stop();
 }
 quadratic_poly prover::sumcheckLiuUpdate(const F &previous_random) {
@@ -208,14 +218,27 @@ quadratic_poly prover::sumcheckLiuUpdate(const F &previous_random) {
     prove_timer.start();
     F o[3];
     check(zk_sumcheck_liu_update(ctx, U(previous_random), U(o[0])), "zk_sumcheck_liu_update");
+    quadratic_poly poly(o[0], o[1], o[2]);
+    zkMask(poly, previous_random);
     prove_timer.stop();
-    return quadratic_poly(o[0], o[1], o[2]);
+    return poly;
 }
 
 // reference src/prover.cpp:503-511. The HBM copy of val[0] is already zero padded to 2^bit_length.
 hyrax_bls12_381::polyProverBase &prover::commitInput(const vector<G> &gens) {
     TIMED();
     if (!ctx || !resident) throw std::runtime_error("prover::commitInput before prover::init");
+    zkReset();
     poly_p.reset(new hyrax_bls12_381::polyProver(ctx, C.circuit[0].bit_length, gens, &gens_cache));
+    return *poly_p;
+}
+
+hyrax_bls12_381::polyProverBase &prover::commitInputZk(const vector<G> &gens) {
+    TIMED();
+    if (!ctx || !resident) throw std::runtime_error("prover::commitInputZk before prover::init");
+    zkReset();
+    const int bl = C.circuit[0].bit_length;
+    const vector<F> blinds = zkDrawBlinds((size_t) 1 << (bl >> 1));
+    poly_p.reset(new hyrax_bls12_381::polyProver(ctx, bl, gens, &gens_cache, &blinds));
     return *poly_p;
 }

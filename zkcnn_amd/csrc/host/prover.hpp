@@ -11,10 +11,11 @@
 #include "circuit.h"
 #include "polynomial.h"
 #include "polyProver.hpp"
+#include "zk_mask.hpp"
 
 class neuralNetwork;
 
-class prover {
+class prover : public zkmask::proverMixin {
 public:
     prover();
     explicit prover(int device);
@@ -45,6 +46,9 @@ public:
     quadratic_poly sumcheckLiuUpdate(const F &previous_random);
 
     hyrax_bls12_381::polyProverBase &commitInput(const vector<G> &gens);
+    // zero-knowledge mode (additive; ZKCNN_MODE_ZK): gens = (g_0 .. g_{m-1}, H), every row commitment blinded; the round polynomials of all
+    // following sumchecks are masked (zk_mask.hpp: zkMaskCommit / zkSetRho / zkMaskEval / zkMaskOpen1,2 come from the mixin)
+    hyrax_bls12_381::polyProverBase &commitInputZk(const vector<G> &gens);
 
     timer prove_timer;
     double proveTime() const { return prove_timer.elapse_sec(); }
@@ -63,6 +67,8 @@ public:
 
     void ensureContext();                       // creates the GPU context (and its stream) without uploading anything
 private:
+    hyrax_bls12_381::polyProverBase &zkBackend() override { return *poly_p; }
+    const layeredCircuit &zkCircuit() const override { return C; }
     void check(int rc, const char *what) const;
 
     zk_ctx *ctx;

@@ -11,6 +11,7 @@
 #include "../ff/sha256.hpp"
 #include "../../../include/zkcnn_api.h"
 #include "verifier.hpp"
+#include "zk_mask.hpp"
 
 class fiatShamir : public zkff::ChallengeSource, public transcriptTap {
 public:
@@ -91,9 +92,10 @@ private:
 
 class replayPolyProver : public hyrax_bls12_381::polyProverBase {
 public:
-    replayPolyProver(proofReader &reader, int input_bits) : rd(reader) {
+    replayPolyProver(proofReader &reader, int input_bits, bool zk = false) : rd(reader) {
         const int rb = input_bits >> 1;
         cb = input_bits - rb;
+        if (zk) zk_m = (size_t) 1 << cb;
         comm.resize((size_t) 1 << rb);
         for (auto &c : comm) c = rd.g1();
     }
@@ -113,6 +115,24 @@ public:
     }
     double getPT() const override { return 0; }
     double getPS() const override { return 0; }
+    // zero-knowledge opening: both prover messages come from the bytes
+    hyrax_bls12_381::dotProofCommit zkOpenCommit(const std::vector<Fr> &, const std::vector<Fr> &) override { return readDot1(1); }
+    hyrax_bls12_381::dotProofResponse zkOpenRespond(const Fr &) override { return readDot2(1); }
+    hyrax_bls12_381::dotProofCommit readDot1(size_t rows) {
+        hyrax_bls12_381::dotProofCommit m;
+        m.delta.resize(rows);
+        for (auto &d : m.delta) d = rd.g1();
+        m.t = rd.fr();
+        return m;
+    }
+    hyrax_bls12_381::dotProofResponse readDot2(size_t rows) {
+        hyrax_bls12_381::dotProofResponse m;
+        m.z.resize(rows * zk_m);
+        for (auto &x : m.z) x = rd.fr();
+        m.z_blind.resize(rows);
+        for (auto &x : m.z_blind) x = rd.fr();
+        return m;
+    }
 private:
     proofReader &rd;
     std::vector<G1> comm;
@@ -144,6 +164,25 @@ public:
         pp.reset(new replayPolyProver(rd, C->circuit[0].bit_length));
         return *pp;
     }
+    // zero-knowledge mode: the same messages, parsed
+    hyrax_bls12_381::polyProverBase &commitInputZk(const std::vector<G1> &) {
+        pp.reset(new replayPolyProver(rd, C->circuit[0].bit_length, true));
+        return *pp;
+    }
+    zkmask::maskCommitMsg zkMaskCommit() {
+        const zkmask::plan pl(*C);
+        mask_rows = (pl.total + pp->zkColumns() - 1) / pp->zkColumns();
+        zkmask::maskCommitMsg m;
+        m.commit.resize(mask_rows);
+        for (auto &c : m.commit) c = rd.g1();
+        m.sums.resize(pl.items.size());
+        for (auto &x : m.sums) x = rd.fr();
+        return m;
+    }
+    void zkSetRho(const F &) {}
+    F zkMaskEval(const F &) { return rd.fr(); }
+    hyrax_bls12_381::dotProofCommit zkMaskOpen1(const vector<F> &) { return pp->readDot1(mask_rows); }
+    hyrax_bls12_381::dotProofResponse zkMaskOpen2(const F &) { return pp->readDot2(mask_rows); }
     double proveTime() const { return 0; }
     double proofSize() const { return 0; }
     double polyProverTime() const { return 0; }
@@ -153,5 +192,6 @@ private:
     const layeredCircuit *C;                  // the statement (only the size of the input layer is needed here)
     proofReader rd;
     std::unique_ptr<replayPolyProver> pp;
+    size_t mask_rows = 0;
     quadratic_poly quad() { F a = rd.fr(), b = rd.fr(), c = rd.fr(); return quadratic_poly(a, b, c); }
 };

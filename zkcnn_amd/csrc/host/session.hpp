@@ -72,10 +72,12 @@ struct sessionT {
         // generators both sides know in advance must not have a known discrete logarithm: hash-to-curve (ff/hash_to_curve.hpp).
         // Only the in-process interactive run keeps the reference's k_i * G, with k_i drawn by the verifier and never shown to the prover.
         const bool public_gens = fiat || (mode & ZKCNN_MODE_REUSE_GENS);
+        const bool zk = (mode & ZKCNN_MODE_ZK) != 0;
         const u8 logn = p.C.circuit[0].bit_length;
-        const size_t n_sqrt = (size_t) 1 << (logn - (logn >> 1));
-        if (mode & ZKCNN_MODE_SEEDED) Fr::seedCSPRNG(challenge_seed);
-        else Fr::useOsRandom();
+        const size_t n_sqrt = ((size_t) 1 << (logn - (logn >> 1))) + (zk ? 1 : 0);       // zero-knowledge mode: one more generator, H
+        if (mode & ZKCNN_MODE_SEEDED) { Fr::seedCSPRNG(challenge_seed); zkff::privateCoins().seed(challenge_seed); }
+        else { Fr::useOsRandom(); zkff::privateCoins().useOsRandom(); }
+        v.zk = zk;
         const zkff::publicGenerators *pg = nullptr;
         if (public_gens) {
             pg = &zkff::publicGeneratorSet(n_sqrt);

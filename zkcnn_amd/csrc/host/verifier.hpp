@@ -12,6 +12,7 @@
 #include "circuit.h"
 #include "polynomial.h"
 #include "utils.hpp"
+#include "zk_mask.hpp"
 
 // anything that wants to see every serialized message as it is recorded (the Fiat-Shamir state of replay.hpp)
 struct transcriptTap {
@@ -100,6 +101,9 @@ public:
     // recorded instead of all of a phase's challenges up front as the reference does (src/verifier.cpp:155,207,279)
     bool lazy_challenges = false;
     const std::vector<G1> *fixed_gens = nullptr;   // re-use generators instead of drawing new ones
+    // zero-knowledge mode (zk_mask.hpp; no reference counterpart): blinded commitments over (g, H), masked round polynomials, proofs of dot
+    // product instead of the inner-product argument. The checks of the reference protocol are unchanged underneath the masks.
+    bool zk = false;
     bool full_ipa = false;                   // run the inner-product argument down to length 1 instead of stopping at IPA_STOP_LEN
     proofTranscript transcript;
     // test hook: add 1 to the k-th message received from the prover (a cheating prover); -1 = off.
@@ -111,15 +115,18 @@ public:
     bool verify() {
         const u8 logn = C.circuit[0].bit_length;
         const size_t n_sqrt = (size_t) 1 << (logn - (logn >> 1));
+        const size_t n_gens = n_sqrt + (zk ? 1 : 0);                 // zero-knowledge mode: one more generator, H
         if (fixed_gens) gens = *fixed_gens;
-        else drawGenerators(gens, n_sqrt);
-        if (gens.size() != n_sqrt) return false;
+        else drawGenerators(gens, n_gens);
+        if (gens.size() != n_gens) return false;
         delete poly_v;
-        poly_v = new hyrax_bls12_381::polyVerifier(p->commitInput(gens), gens, &transcript);
+        poly_v = new hyrax_bls12_381::polyVerifier(zk ? p->commitInputZk(gens) : p->commitInput(gens), gens, &transcript);
         poly_v->drive_only = drive_only;
+        if (zk && !receiveMasks(n_sqrt)) return false;
         poly_v->stop_len = full_ipa ? 1 : (size_t) hyrax_bls12_381::IPA_STOP_LEN;
         msg_count = 0;
         if (!(verifyInnerLayers() && verifyFirstLayer())) return false;
+        if (zk && !verifyMasks()) return false;
         poly_v->tamper_at = tamper_at < 0 ? -1 : tamper_at - msg_count;
         return verifyInput();
     }
@@ -141,6 +148,79 @@ private:
     std::vector<G1> gens;
     hyrax_bls12_381::polyVerifier *poly_v;
     string fail_msg;
+
+    // ---- zero-knowledge mode: masking polynomials of the sumcheck instances (zk_mask.hpp) ----
+    zkmask::plan mask_plan;
+    std::vector<G1> mask_commit;
+    std::vector<F> mask_sums, mask_vals;
+    std::vector<vector<F>> mask_points;
+    F mask_rho;
+    size_t mask_k = 0;
+
+    // the prover's commitment to every masking polynomial and their sums over the cube, then rho
+    bool receiveMasks(size_t m) {
+        mask_plan = zkmask::plan(C);
+        zkmask::maskCommitMsg msg = p->zkMaskCommit();
+        if (msg.commit.size() != (mask_plan.total + m - 1) / m || msg.sums.size() != mask_plan.items.size()) return fail("masking commitment of the wrong shape");
+        for (const G1 &c : msg.commit) transcript.put(c);
+        for (const F &x : msg.sums) transcript.put(x);
+        mask_commit = msg.commit;
+        mask_sums = msg.sums;
+        mask_vals.clear();
+        mask_points.clear();
+        mask_k = 0;
+        tic();
+        mask_rho.setByCSPRNG();
+        toc();
+        p->zkSetRho(mask_rho);
+        return true;
+    }
+    // a sumcheck instance starts: its claim becomes H + rho G
+    void maskOpen(F &claim) { if (zk) claim = claim + mask_rho * mask_sums.at(mask_k); }
+    // ... and ends: the prover reveals g(r), the claim about f is what is left
+    void maskClose(F &claim, const vector<F> &point, const F &last_r) {
+        if (!zk) return;
+        F v = p->zkMaskEval(last_r);
+        if (hit()) v = v + F_ONE;
+        transcript.put(v);
+        claim = claim - mask_rho * v;
+        mask_vals.push_back(v);
+        mask_points.push_back(point);
+        ++mask_k;
+    }
+    // one proof of dot product for all revealed evaluations: <a, sum_k gamma^k u_k> = sum_k gamma^k v_k against the commitment of a
+    bool verifyMasks() {
+        tic();
+        F gamma, y = F_ZERO, w = F_ONE;
+        gamma.setByCSPRNG();
+        zkmask::evalVector ev(mask_plan);
+        for (size_t k = 0; k < mask_vals.size(); ++k) {
+            ev.add(k, mask_points[k], w);
+            y = y + w * mask_vals[k];
+            w = w * gamma;
+        }
+        toc();
+        if (mask_vals.size() != mask_plan.items.size()) return fail("masking: instance count");
+        hyrax_bls12_381::dotProofCommit m1 = p->zkMaskOpen1(ev.u);
+        if (hit()) m1.t = m1.t + F_ONE;
+        for (const G1 &d : m1.delta) transcript.put(d);
+        transcript.put(m1.t);
+        tic();
+        F c;
+        c.setByCSPRNG();
+        toc();
+        hyrax_bls12_381::dotProofResponse m2 = p->zkMaskOpen2(c);
+        if (hit() && !m2.z.empty()) m2.z[m2.z.size() / 3] = m2.z[m2.z.size() / 3] + F_ONE;
+        for (const F &x : m2.z) transcript.put(x);
+        for (const F &x : m2.z_blind) transcript.put(x);
+        if (drive_only) return true;
+        tic();
+        std::vector<G1Affine> gA;
+        zkff::batchToAffine(poly_v->generators(), gA);
+        const bool ok = hyrax_bls12_381::dotVerify(mask_commit, gA, ev.u, y, m1, c, m2);
+        toc();
+        return ok ? true : fail("masking polynomials: proof of dot product");
+    }
 
     void tic() { total_timer.start(); total_slow_timer.start(); }
     void toc() { total_timer.stop(); total_slow_timer.stop(); }
@@ -253,6 +333,7 @@ private:
             else p->sumcheckInitPhase1(relu_rou);
 
             F previousRandom = F_ZERO;
+            maskOpen(previousSum);
             for (i8 j = 0; j < cur.max_bl_u; ++j) {
                 F at01, at_r;
                 if (dot) {
@@ -278,6 +359,7 @@ private:
                 previousSum = at_r;
                 toc();
             }
+            maskClose(previousSum, r_u[i], previousRandom);
             if (dot) {
                 p->sumcheckDotProdFinalize1(previousRandom, claim_u1);
                 if (hit()) claim_u1 = claim_u1 + F_ONE;
@@ -301,6 +383,7 @@ private:
                 toc();
                 p->sumcheckInitPhase2();
                 previousRandom = F_ZERO;
+                maskOpen(previousSum);
                 for (i8 j = 0; j < cur.max_bl_v; ++j) {
                     quadratic_poly poly = p->sumcheckUpdate2(previousRandom);
                     if (hit()) poly.a = poly.a + F_ONE;
@@ -313,6 +396,7 @@ private:
                     previousSum = poly.eval(previousRandom);
                     toc();
                 }
+                maskClose(previousSum, r_v[i], previousRandom);
                 p->sumcheckFinalize2(previousRandom, final_claim_v0[i], claim_v1);
                 if (hit()) claim_v1 = claim_v1 + F_ONE;
                 transcript.put(final_claim_v0[i]);
@@ -380,6 +464,7 @@ private:
 
         p->sumcheckLiuInit(sig_u, sig_v);
         F previousRandom = F_ZERO;
+        maskOpen(previousSum);
         for (int j = 0; j < cur.bit_length; ++j) {
             quadratic_poly poly = p->sumcheckLiuUpdate(previousRandom);
             if (hit()) poly.b = poly.b + F_ONE;
@@ -390,6 +475,7 @@ private:
             previousRandom = r_u[0][j];
             previousSum = poly.eval(previousRandom);
         }
+        maskClose(previousSum, r_u[0], previousRandom);
         p->sumcheckLiuFinalize(previousRandom, eval_in);
         if (hit()) eval_in = eval_in + F_ONE;
         transcript.put(eval_in);
@@ -433,7 +519,7 @@ private:
 
     // ---- stage 3: open the committed input at r_u[0] (reference src/verifier.cpp:359-373) ----
     bool verifyInput() {
-        if (!poly_v->verify(r_u[0], eval_in)) return fail("final input check fail");
+        if (!(zk ? poly_v->verifyZk(r_u[0], eval_in) : poly_v->verify(r_u[0], eval_in))) return fail("final input check fail");
         output_tb[POLY_PT_OUT_ID] = to_string_wp(p->polyProverTime());
         output_tb[POLY_VT_OUT_ID] = to_string_wp(poly_v->getVT());
         output_tb[POLY_PS_OUT_ID] = to_string_wp(p->polyProofSize());

@@ -17,10 +17,16 @@
 //     the recursion stops at length IPA_STOP_LEN (256): the prover sends the remaining vector a* and the verifier
 //     checks  P* == <a*, g*>  and  y* == <a*, b*>  (g*, b* = generators / eq table folded with the challenges).
 //     Stopping early trades 8 KB of proof for 8 latency-bound rounds (each round is two MSMs over half of the generators).
+// Zero-knowledge mode (ZKCNN_MODE_ZK): `gens` carries one more generator H, every commitment is blinded,
+//   Com(v; s) = <v, g> + s H, and the opening is Hyrax's proof of dot product instead of the inner-product argument:
+//     prover: d random, delta = Com(d; s_d), t = <d, b>      verifier: c      prover: z = c w + d, z_s = c s_w + s_d
+//     check:  Com(z; z_s) == c P + delta   and   <z, b> == c y + t             (perfect honest-verifier zero knowledge; m scalars)
+//   The same protocol, over several rows, proves the evaluations of the sumcheck masking polynomials (host/zk_mask.hpp).
 // Message order/format of the upstream library is unknowable here ("parity unpinned").
 #pragma once
 #include <chrono>
 #include <memory>
+#include <stdexcept>
 #include <vector>
 #include "../ff/fr.hpp"
 #include "../ff/g1.hpp"
@@ -94,6 +100,10 @@ struct ipaRoundMsg {
     Fr yL, yR;
 };
 
+// proof of dot product over a blinded matrix commitment (rows of m = gens.size() - 1 scalars)
+struct dotProofCommit { std::vector<G1> delta; Fr t; };
+struct dotProofResponse { std::vector<Fr> z, z_blind; };
+
 // What the verifier needs from a commitment prover. Two implementations exist: the HIP one
 // (class polyProver, zkcnn_amd/csrc/host/polyProver.{hpp,cpp}) and the CPU checker under oracle/.
 class polyProverBase {
@@ -106,7 +116,75 @@ public:
     virtual std::vector<Fr> openFinal() = 0;     // the vector left after ipaRounds(cb) rounds
     virtual double getPT() const = 0;      // seconds
     virtual double getPS() const = 0;      // KB
+
+    // ---- zero-knowledge mode: two primitives per backend, the protocol on top of them is generic ----
+    // blinded commitments of a host vector laid out in rows of m scalars (zero padded): out[i] = <v_i, g> + blinds[i] H
+    virtual std::vector<G1> commitHostVector(const std::vector<Fr> &, const std::vector<Fr> &) { throw std::runtime_error("commitment backend without zero-knowledge support"); }
+    // w = L^T Z of the committed input, L = eq(x[cb..n)): the vector the opening is about (m scalars)
+    virtual std::vector<Fr> combineRows(const std::vector<Fr> &) { throw std::runtime_error("commitment backend without zero-knowledge support"); }
+    virtual void addProofBytes(size_t) {}
+    size_t zkColumns() const { return zk_m; }
+
+    // proof of dot product for ANY vector `a` committed row-wise with blinds `r` (C_i = Com(a_i; r_i)): shows <a, u> = y
+    dotProofCommit dotCommit(const std::vector<Fr> &u, size_t rows, zkff::PrivateCoins &rnd) {
+        dot_d.resize(rows * zk_m);
+        for (Fr &x : dot_d) x = rnd.next();
+        dot_s.resize(rows);
+        for (Fr &x : dot_s) x = rnd.next();
+        dotProofCommit m1;
+        m1.delta = commitHostVector(dot_d, dot_s);
+        m1.t = Fr(0LL);
+        for (size_t j = 0; j < u.size() && j < dot_d.size(); ++j) m1.t = m1.t + dot_d[j] * u[j];
+        addProofBytes(rows * 48 + 32);
+        return m1;
+    }
+    dotProofResponse dotRespond(const std::vector<Fr> &a, const std::vector<Fr> &r, const Fr &c) {
+        dotProofResponse m2;
+        m2.z = dot_d;
+        for (size_t j = 0; j < a.size() && j < m2.z.size(); ++j) m2.z[j] = m2.z[j] + c * a[j];
+        m2.z_blind = dot_s;
+        for (size_t i = 0; i < r.size() && i < m2.z_blind.size(); ++i) m2.z_blind[i] = m2.z_blind[i] + c * r[i];
+        addProofBytes(32 * (m2.z.size() + m2.z_blind.size()));
+        dot_d.clear(); dot_s.clear();
+        return m2;
+    }
+    // the two prover messages of the INPUT opening in zero-knowledge mode
+    virtual dotProofCommit zkOpenCommit(const std::vector<Fr> &x, const std::vector<Fr> &b) {
+        zkff::PrivateCoins &rnd = zkff::privateCoins();
+        zk_w = combineRows(x);
+        const int n = (int) x.size(), rb = n >> 1, cb = n - rb;
+        std::vector<Fr> Lrow;
+        eqTable(Lrow, x.data() + cb, rb, Fr::one());
+        zk_w_blind = Fr(0LL);
+        for (size_t i = 0; i < Lrow.size() && i < input_blinds.size(); ++i) zk_w_blind = zk_w_blind + Lrow[i] * input_blinds[i];
+        return dotCommit(b, 1, rnd);
+    }
+    virtual dotProofResponse zkOpenRespond(const Fr &c) { return dotRespond(zk_w, std::vector<Fr>(1, zk_w_blind), c); }
+
+protected:
+    size_t zk_m = 0;                       // columns of a commitment row (set by the backend when it is built for zero knowledge)
+    std::vector<Fr> input_blinds;          // blinding factor of every input row
+private:
+    std::vector<Fr> dot_d, dot_s, zk_w;
+    Fr zk_w_blind;
 };
+
+// verifier's side of the proof of dot product: rows C_i, generators in affine form (m + 1 of them, H last)
+inline bool dotVerify(const std::vector<G1> &C, const std::vector<G1Affine> &gA, const std::vector<Fr> &u, const Fr &y, const dotProofCommit &m1,
+                      const Fr &c, const dotProofResponse &m2) {
+    const size_t rows = C.size(), m = gA.size() - 1;
+    if (m1.delta.size() != rows || m2.z.size() != rows * m || m2.z_blind.size() != rows || u.size() > rows * m) return false;
+    std::vector<Fr> sc(m + 1);
+    for (size_t i = 0; i < rows; ++i) {
+        for (size_t j = 0; j < m; ++j) sc[j] = m2.z[i * m + j];
+        sc[m] = m2.z_blind[i];
+        const G1 lhs = zkff::msmCPU(sc.data(), gA.data(), m + 1);
+        if (lhs != C[i] * c + m1.delta[i]) return false;
+    }
+    Fr zu(0LL);
+    for (size_t j = 0; j < u.size(); ++j) zu = zu + m2.z[j] * u[j];
+    return zu == c * y + m1.t;
+}
 
 // hook so a transcript recorder can observe every commitment-phase message in order
 struct transcriptSink {
@@ -192,6 +270,42 @@ public:
         vt.stop();
         return ok;
     }
+    // zero-knowledge opening: gens = (g_0 .. g_{m-1}, H); proof of dot product <w, R> = eval against P = sum_i L_i C_i
+    bool verifyZk(const std::vector<Fr> &x, const Fr &eval) {
+        vt.start();
+        const int n = (int) x.size();
+        const int rb = n >> 1, cb = n - rb;
+        if (((size_t) 1 << cb) + 1 != g.size() || ((size_t) 1 << rb) != comm.size()) { vt.stop(); return false; }
+        std::vector<Fr> Lrow, b;
+        eqTable(Lrow, x.data() + cb, rb, Fr::one());
+        eqTable(b, x.data(), cb, Fr::one());
+        G1 P;
+        if (!drive_only) {
+            std::vector<G1Affine> commA;
+            zkff::batchToAffine(comm, commA);
+            P = zkff::msmCPU(Lrow.data(), commA.data(), commA.size());
+        }
+        vt.stop();
+        dotProofCommit m1 = p.zkOpenCommit(x, b);
+        if (tamper_at == 0) m1.t = m1.t + Fr::one();
+        if (sink_) { for (const G1 &d : m1.delta) sink_->put(d); sink_->put(m1.t); }
+        vt.start();
+        Fr c;
+        c.setByCSPRNG();
+        vt.stop();
+        dotProofResponse m2 = p.zkOpenRespond(c);
+        if (tamper_at == 1) m2.z[m2.z.size() / 2] = m2.z[m2.z.size() / 2] + Fr::one();
+        if (tamper_at == 2) m2.z_blind[0] = m2.z_blind[0] + Fr::one();
+        if (sink_) { for (const Fr &v : m2.z) sink_->put(v); for (const Fr &v : m2.z_blind) sink_->put(v); }
+        if (drive_only) return true;
+        vt.start();
+        std::vector<G1Affine> gA;
+        zkff::batchToAffine(g, gA);
+        const bool ok = dotVerify(std::vector<G1>(1, P), gA, b, eval, m1, c, m2);
+        vt.stop();
+        return ok;
+    }
+    const std::vector<G1> &generators() const { return g; }
     double getVT() const { return vt.elapse_sec(); }
     long tamper_at = -1;       // test hook: corrupt the k-th opening message (round k, or ipaRounds = the final vector)
     bool drive_only = false;   // make the prover calls and draw the challenges, skip the checks (bench mode)
