@@ -31,6 +31,7 @@ def test_reference_callers_typecheck_against_our_prover_header(tmp_path, src):
     host = os.path.join(ROOT, "zkcnn_amd", "csrc", "host")
     os.symlink(os.path.join(host, "prover.hpp"), sdir / "prover.hpp")
     os.symlink(os.path.join(host, "polyProver.hpp"), sdir / "polyProver.hpp")
+    os.symlink(os.path.join(host, "zk_mask.hpp"), sdir / "zk_mask.hpp")        # additive zero-knowledge mixin; compiles against the reference's circuit.h / polynomial.h
     cmd = ["g++", "-std=c++14", "-fsyntax-only", "-I", str(sdir), "-I", os.path.join(ROOT, "zkcnn_amd", "csrc"), str(sdir / src)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
