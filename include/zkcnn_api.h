@@ -27,7 +27,8 @@ typedef struct {
 #define ZKCNN_MODE_REUSE_GENS  2u  /* public commitment generators (hash-to-curve, nobody knows a discrete log) instead of fresh random multiples of G */
 #define ZKCNN_MODE_TAMPER      4u  /* test hook: the verifier corrupts message number ((mode >> 8) & 0xffff) before checking it; flags continue at bit 24 */
 #define ZKCNN_MODE_HOST_PRED   8u  /* verifier's wiring predicates on the host (reference src/verifier.cpp:89-116) instead of the GPU */
-#define ZKCNN_MODE_FIAT_SHAMIR 32u /* non-interactive: challenges are SHA-256 of the statement and of every message so far (the seed is ignored);
+#define ZKCNN_MODE_FIAT_SHAMIR 32u /* non-interactive: challenges are a BLAKE2s chain over the statement and every message so far (the seed is ignored); the GPU
+                                     runs the small rounds of each phase by itself (ZKCNN_MODE_HOST_ROUNDS keeps every round on the host <-> GPU path);
                                      always on the public hash-to-curve generators, whose digest is part of the hashed statement */
 #define ZKCNN_MODE_SEEDED      64u /* reproducible run for parity tests / benches: challenges (and, without REUSE_GENS, generator scalars) come from a
                                      xoshiro stream seeded with challenge_seed. NOT secure -- every challenge is predictable from the seed.
@@ -35,6 +36,9 @@ typedef struct {
                                      known challenge stream is a debugging aid, never evidence that a statement is true */
 #define ZKCNN_MODE_FULL_IPA  128u  /* inner-product argument down to length 1 (log2(m) rounds) instead of sending the last 256 scalars in the clear */
 #define ZKCNN_MODE_ZK  (1u << 24)  /* zero-knowledge masking: blinded commitments, masked round polynomials, proofs of dot product */
+#define ZKCNN_MODE_HOST_ROUNDS (1u << 25)  /* Fiat-Shamir with every round driven from the host (A/B and parity of the device-side rounds) */
+#define ZKCNN_MODE_HOST_TAIL (1u << 26)    /* hybrid tail (off by default): once a phase's tables have <= 64 entries they travel to the host and its last
+                                            ~6 rounds run there (a few hundred host multiplications instead of six latency-bound launches) */
 #define ZKCNN_MODE_CROSS_PRED 16u  /* both, and the verifier rejects if they differ (parity check of zk_verifier_*) */
 
 typedef struct {
@@ -80,6 +84,9 @@ void *zkcnn_verifier_create(const zkcnn_model_desc *desc, const int32_t *scales,
 void zkcnn_session_destroy(void *session);
 /* The reference CLI's 16-column result row of the last prove call ("a, b, c, ..."), NUL terminated. */
 int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap);
+
+/* Product library only: sumcheck rounds / phases the GPU has run by itself in Fiat-Shamir mode so far (include/zkcnn_hip.h: zk_fs_attach) */
+int32_t zkcnn_session_fs_stats(void *session, uint64_t *rounds, uint64_t *phases);
 
 /* Product library only: HIP-event profiler of the GPU kernels (see zk_profile_enable / zk_profile_report in zkcnn_hip.h). */
 int32_t zkcnn_session_profile(void *session, uint32_t class_mask);

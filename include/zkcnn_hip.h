@@ -100,6 +100,20 @@ int32_t zk_witness_ntt(zk_ctx *ctx, uint64_t *dst, const uint64_t *src, int32_t 
 int32_t zk_witness_dotprod(zk_ctx *ctx, uint64_t *out, uint64_t n_out, const uint64_t *F, uint64_t n_in, const zk_bin_gate *gates,
                            uint64_t n_gates, int32_t fft_bl);
 
+/* ---- non-interactive mode: device-side Fiat-Shamir rounds (replaces the verifier <-> prover round trips of reference
+ * src/verifier.cpp:169-194,214-229,294-302 once a phase's tables are small). `state` points at the 8 words of the host's BLAKE2s
+ * challenge chain (host/replay.hpp: fiatShamir), `pending` at its count of message bytes not yet hashed; both must stay valid until
+ * zk_fs_attach(ctx, NULL, NULL). While attached, zk_sumcheck_update1/2 and zk_sumcheck_liu_update run all remaining rounds of a phase in
+ * one kernel as soon as the live tables have at most 2^12 entries, answer the following calls from that record and fail with
+ * ZK_ERR_STATE if a challenge passed in differs from the one the kernel derived. ---- */
+int32_t zk_fs_attach(zk_ctx *ctx, const uint32_t *state, const uint64_t *pending);
+/* Hybrid tail (optional, off by default): tables of at most 2^log_entries entries (log_entries <= 8) are copied to the host when a phase
+ * reaches them and its last rounds run there -- O(2^log_entries) host multiplications per round instead of a latency-bound launch and
+ * hand-over. Same field elements either way. log_entries < 0 switches it off. */
+int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries);
+/* rounds / phases served by the tail kernel since the context was created (tests, bench) */
+int32_t zk_fs_stats(zk_ctx *ctx, uint64_t *rounds, uint64_t *phases);
+
 /* ---- zero-knowledge mode of the commitment (no reference counterpart: reference README.md:5 "not fully
  * zero-knowledge"): the generator set has one more entry H = gens[n_gens - 1] and every commitment is blinded, Com(v; s) = <v, g> + s H -- */
 /* zk_commit_input with n_gens = 2^cb + 1 generators and one blinding factor per row: out_comm[i] = <row_i, g> + blinds[i] H */

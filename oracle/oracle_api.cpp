@@ -2,6 +2,7 @@
 // C entry points of liboracle.so: the whole-proof driver of include/zkcnn_api.h backed by the CPU
 // restatement, plus array-level reference functions the kernel parity tests compare against.
 #include "../zkcnn_amd/csrc/ff/sha256.hpp"
+#include "../zkcnn_amd/csrc/ff/blake2s.hpp"
 #include "ref_prover.hpp"
 #include "session.hpp"
 
@@ -44,6 +45,17 @@ int32_t oracle_session_row(void *session, char *buf, uint64_t cap) {
     std::snprintf(buf, cap, "%s", r.c_str());
     return 0;
 }
+
+// BLAKE2s-256 of `data` fed in two pieces (split point `split`), and the word-level chain step the GPU kernel uses
+void oracle_blake2s(uint8_t out[32], const uint8_t *data, uint64_t n, uint64_t split) {
+    zkff::Blake2s h;
+    h.init();
+    if (split > n) split = n;
+    h.update(data, split);
+    h.update(data + split, n - split);
+    h.final(out);
+}
+void oracle_blake2s_chain(uint32_t state[8], const uint32_t *msg, int32_t n_words) { zkff::blake2s_chain_words(state, msg, n_words); }
 
 // public commitment generators (ff/hash_to_curve.hpp): affine points in the C-ABI layout + the digest a transcript absorbs
 void oracle_public_generators(uint64_t *out, uint8_t digest[32], uint64_t n) {

@@ -130,6 +130,19 @@ class Oracle:
         self.lib.oracle_sha256(out, buf, ctypes.c_uint64(len(data)), ctypes.c_uint64(split))
         return bytes(out)
 
+    def blake2s(self, data, split=0):
+        out = (ctypes.c_uint8 * 32)()
+        buf = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+        self.lib.oracle_blake2s(out, buf, ctypes.c_uint64(len(data)), ctypes.c_uint64(split))
+        return bytes(out)
+
+    def blake2s_chain(self, state, msg):
+        """state' = BLAKE2s(state || msg) on 32-bit words (the GPU kernel's form of the Fiat-Shamir chain step)"""
+        st = (ctypes.c_uint32 * 8)(*state)
+        m = (ctypes.c_uint32 * max(len(msg), 1))(*msg)
+        self.lib.oracle_blake2s_chain(st, m, ctypes.c_int32(len(msg)))
+        return list(st)
+
     def fp_to_canonical(self, a):
         a = np.ascontiguousarray(a.reshape(-1, 6))
         out = np.zeros_like(a)

@@ -22,6 +22,21 @@ def test_sha256_matches_hashlib(oracle):
     assert oracle.sha256(b"abc").hex() == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad"
 
 
+def test_blake2s_matches_hashlib_and_the_word_chain(oracle):
+    """the Fiat-Shamir hash (ff/blake2s.hpp, RFC 7693) against hashlib.blake2s, and the word-level chain step the GPU uses against the same"""
+    import struct
+    rng = np.random.default_rng(2)
+    for n in [0, 1, 3, 32, 63, 64, 65, 127, 128, 129, 200, 1000, 4097]:
+        data = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        for split in (0, 1, 64, n // 2):
+            assert oracle.blake2s(data, split) == hashlib.blake2s(data).digest(), (n, split)
+    for n_words in (0, 8, 24):              # empty retry step, one claim, a quadratic round polynomial (exactly two compressions)
+        state = [int(x) for x in rng.integers(0, 1 << 32, size=8)]
+        msg = [int(x) for x in rng.integers(0, 1 << 32, size=n_words)]
+        want = hashlib.blake2s(struct.pack("<8I", *state) + struct.pack(f"<{n_words}I", *msg)).digest()
+        assert struct.pack("<8I", *oracle.blake2s_chain(state, msg)) == want
+
+
 def test_g1_compression_round_trip_and_rejections(oracle):
     base = oracle.g1_base()
     ks = oracle.random(6, 99)

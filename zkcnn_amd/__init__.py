@@ -20,6 +20,8 @@ P_MOD = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabff
 
 MODE_VERIFY, MODE_DRIVE_ONLY, MODE_REUSE_GENS, MODE_TAMPER, MODE_HOST_PRED, MODE_CROSS_PRED, MODE_FIAT_SHAMIR, MODE_SEEDED, MODE_FULL_IPA = 0, 1, 2, 4, 8, 16, 32, 64, 128
 MODE_ZK = 1 << 24
+MODE_HOST_ROUNDS = 1 << 25
+MODE_HOST_TAIL = 1 << 26
 
 
 class ModelDesc(ctypes.Structure):
@@ -343,6 +345,13 @@ class Session(_SessionBase):
         rc = self.lib.zkcnn_session_profile(ctypes.c_void_p(self.h), ctypes.c_uint32(mask))
         if rc != 0:
             raise RuntimeError("zkcnn_session_profile failed")
+
+    def fs_stats(self):
+        """(rounds, phases) the GPU has run by itself in Fiat-Shamir mode on this session so far"""
+        r, p = ctypes.c_uint64(), ctypes.c_uint64()
+        if self.lib.zkcnn_session_fs_stats(ctypes.c_void_p(self.h), ctypes.byref(r), ctypes.byref(p)) != 0:
+            raise RuntimeError("zkcnn_session_fs_stats failed")
+        return r.value, p.value
 
     def profile_report(self, reset=True):
         import json

@@ -79,6 +79,9 @@ struct Xoshiro {
 struct ChallengeSource {
     virtual ~ChallengeSource() {}
     virtual void words(uint64_t out[4]) = 0;     // 256 fresh pseudo-random bits
+    // true: an accepted draw (< r after clearing bit 255) IS the element's Montgomery representation -- no conversion product, which the
+    // GPU side of the Fiat-Shamir chain would otherwise pay on its critical path; uniform either way (x -> x R^-1 is a bijection)
+    virtual bool rawMontgomery() const { return false; }
 };
 inline ChallengeSource *&challengeOverride() {
     static thread_local ChallengeSource *src = nullptr;
@@ -162,7 +165,8 @@ public:
             else osRandom().words(t);
             t[3] &= 0x7fffffffffffffffULL;
             if (!Base::geMod(t)) {
-                *this = Fr(Base::fromCanonical(t));
+                if (src && src->rawMontgomery()) std::memcpy(static_cast<void *>(this), t, 32);
+                else *this = Fr(Base::fromCanonical(t));
                 return;
             }
         }

@@ -104,6 +104,22 @@ struct zk_ctx {
     bool circuit_ready = false;
 
     msm_state *msm = nullptr;
+
+    // device-side Fiat-Shamir rounds (fs_tail.cuh): the host's chain state (8 words) and its count of not yet hashed message bytes, attached by the
+    // non-interactive driver; the record of the phase the tail kernel has run ahead
+    const uint32_t *fs_state = nullptr;
+    const uint64_t *fs_pending = nullptr;
+    void *h_tail = nullptr, *d_tail = nullptr;     // tail_out, pinned + mapped
+    bool tail_active = false;
+    int tail_count = 0, tail_cursor = 0, phase_rounds = 0;
+    unsigned long long tail_seq = 0;
+    uint64_t tail_rounds_total = 0, tail_phases_total = 0;
+    // hybrid tail (zk_set_host_tail): once the live tables of a phase have at most 2^host_tail_log entries they travel to the host (a few KB)
+    // and the remaining rounds -- a few hundred multiplications each -- run there; -1 = off (every round is a kernel)
+    int host_tail_log = -1;
+    bool host_tail_active = false;
+    std::vector<HFr> ht_V[2], ht_M[2];
+    uint64_t host_tail_rounds_total = 0;
     // ZKCNN_TIMING: host view of a round call: time between calls (verifier + wrappers), before / in / after the wait for the result
     double t_seg[4] = {0, 0, 0, 0}; uint64_t n_seg = 0; double t_last_exit = 0;
 

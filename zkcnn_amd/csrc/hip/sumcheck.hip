@@ -7,6 +7,7 @@
 #include <cstring>
 #include "ctx.hpp"
 #include "kernels.cuh"
+#include "fs_tail.cuh"
 
 static std::string g_create_err;
 
@@ -76,12 +77,15 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
         hipHostMalloc((void **) &ctx->h_slot, sizeof(*ctx->h_slot), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer(&ctx->d_slot, ctx->h_slot, 0) != hipSuccess ||
         hipMemsetAsync(ctx->d_counter, 0, 64, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
-        hipHostMalloc((void **) &ctx->h_result, 32 * 32) != hipSuccess) {
+        hipHostMalloc((void **) &ctx->h_result, 32 * 32) != hipSuccess ||
+        hipHostMalloc((void **) &ctx->h_tail, std::max(sizeof(tail_out), sizeof(export_out)), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&ctx->d_tail, ctx->h_tail, 0) != hipSuccess) {
         g_create_err = ctx->err.empty() ? "allocation failed" : ctx->err;
         zk_ctx_destroy(ctx);
         return ZK_ERR_NOMEM;
     }
     std::memset((void *) ctx->h_slot, 0, sizeof(*ctx->h_slot));
+    std::memset(ctx->h_tail, 0, std::max(sizeof(tail_out), sizeof(export_out)));
     {
         const int light = getenv("ZKCNN_FINISH_LIGHT") ? atoi(getenv("ZKCNN_FINISH_LIGHT")) : 1;
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_finish_light), &light, sizeof(int)) != hipSuccess) {
@@ -109,6 +113,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     for (dev_buf &b : ctx->w_stage) if (b.p) hipFree(b.p);
     if (ctx->h_result) hipHostFree(ctx->h_result);
     if (ctx->h_slot) hipHostFree((void *) ctx->h_slot);
+    if (ctx->h_tail) hipHostFree(ctx->h_tail);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -145,6 +150,26 @@ extern "C" int32_t zk_profile_report(zk_ctx *ctx, char *buf, uint64_t cap, int32
     std::snprintf(buf, cap, "%s", js.c_str());
     if (reset)
         for (int c = 0; c < PC_COUNT; ++c) { ctx->prof_ms[c] = 0; ctx->prof_bytes[c] = 0; ctx->prof_cnt[c] = 0; }
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_fs_attach(zk_ctx *ctx, const uint32_t *state, const uint64_t *pending) {
+    if (!ctx || ((state == nullptr) != (pending == nullptr))) return ZK_ERR_ARG;
+    ctx->fs_state = state;
+    ctx->fs_pending = pending;
+    ctx->tail_active = false;
+    ctx->host_tail_active = false;
+    return ZK_OK;
+}
+extern "C" int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries) {
+    if (!ctx || log_entries > 8) return ZK_ERR_ARG;
+    ctx->host_tail_log = log_entries < 0 ? -1 : log_entries;
+    return ZK_OK;
+}
+extern "C" int32_t zk_fs_stats(zk_ctx *ctx, uint64_t *rounds, uint64_t *phases) {
+    if (!ctx || !rounds || !phases) return ZK_ERR_ARG;
+    *rounds = ctx->tail_rounds_total;
+    *phases = ctx->tail_phases_total;
     return ZK_OK;
 }
 
@@ -655,6 +680,9 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
     int32_t rc;
     reset_pairs(ctx, d.bit_length_u[0], d.bit_length_u[1]);
     ctx->r_u[id].assign(std::max<int>(d.max_bl_u, 0), HFr(0LL));
+    ctx->phase_rounds = std::max<int>(d.max_bl_u, 0);
+    ctx->tail_active = false;
+    ctx->host_tail_active = false;
     ctx->relu_rou = H(relu_rou);
     ctx->add_term.clear();
     ctx->round = 0;
@@ -715,6 +743,9 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
     const int fft_bl = d.fft_bit_length;
     reset_pairs(ctx, d.bit_length_u[1], d.bit_length_u[1]);       // V0 and V1 both span the whole FFT layer
     ctx->r_u[id].assign(d.max_bl_u, HFr(0LL));
+    ctx->phase_rounds = 0;                  // cubic rounds are always driven from the host
+    ctx->tail_active = false;
+    ctx->host_tail_active = false;
     ctx->round = 0;
     ctx->small_len = 1u << fft_bl;
     ctx->small_cur = 0;
@@ -803,6 +834,9 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
     int32_t rc;
     reset_pairs(ctx, d.bit_length_v[0], d.bit_length_v[1]);
     ctx->r_v[id].assign(std::max<int>(d.max_bl_v, 0), HFr(0LL));
+    ctx->phase_rounds = std::max<int>(d.max_bl_v, 0);
+    ctx->tail_active = false;
+    ctx->host_tail_active = false;
     ctx->add_term.clear();
     ctx->round = 0;
     const HFr *ru = ctx->r_u[id].data();
@@ -850,8 +884,177 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
 
 // One quadratic round over the live table pairs. reference src/prover.cpp:368-426.
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// Non-interactive mode: all remaining rounds of the phase in one single-workgroup kernel (fs_tail.cuh). Called at the start of a round
+// whose live tables are small; fills the context's tail record and leaves every table pair either collapsed or down to its last pair.
+static int32_t run_tail(zk_ctx *ctx, const HFr &r, bool with_add_term) {
+    tail_args A;
+    std::memset(&A, 0, sizeof(A));
+    const bool first = ctx->round == 0;
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        if (!t.len) continue;
+        A.Vin[b] = vin(t); A.Min[b] = t.M[t.cur];
+        A.Vbuf[b][0] = t.V[0]; A.Vbuf[b][1] = t.V[1];
+        A.Mbuf[b][0] = t.M[0]; A.Mbuf[b][1] = t.M[1];
+        A.out_idx[b] = t.cur ^ 1;
+        A.n[b] = t.len;
+    }
+    A.first = first ? 1 : 0;
+    A.rounds = ctx->phase_rounds - ctx->round;
+    A.with_add_term = with_add_term ? 1 : 0;
+    A.prev_r = to_dev(r);
+    A.add_term = to_dev(ctx->add_term);
+    std::memcpy(A.fs_state, ctx->fs_state, 32);
+    A.out = (tail_out *) ctx->d_tail;
+    A.seq = ++ctx->tail_seq;
+    ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_fs_tail, dim3(1), dim3(FS_TAIL_THREADS), A);
+    ZK_HIP(hipGetLastError());
+    volatile unsigned long long *p = &((tail_out *) ctx->h_tail)->seq;
+    for (uint64_t spins = 0; *p != A.seq; ++spins) {
+        if (spins > (1ull << 24)) {
+            ZK_HIP(hipStreamSynchronize(ctx->stream));
+            if (*p != A.seq) { ctx->err = "tail rounds were not published"; return ZK_ERR_STATE; }
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const tail_out *o = (const tail_out *) ctx->h_tail;
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        if (!t.len) continue;
+        t.Vsrc = nullptr;
+        if (o->pair_state[b] == 1) {
+            t.len = 2;
+            std::memcpy(&t.tail_v[0], &o->tail_v[b][0], 32);
+            std::memcpy(&t.tail_v[1], &o->tail_v[b][1], 32);
+            t.tail_valid = true;
+        } else {
+            t.len = 0;
+            t.absorbed = true;
+            std::memcpy(&t.final_v, &o->final_v[b], 32);
+        }
+    }
+    std::memcpy(&ctx->add_term, &o->add_term, 32);
+    ctx->tail_active = true;
+    ctx->tail_count = A.rounds;
+    ctx->tail_cursor = 0;
+    ctx->tail_rounds_total += (uint64_t) A.rounds;
+    ++ctx->tail_phases_total;
+    return ZK_OK;
+}
+
+// Hybrid tail: the (small) live tables come to the host ...
+static int32_t host_tail_begin(zk_ctx *ctx) {
+    export_args A;
+    std::memset(&A, 0, sizeof(A));
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        A.V[b] = t.len ? vin(t) : nullptr;
+        A.M[b] = t.len ? t.M[t.cur] : nullptr;
+        A.n[b] = (uint32_t) t.len;
+    }
+    A.out = (export_out *) ctx->d_tail;
+    A.seq = ++ctx->tail_seq;
+    ZK_LAUNCH(PC_FOLD, 0.0, k_export_tables, dim3(1), dim3(512), A);
+    ZK_HIP(hipGetLastError());
+    const export_out *o = (const export_out *) ctx->h_tail;
+    volatile const unsigned long long *p = &o->seq;
+    for (uint64_t spins = 0; *p != A.seq; ++spins) {
+        if (spins > (1ull << 24)) {
+            ZK_HIP(hipStreamSynchronize(ctx->stream));
+            if (*p != A.seq) { ctx->err = "tables were not published"; return ZK_ERR_STATE; }
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int b = 0; b < 2; ++b) {
+        const uint64_t n = ctx->tp[b].len;
+        ctx->ht_V[b].resize(n);
+        ctx->ht_M[b].resize(n);
+        if (n) {
+            std::memcpy(ctx->ht_V[b].data(), o->V[b], n * 32);
+            std::memcpy(ctx->ht_M[b].data(), o->M[b], n * 32);
+        }
+    }
+    ctx->host_tail_active = true;
+    return ZK_OK;
+}
+// ... and one round there: the arithmetic of reference src/prover.cpp:368-426 on plain folded tables (what the round kernels compute)
+static void host_tail_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]) {
+    const bool first = ctx->round == 0;
+    ++ctx->round;
+    if (with_add_term) ctx->add_term = ctx->add_term * (HFr::one() - r);
+    HFr a(0LL), c(0LL), p1(0LL);
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        if (!t.len) continue;
+        std::vector<HFr> &V = ctx->ht_V[b], &M = ctx->ht_M[b];
+        if (!first) {
+            for (uint64_t j = 0; j < t.len / 2; ++j) {
+                V[j] = V[2 * j] + r * (V[2 * j + 1] - V[2 * j]);
+                M[j] = M[2 * j] + r * (M[2 * j + 1] - M[2 * j]);
+            }
+            t.len >>= 1;
+            t.Vsrc = nullptr;
+        }
+        if (t.len == 1) {                                   // the reference's `total == 1` case (prover.cpp:400-404)
+            t.final_v = V[0];
+            ctx->add_term = ctx->add_term + V[0] * M[0];
+            t.absorbed = true;
+            t.len = 0;
+            continue;
+        }
+        for (uint64_t j = 0; j < t.len / 2; ++j) {
+            const HFr &v0 = V[2 * j], &v1 = V[2 * j + 1], &m0 = M[2 * j], &m1 = M[2 * j + 1];
+            a = a + (v1 - v0) * (m1 - m0);
+            c = c + v0 * m0;
+            p1 = p1 + v1 * m1;
+        }
+        if (t.len == 2) { t.tail_v[0] = V[0]; t.tail_v[1] = V[1]; t.tail_valid = true; }
+    }
+    HFr bcoef = p1 - a - c;
+    if (with_add_term) { bcoef = bcoef - ctx->add_term; c = c + ctx->add_term; }
+    put(out_abc, a);
+    put(out_abc + 4, bcoef);
+    put(out_abc + 8, c);
+    ctx->proof_size += 32 * 3;
+    ++ctx->host_tail_rounds_total;
+}
+
 static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]) {
     static const bool seg_timing = getenv("ZKCNN_TIMING") != nullptr;
+    if (ctx->host_tail_log >= 0 && !ctx->host_tail_active && !ctx->tail_active && ctx->phase_rounds > ctx->round &&
+        std::max(ctx->tp[0].len, ctx->tp[1].len) <= (1ull << ctx->host_tail_log) && ctx->tp[0].len + ctx->tp[1].len > 0) {
+        int32_t rc = host_tail_begin(ctx);
+        if (rc) return rc;
+    }
+    if (ctx->host_tail_active) {
+        host_tail_round(ctx, r, with_add_term, out_abc);
+        return ZK_OK;
+    }
+    static const uint64_t tail_quads = getenv("ZKCNN_TAIL_QUADS") ? std::min<uint64_t>(FS_TAIL_QUADS, (uint64_t) atoll(getenv("ZKCNN_TAIL_QUADS"))) : FS_TAIL_QUADS;
+    // quads of this round over both pairs (a first round works on pairs, not quads): small enough for one thread each?
+    const uint64_t round_quads = ctx->round == 0 ? (ctx->tp[0].len + ctx->tp[1].len) / 2 : (ctx->tp[0].len + ctx->tp[1].len) / 4;
+    if (ctx->fs_state && !ctx->tail_active && ctx->phase_rounds > ctx->round && *ctx->fs_pending == 0 && round_quads <= tail_quads &&
+        ctx->tp[0].len + ctx->tp[1].len > 0) {
+        int32_t rc = run_tail(ctx, r, with_add_term);
+        if (rc) return rc;
+    }
+    if (ctx->tail_active) {
+        const tail_out *o = (const tail_out *) ctx->h_tail;
+        const int k = ctx->tail_cursor;
+        if (k > 0 && std::memcmp(&r, &o->chal[k - 1], 32) != 0) {
+            ctx->err = "Fiat-Shamir chain diverged: the verifier's challenge is not the one derived on the device";
+            return ZK_ERR_STATE;
+        }
+        std::memcpy(out_abc, &o->poly[k][0], 96);
+        ++ctx->round;
+        ctx->proof_size += 32 * 3;
+        if (++ctx->tail_cursor == ctx->tail_count) ctx->tail_active = false;
+        return ZK_OK;
+    }
     const double ts_enter = seg_timing ? now_s() : 0;
     double ts_wait0 = 0, ts_wait1 = 0;
     const bool first = ctx->round == 0;
@@ -1024,6 +1227,9 @@ extern "C" int32_t zk_sumcheck_liu_init(zk_ctx *ctx, const uint64_t *s_u, const 
     const dev_layer &L0 = ctx->L[0];
     reset_pairs(ctx, -1, L0.d.bit_length);
     ctx->r_u[0].assign(L0.d.bit_length, HFr(0LL));
+    ctx->phase_rounds = L0.d.bit_length;
+    ctx->tail_active = false;
+    ctx->host_tail_active = false;
     ctx->add_term.clear();
     ctx->round = 0;
     table_pair &t = ctx->tp[1];

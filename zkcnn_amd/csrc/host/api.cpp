@@ -152,6 +152,12 @@ int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap) {
     return 0;
 }
 
+int32_t zkcnn_session_fs_stats(void *session, uint64_t *rounds, uint64_t *phases) {
+    if (!session || !rounds || !phases) return -1;
+    ((gpuSession *) session)->p.tailStats(*rounds, *phases);
+    return 0;
+}
+
 int32_t zkcnn_session_profile(void *session, uint32_t class_mask) {
     if (!session) return -1;
     return zk_profile_enable(((gpuSession *) session)->p.context(), class_mask);

@@ -48,6 +48,18 @@ void prover::check(int rc, const char *what) const {
     if (rc != ZK_OK) throw std::runtime_error(string(what) + " failed: " + zk_last_error(ctx));
 }
 
+void prover::attachFiatShamir(const uint32_t *state, const uint64_t *pending) {
+    if (!ctx) return;
+    check(zk_fs_attach(ctx, state, pending), "zk_fs_attach");
+}
+void prover::setHostTail(int log_entries) {
+    if (ctx) check(zk_set_host_tail(ctx, log_entries), "zk_set_host_tail");
+}
+void prover::tailStats(uint64_t &rounds, uint64_t &phases) const {
+    rounds = phases = 0;
+    if (ctx) zk_fs_stats(ctx, &rounds, &phases);
+}
+
 void prover::ensureContext() {
     if (ctx) return;
     int rc = zk_ctx_create(device_id, &ctx);

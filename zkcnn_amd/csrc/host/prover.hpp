@@ -66,6 +66,11 @@ public:
     zk_ctx *context() const { return ctx; }     // for the profiler entry points of include/zkcnn_hip.h
 
     void ensureContext();                       // creates the GPU context (and its stream) without uploading anything
+    // non-interactive mode: the verifier's challenge chain (8 state words, count of unhashed bytes); the GPU then runs the small rounds of
+    // every phase by itself (include/zkcnn_hip.h: zk_fs_attach). NULL, NULL detaches.
+    void attachFiatShamir(const uint32_t *state, const uint64_t *pending);
+    void tailStats(uint64_t &rounds, uint64_t &phases) const;
+    void setHostTail(int log_entries);          // hybrid tail (include/zkcnn_hip.h: zk_set_host_tail); < 0 = off
 private:
     hyrax_bls12_381::polyProverBase &zkBackend() override { return *poly_p; }
     const layeredCircuit &zkCircuit() const override { return C; }
@@ -79,3 +84,7 @@ private:
     hyrax_bls12_381::polyProver::gensCache gens_cache;      // affine form of the last generator set (re-used generators)
     friend neuralNetwork;
 };
+
+// session.hpp calls this for whatever prover type it drives; only the HIP-backed prover can continue the chain on its own
+inline void attachFsChain(prover &p, const uint32_t *state, const uint64_t *pending) { p.attachFiatShamir(state, pending); }
+inline void setHostTail(prover &p, int log_entries) { p.setHostTail(log_entries); }

@@ -3,20 +3,40 @@
 //   * replayProver: an object with the `prover` interface whose answers are parsed, in order, from a transcript. The unchanged
 //     verifier template runs against it (verifierT<replayProver>), so every check of the interactive protocol is applied to the
 //     bytes; the challenges come from the same seeded stream (interactive mode) or from the transcript itself:
-//   * fiatShamir: a ChallengeSource that hashes everything the verifier has received so far (SHA-256, counter mode), which
+//   * fiatShamir: a ChallengeSource that hashes everything the verifier has received so far (a BLAKE2s chain), which
 //     turns the same protocol into a non-interactive proof. Optional; the interactive path is untouched.
 // The reference has neither (its proof never leaves the process); nothing here is on the hot path.
 #pragma once
 #include <stdexcept>
 #include "../ff/sha256.hpp"
+#include "../ff/blake2s.hpp"
 #include "../../../include/zkcnn_api.h"
 #include "verifier.hpp"
 #include "zk_mask.hpp"
 
 class fiatShamir : public zkff::ChallengeSource, public transcriptTap {
 public:
-    fiatShamir() { absorb("zkcnn-amd/fiat-shamir/v1", 24); }
-    void absorb(const void *data, size_t n) override { st.update(data, n); }
+    // Challenge chain: state (32 bytes) <- BLAKE2s-256(state || everything absorbed since the last challenge), one step per challenge;
+    // a draw that is not below r costs one more step with an empty message. A field element is absorbed as its 32 bytes in memory
+    // (Montgomery limbs: a bijection of the element), a group element as its 48-byte compressed encoding. The state after a round
+    // polynomial's challenge is all the GPU needs to continue the chain by itself (hip/fs_tail.cuh).
+    fiatShamir() {
+        zkff::Blake2s h;
+        h.init();
+        h.update("zkcnn-amd/fiat-shamir/v2", 24);
+        uint8_t d[32];
+        h.final(d);
+        std::memcpy(st, d, 32);
+    }
+    void absorb(const void *data, size_t n) override {
+        const uint8_t *p = static_cast<const uint8_t *>(data);
+        pending.insert(pending.end(), p, p + n);
+        pending_len = pending.size();
+    }
+    void absorbFr(const Fr &x) override { absorb(&x, 32); }
+    bool rawMontgomery() const override { return true; }
+    const uint32_t *stateWords() const { return st; }
+    const uint64_t *pendingBytes() const { return &pending_len; }
     // binds the statement: the whole model descriptor, every quantisation scale (they fix gate exponents, layer sizes and Q_MAX), the
     // shape of every layer and a digest of the wiring (gate lists, subset maps): statements that differ anywhere get unrelated challenges
     void absorbStatement(const zkcnn_model_desc &d, const vector<int> &scales, const layeredCircuit &C) {
@@ -43,21 +63,21 @@ public:
         absorb(C.wiringDigest(), 32);
     }
     void words(uint64_t out[4]) override {
-        zkff::Sha256 c = st;
-        uint8_t tag[12] = {'c', 'h', 'a', 'l'};
-        for (int i = 0; i < 8; ++i) tag[4 + i] = (uint8_t) (ctr >> (8 * i));
-        ++ctr;
-        c.update(tag, sizeof(tag));
+        zkff::Blake2s h;
+        h.init();
+        h.update(st, 32);
+        if (!pending.empty()) h.update(pending.data(), pending.size());
         uint8_t d[32];
-        c.digest(d);
-        for (int i = 0; i < 4; ++i) {
-            out[i] = 0;
-            for (int b = 0; b < 8; ++b) out[i] |= (uint64_t) d[8 * i + b] << (8 * b);
-        }
+        h.final(d);
+        std::memcpy(st, d, 32);
+        pending.clear();
+        pending_len = 0;
+        std::memcpy(out, st, 32);            // little-endian host: words as they lie in the state
     }
 private:
-    zkff::Sha256 st;
-    uint64_t ctr = 0;
+    uint32_t st[8];
+    std::vector<uint8_t> pending;
+    uint64_t pending_len = 0;
 };
 
 // RAII: installs a challenge source for the current thread

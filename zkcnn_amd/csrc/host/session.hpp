@@ -9,6 +9,10 @@
 #include "replay.hpp"
 #include "../ff/hash_to_curve.hpp"
 
+// provers that can continue the Fiat-Shamir chain themselves (the HIP-backed one: prover.hpp) overload this; everybody else ignores it
+template <class P> inline void attachFsChain(P &, const uint32_t *, const uint64_t *) {}
+template <class P> inline void setHostTail(P &, int) {}
+
 template <class ProverT>
 struct sessionT {
     sessionT() {}
@@ -78,6 +82,7 @@ struct sessionT {
         if (mode & ZKCNN_MODE_SEEDED) { Fr::seedCSPRNG(challenge_seed); zkff::privateCoins().seed(challenge_seed); }
         else { Fr::useOsRandom(); zkff::privateCoins().useOsRandom(); }
         v.zk = zk;
+        setHostTail(p, (mode & ZKCNN_MODE_HOST_TAIL) ? 6 : -1);      // hybrid tail: tables of <= 64 entries finish their phase on the host
         const zkff::publicGenerators *pg = nullptr;
         if (public_gens) {
             pg = &zkff::publicGeneratorSet(n_sqrt);
@@ -100,6 +105,9 @@ struct sessionT {
             v.transcript.tap = &fs;
             v.lazy_challenges = true;
             scope.reset(new challengeScope(&fs));
+            // the prover may run the small rounds of every phase ahead of the verifier: the challenges are a function of the transcript.
+            // Not with masked round polynomials (the masks are added on the host) and not when a message is corrupted on purpose.
+            if (!zk && !(mode & (ZKCNN_MODE_TAMPER | ZKCNN_MODE_HOST_ROUNDS))) attachFsChain(p, fs.stateWords(), fs.pendingBytes());
         }
     }
 
@@ -119,7 +127,15 @@ struct sessionT {
         fiatShamir fs;
         std::unique_ptr<challengeScope> scope;
         configure(v, challenge_seed, mode, fs, scope);
-        bool ok = v.verify();
+        bool ok = false;
+        try {
+            ok = v.verify();
+        } catch (...) {
+            attachFsChain(p, nullptr, nullptr);
+            scope.reset();
+            throw;
+        }
+        attachFsChain(p, nullptr, nullptr);
         scope.reset();
         out->accepted = drive ? -1 : (ok ? 1 : 0);
         out->n_layers = p.C.size;

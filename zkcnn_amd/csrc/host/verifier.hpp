@@ -18,6 +18,7 @@
 struct transcriptTap {
     virtual ~transcriptTap() {}
     virtual void absorb(const void *data, size_t n) = 0;
+    virtual void absorbFr(const Fr &x) = 0;        // a field element (the tap decides on its encoding)
 };
 
 struct proofTranscript : public hyrax_bls12_381::transcriptSink {
@@ -27,7 +28,7 @@ struct proofTranscript : public hyrax_bls12_381::transcriptSink {
         size_t o = bytes.size();
         bytes.resize(o + 32);
         x.toBytesLE(&bytes[o]);
-        if (tap) tap->absorb(&bytes[o], 32);
+        if (tap) tap->absorbFr(x);
     }
     void put(const G1 &p) override {
         size_t o = bytes.size();
