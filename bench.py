@@ -337,6 +337,15 @@ def main():
         r, _ = sess.prove(seed=0x5EED0211, mode=drive, want_transcript=False)
         r, _ = sess.prove(seed=0x5EED0212, mode=drive | zkcnn_amd.MODE_FULL_IPA, want_transcript=False)
         extras["prover_ms_session_gens_full_ipa"] = round(1e3 * (r.prove_s + r.poly_prove_s), 3)
+        # other modes of the same prover, single stream, best of 3 (all with the session's public generators)
+        def best(mode):
+            return round(min(1e3 * (x.prove_s + x.poly_prove_s) for x in (sess.prove(seed=0x5EED0300 + k, mode=mode, want_transcript=False)[0] for k in range(3))), 3)
+        extras["prover_ms_hybrid_tail"] = best(drive | zkcnn_amd.MODE_HOST_TAIL)          # tables of <= 64 entries finish their phase on the host
+        fs = zkcnn_amd.MODE_FIAT_SHAMIR | zkcnn_amd.MODE_DRIVE_ONLY
+        extras["prover_ms_fiat_shamir_device_rounds"] = best(fs)                          # non-interactive: small rounds run on the GPU by themselves
+        extras["prover_ms_fiat_shamir_host_rounds"] = best(fs | zkcnn_amd.MODE_HOST_ROUNDS)
+        extras["prover_ms_zero_knowledge"] = best(drive | zkcnn_amd.MODE_ZK)              # blinded commitments, masked rounds, proofs of dot product
+        extras["fs_device_rounds_phases"] = list(sess.fs_stats())
     except Exception as e:          # noqa: BLE001 - the headline does not depend on these
         extras["companions_error"] = str(e)
     sess.close()

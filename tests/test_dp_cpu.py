@@ -9,6 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import zkcnn_amd
 from zkcnn_amd import dp
 
 MODEL, PIC = "custom:C2:3:1:s M F4", (4, 4, 1)
@@ -154,3 +155,61 @@ def test_two_ranks_two_streams_each_all_proofs_verify(oracle):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(got) == [(step, img, 1) for step in range(2) for img in range(4)]
+
+
+def _bench_shape_worker(rank, world, port, q):
+    """bench.py's step loop per rank, shrunk: K sessions on K host threads, a step = K proofs, one packed asynchronous gather per step to rank 0"""
+    import queue
+    import threading
+    from tests import oracle_ffi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    K, steps = 2, 2
+    sessions = [oracle_ffi.OracleSession("custom:F4", (4, 4, 1), 1, data_seed=9000 + rank * K + i) for i in range(K)]
+    g = dp.AsyncGather(dist, "cpu", K << 14)
+    done = [queue.Queue() for _ in range(K)]
+
+    def stream(i):
+        for k in range(steps):
+            done[i].put(sessions[i].prove(seed=100 + k, mode=zkcnn_amd.MODE_REUSE_GENS | zkcnn_amd.MODE_DRIVE_ONLY)[1])
+    th = [threading.Thread(target=stream, args=(i,)) for i in range(K)]
+    dist.barrier()
+    [t.start() for t in th]
+    for k in range(steps):
+        batch = [done[i].get() for i in range(K)]
+        g.submit(rank, dp.pack([(rank * K + i, tr) for i, tr in enumerate(batch)]))
+    [t.join() for t in th]
+    res = g.wait()
+    dist.barrier()
+    if rank == 0:
+        q.put([(step, r, sorted(img for img, _ in dp.unpack(blob))) for step, per_rank in enumerate(res) for r, blob in per_rank])
+    for s in sessions:
+        s.close()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_step_loop_shape(oracle):
+    """the N = 8 launch of bench.py (8 ranks x K streams, a gather per step) on gloo: every rank's K proofs of every step arrive at rank 0"""
+    world = 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_shape_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(got) == [(step, r, [2 * r, 2 * r + 1]) for step in range(2) for r in range(world)]
+
+
+def test_session_count_respects_host_memory():
+    """bench.py lowers the streams per rank to what the host's memory allows (a vgg11 session keeps ~10 GB of circuit + witness on the
+    host): the rule, on made-up numbers -- 8 ranks x 8 streams need ~640 GB"""
+    def k_fit(avail_bytes, world, asked):
+        return max(1, min(asked, int(avail_bytes / (10e9 * max(world, 1)))))
+    assert k_fit(2e12, 8, 8) == 8 and k_fit(512e9, 8, 8) == 6 and k_fit(60e9, 8, 8) == 1 and k_fit(60e9, 1, 8) == 6

@@ -3,6 +3,8 @@
 // the O(1)-per-round scalar bookkeeping (add_term, round counters, proof-size counter) stays in
 // host code here exactly as in the reference, everything that is O(table) or O(gates) is a kernel.
 #include <chrono>
+#include <sched.h>
+#include <time.h>
 #include <algorithm>
 #include <cstring>
 #include "ctx.hpp"
@@ -476,7 +478,11 @@ static int32_t wait_slot(zk_ctx *ctx, unsigned long long seq) {
             if (*p != seq) { ctx->err = "round result was not published"; return ZK_ERR_STATE; }
             break;
         }
-        __builtin_ia32_pause();
+        // a small round answers within ~20 us of spinning; behind a long kernel (a 2^24-entry round, a gate scatter) the thread stops
+        // burning its core: 8 ranks x 8 proving threads share one host, and a yielding waiter costs a late round ~1 us, not the others a core
+        if (spins < 4096) __builtin_ia32_pause();
+        else if (spins < 65536) sched_yield();
+        else { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return ZK_OK;
