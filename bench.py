@@ -50,9 +50,9 @@ WORKLOADS = {
     "vgg11_half": ("vgg:32 M 64 M 128 128 M 256 256 M 256 256 M", (32, 32, 3), 1),
 }
 # HBM bytes per launch of a kernel class from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, separate passes,
-# scripts/pmc_proof.sh): r01g_vgg11_pmc_traffic.md: (5.03 + 1.76 + 69.18 + 23.58) GB over 7976 + 1056 launches of k_round_quad_fine / 2;
-# r01g_vgg11_pp8_pmc_traffic.md likewise. None where no PMC pass exists for the (workload, class).
-PMC_TRAFFIC_PER_LAUNCH = {("vgg11", "round_quad"): 11.02e6, ("vgg11_pp8", "round_quad"): (6.50 + 2.55 + 299.46 + 105.63) * 1e9 / (10000 + 2312)}
+# scripts/pmc_proof.sh): r02q_vgg11_pmc_traffic.md: (5.07 + 1.83 + 81.03 + 28.91) GB over 7976 + 1067 launches of k_round_quad_fine / 2;
+# r01g_vgg11_pp8_pmc_traffic.md likewise. None where no PMC pass exists for the (workload, class). Constants of those passes, not measured in a bench run.
+PMC_TRAFFIC_PER_LAUNCH = {("vgg11", "round_quad"): (5.07 + 1.83 + 81.03 + 28.91) * 1e9 / (7976 + 1067), ("vgg11_pp8", "round_quad"): (6.50 + 2.55 + 299.46 + 105.63) * 1e9 / (10000 + 2312)}
 # kernel classes whose algorithmic byte count is defined; the dominant one is reported
 STREAMING_PMC_BYTES = 1.7037e9      # profiles/r01_round_quad_kernel.md (FETCH_SIZE x2 + WRITE_SIZE) for 2 x 2^24 entries
 ROOFLINE_CLASSES = ["gate_reduce", "round_quad", "round_cubic", "msm_planes"]
@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default=None, choices=sorted(WORKLOADS), help="CPU baseline workload (default: the bench workload itself)")
     ap.add_argument("--cpu-procs", type=int, default=8, help="independent CPU provers run side by side for the host throughput figure (0 = skip)")
+    ap.add_argument("--no-companions", action="store_true", help="skip the extra single-stream measurements of other modes (profiling runs)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel-class table of one extra proof to stderr")
     args = ap.parse_args()
 
@@ -328,6 +329,8 @@ def main():
     # ---- conservative companions of the headline (not timed steps): nothing pre-built, nothing cut ----
     extras = {}
     try:
+        if args.no_companions:
+            raise KeyboardInterrupt
         fresh = []
         for k in range(2):          # new random generators per proof (no REUSE_GENS): tables rebuilt inside the prover's clock; IPA down to length 1
             r, _ = sess.prove(seed=0x5EED0200 + k, mode=zkcnn_amd.MODE_DRIVE_ONLY | zkcnn_amd.MODE_FULL_IPA, want_transcript=False)
@@ -346,6 +349,8 @@ def main():
         extras["prover_ms_fiat_shamir_host_rounds"] = best(fs | zkcnn_amd.MODE_HOST_ROUNDS)
         extras["prover_ms_zero_knowledge"] = best(drive | zkcnn_amd.MODE_ZK)              # blinded commitments, masked rounds, proofs of dot product
         extras["fs_device_rounds_phases"] = list(sess.fs_stats())
+    except KeyboardInterrupt:
+        pass
     except Exception as e:          # noqa: BLE001 - the headline does not depend on these
         extras["companions_error"] = str(e)
     sess.close()

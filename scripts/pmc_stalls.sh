@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/sq -o pmc -- \
-  python $ROOT/bench.py --workload $WL --streams 1 --steps 2 --warmup 2 --no-cpu-baseline > $OUT/sq.log 2>&1 || true
+  python $ROOT/bench.py --workload $WL --streams 1 --steps 2 --warmup 2 --no-cpu-baseline --no-companions > $OUT/sq.log 2>&1 || true
 python3 - <<PY
 import csv, glob, collections
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
