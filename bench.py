@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default=None, choices=sorted(WORKLOADS), help="CPU baseline workload (default: the bench workload itself)")
     ap.add_argument("--cpu-procs", type=int, default=8, help="independent CPU provers run side by side for the host throughput figure (0 = skip)")
+    ap.add_argument("--hybrid-tail", action="store_true", help="timed proofs with ZKCNN_MODE_HOST_TAIL (experiment; not the headline configuration)")
+    ap.add_argument("--fiat-shamir", action="store_true", help="timed proofs non-interactive (device-side rounds; experiment)")
     ap.add_argument("--no-companions", action="store_true", help="skip the extra single-stream measurements of other modes (profiling runs)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel-class table of one extra proof to stderr")
     args = ap.parse_args()
@@ -134,6 +136,10 @@ def main():
     except ImportError:
         pass
     drive = zkcnn_amd.MODE_DRIVE_ONLY | zkcnn_amd.MODE_REUSE_GENS
+    if args.hybrid_tail:
+        drive |= zkcnn_amd.MODE_HOST_TAIL
+    if args.fiat_shamir:
+        drive |= zkcnn_amd.MODE_FIAT_SHAMIR
 
     def in_threads(fn):
         """fn(i) for every stream i on its own host thread (the C calls release the GIL); re-raises the first failure"""
@@ -267,8 +273,8 @@ def main():
         elapsed = float(te.item())
 
     # the timed steps ran drive-only: replay the last proof of every stream through the full verifier (not timed)
-    timed_ok = all(sessions[i].verify(last_proofs[i], seed=0x5EED1000 + args.steps - 1, mode=zkcnn_amd.MODE_REUSE_GENS).accepted == 1
-                   for i in range(K))
+    replay_mode = zkcnn_amd.MODE_REUSE_GENS | (zkcnn_amd.MODE_FIAT_SHAMIR if args.fiat_shamir else 0)
+    timed_ok = all(sessions[i].verify(last_proofs[i], seed=0x5EED1000 + args.steps - 1, mode=replay_mode).accepted == 1 for i in range(K))
     if not timed_ok:
         raise SystemExit("a proof produced inside the timed region does not verify")
 
@@ -393,7 +399,8 @@ def main():
     steps = args.steps
     out = {
         "metric": f"proofs/s (GKR prover, {args.workload} pic_cnt={pp} proofs, {K} in flight per GPU; modes SEEDED|DRIVE_ONLY|REUSE_GENS: public generators "
-                  "with a resident byte table, IPA cut at 256); prover_ms_per_image = single-stream latency; conservative companions alongside",
+                  "with a resident byte table, IPA cut at 256" + ("; EXPERIMENT: hybrid host tail" if args.hybrid_tail else "") + ("; EXPERIMENT: Fiat-Shamir, device-side rounds" if args.fiat_shamir else "") +
+                  "); prover_ms_per_image = single-stream latency; conservative companions alongside",
         "value": round(world * K * steps / elapsed, 4),
         "unit": "proofs/s",
         "n_gpus": world, "steps": steps, "warmup": args.warmup,

@@ -137,6 +137,12 @@ int32_t zk_verifier_predicates(zk_ctx *ctx, int32_t layer, const uint64_t *r_0, 
 int32_t zk_verifier_input_predicate(zk_ctx *ctx, const uint64_t *r_u0, const uint64_t *const *r_u, const uint64_t *const *r_v,
                                     const uint64_t *sig_u, const uint64_t *sig_v, uint32_t n, uint64_t out[4]);
 
+/* The multi-scalar multiplications of the verifier's opening check (reference src/verifier.cpp:360 -> hyrax polyVerifier::verify):
+ * out = sum scalars[i] * bases[i] (affine, C-ABI layout). bases_are_generators != 0: `bases` must be a prefix of the generator set of the
+ * last zk_commit_input* call (ZK_ERR_STATE otherwise) and the resident tables serve it; == 0: arbitrary points (the commitment rows), through a
+ * second, verifier-owned table set. */
+int32_t zk_verifier_msm(zk_ctx *ctx, uint64_t out[12], const uint64_t *scalars, const uint64_t *bases, uint64_t n, int32_t bases_are_generators);
+
 /* ---- witness of a generic layer (reference src/neuralNetwork.cpp:918-935, calcNormalLayer) -------------------------------- */
 /* Layer 0 is built piecewise while the circuit is generated (weights, then the bit / sign / max witnesses of every RELU and pooling
  * layer): the context keeps a device copy; call this with every span the host has written since the last call (no holes:

@@ -101,9 +101,12 @@ struct zk_ctx {
     HFr small_final;               // collapsed periodic table (DOT_PROD)
     uint64_t proof_size = 0;
     int sumcheck_id = 0, round = 0;
+    HFr last_poly[3];              // the quadratic the previous round returned (a, b, c): p(0) + p(1) of this round must equal it at the challenge
+    bool last_poly_valid = false;
     bool circuit_ready = false;
 
     msm_state *msm = nullptr;
+    msm_state *vmsm = nullptr;     // verifier-owned second table set (zk_verifier_msm over arbitrary points)
 
     // device-side Fiat-Shamir rounds (fs_tail.cuh): the host's chain state (8 words) and its count of not yet hashed message bytes, attached by the
     // non-interactive driver; the record of the phase the tail kernel has run ahead

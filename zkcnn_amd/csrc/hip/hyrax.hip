@@ -50,7 +50,13 @@ struct msm_state {
 #define MSM_WIDE_CAP 128u          // rows with wide scalars whose higher windows ride along as virtual rows of the commitment's launches
 #define ZK_RETRY_SAFE 0x5afe       // internal status: repeat the batch with the SAFE kernels
 
+static void msm_destroy_one(zk_ctx *ctx);
 void zk_msm_destroy(zk_ctx *ctx) {
+    msm_destroy_one(ctx);
+    std::swap(ctx->msm, ctx->vmsm);
+    msm_destroy_one(ctx);
+}
+static void msm_destroy_one(zk_ctx *ctx) {
     if (!ctx->msm) return;
     msm_state *s = ctx->msm;
     void *bufs[] = {s->tables, s->partials, s->rowsJ, s->rowsA, s->a, s->b, s->coef, s->Lrow, s->sL, s->idxL, s->d_y, s->tbl_scratch,
@@ -592,6 +598,39 @@ extern "C" int32_t zk_hyrax_open_final(zk_ctx *ctx, uint64_t *a, uint32_t cap, u
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     *n = s->len;
     return ZK_OK;
+}
+
+extern "C" int32_t zk_verifier_msm(zk_ctx *ctx, uint64_t out[12], const uint64_t *scalars, const uint64_t *bases, uint64_t n, int32_t bases_are_generators) {
+    if (!ctx || !n || n > (1u << 20) || !scalars || !bases || !out) return ZK_ERR_ARG;
+    ZK_HIP(hipSetDevice(ctx->device));
+    int32_t rc;
+    if (bases_are_generators) {
+        msm_state *s = ctx->msm;
+        if (!s || !s->tables || n > s->m || std::memcmp(s->gens_host.data(), bases, n * 96) != 0) { ctx->err = "verifier MSM: these are not the cached generators"; return ZK_ERR_STATE; }
+        ++s->gens_hits;
+        if ((rc = zk_scratch(ctx, n * 32))) return rc;
+        ZK_HIP(hipMemcpyAsync(ctx->scratch.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+        return with_safe_retry(ctx, [&]() -> int32_t {
+            int32_t r = run_msm(ctx, (const fr_t *) ctx->scratch.p, n, nullptr, 1, (uint32_t) n);
+            return r ? r : fetch_points(ctx, 1, out);
+        });
+    }
+    std::swap(ctx->msm, ctx->vmsm);                     // the verifier's own tables: the prover's cached generator set is left alone
+    rc = ensure_state(ctx);
+    if (!rc) ctx->msm->full_failed = true;              // never a 3 GB byte table for points that change with every proof
+    if (!rc) rc = ensure_tables(ctx, bases, n);
+    if (!rc) rc = zk_scratch(ctx, n * 32);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(ctx->scratch.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { ctx->err = hipGetErrorString(e); rc = ZK_ERR_HIP; }
+    }
+    if (!rc)
+        rc = with_safe_retry(ctx, [&]() -> int32_t {
+            int32_t r = run_msm(ctx, (const fr_t *) ctx->scratch.p, n, nullptr, 1, (uint32_t) n);
+            return r ? r : fetch_points(ctx, 1, out);
+        });
+    std::swap(ctx->msm, ctx->vmsm);
+    return rc;
 }
 
 // stand-alone MSM over arbitrary bases (kernel-level parity tests)

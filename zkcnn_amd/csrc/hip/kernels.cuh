@@ -522,6 +522,7 @@ struct round2_args {
     fr_t r;
     int32_t first;
     int32_t fine;               // small tables: 4 lanes per quad so that the dependent chain is 2 multiplications, not 7
+    int32_t skip_p1;            // the caller derives p(1) from the running claim (p(0) + p(1) = claim): one product per pair less
     fr_t *partials;
     uint32_t *counter;
     host_slot *slot;
@@ -578,7 +579,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad2(round2_args a) {
                 fr_store(Mout + 2 * q + 1, m1);
                 acc[0] = fr_add(acc[0], fr_mul(fr_sub(v1, v0), fr_sub(m1, m0)));
                 acc[1] = fr_add(acc[1], fr_mul(v0, m0));
-                acc[2] = fr_add(acc[2], fr_mul(v1, m1));
+                if (!a.skip_p1) acc[2] = fr_add(acc[2], fr_mul(v1, m1));          // wave-uniform: 6 products per quad instead of 7
             }
         }
     }
@@ -657,7 +658,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad_fine(round2_args a) {
         // role 0: X = v0, y1 = m0;  role 1: X = v1, y1 = m1;  role 2: X = m0, y1 = v0, y2 = m1, y3 = v1
         opA = role == 2 ? fr_sub(y3, y1) : X;
         opB = role == 2 ? fr_sub(y2, X) : y1;
-        if (role == 3 || !live || special) { opA = fr_zero(); opB = fr_zero(); }
+        if (role == 3 || !live || special || (role == 1 && a.skip_p1)) { opA = fr_zero(); opB = fr_zero(); }
     }
     fr_t prod = fr_mul(opA, opB);
 #pragma unroll

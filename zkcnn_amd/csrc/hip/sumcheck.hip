@@ -161,6 +161,7 @@ extern "C" int32_t zk_fs_attach(zk_ctx *ctx, const uint32_t *state, const uint64
     ctx->fs_pending = pending;
     ctx->tail_active = false;
     ctx->host_tail_active = false;
+    ctx->last_poly_valid = false;
     return ZK_OK;
 }
 extern "C" int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries) {
@@ -689,6 +690,7 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
     ctx->phase_rounds = std::max<int>(d.max_bl_u, 0);
     ctx->tail_active = false;
     ctx->host_tail_active = false;
+    ctx->last_poly_valid = false;
     ctx->relu_rou = H(relu_rou);
     ctx->add_term.clear();
     ctx->round = 0;
@@ -752,6 +754,7 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
     ctx->phase_rounds = 0;                  // cubic rounds are always driven from the host
     ctx->tail_active = false;
     ctx->host_tail_active = false;
+    ctx->last_poly_valid = false;
     ctx->round = 0;
     ctx->small_len = 1u << fft_bl;
     ctx->small_cur = 0;
@@ -843,6 +846,7 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
     ctx->phase_rounds = std::max<int>(d.max_bl_v, 0);
     ctx->tail_active = false;
     ctx->host_tail_active = false;
+    ctx->last_poly_valid = false;
     ctx->add_term.clear();
     ctx->round = 0;
     const HFr *ru = ctx->r_u[id].data();
@@ -1070,6 +1074,12 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
     round2_args A;
     std::memset(&A, 0, sizeof(A));
     double alg_bytes = 0;
+    // From the second round of a phase on, the claim this round's polynomial must meet is known: p(0) + p(1) = p_prev(r). The kernels then
+    // skip the sum of v1 m1 (one product per pair of 7) and b follows from the claim -- the same field element the direct sum gives.
+    static const bool use_claim = !(getenv("ZKCNN_ROUND_CLAIM") && atoi(getenv("ZKCNN_ROUND_CLAIM")) == 0);
+    const bool skip_p1 = use_claim && !first && ctx->last_poly_valid;
+    HFr claim(0LL);
+    if (skip_p1) claim = (ctx->last_poly[0] * r + ctx->last_poly[1]) * r + ctx->last_poly[2];
     // small tables are latency bound: spread each quad over 4 lanes (k_round_quad2, `fine`)
     static const int fine_log = getenv("ZKCNN_FINE_LOG") ? atoi(getenv("ZKCNN_FINE_LOG")) : 16;
     // (one block per 64 quads and 3 partial sums per block: both pairs together must stay within the partials buffer)
@@ -1094,6 +1104,7 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
     } else {
         A.r = to_dev(r);
         A.first = first ? 1 : 0;
+        A.skip_p1 = skip_p1 ? 1 : 0;
         A.partials = ctx->partials;
         A.counter = ctx->d_counter;
         A.slot = (host_slot *) ctx->d_slot;
@@ -1135,6 +1146,9 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         bcoef = bcoef - ctx->add_term;
         c = c + ctx->add_term;
     }
+    if (skip_p1) bcoef = claim - c - c - a;           // p(0) + p(1) = c + (a + b + c) = claim
+    ctx->last_poly[0] = a; ctx->last_poly[1] = bcoef; ctx->last_poly[2] = c;
+    ctx->last_poly_valid = true;
     put(out_abc, a);
     put(out_abc + 4, bcoef);
     put(out_abc + 8, c);
@@ -1236,6 +1250,7 @@ extern "C" int32_t zk_sumcheck_liu_init(zk_ctx *ctx, const uint64_t *s_u, const 
     ctx->phase_rounds = L0.d.bit_length;
     ctx->tail_active = false;
     ctx->host_tail_active = false;
+    ctx->last_poly_valid = false;
     ctx->add_term.clear();
     ctx->round = 0;
     table_pair &t = ctx->tp[1];
@@ -1759,6 +1774,7 @@ extern "C" int32_t zk_bench_round_quadratic(zk_ctx *ctx, uint32_t log_n, uint32_
     A.n[0] = n;
     A.blocks[0] = std::min<uint32_t>(grid_for(n / 4, 1024), ctx->partial_blocks / 2);
     A.r = to_dev(r[0]);
+    A.skip_p1 = 1;                        // as every round but the first of a phase runs: b comes from the running claim
     A.partials = ctx->partials;
     A.counter = ctx->d_counter;
     A.slot = (host_slot *) ctx->d_slot;

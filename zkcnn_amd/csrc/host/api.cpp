@@ -52,6 +52,18 @@ public:
                                         reinterpret_cast<uint64_t *>(uni), reinterpret_cast<uint64_t *>(bin));
         if (rc != ZK_OK) throw std::runtime_error(string("zk_verifier_predicates: ") + zk_last_error(p->context()));
     }
+    // the two MSMs of the opening check on the prover's GPU: over the proof's generators (their tables are resident) or over the
+    // commitment rows (a second, verifier-owned table set so that the prover's byte table survives)
+    bool msm(G1 &out, const Fr *k, const G1Affine *bases, size_t n, bool bases_are_generators) override {
+        uint64_t pt[12];
+        int rc = zk_verifier_msm(p->context(), pt, reinterpret_cast<const uint64_t *>(k), reinterpret_cast<const uint64_t *>(bases), n, bases_are_generators ? 1 : 0);
+        if (rc == ZK_ERR_STATE) return false;            // generators not cached on this context: the host takes it
+        if (rc != ZK_OK) throw std::runtime_error(string("zk_verifier_msm: ") + zk_last_error(p->context()));
+        G1Affine a;
+        std::memcpy(&a, pt, 96);
+        out = G1::fromAffine(a);
+        return true;
+    }
     F inputPredicate(const vector<F> &r_u0, const vector<vector<F>> &r_u, const vector<vector<F>> &r_v, const vector<F> &sig_u,
                      const vector<F> &sig_v) override {
         const size_t n = sig_u.size();

@@ -73,8 +73,9 @@ inline void drawGenerators(std::vector<G1> &gens, size_t count) {
 // Optional accelerator for the verifier's wiring predicates (the only part of the verifier that walks every gate:
 // reference src/verifier.cpp:36-116 and :304-325, `total_slow_timer`). The product driver plugs the HIP implementation
 // in (include/zkcnn_hip.h: zk_verifier_*); without one the loops below run on the host as in the reference.
-struct verifierAccel {
+struct verifierAccel : public hyrax_bls12_381::msmAccel {
     virtual ~verifierAccel() {}
+    bool msm(G1 &, const Fr *, const G1Affine *, size_t, bool) override { return false; }     // default: the host Pippenger
     virtual void predicates(u8 layer, const F *r_0, const F *r_1, const F &alpha, const F &beta, const F &relu_rou, const F *r_u,
                             const F *r_v, const F *r_u2, const F *r_v2, F uni[2], F bin[3]) = 0;
     virtual F inputPredicate(const vector<F> &r_u0, const vector<vector<F>> &r_u, const vector<vector<F>> &r_v, const vector<F> &sig_u,
@@ -125,6 +126,8 @@ public:
         poly_v->drive_only = drive_only;
         if (zk && !receiveMasks(n_sqrt)) return false;
         poly_v->stop_len = full_ipa ? 1 : (size_t) hyrax_bls12_381::IPA_STOP_LEN;
+        poly_v->accel = accel;
+        poly_v->cross_check = cross_check;
         msg_count = 0;
         if (!(verifyInnerLayers() && verifyFirstLayer())) return false;
         if (zk && !verifyMasks()) return false;
@@ -218,7 +221,7 @@ private:
         tic();
         std::vector<G1Affine> gA;
         zkff::batchToAffine(poly_v->generators(), gA);
-        const bool ok = hyrax_bls12_381::dotVerify(mask_commit, gA, ev.u, y, m1, c, m2);
+        const bool ok = hyrax_bls12_381::dotVerify(mask_commit, gA, ev.u, y, m1, c, m2, accel, cross_check);
         toc();
         return ok ? true : fail("masking polynomials: proof of dot product");
     }
