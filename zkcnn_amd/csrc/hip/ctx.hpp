@@ -105,6 +105,12 @@ struct zk_ctx {
     bool last_poly_valid = false;
     bool circuit_ready = false;
 
+    // layer-0 combine (zk_sumcheck_liu_init): CSR of (table, index) pairs by layer-0 index, half tables, per-call table descriptors
+    uint32_t *liu_ptr = nullptr; void *liu_ent = nullptr; fr_t *liu_halves = nullptr;
+    void *liu_tabs = nullptr, *h_liu_tabs = nullptr;      // device / pinned host array of liu_table
+    uint32_t liu_ntabs = 0;
+    std::vector<int> liu_tab_layer, liu_tab_side;           // table id -> (layer, 0 = u / 1 = v)
+
     msm_state *msm = nullptr;
     msm_state *vmsm = nullptr;     // verifier-owned second table set (zk_verifier_msm over arbitrary points)
 

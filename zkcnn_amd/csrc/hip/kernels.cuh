@@ -77,6 +77,58 @@ __global__ void __launch_bounds__(1024) k_eq_halves(fr_t *lo, fr_t *hi, uint32_t
     for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) fr_store(T + j, fr_mul(q[0][j & ma], q[1][j >> qa]));
 }
 
+// ---- layer-0 combine in two launches (reference src/prover.cpp:334-354 loops over every layer: an eq table and a scatter each) ----
+// M[x] = sum over layers i and sides of  sig * eq(r_{u|v}[i], h)  for every (i, side, h) with ori_id[h] == x. The pairs are known when the
+// circuit is uploaded (a CSR by x); eq(r, h) = lo[h & mask] * hi[h >> fh] needs only the two HALF tables of each (layer, side), so the full
+// eq tables are never written: one launch builds all half tables, one launch gathers. ~50 eq tables + ~50 scatters per vgg11 proof before.
+struct liu_table { fr_vec r; fr_t init; int32_t n, fh, sh, pad_; };      // one per (layer, side) that touches layer 0
+#define LIU_HALF_STRIDE 4096u                                               // entries per half table (bit length of a subset table <= 24)
+// grid (2, ntables): block (is_hi, t) builds one half table of table t in LDS (same doubling as k_eq_halves) and stores it
+__global__ void __launch_bounds__(1024) k_eq_halves_multi(fr_t *halves, const liu_table *tabs) {
+    __shared__ fr_t q[2][256];
+    const int is_hi = blockIdx.x, tb = blockIdx.y;
+    const liu_table &a = tabs[tb];
+    if (a.n < 0) return;
+    fr_t *T = halves + ((size_t) tb * 2 + is_hi) * LIU_HALF_STRIDE;
+    const int steps = is_hi ? a.sh : a.fh, base = is_hi ? a.fh : 0;
+    const int qa = (steps + 1) >> 1, qb = steps - qa;
+    const int side = threadIdx.x >> 9, t = threadIdx.x & 511;
+    const int nq = side ? qb : qa, qbase = base + (side ? qa : 0);
+    if (t == 0) q[side][0] = side ? fr_one() : (is_hi ? fr_one() : fr_load(&a.init));
+    __syncthreads();
+    for (int i = 0; i < qa; ++i) {
+        const uint32_t half = 1u << i;
+        if (i < nq && (uint32_t) t < half) {
+            const fr_t cur = q[side][t];
+            const fr_t x = fr_mul(cur, fr_load(&a.r.v[qbase + i]));
+            q[side][t | half] = x;
+            q[side][t] = fr_sub(cur, x);
+        }
+        __syncthreads();
+    }
+    const uint32_t n = 1u << steps, ma = (1u << qa) - 1;
+    if (qb == 0) {
+        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) fr_store(T + j, q[0][j]);
+        return;
+    }
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) fr_store(T + j, fr_mul(q[0][j & ma], q[1][j >> qa]));
+}
+struct liu_entry { uint32_t h, t; };                                        // index inside table t
+// one thread per layer-0 index x: sums its entries (CSR rows are contiguous, so a wave reads them coalesced)
+__global__ void __launch_bounds__(ZK_BLOCK) k_liu_gather(fr_t *M, const uint32_t *row_ptr, const liu_entry *ent, const fr_t *halves,
+                                                         const liu_table *tabs, uint64_t n) {
+    for (uint64_t x = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x; x < n; x += (uint64_t) gridDim.x * ZK_BLOCK) {
+        fr_t acc = fr_zero();
+        for (uint32_t e = row_ptr[x]; e < row_ptr[x + 1]; ++e) {
+            const liu_entry en = ent[e];
+            const int fh = tabs[en.t].fh;
+            const fr_t *lo = halves + (size_t) en.t * 2 * LIU_HALF_STRIDE;
+            acc = fr_add(acc, fr_mul(fr_load(lo + (en.h & ((1u << fh) - 1))), fr_load(lo + LIU_HALF_STRIDE + (en.h >> fh))));
+        }
+        fr_store(M + x, acc);
+    }
+}
+
 // out[i] = sum_p lo_p[i & mask] * hi_p[i >> fh]; entries >= tail_start are additionally scaled
 // (the relu_rou factor on the constraint rows, reference src/prover.cpp:221-222)
 __global__ void k_eq_expand(fr_t *out, const fr_t *lo, const fr_t *hi, uint32_t lo_stride, uint32_t hi_stride, int npoints,

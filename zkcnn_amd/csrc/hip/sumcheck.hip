@@ -116,6 +116,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     if (ctx->h_result) hipHostFree(ctx->h_result);
     if (ctx->h_slot) hipHostFree((void *) ctx->h_slot);
     if (ctx->h_tail) hipHostFree(ctx->h_tail);
+    if (ctx->h_liu_tabs) hipHostFree(ctx->h_liu_tabs);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -371,6 +372,53 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
         }
         D.n_uni2 = un.size();
         if ((rc = upload(ctx, &D.uni2, un))) return rc;
+    }
+    // layer-0 combine: every (layer, side) whose operands reach into layer 0 is a table; CSR of its (index h -> layer-0 index ori[h]) pairs by x
+    {
+        const uint64_t n0 = 1ull << layers[0].bit_length;
+        std::vector<uint32_t> cnt(n0 + 1, 0);
+        uint64_t total = 0;
+        for (int i = 1; i < n_layers; ++i) {
+            const zk_layer_desc &S = layers[i];
+            for (int side = 0; side < 2; ++side) {
+                const int bl = side ? S.bit_length_v[0] : S.bit_length_u[0];
+                const uint32_t sz = side ? S.size_v[0] : S.size_u[0];
+                const uint32_t *ori = side ? S.ori_id_v : S.ori_id_u;
+                if (bl < 0 || !sz) continue;
+                if (bl > 24) { ctx->err = "layer-0 subset table too large for the combined gather"; return ZK_ERR_ARG; }
+                ctx->liu_tab_layer.push_back(i);
+                ctx->liu_tab_side.push_back(side);
+                for (uint32_t h = 0; h < sz; ++h) {
+                    if (ori[h] >= n0) { ctx->err = "ori_id out of range"; return ZK_ERR_ARG; }
+                    ++cnt[ori[h] + 1];
+                }
+                total += sz;
+            }
+        }
+        if (total >= 0xffffffffull) { ctx->err = "too many layer-0 references"; return ZK_ERR_ARG; }
+        for (uint64_t x = 0; x < n0; ++x) cnt[x + 1] += cnt[x];
+        std::vector<liu_entry> ent(total);
+        {
+            std::vector<uint32_t> pos(cnt.begin(), cnt.end() - 1);
+            for (size_t tb = 0; tb < ctx->liu_tab_layer.size(); ++tb) {
+                const zk_layer_desc &S = layers[ctx->liu_tab_layer[tb]];
+                const int side = ctx->liu_tab_side[tb];
+                const uint32_t sz = side ? S.size_v[0] : S.size_u[0];
+                const uint32_t *ori = side ? S.ori_id_v : S.ori_id_u;
+                for (uint32_t h = 0; h < sz; ++h) {
+                    liu_entry e = {h, (uint32_t) tb};
+                    ent[pos[ori[h]]++] = e;
+                }
+            }
+        }
+        ctx->liu_ntabs = (uint32_t) ctx->liu_tab_layer.size();
+        liu_entry *d_ent = nullptr;
+        if ((rc = upload(ctx, &ctx->liu_ptr, cnt)) || (rc = upload(ctx, &d_ent, ent))) return rc;
+        ctx->liu_ent = d_ent;
+        const uint32_t nt = std::max<uint32_t>(ctx->liu_ntabs, 1);
+        if ((rc = zk_dev_alloc(ctx, (void **) &ctx->liu_halves, (size_t) nt * 2 * LIU_HALF_STRIDE * 32))) return rc;
+        if ((rc = zk_dev_alloc(ctx, &ctx->liu_tabs, (size_t) nt * sizeof(liu_table)))) return rc;
+        ZK_HIP(hipHostMalloc(&ctx->h_liu_tabs, (size_t) nt * sizeof(liu_table)));
     }
     // work buffers sized for the largest layer
     ctx->max_table = max_table;
@@ -1255,6 +1303,32 @@ extern "C" int32_t zk_sumcheck_liu_init(zk_ctx *ctx, const uint64_t *s_u, const 
     ctx->round = 0;
     table_pair &t = ctx->tp[1];
     t.Vsrc = L0.val;
+    static const bool batched = !(getenv("ZKCNN_LIU_BATCHED") && atoi(getenv("ZKCNN_LIU_BATCHED")) == 0);
+    if (batched) {
+        // descriptors of every (layer, side) table: point, sigma, bit split; then two launches (k_eq_halves_multi, k_liu_gather)
+        liu_table *T = (liu_table *) ctx->h_liu_tabs;
+        for (uint32_t tb = 0; tb < ctx->liu_ntabs; ++tb) {
+            const int i = ctx->liu_tab_layer[tb], side = ctx->liu_tab_side[tb];
+            const dev_layer &Li = ctx->L[i];
+            const int bl = side ? Li.d.bit_length_v[0] : Li.d.bit_length_u[0];
+            const std::vector<HFr> &pt = side ? ctx->r_v[i] : ctx->r_u[i];
+            if ((int) pt.size() < bl) return ZK_ERR_STATE;
+            for (int j = 0; j < bl; ++j) T[tb].r.v[j] = to_dev(pt[j]);
+            T[tb].init = to_dev(H((side ? s_v : s_u) + 4 * (i - 1)));
+            T[tb].n = bl;
+            T[tb].fh = bl >> 1;
+            T[tb].sh = bl - (bl >> 1);
+            T[tb].pad_ = 0;
+        }
+        if (ctx->liu_ntabs) {
+            ZK_HIP(hipMemcpyAsync(ctx->liu_tabs, T, (size_t) ctx->liu_ntabs * sizeof(liu_table), hipMemcpyHostToDevice, ctx->stream));
+            ZK_LAUNCH(PC_EQ, 0.0, k_eq_halves_multi, dim3(2, ctx->liu_ntabs), dim3(1024), ctx->liu_halves, (const liu_table *) ctx->liu_tabs);
+        }
+        ZK_LAUNCH(PC_LIU, 0.0, k_liu_gather, dim3(grid_for(t.len)), dim3(ZK_BLOCK), t.M[0], ctx->liu_ptr, (const liu_entry *) ctx->liu_ent, ctx->liu_halves,
+                  (const liu_table *) ctx->liu_tabs, t.len);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
     ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
     fr_t *bg = ctx->beta_g[ctx->beta_g_cur];
     int32_t rc;
