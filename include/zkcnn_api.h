@@ -20,6 +20,8 @@ typedef struct {
     int32_t pic_x, pic_y, pic_channel;
     int32_t pic_cnt;       /* pictures folded into ONE circuit (reference pic_parallel) */
     uint64_t data_seed;    /* synthetic picture / weights / biases (reference data.tar.gz is absent) */
+    uint64_t picture_seed; /* 0: the picture comes from the data_seed stream; else from its own stream, so that sessions with one data_seed share
+                              their weights and differ in the picture (zkcnn_session_new_image switches a session to another picture_seed) */
 } zkcnn_model_desc;
 
 #define ZKCNN_MODE_VERIFY      0u  /* full verifier (reference behaviour): challenges from the operating system's CSPRNG, fresh random generators */
@@ -81,6 +83,18 @@ int64_t zkcnn_session_statement(void *session, int32_t *scales, uint64_t cap);
  * weights or witness; zkcnn_session_verify works on it, zkcnn_session_prove fails. Returns NULL on error (also on a statement
  * that does not fit the model). */
 void *zkcnn_verifier_create(const zkcnn_model_desc *desc, const int32_t *scales, uint64_t n_scales, int32_t device);
+/* Product library only -- the next picture on the session's resident circuit: `pixels` (channel, x, y order, n_pixels =
+ * channel * x * y values; NULL: the synthetic picture of `picture_seed`) is quantised on the host and every layer value and auxiliary
+ * witness is recomputed in HBM by replaying the witness program the circuit generator recorded -- no circuit generation, no upload of
+ * values. The circuit's shape depends on the picture through its quantisation scales; returns
+ *   0  done: the session now proves the new picture (same transcript as a session created for it from scratch),
+ *   1  this picture's own range asks for another input scale -- nothing was changed,
+ *   2  some layer's activation range asks for another scale -- the values in HBM are now unusable until a later call returns 0
+ *      (create a new session for such a picture),
+ *  <0  error. *ms (may be NULL) receives the wall-clock milliseconds of the call. */
+int32_t zkcnn_session_new_image(void *session, uint64_t picture_seed, const double *pixels, uint64_t n_pixels, double *ms);
+/* the pixel values of synthetic picture `picture_seed` for this session's model (cap >= channel * x * y); returns their number */
+int64_t zkcnn_session_synthetic_picture(void *session, uint64_t picture_seed, double *pixels, uint64_t cap);
 void zkcnn_session_destroy(void *session);
 /* The reference CLI's 16-column result row of the last prove call ("a, b, c, ..."), NUL terminated. */
 int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap);

@@ -156,6 +156,27 @@ int32_t zk_witness_gates(zk_ctx *ctx, uint64_t *out, uint64_t n_out, const zk_un
                          uint64_t n_bin, const uint64_t *prev, uint64_t n_prev, const uint64_t *two_mul, uint32_t n_two_mul,
                          const uint64_t scale[4]);
 
+/* ---- the next picture on a resident circuit (replaces the host loops of reference src/neuralNetwork.cpp:60-142,
+ * 652-728, 899-977 for every picture after the first). The host generator records HOW layer 0's auxiliary witnesses follow from the
+ * layer values (host/neuralNetwork.hpp: witnessProgram); the context keeps that program, the gate lists grouped by output and all
+ * layer values in HBM and replays it for a new picture: evaluate a layer, derive bits / signs / maxima into layer 0, scan a range. ---- */
+typedef struct { uint32_t src, dst; uint8_t src_layer, op, shift, pad_; } zk_witness_op;     /* op: 0 bit, 1 sign, 2 running max, 3 bit of a window sum */
+typedef struct {
+    int32_t what;            /* 0 = auxiliary operations, 1 = evaluate `layer`, 2 = range of `layer` */
+    int32_t layer;
+    uint64_t op_begin, op_end, win_begin;
+    int32_t win, bits, scale_index, pad_;
+} zk_witness_step;
+/* After zk_upload_circuit, with the SAME layer descriptors (gate lists as uploaded, ori_id_u / ori_id_v). Validates every index. */
+int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *ops, uint64_t n_ops, const uint32_t *windows, uint64_t n_windows,
+                                  const zk_witness_step *steps, uint32_t n_steps, const zk_layer_desc *layers, int32_t n_layers);
+/* Writes `picture` (n_picture field elements) over the start of layer 0 and recomputes every layer's values and layer 0's auxiliary
+ * witnesses in HBM. ranges[2k], ranges[2k+1] = largest non-negative value / largest magnitude of a negative value of the k-th
+ * range step (the host turns them into quantisation scales and compares with the circuit's); last_layer (may be NULL) receives the
+ * first n_last values of the output layer. ZK_ERR_STATE if a value exceeded 63 bits (the int64 view of the reference would differ). */
+int32_t zk_witness_rerun(zk_ctx *ctx, const uint64_t *picture, uint64_t n_picture, uint64_t *ranges, uint32_t n_ranges,
+                         uint64_t *last_layer, uint64_t n_last);
+
 /* frees the device copy of layer 0 and the staging buffers of zk_witness_* (the witness is complete) */
 int32_t zk_witness_release(zk_ctx *ctx);
 

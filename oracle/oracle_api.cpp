@@ -38,6 +38,111 @@ void *oracle_verifier_create(const zkcnn_model_desc *desc, const int32_t *scales
 int32_t oracle_session_verify(void *session, uint64_t seed, uint32_t mode, const uint8_t *proof, uint64_t len, zkcnn_result *out) {
     return ((oracleSession *) session)->verifyProof(proof, len, seed, mode, out);
 }
+// ---- the recorded witness program, interpreted on the CPU (what zk_witness_rerun does in HBM, restated with plain loops) ----
+// Session `session` was built for some picture; this replays its program for synthetic picture `picture_seed` and compares EVERY layer
+// value with a second session built for that picture from scratch. Returns the number of differing entries (0 = the program is a
+// faithful description of the witness), -2 if the two pictures need different quantisation scales (nothing to compare), -1 on error.
+int64_t oracle_session_replay_program(void *session, uint64_t picture_seed) {
+    oracleSession *s = (oracleSession *) session;
+    if (!s || !s->nn || !s->has_witness) return -1;
+    zkcnn_model_desc d;
+    d.model = s->model_name.c_str();
+    d.pic_x = s->pic_x; d.pic_y = s->pic_y; d.pic_channel = s->pic_channel; d.pic_cnt = s->pic_cnt;
+    d.data_seed = s->data_seed; d.picture_seed = picture_seed;
+    oracleSession full;
+    if (!full.build(&d)) return -1;
+    if (full.statementScales() != s->statementScales()) return -2;
+
+    const layeredCircuit &C = s->p.C;
+    const witnessProgram &pg = s->nn->program();
+    vector<F> picture;
+    if (!s->nn->quantisePicture(s->nn->syntheticPicture(picture_seed), picture)) return -2;
+    vector<vector<F>> val(C.size);
+    for (int i = 0; i < C.size; ++i) val[i].assign(C.circuit[i].size, F_ZERO);
+    val[0] = s->p.val[0];                                  // weights and biases stay; picture and auxiliary witnesses are rewritten
+    for (size_t i = 0; i < picture.size(); ++i) val[0][i] = picture[i];
+    vector<std::pair<u64, u64>> ranges;
+    for (const witnessStep &st : pg.steps) {
+        if (st.what == witnessStep::AUX) {
+            const vector<F> &src = val[st.layer];
+            for (u64 j = st.op_begin; j < st.op_end; ++j) {
+                const witnessOp &op = pg.ops[j];
+                if (op.op == witnessOp::MAX) {
+                    if (j > st.op_begin && pg.ops[j - 1].dst == op.dst) continue;
+                    F best = F_ZERO;
+                    for (u64 k = j; k < st.op_end && pg.ops[k].dst == op.dst; ++k) {
+                        const F &x = src.at(pg.ops[k].src);
+                        if (!x.isNegative() && x > best) best = x;
+                    }
+                    val[0].at(op.dst) = best;
+                    continue;
+                }
+                F x = F_ZERO;
+                if (op.op == witnessOp::SUM_BIT)
+                    for (i32 k = 0; k < st.win; ++k) x = x + src.at(pg.windows.at(st.win_begin + (u64) op.src * st.win + k));
+                else x = src.at(op.src);
+                const i64 mag = std::llabs(x.getInt64());
+                const bool bit = op.op == witnessOp::SIGN ? x.isNegative() : ((mag >> op.shift) & 1) != 0;
+                val[0].at(op.dst) = bit ? F_ONE : F_ZERO;
+            }
+        } else if (st.what == witnessStep::RANGE) {
+            F mx = F_ZERO, mn = F_ZERO;
+            for (const F &x : val[st.layer]) {
+                if (!x.isNegative()) { if (x > mx) mx = x; }
+                else { F nx = -x; if (nx > mn) mn = nx; }
+            }
+            ranges.push_back(std::make_pair((u64) mx.getInt64(), (u64) mn.getInt64()));
+        } else {
+            const layer &L = C.circuit[st.layer];
+            vector<F> &out = val[st.layer];
+            const vector<F> &prev = val[st.layer - 1];
+            std::fill(out.begin(), out.end(), F_ZERO);
+            if (L.ty == layerType::FFT || L.ty == layerType::IFFT) {
+                const size_t len = (size_t) 1 << L.fft_bit_length, lenh = len >> 1;
+                vector<F> arr(len);
+                if (L.ty == layerType::FFT)
+                    for (size_t c = 0, e = 0; e < L.size; c += lenh, e += len) {
+                        for (size_t j = 0; j < len; ++j) arr[j] = j < lenh ? prev.at(c + j) : F_ZERO;
+                        fft(arr, L.fft_bit_length, false);
+                        for (size_t j = 0; j < len; ++j) out[e + j] = arr[j];
+                    }
+                else
+                    for (size_t c = 0, e = 0; c < L.size; c += lenh, e += len) {
+                        for (size_t j = 0; j < len; ++j) arr[j] = prev.at(e + j);
+                        fft(arr, L.fft_bit_length, true);
+                        for (size_t j = 0; j < lenh; ++j) out[c + j] = arr[j];
+                    }
+            } else if (L.ty == layerType::DOT_PROD) {
+                const int fb = L.fft_bit_length;
+                for (const binGate &gt : L.bin_gates)
+                    for (u32 t = 0; t < (1u << fb); ++t)
+                        out[((size_t) gt.g << fb) + t] = out[((size_t) gt.g << fb) + t] + prev[((size_t) gt.u << fb) + t] * prev[((size_t) gt.v << fb) + t];
+            } else {
+                // gates as they are after initSubset: an operand in layer 0 is an index into the layer's subset (ori_id_u / ori_id_v)
+                const u8 id = (u8) st.layer;
+                for (const uniGate &gt : L.uni_gates) {
+                    const F &x = gt.lu == 0 ? val[0].at(L.ori_id_u.at(gt.u)) : prev.at(gt.u);
+                    out[gt.g] = out[gt.g] + (gt.sc ? x * C.two_mul[gt.sc] : x);
+                }
+                for (const binGate &gt : L.bin_gates) {
+                    const F &x = gt.getLayerIdU(id) == 0 ? val[0].at(L.ori_id_u.at(gt.u)) : prev.at(gt.u);
+                    const F &y = gt.getLayerIdV(id) == 0 ? val[0].at(L.ori_id_v.at(gt.v)) : prev.at(gt.v);
+                    F pr = x * y;
+                    out[gt.g] = out[gt.g] + (gt.sc ? pr * C.two_mul[gt.sc] : pr);
+                }
+                if (!(L.scale == F_ONE)) for (F &x : out) x = x * L.scale;
+            }
+        }
+    }
+    if (!s->nn->rangesReproduceScales(ranges)) return -2;
+    int64_t diff = 0;
+    for (int i = 0; i < C.size; ++i) {
+        if (val[i].size() != full.p.val[i].size()) return -1;
+        for (size_t j = 0; j < val[i].size(); ++j) diff += !(val[i][j] == full.p.val[i][j]);
+    }
+    return diff;
+}
+
 void oracle_session_destroy(void *session) { delete (oracleSession *) session; }
 int32_t oracle_session_row(void *session, char *buf, uint64_t cap) {
     const string &r = ((oracleSession *) session)->row;

@@ -1,0 +1,105 @@
+"""The next picture on a resident circuit (zkcnn_session_new_image -> zk_witness_program_upload / zk_witness_rerun):
+picture quantised on the host, every layer value and auxiliary witness recomputed in HBM by replaying the recorded witness program.
+The session must then produce, byte for byte, the transcript of a session created for that picture from scratch -- on the GPU and in
+the CPU oracle."""
+import pytest
+
+import zkcnn_amd
+from tests import oracle_ffi
+
+pytestmark = pytest.mark.gpu
+
+REUSE, FS = zkcnn_amd.MODE_REUSE_GENS, zkcnn_amd.MODE_FIAT_SHAMIR
+W = 4242
+SEED = 0x5EED0021
+
+MODELS = [
+    ("lenet", (32, 32, 1), 1),
+    ("lenet.avg", (32, 32, 1), 2),
+    ("custom:C2:3:0:f C3:3:1:f M C2:3:1:s A F5 F3", (10, 10, 2), 2),
+    ("custom:C3:3:1:n M F6 F4", (8, 8, 1), 1),
+    ("vgg:16 M 32 M 64 64 M 128 128 M 128 128 M", (32, 32, 3), 1),          # vgg11 at quarter width
+]
+
+
+def _group_by_statement(model, pic, pp, pictures):
+    groups = {}
+    for p in pictures:
+        with oracle_ffi.OracleSession(model, pic, pp, data_seed=W, picture_seed=p) as o:
+            groups.setdefault(tuple(o.statement()), []).append(p)
+    same = max(groups.values(), key=len)
+    other = [p for g in groups.values() for p in g if p not in same]
+    return same, other
+
+
+@pytest.mark.parametrize("model,pic,pp", MODELS)
+def test_new_image_transcripts_identical_to_fresh_sessions(built, model, pic, pp):
+    same, other = _group_by_statement(model, pic, pp, range(1, 7))
+    assert len(same) >= 2, "no two of six pictures share their quantisation scales"
+    want = {}
+    for p in same[:3]:
+        with oracle_ffi.OracleSession(model, pic, pp, data_seed=W, picture_seed=p) as o:
+            res, tr = o.prove(seed=SEED, mode=REUSE)
+            assert res.accepted == 1
+            want[p] = tr
+    with zkcnn_amd.Session(model, pic, pp, data_seed=W, picture_seed=same[0]) as s:
+        res, tr = s.prove(seed=SEED, mode=REUSE)
+        assert res.accepted == 1 and tr == want[same[0]]
+        for p in same[1:3]:
+            rc, ms = s.new_image(p)
+            assert rc == 0, f"picture {p} has the session's scales but new_image returned {rc}"
+            res, tr = s.prove(seed=SEED, mode=REUSE)
+            assert res.accepted == 1, res.message.decode()
+            assert tr == want[p], f"picture {p}: transcript after new_image differs from a session built for it"
+            assert s.statement() == list(_stmt(model, pic, pp, p))
+        # the same picture handed over as pixel values
+        rc, _ = s.new_image(pixels=s.synthetic_picture(same[0]))
+        assert rc == 0
+        assert s.prove(seed=SEED, mode=REUSE)[1] == want[same[0]]
+        # a Fiat-Shamir proof of the new picture verifies off line
+        rc, _ = s.new_image(same[1])
+        res, proof = s.prove(mode=FS)
+        assert rc == 0 and res.accepted == 1 and s.verify(proof, mode=FS).accepted == 1
+        if other:
+            # a picture whose scales differ: refused; if the values in HBM were already overwritten the session says so until it is repaired
+            rc, _ = s.new_image(other[0])
+            assert rc in (1, 2)
+            if rc == 2:
+                with pytest.raises(RuntimeError):
+                    s.prove(seed=SEED, mode=REUSE)
+            else:
+                assert s.prove(seed=SEED, mode=REUSE)[1] == want[same[1]]
+            rc, _ = s.new_image(same[0])
+            assert rc == 0 and s.prove(seed=SEED, mode=REUSE)[1] == want[same[0]]
+    with zkcnn_amd.Session(model, pic, pp, data_seed=W, picture_seed=same[1]) as fresh:
+        assert fresh.prove(seed=SEED, mode=REUSE)[1] == want[same[1]]
+
+
+def _stmt(model, pic, pp, p):
+    with oracle_ffi.OracleSession(model, pic, pp, data_seed=W, picture_seed=p) as o:
+        return tuple(o.statement())
+
+
+def test_new_image_full_vgg11(built):
+    """BASELINE configs[1] at full size: the program covers 8 FFT convolutions with 2^12-point transforms, 5 max poolings, 3 fc layers"""
+    model, pic, pp = "vgg11", (32, 32, 3), 1
+    with zkcnn_amd.Session(model, pic, pp, data_seed=W, picture_seed=1) as s:
+        assert s.prove(seed=SEED, mode=REUSE).__getitem__(0).accepted == 1
+        done = None
+        times = []
+        for p in range(2, 10):
+            rc, ms = s.new_image(p)
+            times.append(ms)
+            if rc == 0:
+                done = p
+                break
+        assert done is not None, "none of eight pictures kept the quantisation scales"
+        res, tr = s.prove(seed=SEED, mode=REUSE)
+        assert res.accepted == 1, res.message.decode()
+        res, proof = s.prove(mode=FS)
+        assert res.accepted == 1 and s.verify(proof, mode=FS).accepted == 1
+        stmt = s.statement()
+    with zkcnn_amd.Session(model, pic, pp, data_seed=W, picture_seed=done) as fresh:
+        assert fresh.statement() == stmt
+        assert fresh.prove(seed=SEED, mode=REUSE)[1] == tr
+    print("new_image ms:", times)

@@ -26,7 +26,8 @@ MODE_HOST_TAIL = 1 << 26
 
 class ModelDesc(ctypes.Structure):
     _fields_ = [("model", ctypes.c_char_p), ("pic_x", ctypes.c_int32), ("pic_y", ctypes.c_int32),
-                ("pic_channel", ctypes.c_int32), ("pic_cnt", ctypes.c_int32), ("data_seed", ctypes.c_uint64)]
+                ("pic_channel", ctypes.c_int32), ("pic_cnt", ctypes.c_int32), ("data_seed", ctypes.c_uint64),
+                ("picture_seed", ctypes.c_uint64)]
 
 
 class Result(ctypes.Structure):
@@ -239,12 +240,15 @@ class _SessionBase:
     def _fn(self, name):
         return getattr(self.lib, self._prefix + name)
 
-    def __init__(self, lib, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0, statement=None):
-        """statement=None: circuit + witness from the (synthetic) data. statement=[ints]: a verifier-only session whose circuit is
+    def __init__(self, lib, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0, statement=None, picture_seed=0):
+        """picture_seed=0: picture, weights and biases all come from the data_seed stream; otherwise the picture has its own stream, so
+        that sessions with one data_seed share their weights and differ in the picture.
+        statement=None: circuit + witness from the (synthetic) data. statement=[ints]: a verifier-only session whose circuit is
         rebuilt from the model descriptor and the quantisation scales of a prover's session (no witness; prove() fails)."""
         self.lib = lib
         self.model, self.pic, self.pic_cnt, self.data_seed = model, tuple(pic), pic_cnt, data_seed
-        self.desc = ModelDesc(model.encode(), pic[0], pic[1], pic[2], pic_cnt, data_seed)
+        self.picture_seed = picture_seed
+        self.desc = ModelDesc(model.encode(), pic[0], pic[1], pic[2], pic_cnt, data_seed, picture_seed)
         if statement is None:
             self._fn("session_create").restype = ctypes.c_void_p
             self.h = self._fn("session_create")(ctypes.byref(self.desc), ctypes.c_int32(device))
@@ -331,8 +335,34 @@ class Session(_SessionBase):
     """Circuit + witness resident on one GPU; prove() runs verifier <-> HIP prover (include/zkcnn_api.h)."""
     _prefix = "zkcnn_"
 
-    def __init__(self, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0, statement=None):
-        super().__init__(host_lib(), model, pic, pic_cnt, data_seed, device, statement)
+    def __init__(self, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0, statement=None, picture_seed=0):
+        super().__init__(host_lib(), model, pic, pic_cnt, data_seed, device, statement, picture_seed)
+
+    def new_image(self, picture_seed=None, pixels=None):
+        """the next picture on the resident circuit (zkcnn_session_new_image): the synthetic picture of `picture_seed`, or `pixels`
+        (channel, x, y order). Layer values and auxiliary witnesses are recomputed in HBM -- no circuit generation, no upload.
+        Returns (code, ms): 0 = the session now proves this picture; 1 = its input range needs another circuit (nothing changed);
+        2 = an activation range needs another circuit (this session cannot prove until a later call returns 0)."""
+        ms = ctypes.c_double(0)
+        if pixels is not None:
+            arr = (ctypes.c_double * len(pixels))(*pixels)
+            rc = self.lib.zkcnn_session_new_image(ctypes.c_void_p(self.h), ctypes.c_uint64(0), arr, ctypes.c_uint64(len(pixels)), ctypes.byref(ms))
+        else:
+            rc = self.lib.zkcnn_session_new_image(ctypes.c_void_p(self.h), ctypes.c_uint64(picture_seed), None, ctypes.c_uint64(0), ctypes.byref(ms))
+        if rc < 0:
+            raise RuntimeError(f"zkcnn_session_new_image failed ({rc})")
+        if rc == 0 and pixels is None:
+            self.picture_seed = picture_seed
+        return rc, ms.value
+
+    def synthetic_picture(self, picture_seed):
+        n = self.pic[0] * self.pic[1] * self.pic[2]
+        arr = (ctypes.c_double * n)()
+        self.lib.zkcnn_session_synthetic_picture.restype = ctypes.c_int64
+        got = self.lib.zkcnn_session_synthetic_picture(ctypes.c_void_p(self.h), ctypes.c_uint64(picture_seed), arr, ctypes.c_uint64(n))
+        if got != n:
+            raise RuntimeError("zkcnn_session_synthetic_picture failed")
+        return list(arr)
 
     def profile(self, classes="all"):
         """HIP-event timing of the selected kernel classes (list of names, "all", or None to switch off)"""

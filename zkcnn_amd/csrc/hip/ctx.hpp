@@ -36,6 +36,12 @@ struct dev_layer {
     gate_rec *d1 = nullptr;
     uint32_t *d1_rowptr = nullptr;
     uint32_t d1_rows = 0;
+    // resident witness program (zk_witness_program_upload): gate lists grouped by output with layer-0 operands as raw layer-0 indices;
+    // DOT_PROD: CSR by output vector
+    void *ev_uni = nullptr, *ev_bin = nullptr;
+    uint64_t n_ev_uni = 0, n_ev_bin = 0;
+    gate_rec *ev_dot = nullptr;
+    uint32_t *ev_dot_ptr = nullptr;
 };
 
 // one (V, M) bookkeeping-table pair of a sumcheck, ping-pong buffered
@@ -138,6 +144,18 @@ struct zk_ctx {
     // witness generation (zk_witness_input / zk_witness_gates): device copy of layer 0 while it is being built + staging
     dev_buf w_val0, w_stage[5];
     uint64_t w_val0_len = 0;
+
+    // resident witness program
+    bool wp_ready = false;
+    std::vector<zk_witness_step> wp_steps;
+    void *wp_ops = nullptr;
+    uint32_t *wp_windows = nullptr;
+    uint64_t wp_n_ops = 0, wp_n_windows = 0;
+    fr_t *wp_tmp = nullptr;                 // 2 x (largest generic layer) partial sums
+    uint32_t *wp_carry_key = nullptr; fr_t *wp_carry_val = nullptr;
+    unsigned long long *wp_ranges = nullptr;    // device: 2 per range step, then one word of flags
+    unsigned long long *h_wp_ranges = nullptr;  // pinned copy
+    uint32_t wp_n_ranges = 0;
 
     // profiler: when a class bit is set in prof_mask every launch of that class is bracketed by events
     uint32_t prof_mask = 0;

@@ -10,6 +10,7 @@
 #include "ctx.hpp"
 #include "kernels.cuh"
 #include "fs_tail.cuh"
+#include "witness_kernels.cuh"
 
 static std::string g_create_err;
 
@@ -117,6 +118,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     if (ctx->h_slot) hipHostFree((void *) ctx->h_slot);
     if (ctx->h_tail) hipHostFree(ctx->h_tail);
     if (ctx->h_liu_tabs) hipHostFree(ctx->h_liu_tabs);
+    if (ctx->h_wp_ranges) hipHostFree(ctx->h_wp_ranges);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1770,6 +1772,225 @@ extern "C" int32_t zk_witness_gates(zk_ctx *ctx, uint64_t *out, uint64_t n_out, 
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(out, dO, n_out * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// resident witness program: the next picture without the host round trip of the layer values
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *ops, uint64_t n_ops, const uint32_t *windows, uint64_t n_windows,
+                                             const zk_witness_step *steps, uint32_t n_steps, const zk_layer_desc *layers, int32_t n_layers) {
+    CHECK_READY();
+    static_assert(sizeof(zk_witness_op) == sizeof(wit_op) && sizeof(zk_witness_op) == 12 && sizeof(zk_witness_step) == 48, "program records");
+    if (ctx->wp_ready) { ctx->err = "witness program already uploaded"; return ZK_ERR_STATE; }
+    if (n_layers != (int32_t) ctx->L.size() || !steps || !n_steps || (n_ops && !ops) || (n_windows && !windows)) return ZK_ERR_ARG;
+    const uint64_t n0 = ctx->L[0].d.size;
+    int32_t rc;
+    // ---- the steps: every index an operation touches must exist ----
+    uint32_t n_ranges = 0;
+    std::vector<uint8_t> evaluated(n_layers, 0);
+    evaluated[0] = 1;
+    for (uint32_t k = 0; k < n_steps; ++k) {
+        const zk_witness_step &st = steps[k];
+        if (st.layer < 0 || st.layer >= n_layers) { ctx->err = "witness step: layer out of range"; return ZK_ERR_ARG; }
+        if (st.what == 1) {
+            if (st.layer < 1 || !evaluated[st.layer - 1]) { ctx->err = "witness step: layer evaluated before its inputs"; return ZK_ERR_ARG; }
+            evaluated[st.layer] = 1;
+        } else if (st.what == 2) {
+            if (!evaluated[st.layer]) { ctx->err = "witness step: range of a layer not yet evaluated"; return ZK_ERR_ARG; }
+            ++n_ranges;
+        } else if (st.what == 0) {
+            if (st.op_begin > st.op_end || st.op_end > n_ops || !evaluated[st.layer]) { ctx->err = "witness step: bad operation span"; return ZK_ERR_ARG; }
+            const uint64_t src_n = ctx->L[st.layer].d.size;
+            const bool sum = st.op_begin < st.op_end && ops[st.op_begin].op == 3;
+            uint64_t n_win = 0;
+            if (sum) {
+                if (st.win < 1 || st.win_begin > n_windows) { ctx->err = "witness step: bad window table"; return ZK_ERR_ARG; }
+                n_win = (n_windows - st.win_begin) / (uint64_t) st.win;
+            }
+            uint64_t used_win = 0;
+            for (uint64_t j = st.op_begin; j < st.op_end; ++j) {
+                const zk_witness_op &op = ops[j];
+                if (op.op > 3 || op.dst >= n0 || op.shift > 63 || (op.op == 3) != sum || ((op.op == 2) != (ops[st.op_begin].op == 2)) ||
+                    (sum ? op.src >= n_win : op.src >= src_n)) { ctx->err = "witness operation out of range"; return ZK_ERR_ARG; }
+                if (sum) used_win = std::max<uint64_t>(used_win, (uint64_t) op.src + 1);
+            }
+            for (uint64_t w = st.win_begin; w < st.win_begin + used_win * (uint64_t) (sum ? st.win : 0); ++w)
+                if (windows[w] >= src_n) { ctx->err = "witness window entry out of range"; return ZK_ERR_ARG; }
+        } else {
+            ctx->err = "witness step: unknown kind";
+            return ZK_ERR_ARG;
+        }
+    }
+    for (int i = 1; i < n_layers; ++i)
+        if (!evaluated[i]) { ctx->err = "witness program does not evaluate every layer"; return ZK_ERR_ARG; }
+    // ---- gate lists grouped by output, operands in layer 0 as raw layer-0 indices ----
+    uint64_t max_out = 1, max_blocks = 1;
+    for (int i = 1; i < n_layers; ++i) {
+        const zk_layer_desc &S = layers[i];
+        dev_layer &D = ctx->L[i];
+        if (S.size != D.d.size || S.ty != D.d.ty) { ctx->err = "witness program: layer descriptors differ from the uploaded circuit"; return ZK_ERR_ARG; }
+        const uint64_t n_out = S.size, n_prev = ctx->L[i - 1].d.size;
+        if (S.ty == ZK_FFT || S.ty == ZK_IFFT) {
+            if (S.fft_bit_length < 1 || S.fft_bit_length > 12) { ctx->err = "witness program: transform longer than 2^12"; return ZK_ERR_ARG; }
+            continue;
+        }
+        if (S.ty == ZK_DOT_PROD) {
+            const int fb = S.fft_bit_length;
+            if (fb < 1 || fb > 20) return ZK_ERR_ARG;
+            const uint64_t vec_out = n_out >> fb, vec_in = n_prev >> fb;
+            std::vector<uint32_t> ptr(vec_out + 1, 0);
+            for (uint64_t k = 0; k < S.n_bin; ++k) {
+                const zk_bin_gate &gt = S.bin_gates[k];
+                if (gt.g >= vec_out || gt.u >= vec_in || gt.v >= vec_in) { ctx->err = "dot-prod gate out of range"; return ZK_ERR_ARG; }
+                ++ptr[gt.g + 1];
+            }
+            for (uint64_t g = 0; g < vec_out; ++g) ptr[g + 1] += ptr[g];
+            std::vector<gate_rec> sorted(S.n_bin);
+            std::vector<uint32_t> pos(ptr.begin(), ptr.end() - 1);
+            for (uint64_t k = 0; k < S.n_bin; ++k) {
+                const zk_bin_gate &gt = S.bin_gates[k];
+                gate_rec r = {gt.g, gt.u, gt.v, 0};
+                sorted[pos[gt.g]++] = r;
+            }
+            if ((rc = upload(ctx, &D.ev_dot, sorted)) || (rc = upload(ctx, &D.ev_dot_ptr, ptr))) return rc;
+            continue;
+        }
+        std::vector<zk_uni_gate> uni(S.uni_gates, S.uni_gates + S.n_uni);
+        std::vector<zk_bin_gate> bin(S.bin_gates, S.bin_gates + S.n_bin);
+        bool ok = true;
+        for (zk_uni_gate &gt : uni) {
+            if (gt.lu == 0) { if (gt.u >= S.size_u[0]) { ok = false; break; } gt.u = S.ori_id_u[gt.u]; }
+        }
+        for (zk_bin_gate &gt : bin) {
+            if (!ok || gt.l > 2) { ok = false; break; }
+            if (gt.l == 0) { if (gt.u >= S.size_u[0]) { ok = false; break; } gt.u = S.ori_id_u[gt.u]; }
+            if (!(gt.l & 1)) { if (gt.v >= S.size_v[0]) { ok = false; break; } gt.v = S.ori_id_v[gt.v]; }
+        }
+        if (!ok) { ctx->err = "witness program: gate operand outside its subset"; return ZK_ERR_ARG; }
+        std::vector<uint8_t> seen(n_out);
+        int g1 = grouped_by_output(uni.data(), uni.size(), n_out, seen, [&](const zk_uni_gate &gt) {
+            return (int) gt.sc < ctx->n_two_mul && gt.u < (gt.lu ? n_prev : n0); });
+        int g2 = g1 < 0 ? -1 : grouped_by_output(bin.data(), bin.size(), n_out, seen, [&](const zk_bin_gate &gt) {
+            return (int) gt.sc < ctx->n_two_mul && gt.u < (gt.l == 0 ? n0 : n_prev) && gt.v < ((gt.l & 1) ? n_prev : n0); });
+        if (g1 < 0 || g2 < 0) { ctx->err = "witness gate operand out of range"; return ZK_ERR_ARG; }
+        if (!g1) { std::vector<zk_uni_gate> t; regroup(t, uni.data(), uni.size(), n_out); uni.swap(t); }
+        if (!g2) { std::vector<zk_bin_gate> t; regroup(t, bin.data(), bin.size(), n_out); bin.swap(t); }
+        zk_uni_gate *du = nullptr;
+        zk_bin_gate *db = nullptr;
+        if ((rc = upload(ctx, &du, uni)) || (rc = upload(ctx, &db, bin))) return rc;
+        D.ev_uni = du; D.n_ev_uni = uni.size();
+        D.ev_bin = db; D.n_ev_bin = bin.size();
+        max_out = std::max(max_out, n_out);
+        max_blocks = std::max<uint64_t>(max_blocks, (std::max(uni.size(), bin.size()) + ZK_BLOCK - 1) / ZK_BLOCK);
+    }
+    std::vector<zk_witness_op> vops(ops, ops + n_ops);
+    std::vector<uint32_t> vwin(windows, windows + n_windows);
+    zk_witness_op *d_ops = nullptr;
+    if ((rc = upload(ctx, &d_ops, vops)) || (rc = upload(ctx, &ctx->wp_windows, vwin))) return rc;
+    ctx->wp_ops = d_ops;
+    ctx->wp_n_ops = n_ops;
+    ctx->wp_n_windows = n_windows;
+    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->wp_tmp, 2 * max_out * 32)) ||
+        (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_carry_val, 2 * max_blocks * 32)) ||
+        (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_carry_key, 2 * max_blocks * 4)) ||
+        (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_ranges, (2 * (size_t) n_ranges + 1) * 8)))
+        return rc;
+    ZK_HIP(hipHostMalloc((void **) &ctx->h_wp_ranges, (2 * (size_t) n_ranges + 1) * 8));
+    ctx->wp_n_ranges = n_ranges;
+    ctx->wp_steps.assign(steps, steps + n_steps);
+    ctx->wp_ready = true;
+    return ZK_OK;
+}
+
+// FFT / IFFT layer between two resident value tables (the host-array variant is zk_witness_ntt)
+static int32_t resident_ntt(zk_ctx *ctx, const dev_layer &D, const dev_layer &P) {
+    const int logn = D.d.fft_bit_length;
+    const bool inverse = D.d.ty == ZK_IFFT;
+    const uint32_t len = 1u << logn, in_len = inverse ? len : len / 2, out_len = inverse ? len / 2 : len;
+    const uint64_t count = D.d.size / out_len;
+    if (!count || (uint64_t) count * in_len > P.val_len) { ctx->err = "transform layer larger than its input"; return ZK_ERR_ARG; }
+    fr_t *pw = powers_of_root(ctx, logn, inverse);
+    if (!pw) { ctx->err = "root table allocation failed"; return ZK_ERR_NOMEM; }
+    HFr ilen;
+    HFr::inv(ilen, HFr((unsigned long long) len));
+    static bool attr_set = false;
+    if (!attr_set) {
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_batch), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+    }
+    const uint32_t threads = std::min<uint32_t>(1024, std::max<uint32_t>(64, len / 2));
+    prof_begin(ctx, PC_MISC, 64.0 * len * count);
+    hipLaunchKernelGGL(k_ntt_batch, dim3((uint32_t) count), dim3(threads), (size_t) len * 32, ctx->stream, D.val, P.val, pw, logn, in_len, out_len,
+                       to_dev(ilen), inverse ? 1 : 0);
+    prof_end(ctx, PC_MISC);
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_witness_rerun(zk_ctx *ctx, const uint64_t *picture, uint64_t n_picture, uint64_t *ranges, uint32_t n_ranges,
+                                    uint64_t *last_layer, uint64_t n_last) {
+    CHECK_READY();
+    if (!ctx->wp_ready) { ctx->err = "no witness program on this context"; return ZK_ERR_STATE; }
+    dev_layer &L0 = ctx->L[0];
+    if (!picture || !n_picture || n_picture > L0.d.size || n_ranges != ctx->wp_n_ranges || (n_ranges && !ranges) ||
+        (last_layer && n_last > ctx->L.back().d.size))
+        return ZK_ERR_ARG;
+    int32_t rc;
+    ZK_HIP(hipMemcpyAsync(L0.val, picture, n_picture * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemsetAsync(ctx->wp_ranges, 0, (2 * (size_t) n_ranges + 1) * 8, ctx->stream));
+    uint32_t *flags = (uint32_t *) (ctx->wp_ranges + 2 * (size_t) n_ranges);
+    uint32_t range_k = 0;
+    for (const zk_witness_step &st : ctx->wp_steps) {
+        dev_layer &D = ctx->L[st.layer];
+        if (st.what == 0) {
+            const uint64_t n = st.op_end - st.op_begin;
+            if (!n) continue;
+            ZK_LAUNCH(PC_MISC, 0.0, k_witness_aux, dim3(grid_for(n)), dim3(ZK_BLOCK), L0.val, (const fr_t *) D.val, (const wit_op *) ctx->wp_ops + st.op_begin, n,
+                      ctx->wp_windows ? ctx->wp_windows + st.win_begin : nullptr, (uint32_t) st.win, flags);
+        } else if (st.what == 2) {
+            ZK_LAUNCH(PC_MISC, 0.0, k_witness_range, dim3(grid_for(D.d.size, 512)), dim3(ZK_BLOCK), ctx->wp_ranges + 2 * (size_t) range_k, (const fr_t *) D.val,
+                      (uint64_t) D.d.size, flags);
+            ++range_k;
+        } else {
+            const dev_layer &P = ctx->L[st.layer - 1];
+            if (D.d.ty == ZK_FFT || D.d.ty == ZK_IFFT) {
+                if ((rc = resident_ntt(ctx, D, P))) return rc;
+            } else if (D.d.ty == ZK_DOT_PROD) {
+                const int fb = D.d.fft_bit_length;
+                const uint64_t len = 1ull << fb, n_out = D.d.size >> fb;
+                for (uint64_t g0 = 0; g0 < n_out; g0 += 32768) {
+                    const uint32_t ng = (uint32_t) std::min<uint64_t>(32768, n_out - g0);
+                    dim3 grid((uint32_t) ((len + ZK_BLOCK - 1) / ZK_BLOCK), ng);
+                    ZK_LAUNCH(PC_DOT, 0.0, k_dot_witness, grid, dim3(ZK_BLOCK), D.val + g0 * len, (const fr_t *) P.val, (const gate_rec *) D.ev_dot, D.ev_dot_ptr + g0, fb);
+                }
+            } else {
+                const uint64_t n_out = D.d.size;
+                fr_t *dA = ctx->wp_tmp, *dB = dA + n_out;
+                ZK_HIP(hipMemsetAsync(dA, 0, 2 * n_out * 32, ctx->stream));
+                if (D.n_ev_uni) {
+                    const uint64_t blocks = (D.n_ev_uni + ZK_BLOCK - 1) / ZK_BLOCK;
+                    ZK_LAUNCH(PC_GATE, 44.0 * (double) D.n_ev_uni, k_eval_uni, dim3((uint32_t) blocks), dim3(ZK_BLOCK), dA, ctx->wp_carry_key, ctx->wp_carry_val,
+                              (const uni_gate_dev *) D.ev_uni, D.n_ev_uni, (const fr_t *) L0.val, (const fr_t *) P.val, (const fr_t *) ctx->two_mul);
+                    ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup, dim3(grid_for(2 * blocks)), dim3(ZK_BLOCK), dA, ctx->wp_carry_key, ctx->wp_carry_val, 2 * blocks);
+                }
+                if (D.n_ev_bin) {
+                    const uint64_t blocks = (D.n_ev_bin + ZK_BLOCK - 1) / ZK_BLOCK;
+                    ZK_LAUNCH(PC_GATE, 80.0 * (double) D.n_ev_bin, k_eval_bin, dim3((uint32_t) blocks), dim3(ZK_BLOCK), dB, ctx->wp_carry_key, ctx->wp_carry_val,
+                              (const bin_gate_dev *) D.ev_bin, D.n_ev_bin, (const fr_t *) L0.val, (const fr_t *) P.val, (const fr_t *) ctx->two_mul);
+                    ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup, dim3(grid_for(2 * blocks)), dim3(ZK_BLOCK), dB, ctx->wp_carry_key, ctx->wp_carry_val, 2 * blocks);
+                }
+                const HFr sc = H(D.d.scale);
+                ZK_LAUNCH(PC_MISC, 0.0, k_eval_combine, dim3(grid_for(n_out)), dim3(ZK_BLOCK), D.val, (const fr_t *) dA, (const fr_t *) dB, to_dev(sc),
+                          sc == HFr::one() ? 0 : 1, n_out);
+            }
+        }
+    }
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpyAsync(ctx->h_wp_ranges, ctx->wp_ranges, (2 * (size_t) n_ranges + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (last_layer && n_last) ZK_HIP(hipMemcpyAsync(last_layer, ctx->L.back().val, n_last * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    for (uint32_t k = 0; k < 2 * n_ranges; ++k) ranges[k] = ctx->h_wp_ranges[k];
+    if (ctx->h_wp_ranges[2 * (size_t) n_ranges] & WIT_FLAG_WIDE) { ctx->err = "a layer value does not fit 63 bits"; return ZK_ERR_STATE; }
     return ZK_OK;
 }
 

@@ -1,6 +1,7 @@
 // C entry points of libzkcnn_host.so (include/zkcnn_api.h): circuit + witness on the host, the
 // prover on the GPU, the reference verifier driving it.
 #include <stdexcept>
+#include <cstddef>
 #include "session.hpp"
 #include "verifier_alias.hpp"
 
@@ -83,10 +84,37 @@ private:
     prover *p;
 };
 
+static_assert(sizeof(witnessOp) == sizeof(zk_witness_op) && sizeof(witnessStep) == sizeof(zk_witness_step) && offsetof(witnessStep, win) == offsetof(zk_witness_step, win) &&
+              offsetof(witnessOp, shift) == offsetof(zk_witness_op, shift), "the recorded witness program crosses the C-ABI as it is");
+
 struct gpuSession : public sessionT<prover> {
     explicit gpuSession(int device) : sessionT<prover>(device), dev(device), va(&p) { vaccel = &va; }
     int dev;
     hipVerifierAccel va;
+
+    // the next picture on the resident circuit: 0 = done, 1 = other input scale (untouched), 2 = other activation scale (values stale)
+    int newImage(const vector<double> &pixels) {
+        if (!nn || nn->program().steps.empty()) throw std::runtime_error("this session has no witness program (verifier-only session?)");
+        vector<F> picture;
+        if (!nn->quantisePicture(pixels, picture)) return 1;
+        const witnessProgram &pg = nn->program();
+        if (picture.size() != pg.picture_values) throw std::runtime_error("picture size differs from the circuit's");
+        if (!p.hasWitnessProgram())
+            p.uploadWitnessProgram(reinterpret_cast<const zk_witness_op *>(pg.ops.data()), pg.ops.size(), pg.windows.data(), pg.windows.size(),
+                                   reinterpret_cast<const zk_witness_step *>(pg.steps.data()), pg.steps.size());
+        size_t n_ranges = 0;
+        for (const witnessStep &st : pg.steps) n_ranges += st.what == witnessStep::RANGE;
+        vector<u64> raw;
+        vector<F> last;
+        has_witness = false;
+        p.rerunWitness(picture, raw, n_ranges, last);
+        vector<std::pair<u64, u64>> ranges(n_ranges);
+        for (size_t k = 0; k < n_ranges; ++k) ranges[k] = std::make_pair(raw[2 * k], raw[2 * k + 1]);
+        if (!nn->rangesReproduceScales(ranges)) return 2;
+        nn->setInferenceFrom(last);
+        has_witness = true;
+        return 0;
+    }
 };
 
 extern "C" {
@@ -154,6 +182,29 @@ int32_t zkcnn_session_verify(void *session, uint64_t seed, uint32_t mode, const 
         std::snprintf(out->message, sizeof(out->message), "%s", e.what());
         return -2;
     }
+}
+
+int32_t zkcnn_session_new_image(void *session, uint64_t picture_seed, const double *pixels, uint64_t n_pixels, double *ms) {
+    if (!session) return -1;
+    gpuSession *s = (gpuSession *) session;
+    try {
+        const double t0 = gpuSession::now();
+        if (!s->nn) return -1;
+        vector<double> px = pixels ? vector<double>(pixels, pixels + n_pixels) : s->nn->syntheticPicture(picture_seed);
+        int rc = s->newImage(px);
+        if (ms) *ms = 1e3 * (gpuSession::now() - t0);
+        return rc;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkcnn_session_new_image: %s\n", e.what());
+        return -2;
+    }
+}
+
+int64_t zkcnn_session_synthetic_picture(void *session, uint64_t picture_seed, double *pixels, uint64_t cap) {
+    if (!session || !((gpuSession *) session)->nn) return -1;
+    vector<double> px = ((gpuSession *) session)->nn->syntheticPicture(picture_seed);
+    for (size_t i = 0; i < px.size() && i < cap; ++i) pixels[i] = px[i];
+    return (int64_t) px.size();
 }
 
 void zkcnn_session_destroy(void *session) { delete (gpuSession *) session; }

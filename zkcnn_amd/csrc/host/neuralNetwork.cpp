@@ -21,15 +21,16 @@ private:
 
 class synthSource : public dataSource {
 public:
-    explicit synthSource(u64 seed) { g.seed(seed); }
+    synthSource(u64 seed, u64 picture_seed) : own_picture(picture_seed != 0) { g.seed(seed); if (own_picture) gp.seed(picture_seed); }
     double next(kind k, i64 fan_in) override {
         double u = g.nextUnit();
-        if (k == PICTURE) return u;
+        if (k == PICTURE) return own_picture ? gp.nextUnit() : u;
         double bound = 1.0 / std::sqrt((double) std::max<i64>(fan_in, 1));
         return (2.0 * u - 1.0) * bound;
     }
 private:
-    zkff::Xoshiro g;
+    zkff::Xoshiro g, gp;
+    bool own_picture;
 };
 
 } // namespace
@@ -43,7 +44,14 @@ neuralNetwork::neuralNetwork(i64 psize_x, i64 psize_y, i64 pchannel, i64 pparall
     if (!i_filename.empty()) src.reset(new fileSource(i_filename));
 }
 
-void neuralNetwork::useSyntheticData(u64 seed) { src.reset(new synthSource(seed)); }
+void neuralNetwork::useSyntheticData(u64 seed, u64 picture_seed) { src.reset(new synthSource(seed, picture_seed)); }
+
+vector<double> neuralNetwork::syntheticPicture(u64 picture_seed) const {
+    synthSource s(0, picture_seed);
+    vector<double> px((size_t) (pic_channel * pic_size_x * pic_size_y));
+    for (double &x : px) x = s.next(dataSource::PICTURE, 1);
+    return px;
+}
 
 // ---------------------------------------------------------------------------------------------
 // sizing
@@ -140,6 +148,8 @@ void neuralNetwork::build(layeredCircuit &C, vector<vector<F>> &val, bool only_c
     two_mul = C.two_mul.data();
     n_two_mul = C.two_mul.size();
     in_dirty_lo = 0;
+    prog.clear();
+    prog.picture_values = (u64) (pic_size_x * pic_size_y * pic_channel * pic_parallel);
 
     i64 layer_id = 0;
     emitInput(C.circuit[layer_id++]);
@@ -270,25 +280,64 @@ void neuralNetwork::loadBias(i64 first_id) {
     }
 }
 
+// ---- recording of the witness program (neuralNetwork.hpp: witnessProgram) ----
+void neuralNetwork::logOp(witnessOp::kind k, i64 src_layer, i64 src, i64 dst, i64 shift) {
+    // consecutive operations form one step as long as they may run side by side: same source layer, and a running maximum (which
+    // later operations of the same step would read) never shares a step with anything else
+    const bool fresh = prog.steps.empty() || prog.steps.back().what != witnessStep::AUX || prog.steps.back().layer != (i32) src_layer ||
+                       ((prog.ops[prog.steps.back().op_begin].op == witnessOp::MAX) != (k == witnessOp::MAX)) ||
+                       ((prog.ops[prog.steps.back().op_begin].op == witnessOp::SUM_BIT) != (k == witnessOp::SUM_BIT));
+    if (fresh) {
+        witnessStep st;
+        std::memset(&st, 0, sizeof(st));
+        st.what = witnessStep::AUX;
+        st.layer = (i32) src_layer;
+        st.op_begin = st.op_end = prog.ops.size();
+        st.win_begin = prog.windows.size();
+        prog.steps.push_back(st);
+    }
+    witnessOp op = {(u32) src, (u32) dst, (u8) src_layer, (u8) k, (u8) shift, 0};
+    prog.ops.push_back(op);
+    prog.steps.back().op_end = prog.ops.size();
+}
+void neuralNetwork::logEval(i64 layer_id) {
+    witnessStep st;
+    std::memset(&st, 0, sizeof(st));
+    st.what = witnessStep::EVAL;
+    st.layer = (i32) layer_id;
+    prog.steps.push_back(st);
+}
+
 void neuralNetwork::putBit(i64 layer_id, i64 idx, i64 dst, i64 shift) {
     if (structure_only) return;
+    logOp(witnessOp::BIT, layer_id, idx, dst, shift);
     i64 mag = std::llabs((*vals)[layer_id].at(idx).getInt64());
     touch0(dst);
     (*vals)[0].at(dst) = F((i64) ((mag >> shift) & 1));
 }
-void neuralNetwork::putFieldBit(const F &data, i64 dst, i64 shift) {
+void neuralNetwork::putFieldBit(const F &data, i64 dst, i64 shift, i64 src_layer, const vector<u32> &window, bool first_of_window) {
     if (structure_only) return;
+    {
+        const size_t steps_before = prog.steps.size();
+        logOp(witnessOp::SUM_BIT, src_layer, 0, dst, shift);
+        witnessStep &st = prog.steps.back();
+        if (prog.steps.size() != steps_before) st.win = (i32) window.size();
+        if (first_of_window) prog.windows.insert(prog.windows.end(), window.begin(), window.end());
+        prog.ops.back().src = (u32) ((prog.windows.size() - st.win_begin) / window.size() - 1);      // the window inserted last
+    }
     i64 mag = std::llabs(data.getInt64());
     touch0(dst);
     (*vals)[0].at(dst) = F((i64) ((mag >> shift) & 1));
 }
 void neuralNetwork::putSign(i64 layer_id, i64 idx, i64 dst) {
     if (structure_only) return;
+    logOp(witnessOp::SIGN, layer_id, idx, dst, 0);
     touch0(dst);
     (*vals)[0].at(dst) = (*vals)[layer_id].at(idx).isNegative() ? F_ONE : F_ZERO;
 }
 void neuralNetwork::putMax(i64 layer_id, i64 idx, i64 dst) {
     if (structure_only) return;
+    logOp(witnessOp::MAX, layer_id, idx, dst, 0);
     const F &x = (*vals)[layer_id].at(idx);
     F clamped = x.isNegative() ? F_ZERO : x;
     touch0(dst);
@@ -298,6 +347,7 @@ void neuralNetwork::putMax(i64 layer_id, i64 idx, i64 dst) {
 // value of every gate of a generic layer (reference src/neuralNetwork.cpp:918-935)
 void neuralNetwork::evalGates(const layer &L, i64 layer_id) {
     if (structure_only) return;
+    logEval(layer_id);
     auto &val = *vals;
     auto &out = val[layer_id];
     out.assign(L.size, F_ZERO);
@@ -328,6 +378,7 @@ void neuralNetwork::evalGates(const layer &L, i64 layer_id) {
 // per-frequency channel contraction (reference src/neuralNetwork.cpp:937-948)
 void neuralNetwork::evalDotProd(const layer &L, i64 layer_id) {
     if (structure_only) return;
+    logEval(layer_id);
     auto &val = *vals;
     auto &out = val[layer_id];
     out.assign(L.size, F_ZERO);
@@ -347,6 +398,7 @@ void neuralNetwork::evalDotProd(const layer &L, i64 layer_id) {
 // and keep the first half (reference src/neuralNetwork.cpp:950-965)
 void neuralNetwork::evalTransform(const layer &L, i64 layer_id) {
     if (structure_only) return;
+    logEval(layer_id);
     auto &val = *vals;
     const size_t len = (size_t) 1 << L.fft_bit_length, lenh = len >> 1;
     auto &out = val[layer_id];
@@ -394,8 +446,59 @@ int neuralNetwork::nextScaleBits(i64 layer_id) {
         else { F nx = -x; if (nx > mn) mn = nx; }
     }
     i64 range = (mx + mn).getInt64();
-    double real_scale = range / std::exp2(x_bit + w_bit);
-    return logged((int) std::log2(((1 << (Q - 1)) - 1) / real_scale));
+    witnessStep st;
+    std::memset(&st, 0, sizeof(st));
+    st.what = witnessStep::RANGE;
+    st.layer = (i32) layer_id;
+    st.bits = x_bit + w_bit;
+    st.scale_index = (i32) scale_log.size();
+    prog.steps.push_back(st);
+    return logged(scaleFromRange(range, x_bit + w_bit));
+}
+int neuralNetwork::scaleFromRange(i64 range, int bits) const {
+    double real_scale = range / std::exp2(bits);
+    return (int) std::log2(((1 << (Q - 1)) - 1) / real_scale);
+}
+
+bool neuralNetwork::quantisePicture(const vector<double> &pixels, vector<F> &out) const {
+    const i64 n = pic_channel * pic_size_x * pic_size_y;
+    if ((i64) pixels.size() != n || scale_log.empty()) return false;
+    double mx = -10000, mn = 10000;
+    for (double x : pixels) { mx = std::max(mx, x); mn = std::min(mn, x); }
+    if (!(mx > mn) || quantBits(mx, mn) != scale_log[0]) return false;
+    out.resize((size_t) (n * pic_parallel));
+    size_t pos = 0;
+    for (i64 p = 0; p < pic_parallel; ++p)
+        for (i64 i = 0; i < n; ++i) out[pos++] = F((i64) (pixels[i] * std::exp2(scale_log[0])));
+    return true;
+}
+
+bool neuralNetwork::rangesReproduceScales(const vector<std::pair<u64, u64>> &ranges) const {
+    size_t k = 0;
+    for (const witnessStep &st : prog.steps) {
+        if (st.what != witnessStep::RANGE) continue;
+        if (k >= ranges.size() || st.scale_index < 0 || (size_t) st.scale_index >= scale_log.size()) return false;
+        if ((ranges[k].first >> 62) || (ranges[k].second >> 62)) return false;
+        const i64 range = (i64) (ranges[k].first + ranges[k].second);
+        ++k;
+        if (range <= 0 || scaleFromRange(range, st.bits) != scale_log[st.scale_index]) return false;
+    }
+    return k == ranges.size();
+}
+
+void neuralNetwork::setInferenceFrom(const vector<F> &last_layer) {
+    infer_result.clear();
+    if (full_conn.empty()) return;
+    const int n_class = (int) full_conn.back().channel_out;
+    for (int p = 0; p < pic_parallel; ++p) {
+        int k = -1;
+        F best = F_ZERO;
+        for (int c = 0; c < n_class; ++c) {
+            const F &t = last_layer.at(matIdx(p, c, n_class));
+            if (!t.isNegative() && (k == -1 || best < t)) { k = c; best = t; }
+        }
+        infer_result.push_back(k);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -624,17 +727,19 @@ void neuralNetwork::emitAvgPool(layer &L, i64 &layer_id) {
                 for (i64 y = 0; y + pool_sz <= ny_out; y += pool_stride) {
                     i64 g = tesIdx(p, co, x >> pool_stride_bl, y >> pool_stride_bl, channel_out, new_nx_in, new_ny_in);
                     F sum = F_ZERO;
+                    vector<u32> window;
                     for (i64 tx = x; tx < x + pool_sz; ++tx)
                         for (i64 ty = y; ty < y + pool_sz; ++ty) {
                             i64 u = tesIdx(p, co, tx, ty, channel_out, nx_out, ny_out);
                             L.uni_gates.emplace_back((u32) g, (u32) u, (u8) (layer_id - 1), (u8) 0);
                             if (!structure_only) sum = sum + val[layer_id - 1][u];
+                            window.push_back((u32) u);
                         }
                     // subtract the remainder bits so that the division by pool_sz^2 is exact
                     for (i64 k = 0; k < dbl; ++k) {
                         i64 idx = matIdx(g, k, dbl), u = first_gate_id + idx, g_bit = zero_start + idx;
                         L.uni_gates.emplace_back((u32) g, (u32) u, (u8) 0, (u8) (dbl - k + Q_BIT_SIZE));
-                        putFieldBit(sum, u, dbl - k - 1);
+                        putFieldBit(sum, u, dbl - k - 1, layer_id - 1, window, k == 0);
                         L.bin_gates.emplace_back((u32) g_bit, (u32) u, (u32) u, (u8) 0, (u8) 0);
                         L.uni_gates.emplace_back((u32) g_bit, (u32) u, (u8) 0, (u8) (Q_BIT_SIZE + 1));
                     }

@@ -59,6 +59,36 @@ public:
                        size_t n_prev, const F *two_mul, size_t n_two_mul, const F &scale) = 0;
 };
 
+// ---- the witness as a PROGRAM ("a new picture without the host round trip of val") ----
+// The circuit's wiring never depends on the picture, only its quantisation scales do. A normal build therefore records, next to the
+// circuit, how layer 0's auxiliary witnesses come out of the layer values: which bit / sign / running maximum / window sum of which
+// value goes where, and after which layers the range of the activations fixes the next scale. A backend that keeps the circuit and
+// the values resident (the HIP prover: zk_witness_program_upload / zk_witness_rerun) replays that program for the next picture; the
+// host then only quantises the picture and checks that every recorded scale still comes out the same (else: rebuild).
+struct witnessOp {
+    enum kind : u8 { BIT = 0, SIGN = 1, MAX = 2, SUM_BIT = 3 };
+    u32 src;         // BIT / SIGN / MAX: index in layer src_layer; SUM_BIT: number of the window whose entries are summed
+    u32 dst;         // index in layer 0
+    u8 src_layer, op, shift, pad_;
+};
+struct witnessStep {
+    enum kind : i32 { AUX = 0, EVAL = 1, RANGE = 2 };
+    i32 what;
+    i32 layer;           // EVAL: the layer evaluated; RANGE: the layer scanned; AUX: the layer its operations read
+    u64 op_begin, op_end;    // AUX: span of `ops`
+    u64 win_begin;       // AUX with SUM_BIT: first entry of `windows` of window 0 of this step
+    i32 win;             // entries per window
+    i32 bits;            // RANGE: x_bit + w_bit of the accumulator; the scale it must reproduce is scales()[scale_index]
+    i32 scale_index, pad_;
+};
+struct witnessProgram {
+    vector<witnessOp> ops;
+    vector<u32> windows;
+    vector<witnessStep> steps;
+    u64 picture_values = 0;      // entries [0, picture_values) of layer 0 are the picture (pic_parallel copies)
+    void clear() { ops.clear(); windows.clear(); steps.clear(); picture_values = 0; }
+};
+
 class neuralNetwork {
 public:
     neuralNetwork(i64 psize_x, i64 psize_y, i64 pchannel, i64 pparallel, const string &i_filename,
@@ -67,7 +97,21 @@ public:
 
     // replace the input file by a seeded synthetic stream (picture ~ U[0,1), weights/biases ~ U(-k,k),
     // k = 1/sqrt(fan_in)); must be called before create()
-    void useSyntheticData(u64 seed);
+    // picture_seed != 0: the picture comes from its own stream (the weight stream still skips as many draws), so that sessions with the
+    // same `seed` share weights and differ in the picture
+    void useSyntheticData(u64 seed, u64 picture_seed = 0);
+    // the pixel values synthetic stream `picture_seed` yields for this model's picture (what a caller would read from a file)
+    vector<double> syntheticPicture(u64 picture_seed) const;
+
+    // ---- next picture on a resident circuit ----
+    const witnessProgram &program() const { return prog; }
+    // quantises `pixels` (channel, x, y order; one picture, replicated pic_parallel times like the reference does) with the scale the
+    // circuit was built for; false if this picture's range asks for another scale (the circuit would differ: rebuild)
+    bool quantisePicture(const vector<double> &pixels, vector<F> &out) const;
+    // ranges[k] = (largest non-negative value, largest magnitude of a negative value) of the layer RANGE step k scanned, as the
+    // resident backend found them: true iff every recorded scale comes out the same
+    bool rangesReproduceScales(const vector<std::pair<u64, u64>> &ranges) const;
+    void setInferenceFrom(const vector<F> &last_layer);
     void setWitnessAccel(witnessAccel *a) { accel = a; }
 
     // The circuit's shape depends on the data only through the quantisation scales (bits kept per layer): a build records them,
@@ -122,6 +166,9 @@ private:
         if (v < 0 || v > 62) throw std::runtime_error("statement: quantisation scale out of range");      // untrusted input (proof file)
         return v;
     }
+    witnessProgram prog;
+    void logOp(witnessOp::kind k, i64 src_layer, i64 src, i64 dst, i64 shift);
+    void logEval(i64 layer_id);
     vector<vector<F>> *vals;       // == &pr.val while building
     i64 in_dirty_lo = 0;           // layer-0 entries from here on are newer than the accelerator's copy
     size_t n_two_mul = 0;
@@ -136,6 +183,7 @@ private:
     i64 fftBits() const;
     i64 poolAuxSize() const;
     int nextScaleBits(i64 layer_id);
+    int scaleFromRange(i64 range, int bits) const;
 
     // witness helpers
     void loadPicture(layer &L);
@@ -144,7 +192,7 @@ private:
     void loadBias(i64 first_id);
     int quantBits(double mx, double mn) const;
     void putBit(i64 layer_id, i64 idx, i64 dst, i64 shift);
-    void putFieldBit(const F &data, i64 dst, i64 shift);
+    void putFieldBit(const F &data, i64 dst, i64 shift, i64 src_layer, const vector<u32> &window, bool first_of_window);
     void putSign(i64 layer_id, i64 idx, i64 dst);
     void putMax(i64 layer_id, i64 idx, i64 dst);
     void evalGates(const layer &L, i64 layer_id);

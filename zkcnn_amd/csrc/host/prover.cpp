@@ -69,48 +69,70 @@ void prover::ensureContext() {
     }
 }
 
+vector<zk_layer_desc> prover::layerDescs() const {
+    static_assert(sizeof(layerType) == sizeof(int), "layerType is passed as int32");
+    vector<zk_layer_desc> desc(C.size);
+    for (int i = 0; i < C.size; ++i) {
+        const layer &L = C.circuit[i];
+        zk_layer_desc &d = desc[i];
+        std::memset(&d, 0, sizeof(d));
+        d.ty = (int32_t) L.ty;
+        d.size = L.size;
+        for (int b = 0; b < 2; ++b) {
+            d.size_u[b] = L.size_u[b]; d.size_v[b] = L.size_v[b];
+            d.bit_length_u[b] = L.bit_length_u[b]; d.bit_length_v[b] = L.bit_length_v[b];
+        }
+        d.bit_length = L.bit_length;
+        d.max_bl_u = L.max_bl_u; d.max_bl_v = L.max_bl_v;
+        d.fft_bit_length = L.fft_bit_length;
+        d.need_phase2 = L.need_phase2;
+        d.zero_start_id = L.zero_start_id;
+        std::memcpy(d.scale, &L.scale, 32);
+        // layer 0 only carries identity gates that the sumcheck never walks
+        d.uni_gates = i ? reinterpret_cast<const zk_uni_gate *>(L.uni_gates.data()) : nullptr;
+        d.n_uni = i ? L.uni_gates.size() : 0;
+        d.bin_gates = i ? reinterpret_cast<const zk_bin_gate *>(L.bin_gates.data()) : nullptr;
+        d.n_bin = i ? L.bin_gates.size() : 0;
+        d.ori_id_u = L.ori_id_u.data();
+        d.ori_id_v = L.ori_id_v.data();
+    }
+    return desc;
+}
+
+void prover::uploadWitnessProgram(const zk_witness_op *ops, size_t n_ops, const u32 *windows, size_t n_windows, const zk_witness_step *steps, size_t n_steps) {
+    if (!ctx || !resident) throw std::runtime_error("uploadWitnessProgram: the circuit is not resident (call init() first)");
+    vector<zk_layer_desc> desc = layerDescs();
+    check(zk_witness_program_upload(ctx, ops, n_ops, windows, n_windows, steps, (uint32_t) n_steps, desc.data(), C.size), "zk_witness_program_upload");
+    program_resident = true;
+}
+
+void prover::rerunWitness(const vector<F> &picture, vector<u64> &ranges, size_t n_ranges, vector<F> &last_layer) {
+    if (!program_resident) throw std::runtime_error("rerunWitness: no witness program on the GPU");
+    ranges.assign(2 * n_ranges, 0);
+    last_layer.assign(C.circuit[C.size - 1].size, F_ZERO);
+    releaseHostValues();           // stale from here on
+    check(zk_witness_rerun(ctx, U(picture[0]), picture.size(), reinterpret_cast<uint64_t *>(ranges.data()), (uint32_t) n_ranges, U(last_layer[0]), last_layer.size()), "zk_witness_rerun");
+}
+
 // prover::init (reference src/prover.cpp:17-21) + residency of C and val in HBM
 void prover::init() {
     ensureContext();
     if (!resident) {
         upload_timer.start();
         // a context holds one circuit; a changed circuit gets a fresh one
-        static_assert(sizeof(layerType) == sizeof(int), "layerType is passed as int32");
-        vector<zk_layer_desc> desc(C.size);
-        for (int i = 0; i < C.size; ++i) {
-            const layer &L = C.circuit[i];
-            zk_layer_desc &d = desc[i];
-            std::memset(&d, 0, sizeof(d));
-            d.ty = (int32_t) L.ty;
-            d.size = L.size;
-            for (int b = 0; b < 2; ++b) {
-                d.size_u[b] = L.size_u[b]; d.size_v[b] = L.size_v[b];
-                d.bit_length_u[b] = L.bit_length_u[b]; d.bit_length_v[b] = L.bit_length_v[b];
-            }
-            d.bit_length = L.bit_length;
-            d.max_bl_u = L.max_bl_u; d.max_bl_v = L.max_bl_v;
-            d.fft_bit_length = L.fft_bit_length;
-            d.need_phase2 = L.need_phase2;
-            d.zero_start_id = L.zero_start_id;
-            std::memcpy(d.scale, &L.scale, 32);
-            // layer 0 only carries identity gates that the sumcheck never walks
-            d.uni_gates = i ? reinterpret_cast<const zk_uni_gate *>(L.uni_gates.data()) : nullptr;
-            d.n_uni = i ? L.uni_gates.size() : 0;
-            d.bin_gates = i ? reinterpret_cast<const zk_bin_gate *>(L.bin_gates.data()) : nullptr;
-            d.n_bin = i ? L.bin_gates.size() : 0;
-            d.ori_id_u = L.ori_id_u.data();
-            d.ori_id_v = L.ori_id_v.data();
-        }
+        vector<zk_layer_desc> desc = layerDescs();
         if (zk_upload_circuit(ctx, desc.data(), C.size, U(C.two_mul[0]), (int) C.two_mul.size()) != ZK_OK) {
             // the context already holds another circuit: start over with a new one
             string first_err = zk_last_error(ctx);
             poly_p.reset();
             zk_ctx_destroy(ctx);
             ctx = nullptr;
+            program_resident = false;
             ensureContext();
             if (zk_upload_circuit(ctx, desc.data(), C.size, U(C.two_mul[0]), (int) C.two_mul.size()) != ZK_OK)
                 throw std::runtime_error("zk_upload_circuit failed: " + string(zk_last_error(ctx)) + " / " + first_err);
         }
+        if ((int) val.size() != C.size) throw std::runtime_error("prover::init: no host values to upload (released after an earlier upload)");
         for (int i = 0; i < C.size; ++i)
             check(zk_upload_layer_values(ctx, i, val[i].empty() ? nullptr : U(val[i][0]), val[i].size()), "zk_upload_layer_values");
         resident = true;

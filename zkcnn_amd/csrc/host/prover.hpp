@@ -71,7 +71,18 @@ public:
     void attachFiatShamir(const uint32_t *state, const uint64_t *pending);
     void tailStats(uint64_t &rounds, uint64_t &phases) const;
     void setHostTail(int log_entries);          // hybrid tail (include/zkcnn_hip.h: zk_set_host_tail); < 0 = off
+
+    // ---- the next picture on the resident circuit (include/zkcnn_hip.h: zk_witness_program_upload / zk_witness_rerun). The program is
+    // what the circuit generator recorded (host/neuralNetwork.hpp: witnessProgram, records layout-equal to the C-ABI's). After a rerun
+    // the values in HBM belong to the new picture; the host copy `val` is dropped (nothing on the proving path reads it). ----
+    void uploadWitnessProgram(const zk_witness_op *ops, size_t n_ops, const u32 *windows, size_t n_windows, const zk_witness_step *steps, size_t n_steps);
+    bool hasWitnessProgram() const { return program_resident; }
+    // ranges: 2 per RANGE step (largest non-negative value, largest magnitude of a negative one); last_layer: values of the output layer
+    void rerunWitness(const vector<F> &picture, vector<u64> &ranges, size_t n_ranges, vector<F> &last_layer);
+    void releaseHostValues() { vector<vector<F>>().swap(val); }
 private:
+    vector<zk_layer_desc> layerDescs() const;
+    bool program_resident = false;
     hyrax_bls12_381::polyProverBase &zkBackend() override { return *poly_p; }
     const layeredCircuit &zkCircuit() const override { return C; }
     void check(int rc, const char *what) const;

@@ -22,6 +22,7 @@ struct sessionT {
     std::vector<G1> gens;
     string model_name;
     int pic_cnt = 1, pic_x = 0, pic_y = 0, pic_channel = 0;
+    uint64_t data_seed = 0;
     double witness_s = 0;
     string row;
     witnessAccel *accel = nullptr;     // set by the product driver while the witness is generated
@@ -61,7 +62,8 @@ struct sessionT {
         if (!sane(d)) return false;
         nn.reset(makeModel(model_name, d->pic_x, d->pic_y, d->pic_channel, d->pic_cnt));
         if (!nn) return false;
-        nn->useSyntheticData(d->data_seed);
+        data_seed = d->data_seed;
+        nn->useSyntheticData(d->data_seed, d->picture_seed);
         nn->setWitnessAccel(accel);
         double t0 = now();
         nn->create(p, false);
@@ -99,7 +101,7 @@ struct sessionT {
             // shape, a digest of the wiring, the generators) and of all messages received so far
             zkcnn_model_desc d;
             d.model = model_name.c_str();
-            d.pic_x = pic_x; d.pic_y = pic_y; d.pic_channel = pic_channel; d.pic_cnt = pic_cnt; d.data_seed = 0;
+            d.pic_x = pic_x; d.pic_y = pic_y; d.pic_channel = pic_channel; d.pic_cnt = pic_cnt; d.data_seed = 0; d.picture_seed = 0;
             fs.absorbStatement(d, nn->scales(), p.C);
             fs.absorb(pg->digest, 32);
             v.transcript.tap = &fs;
@@ -114,7 +116,7 @@ struct sessionT {
     int prove(uint64_t challenge_seed, uint32_t mode, uint8_t *transcript, uint64_t cap, zkcnn_result *out) {
         std::memset(out, 0, sizeof(*out));
         if (!has_witness) {
-            std::snprintf(out->message, sizeof(out->message), "verifier-only session: nothing to prove");
+            std::snprintf(out->message, sizeof(out->message), "no valid witness: a verifier-only session, or the last new_image call did not succeed");
             return -3;
         }
         double t0 = now();
