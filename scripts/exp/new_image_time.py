@@ -3,7 +3,8 @@ import json
 import sys
 import time
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import zkcnn_amd
 
 s = zkcnn_amd.Session("vgg11", (32, 32, 3), 1, data_seed=4242, picture_seed=1)

@@ -132,6 +132,7 @@ void *zkcnn_session_create(const zkcnn_model_desc *desc, int32_t device) {
             if (!ok) return nullptr;
         }
         s->p.init();                 // residency: circuit + witness to HBM, outside any timed region
+        s->p.releaseHostValues();    // the host copy of every layer's values (0.7 GB for vgg11) has no reader left: proofs and new pictures work on the HBM copy
         return s.release();
     } catch (const std::exception &e) {
         fprintf(stderr, "zkcnn_session_create: %s\n", e.what());
