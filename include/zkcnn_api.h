@@ -102,6 +102,9 @@ int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap);
 /* Product library only: sumcheck rounds / phases the GPU has run by itself in Fiat-Shamir mode so far (include/zkcnn_hip.h: zk_fs_attach) */
 int32_t zkcnn_session_fs_stats(void *session, uint64_t *rounds, uint64_t *phases);
 
+/* Product library only: how many direct-convolution layers of the session's circuit run the factored gate sums (include/zkcnn_hip.h: zk_conv_hint) */
+int32_t zkcnn_session_structured_layers(void *session);
+
 /* Product library only: HIP-event profiler of the GPU kernels (see zk_profile_enable / zk_profile_report in zkcnn_hip.h). */
 int32_t zkcnn_session_profile(void *session, uint32_t class_mask);
 int32_t zkcnn_session_profile_report(void *session, char *buf, uint64_t cap, int32_t reset);

@@ -59,6 +59,20 @@ int32_t zk_device_count(void);
  * scatter kernels need) and sizes all work buffers. two_mul = layeredCircuit::two_mul. */
 int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul,
                           int32_t n_two_mul);
+/* Optional knowledge about direct-convolution layers (layer type NCONV, reference src/neuralNetwork.cpp:240-275 naiveConvLayerFast):
+ * the parameters its gate list was generated from. The upload regenerates the list from them and compares it record by record with
+ * the layer's gates; only on a match (and power-of-two channel counts and picture sides) are the layer's two large gate sums
+ * (reference src/prover.cpp:224-233, 297-305) computed in factored form -- the same field elements for channel_out * channel_in * m^2
+ * products instead of that times the number of positions. A hint that does not match is ignored (generic path). */
+typedef struct {
+    int32_t layer;
+    uint32_t pic_parallel, channel_out, channel_in, nx_in, ny_in, nx_out, ny_out, m, padding, log_stride;
+    uint32_t weight_start;     /* raw layer-0 index of weight (co = 0, ci = 0, 0, 0) */
+} zk_conv_hint;
+int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul, int32_t n_two_mul,
+                                 const zk_conv_hint *hints, uint32_t n_hints);
+/* how many layers run the factored path (after an upload) */
+int32_t zk_structured_layers(const zk_ctx *ctx);
 /* val[layer] (n = layer size); stored zero-padded to 2^bit_length */
 int32_t zk_upload_layer_values(zk_ctx *ctx, int32_t layer, const uint64_t *values, uint64_t n);
 

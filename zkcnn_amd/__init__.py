@@ -355,6 +355,10 @@ class Session(_SessionBase):
             self.picture_seed = picture_seed
         return rc, ms.value
 
+    def structured_layers(self):
+        """direct-convolution layers whose gate sums run in factored form (hint checked against the gate list at upload)"""
+        return int(self.lib.zkcnn_session_structured_layers(ctypes.c_void_p(self.h)))
+
     def synthetic_picture(self, picture_seed):
         n = self.pic[0] * self.pic[1] * self.pic[2]
         arr = (ctypes.c_double * n)()

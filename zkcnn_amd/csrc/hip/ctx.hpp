@@ -42,6 +42,9 @@ struct dev_layer {
     uint64_t n_ev_uni = 0, n_ev_bin = 0;
     gate_rec *ev_dot = nullptr;
     uint32_t *ev_dot_ptr = nullptr;
+    // direct convolution whose gate list matches the structured pattern (zk_upload_circuit_hinted): its two big gate sums are factored
+    bool conv_ok = false;
+    conv_desc conv;
 };
 
 // one (V, M) bookkeeping-table pair of a sumcheck, ping-pong buffered
@@ -116,6 +119,13 @@ struct zk_ctx {
     void *liu_tabs = nullptr, *h_liu_tabs = nullptr;      // device / pinned host array of liu_table
     uint32_t liu_ntabs = 0;
     std::vector<int> liu_tab_layer, liu_tab_side;           // table id -> (layer, 0 = u / 1 = v)
+
+    // structured convolution layers (conv_kernels.cuh): small eq tables, their descriptors (device + pinned host, one set per phase), work buffers
+    fr_t *conv_small = nullptr;
+    void *conv_tabs = nullptr, *h_conv_tabs = nullptr;
+    fr_t *conv_wa = nullptr, *conv_part = nullptr, *conv_e = nullptr, *conv_ae = nullptr;
+    int conv_K = 0;
+    uint32_t conv_layers = 0;
 
     msm_state *msm = nullptr;
     msm_state *vmsm = nullptr;     // verifier-owned second table set (zk_verifier_msm over arbitrary points)

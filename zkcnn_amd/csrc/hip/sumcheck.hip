@@ -11,6 +11,7 @@
 #include "kernels.cuh"
 #include "fs_tail.cuh"
 #include "witness_kernels.cuh"
+#include "conv_kernels.cuh"
 
 static std::string g_create_err;
 
@@ -119,6 +120,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     if (ctx->h_tail) hipHostFree(ctx->h_tail);
     if (ctx->h_liu_tabs) hipHostFree(ctx->h_liu_tabs);
     if (ctx->h_wp_ranges) hipHostFree(ctx->h_wp_ranges);
+    if (ctx->h_conv_tabs) hipHostFree(ctx->h_conv_tabs);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -251,9 +253,69 @@ static void counting_sort(std::vector<gate_rec> &recs, uint32_t nkeys) {
     recs.swap(out);
 }
 
+static uint32_t ceil_log2(uint32_t x) {
+    uint32_t b = 0;
+    while ((1ull << b) < x) ++b;
+    return b;
+}
+static int log2_exact(uint32_t x) {          // -1 unless x is a power of two
+    if (!x || (x & (x - 1))) return -1;
+    int b = 0;
+    while ((1u << b) < x) ++b;
+    return b;
+}
+// does layer S (with its predecessor P) consist of exactly the gates a direct convolution with these parameters emits?
+static bool conv_hint_matches(const zk_conv_hint &h, const zk_layer_desc &S, const zk_layer_desc &P, conv_desc &c) {
+    static const bool enabled = !(getenv("ZKCNN_CONV_STRUCT") && atoi(getenv("ZKCNN_CONV_STRUCT")) == 0);
+    if (!enabled || S.ty != ZK_NCONV) return false;
+    c.pp = h.pic_parallel; c.CO = h.channel_out; c.CI = h.channel_in; c.nxi = h.nx_in; c.nyi = h.ny_in; c.nxo = h.nx_out; c.nyo = h.ny_out;
+    c.m = h.m; c.pad = h.padding; c.ls = h.log_stride; c.wstart = h.weight_start;
+    c.bx_i = log2_exact(c.nxi); c.by_i = log2_exact(c.nyi); c.bc_i = log2_exact(c.CI);
+    c.bx_o = log2_exact(c.nxo); c.by_o = log2_exact(c.nyo); c.bc_o = log2_exact(c.CO);
+    if (c.bx_i < 0 || c.by_i < 0 || c.bc_i < 0 || c.bx_o < 0 || c.by_o < 0 || c.bc_o < 0 || !c.pp || !c.m || c.m > 16 || c.ls > 4 || c.pad > 16) return false;
+    if (c.bx_i + c.by_i > 12 || c.bx_o + c.by_o > 12 || c.bc_i > 12 || c.bc_o > 12 || c.pp > 4096) return false;
+    const uint64_t n_out = (uint64_t) c.pp * c.CO * c.nxo * c.nyo, n_in = (uint64_t) c.pp * c.CI * c.nxi * c.nyi;
+    // (the previous layer may be longer than the tensor the convolution reads: a RELU / pooling layer keeps its constraint rows behind its outputs)
+    if (n_out != S.size || n_in > P.size || S.size_u[1] != P.size || S.size_v[0] != (uint64_t) c.CO * c.CI * c.m * c.m) return false;
+    if (S.bit_length != c.bx_o + c.by_o + c.bc_o + (int) ceil_log2(c.pp) || S.bit_length_u[1] != P.bit_length) return false;
+    if (S.max_bl_u - (c.bx_i + c.by_i + c.bc_i) > 12 || S.bit_length - (c.bx_o + c.by_o + c.bc_o) > 12) return false;
+    if (((c.nxi + 2 * c.pad - c.m) >> c.ls) + 1 != c.nxo || ((c.nyi + 2 * c.pad - c.m) >> c.ls) + 1 != c.nyo) return false;
+    // every bin gate, in emission order (p, co, ci, window origin, offset inside the window); operands: u in the previous layer, v in layer 0
+    const int64_t lo = -(int64_t) c.pad, Rx = (int64_t) c.nxi + c.pad, Ry = (int64_t) c.nyi + c.pad, st = 1ll << c.ls;
+    uint64_t k = 0;
+    for (uint32_t p = 0; p < c.pp; ++p)
+        for (uint32_t co = 0; co < c.CO; ++co)
+            for (uint32_t ci = 0; ci < c.CI; ++ci)
+                for (int64_t x = lo; x + c.m <= Rx; x += st)
+                    for (int64_t y = lo; y + c.m <= Ry; y += st) {
+                        const uint64_t g = (((uint64_t) p * c.CO + co) * c.nxo + ((x - lo) >> c.ls)) * c.nyo + ((y - lo) >> c.ls);
+                        for (int64_t tx = x; tx < x + c.m; ++tx)
+                            for (int64_t ty = y; ty < y + c.m; ++ty) {
+                                if (tx < 0 || tx >= c.nxi || ty < 0 || ty >= c.nyi) continue;
+                                if (k >= S.n_bin) return false;
+                                const zk_bin_gate &gt = S.bin_gates[k++];
+                                const uint64_t u = (((uint64_t) p * c.CI + ci) * c.nxi + tx) * c.nyi + ty;
+                                const uint64_t v = (uint64_t) c.wstart + (((uint64_t) co * c.CI + ci) * c.m + (tx - x)) * c.m + (ty - y);
+                                if (gt.g != g || gt.u != u || gt.sc != 0 || gt.l != 2 || gt.v >= S.size_v[0] || S.ori_id_v[gt.v] != v) return false;
+                            }
+                    }
+    if (k != S.n_bin) return false;
+    // the only other gates may be uni gates whose operand lives in layer 0 (the biases): they stay on the generic lists
+    for (uint64_t j = 0; j < S.n_uni; ++j)
+        if (S.uni_gates[j].lu != 0) return false;
+    return true;
+}
+
+extern "C" int32_t zk_structured_layers(const zk_ctx *ctx) { return ctx ? (int32_t) ctx->conv_layers : 0; }
+
 extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul,
                                      int32_t n_two_mul) {
-    if (!ctx || !layers || n_layers < 2 || !two_mul || n_two_mul > 512) return ZK_ERR_ARG;
+    return zk_upload_circuit_hinted(ctx, layers, n_layers, two_mul, n_two_mul, nullptr, 0);
+}
+
+extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul,
+                                            int32_t n_two_mul, const zk_conv_hint *hints, uint32_t n_hints) {
+    if (!ctx || !layers || n_layers < 2 || !two_mul || n_two_mul > 512 || (n_hints && !hints)) return ZK_ERR_ARG;
     ZK_HIP(hipSetDevice(ctx->device));
     if (ctx->circuit_ready) { ctx->err = "circuit already uploaded; create a new context"; return ZK_ERR_STATE; }
     int32_t rc;
@@ -421,6 +483,32 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
         if ((rc = zk_dev_alloc(ctx, (void **) &ctx->liu_halves, (size_t) nt * 2 * LIU_HALF_STRIDE * 32))) return rc;
         if ((rc = zk_dev_alloc(ctx, &ctx->liu_tabs, (size_t) nt * sizeof(liu_table)))) return rc;
         ZK_HIP(hipHostMalloc(&ctx->h_liu_tabs, (size_t) nt * sizeof(liu_table)));
+    }
+    // structured convolution layers: hints that reproduce the layer's gate list switch the factored sums on
+    {
+        uint64_t max_wa = 0, max_part = 0, max_ae = 0;
+        for (uint32_t k = 0; k < n_hints; ++k) {
+            const int i = hints[k].layer;
+            if (i < 2 || i >= n_layers) continue;
+            dev_layer &D = ctx->L[i];
+            conv_desc c;
+            if (D.conv_ok || !conv_hint_matches(hints[k], layers[i], layers[i - 1], c)) continue;
+            D.conv = c;
+            D.conv_ok = true;
+            ++ctx->conv_layers;
+            const uint64_t len = (uint64_t) c.CI * c.m * c.m, chunks = (c.CO + 31) / 32;
+            max_wa = std::max(max_wa, 2 * len);
+            max_part = std::max(max_part, chunks * 2 * len);
+            max_ae = std::max<uint64_t>(max_ae, (uint64_t) c.CO * c.m * c.m + c.CI);
+        }
+        if (ctx->conv_layers) {
+            if ((rc = zk_dev_alloc(ctx, (void **) &ctx->conv_small, (size_t) CT_COUNT * CONV_TAB_STRIDE * 32)) ||
+                (rc = zk_dev_alloc(ctx, &ctx->conv_tabs, 2 * CT_COUNT * sizeof(liu_table))) ||
+                (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_wa, max_wa * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_part, max_part * 32)) ||
+                (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_e, 2 * 16 * 16 * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_ae, max_ae * 32)))
+                return rc;
+            ZK_HIP(hipHostMalloc(&ctx->h_conv_tabs, 2 * CT_COUNT * sizeof(liu_table)));
+        }
     }
     // work buffers sized for the largest layer
     ctx->max_table = max_table;
@@ -728,6 +816,71 @@ extern "C" int32_t zk_sumcheck_init(zk_ctx *ctx, const uint64_t alpha[4], const 
     return ZK_OK;
 }
 
+// ---- factored gate sums of a structured convolution layer (conv_kernels.cuh) ----
+static void conv_tab(liu_table &T, const HFr *r, int from, int n, const HFr &init) {
+    T.n = n; T.fh = n >> 1; T.sh = n - (n >> 1); T.pad_ = 0;
+    for (int j = 0; j < n; ++j) T.r.v[j] = to_dev(r[from + j]);
+    T.init = to_dev(init);
+}
+static int32_t conv_small_tables(zk_ctx *ctx, int set) {
+    liu_table *h = (liu_table *) ctx->h_conv_tabs + set * CT_COUNT;
+    liu_table *d = (liu_table *) ctx->conv_tabs + set * CT_COUNT;
+    ZK_HIP(hipMemcpyAsync(d, h, CT_COUNT * sizeof(liu_table), hipMemcpyHostToDevice, ctx->stream));
+    ZK_LAUNCH(PC_EQ, 0.0, k_eq_small_multi, dim3(CT_COUNT), dim3(1024), ctx->conv_small, (const liu_table *) d);
+    return ZK_OK;
+}
+// phase 1: M over the previous layer's table. false in *done if the layer's claims are both zero (the generic path then writes zeros)
+static int32_t conv_phase1(zk_ctx *ctx, const dev_layer &cur, fr_t *M, uint64_t len, const HFr &a0, const HFr &a1, bool *done) {
+    const conv_desc &c = cur.conv;
+    liu_table *T = (liu_table *) ctx->h_conv_tabs;
+    for (int t = 0; t < CT_COUNT; ++t) T[t].n = -1;
+    const int bpos = c.bx_o + c.by_o, bl = cur.d.bit_length;
+    int K = 0;
+    const HFr *pts[2] = {ctx->r_0, ctx->r_1};
+    const HFr inits[2] = {a0, a1};
+    for (int k = 0; k < 2; ++k) {
+        if (inits[k].isZero() || !pts[k]) continue;
+        conv_tab(T[K ? CT_S1 : CT_S0], pts[k], 0, bpos, HFr::one());
+        conv_tab(T[K ? CT_A1 : CT_A0], pts[k], bpos, c.bc_o, HFr::one());
+        conv_tab(T[K ? CT_P1 : CT_P0], pts[k], bpos + c.bc_o, bl - bpos - c.bc_o, inits[k]);
+        ++K;
+    }
+    ctx->conv_K = K;
+    *done = K > 0;
+    if (!K) return ZK_OK;
+    int32_t rc;
+    if ((rc = conv_small_tables(ctx, 0))) return rc;
+    const uint32_t wlen = c.CI * c.m * c.m, per = 32, chunks = (c.CO + per - 1) / per;
+    fr_t *part = chunks == 1 ? ctx->conv_wa : ctx->conv_part;
+    ZK_LAUNCH(PC_GATE, 0.0, k_conv_wa, dim3((wlen + ZK_BLOCK - 1) / ZK_BLOCK, chunks), dim3(ZK_BLOCK), part, (const fr_t *) ctx->L[0].val + c.wstart,
+              (const fr_t *) ctx->conv_small, wlen, c.CO, per, K);
+    if (chunks > 1)
+        ZK_LAUNCH(PC_GATE, 0.0, k_sum_rows, dim3((K * wlen + 63) / 64), dim3(1024), ctx->conv_wa, (const fr_t *) part, K * wlen, chunks);
+    ZK_LAUNCH(PC_GATE, 0.0, k_conv_m1, dim3(grid_for(len)), dim3(ZK_BLOCK), M, (const fr_t *) ctx->conv_wa, (const fr_t *) ctx->conv_small, c, K, len);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+// phase 2: M over the layer-0 subset table of the weights (needs the phase-1 tables of the same layer: S, A, P stay in conv_small)
+static int32_t conv_phase2(zk_ctx *ctx, const dev_layer &cur, fr_t *M, uint64_t len, const HFr *ru) {
+    const conv_desc &c = cur.conv;
+    const int K = ctx->conv_K;
+    liu_table *T = (liu_table *) ctx->h_conv_tabs + CT_COUNT;
+    for (int t = 0; t < CT_COUNT; ++t) T[t].n = -1;
+    const int bpos = c.bx_i + c.by_i;
+    conv_tab(T[CT_D], ru, 0, bpos, HFr::one());
+    conv_tab(T[CT_C], ru, bpos, c.bc_i, HFr::one());
+    conv_tab(T[CT_PU], ru, bpos + c.bc_i, cur.d.max_bl_u - bpos - c.bc_i, HFr::one());
+    int32_t rc;
+    if ((rc = conv_small_tables(ctx, 1))) return rc;
+    const uint32_t mm = c.m * c.m;
+    ZK_LAUNCH(PC_GATE, 0.0, k_conv_e, dim3(mm, K), dim3(ZK_BLOCK), ctx->conv_e, (const fr_t *) ctx->conv_small, c);
+    ZK_LAUNCH(PC_GATE, 0.0, k_conv_ae, dim3((c.CO * mm + c.CI + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), ctx->conv_ae, (const fr_t *) ctx->conv_e,
+              (const fr_t *) ctx->conv_small, c, K, to_dev(ctx->V_u1));
+    ZK_LAUNCH(PC_GATE, 0.0, k_conv_m2, dim3(grid_for(len)), dim3(ZK_BLOCK), M, (const uint32_t *) cur.ori_v, (const fr_t *) ctx->conv_ae, c, cur.d.size_v[0], len);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+}
+
 extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[4]) {
     CHECK_READY();
     const int id = ctx->sumcheck_id;
@@ -784,6 +937,12 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
     for (int b = 0; b < 2; ++b) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
+        ctx->conv_K = 0;
+        if (b == 1 && cur.conv_ok) {
+            bool done = false;
+            if ((rc = conv_phase1(ctx, cur, t.M[0], t.len, ctx->alpha * scale, ctx->beta * scale, &done))) return rc;
+            if (done) continue;
+        }
         if (cur.p1_cov[b] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p1_cov[b], 0, (t.len - cur.p1_cov[b]) * 32, ctx->stream));
         if ((rc = gate_scatter(ctx, t.M[0], cur.p1[b], cur.n_p1[b], cur.n_p1_real[b], 1, cur, prev, cur.n_p1_uni[b], t.len, cur.p1_G[b]))) return rc;
     }
@@ -931,6 +1090,10 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
     for (int b = 0; b < 2; ++b) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
+        if (b == 0 && cur.conv_ok && ctx->conv_K > 0) {
+            if ((rc = conv_phase2(ctx, cur, t.M[0], t.len, ru))) return rc;
+            continue;
+        }
         if (cur.p2_cov[b] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p2_cov[b], 0, (t.len - cur.p2_cov[b]) * 32, ctx->stream));
         if ((rc = gate_scatter(ctx, t.M[0], cur.p2[b], cur.n_p2[b], cur.n_p2_real[b], 2, cur, prev, 0, t.len, cur.p2_G[b], cur.p2_uniform[b]))) return rc;
     }

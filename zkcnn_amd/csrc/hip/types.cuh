@@ -23,3 +23,8 @@ struct __align__(16) gate_rec {
 #define GATE_GROUP 4u
 #define GATE_NOKEY 0xffffffffu
 
+// a direct-convolution layer whose gate list was checked against the pattern of conv_kernels.cuh (sizes, and the bit widths of the index fields)
+struct conv_desc {
+    uint32_t pp, CO, CI, nxi, nyi, nxo, nyo, m, pad, ls, wstart;
+    int32_t bx_i, by_i, bc_i, bx_o, by_o, bc_o;
+};

@@ -222,6 +222,11 @@ int32_t zkcnn_session_fs_stats(void *session, uint64_t *rounds, uint64_t *phases
     return 0;
 }
 
+int32_t zkcnn_session_structured_layers(void *session) {
+    if (!session) return -1;
+    return ((gpuSession *) session)->p.structuredLayers();
+}
+
 int32_t zkcnn_session_profile(void *session, uint32_t class_mask) {
     if (!session) return -1;
     return zk_profile_enable(((gpuSession *) session)->p.context(), class_mask);

@@ -149,6 +149,7 @@ void neuralNetwork::build(layeredCircuit &C, vector<vector<F>> &val, bool only_c
     n_two_mul = C.two_mul.size();
     in_dirty_lo = 0;
     prog.clear();
+    conv_hints.clear();
     prog.picture_values = (u64) (pic_size_x * pic_size_y * pic_channel * pic_parallel);
 
     i64 layer_id = 0;
@@ -612,6 +613,11 @@ void neuralNetwork::emitConvFast(layer &L, i64 &layer_id, i64 first_conv_id, i64
                                 L.bin_gates.emplace_back((u32) g, (u32) u, (u32) v, (u8) 0, lcode);
                             }
                     }
+    {
+        convHint h = {(i32) layer_id, (u32) pic_parallel, (u32) channel_out, (u32) channel_in, (u32) nx_in, (u32) ny_in, (u32) nx_out, (u32) ny_out,
+                      (u32) m, (u32) padding, (u32) log_stride, (u32) first_conv_id};
+        conv_hints.push_back(h);
+    }
     loadConvWeight(first_conv_id);
     if (~first_bias_id) loadBias(first_bias_id);
     evalGates(L, layer_id);

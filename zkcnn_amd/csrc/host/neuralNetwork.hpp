@@ -81,6 +81,13 @@ struct witnessStep {
     i32 bits;            // RANGE: x_bit + w_bit of the accumulator; the scale it must reproduce is scales()[scale_index]
     i32 scale_index, pad_;
 };
+// what a direct-convolution layer (layerType::NCONV) was generated from: lets a prover that knows the pattern factor the layer's gate
+// sums (include/zkcnn_hip.h: zk_conv_hint, same layout; the prover checks the hint against the gate list before it trusts it)
+struct convHint {
+    i32 layer;
+    u32 pic_parallel, channel_out, channel_in, nx_in, ny_in, nx_out, ny_out, m, padding, log_stride, weight_start;
+};
+
 struct witnessProgram {
     vector<witnessOp> ops;
     vector<u32> windows;
@@ -105,6 +112,7 @@ public:
 
     // ---- next picture on a resident circuit ----
     const witnessProgram &program() const { return prog; }
+    const vector<convHint> &convHints() const { return conv_hints; }
     // quantises `pixels` (channel, x, y order; one picture, replicated pic_parallel times like the reference does) with the scale the
     // circuit was built for; false if this picture's range asks for another scale (the circuit would differ: rebuild)
     bool quantisePicture(const vector<double> &pixels, vector<F> &out) const;
@@ -167,6 +175,7 @@ private:
         return v;
     }
     witnessProgram prog;
+    vector<convHint> conv_hints;
     void logOp(witnessOp::kind k, i64 src_layer, i64 src, i64 dst, i64 shift);
     void logEval(i64 layer_id);
     vector<vector<F>> *vals;       // == &pr.val while building

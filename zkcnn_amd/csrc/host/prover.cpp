@@ -121,7 +121,8 @@ void prover::init() {
         upload_timer.start();
         // a context holds one circuit; a changed circuit gets a fresh one
         vector<zk_layer_desc> desc = layerDescs();
-        if (zk_upload_circuit(ctx, desc.data(), C.size, U(C.two_mul[0]), (int) C.two_mul.size()) != ZK_OK) {
+        auto up = [&]() { return zk_upload_circuit_hinted(ctx, desc.data(), C.size, U(C.two_mul[0]), (int) C.two_mul.size(), conv_hints.data(), (uint32_t) conv_hints.size()); };
+        if (up() != ZK_OK) {
             // the context already holds another circuit: start over with a new one
             string first_err = zk_last_error(ctx);
             poly_p.reset();
@@ -129,7 +130,7 @@ void prover::init() {
             ctx = nullptr;
             program_resident = false;
             ensureContext();
-            if (zk_upload_circuit(ctx, desc.data(), C.size, U(C.two_mul[0]), (int) C.two_mul.size()) != ZK_OK)
+            if (up() != ZK_OK)
                 throw std::runtime_error("zk_upload_circuit failed: " + string(zk_last_error(ctx)) + " / " + first_err);
         }
         if ((int) val.size() != C.size) throw std::runtime_error("prover::init: no host values to upload (released after an earlier upload)");

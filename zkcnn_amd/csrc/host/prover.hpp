@@ -80,9 +80,14 @@ public:
     // ranges: 2 per RANGE step (largest non-negative value, largest magnitude of a negative one); last_layer: values of the output layer
     void rerunWitness(const vector<F> &picture, vector<u64> &ranges, size_t n_ranges, vector<F> &last_layer);
     void releaseHostValues() { vector<vector<F>>().swap(val); }
+    // optional: what the circuit generator knows about its direct-convolution layers (include/zkcnn_hip.h: zk_conv_hint; checked against the
+    // gate lists at upload). Must be set before the first init().
+    void setConvHints(const zk_conv_hint *hints, size_t n) { conv_hints.assign(hints, hints + n); }
+    int structuredLayers() const { return ctx ? zk_structured_layers(ctx) : 0; }
 private:
     vector<zk_layer_desc> layerDescs() const;
     bool program_resident = false;
+    vector<zk_conv_hint> conv_hints;
     hyrax_bls12_381::polyProverBase &zkBackend() override { return *poly_p; }
     const layeredCircuit &zkCircuit() const override { return C; }
     void check(int rc, const char *what) const;
@@ -99,3 +104,7 @@ private:
 // session.hpp calls this for whatever prover type it drives; only the HIP-backed prover can continue the chain on its own
 inline void attachFsChain(prover &p, const uint32_t *state, const uint64_t *pending) { p.attachFiatShamir(state, pending); }
 inline void setHostTail(prover &p, int log_entries) { p.setHostTail(log_entries); }
+template <class H> inline void setConvHints(prover &p, const std::vector<H> &hints) {
+    static_assert(sizeof(H) == sizeof(zk_conv_hint), "convolution hints cross the C-ABI as they are");
+    p.setConvHints(reinterpret_cast<const zk_conv_hint *>(hints.data()), hints.size());
+}

@@ -12,6 +12,7 @@
 // provers that can continue the Fiat-Shamir chain themselves (the HIP-backed one: prover.hpp) overload this; everybody else ignores it
 template <class P> inline void attachFsChain(P &, const uint32_t *, const uint64_t *) {}
 template <class P> inline void setHostTail(P &, int) {}
+template <class P, class H> inline void setConvHints(P &, const std::vector<H> &) {}
 
 template <class ProverT>
 struct sessionT {
@@ -51,6 +52,7 @@ struct sessionT {
         if (!nn) return false;
         nn->setStructureOnly(vector<int>(scales, scales + n));
         nn->create(p, false);
+        setConvHints(p, nn->convHints());
         if (!nn->scalesConsumed()) return false;           // a statement with more scales than the model asks for is malformed
         has_witness = false;
         return true;
@@ -68,6 +70,7 @@ struct sessionT {
         double t0 = now();
         nn->create(p, false);
         witness_s = now() - t0;
+        setConvHints(p, nn->convHints());        // a prover that knows the pattern of a direct convolution factors its gate sums (checked at upload)
         return true;
     }
 
