@@ -18,6 +18,7 @@ struct dev_layer {
     zk_layer_desc d;               // copy of the descriptor (host pointers nulled)
     fr_t *val = nullptr;           // 2^bit_length entries, zero padded
     uint64_t val_len = 0;
+    uint64_t val_live = 0;         // 1 + index of the last non-zero value (measured when the values arrive or are recomputed)
     // phase-1 lists: gates whose u operand lives in table b (0: layer-0 subset, 1: previous layer), sorted by u
     gate_rec *p1[2] = {nullptr, nullptr};
     uint64_t n_p1[2] = {0, 0};      // records incl. padding (runs of equal keys padded to multiples of GATE_GROUP)
@@ -27,6 +28,7 @@ struct dev_layer {
     // phase-2 lists: bin gates whose v operand lives in table b, sorted by v
     gate_rec *p2[2] = {nullptr, nullptr};
     uint64_t n_p2[2] = {0, 0};
+    uint32_t p1_live[2] = {0, 0}, p2_live[2] = {0, 0};  // 1 + the largest key with a gate: M is zero from there on
     uint32_t p1_cov[2] = {0, 0}, p2_cov[2] = {0, 0};   // keys [0, cov) all have a gate: the scatter writes them, only the rest is zeroed
     int p2_uniform[2] = {-1, -1};   // every gate of the list has its u operand in the same layer: 0 = layer 0, 1 = previous, -1 = mixed
     gate_rec *uni2 = nullptr;      // uni gates for the phase-2 constant term (aux = u, bit 10 = u in previous layer)
@@ -54,6 +56,7 @@ struct table_pair {
     int cur = 0;
     const fr_t *Vsrc = nullptr;    // until the first fold the V input is read straight from a layer's values (no copy into V[cur])
     uint64_t len = 0;              // current (pre-fold) length; 0 = absent or already absorbed
+    uint64_t live = 0;             // V and M are zero from this entry on (<= len); the large-table round kernel skips those pairs
     bool absorbed = false;         // collapsed to a constant whose product went into add_term
     bool tail_valid = false;       // the two entries left in V are known on the host (sent along with the last round)
     HFr tail_v[2];
@@ -166,6 +169,7 @@ struct zk_ctx {
     unsigned long long *wp_ranges = nullptr;    // device: 2 per range step, then one word of flags
     unsigned long long *h_wp_ranges = nullptr;  // pinned copy
     uint32_t wp_n_ranges = 0;
+    void *wp_segments = nullptr;                // one wit_segment per layer (k_last_nonzero)
 
     // profiler: when a class bit is set in prof_mask every launch of that class is bracketed by events
     uint32_t prof_mask = 0;

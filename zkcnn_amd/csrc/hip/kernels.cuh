@@ -570,6 +570,8 @@ struct round2_args {
     const fr_t *Vin[2], *Min[2];
     fr_t *Vout[2], *Mout[2];
     uint64_t n[2];              // pre-fold length of each pair; 0 = absent
+    uint64_t nl[2];             // k_round_quad2 only: entries from here on are zero in V AND M (<= n): their pairs add nothing and fold to zero
+    int32_t fill[2];            // k_round_quad2 only: store the zeros of the skipped outputs (the next reader is not bound-aware); else just one guard quad
     uint32_t blocks[2];         // blocks working on each pair (grid.x = blocks[0] + blocks[1])
     fr_t r;
     int32_t first;
@@ -611,8 +613,10 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad2(round2_args a) {
         }
     } else {
         const uint64_t tid = lb * (uint64_t) ZK_BLOCK + threadIdx.x, stride = (uint64_t) nblk * ZK_BLOCK;
+        // only the live prefix is read: pairs past it are zero in both tables
+        const uint64_t live = a.nl[b] < n ? a.nl[b] : n;
         if (a.first) {
-            for (uint64_t p = tid; p < n / 2; p += stride) {
+            for (uint64_t p = tid; p < (live + 1) / 2; p += stride) {
                 fr_t v0 = fr_load(Vin + 2 * p), v1 = fr_load(Vin + 2 * p + 1);
                 fr_t m0 = fr_load(Min + 2 * p), m1 = fr_load(Min + 2 * p + 1);
                 acc[0] = fr_add(acc[0], fr_mul(fr_sub(v1, v0), fr_sub(m1, m0)));
@@ -620,7 +624,16 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad2(round2_args a) {
                 acc[2] = fr_add(acc[2], fr_mul(v1, m1));
             }
         } else {
-            for (uint64_t q = tid; q < n / 4; q += stride) {
+            const uint64_t Q = (live + 3) / 4;
+            // outputs of the skipped quads: all of them if the next reader knows nothing about the bound, else the one quad the next
+            // round of this kernel may reach into (its bound 2Q rounded up to a multiple of 4)
+            const uint64_t zend = a.fill[b] ? n / 4 : ((Q & 1) && Q < n / 4 ? Q + 1 : Q);
+            for (uint64_t q = Q + tid; q < zend; q += stride) {
+                const fr_t z = fr_zero();
+                fr_store(Vout + 2 * q, z); fr_store(Vout + 2 * q + 1, z);
+                fr_store(Mout + 2 * q, z); fr_store(Mout + 2 * q + 1, z);
+            }
+            for (uint64_t q = tid; q < Q; q += stride) {
                 fr_t a0 = fr_load(Vin + 4 * q), a1 = fr_load(Vin + 4 * q + 1), a2 = fr_load(Vin + 4 * q + 2), a3 = fr_load(Vin + 4 * q + 3);
                 fr_t v0 = fr_lerp(a0, a1, a.r), v1 = fr_lerp(a2, a3, a.r);
                 fr_store(Vout + 2 * q, v0);

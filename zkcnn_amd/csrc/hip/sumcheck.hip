@@ -332,6 +332,7 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
         D.d.uni_gates = nullptr; D.d.bin_gates = nullptr; D.d.ori_id_u = nullptr; D.d.ori_id_v = nullptr;
         if (S.bit_length < 0 || S.bit_length > ZK_MAX_VARS) { ctx->err = "layer bit length out of range"; return ZK_ERR_ARG; }
         D.val_len = 1ull << S.bit_length;
+        D.val_live = D.val_len;          // until the values arrive
         if ((rc = zk_dev_alloc(ctx, (void **) &D.val, D.val_len * 32))) return rc;
         ZK_HIP(hipMemsetAsync(D.val, 0, D.val_len * 32, ctx->stream));
         max_table = std::max<uint64_t>(max_table, D.val_len);
@@ -370,6 +371,7 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
             if (S.bit_length_v[b] < 0) { ctx->err = "bin gate refers to an absent v table"; return ZK_ERR_ARG; }
             counting_sort(q[b], 1u << S.bit_length_v[b]);
             D.p2_cov[b] = covered_prefix(q[b]);
+            D.p2_live[b] = q[b].empty() ? 0 : q[b].back().key + 1;
             {
                 const uint32_t f0 = GATE_IN_PREV(q[b][0].meta);
                 bool same = true;
@@ -426,6 +428,7 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
             if (S.bit_length_u[b] < 0) { ctx->err = "gate refers to an absent u table"; return ZK_ERR_ARG; }
             counting_sort(p[b], 1u << S.bit_length_u[b]);
             D.p1_cov[b] = covered_prefix(p[b]);
+            D.p1_live[b] = p[b].empty() ? 0 : p[b].back().key + 1;
             D.n_p1_real[b] = p[b].size();
             D.p1_G[b] = choose_group(p[b]);
             pad_runs(p[b], D.p1_G[b]);
@@ -510,6 +513,12 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
             ZK_HIP(hipHostMalloc(&ctx->h_conv_tabs, 2 * CT_COUNT * sizeof(liu_table)));
         }
     }
+    if (getenv("ZKCNN_DUMP_TABLES"))
+        for (int i = 1; i < n_layers; ++i) {
+            const dev_layer &D = ctx->L[i];
+            fprintf(stderr, "[tables] layer %d ty %d size %u | u0 bl %d live %u | u1 bl %d live %u | v0 bl %d live %u | v1 bl %d live %u\n", i, D.d.ty, D.d.size,
+                    D.d.bit_length_u[0], D.p1_live[0], D.d.bit_length_u[1], D.p1_live[1], D.d.bit_length_v[0], D.p2_live[0], D.d.bit_length_v[1], D.p2_live[1]);
+        }
     // work buffers sized for the largest layer
     ctx->max_table = max_table;
     for (int b = 0; b < 2; ++b)
@@ -540,6 +549,9 @@ extern "C" int32_t zk_upload_layer_values(zk_ctx *ctx, int32_t layer, const uint
     ZK_HIP(hipSetDevice(ctx->device));
     if (n) ZK_HIP(hipMemcpyAsync(D.val, values, n * 32, hipMemcpyHostToDevice, ctx->stream));
     if (n < D.val_len) ZK_HIP(hipMemsetAsync(D.val + n, 0, (D.val_len - n) * 32, ctx->stream));
+    uint64_t last = n;
+    while (last && !(values[4 * last - 4] | values[4 * last - 3] | values[4 * last - 2] | values[4 * last - 1])) --last;
+    D.val_live = last;
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     return ZK_OK;
 }
@@ -688,6 +700,7 @@ static void reset_pairs(zk_ctx *ctx, int bl0, int bl1) {
         ctx->tp[b].tail_valid = false;
         ctx->tp[b].Vsrc = nullptr;
         ctx->tp[b].len = bl[b] >= 0 ? 1ull << bl[b] : 0;
+        ctx->tp[b].live = ctx->tp[b].len;
         ctx->tp[b].absorbed = false;
         ctx->tp[b].final_v.clear();
     }
@@ -946,6 +959,10 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
         if (cur.p1_cov[b] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p1_cov[b], 0, (t.len - cur.p1_cov[b]) * 32, ctx->stream));
         if ((rc = gate_scatter(ctx, t.M[0], cur.p1[b], cur.n_p1[b], cur.n_p1_real[b], 1, cur, prev, cur.n_p1_uni[b], t.len, cur.p1_G[b]))) return rc;
     }
+    // where both tables of a pair end: M has no gate behind p1_live (the factored convolution: behind the tensor it reads); V is the layer-0
+    // subset (size_u[0] entries) or the previous layer (non-zero up to val_live: a RELU / pooling layer's constraint rows are zero for a valid witness)
+    ctx->tp[0].live = std::min<uint64_t>(ctx->tp[0].len, d.size_u[0]);
+    ctx->tp[1].live = std::min<uint64_t>(ctx->tp[1].len, std::max<uint64_t>(cur.p1_live[1], prev.val_live));
     return ZK_OK;
 }
 
@@ -1097,6 +1114,8 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         if (cur.p2_cov[b] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p2_cov[b], 0, (t.len - cur.p2_cov[b]) * 32, ctx->stream));
         if ((rc = gate_scatter(ctx, t.M[0], cur.p2[b], cur.n_p2[b], cur.n_p2_real[b], 2, cur, prev, 0, t.len, cur.p2_G[b], cur.p2_uniform[b]))) return rc;
     }
+    ctx->tp[0].live = std::min<uint64_t>(ctx->tp[0].len, d.size_v[0]);
+    ctx->tp[1].live = std::min<uint64_t>(ctx->tp[1].len, std::max<uint64_t>(cur.p2_live[1], prev.val_live));
     if (cur.n_uni2) {
         ZK_HIP(hipMemcpyAsync(ctx->h_result + 8, ctx->d_result + 8, 64, hipMemcpyDeviceToHost, ctx->stream));
         ZK_HIP(hipStreamSynchronize(ctx->stream));
@@ -1308,9 +1327,16 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         A.n[b] = t.len;
         collapsed[b] = (first && t.len == 1) || (!first && t.len == 2);     // the reference's `total == 1` case
         const uint64_t npairs = first ? t.len / 2 : t.len / 4;
-        A.blocks[b] = collapsed[b] ? 1 : std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks / 2);
+        // the large-table kernel skips the pairs behind the live prefix; once this table's output is small enough for the other kernels
+        // (which read whole tables) the zeros are stored
+        static const bool use_live = !(getenv("ZKCNN_LIVE_PREFIX") && atoi(getenv("ZKCNN_LIVE_PREFIX")) == 0);
+        const uint64_t live = use_live ? std::min(t.live, t.len) : t.len;
+        A.nl[b] = live;
+        A.fill[b] = (t.len / 2 <= (1ull << std::max(fine_log, 16))) ? 1 : 0;
+        const uint64_t work = fine ? npairs : std::max<uint64_t>(first ? (live + 1) / 2 : (live + 3) / 4, first ? 1 : (A.fill[b] ? npairs / 8 : 1));
+        A.blocks[b] = collapsed[b] ? 1 : std::min<uint32_t>(grid_for(work, 1024), ctx->partial_blocks / 2);
         fine_items += collapsed[b] ? 1 : npairs;
-        alg_bytes += (first ? 64.0 : 96.0) * (double) t.len;
+        alg_bytes += (first ? 64.0 : 96.0) * (double) (fine ? t.len : live);      // entries the launch has to read: the live prefix
     }
     if (A.blocks[0] + A.blocks[1] == 0) {
         for (int k = 0; k < 3; ++k) ctx->h_result[k].clear();
@@ -1329,7 +1355,10 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         ZK_HIP(hipGetLastError());
         for (int b = 0; b < 2; ++b) {
             table_pair &t = ctx->tp[b];
-            if (t.len && !first) { t.cur ^= 1; t.len >>= 1; t.Vsrc = nullptr; }
+            if (t.len && !first) {
+                t.cur ^= 1; t.len >>= 1; t.Vsrc = nullptr;
+                t.live = (fine || A.fill[b]) ? std::min(t.len, 2 * ((A.nl[b] + 3) / 4)) : std::min(t.len, 2 * ((A.nl[b] + 3) / 4));
+            }
         }
         if (seg_timing) ts_wait0 = now_s();
         int32_t rc = wait_slot(ctx, A.seq);
@@ -1468,6 +1497,7 @@ extern "C" int32_t zk_sumcheck_liu_init(zk_ctx *ctx, const uint64_t *s_u, const 
     ctx->round = 0;
     table_pair &t = ctx->tp[1];
     t.Vsrc = L0.val;
+    t.live = std::min<uint64_t>(t.len, L0.d.size);          // layer 0 is zero padded behind its size, and no layer refers to entries there
     static const bool batched = !(getenv("ZKCNN_LIU_BATCHED") && atoi(getenv("ZKCNN_LIU_BATCHED")) == 0);
     if (batched) {
         // descriptors of every (layer, side) table: point, sigma, bit split; then two launches (k_eq_halves_multi, k_liu_gather)
@@ -1595,6 +1625,7 @@ extern "C" int32_t zk_k_round_quadratic(zk_ctx *ctx, uint64_t *V, uint64_t *M, u
     std::memset(&A, 0, sizeof(A));
     A.Vin[0] = dV; A.Min[0] = dM; A.Vout[0] = dV2; A.Mout[0] = dM2;
     A.n[0] = n;
+    A.nl[0] = n;
     A.blocks[0] = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks / 2);
     A.r = to_dev(H(r));
     A.first = first ? 1 : 0;
@@ -2057,9 +2088,16 @@ extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *o
     if ((rc = zk_dev_alloc(ctx, (void **) &ctx->wp_tmp, 2 * max_out * 32)) ||
         (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_carry_val, 2 * max_blocks * 32)) ||
         (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_carry_key, 2 * max_blocks * 4)) ||
-        (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_ranges, (2 * (size_t) n_ranges + 1) * 8)))
+        (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_ranges, (2 * (size_t) n_ranges + 1 + n_layers) * 8)))
         return rc;
-    ZK_HIP(hipHostMalloc((void **) &ctx->h_wp_ranges, (2 * (size_t) n_ranges + 1) * 8));
+    ZK_HIP(hipHostMalloc((void **) &ctx->h_wp_ranges, (2 * (size_t) n_ranges + 1 + n_layers) * 8));
+    {
+        std::vector<wit_segment> seg(n_layers);
+        for (int i = 0; i < n_layers; ++i) { seg[i].p = ctx->L[i].val; seg[i].n = ctx->L[i].d.size; }
+        wit_segment *d_seg = nullptr;
+        if ((rc = upload(ctx, &d_seg, seg))) return rc;
+        ctx->wp_segments = d_seg;
+    }
     ctx->wp_n_ranges = n_ranges;
     ctx->wp_steps.assign(steps, steps + n_steps);
     ctx->wp_ready = true;
@@ -2100,7 +2138,8 @@ extern "C" int32_t zk_witness_rerun(zk_ctx *ctx, const uint64_t *picture, uint64
         return ZK_ERR_ARG;
     int32_t rc;
     ZK_HIP(hipMemcpyAsync(L0.val, picture, n_picture * 32, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipMemsetAsync(ctx->wp_ranges, 0, (2 * (size_t) n_ranges + 1) * 8, ctx->stream));
+    const size_t n_lay = ctx->L.size(), wp_words = 2 * (size_t) n_ranges + 1 + n_lay;
+    ZK_HIP(hipMemsetAsync(ctx->wp_ranges, 0, wp_words * 8, ctx->stream));
     uint32_t *flags = (uint32_t *) (ctx->wp_ranges + 2 * (size_t) n_ranges);
     uint32_t range_k = 0;
     for (const zk_witness_step &st : ctx->wp_steps) {
@@ -2148,11 +2187,15 @@ extern "C" int32_t zk_witness_rerun(zk_ctx *ctx, const uint64_t *picture, uint64
             }
         }
     }
+    // where every layer's values end (the round kernels skip the zero tails of the tables they fold)
+    ZK_LAUNCH(PC_MISC, 0.0, k_last_nonzero, dim3(64, (uint32_t) n_lay), dim3(ZK_BLOCK), ctx->wp_ranges + 2 * (size_t) n_ranges + 1, (const wit_segment *) ctx->wp_segments);
     ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpyAsync(ctx->h_wp_ranges, ctx->wp_ranges, (2 * (size_t) n_ranges + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    for (dev_layer &D : ctx->L) D.val_live = D.val_len;          // until the copy below is back
+    ZK_HIP(hipMemcpyAsync(ctx->h_wp_ranges, ctx->wp_ranges, wp_words * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (last_layer && n_last) ZK_HIP(hipMemcpyAsync(last_layer, ctx->L.back().val, n_last * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     for (uint32_t k = 0; k < 2 * n_ranges; ++k) ranges[k] = ctx->h_wp_ranges[k];
+    for (size_t i = 0; i < n_lay; ++i) ctx->L[i].val_live = ctx->h_wp_ranges[2 * (size_t) n_ranges + 1 + i];
     if (ctx->h_wp_ranges[2 * (size_t) n_ranges] & WIT_FLAG_WIDE) { ctx->err = "a layer value does not fit 63 bits"; return ZK_ERR_STATE; }
     return ZK_OK;
 }
@@ -2230,6 +2273,7 @@ extern "C" int32_t zk_bench_round_quadratic(zk_ctx *ctx, uint32_t log_n, uint32_
     std::memset(&A, 0, sizeof(A));
     A.Vin[0] = dV; A.Min[0] = dM; A.Vout[0] = dO; A.Mout[0] = dO + n / 2;
     A.n[0] = n;
+    A.nl[0] = n;
     A.blocks[0] = std::min<uint32_t>(grid_for(n / 4, 1024), ctx->partial_blocks / 2);
     A.r = to_dev(r[0]);
     A.skip_p1 = 1;                        // as every round but the first of a phase runs: b comes from the running claim

@@ -94,3 +94,18 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_witness_range(unsigned long long *
     }
     if (any_wide) atomicOr(flags, WIT_FLAG_WIDE);
 }
+
+// out[y] = 1 + index of the last non-zero entry of segment y (0 if it is all zero); out zeroed by the caller. grid (blocks, segments)
+struct wit_segment { const fr_t *p; uint64_t n; };
+__global__ void __launch_bounds__(ZK_BLOCK) k_last_nonzero(unsigned long long *out, const wit_segment *seg) {
+    const wit_segment s = seg[blockIdx.y];
+    unsigned long long last = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x; i < s.n; i += (uint64_t) gridDim.x * ZK_BLOCK)
+        if (!fr_is_zero(fr_load(s.p + i))) last = i + 1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_down(last, d);
+        last = o > last ? o : last;
+    }
+    if ((threadIdx.x & 63) == 0 && last) atomicMax(out + blockIdx.y, last);
+}
