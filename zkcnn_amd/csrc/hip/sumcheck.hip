@@ -499,7 +499,7 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
             D.conv = c;
             D.conv_ok = true;
             ++ctx->conv_layers;
-            const uint64_t len = (uint64_t) c.CI * c.m * c.m, chunks = (c.CO + 31) / 32;
+            const uint64_t len = (uint64_t) c.CI * c.m * c.m, chunks = (c.CO + 7) / 8;
             max_wa = std::max(max_wa, 2 * len);
             max_part = std::max(max_part, chunks * 2 * len);
             max_ae = std::max<uint64_t>(max_ae, (uint64_t) c.CO * c.m * c.m + c.CI);
@@ -863,7 +863,7 @@ static int32_t conv_phase1(zk_ctx *ctx, const dev_layer &cur, fr_t *M, uint64_t 
     if (!K) return ZK_OK;
     int32_t rc;
     if ((rc = conv_small_tables(ctx, 0))) return rc;
-    const uint32_t wlen = c.CI * c.m * c.m, per = 32, chunks = (c.CO + per - 1) / per;
+    const uint32_t wlen = c.CI * c.m * c.m, per = 8, chunks = (c.CO + per - 1) / per;
     fr_t *part = chunks == 1 ? ctx->conv_wa : ctx->conv_part;
     ZK_LAUNCH(PC_GATE, 0.0, k_conv_wa, dim3((wlen + ZK_BLOCK - 1) / ZK_BLOCK, chunks), dim3(ZK_BLOCK), part, (const fr_t *) ctx->L[0].val + c.wstart,
               (const fr_t *) ctx->conv_small, wlen, c.CO, per, K);
