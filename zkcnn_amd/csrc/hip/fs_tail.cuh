@@ -18,7 +18,8 @@
 #include "../ff/blake2s.hpp"
 
 #define FS_TAIL_THREADS 576            // 8 waves of quads + one wave of scalar bookkeeping
-#define FS_TAIL_QUADS 128              // quads (both table pairs together) the kernel takes: four lanes each
+#define FS_TAIL_SLOTS 128              // quads in flight: four lanes each on 8 waves
+#define FS_TAIL_QUADS 512              // quads (both table pairs together) the kernel takes: its first two rounds then make 4 and 2 passes over the slots
 #define FS_TAIL_MAX_ROUNDS ZK_MAX_VARS
 
 struct tail_out {                     // pinned, mapped host memory
@@ -98,44 +99,48 @@ __global__ void __launch_bounds__(FS_TAIL_THREADS) k_fs_tail(tail_args a) {
         // Four lanes per quad (the layout of k_round_quad_fine: a lone wave issues its products one after the other, so the chain per
         // lane is what counts):   fold     role 0: v0   1: v1   2: m0   3: m1        (one product)
         //                         product  role 0: c = v0 m0   1: p(1) = v1 m1   2: a = (v1 - v0)(m1 - m0)     (one more)
-        const uint32_t item = (uint32_t) tid >> 2, role = (uint32_t) tid & 3;
-        const bool live = wave != scalar_wave && item < quads[0] + quads[1];
-        const int b = (live && item >= quads[0]) ? 1 : 0;
-        const uint32_t q = b ? item - quads[0] : item, quads_b = b ? quads[1] : quads[0];
-        const fr_t *Vb = b ? Vin[1] : Vin[0], *Mb = b ? Min[1] : Min[0];
-        const int oib = b ? oi[1] : oi[0];
-        fr_t X = fr_zero(), opA = fr_zero(), opB = fr_zero();
-        if (live && first) {
-            if (role < 3) {
-                const fr_t v0 = fr_load(Vb + 2 * q), v1 = fr_load(Vb + 2 * q + 1), m0 = fr_load(Mb + 2 * q), m1 = fr_load(Mb + 2 * q + 1);
-                opA = role == 0 ? v0 : role == 1 ? v1 : fr_sub(v1, v0);
-                opB = role == 0 ? m0 : role == 1 ? m1 : fr_sub(m1, m0);
-                if (quads_b == 1 && role < 2) s_tail[b][role] = opA;
+        const uint32_t role = (uint32_t) tid & 3, total_quads = quads[0] + quads[1];
+        fr_t prod = fr_zero();
+        for (uint32_t base = 0; base == 0 || base < total_quads; base += FS_TAIL_SLOTS) {
+            const uint32_t item = base + ((uint32_t) tid >> 2);
+            const bool live = wave != scalar_wave && item < total_quads;
+            const int b = (live && item >= quads[0]) ? 1 : 0;
+            const uint32_t q = b ? item - quads[0] : item, quads_b = b ? quads[1] : quads[0];
+            const fr_t *Vb = b ? Vin[1] : Vin[0], *Mb = b ? Min[1] : Min[0];
+            const int oib = b ? oi[1] : oi[0];
+            fr_t X = fr_zero(), opA = fr_zero(), opB = fr_zero();
+            if (live && first) {
+                if (role < 3) {
+                    const fr_t v0 = fr_load(Vb + 2 * q), v1 = fr_load(Vb + 2 * q + 1), m0 = fr_load(Mb + 2 * q), m1 = fr_load(Mb + 2 * q + 1);
+                    opA = role == 0 ? v0 : role == 1 ? v1 : fr_sub(v1, v0);
+                    opB = role == 0 ? m0 : role == 1 ? m1 : fr_sub(m1, m0);
+                    if (quads_b == 1 && role < 2) s_tail[b][role] = opA;
+                }
+            } else if (live) {
+                const fr_t *src = (role < 2 ? Vb : Mb) + 4 * q + 2 * (role & 1);
+                X = fr_lerp(fr_load(src), fr_load(src + 1), r);
+                fr_store((role < 2 ? a.Vbuf[b][oib] : a.Mbuf[b][oib]) + 2 * q + (role & 1), X);
+                if (quads_b == 1 && role < 2) s_tail[b][role] = X;           // the pair the phase may end with
             }
-        } else if (live) {
-            const fr_t *src = (role < 2 ? Vb : Mb) + 4 * q + 2 * (role & 1);
-            X = fr_lerp(fr_load(src), fr_load(src + 1), r);
-            fr_store((role < 2 ? a.Vbuf[b][oib] : a.Mbuf[b][oib]) + 2 * q + (role & 1), X);
-            if (quads_b == 1 && role < 2) s_tail[b][role] = X;           // the pair the phase may end with
-        }
-        if (!first && wave != scalar_wave) {
-            fr_t y1, y2, y3;
+            if (!first && wave != scalar_wave) {
+                fr_t y1, y2, y3;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                y1.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 2, 64);
-                y2.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 1, 64);
+                for (int i = 0; i < 8; ++i) {
+                    y1.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 2, 64);
+                    y2.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 1, 64);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y3.v[i] = (uint32_t) __shfl_xor((int) y1.v[i], 1, 64);
+                // role 0: X = v0, y1 = m0;  role 1: X = v1, y1 = m1;  role 2: X = m0, y1 = v0, y2 = m1, y3 = v1
+                opA = role == 2 ? fr_sub(y3, y1) : X;
+                opB = role == 2 ? fr_sub(y2, X) : y1;
+                if (role == 3 || !live) { opA = fr_zero(); opB = fr_zero(); }
             }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) y3.v[i] = (uint32_t) __shfl_xor((int) y1.v[i], 1, 64);
-            // role 0: X = v0, y1 = m0;  role 1: X = v1, y1 = m1;  role 2: X = m0, y1 = v0, y2 = m1, y3 = v1
-            opA = role == 2 ? fr_sub(y3, y1) : X;
-            opB = role == 2 ? fr_sub(y2, X) : y1;
-            if (role == 3 || !live) { opA = fr_zero(); opB = fr_zero(); }
+            if (wave != scalar_wave && (base == 0 || live)) prod = fr_add(prod, fr_mul(opA, opB));
         }
         // reduction: lanes of equal role by butterflies, lanes 0..2 of every wave that holds quads leave the wave's sums, threads 0..2 add those
-        const int nw = (int) ((4 * (quads[0] + quads[1]) + 63) / 64);
+        const int nw = (int) std::min<uint32_t>(FS_TAIL_THREADS / 64 - 1, (4 * total_quads + 63) / 64);
         if (wave < nw) {
-            fr_t prod = fr_mul(opA, opB);
 #pragma unroll
             for (int off = 4; off < 64; off <<= 1) {
                 fr_t o;

@@ -1276,7 +1276,8 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         host_tail_round(ctx, r, with_add_term, out_abc);
         return ZK_OK;
     }
-    static const uint64_t tail_quads = getenv("ZKCNN_TAIL_QUADS") ? std::min<uint64_t>(FS_TAIL_QUADS, (uint64_t) atoll(getenv("ZKCNN_TAIL_QUADS"))) : FS_TAIL_QUADS;
+    // (measured on vgg11: the kernel taking over at 256 quads -- two passes over its 128 quad slots in its first round -- is 1 ms per proof faster than at 128 or 512)
+    static const uint64_t tail_quads = getenv("ZKCNN_TAIL_QUADS") ? std::min<uint64_t>(FS_TAIL_QUADS, (uint64_t) atoll(getenv("ZKCNN_TAIL_QUADS"))) : 256;
     // quads of this round over both pairs (a first round works on pairs, not quads): small enough for one thread each?
     const uint64_t round_quads = ctx->round == 0 ? (ctx->tp[0].len + ctx->tp[1].len) / 2 : (ctx->tp[0].len + ctx->tp[1].len) / 4;
     if (ctx->fs_state && !ctx->tail_active && ctx->phase_rounds > ctx->round && *ctx->fs_pending == 0 && round_quads <= tail_quads &&
