@@ -324,6 +324,18 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
     ZK_HIP(hipMemcpy(ctx->two_mul, two_mul, (size_t) n_two_mul * 32, hipMemcpyHostToDevice));
 
     ctx->L.assign(n_layers, dev_layer());
+    // structured convolution layers: a hint that reproduces the layer's gate list switches the factored sums on (and the layer's phase-1 list
+    // of those gates is then not built at all)
+    for (uint32_t k = 0; k < n_hints; ++k) {
+        const int i = hints[k].layer;
+        if (i < 2 || i >= n_layers) continue;
+        dev_layer &D = ctx->L[i];
+        conv_desc c;
+        if (D.conv_ok || !conv_hint_matches(hints[k], layers[i], layers[i - 1], c)) continue;
+        D.conv = c;
+        D.conv_ok = true;
+        ++ctx->conv_layers;
+    }
     uint64_t max_table = 1, max_bg = 1, max_bu = 1, max_gs = 1, max_list = 1;
     for (int i = 0; i < n_layers; ++i) {
         dev_layer &D = ctx->L[i];
@@ -416,13 +428,14 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
             gate_rec r2 = {g.g, 0, g.u, (uint32_t) g.sc | (in_prev << 10)};
             un.push_back(r2);
         }
-        for (uint64_t k = 0; k < S.n_bin; ++k) {
+        for (uint64_t k = 0; k < S.n_bin && !D.conv_ok; ++k) {          // (a structured convolution: every bin gate is covered by the factored sum)
             const zk_bin_gate &g = S.bin_gates[k];
             const uint32_t v_prev = g.l & 1, u_prev = g.l != 0;
             const uint32_t vres = v_prev ? g.v : S.ori_id_v[g.v];     // resolve the layer-0 subset index once
             gate_rec r = {g.g, g.u, vres, (uint32_t) g.sc | (1u << 9) | (v_prev << 10)};
             p[u_prev].push_back(r);
         }
+        if (D.conv_ok) D.p1_live[1] = (uint32_t) std::min<uint64_t>((uint64_t) D.conv.pp * D.conv.CI * D.conv.nxi * D.conv.nyi, 0xffffffffu);
         for (int b = 0; b < 2; ++b) {
             if (p[b].empty()) continue;
             if (S.bit_length_u[b] < 0) { ctx->err = "gate refers to an absent u table"; return ZK_ERR_ARG; }
@@ -487,18 +500,11 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
         if ((rc = zk_dev_alloc(ctx, &ctx->liu_tabs, (size_t) nt * sizeof(liu_table)))) return rc;
         ZK_HIP(hipHostMalloc(&ctx->h_liu_tabs, (size_t) nt * sizeof(liu_table)));
     }
-    // structured convolution layers: hints that reproduce the layer's gate list switch the factored sums on
     {
         uint64_t max_wa = 0, max_part = 0, max_ae = 0;
-        for (uint32_t k = 0; k < n_hints; ++k) {
-            const int i = hints[k].layer;
-            if (i < 2 || i >= n_layers) continue;
-            dev_layer &D = ctx->L[i];
-            conv_desc c;
-            if (D.conv_ok || !conv_hint_matches(hints[k], layers[i], layers[i - 1], c)) continue;
-            D.conv = c;
-            D.conv_ok = true;
-            ++ctx->conv_layers;
+        for (const dev_layer &D : ctx->L) {
+            if (!D.conv_ok) continue;
+            const conv_desc &c = D.conv;
             const uint64_t len = (uint64_t) c.CI * c.m * c.m, chunks = (c.CO + 7) / 8;
             max_wa = std::max(max_wa, 2 * len);
             max_part = std::max(max_part, chunks * 2 * len);
@@ -954,7 +960,8 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
         if (b == 1 && cur.conv_ok) {
             bool done = false;
             if ((rc = conv_phase1(ctx, cur, t.M[0], t.len, ctx->alpha * scale, ctx->beta * scale, &done))) return rc;
-            if (done) continue;
+            if (!done) ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));       // both claims weighted with zero: every sum is zero
+            continue;
         }
         if (cur.p1_cov[b] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p1_cov[b], 0, (t.len - cur.p1_cov[b]) * 32, ctx->stream));
         if ((rc = gate_scatter(ctx, t.M[0], cur.p1[b], cur.n_p1[b], cur.n_p1_real[b], 1, cur, prev, cur.n_p1_uni[b], t.len, cur.p1_G[b]))) return rc;
