@@ -50,9 +50,10 @@ WORKLOADS = {
     "vgg11_half": ("vgg:32 M 64 M 128 128 M 256 256 M 256 256 M", (32, 32, 3), 1),
 }
 # HBM bytes per launch of a kernel class from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, separate passes,
-# scripts/pmc_proof.sh): r02q_vgg11_pmc_traffic.md: (5.07 + 1.83 + 81.03 + 28.91) GB over 7976 + 1067 launches of k_round_quad_fine / 2;
+# scripts/pmc_proof.sh): r02t_vgg11_pmc_traffic.md: (5.10 + 1.83 + 53.74 + 20.32) GB over 7976 + 1067 launches of k_round_quad_fine / 2;
 # r01g_vgg11_pp8_pmc_traffic.md likewise. None where no PMC pass exists for the (workload, class). Constants of those passes, not measured in a bench run.
-PMC_TRAFFIC_PER_LAUNCH = {("vgg11", "round_quad"): (5.07 + 1.83 + 81.03 + 28.91) * 1e9 / (7976 + 1067), ("vgg11_pp8", "round_quad"): (6.50 + 2.55 + 299.46 + 105.63) * 1e9 / (10000 + 2312)}
+PMC_TRAFFIC_PER_LAUNCH = {("vgg11", "round_quad"): (5.10 + 1.83 + 53.74 + 20.32) * 1e9 / (7976 + 1067),      # profiles/r02t_vgg11_pmc_traffic.md
+                           ("vgg11_pp8", "round_quad"): (6.50 + 2.55 + 299.46 + 105.63) * 1e9 / (10000 + 2312)}
 # kernel classes whose algorithmic byte count is defined; the dominant one is reported
 STREAMING_PMC_BYTES = 1.7037e9      # profiles/r01_round_quad_kernel.md (FETCH_SIZE x2 + WRITE_SIZE) for 2 x 2^24 entries
 ROOFLINE_CLASSES = ["gate_reduce", "round_quad", "round_cubic", "msm_planes"]
