@@ -566,11 +566,12 @@ extern "C" int32_t zk_upload_layer_values(zk_ctx *ctx, int32_t layer, const uint
 // building blocks
 // ------------------------------------------------------------------------------------------------
 // out[i] = a * eq(r0, i) + b * eq(r1, i), i < 2^n; entries >= tail_start additionally scaled
+// `limit`: only entries [0, limit) are needed (a layer whose size is not a power of two: nothing refers to the rest)
 static int32_t eq_table(zk_ctx *ctx, fr_t *out, int n, const HFr *r0, const HFr &a, const HFr *r1, const HFr &b,
-                        uint64_t tail_start, const HFr &tail_scale) {
+                        uint64_t tail_start, const HFr &tail_scale, uint64_t limit = ~0ull) {
     if (n < 0) return ZK_OK;
     if (n > ZK_MAX_VARS) { ctx->err = "eq table too large"; return ZK_ERR_ARG; }
-    const uint64_t len = 1ull << n;
+    const uint64_t len = std::min<uint64_t>(1ull << n, std::max<uint64_t>(limit, 1));
     eq_args A;
     A.npoints = 0;
     A.fh = n >> 1;
@@ -592,8 +593,8 @@ static int32_t eq_table(zk_ctx *ctx, fr_t *out, int n, const HFr *r0, const HFr 
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
-static int32_t eq_table1(zk_ctx *ctx, fr_t *out, int n, const HFr *r, const HFr &init) {
-    return eq_table(ctx, out, n, r, init, nullptr, HFr(0LL), ~0ull, HFr::one());
+static int32_t eq_table1(zk_ctx *ctx, fr_t *out, int n, const HFr *r, const HFr &init, uint64_t limit = ~0ull) {
+    return eq_table(ctx, out, n, r, init, nullptr, HFr(0LL), ~0ull, HFr::one(), limit);
 }
 
 int32_t zk_eq_table1_dev(zk_ctx *ctx, fr_t *out, int n, const HFr *r, const HFr &init) { return eq_table1(ctx, out, n, r, init); }
@@ -677,6 +678,12 @@ static int32_t gate_scatter(zk_ctx *ctx, fr_t *out, const gate_rec *recs, uint64
     return ZK_OK;
 }
 
+// the large-table round kernel stops at the live prefix of its tables (ZKCNN_LIVE_PREFIX=0: A/B switch, everything is read and written)
+static bool live_prefix_on() {
+    static const bool on = !(getenv("ZKCNN_LIVE_PREFIX") && atoi(getenv("ZKCNN_LIVE_PREFIX")) == 0);
+    return on;
+}
+
 // V-table of one side: layer-0 subset through ori ids, or the previous layer as it is
 static inline const fr_t *vin(const table_pair &t) { return t.Vsrc ? t.Vsrc : t.V[t.cur]; }
 
@@ -689,7 +696,9 @@ static int32_t load_v_table(zk_ctx *ctx, table_pair &t, int b, int bl, uint32_t 
         return ZK_OK;
     }
     if (b == 0) {
-        ZK_LAUNCH(PC_GATHER, 0.0, k_gather, dim3(grid_for(len)), dim3(ZK_BLOCK), dst, ctx->L[0].val, ori, (uint64_t) size, len);
+        // a large table is first read by the round kernel that stops at the live prefix (rounded up to whole quads): no zeros needed behind it
+        const uint64_t fill = (len <= (1ull << 16) || !live_prefix_on()) ? len : std::min<uint64_t>(len, (((uint64_t) size + 3) & ~3ull) + 4);
+        ZK_LAUNCH(PC_GATHER, 0.0, k_gather, dim3(grid_for(fill)), dim3(ZK_BLOCK), dst, ctx->L[0].val, ori, (uint64_t) size, fill);
         ZK_HIP(hipGetLastError());
     } else {
         const uint64_t have = std::min<uint64_t>(len, prev.val_len);
@@ -949,8 +958,10 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
         if (d.zero_start_id < d.size) { ctx->err = "PADDING layer with constraint rows is not supported"; return ZK_ERR_ARG; }
     } else {
         const bool tail = d.zero_start_id < d.size;
+        // (gates only refer to outputs below the layer's size; the FFT-convolution layer types hand their table on to the next layer: whole table)
+        const bool plain = d.ty == ZK_RELU || d.ty == ZK_MAX_POOL || d.ty == ZK_AVG_POOL || d.ty == ZK_NCONV || d.ty == ZK_FCONN;
         rc = eq_table(ctx, ctx->beta_g[ctx->beta_g_cur], d.bit_length, ctx->r_0, ctx->alpha * scale, ctx->r_1, ctx->beta * scale,
-                      tail ? d.zero_start_id : ~0ull, tail ? ctx->relu_rou : HFr::one());
+                      tail ? d.zero_start_id : ~0ull, tail ? ctx->relu_rou : HFr::one(), plain ? (uint64_t) d.size : ~0ull);
         if (rc) return rc;
     }
     for (int b = 0; b < 2; ++b) {
@@ -1097,7 +1108,8 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         return gate_scatter(ctx, t.M[0], cur.p2[1], cur.n_p2[1], cur.n_p2_real[1], 2, cur, prev, 0, t.len, cur.p2_G[1], cur.p2_uniform[1]);
     }
 
-    if ((rc = eq_table1(ctx, ctx->beta_u, d.max_bl_u, ru, HFr::one()))) return rc;
+    // (the u operands of the layer's gates: the layer-0 subset and / or the previous layer, both referred to below their sizes)
+    if ((rc = eq_table1(ctx, ctx->beta_u, d.max_bl_u, ru, HFr::one(), std::max<uint64_t>(d.size_u[0], d.bit_length_u[1] >= 0 ? prev.d.size : 0)))) return rc;
     for (int b = 0; b < 2; ++b)
         if ((rc = load_v_table(ctx, ctx->tp[b], b, d.bit_length_v[b], d.size_v[b], cur.ori_v, prev))) return rc;
     if (cur.n_uni2) {
@@ -1337,8 +1349,7 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         const uint64_t npairs = first ? t.len / 2 : t.len / 4;
         // the large-table kernel skips the pairs behind the live prefix; once this table's output is small enough for the other kernels
         // (which read whole tables) the zeros are stored
-        static const bool use_live = !(getenv("ZKCNN_LIVE_PREFIX") && atoi(getenv("ZKCNN_LIVE_PREFIX")) == 0);
-        const uint64_t live = use_live ? std::min(t.live, t.len) : t.len;
+        const uint64_t live = live_prefix_on() ? std::min(t.live, t.len) : t.len;
         A.nl[b] = live;
         A.fill[b] = (t.len / 2 <= (1ull << std::max(fine_log, 16))) ? 1 : 0;
         const uint64_t work = fine ? npairs : std::max<uint64_t>(first ? (live + 1) / 2 : (live + 3) / 4, first ? 1 : (A.fill[b] ? npairs / 8 : 1));
