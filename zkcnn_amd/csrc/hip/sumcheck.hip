@@ -970,11 +970,18 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
         ctx->conv_K = 0;
         if (b == 1 && cur.conv_ok) {
             bool done = false;
-            if ((rc = conv_phase1(ctx, cur, t.M[0], t.len, ctx->alpha * scale, ctx->beta * scale, &done))) return rc;
-            if (!done) ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));       // both claims weighted with zero: every sum is zero
+            const uint64_t lv1 = std::max<uint64_t>(cur.p1_live[1], prev.val_live);
+            const uint64_t end1 = (t.len <= (1ull << 16) || !live_prefix_on()) ? t.len : std::min<uint64_t>(t.len, ((lv1 + 3) & ~3ull) + 4);
+            if ((rc = conv_phase1(ctx, cur, t.M[0], end1, ctx->alpha * scale, ctx->beta * scale, &done))) return rc;
+            if (!done) ZK_HIP(hipMemsetAsync(t.M[0], 0, end1 * 32, ctx->stream));       // both claims weighted with zero: every sum is zero
             continue;
         }
-        if (cur.p1_cov[b] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p1_cov[b], 0, (t.len - cur.p1_cov[b]) * 32, ctx->stream));
+        {
+            // zeros behind the gates' keys: a large table is only ever read up to its live prefix (rounded up to whole quads)
+            const uint64_t lv = b ? std::max<uint64_t>(cur.p1_live[1], prev.val_live) : d.size_u[0];
+            const uint64_t end = (t.len <= (1ull << 16) || !live_prefix_on()) ? t.len : std::min<uint64_t>(t.len, ((lv + 3) & ~3ull) + 4);
+            if (cur.p1_cov[b] < end) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p1_cov[b], 0, (end - cur.p1_cov[b]) * 32, ctx->stream));
+        }
         if ((rc = gate_scatter(ctx, t.M[0], cur.p1[b], cur.n_p1[b], cur.n_p1_real[b], 1, cur, prev, cur.n_p1_uni[b], t.len, cur.p1_G[b]))) return rc;
     }
     // where both tables of a pair end: M has no gate behind p1_live (the factored convolution: behind the tensor it reads); V is the layer-0
@@ -1127,10 +1134,15 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
         if (b == 0 && cur.conv_ok && ctx->conv_K > 0) {
-            if ((rc = conv_phase2(ctx, cur, t.M[0], t.len, ru))) return rc;
+            const uint64_t end0 = (t.len <= (1ull << 16) || !live_prefix_on()) ? t.len : std::min<uint64_t>(t.len, (((uint64_t) d.size_v[0] + 3) & ~3ull) + 4);
+            if ((rc = conv_phase2(ctx, cur, t.M[0], end0, ru))) return rc;
             continue;
         }
-        if (cur.p2_cov[b] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p2_cov[b], 0, (t.len - cur.p2_cov[b]) * 32, ctx->stream));
+        {
+            const uint64_t lv = b ? std::max<uint64_t>(cur.p2_live[1], prev.val_live) : d.size_v[0];
+            const uint64_t end = (t.len <= (1ull << 16) || !live_prefix_on()) ? t.len : std::min<uint64_t>(t.len, ((lv + 3) & ~3ull) + 4);
+            if (cur.p2_cov[b] < end) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p2_cov[b], 0, (end - cur.p2_cov[b]) * 32, ctx->stream));
+        }
         if ((rc = gate_scatter(ctx, t.M[0], cur.p2[b], cur.n_p2[b], cur.n_p2_real[b], 2, cur, prev, 0, t.len, cur.p2_G[b], cur.p2_uniform[b]))) return rc;
     }
     ctx->tp[0].live = std::min<uint64_t>(ctx->tp[0].len, d.size_v[0]);
