@@ -95,6 +95,10 @@ void *zkcnn_verifier_create(const zkcnn_model_desc *desc, const int32_t *scales,
 int32_t zkcnn_session_new_image(void *session, uint64_t picture_seed, const double *pixels, uint64_t n_pixels, double *ms);
 /* the pixel values of synthetic picture `picture_seed` for this session's model (cap >= channel * x * y); returns their number */
 int64_t zkcnn_session_synthetic_picture(void *session, uint64_t picture_seed, double *pixels, uint64_t cap);
+/* Test hooks (both libraries): size of layer `layer` of the session's circuit (its layerType in *type), and overwriting one value of the
+ * witness -- an INVALID witness on purpose: proofs must then be rejected, and a seeded GPU proof must still equal the oracle's. */
+int64_t zkcnn_session_layer_size(void *session, int32_t layer, int32_t *type);
+int32_t zkcnn_session_poke(void *session, int32_t layer, uint64_t index, const uint64_t value[4]);
 void zkcnn_session_destroy(void *session);
 /* The reference CLI's 16-column result row of the last prove call ("a, b, c, ..."), NUL terminated. */
 int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap);

@@ -71,6 +71,9 @@ typedef struct {
 } zk_conv_hint;
 int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul, int32_t n_two_mul,
                                  const zk_conv_hint *hints, uint32_t n_hints);
+/* Test hook: overwrite ONE resident value (an INVALID witness on purpose: the proof must then be rejected, and -- seeded -- still be
+ * byte-identical to the CPU oracle's proof of the same corrupted witness). Keeps the bookkeeping of zk_upload_layer_values exact. */
+int32_t zk_poke_layer_value(zk_ctx *ctx, int32_t layer, uint64_t index, const uint64_t value[4]);
 /* how many layers run the factored path (after an upload) */
 int32_t zk_structured_layers(const zk_ctx *ctx);
 /* val[layer] (n = layer size); stored zero-padded to 2^bit_length */

@@ -143,6 +143,20 @@ int64_t oracle_session_replay_program(void *session, uint64_t picture_seed) {
     return diff;
 }
 
+int64_t oracle_session_layer_size(void *session, int32_t layer, int32_t *type) {
+    if (!session) return -1;
+    const layeredCircuit &C = ((oracleSession *) session)->p.C;
+    if (layer < 0 || layer >= C.size) return -1;
+    if (type) *type = (int32_t) C.circuit[layer].ty;
+    return (int64_t) C.circuit[layer].size;
+}
+int32_t oracle_session_poke(void *session, int32_t layer, uint64_t index, const uint64_t value[4]) {
+    oracleSession *s = (oracleSession *) session;
+    if (!s || !value || layer < 0 || layer >= s->p.C.size || index >= s->p.val[layer].size()) return -1;
+    std::memcpy(&s->p.val[layer][index], value, 32);
+    return 0;
+}
+
 void oracle_session_destroy(void *session) { delete (oracleSession *) session; }
 int32_t oracle_session_row(void *session, char *buf, uint64_t cap) {
     const string &r = ((oracleSession *) session)->row;

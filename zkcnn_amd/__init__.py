@@ -310,6 +310,20 @@ class _SessionBase:
             raise RuntimeError(f"{self._prefix}session_verify failed ({rc}): {res.message.decode(errors='replace')}")
         return res
 
+    def layer_size(self, layer):
+        """(size, layerType) of one layer of the circuit"""
+        fn = self._fn("session_layer_size")
+        fn.restype = ctypes.c_int64
+        ty = ctypes.c_int32(0)
+        return int(fn(ctypes.c_void_p(self.h), ctypes.c_int32(layer), ctypes.byref(ty))), int(ty.value)
+
+    def poke(self, layer, index, value):
+        """test hook: overwrite one witness value (4 x u64 Montgomery limbs) -- an invalid witness on purpose"""
+        arr = (ctypes.c_uint64 * 4)(*value)
+        rc = self._fn("session_poke")(ctypes.c_void_p(self.h), ctypes.c_int32(layer), ctypes.c_uint64(index), arr)
+        if rc != 0:
+            raise RuntimeError(f"{self._prefix}session_poke failed ({rc})")
+
     def row(self):
         buf = ctypes.create_string_buffer(1024)
         self._fn("session_row")(ctypes.c_void_p(self.h), buf, ctypes.c_uint64(1024))

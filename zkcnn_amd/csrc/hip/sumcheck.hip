@@ -562,6 +562,17 @@ extern "C" int32_t zk_upload_layer_values(zk_ctx *ctx, int32_t layer, const uint
     return ZK_OK;
 }
 
+extern "C" int32_t zk_poke_layer_value(zk_ctx *ctx, int32_t layer, uint64_t index, const uint64_t value[4]) {
+    if (!ctx || !ctx->circuit_ready || layer < 0 || layer >= (int) ctx->L.size() || !value) return ZK_ERR_ARG;
+    dev_layer &D = ctx->L[layer];
+    if (index >= D.d.size) { ctx->err = "poke: index behind the layer"; return ZK_ERR_ARG; }
+    ZK_HIP(hipSetDevice(ctx->device));
+    ZK_HIP(hipMemcpyAsync(D.val + index, value, 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if ((value[0] | value[1] | value[2] | value[3]) && index + 1 > D.val_live) D.val_live = index + 1;      // (an upper bound stays an upper bound)
+    return ZK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // building blocks
 // ------------------------------------------------------------------------------------------------

@@ -208,6 +208,19 @@ int64_t zkcnn_session_synthetic_picture(void *session, uint64_t picture_seed, do
     return (int64_t) px.size();
 }
 
+int64_t zkcnn_session_layer_size(void *session, int32_t layer, int32_t *type) {
+    if (!session) return -1;
+    const layeredCircuit &C = ((gpuSession *) session)->p.C;
+    if (layer < 0 || layer >= C.size) return -1;
+    if (type) *type = (int32_t) C.circuit[layer].ty;
+    return (int64_t) C.circuit[layer].size;
+}
+int32_t zkcnn_session_poke(void *session, int32_t layer, uint64_t index, const uint64_t value[4]) {
+    if (!session || !value) return -1;
+    gpuSession *s = (gpuSession *) session;
+    return zk_poke_layer_value(s->p.context(), layer, index, value) == ZK_OK ? 0 : -2;
+}
+
 void zkcnn_session_destroy(void *session) { delete (gpuSession *) session; }
 
 int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap) {
