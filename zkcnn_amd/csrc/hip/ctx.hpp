@@ -100,6 +100,10 @@ struct zk_ctx {
     // per-round hand-over: mapped pinned host slot written by the last block of a fused round kernel
     struct host_slot_h { HFr v[12]; volatile unsigned long long seq; } *h_slot = nullptr;
     void *d_slot = nullptr;        // device address of h_slot
+    // second slot: the two sums behind a phase's add_term (k_sum_partials_slot); read lazily, behind the phase's first round
+    host_slot_h *h_aux = nullptr; void *d_aux = nullptr;
+    unsigned long long aux_seq = 0;
+    bool add_pending = false;
     uint32_t *d_counter = nullptr; // arrival counter of the grid-wide reduction
     unsigned long long slot_seq = 0;
     uint32_t *carry_key = nullptr; fr_t *carry_val = nullptr; uint64_t carry_slots = 0;

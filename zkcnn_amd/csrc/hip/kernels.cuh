@@ -566,6 +566,23 @@ __device__ __forceinline__ void grid_finish(fr_t (&acc)[K], fr_t *partials, uint
     }
 }
 
+// sum of 2 partials per block straight into a mapped host slot (v[0], v[1], then seq): the host reads them when it needs them, no copy, no stream wait
+__global__ void __launch_bounds__(ZK_BLOCK) k_sum_partials_slot(host_slot *slot, const fr_t *partials, uint32_t nblocks, unsigned long long seq) {
+    __shared__ fr_t smem[2 * ZK_BLOCK / 64];
+    fr_t acc[2] = {fr_zero(), fr_zero()};
+    for (uint32_t b = threadIdx.x; b < nblocks; b += ZK_BLOCK) {
+        acc[0] = fr_add(acc[0], fr_load(partials + (size_t) b * 2));
+        acc[1] = fr_add(acc[1], fr_load(partials + (size_t) b * 2 + 1));
+    }
+    fr_block_sum<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        fr_store_scoped(&slot->v[0], acc[0], true);
+        fr_store_scoped(&slot->v[1], acc[1], true);
+        ZK_WAIT_STORES();
+        __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 struct round2_args {
     const fr_t *Vin[2], *Min[2];
     fr_t *Vout[2], *Mout[2];

@@ -6,6 +6,7 @@
 #include <sched.h>
 #include <time.h>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include "ctx.hpp"
 #include "kernels.cuh"
@@ -80,6 +81,8 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
         zk_dev_alloc(ctx, (void **) &ctx->d_counter, 64) ||
         hipHostMalloc((void **) &ctx->h_slot, sizeof(*ctx->h_slot), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer(&ctx->d_slot, ctx->h_slot, 0) != hipSuccess ||
+        hipHostMalloc((void **) &ctx->h_aux, sizeof(*ctx->h_aux), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&ctx->d_aux, ctx->h_aux, 0) != hipSuccess ||
         hipMemsetAsync(ctx->d_counter, 0, 64, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
         hipHostMalloc((void **) &ctx->h_result, 32 * 32) != hipSuccess ||
         hipHostMalloc((void **) &ctx->h_tail, std::max(sizeof(tail_out), sizeof(export_out)), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -89,6 +92,7 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
         return ZK_ERR_NOMEM;
     }
     std::memset((void *) ctx->h_slot, 0, sizeof(*ctx->h_slot));
+    std::memset((void *) ctx->h_aux, 0, sizeof(*ctx->h_aux));
     std::memset(ctx->h_tail, 0, std::max(sizeof(tail_out), sizeof(export_out)));
     {
         const int light = getenv("ZKCNN_FINISH_LIGHT") ? atoi(getenv("ZKCNN_FINISH_LIGHT")) : 1;
@@ -117,6 +121,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     for (dev_buf &b : ctx->w_stage) if (b.p) hipFree(b.p);
     if (ctx->h_result) hipHostFree(ctx->h_result);
     if (ctx->h_slot) hipHostFree((void *) ctx->h_slot);
+    if (ctx->h_aux) hipHostFree((void *) ctx->h_aux);
     if (ctx->h_tail) hipHostFree(ctx->h_tail);
     if (ctx->h_liu_tabs) hipHostFree(ctx->h_liu_tabs);
     if (ctx->h_wp_ranges) hipHostFree(ctx->h_wp_ranges);
@@ -935,6 +940,7 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
     ctx->last_poly_valid = false;
     ctx->relu_rou = H(relu_rou);
     ctx->add_term.clear();
+    ctx->add_pending = false;
     ctx->round = 0;
     const HFr scale = H(d.scale);
 
@@ -1110,6 +1116,7 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
     ctx->host_tail_active = false;
     ctx->last_poly_valid = false;
     ctx->add_term.clear();
+    ctx->add_pending = false;
     ctx->round = 0;
     const HFr *ru = ctx->r_u[id].data();
 
@@ -1138,8 +1145,10 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         A.Vu0 = to_dev(ctx->V_u0); A.Vu1 = to_dev(ctx->V_u1); A.phase = 2; A.post_scale = 0; A.post = A.Vu0;
         const uint32_t g = std::min<uint32_t>(grid_for(cur.n_uni2, 1024), ctx->partial_blocks);
         ZK_LAUNCH(PC_GATE_SUM, 0.0, k_gate_sum2, dim3(g), dim3(ZK_BLOCK), ctx->partials, A);
-        ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials<2>, dim3(1), dim3(ZK_BLOCK), ctx->d_result + 8, ctx->partials, g, 0);
+        // the two sums go to a mapped host slot; add_term = V_u0 s0 + V_u1 s1 is formed when the first round needs it (resolve_add_term)
+        ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials_slot, dim3(1), dim3(ZK_BLOCK), (host_slot *) ctx->d_aux, (const fr_t *) ctx->partials, g, ++ctx->aux_seq);
         ZK_HIP(hipGetLastError());
+        ctx->add_pending = true;
     }
     for (int b = 0; b < 2; ++b) {
         table_pair &t = ctx->tp[b];
@@ -1158,11 +1167,25 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
     }
     ctx->tp[0].live = std::min<uint64_t>(ctx->tp[0].len, d.size_v[0]);
     ctx->tp[1].live = std::min<uint64_t>(ctx->tp[1].len, std::max<uint64_t>(cur.p2_live[1], prev.val_live));
-    if (cur.n_uni2) {
-        ZK_HIP(hipMemcpyAsync(ctx->h_result + 8, ctx->d_result + 8, 64, hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->add_term = ctx->V_u0 * ctx->h_result[8] + ctx->V_u1 * ctx->h_result[9];
+    return ZK_OK;
+}
+
+// add_term of a phase 2 whose two sums are still on their way (zk_sumcheck_init_phase2): waits for the mapped slot like wait_slot does
+static int32_t resolve_add_term(zk_ctx *ctx) {
+    if (!ctx->add_pending) return ZK_OK;
+    volatile unsigned long long *p = &ctx->h_aux->seq;
+    for (uint64_t spins = 0; *p != ctx->aux_seq; ++spins) {
+        if (spins > (1ull << 21)) {
+            ZK_HIP(hipStreamSynchronize(ctx->stream));
+            if (*p != ctx->aux_seq) { ctx->err = "add_term sums were not published"; return ZK_ERR_STATE; }
+            break;
+        }
+        if (spins >= 4096) sched_yield();
+        else __builtin_ia32_pause();
     }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    ctx->add_term = ctx->V_u0 * ctx->h_aux->v[0] + ctx->V_u1 * ctx->h_aux->v[1];
+    ctx->add_pending = false;
     return ZK_OK;
 }
 
@@ -1309,6 +1332,8 @@ static void host_tail_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint6
 
 static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]) {
     static const bool seg_timing = getenv("ZKCNN_TIMING") != nullptr;
+    // the tail paths start from add_term: it must be there before they are considered (the plain round below picks it up behind its launch)
+    if (ctx->add_pending && (ctx->host_tail_log >= 0 || ctx->fs_state)) { int32_t rc0 = resolve_add_term(ctx); if (rc0) return rc0; }
     if (ctx->host_tail_log >= 0 && !ctx->host_tail_active && !ctx->tail_active && ctx->phase_rounds > ctx->round &&
         std::max(ctx->tp[0].len, ctx->tp[1].len) <= (1ull << ctx->host_tail_log) && ctx->tp[0].len + ctx->tp[1].len > 0) {
         int32_t rc = host_tail_begin(ctx);
@@ -1344,7 +1369,8 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
     double ts_wait0 = 0, ts_wait1 = 0;
     const bool first = ctx->round == 0;
     ++ctx->round;
-    if (with_add_term) ctx->add_term = ctx->add_term * (HFr::one() - r);
+    const bool add_deferred = ctx->add_pending;
+    if (with_add_term && !add_deferred) ctx->add_term = ctx->add_term * (HFr::one() - r);
     bool collapsed[2] = {false, false};
     round2_args A;
     std::memset(&A, 0, sizeof(A));
@@ -1415,6 +1441,11 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
                 t.tail_valid = true;
             }
         }
+    }
+    if (add_deferred) {            // (its kernels ran before this round's: the slot is there by now)
+        int32_t rc1 = resolve_add_term(ctx);
+        if (rc1) return rc1;
+        if (with_add_term) ctx->add_term = ctx->add_term * (HFr::one() - r);
     }
     HFr a = ctx->h_result[0], c = ctx->h_result[1], p1 = ctx->h_result[2];
     HFr bcoef = p1 - a - c;
@@ -1536,6 +1567,7 @@ extern "C" int32_t zk_sumcheck_liu_init(zk_ctx *ctx, const uint64_t *s_u, const 
     ctx->host_tail_active = false;
     ctx->last_poly_valid = false;
     ctx->add_term.clear();
+    ctx->add_pending = false;
     ctx->round = 0;
     table_pair &t = ctx->tp[1];
     t.Vsrc = L0.val;
