@@ -89,8 +89,8 @@ void *zkcnn_verifier_create(const zkcnn_model_desc *desc, const int32_t *scales,
  * values. The circuit's shape depends on the picture through its quantisation scales; returns
  *   0  done: the session now proves the new picture (same transcript as a session created for it from scratch),
  *   1  this picture's own range asks for another input scale -- nothing was changed,
- *   2  some layer's activation range asks for another scale -- the values in HBM are now unusable until a later call returns 0
- *      (create a new session for such a picture),
+ *   2  some layer's activation range asks for another scale -- refused; the witness of the picture the session proved before is put
+ *      back (a second replay), so the session keeps proving THAT picture (create a new session for the refused one),
  *  <0  error. *ms (may be NULL) receives the wall-clock milliseconds of the call. */
 int32_t zkcnn_session_new_image(void *session, uint64_t picture_seed, const double *pixels, uint64_t n_pixels, double *ms);
 /* the pixel values of synthetic picture `picture_seed` for this session's model (cap >= channel * x * y); returns their number */

@@ -356,7 +356,7 @@ class Session(_SessionBase):
         """the next picture on the resident circuit (zkcnn_session_new_image): the synthetic picture of `picture_seed`, or `pixels`
         (channel, x, y order). Layer values and auxiliary witnesses are recomputed in HBM -- no circuit generation, no upload.
         Returns (code, ms): 0 = the session now proves this picture; 1 = its input range needs another circuit (nothing changed);
-        2 = an activation range needs another circuit (this session cannot prove until a later call returns 0)."""
+        2 = an activation range needs another circuit: refused, the session keeps proving the picture it proved before."""
         ms = ctypes.c_double(0)
         if pixels is not None:
             arr = (ctypes.c_double * len(pixels))(*pixels)

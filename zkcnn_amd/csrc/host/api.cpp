@@ -110,11 +110,21 @@ struct gpuSession : public sessionT<prover> {
         p.rerunWitness(picture, raw, n_ranges, last);
         vector<std::pair<u64, u64>> ranges(n_ranges);
         for (size_t k = 0; k < n_ranges; ++k) ranges[k] = std::make_pair(raw[2 * k], raw[2 * k + 1]);
-        if (!nn->rangesReproduceScales(ranges)) return 2;
+        if (!nn->rangesReproduceScales(ranges)) {
+            // refused: put the picture the session proved before back (a second replay; its ranges are the circuit's by construction)
+            if (good_picture.size() == picture.size()) {
+                p.rerunWitness(good_picture, raw, n_ranges, last);
+                for (size_t k = 0; k < n_ranges; ++k) ranges[k] = std::make_pair(raw[2 * k], raw[2 * k + 1]);
+                has_witness = nn->rangesReproduceScales(ranges);
+            }
+            return 2;
+        }
         nn->setInferenceFrom(last);
+        good_picture.swap(picture);
         has_witness = true;
         return 0;
     }
+    vector<F> good_picture;            // quantised picture of the witness in HBM (what a refused new_image restores)
 };
 
 extern "C" {
@@ -132,6 +142,8 @@ void *zkcnn_session_create(const zkcnn_model_desc *desc, int32_t device) {
             if (!ok) return nullptr;
         }
         s->p.init();                 // residency: circuit + witness to HBM, outside any timed region
+        if (s->nn && !s->p.val.empty() && s->p.val[0].size() >= s->nn->program().picture_values)
+            s->good_picture.assign(s->p.val[0].begin(), s->p.val[0].begin() + (size_t) s->nn->program().picture_values);
         s->p.releaseHostValues();    // the host copy of every layer's values (0.7 GB for vgg11) has no reader left: proofs and new pictures work on the HBM copy
         return s.release();
     } catch (const std::exception &e) {
