@@ -43,3 +43,16 @@ def test_full_vgg11_uses_the_factored_path(built):
         n = res.n_messages
         bad, _ = s.prove(seed=0x5EED0033, mode=REUSE | zkcnn_amd.MODE_TAMPER | ((n // 2) << 8))
         assert bad.accepted == 0
+
+
+@pytest.mark.parametrize("model,pic,pp,n_struct", [CASES[0], CASES[1], CASES[2], CASES[4]])
+def test_convolution_parameters_are_found_without_hints(built, monkeypatch, model, pic, pp, n_struct):
+    """an unmodified reference generator passes no hints: the upload infers channel counts, sides, kernel size, padding and stride from
+    the gate list (and checks them against every gate) -- same layers factored, same transcript"""
+    with zkcnn_amd.Session(model, pic, pp) as s:
+        _, want = s.prove(seed=0x5EED0035, mode=REUSE)
+    monkeypatch.setenv("ZKCNN_CONV_HINTS", "0")
+    with zkcnn_amd.Session(model, pic, pp) as s:
+        assert s.structured_layers() == n_struct
+        res, got = s.prove(seed=0x5EED0035, mode=REUSE)
+        assert res.accepted == 1 and got == want

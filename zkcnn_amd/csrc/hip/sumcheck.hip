@@ -6,6 +6,7 @@
 #include <sched.h>
 #include <time.h>
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <cstring>
 #include "ctx.hpp"
@@ -311,6 +312,44 @@ static bool conv_hint_matches(const zk_conv_hint &h, const zk_layer_desc &S, con
     return true;
 }
 
+// No hint for an NCONV layer (e.g. the reference's unmodified circuit generator drives this library): look for the parameters. The number
+// of distinct bias operands gives channel_out, the smallest weight index the first weight, the subset size channel_out * channel_in * m^2;
+// kernel size, padding, stride and the number of pictures are tried (square pictures), and every candidate has to reproduce the gate list
+// in conv_hint_matches -- a wrong guess fails on its first gates.
+static bool conv_infer(const zk_layer_desc &S, const zk_layer_desc &P, int layer, conv_desc &c) {
+    if (S.ty != ZK_NCONV || !S.n_bin || !S.n_uni || !S.size_v[0] || S.n_uni > S.size) return false;
+    uint32_t lo_u = 0xffffffffu, hi_u = 0;
+    for (uint64_t j = 0; j < S.n_uni; ++j) {
+        if (S.uni_gates[j].lu != 0 || S.uni_gates[j].u >= S.size_u[0]) return false;
+        const uint32_t raw = S.ori_id_u[S.uni_gates[j].u];
+        lo_u = std::min(lo_u, raw);
+        hi_u = std::max(hi_u, raw);
+    }
+    const uint32_t CO = hi_u - lo_u + 1;                    // the biases are consecutive layer-0 entries
+    if (!CO || S.size % CO || S.size_v[0] % CO) return false;
+    uint32_t wstart = 0xffffffffu;
+    for (uint32_t v = 0; v < S.size_v[0]; ++v) wstart = std::min(wstart, S.ori_id_v[v]);
+    const uint64_t per_co = S.size / CO;                    // pictures * output positions
+    for (uint32_t m = 1; m <= 7; m += 2) {
+        if ((S.size_v[0] / CO) % (m * m)) continue;
+        const uint32_t CI = S.size_v[0] / CO / (m * m);
+        for (uint32_t pp = 1; pp <= 64; ++pp) {
+            if (per_co % pp) continue;
+            const uint64_t pos = per_co / pp;
+            const uint32_t nxo = (uint32_t) std::llround(std::sqrt((double) pos));
+            if ((uint64_t) nxo * nxo != pos) continue;
+            for (uint32_t ls = 0; ls <= 2; ++ls)
+                for (uint32_t pad = 0; pad < m; ++pad) {
+                    const int64_t nxi = ((int64_t) (nxo - 1) << ls) + m - 2 * (int64_t) pad;
+                    if (nxi < 1 || (uint64_t) pp * CI * nxi * nxi > P.size) continue;
+                    zk_conv_hint h = {layer, pp, CO, CI, (uint32_t) nxi, (uint32_t) nxi, nxo, nxo, m, pad, ls, wstart};
+                    if (conv_hint_matches(h, S, P, c)) return true;
+                }
+        }
+    }
+    return false;
+}
+
 extern "C" int32_t zk_structured_layers(const zk_ctx *ctx) { return ctx ? (int32_t) ctx->conv_layers : 0; }
 
 extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul,
@@ -337,6 +376,14 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
         dev_layer &D = ctx->L[i];
         conv_desc c;
         if (D.conv_ok || !conv_hint_matches(hints[k], layers[i], layers[i - 1], c)) continue;
+        D.conv = c;
+        D.conv_ok = true;
+        ++ctx->conv_layers;
+    }
+    for (int i = 2; i < n_layers; ++i) {                    // layers nobody described
+        dev_layer &D = ctx->L[i];
+        conv_desc c;
+        if (D.conv_ok || layers[i].ty != ZK_NCONV || !conv_infer(layers[i], layers[i - 1], i, c)) continue;
         D.conv = c;
         D.conv_ok = true;
         ++ctx->conv_layers;

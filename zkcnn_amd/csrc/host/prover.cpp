@@ -121,7 +121,10 @@ void prover::init() {
         upload_timer.start();
         // a context holds one circuit; a changed circuit gets a fresh one
         vector<zk_layer_desc> desc = layerDescs();
-        auto up = [&]() { return zk_upload_circuit_hinted(ctx, desc.data(), C.size, U(C.two_mul[0]), (int) C.two_mul.size(), conv_hints.data(), (uint32_t) conv_hints.size()); };
+        // (ZKCNN_CONV_HINTS=0: upload without the generator's hints, as an unmodified reference generator would -- the library then infers them)
+        const char *he = std::getenv("ZKCNN_CONV_HINTS");
+        const uint32_t n_hints = (he && std::atoi(he) == 0) ? 0u : (uint32_t) conv_hints.size();
+        auto up = [&]() { return zk_upload_circuit_hinted(ctx, desc.data(), C.size, U(C.two_mul[0]), (int) C.two_mul.size(), conv_hints.data(), n_hints); };
         if (up() != ZK_OK) {
             // the context already holds another circuit: start over with a new one
             string first_err = zk_last_error(ctx);
