@@ -134,9 +134,9 @@ def main():
 
     model, pic, pp = WORKLOADS[args.workload]
     K = max(1, args.streams)
-    try:                                # a session keeps ~8 GB of host memory (circuit + witness): do not overcommit a small node
+    try:                                # a vgg11 session holds 2.7 GB on the host (4.3 GB at its peak while it is built: host_peak_rss_gb_while_building): do not overcommit a small node
         import psutil
-        K_ram = max(1, int(psutil.virtual_memory().available / (10e9 * max(world, 1))))
+        K_ram = max(1, int(psutil.virtual_memory().available / (6e9 * max(world, 1))))
         if K_ram < K:
             print(f"[bench] host memory allows {K_ram} sessions per rank, not the {K} asked for", file=sys.stderr)
             K = K_ram
@@ -190,6 +190,13 @@ def main():
         raise SystemExit("a session could not be built")
     setup_s = time.time() - t0
     sess = sessions[0]
+    try:
+        import psutil
+        import resource
+        host_rss_gb = round(psutil.Process().memory_info().rss / 1e9, 2)                      # all K sessions of this rank, resident now
+        host_peak_gb = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024 / 1e9, 2)     # peak while they were being built side by side
+    except Exception:       # noqa: BLE001
+        host_rss_gb = host_peak_gb = None
 
     # ---- warm-up: first step with the full verifier on every image (acceptance), the rest as the timed steps run ----
     firsts = [None] * K
@@ -470,6 +477,8 @@ def main():
         "setup_s": round(setup_s, 1), "witness_s": round(first.witness_s, 1), "upload_sort_s": round(first.upload_s, 2),
         "roofline": roofline, "cpu_baseline": cpu,
     }
+    out["host_rss_gb_all_sessions"] = host_rss_gb
+    out["host_peak_rss_gb_while_building"] = host_peak_gb
     out.update(extras)
     print(json.dumps(out), flush=True)
     if dist is not None:
