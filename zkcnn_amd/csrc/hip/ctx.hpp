@@ -142,6 +142,8 @@ struct zk_ctx {
     const uint32_t *fs_state = nullptr;
     const uint64_t *fs_pending = nullptr;
     void *h_tail = nullptr, *d_tail = nullptr;     // tail_out, pinned + mapped
+    void *d_chain = nullptr;                        // chain_state: challenge, add_term, chain state handed from one chained round launch to the next
+    uint64_t chain_rounds_total = 0;
     bool tail_active = false;
     int tail_count = 0, tail_cursor = 0, phase_rounds = 0;
     unsigned long long tail_seq = 0;

@@ -78,6 +78,7 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
     if (zk_dev_alloc(ctx, (void **) &ctx->eq_lo, 2 * (size_t) ctx->eq_stride * 32) ||
         zk_dev_alloc(ctx, (void **) &ctx->eq_hi, 2 * (size_t) ctx->eq_stride * 32) ||
         zk_dev_alloc(ctx, (void **) &ctx->partials, (size_t) ctx->partial_blocks * 4 * 32) ||
+        zk_dev_alloc(ctx, &ctx->d_chain, sizeof(chain_state)) ||
         zk_dev_alloc(ctx, (void **) &ctx->d_result, 32 * 32) ||
         zk_dev_alloc(ctx, (void **) &ctx->d_counter, 64) ||
         hipHostMalloc((void **) &ctx->h_slot, sizeof(*ctx->h_slot), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -1240,61 +1241,108 @@ static int32_t resolve_add_term(zk_ctx *ctx) {
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // Non-interactive mode: all remaining rounds of the phase in one single-workgroup kernel (fs_tail.cuh). Called at the start of a round
 // whose live tables are small; fills the context's tail record and leaves every table pair either collapsed or down to its last pair.
-static int32_t run_tail(zk_ctx *ctx, const HFr &r, bool with_add_term) {
+// Non-interactive mode: rounds the device runs by itself. `chain` rounds (planned by the caller: tables of at most 2^16 entries, no table
+// collapsing or down to its last pair) are one launch each, enqueued back to back, each deriving the next challenge in its last block
+// (k_round_chain); behind them -- or alone -- the single-workgroup kernel runs ALL remaining rounds of the phase once the tables are small
+// (k_fs_tail, `with_tail`). The host waits once, fills the record the following calls are answered from, and leaves every table pair
+// collapsed, down to its last pair, or (chain only) where the last chained round left it.
+static int32_t run_device_rounds(zk_ctx *ctx, const HFr &r, bool with_add_term, int chain, bool with_tail) {
+    const bool first0 = ctx->round == 0;
+    const unsigned long long seq = ++ctx->tail_seq;
+    for (int j = 0; j < chain; ++j) {
+        const bool f = first0 && j == 0;
+        chain_args C;
+        std::memset(&C, 0, sizeof(C));
+        uint64_t items = 0;
+        for (int b = 0; b < 2; ++b) {
+            table_pair &t = ctx->tp[b];
+            if (!t.len) continue;
+            C.Vin[b] = vin(t); C.Min[b] = t.M[t.cur];
+            C.Vout[b] = t.V[t.cur ^ 1]; C.Mout[b] = t.M[t.cur ^ 1];
+            C.n[b] = t.len;
+            items += f ? t.len / 2 : t.len / 4;
+        }
+        C.first = f ? 1 : 0;
+        C.with_add_term = with_add_term ? 1 : 0;
+        C.from_args = j == 0 ? 1 : 0;
+        C.k = j;
+        C.last = (j == chain - 1 && !with_tail) ? 1 : 0;
+        C.prev_r = to_dev(r);
+        C.add_term = to_dev(ctx->add_term);
+        std::memcpy(C.fs_state, ctx->fs_state, 32);
+        C.cs = (chain_state *) ctx->d_chain;
+        C.partials = ctx->partials;
+        C.counter = ctx->d_counter;
+        C.out = (tail_out *) ctx->d_tail;
+        C.seq = seq;
+        const uint32_t blocks = (uint32_t) ((items + ZK_BLOCK / 4 - 1) / (ZK_BLOCK / 4));
+        ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_round_chain, dim3(blocks), dim3(ZK_BLOCK), C);
+        for (int b = 0; b < 2; ++b) {
+            table_pair &t = ctx->tp[b];
+            if (t.len && !f) { t.cur ^= 1; t.len >>= 1; t.Vsrc = nullptr; t.live = t.len; }
+        }
+    }
     tail_args A;
     std::memset(&A, 0, sizeof(A));
-    const bool first = ctx->round == 0;
-    for (int b = 0; b < 2; ++b) {
-        table_pair &t = ctx->tp[b];
-        if (!t.len) continue;
-        A.Vin[b] = vin(t); A.Min[b] = t.M[t.cur];
-        A.Vbuf[b][0] = t.V[0]; A.Vbuf[b][1] = t.V[1];
-        A.Mbuf[b][0] = t.M[0]; A.Mbuf[b][1] = t.M[1];
-        A.out_idx[b] = t.cur ^ 1;
-        A.n[b] = t.len;
+    if (with_tail) {
+        const bool first = first0 && chain == 0;
+        for (int b = 0; b < 2; ++b) {
+            table_pair &t = ctx->tp[b];
+            if (!t.len) continue;
+            A.Vin[b] = vin(t); A.Min[b] = t.M[t.cur];
+            A.Vbuf[b][0] = t.V[0]; A.Vbuf[b][1] = t.V[1];
+            A.Mbuf[b][0] = t.M[0]; A.Mbuf[b][1] = t.M[1];
+            A.out_idx[b] = t.cur ^ 1;
+            A.n[b] = t.len;
+        }
+        A.first = first ? 1 : 0;
+        A.rounds = ctx->phase_rounds - ctx->round - chain;
+        A.with_add_term = with_add_term ? 1 : 0;
+        A.prev_r = to_dev(r);
+        A.add_term = to_dev(ctx->add_term);
+        std::memcpy(A.fs_state, ctx->fs_state, 32);
+        A.out = (tail_out *) ctx->d_tail;
+        A.seq = seq;
+        A.cs = chain ? (const chain_state *) ctx->d_chain : nullptr;
+        A.k0 = chain;
+        ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_fs_tail, dim3(1), dim3(FS_TAIL_THREADS), A);
     }
-    A.first = first ? 1 : 0;
-    A.rounds = ctx->phase_rounds - ctx->round;
-    A.with_add_term = with_add_term ? 1 : 0;
-    A.prev_r = to_dev(r);
-    A.add_term = to_dev(ctx->add_term);
-    std::memcpy(A.fs_state, ctx->fs_state, 32);
-    A.out = (tail_out *) ctx->d_tail;
-    A.seq = ++ctx->tail_seq;
-    ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_fs_tail, dim3(1), dim3(FS_TAIL_THREADS), A);
     ZK_HIP(hipGetLastError());
     volatile unsigned long long *p = &((tail_out *) ctx->h_tail)->seq;
-    for (uint64_t spins = 0; *p != A.seq; ++spins) {
+    for (uint64_t spins = 0; *p != seq; ++spins) {
         if (spins > (1ull << 24)) {
             ZK_HIP(hipStreamSynchronize(ctx->stream));
-            if (*p != A.seq) { ctx->err = "tail rounds were not published"; return ZK_ERR_STATE; }
+            if (*p != seq) { ctx->err = "device rounds were not published"; return ZK_ERR_STATE; }
             break;
         }
         __builtin_ia32_pause();
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const tail_out *o = (const tail_out *) ctx->h_tail;
-    for (int b = 0; b < 2; ++b) {
-        table_pair &t = ctx->tp[b];
-        if (!t.len) continue;
-        t.Vsrc = nullptr;
-        if (o->pair_state[b] == 1) {
-            t.len = 2;
-            std::memcpy(&t.tail_v[0], &o->tail_v[b][0], 32);
-            std::memcpy(&t.tail_v[1], &o->tail_v[b][1], 32);
-            t.tail_valid = true;
-        } else {
-            t.len = 0;
-            t.absorbed = true;
-            std::memcpy(&t.final_v, &o->final_v[b], 32);
+    if (with_tail)
+        for (int b = 0; b < 2; ++b) {
+            table_pair &t = ctx->tp[b];
+            if (!t.len) continue;
+            t.Vsrc = nullptr;
+            if (o->pair_state[b] == 1) {
+                t.len = 2;
+                std::memcpy(&t.tail_v[0], &o->tail_v[b][0], 32);
+                std::memcpy(&t.tail_v[1], &o->tail_v[b][1], 32);
+                t.tail_valid = true;
+            } else {
+                t.len = 0;
+                t.absorbed = true;
+                std::memcpy(&t.final_v, &o->final_v[b], 32);
+            }
         }
-    }
     std::memcpy(&ctx->add_term, &o->add_term, 32);
     ctx->tail_active = true;
-    ctx->tail_count = A.rounds;
+    ctx->tail_count = chain + (with_tail ? A.rounds : 0);
     ctx->tail_cursor = 0;
-    ctx->tail_rounds_total += (uint64_t) A.rounds;
-    ++ctx->tail_phases_total;
+    ctx->last_poly_valid = false;          // (the rounds answered from the record do not maintain the running claim)
+    ctx->tail_rounds_total += (uint64_t) ctx->tail_count;
+    ctx->chain_rounds_total += (uint64_t) chain;
+    if (with_tail) ++ctx->tail_phases_total;
     return ZK_OK;
 }
 
@@ -1394,10 +1442,31 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
     static const uint64_t tail_quads = getenv("ZKCNN_TAIL_QUADS") ? std::min<uint64_t>(FS_TAIL_QUADS, (uint64_t) atoll(getenv("ZKCNN_TAIL_QUADS"))) : 256;
     // quads of this round over both pairs (a first round works on pairs, not quads): small enough for one thread each?
     const uint64_t round_quads = ctx->round == 0 ? (ctx->tp[0].len + ctx->tp[1].len) / 2 : (ctx->tp[0].len + ctx->tp[1].len) / 4;
-    if (ctx->fs_state && !ctx->tail_active && ctx->phase_rounds > ctx->round && *ctx->fs_pending == 0 && round_quads <= tail_quads &&
-        ctx->tp[0].len + ctx->tp[1].len > 0) {
-        int32_t rc = run_tail(ctx, r, with_add_term);
-        if (rc) return rc;
+    if (ctx->fs_state && !ctx->tail_active && ctx->phase_rounds > ctx->round && *ctx->fs_pending == 0 && ctx->tp[0].len + ctx->tp[1].len > 0) {
+        // plan: chained rounds (one launch each, no host in between) while the tables are too large for the tail kernel, then the tail kernel.
+        // A round is chained if every table has at most 2^16 entries and at least two quads (nothing collapses, no last pair to hand over).
+        // (chaining is OFF unless ZKCNN_FS_CHAIN=1: measured on vgg11 it is 0.5 ms per proof SLOWER than letting the host drive these rounds --
+        // the last block's epilogue, partial sums reloaded across the chip plus two BLAKE2s compressions on one lane, costs what the host turn-around cost)
+        const char *ce = getenv("ZKCNN_FS_CHAIN");
+        const bool chain_on = ce && atoi(ce) != 0;
+        uint64_t L[2] = {ctx->tp[0].len, ctx->tp[1].len};
+        int chain = 0;
+        bool with_tail = false;
+        for (int j = 0; ctx->round + j < ctx->phase_rounds; ++j) {
+            const bool f = ctx->round == 0 && j == 0;
+            const uint64_t q = f ? (L[0] + L[1]) / 2 : (L[0] + L[1]) / 4;
+            if (q <= tail_quads) { with_tail = true; break; }
+            bool ok = chain_on && std::max(L[0], L[1]) <= (1ull << 16) && 2 * (std::max(L[0], L[1]) / 4 / (ZK_BLOCK / 4) + 1) <= ctx->partial_blocks;
+            for (int b = 0; b < 2 && ok; ++b)
+                if (L[b] && (f ? L[b] / 2 : L[b] / 4) < 2) ok = false;
+            if (!ok) break;
+            ++chain;
+            if (!f) { L[0] >>= 1; L[1] >>= 1; }
+        }
+        if (chain || (with_tail && round_quads <= tail_quads)) {
+            int32_t rc = run_device_rounds(ctx, r, with_add_term, chain, with_tail);
+            if (rc) return rc;
+        }
     }
     if (ctx->tail_active) {
         const tail_out *o = (const tail_out *) ctx->h_tail;
