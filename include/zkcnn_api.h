@@ -67,6 +67,10 @@ typedef struct {
 /* Builds the circuit and the witness (and, for the product library, uploads both to `device`).
  * Returns NULL on error. */
 void *zkcnn_session_create(const zkcnn_model_desc *desc, int32_t device);
+/* Calibrated session: the same, but under GIVEN quantisation scales (zkcnn_session_statement of an earlier session of the model) instead of
+ * the ones this picture's ranges would give -- every picture of a calibrated model then has the same circuit. NULL if the picture's values
+ * do not fit the scales. */
+void *zkcnn_session_create_calibrated(const zkcnn_model_desc *desc, const int32_t *scales, uint64_t n_scales, int32_t device);
 /* One proof. `transcript` may be NULL; at most `cap` bytes are written, the full length is reported. */
 int32_t zkcnn_session_prove(void *session, uint64_t challenge_seed, uint32_t mode, uint8_t *transcript,
                             uint64_t cap, zkcnn_result *out);
@@ -87,9 +91,10 @@ void *zkcnn_verifier_create(const zkcnn_model_desc *desc, const int32_t *scales,
  * channel * x * y values; NULL: the synthetic picture of `picture_seed`) is quantised on the host and every layer value and auxiliary
  * witness is recomputed in HBM by replaying the witness program the circuit generator recorded -- no circuit generation, no upload of
  * values. The circuit's shape depends on the picture through its quantisation scales; returns
- *   0  done: the session now proves the new picture (same transcript as a session created for it from scratch),
- *   1  this picture's own range asks for another input scale -- nothing was changed,
- *   2  some layer's activation range asks for another scale -- refused; the witness of the picture the session proved before is put
+ *   0  done: the session now proves the new picture (same transcript as a calibrated session created for it from scratch: every value
+ *      range fits the circuit's scale -- the picture's own scales are equal or larger),
+ *   1  this picture's own range does not fit the input scale -- nothing was changed,
+ *   2  some layer's activation range does not fit its scale -- refused; the witness of the picture the session proved before is put
  *      back (a second replay), so the session keeps proving THAT picture (create a new session for the refused one),
  *  <0  error. *ms (may be NULL) receives the wall-clock milliseconds of the call. */
 int32_t zkcnn_session_new_image(void *session, uint64_t picture_seed, const double *pixels, uint64_t n_pixels, double *ms);

@@ -19,6 +19,15 @@ void *oracle_session_create(const zkcnn_model_desc *desc, int32_t) {
     if (!s->build(desc)) { delete s; return nullptr; }
     return s;
 }
+void *oracle_session_create_calibrated(const zkcnn_model_desc *desc, const int32_t *scales, uint64_t n_scales, int32_t) {
+    if (!desc || !scales || !n_scales) return nullptr;
+    oracleSession *s = new oracleSession();
+    const vector<int> given(scales, scales + n_scales);
+    try {
+        if (!s->build(desc, &given)) { delete s; return nullptr; }
+    } catch (const std::exception &) { delete s; return nullptr; }
+    return s;
+}
 int32_t oracle_session_prove(void *session, uint64_t seed, uint32_t mode, uint8_t *transcript, uint64_t cap,
                              zkcnn_result *out) {
     return ((oracleSession *) session)->prove(seed, mode, transcript, cap, out);
@@ -41,7 +50,7 @@ int32_t oracle_session_verify(void *session, uint64_t seed, uint32_t mode, const
 // ---- the recorded witness program, interpreted on the CPU (what zk_witness_rerun does in HBM, restated with plain loops) ----
 // Session `session` was built for some picture; this replays its program for synthetic picture `picture_seed` and compares EVERY layer
 // value with a second session built for that picture from scratch. Returns the number of differing entries (0 = the program is a
-// faithful description of the witness), -2 if the two pictures need different quantisation scales (nothing to compare), -1 on error.
+// faithful description of the witness), -2 if the picture's values do not fit this session's quantisation scales (nothing to compare), -1 on error.
 int64_t oracle_session_replay_program(void *session, uint64_t picture_seed) {
     oracleSession *s = (oracleSession *) session;
     if (!s || !s->nn || !s->has_witness) return -1;
@@ -49,9 +58,11 @@ int64_t oracle_session_replay_program(void *session, uint64_t picture_seed) {
     d.model = s->model_name.c_str();
     d.pic_x = s->pic_x; d.pic_y = s->pic_y; d.pic_channel = s->pic_channel; d.pic_cnt = s->pic_cnt;
     d.data_seed = s->data_seed; d.picture_seed = picture_seed;
-    oracleSession full;
-    if (!full.build(&d)) return -1;
-    if (full.statementScales() != s->statementScales()) return -2;
+    oracleSession full;                                    // the same picture from scratch, under this session's scales
+    try {
+        if (!full.build(&d, &s->statementScales())) return -2;       // its values do not fit them: nothing to compare
+    } catch (const std::exception &) { return -1; }
+    if (full.statementScales() != s->statementScales()) return -1;
 
     const layeredCircuit &C = s->p.C;
     const witnessProgram &pg = s->nn->program();
@@ -134,7 +145,7 @@ int64_t oracle_session_replay_program(void *session, uint64_t picture_seed) {
             }
         }
     }
-    if (!s->nn->rangesReproduceScales(ranges)) return -2;
+    if (!s->nn->rangesFitScales(ranges)) return -2;
     int64_t diff = 0;
     for (int i = 0; i < C.size; ++i) {
         if (val[i].size() != full.p.val[i].size()) return -1;

@@ -154,8 +154,8 @@ class OracleSession(zkcnn_amd._SessionBase):
     """whole-proof driver of include/zkcnn_api.h backed by the CPU restatement"""
     _prefix = "oracle_"
 
-    def __init__(self, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, statement=None, picture_seed=0):
-        super().__init__(load().lib, model, pic, pic_cnt, data_seed, 0, statement, picture_seed)
+    def __init__(self, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, statement=None, picture_seed=0, calibrated=None):
+        super().__init__(load().lib, model, pic, pic_cnt, data_seed, 0, statement, picture_seed, calibrated)
 
 
 _oracle = None

@@ -25,19 +25,24 @@ def _replay(o, picture_seed):
 
 @pytest.mark.parametrize("model,pic,pp", MODELS)
 def test_recorded_program_reproduces_a_fresh_build(oracle, model, pic, pp):
-    # the circuit's shape depends on the picture through its quantisation scales: group a few pictures by statement first
-    groups = {}
-    for p in range(1, 6):
-        with oracle_ffi.OracleSession(model, pic, pp, data_seed=4242, picture_seed=p) as o:
-            groups.setdefault(tuple(o.statement()), []).append(p)
-    same = max(groups.values(), key=len)
-    assert len(same) >= 2, f"no two of five pictures share their quantisation scales: {groups}"
-    other = [p for g in groups.values() for p in g if p not in same]
-    with oracle_ffi.OracleSession(model, pic, pp, data_seed=4242, picture_seed=same[0]) as o:
-        for p in same[1:3]:
-            assert _replay(o, p) == 0, f"picture {p}: layer values of the replayed program differ from a fresh build"
-        if other:
-            assert _replay(o, other[0]) == -2                 # another scale somewhere: the replay must notice
+    """a session built for picture 1 fixes the circuit's quantisation scales; every other picture either fits them -- then the replayed
+    program must give, value for value, what a CALIBRATED build of that picture gives (same scales, from scratch) -- or does not, and
+    both sides must say so"""
+    fits = refused = 0
+    with oracle_ffi.OracleSession(model, pic, pp, data_seed=4242, picture_seed=1) as o:
+        scales = o.statement()
+        for p in range(2, 9):
+            r = _replay(o, p)
+            assert r in (0, -2), f"picture {p}: {r} layer values of the replayed program differ from a calibrated build"
+            try:
+                with oracle_ffi.OracleSession(model, pic, pp, data_seed=4242, picture_seed=p, calibrated=scales) as c:
+                    assert r == 0 and c.statement() == scales and c.prove(seed=3)[0].accepted == 1
+                fits += 1
+            except RuntimeError:
+                assert r == -2, f"picture {p} does not fit the scales but the replay did not notice"
+                refused += 1
+    assert fits >= 1, "none of seven pictures fits the scales of picture 1: nothing was compared"
+    print(f"{model}: {fits} pictures fit, {refused} refused")
 
 
 def test_picture_seed_changes_the_picture_only(oracle):

@@ -22,54 +22,58 @@ MODELS = [
 ]
 
 
-def _group_by_statement(model, pic, pp, pictures):
-    groups = {}
+def _fits_and_refused(model, pic, pp, scales, pictures):
+    """pictures whose values fit `scales` (with the transcript a calibrated oracle session gives for them) / those that do not"""
+    want, refused = {}, []
     for p in pictures:
-        with oracle_ffi.OracleSession(model, pic, pp, data_seed=W, picture_seed=p) as o:
-            groups.setdefault(tuple(o.statement()), []).append(p)
-    same = max(groups.values(), key=len)
-    other = [p for g in groups.values() for p in g if p not in same]
-    return same, other
+        try:
+            with oracle_ffi.OracleSession(model, pic, pp, data_seed=W, picture_seed=p, calibrated=scales) as o:
+                res, tr = o.prove(seed=SEED, mode=REUSE)
+                assert res.accepted == 1 and o.statement() == scales
+                want[p] = tr
+        except RuntimeError:
+            refused.append(p)
+    return want, refused
 
 
 @pytest.mark.parametrize("model,pic,pp", MODELS)
 def test_new_image_transcripts_identical_to_fresh_sessions(built, model, pic, pp):
-    same, other = _group_by_statement(model, pic, pp, range(1, 7))
-    assert len(same) >= 2, "no two of six pictures share their quantisation scales"
-    want = {}
-    for p in same[:3]:
-        with oracle_ffi.OracleSession(model, pic, pp, data_seed=W, picture_seed=p) as o:
-            res, tr = o.prove(seed=SEED, mode=REUSE)
-            assert res.accepted == 1
-            want[p] = tr
-    with zkcnn_amd.Session(model, pic, pp, data_seed=W, picture_seed=same[0]) as s:
-        res, tr = s.prove(seed=SEED, mode=REUSE)
-        assert res.accepted == 1 and tr == want[same[0]]
-        for p in same[1:3]:
+    with zkcnn_amd.Session(model, pic, pp, data_seed=W, picture_seed=1) as s:
+        scales = s.statement()
+        res, first = s.prove(seed=SEED, mode=REUSE)
+        assert res.accepted == 1
+        with oracle_ffi.OracleSession(model, pic, pp, data_seed=W, picture_seed=1) as o:
+            assert o.statement() == scales and o.prove(seed=SEED, mode=REUSE)[1] == first
+        want, refused = _fits_and_refused(model, pic, pp, scales, range(2, 8))
+        assert want, "none of six pictures fits the scales of picture 1"
+        last = first
+        for p in range(2, 8):
             rc, ms = s.new_image(p)
-            assert rc == 0, f"picture {p} has the session's scales but new_image returned {rc}"
-            res, tr = s.prove(seed=SEED, mode=REUSE)
-            assert res.accepted == 1, res.message.decode()
-            assert tr == want[p], f"picture {p}: transcript after new_image differs from a session built for it"
-            assert s.statement() == list(_stmt(model, pic, pp, p))
+            if p in want:
+                assert rc == 0, f"picture {p} fits the session's scales but new_image returned {rc}"
+                res, tr = s.prove(seed=SEED, mode=REUSE)
+                assert res.accepted == 1, res.message.decode()
+                assert tr == want[p], f"picture {p}: transcript after new_image differs from a calibrated session built for it"
+                last = tr
+            else:
+                # refused, and the session keeps proving the picture it proved before (code 2: the values in HBM were overwritten on the
+                # way and the previous picture was replayed)
+                assert rc in (1, 2), f"picture {p} does not fit the session's scales but new_image returned {rc}"
+                assert s.prove(seed=SEED, mode=REUSE)[1] == last
+            assert s.statement() == scales
         # the same picture handed over as pixel values
-        rc, _ = s.new_image(pixels=s.synthetic_picture(same[0]))
-        assert rc == 0
-        assert s.prove(seed=SEED, mode=REUSE)[1] == want[same[0]]
+        p0 = sorted(want)[0]
+        rc, _ = s.new_image(pixels=s.synthetic_picture(p0))
+        assert rc == 0 and s.prove(seed=SEED, mode=REUSE)[1] == want[p0]
         # a Fiat-Shamir proof of the new picture verifies off line
-        rc, _ = s.new_image(same[1])
         res, proof = s.prove(mode=FS)
-        assert rc == 0 and res.accepted == 1 and s.verify(proof, mode=FS).accepted == 1
-        if other:
-            # a picture whose scales differ: refused, and the session keeps proving the picture it proved before (code 2: the values in HBM were
-            # overwritten on the way and the previous picture was replayed)
-            rc, _ = s.new_image(other[0])
-            assert rc in (1, 2)
-            assert s.prove(seed=SEED, mode=REUSE)[1] == want[same[1]]
-            rc, _ = s.new_image(same[0])
-            assert rc == 0 and s.prove(seed=SEED, mode=REUSE)[1] == want[same[0]]
-    with zkcnn_amd.Session(model, pic, pp, data_seed=W, picture_seed=same[1]) as fresh:
-        assert fresh.prove(seed=SEED, mode=REUSE)[1] == want[same[1]]
+        assert res.accepted == 1 and s.verify(proof, mode=FS).accepted == 1
+    # a calibrated GPU session built for the picture from scratch gives the same bytes
+    with zkcnn_amd.Session(model, pic, pp, data_seed=W, picture_seed=p0, calibrated=scales) as fresh:
+        assert fresh.statement() == scales and fresh.prove(seed=SEED, mode=REUSE)[1] == want[p0]
+    if refused:
+        with pytest.raises(RuntimeError):
+            zkcnn_amd.Session(model, pic, pp, data_seed=W, picture_seed=refused[0], calibrated=scales)
 
 
 def _stmt(model, pic, pp, p):
@@ -96,7 +100,7 @@ def test_new_image_full_vgg11(built):
         res, proof = s.prove(mode=FS)
         assert res.accepted == 1 and s.verify(proof, mode=FS).accepted == 1
         stmt = s.statement()
-    with zkcnn_amd.Session(model, pic, pp, data_seed=W, picture_seed=done) as fresh:
+    with zkcnn_amd.Session(model, pic, pp, data_seed=W, picture_seed=done, calibrated=stmt) as fresh:
         assert fresh.statement() == stmt
         assert fresh.prove(seed=SEED, mode=REUSE)[1] == tr
     print("new_image ms:", times)

@@ -240,7 +240,7 @@ class _SessionBase:
     def _fn(self, name):
         return getattr(self.lib, self._prefix + name)
 
-    def __init__(self, lib, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0, statement=None, picture_seed=0):
+    def __init__(self, lib, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0, statement=None, picture_seed=0, calibrated=None):
         """picture_seed=0: picture, weights and biases all come from the data_seed stream; otherwise the picture has its own stream, so
         that sessions with one data_seed share their weights and differ in the picture.
         statement=None: circuit + witness from the (synthetic) data. statement=[ints]: a verifier-only session whose circuit is
@@ -249,7 +249,12 @@ class _SessionBase:
         self.model, self.pic, self.pic_cnt, self.data_seed = model, tuple(pic), pic_cnt, data_seed
         self.picture_seed = picture_seed
         self.desc = ModelDesc(model.encode(), pic[0], pic[1], pic[2], pic_cnt, data_seed, picture_seed)
-        if statement is None:
+        if calibrated is not None:
+            # circuit + witness under GIVEN quantisation scales (the statement() of an earlier session of the model): fails if the picture does not fit them
+            arr = (ctypes.c_int32 * max(len(calibrated), 1))(*calibrated)
+            self._fn("session_create_calibrated").restype = ctypes.c_void_p
+            self.h = self._fn("session_create_calibrated")(ctypes.byref(self.desc), arr, ctypes.c_uint64(len(calibrated)), ctypes.c_int32(device))
+        elif statement is None:
             self._fn("session_create").restype = ctypes.c_void_p
             self.h = self._fn("session_create")(ctypes.byref(self.desc), ctypes.c_int32(device))
         else:
@@ -349,14 +354,15 @@ class Session(_SessionBase):
     """Circuit + witness resident on one GPU; prove() runs verifier <-> HIP prover (include/zkcnn_api.h)."""
     _prefix = "zkcnn_"
 
-    def __init__(self, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0, statement=None, picture_seed=0):
-        super().__init__(host_lib(), model, pic, pic_cnt, data_seed, device, statement, picture_seed)
+    def __init__(self, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0, statement=None, picture_seed=0, calibrated=None):
+        super().__init__(host_lib(), model, pic, pic_cnt, data_seed, device, statement, picture_seed, calibrated)
 
     def new_image(self, picture_seed=None, pixels=None):
         """the next picture on the resident circuit (zkcnn_session_new_image): the synthetic picture of `picture_seed`, or `pixels`
         (channel, x, y order). Layer values and auxiliary witnesses are recomputed in HBM -- no circuit generation, no upload.
-        Returns (code, ms): 0 = the session now proves this picture; 1 = its input range needs another circuit (nothing changed);
-        2 = an activation range needs another circuit: refused, the session keeps proving the picture it proved before."""
+        Returns (code, ms): 0 = the session now proves this picture (every value range fits the circuit's scales: same transcript as
+        Session(..., calibrated=self.statement()) built for it); 1 = its input range does not fit (nothing changed); 2 = an activation range
+        does not fit: refused, the session keeps proving the picture it proved before."""
         ms = ctypes.c_double(0)
         if pixels is not None:
             arr = (ctypes.c_double * len(pixels))(*pixels)

@@ -110,12 +110,12 @@ struct gpuSession : public sessionT<prover> {
         p.rerunWitness(picture, raw, n_ranges, last);
         vector<std::pair<u64, u64>> ranges(n_ranges);
         for (size_t k = 0; k < n_ranges; ++k) ranges[k] = std::make_pair(raw[2 * k], raw[2 * k + 1]);
-        if (!nn->rangesReproduceScales(ranges)) {
+        if (!nn->rangesFitScales(ranges)) {
             // refused: put the picture the session proved before back (a second replay; its ranges are the circuit's by construction)
             if (good_picture.size() == picture.size()) {
                 p.rerunWitness(good_picture, raw, n_ranges, last);
                 for (size_t k = 0; k < n_ranges; ++k) ranges[k] = std::make_pair(raw[2 * k], raw[2 * k + 1]);
-                has_witness = nn->rangesReproduceScales(ranges);
+                has_witness = nn->rangesFitScales(ranges);
             }
             return 2;
         }
@@ -148,6 +148,30 @@ void *zkcnn_session_create(const zkcnn_model_desc *desc, int32_t device) {
         return s.release();
     } catch (const std::exception &e) {
         fprintf(stderr, "zkcnn_session_create: %s\n", e.what());
+        return nullptr;
+    }
+}
+
+void *zkcnn_session_create_calibrated(const zkcnn_model_desc *desc, const int32_t *scales, uint64_t n_scales, int32_t device) {
+    if (!desc || !scales || !n_scales) return nullptr;
+    try {
+        std::unique_ptr<gpuSession> s(new gpuSession(device));
+        const vector<int> given(scales, scales + n_scales);
+        {
+            s->p.ensureContext();
+            hipWitnessAccel accel(s->p.context());
+            s->accel = &accel;
+            bool ok = s->build(desc, &given);
+            s->accel = nullptr;
+            if (!ok) return nullptr;
+        }
+        s->p.init();
+        if (s->nn && !s->p.val.empty() && s->p.val[0].size() >= s->nn->program().picture_values)
+            s->good_picture.assign(s->p.val[0].begin(), s->p.val[0].begin() + (size_t) s->nn->program().picture_values);
+        s->p.releaseHostValues();
+        return s.release();
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkcnn_session_create_calibrated: %s\n", e.what());
         return nullptr;
     }
 }

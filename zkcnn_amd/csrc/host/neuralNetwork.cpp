@@ -139,6 +139,8 @@ void neuralNetwork::build(layeredCircuit &C, vector<vector<F>> &val, bool only_c
     assert((src || structure_only) && "no data source: pass an input file or call useSyntheticData()");
     if (!structure_only) scale_log.clear();
     scale_pos = 0;
+    fixed_pos = 0;
+    scale_overflow = false;
     assert(pool.size() + 1 >= conv_section.size());
     planLayout();
     assert(SIZE > 0 && SIZE < 256);
@@ -466,7 +468,7 @@ bool neuralNetwork::quantisePicture(const vector<double> &pixels, vector<F> &out
     if ((i64) pixels.size() != n || scale_log.empty()) return false;
     double mx = -10000, mn = 10000;
     for (double x : pixels) { mx = std::max(mx, x); mn = std::min(mn, x); }
-    if (!(mx > mn) || quantBits(mx, mn) != scale_log[0]) return false;
+    if (!(mx > mn) || quantBits(mx, mn) < scale_log[0]) return false;
     out.resize((size_t) (n * pic_parallel));
     size_t pos = 0;
     for (i64 p = 0; p < pic_parallel; ++p)
@@ -474,7 +476,7 @@ bool neuralNetwork::quantisePicture(const vector<double> &pixels, vector<F> &out
     return true;
 }
 
-bool neuralNetwork::rangesReproduceScales(const vector<std::pair<u64, u64>> &ranges) const {
+bool neuralNetwork::rangesFitScales(const vector<std::pair<u64, u64>> &ranges) const {
     size_t k = 0;
     for (const witnessStep &st : prog.steps) {
         if (st.what != witnessStep::RANGE) continue;
@@ -482,7 +484,7 @@ bool neuralNetwork::rangesReproduceScales(const vector<std::pair<u64, u64>> &ran
         if ((ranges[k].first >> 62) || (ranges[k].second >> 62)) return false;
         const i64 range = (i64) (ranges[k].first + ranges[k].second);
         ++k;
-        if (range <= 0 || scaleFromRange(range, st.bits) != scale_log[st.scale_index]) return false;
+        if (range <= 0 || scaleFromRange(range, st.bits) < scale_log[st.scale_index]) return false;
     }
     return k == ranges.size();
 }

@@ -114,11 +114,12 @@ public:
     const witnessProgram &program() const { return prog; }
     const vector<convHint> &convHints() const { return conv_hints; }
     // quantises `pixels` (channel, x, y order; one picture, replicated pic_parallel times like the reference does) with the scale the
-    // circuit was built for; false if this picture's range asks for another scale (the circuit would differ: rebuild)
+    // circuit was built for; false if this picture's range needs a smaller scale than the circuit's (its values would not fit)
     bool quantisePicture(const vector<double> &pixels, vector<F> &out) const;
     // ranges[k] = (largest non-negative value, largest magnitude of a negative value) of the layer RANGE step k scanned, as the
-    // resident backend found them: true iff every recorded scale comes out the same
-    bool rangesReproduceScales(const vector<std::pair<u64, u64>> &ranges) const;
+    // resident backend found them: true iff every range FITS the circuit's scale (the scale this picture would get by itself is not smaller;
+    // equal for the picture the circuit was built from, larger for one with a smaller range: it only loses precision)
+    bool rangesFitScales(const vector<std::pair<u64, u64>> &ranges) const;
     void setInferenceFrom(const vector<F> &last_layer);
     void setWitnessAccel(witnessAccel *a) { accel = a; }
 
@@ -128,6 +129,11 @@ public:
     const vector<int> &scales() const { return scale_log; }
     bool scalesConsumed() const { return scale_pos == scale_log.size(); }
     void setStructureOnly(const vector<int> &recorded) { structure_only = true; scale_log = recorded; scale_pos = 0; }
+    // Calibrated build: circuit AND witness for this picture under the given scales (those of scales() of an earlier build of the same model).
+    // Same circuit for every picture; scaleOverflow() after create() says that this picture's values do not fit them (the witness is then invalid).
+    void setFixedScales(const vector<int> &given) { use_fixed = true; fixed_scales = given; }
+    bool scaleOverflow() const { return scale_overflow; }
+    bool fixedScalesConsumed() const { return !use_fixed || fixed_pos == fixed_scales.size(); }
 
     // Fills pr.C (circuit) and pr.val (value of every gate). Works for any prover type exposing those two.
     template <class P>
@@ -167,7 +173,20 @@ private:
     bool structure_only = false;
     vector<int> scale_log;
     size_t scale_pos = 0;
+    // calibrated build: the scales are GIVEN (a model's scales fixed once, from a calibration picture) instead of taken from this picture's
+    // ranges; the build notes whether a range needed a smaller scale than the given one (the picture does not fit: scaleOverflow())
+    vector<int> fixed_scales;
+    size_t fixed_pos = 0;
+    bool use_fixed = false, scale_overflow = false;
     int logged(int computed) {       // record in a normal build, replay in a structure-only build
+        if (!structure_only && use_fixed) {
+            if (fixed_pos >= fixed_scales.size()) throw std::runtime_error("calibrated build: too few quantisation scales");
+            const int v = fixed_scales[fixed_pos++];
+            if (v < 0 || v > 62) throw std::runtime_error("calibrated build: quantisation scale out of range");
+            if (computed < v) scale_overflow = true;
+            scale_log.push_back(v);
+            return v;
+        }
         if (!structure_only) { scale_log.push_back(computed); return computed; }
         if (scale_pos >= scale_log.size()) throw std::runtime_error("statement: too few quantisation scales");
         const int v = scale_log[scale_pos++];

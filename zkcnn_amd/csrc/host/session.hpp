@@ -58,7 +58,9 @@ struct sessionT {
         return true;
     }
 
-    bool build(const zkcnn_model_desc *d) {
+    // calibrated: not NULL = the quantisation scales are given (those of an earlier session of the model); the build fails if this picture's
+    // values do not fit them
+    bool build(const zkcnn_model_desc *d, const vector<int> *calibrated = nullptr) {
         model_name = d->model ? d->model : "";
         pic_cnt = d->pic_cnt; pic_x = d->pic_x; pic_y = d->pic_y; pic_channel = d->pic_channel;
         if (!sane(d)) return false;
@@ -67,9 +69,11 @@ struct sessionT {
         data_seed = d->data_seed;
         nn->useSyntheticData(d->data_seed, d->picture_seed);
         nn->setWitnessAccel(accel);
+        if (calibrated) nn->setFixedScales(*calibrated);
         double t0 = now();
         nn->create(p, false);
         witness_s = now() - t0;
+        if (nn->scaleOverflow() || !nn->fixedScalesConsumed()) return false;
         setConvHints(p, nn->convHints());        // a prover that knows the pattern of a direct convolution factors its gate sums (checked at upload)
         return true;
     }
