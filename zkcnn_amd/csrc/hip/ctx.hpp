@@ -44,6 +44,7 @@ struct dev_layer {
     uint64_t n_ev_uni = 0, n_ev_bin = 0;
     gate_rec *ev_dot = nullptr;
     uint32_t *ev_dot_ptr = nullptr;
+    bool ev_conv = false;          // the bin gates of this (structured) convolution are evaluated by k_conv_eval, not from a list
     // direct convolution whose gate list matches the structured pattern (zk_upload_circuit_hinted): its two big gate sums are factored
     bool conv_ok = false;
     conv_desc conv;
@@ -175,6 +176,7 @@ struct zk_ctx {
     unsigned long long *wp_ranges = nullptr;    // device: 2 per range step, then one word of flags
     unsigned long long *h_wp_ranges = nullptr;  // pinned copy
     uint32_t wp_n_ranges = 0;
+    fr_t *wp_conv_part = nullptr;               // channel chunks of k_conv_eval
     void *wp_segments = nullptr;                // one wit_segment per layer (k_last_nonzero)
 
     // profiler: when a class bit is set in prof_mask every launch of that class is bracketed by events

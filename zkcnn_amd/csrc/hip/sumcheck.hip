@@ -2159,6 +2159,13 @@ extern "C" int32_t zk_witness_gates(zk_ctx *ctx, uint64_t *out, uint64_t n_out, 
     return ZK_OK;
 }
 
+// channel_in chunks of k_conv_eval: about 2^20 threads per launch, so that layers with few outputs (2 x 2 pictures, 512 channels) still fill the GPU
+static uint32_t conv_eval_chunks(const conv_desc &c, uint64_t n_out) {
+    const uint64_t want = std::max<uint64_t>(1, ((1ull << 20) + n_out - 1) / n_out);
+    const uint32_t per = (uint32_t) std::max<uint64_t>(1, (c.CI + want - 1) / want);
+    return (c.CI + per - 1) / per;
+}
+
 // ------------------------------------------------------------------------------------------------
 // resident witness program: the next picture without the host round trip of the layer values
 // ------------------------------------------------------------------------------------------------
@@ -2209,7 +2216,7 @@ extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *o
     for (int i = 1; i < n_layers; ++i)
         if (!evaluated[i]) { ctx->err = "witness program does not evaluate every layer"; return ZK_ERR_ARG; }
     // ---- gate lists grouped by output, operands in layer 0 as raw layer-0 indices ----
-    uint64_t max_out = 1, max_blocks = 1;
+    uint64_t max_out = 1, max_blocks = 1, max_conv_part = 0;
     for (int i = 1; i < n_layers; ++i) {
         const zk_layer_desc &S = layers[i];
         dev_layer &D = ctx->L[i];
@@ -2241,7 +2248,12 @@ extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *o
             continue;
         }
         std::vector<zk_uni_gate> uni(S.uni_gates, S.uni_gates + S.n_uni);
-        std::vector<zk_bin_gate> bin(S.bin_gates, S.bin_gates + S.n_bin);
+        // a convolution whose pattern was checked at upload is evaluated from its two tensors (k_conv_eval): its bin gates are not kept
+        static const bool conv_eval_on = !(getenv("ZKCNN_CONV_EVAL") && atoi(getenv("ZKCNN_CONV_EVAL")) == 0);
+        const bool conv_eval = D.conv_ok && conv_eval_on;
+        std::vector<zk_bin_gate> bin;
+        if (!conv_eval) bin.assign(S.bin_gates, S.bin_gates + S.n_bin);
+        else max_conv_part = std::max<uint64_t>(max_conv_part, (uint64_t) conv_eval_chunks(D.conv, n_out) * n_out);
         bool ok = true;
         for (zk_uni_gate &gt : uni) {
             if (gt.lu == 0) { if (gt.u >= S.size_u[0]) { ok = false; break; } gt.u = S.ori_id_u[gt.u]; }
@@ -2265,6 +2277,7 @@ extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *o
         if ((rc = upload(ctx, &du, uni)) || (rc = upload(ctx, &db, bin))) return rc;
         D.ev_uni = du; D.n_ev_uni = uni.size();
         D.ev_bin = db; D.n_ev_bin = bin.size();
+        D.ev_conv = conv_eval;
         max_out = std::max(max_out, n_out);
         max_blocks = std::max<uint64_t>(max_blocks, (std::max(uni.size(), bin.size()) + ZK_BLOCK - 1) / ZK_BLOCK);
     }
@@ -2275,6 +2288,7 @@ extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *o
     ctx->wp_ops = d_ops;
     ctx->wp_n_ops = n_ops;
     ctx->wp_n_windows = n_windows;
+    if (max_conv_part && (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_conv_part, max_conv_part * 32))) return rc;
     if ((rc = zk_dev_alloc(ctx, (void **) &ctx->wp_tmp, 2 * max_out * 32)) ||
         (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_carry_val, 2 * max_blocks * 32)) ||
         (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_carry_key, 2 * max_blocks * 4)) ||
@@ -2364,6 +2378,15 @@ extern "C" int32_t zk_witness_rerun(zk_ctx *ctx, const uint64_t *picture, uint64
                     ZK_LAUNCH(PC_GATE, 44.0 * (double) D.n_ev_uni, k_eval_uni, dim3((uint32_t) blocks), dim3(ZK_BLOCK), dA, ctx->wp_carry_key, ctx->wp_carry_val,
                               (const uni_gate_dev *) D.ev_uni, D.n_ev_uni, (const fr_t *) L0.val, (const fr_t *) P.val, (const fr_t *) ctx->two_mul);
                     ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup, dim3(grid_for(2 * blocks)), dim3(ZK_BLOCK), dA, ctx->wp_carry_key, ctx->wp_carry_val, 2 * blocks);
+                }
+                if (D.ev_conv) {
+                    const conv_desc &c = D.conv;
+                    const uint32_t chunks = conv_eval_chunks(c, n_out), per = (c.CI + chunks - 1) / chunks;
+                    fr_t *part = chunks == 1 ? dB : ctx->wp_conv_part;
+                    ZK_LAUNCH(PC_GATE, 80.0 * (double) n_out * c.CI * c.m * c.m, k_conv_eval, dim3((uint32_t) ((n_out + ZK_BLOCK - 1) / ZK_BLOCK), chunks), dim3(ZK_BLOCK), part,
+                              (const fr_t *) P.val, (const fr_t *) L0.val + c.wstart, c, per);
+                    if (chunks > 1)
+                        ZK_LAUNCH(PC_GATE, 0.0, k_sum_rows, dim3((uint32_t) ((n_out + 63) / 64)), dim3(1024), dB, (const fr_t *) part, (uint32_t) n_out, chunks);
                 }
                 if (D.n_ev_bin) {
                     const uint64_t blocks = (D.n_ev_bin + ZK_BLOCK - 1) / ZK_BLOCK;
