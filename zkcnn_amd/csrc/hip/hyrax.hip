@@ -41,6 +41,9 @@ struct msm_state {
     bool host_rows_valid = false;      // few-row MSMs end with a short sum on the host (like the single inversion of fetch_points)
     zkff::G1 host_rows[8];
     // scalar pre-pass outputs: 16-bit codes of a whole matrix, canonical signed magnitudes of the rows that need every window
+    // rows of bits: masks of 8 columns each (k_bit_masks) and the subset-sum table they index (k_subset_table; built with the full byte table)
+    uint16_t *masks = nullptr; size_t masks_cap = 0;
+    g1a_t *t8 = nullptr; uint64_t t8_m = 0; bool t8_ready = false;
     uint16_t *codes = nullptr; size_t codes_cap = 0;          // 16-bit codes of a matrix, followed by those of the virtual rows (higher windows of wide rows)
     fr_t *mag = nullptr; size_t mag_cap = 0;
     uint32_t *exc = nullptr;           // device word set by a fast-variant kernel that met P = +-Q
@@ -60,7 +63,7 @@ static void msm_destroy_one(zk_ctx *ctx) {
     if (!ctx->msm) return;
     msm_state *s = ctx->msm;
     void *bufs[] = {s->tables, s->partials, s->rowsJ, s->rowsA, s->a, s->b, s->coef, s->Lrow, s->sL, s->idxL, s->d_y, s->tbl_scratch,
-                    s->digit, s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch, s->full, s->parts2, s->codes, s->mag, s->exc};
+                    s->digit, s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch, s->full, s->parts2, s->codes, s->mag, s->exc, s->masks, s->t8};
     for (void *p : bufs) if (p) hipFree(p);
     delete s;
     ctx->msm = nullptr;
@@ -96,6 +99,7 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
     }
     s->gens_hits = 0;
     s->full_ready = false;
+    s->t8_ready = false;
     if (s->m != m) {
         if (s->tables) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->tables)); s->tables = nullptr; }
         ZK_HIP(hipMalloc((void **) &s->tables, (size_t) MSM_WINDOWS * m * sizeof(g1a_t)));
@@ -161,6 +165,21 @@ static int32_t ensure_full_table(zk_ctx *ctx) {
         if (rc) return rc;
     }
     s->full_ready = true;
+    // subset sums of 8 generators (rows of bits in commit_rows): 256 x m / 8 points
+    static const bool bits_on = !(getenv("ZKCNN_MSM_BITS") && atoi(getenv("ZKCNN_MSM_BITS")) == 0);
+    s->t8_ready = false;
+    if (bits_on && m % 512 == 0 && m <= 64 * MSM_BLOCK) {
+        const uint32_t n8 = m / 8;
+        if (s->t8_m != s->m) {
+            if (s->t8) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->t8)); s->t8 = nullptr; }
+            if (hipMalloc((void **) &s->t8, (size_t) 256 * n8 * sizeof(g1a_t)) != hipSuccess) { (void) hipGetLastError(); s->t8 = nullptr; s->t8_m = 0; return ZK_OK; }
+            s->t8_m = s->m;
+        }
+        ZK_HIP(hipMemsetAsync(s->t8, 0, (size_t) n8 * sizeof(g1a_t), ctx->stream));            // mask 0: the point at infinity, never looked up
+        ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_subset_table, dim3((n8 + 63) / 64, 255), dim3(64), s->t8, (const g1a_t *) (s->full + (size_t) 1 * m), n8);
+        ZK_HIP(hipGetLastError());
+        s->t8_ready = true;
+    }
     return ZK_OK;
 }
 
@@ -333,15 +352,24 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
         ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_compact_flags, dim3(1), dim3(1024), s->row_list, n_wide, s->hi_flags, rows, wide_cap);
         ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_scalar_codes_wide, dim3(cgrid.x, wide_cap), dim3(256), s->codes + (size_t) rows * cols, scalars, ld, s->row_list, n_wide, cols);
     }
+    // rows of bits go through the subset-sum table: 8 columns per lookup (only when one block owns a whole row and the table is there)
+    const bool bits = s->full_ready && s->t8_ready && s->t8_m == s->m && chunks == 1 && cols == s->m && rows_all <= 65535;
+    if (bits) {
+        if ((rc = regrow(ctx, (void **) &s->masks, &s->masks_cap, (size_t) rows * (cols / 8) * 2))) return rc;
+        ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_bit_masks, dim3(2, rows), dim3(256), s->masks, (const uint16_t *) s->codes, (const uint32_t *) s->hi_flags, cols);
+    }
+    const uint32_t *bflags = bits ? s->hi_flags : nullptr;
+    const uint16_t *bmasks = bits ? s->masks : nullptr;
+    const g1a_t *bT8 = bits ? s->t8 : nullptr;
     for (uint32_t r0 = 0; r0 < rows_all; r0 += 65535) {           // one launch whenever rows + virtual rows <= 65535 (always, for the circuits here)
         const uint32_t nr = std::min<uint32_t>(65535, rows_all - r0), n_real = std::min<uint32_t>(nr, r0 < rows ? rows - r0 : 0);
         const double bytes = 32.0 * (double) std::min(nr, n_real) * (double) cols;
         if (s->safe)
             ZK_LAUNCH(PC_MSM_PLANES, bytes, k_msm_codes<true>, dim3(chunks, nr), dim3(MSM_BLOCK), s->partials + (size_t) r0 * n, s->exc,
-                      s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, n_real, n_wide);
+                      s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, n_real, n_wide, bflags, bmasks, bT8);
         else
             ZK_LAUNCH(PC_MSM_PLANES, bytes, k_msm_codes<false>, dim3(chunks, nr), dim3(MSM_BLOCK), s->partials + (size_t) r0 * n, s->exc,
-                      s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, n_real, n_wide);
+                      s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, n_real, n_wide, bflags, bmasks, bT8);
     }
     ZK_HIP(hipGetLastError());
     if ((rc = reduce_rows(ctx, s->partials, n, rows_all, s->rowsJ))) return rc;         // rowsJ[rows + v] = sum of virtual row v
@@ -356,7 +384,7 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     if (flags[rows + 1] && !s->safe) return ZK_RETRY_SAFE;
     if (wide_cap && flags[rows] <= wide_cap) return ZK_OK;       // every wide row went through the virtual rows
-    for (uint32_t r = 0; r < rows; ++r) if (flags[r]) list.push_back(r);
+    for (uint32_t r = 0; r < rows; ++r) if (flags[r] & MSM_ROW_WIDE) list.push_back(r);
     if (list.empty()) return ZK_OK;
     // separate pass: all wide rows when there was no byte table, the ones beyond the list otherwise (list rows are ascending on both sides)
     if (wide_cap) list.erase(list.begin(), list.begin() + wide_cap);

@@ -24,6 +24,8 @@
 #define MSM_BLOCK 64                 // one wave per block: reduction trees of 6 levels, many blocks per CU
 #define MSM_CODE_NEG 0x100u
 #define MSM_CODE_WIDE 0x200u
+#define MSM_ROW_WIDE 1u              // row flags of k_scalar_codes
+#define MSM_ROW_NONBIT 2u
 
 // ---- exceptional-case aware in-place point operations on separate coordinate registers ----
 // doubling, a = 0 (dbl-2009-l); Z == 0 stays Z == 0
@@ -118,7 +120,7 @@ __device__ __forceinline__ void g1_accumulate(fp_t &X, fp_t &Y, fp_t &Z, bool &e
 // row_flags[row] = 1 if the row holds a wide scalar (the caller then adds that row's higher windows, see k_scalar_codes_wide)
 __global__ void __launch_bounds__(256) k_scalar_codes(uint16_t *codes, uint32_t *row_flags, const fr_t *scalars, uint64_t ld, uint32_t cols) {
     const uint32_t row = blockIdx.y;
-    bool wide = false;
+    bool wide = false, nonbit = false;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
         const fr_t raw = fr_load(scalars + (size_t) row * ld + c);
         uint32_t code = 0;
@@ -130,10 +132,49 @@ __global__ void __launch_bounds__(256) k_scalar_codes(uint16_t *codes, uint32_t 
             for (int k = 1; k < 8; ++k) rest |= s.v[k];
             code = (s.v[0] & 0xffu) | (neg ? MSM_CODE_NEG : 0u) | (rest ? MSM_CODE_WIDE : 0u);
             wide |= rest != 0;
+            nonbit |= code != 1u;
         }
         codes[(size_t) row * cols + c] = (uint16_t) code;
     }
-    if (wide) row_flags[row] = 1;
+    // bit 0: a wide scalar in the row; bit 1: an entry other than 0 / 1 (rows without it are rows of bits: k_bit_masks, k_msm_codes)
+    const uint32_t f = (wide ? MSM_ROW_WIDE : 0u) | (nonbit ? MSM_ROW_NONBIT : 0u);
+    if (f) atomicOr(row_flags + row, f);
+}
+
+// Rows of bits (the auxiliary witnesses of RELU / pooling layers: a quarter of vgg11's rows): eight columns become ONE table lookup.
+// masks[row * 512 + s * 64 + j] = sum_k bit(codes[row][s * 512 + k * 64 + j]) << k  -- the eight columns lane j of the commitment kernel owns inside
+// span s -- and T8[mask][s * 64 + j] = the sum of those generators (k_subset_table). The commitment kernel then runs such a row as a row
+// of 512 "columns" with byte codes over T8: 512 mixed additions instead of ~2048. cols must be a multiple of 512. grid (2, rows), 256 threads
+__global__ void __launch_bounds__(256) k_bit_masks(uint16_t *masks, const uint16_t *codes, const uint32_t *row_flags, uint32_t cols) {
+    const uint32_t row = blockIdx.y;
+    if (row_flags[row] & MSM_ROW_NONBIT) return;
+    const uint32_t spans = cols / 512;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < spans * 64; t += gridDim.x * blockDim.x) {
+        const uint32_t s = t >> 6, j = t & 63;
+        const uint16_t *rc = codes + (size_t) row * cols + (size_t) s * 512 + j;
+        uint32_t mask = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) mask |= (uint32_t) (rc[k * 64] & 1u) << k;
+        masks[(size_t) row * (spans * 64) + t] = (uint16_t) mask;
+    }
+}
+// T8[mask * n + t] = sum of the generators G[s * 512 + k * 64 + j] over the set bits k of mask, t = s * 64 + j, n = spans * 64; affine,
+// (0, 0) for mask 0. One thread per entry: <= 7 additions and its own inversion; built once per generator set. grid (ceil(n / 64), 255)
+__global__ void __launch_bounds__(64) k_subset_table(g1a_t *T8, const g1a_t *G, uint32_t n) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x, mask = blockIdx.y + 1;
+    if (t >= n) return;
+    const uint32_t s = t >> 6, j = t & 63;
+    fp_t X = fp_zero(), Y = fp_zero(), Z = fp_zero();
+    bool empty = true, exc = false;
+    for (uint32_t k = 0; k < 8; ++k) {
+        if (!((mask >> k) & 1u)) continue;
+        fp_t px, py;
+        g1a_load(px, py, G + (size_t) s * 512 + k * 64 + j);
+        g1_accumulate<true>(X, Y, Z, empty, px, py, false, exc);
+    }
+    g1j_t acc;
+    acc.X = X; acc.Y = Y; acc.Z = empty ? fp_zero() : Z;
+    T8[(size_t) mask * n + t] = g1_to_affine(acc);
 }
 
 // row_list[0 .. *count) = the rows whose flag is set, ascending (single block; rows <= a few 10^4); *count may exceed `cap`: the
@@ -144,7 +185,7 @@ __global__ void __launch_bounds__(1024) k_compact_flags(uint32_t *row_list, uint
     __syncthreads();
     for (uint32_t r0 = 0; r0 < rows; r0 += 1024) {
         const uint32_t r = r0 + threadIdx.x;
-        const bool on = r < rows && flags[r] != 0;
+        const bool on = r < rows && (flags[r] & MSM_ROW_WIDE) != 0;
         const unsigned long long b = __ballot(on);
         const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         if (lane == 0) s_wave[wave] = (uint32_t) __popcll(b);
@@ -211,7 +252,8 @@ __device__ __forceinline__ bool mag_neg(const fr_t *mag, size_t i) { return (rei
 // ------------------------------------------------------------------------------------------------
 template <bool SAFE>
 __global__ void __launch_bounds__(MSM_BLOCK) k_msm_codes(g1j_t *out, uint32_t *exc_flag, const uint16_t *codes, const g1a_t *D, uint32_t m, uint32_t cols,
-                                                         uint32_t cpt, uint32_t n_real, const uint32_t *n_wide) {
+                                                         uint32_t cpt, uint32_t n_real, const uint32_t *n_wide,
+                                                         const uint32_t *row_flags, const uint16_t *masks, const g1a_t *T8) {
     // the virtual rows come FIRST in the grid (their few long chains then run alongside the heavy rows instead of forming a tail);
     // `row` is the logical row: real rows 0 .. n_real - 1, virtual rows behind them
     const uint32_t n_virtual = gridDim.y - n_real;
@@ -219,6 +261,15 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_codes(g1j_t *out, uint32_t *e
     const uint32_t base = blockIdx.x * (MSM_BLOCK * cpt) + lane;
     const uint16_t *rc = codes + (size_t) row * cols;
     g1j_t *dst = out + ((size_t) row * gridDim.x + blockIdx.x) * MSM_BLOCK + lane;
+    // a row of bits (k_bit_masks; only offered when one block owns a whole row): 8 "columns" per lane, one per 512-column span, whose byte
+    // code is the mask of the lane's eight bits in that span, through the subset-sum table T8 laid out like a digit table of cols / 8 columns
+    if (T8 && row < n_real && !(row_flags[row] & MSM_ROW_NONBIT)) {
+        m = cols >> 3;
+        rc = masks + (size_t) row * m;
+        D = T8;
+        cpt = m / MSM_BLOCK;
+        cols = m;
+    }
     if (row >= n_real) {
         const uint32_t v = row - n_real;
         if (v >= *n_wide * (MSM_WINDOWS - 1)) {          // beyond the list: an empty partial sum, nothing to read
