@@ -339,7 +339,10 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
     }
     ZK_HIP(hipMemsetAsync(s->hi_flags, 0, ((size_t) rows + 1) * 4, ctx->stream));
     if ((rc = regrow(ctx, (void **) &s->codes, &s->codes_cap, (size_t) rows_all * cols * 2))) return rc;
-    const uint32_t cpt = std::max<uint32_t>(1, std::min<uint32_t>(64, (cols + MSM_BLOCK - 1) / MSM_BLOCK));
+    // columns per lane: 64 would give one wave per row, but the ~2 250 full rows of a vgg11 commitment do not divide evenly over 1 024 SIMDs
+    // (some get three such waves, some two: the kernel lasts as long as three); with half rows the spread is 5 against 4.4 on average
+    static const uint32_t cpt_max = getenv("ZKCNN_MSM_CPT") ? std::max(1, atoi(getenv("ZKCNN_MSM_CPT"))) : 32;
+    const uint32_t cpt = std::max<uint32_t>(1, std::min<uint32_t>(cpt_max, (cols + MSM_BLOCK - 1) / MSM_BLOCK));
     const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt), n = chunks * MSM_BLOCK;
     if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows_all * n * sizeof(g1j_t)))) return rc;
     if ((rc = regrow(ctx, (void **) &s->tmpJ, &s->tmp_cap, (size_t) std::max<uint32_t>(wide_cap, 1) * sizeof(g1j_t)))) return rc;
@@ -353,7 +356,7 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
         ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_scalar_codes_wide, dim3(cgrid.x, wide_cap), dim3(256), s->codes + (size_t) rows * cols, scalars, ld, s->row_list, n_wide, cols);
     }
     // rows of bits go through the subset-sum table: 8 columns per lookup (only when one block owns a whole row and the table is there)
-    const bool bits = s->full_ready && s->t8_ready && s->t8_m == s->m && chunks == 1 && cols == s->m && rows_all <= 65535;
+    const bool bits = s->full_ready && s->t8_ready && s->t8_m == s->m && cols == s->m && rows_all <= 65535 && (cols / 8 / MSM_BLOCK) % chunks == 0 && cols % (MSM_BLOCK * cpt) == 0;
     if (bits) {
         if ((rc = regrow(ctx, (void **) &s->masks, &s->masks_cap, (size_t) rows * (cols / 8) * 2))) return rc;
         ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_bit_masks, dim3(2, rows), dim3(256), s->masks, (const uint16_t *) s->codes, (const uint32_t *) s->hi_flags, cols);

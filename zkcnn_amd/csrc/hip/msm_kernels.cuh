@@ -261,14 +261,16 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_codes(g1j_t *out, uint32_t *e
     const uint32_t base = blockIdx.x * (MSM_BLOCK * cpt) + lane;
     const uint16_t *rc = codes + (size_t) row * cols;
     g1j_t *dst = out + ((size_t) row * gridDim.x + blockIdx.x) * MSM_BLOCK + lane;
-    // a row of bits (k_bit_masks; only offered when one block owns a whole row): 8 "columns" per lane, one per 512-column span, whose byte
+    // a row of bits (k_bit_masks; offered when the row's blocks split it into whole spans): 8 "columns" per lane, one per 512-column span, whose byte
     // code is the mask of the lane's eight bits in that span, through the subset-sum table T8 laid out like a digit table of cols / 8 columns
+    uint32_t base_c = base;
     if (T8 && row < n_real && !(row_flags[row] & MSM_ROW_NONBIT)) {
         m = cols >> 3;
         rc = masks + (size_t) row * m;
         D = T8;
-        cpt = m / MSM_BLOCK;
+        cpt = m / MSM_BLOCK / gridDim.x;                 // the spans are split over the row's blocks like the columns are
         cols = m;
+        base_c = blockIdx.x * (MSM_BLOCK * cpt) + lane;
     }
     if (row >= n_real) {
         const uint32_t v = row - n_real;
@@ -282,7 +284,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_codes(g1j_t *out, uint32_t *e
     // so a lane of a half-empty bit row is done after its ~cpt/2 additions instead of idling through cpt iterations
     unsigned long long mask = 0;
     for (uint32_t i = 0; i < cpt; ++i) {
-        const uint32_t c = base + i * MSM_BLOCK;
+        const uint32_t c = base_c + i * MSM_BLOCK;
         if (c < cols && (rc[c] & 0xffu)) mask |= 1ull << i;
     }
     fp_t X = fp_zero(), Y = fp_zero(), Z = fp_zero();
@@ -293,7 +295,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_codes(g1j_t *out, uint32_t *e
     uint32_t c_next = 0, code_next = 0;
     bool have = mask != 0;
     if (have) {
-        c_next = base + (uint32_t) (__ffsll((long long) mask) - 1) * MSM_BLOCK;
+        c_next = base_c + (uint32_t) (__ffsll((long long) mask) - 1) * MSM_BLOCK;
         mask &= mask - 1;
         code_next = rc[c_next];
     }
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_codes(g1j_t *out, uint32_t *e
         const uint32_t c = c_next, code = code_next;
         have = mask != 0;
         if (have) {
-            c_next = base + (uint32_t) (__ffsll((long long) mask) - 1) * MSM_BLOCK;
+            c_next = base_c + (uint32_t) (__ffsll((long long) mask) - 1) * MSM_BLOCK;
             mask &= mask - 1;
             code_next = rc[c_next];
         }
