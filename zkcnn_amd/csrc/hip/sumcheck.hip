@@ -1518,7 +1518,9 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         A.nl[b] = live;
         A.fill[b] = (t.len / 2 <= (1ull << std::max(fine_log, 16))) ? 1 : 0;
         const uint64_t work = fine ? npairs : std::max<uint64_t>(first ? (live + 1) / 2 : (live + 3) / 4, first ? 1 : (A.fill[b] ? npairs / 8 : 1));
-        A.blocks[b] = collapsed[b] ? 1 : std::min<uint32_t>(grid_for(work, 1024), ctx->partial_blocks / 2);
+        // (k_round_quad2 holds 3 waves per SIMD: 768 blocks of 4 waves are exactly one resident set of the 1 024 SIMDs -- no partial second wave of blocks)
+        static const uint32_t quad_cap = getenv("ZKCNN_QUAD_BLOCKS") ? (uint32_t) std::max(1, atoi(getenv("ZKCNN_QUAD_BLOCKS"))) : 768;
+        A.blocks[b] = collapsed[b] ? 1 : std::min<uint32_t>(grid_for(work, fine ? 1024 : quad_cap), ctx->partial_blocks / 2);
         fine_items += collapsed[b] ? 1 : npairs;
         alg_bytes += (first ? 64.0 : 96.0) * (double) (fine ? t.len : live);      // entries the launch has to read: the live prefix
     }
