@@ -137,8 +137,9 @@ __global__ void __launch_bounds__(256) k_scalar_codes(uint16_t *codes, uint32_t 
         codes[(size_t) row * cols + c] = (uint16_t) code;
     }
     // bit 0: a wide scalar in the row; bit 1: an entry other than 0 / 1 (rows without it are rows of bits: k_bit_masks, k_msm_codes)
-    const uint32_t f = (wide ? MSM_ROW_WIDE : 0u) | (nonbit ? MSM_ROW_NONBIT : 0u);
-    if (f) atomicOr(row_flags + row, f);
+    // (one atomic per wave, not per thread: every entry of a weight row sets the second bit)
+    const uint32_t f = (__any(wide) ? MSM_ROW_WIDE : 0u) | (__any(nonbit) ? MSM_ROW_NONBIT : 0u);
+    if (f && (threadIdx.x & 63) == 0) atomicOr(row_flags + row, f);
 }
 
 // Rows of bits (the auxiliary witnesses of RELU / pooling layers: a quarter of vgg11's rows): eight columns become ONE table lookup.
