@@ -303,7 +303,7 @@ def main():
     # Same K streams, same modes; each step = new_image + prove per stream. Pictures whose activation ranges ask for other quantisation
     # scales need a new circuit (a new session) and are skipped by the scan; the scan's first call uploads the program (not timed). ----
     new_image = {}
-    if rank == 0 and not args.no_companions:
+    if rank == 0 and world == 1 and not args.no_companions:          # companions belong to the single-GPU line (like the CPU baseline)
         try:
             valid = [[] for _ in range(K)]
             tried = [0] * K
@@ -394,7 +394,7 @@ def main():
     # ---- conservative companions of the headline (not timed steps): nothing pre-built, nothing cut ----
     extras = dict(new_image)
     try:
-        if args.no_companions:
+        if args.no_companions or world > 1:
             raise KeyboardInterrupt
         fresh = []
         for k in range(2):          # new random generators per proof (no REUSE_GENS): tables rebuilt inside the prover's clock; IPA down to length 1
