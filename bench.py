@@ -95,7 +95,7 @@ def pin_to_gpu_numa_node(torch, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="vgg11", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=8, help="proofs in flight per GPU (one session, host thread and HIP stream each)")
