@@ -56,3 +56,21 @@ def test_convolution_parameters_are_found_without_hints(built, monkeypatch, mode
         assert s.structured_layers() == n_struct
         res, got = s.prove(seed=0x5EED0035, mode=REUSE)
         assert res.accepted == 1 and got == want
+
+
+def test_full_vgg16_factored_and_live_prefix_paths(built):
+    """vgg16 / CIFAR shape, pic_cnt = 1 (13 direct convolutions, layer 0 = 2^25 entries): twelve convolutions factor; acceptance, rejection of a
+    corrupted message, a Fiat-Shamir proof that verifies off line, and the GPU predicates agreeing with the host loops"""
+    with zkcnn_amd.Session("vgg16", (32, 32, 3), 1) as s:
+        assert s.structured_layers() == 12
+        res, tr = s.prove(seed=0x5EED0037, mode=REUSE)
+        assert res.accepted == 1, res.message.decode()
+        assert res.input_bits == 25
+        bad, _ = s.prove(seed=0x5EED0037, mode=REUSE | zkcnn_amd.MODE_TAMPER | ((res.n_messages // 3) << 8))
+        assert bad.accepted == 0
+        r2, tr2 = s.prove(seed=0x5EED0037, mode=REUSE | zkcnn_amd.MODE_DRIVE_ONLY)
+        assert tr2 == tr
+        res, proof = s.prove(mode=zkcnn_amd.MODE_FIAT_SHAMIR)
+        assert res.accepted == 1 and s.verify(proof, mode=zkcnn_amd.MODE_FIAT_SHAMIR).accepted == 1
+        cross, _ = s.prove(seed=0x5EED0038, mode=zkcnn_amd.MODE_CROSS_PRED)
+        assert cross.accepted == 1, cross.message.decode()
