@@ -127,6 +127,26 @@ def test_proof_file_round_trip(oracle, tmp_path):
                 proof_io.loads(bytes(blob))
 
 
+@pytest.mark.parametrize("extra", [zkcnn_amd.MODE_ZK, zkcnn_amd.MODE_FULL_IPA, zkcnn_amd.MODE_ZK | zkcnn_amd.MODE_REUSE_GENS])
+def test_proof_file_keeps_the_protocol_shaping_mode_bits(oracle, extra):
+    """a zero-knowledge / full-argument proof holds other messages than a plain one: the file header must carry those bits, or the replay
+    parses it as a plain proof and rejects it (round-2 advisor finding); run-only bits (TAMPER, DRIVE_ONLY, SEEDED) never reach the file"""
+    mode = FS | extra
+    with oracle_ffi.OracleSession(*MODEL) as o:
+        res, tr = o.prove(seed=9, mode=mode | zkcnn_amd.MODE_SEEDED)
+        assert res.accepted == 1
+        blob = proof_io.dumps_from(o, tr, 9, mode | zkcnn_amd.MODE_SEEDED | zkcnn_amd.MODE_DRIVE_ONLY)
+        header, _ = proof_io.loads(blob)
+        assert header["mode"] == mode & (FS | zkcnn_amd.MODE_REUSE_GENS | zkcnn_amd.MODE_ZK | zkcnn_amd.MODE_FULL_IPA)
+        assert proof_io.verify_with(o, blob).accepted == 1
+    assert proof_io.verify_standalone(blob, oracle_ffi.OracleSession).accepted == 1
+    plain = dict(header, mode=FS)               # the same bytes under a plain header: the messages do not parse as a plain proof
+    import json, struct, hashlib
+    h = json.dumps(plain, sort_keys=True).encode()
+    body = proof_io.MAGIC + struct.pack("<I", len(h)) + h + struct.pack("<Q", len(tr)) + bytes(tr)
+    assert proof_io.verify_standalone(body + hashlib.sha256(body).digest(), oracle_ffi.OracleSession).accepted == 0
+
+
 @pytest.mark.parametrize("model", [MODEL, ("custom:C2:3:0:f C3:3:1:f M C2:3:1:s A F5 F3", (10, 10, 2), 2), ("custom:C2:3:1:n A F4", (4, 4, 2), 1)])
 def test_standalone_verifier_needs_only_the_proof_file(oracle, model):
     """the circuit is rebuilt from the model descriptor + the recorded quantisation scales (no picture, weights or witness) and the

@@ -79,8 +79,10 @@ struct sessionT {
     }
 
     // common set-up of a verifier run: challenge source (OS CSPRNG, seeded stream, or the transcript itself), generators, options
+    // for_prover: the run drives this session's own prover (prove()); only then may the prover be handed the Fiat-Shamir chain -- a replay
+    // (verifyProof) must never leave pointers into its own locals in the prover's context
     template <class V>
-    void configure(V &v, uint64_t challenge_seed, uint32_t mode, fiatShamir &fs, std::unique_ptr<challengeScope> &scope) {
+    void configure(V &v, uint64_t challenge_seed, uint32_t mode, fiatShamir &fs, std::unique_ptr<challengeScope> &scope, bool for_prover) {
         const bool fiat = (mode & ZKCNN_MODE_FIAT_SHAMIR) != 0;
         // generators both sides know in advance must not have a known discrete logarithm: hash-to-curve (ff/hash_to_curve.hpp).
         // Only the in-process interactive run keeps the reference's k_i * G, with k_i drawn by the verifier and never shown to the prover.
@@ -116,7 +118,7 @@ struct sessionT {
             scope.reset(new challengeScope(&fs));
             // the prover may run the small rounds of every phase ahead of the verifier: the challenges are a function of the transcript.
             // Not with masked round polynomials (the masks are added on the host) and not when a message is corrupted on purpose.
-            if (!zk && !(mode & (ZKCNN_MODE_TAMPER | ZKCNN_MODE_HOST_ROUNDS))) attachFsChain(p, fs.stateWords(), fs.pendingBytes());
+            if (for_prover && !zk && !(mode & (ZKCNN_MODE_TAMPER | ZKCNN_MODE_HOST_ROUNDS))) attachFsChain(p, fs.stateWords(), fs.pendingBytes());
         }
     }
 
@@ -135,9 +137,10 @@ struct sessionT {
         verifierT<ProverT> v(&p, p.C);
         fiatShamir fs;
         std::unique_ptr<challengeScope> scope;
-        configure(v, challenge_seed, mode, fs, scope);
+        attachFsChain(p, nullptr, nullptr);            // whatever an earlier run left behind
         bool ok = false;
         try {
+            configure(v, challenge_seed, mode, fs, scope, true);
             ok = v.verify();
         } catch (...) {
             attachFsChain(p, nullptr, nullptr);
@@ -199,7 +202,7 @@ struct sessionT {
             verifierT<replayProver> v(&rp, p.C);
             fiatShamir fs;
             std::unique_ptr<challengeScope> scope;
-            configure(v, challenge_seed, mode, fs, scope);
+            configure(v, challenge_seed, mode, fs, scope, false);
             ok = v.verify();
             scope.reset();
             if (!ok) why = v.failure();

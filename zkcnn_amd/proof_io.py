@@ -12,11 +12,13 @@ MAGIC = b"ZKCNNPF1"
 
 
 def dumps(transcript, model, pic, pic_cnt, data_seed, challenge_seed, mode, statement=None):
-    from . import MODE_FIAT_SHAMIR, MODE_REUSE_GENS
+    from . import MODE_FIAT_SHAMIR, MODE_REUSE_GENS, MODE_ZK, MODE_FULL_IPA
     header = {"model": model, "pic": list(pic), "pic_cnt": pic_cnt, "data_seed": data_seed, "statement": statement,
               "challenges": "fiat-shamir/sha256" if mode & MODE_FIAT_SHAMIR else "seeded-stream",
               "challenge_seed": None if mode & MODE_FIAT_SHAMIR else challenge_seed,
-              "session_generators": bool(mode & MODE_REUSE_GENS), "mode": mode & (MODE_FIAT_SHAMIR | MODE_REUSE_GENS)}
+              "session_generators": bool(mode & MODE_REUSE_GENS),
+              # the bits that shape the protocol (what messages the transcript holds); TAMPER / DRIVE_ONLY / SEEDED are properties of a run, not of a proof
+              "mode": mode & (MODE_FIAT_SHAMIR | MODE_REUSE_GENS | MODE_ZK | MODE_FULL_IPA)}
     h = json.dumps(header, sort_keys=True).encode()
     body = MAGIC + struct.pack("<I", len(h)) + h + struct.pack("<Q", len(transcript)) + bytes(transcript)
     return body + hashlib.sha256(body).digest()
@@ -60,8 +62,8 @@ def _replay_args(header, allow_seeded_replay):
     """(seed, mode) for Session.verify. A header is prover-controlled input: a file that says "seeded-stream" names the very seed its
     challenges came from, so whoever wrote it knew every challenge before sending a single message. Such a file is only ever
     replayed on request (parity / debugging), never accepted as a proof."""
-    from . import MODE_FIAT_SHAMIR, MODE_REUSE_GENS
-    mode = int(header["mode"]) & (MODE_FIAT_SHAMIR | MODE_REUSE_GENS)
+    from . import MODE_FIAT_SHAMIR, MODE_REUSE_GENS, MODE_ZK, MODE_FULL_IPA
+    mode = int(header["mode"]) & (MODE_FIAT_SHAMIR | MODE_REUSE_GENS | MODE_ZK | MODE_FULL_IPA)
     if mode & MODE_FIAT_SHAMIR:
         return None, mode
     if not allow_seeded_replay:
