@@ -57,17 +57,61 @@ PMC_TRAFFIC_PER_LAUNCH = {("vgg11", "round_quad"): (5.10 + 1.83 + 53.74 + 20.32)
 # kernel classes whose algorithmic byte count is defined; the dominant one is reported
 STREAMING_PMC_BYTES = 1.7037e9      # profiles/r01_round_quad_kernel.md (FETCH_SIZE x2 + WRITE_SIZE) for 2 x 2^24 entries
 ROOFLINE_CLASSES = ["gate_reduce", "round_quad", "round_cubic", "msm_planes"]
+DATA_SEED = 20260928         # synthetic picture + weights
+PARITY_SEED = 0x5EED0001     # challenge stream of the proof whose transcript is compared with the CPU oracle's, byte for byte
+
+
+def launch_command(argv, n_gpus, port=None, python=None):
+    """the command `bench.py --gpus N` re-executes itself as when nobody launched the ranks: one process per GPU under torch.distributed.run"""
+    import socket
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+HOST_BYTES_PER_SESSION = 6e9      # a vgg11 session holds 2.7 GB on the host, 4.3 GB at its peak while it is built (host_peak_rss_gb_while_building)
+
+
+def streams_that_fit(available_bytes, world, asked):
+    """sessions per rank the host's memory allows: every rank of the node builds its sessions side by side on the same host"""
+    return max(1, min(int(asked), int(available_bytes / (HOST_BYTES_PER_SESSION * max(world, 1)))))
+
+
+def visible_gpus():
+    """number of GPUs this process could use, without creating a HIP context in it (the ranks are separate processes)"""
+    try:
+        import torch
+        return int(torch.cuda.device_count()) if torch.cuda.is_available() else 0
+    except Exception:       # noqa: BLE001
+        return 0
+
+
+def self_launch_if_needed(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment: become the launcher (exec, same stdout: rank 0 prints the line)"""
+    if args.gpus <= 1 or "RANK" in os.environ:
+        return
+    have = visible_gpus()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this box has {have} GPU(s); one rank per GPU is needed (no CPU fallback, no oversubscription)")
+    cmd = launch_command(argv, args.gpus)
+    print("[bench] launching the ranks: " + " ".join(cmd), file=sys.stderr, flush=True)
+    os.execv(cmd[0], cmd)
 
 
 def _cpu_prover_worker(args):
-    """one single-threaded CPU prover (the oracle) on the workload: returns (prover seconds, wall seconds incl. circuit + witness)"""
+    """one single-threaded CPU prover (the oracle) on the workload: returns (prover seconds, wall seconds incl. circuit + witness, ...,
+    sha256 of the canonical transcript -- the GPU proof of the same picture, challenge seed and modes must hash to the same value)"""
     model, pic, pp, seed, mode = args
     sys.path.insert(0, ROOT)
+    import hashlib
     from tests import oracle_ffi
     t0 = time.time()
     with oracle_ffi.OracleSession(model, pic, pp, data_seed=seed) as o:
-        res, _ = o.prove(seed=0x5EED0001, mode=mode, want_transcript=False)
-    return res.prove_s + res.poly_prove_s, time.time() - t0, int(res.gate_cnt_bin), res.prove_s, res.poly_prove_s
+        res, tr = o.prove(seed=PARITY_SEED, mode=mode, want_transcript=True)
+    return res.prove_s + res.poly_prove_s, time.time() - t0, int(res.gate_cnt_bin), res.prove_s, res.poly_prove_s, hashlib.sha256(tr).hexdigest(), len(tr)
 
 
 def pin_to_gpu_numa_node(torch, local_rank):
@@ -107,6 +151,9 @@ def main():
     ap.add_argument("--no-companions", action="store_true", help="skip the extra single-stream measurements of other modes (profiling runs)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel-class table of one extra proof to stderr")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    self_launch_if_needed(args, sys.argv[1:])
 
     import torch
     import zkcnn_amd
@@ -130,13 +177,14 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="nccl")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch one rank per GPU (or run it without RANK set: it launches them itself)")
 
     model, pic, pp = WORKLOADS[args.workload]
     K = max(1, args.streams)
-    try:                                # a vgg11 session holds 2.7 GB on the host (4.3 GB at its peak while it is built: host_peak_rss_gb_while_building): do not overcommit a small node
+    try:                                # do not overcommit a small node
         import psutil
-        K_ram = max(1, int(psutil.virtual_memory().available / (6e9 * max(world, 1))))
+        K_ram = streams_that_fit(psutil.virtual_memory().available, world, K)
         if K_ram < K:
             print(f"[bench] host memory allows {K_ram} sessions per rank, not the {K} asked for", file=sys.stderr)
             K = K_ram
@@ -168,7 +216,7 @@ def main():
     sessions = [None] * K
 
     def build(i):
-        sessions[i] = zkcnn_amd.Session(model, pic, pp, data_seed=20260928 + rank * K + i, device=local_rank)
+        sessions[i] = zkcnn_amd.Session(model, pic, pp, data_seed=DATA_SEED + rank * K + i, device=local_rank)
     # Large single-circuit workloads do not fit 8 times: a probe session measures what one costs in HBM (tables + circuit now; the MSM
     # byte table and scratch come with the first proofs, hence the margin) and is closed again. All K sessions are then built side by
     # side -- with the sessions created one after the other the same 8 streams reach 51 instead of 59 proofs/s, reproducibly
@@ -211,6 +259,14 @@ def main():
                 sessions[i].prove(seed=0x5EED0001 + w, mode=drive, want_transcript=False)
     in_threads(warm)
     first, accepted = firsts[0], True
+    # full-size byte parity inside the driver's evidence: session 0 of rank 0 proves its picture under the challenge seed and the modes the CPU
+    # oracle leg below uses (same data seed): the two canonical transcripts must be the same bytes (compared through their SHA-256)
+    import hashlib
+    parity_sha = parity_len = None
+    if rank == 0:
+        _, ptr = sess.prove(seed=PARITY_SEED, mode=drive, want_transcript=True)
+        parity_sha, parity_len = hashlib.sha256(ptr).hexdigest(), len(ptr)
+        del ptr
 
     # one profiled proof to find the dominant kernel class (events on every launch; not timed)
     sess.profile("all")
@@ -271,9 +327,13 @@ def main():
             # the step's only exchange: this GPU's K proofs to rank 0 over RCCL, overlapped with the next proofs (zkcnn_amd/dp.py)
             gatherer.submit(rank, dp.pack([(rank * K + i, tr) for i, (_, tr) in enumerate(batch)]))
     [t.join() for t in workers]
+    rank_busy_s = time.perf_counter() - t_start          # this rank's own proving time (no collective, no other rank in it)
     last_proofs = [tr for _, tr in batch]          # the last timed proof of every stream, checked after the clock stops
+    gather_wait_s = 0.0
     if gatherer is not None:
+        t_g = time.perf_counter()
         gathered = gatherer.wait()
+        gather_wait_s = time.perf_counter() - t_g      # what was left of the asynchronous gathers once the last proof was done
         if rank == 0:
             assert len(gathered) == args.steps and all(len(g) == world for g in gathered)
             assert all(len(dp.unpack(blob)) == K for g in gathered for _, blob in g)
@@ -281,10 +341,17 @@ def main():
     if dist is not None:
         dist.barrier(device_ids=[local_rank])
     elapsed = time.perf_counter() - t_start
+    per_rank = [{"rank": 0, "proofs_per_s": round(K * args.steps / rank_busy_s, 3), "streams": K, "gather_wait_s": round(gather_wait_s, 4)}]
     if dist is not None:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
+        # attribution of a sub-linear scaling figure: every rank's own rate, its stream count and how long it waited for the gather
+        mine = torch.tensor([rank_busy_s, float(K), gather_wait_s], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "proofs_per_s": round(float(t[1]) * args.steps / max(float(t[0]), 1e-9), 3), "streams": int(t[1]),
+                     "gather_wait_s": round(float(t[2]), 4)} for r, t in enumerate(a.cpu() for a in allr)]
 
     # the timed steps ran drive-only: replay the last proof of every stream through the full verifier (not timed)
     replay_mode = zkcnn_amd.MODE_REUSE_GENS | (zkcnn_amd.MODE_FIAT_SHAMIR if args.fiat_shamir else 0)
@@ -423,18 +490,25 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference prover) on the same workload ----
     cpu = None
+    parity = {}
     if not args.no_cpu_baseline and world == 1:        # the host baseline belongs to the single-GPU line (rank 0, N = 1)
         import multiprocessing as mp
         cm, cpic, cpp = WORKLOADS[args.cpu_sample or args.workload]
-        job = (cm, cpic, cpp, 20260928, drive)
+        job = (cm, cpic, cpp, DATA_SEED, drive)
         ctx = mp.get_context("spawn")
         with ctx.Pool(1) as pool:                          # (i) one core, nothing else running
-            one_s, one_wall, gates, one_sum, one_poly = pool.map(_cpu_prover_worker, [job])[0]
+            one_s, one_wall, gates, one_sum, one_poly, cpu_sha, cpu_len = pool.map(_cpu_prover_worker, [job])[0]
         cpu = {"value": round(1e3 * one_s, 1), "unit": "prover ms/image", "cores": 1, "kind": "port",
                "sample": f"{args.cpu_sample or args.workload} ({cm}), pic_cnt={cpp}, {gates} mul gates -- the full bench workload: CPU oracle prover time "
                          f"(sumcheck {1e3 * one_sum:.0f} ms + Hyrax {1e3 * one_poly:.0f} ms), same modes as the timed GPU proofs",
                "gpu_speedup_vs_one_core": round(1e3 * one_s / max(1e3 * (lat_prove + lat_poly), 1e-9), 1),
                "host_cores_available": os.cpu_count()}
+        if (args.cpu_sample or args.workload) == args.workload:
+            parity = {"transcript_equal_to_cpu_oracle": bool(parity_sha == cpu_sha and parity_len == cpu_len), "transcript_sha256_gpu": parity_sha,
+                      "transcript_sha256_cpu_oracle": cpu_sha, "transcript_bytes": parity_len,
+                      "parity_proof": f"session 0: data seed {DATA_SEED}, challenge seed {PARITY_SEED:#x}, the modes of the timed proofs; full workload"}
+            if not parity["transcript_equal_to_cpu_oracle"]:
+                raise SystemExit(f"GPU transcript differs from the CPU oracle's on the full workload: {parity}")
         n_proc = max(0, min(args.cpu_procs, (os.cpu_count() or 1)))
         try:
             import psutil
@@ -444,7 +518,7 @@ def main():
         if n_proc >= 2:                                    # (ii) independent single-threaded provers side by side
             t0 = time.time()
             with ctx.Pool(n_proc) as pool:
-                rs = pool.map(_cpu_prover_worker, [(cm, cpic, cpp, 20260928 + i, drive) for i in range(n_proc)])
+                rs = pool.map(_cpu_prover_worker, [(cm, cpic, cpp, DATA_SEED + i, drive) for i in range(n_proc)])
             wall = time.time() - t0
             per = sum(r[0] for r in rs) / n_proc
             cores = os.cpu_count() or 1
@@ -477,6 +551,8 @@ def main():
         "setup_s": round(setup_s, 1), "witness_s": round(first.witness_s, 1), "upload_sort_s": round(first.upload_s, 2),
         "roofline": roofline, "cpu_baseline": cpu,
     }
+    out.update(parity)
+    out["per_rank"] = per_rank
     out["host_rss_gb_all_sessions"] = host_rss_gb
     out["host_peak_rss_gb_while_building"] = host_peak_gb
     out.update(extras)

@@ -6,6 +6,9 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the soundness tests corrupt messages (ZKCNN_MODE_TAMPER) and resident witness values (zkcnn_session_poke) of the PRODUCT library on purpose:
+# both hooks refuse to work unless the process opts in
+os.environ.setdefault("ZKCNN_TEST_HOOKS", "1")
 
 
 def pytest_configure(config):

@@ -94,7 +94,8 @@ struct gpuSession : public sessionT<prover> {
 
     // the next picture on the resident circuit: 0 = done, 1 = other input scale (untouched), 2 = other activation scale (values stale)
     int newImage(const vector<double> &pixels) {
-        if (!nn || nn->program().steps.empty()) throw std::runtime_error("this session has no witness program (verifier-only session?)");
+        if (!nn || nn->program().steps.empty() || nn->program().picture_values == 0 || !ever_had_witness)
+            throw std::runtime_error("this session has no witness program (verifier-only session?)");
         vector<F> picture;
         if (!nn->quantisePicture(pixels, picture)) return 1;
         const witnessProgram &pg = nn->program();
@@ -124,6 +125,7 @@ struct gpuSession : public sessionT<prover> {
         has_witness = true;
         return 0;
     }
+    bool ever_had_witness = false;     // set once a build with picture + weights succeeded (a verifier-only session never gets there)
     vector<F> good_picture;            // quantised picture of the witness in HBM (what a refused new_image restores)
 };
 
@@ -144,6 +146,7 @@ void *zkcnn_session_create(const zkcnn_model_desc *desc, int32_t device) {
         s->p.init();                 // residency: circuit + witness to HBM, outside any timed region
         if (s->nn && !s->p.val.empty() && s->p.val[0].size() >= s->nn->program().picture_values)
             s->good_picture.assign(s->p.val[0].begin(), s->p.val[0].begin() + (size_t) s->nn->program().picture_values);
+        s->ever_had_witness = true;
         s->p.releaseHostValues();    // the host copy of every layer's values (0.7 GB for vgg11) has no reader left: proofs and new pictures work on the HBM copy
         return s.release();
     } catch (const std::exception &e) {
@@ -168,6 +171,7 @@ void *zkcnn_session_create_calibrated(const zkcnn_model_desc *desc, const int32_
         s->p.init();
         if (s->nn && !s->p.val.empty() && s->p.val[0].size() >= s->nn->program().picture_values)
             s->good_picture.assign(s->p.val[0].begin(), s->p.val[0].begin() + (size_t) s->nn->program().picture_values);
+        s->ever_had_witness = true;
         s->p.releaseHostValues();
         return s.release();
     } catch (const std::exception &e) {
@@ -176,9 +180,21 @@ void *zkcnn_session_create_calibrated(const zkcnn_model_desc *desc, const int32_
     }
 }
 
+// Test hooks (a message corrupted on purpose, a resident witness value overwritten) are part of the library because the parity and
+// soundness tests drive the PRODUCT through them -- but a deployment must opt in: ZKCNN_TEST_HOOKS=1 (tests/conftest.py sets it).
+static bool test_hooks_enabled() {
+    static const bool on = getenv("ZKCNN_TEST_HOOKS") && atoi(getenv("ZKCNN_TEST_HOOKS")) != 0;
+    return on;
+}
+
 int32_t zkcnn_session_prove(void *session, uint64_t seed, uint32_t mode, uint8_t *transcript, uint64_t cap, zkcnn_result *out) {
     if (!session || !out) return -1;
     gpuSession *s = (gpuSession *) session;
+    if ((mode & ZKCNN_MODE_TAMPER) && !test_hooks_enabled()) {
+        std::memset(out, 0, sizeof(*out));
+        std::snprintf(out->message, sizeof(out->message), "ZKCNN_MODE_TAMPER is a test hook: set ZKCNN_TEST_HOOKS=1");
+        return -4;
+    }
     try {
         int rc = s->prove(seed, mode, transcript, cap, out);
         out->upload_s = s->p.uploadTime();
@@ -238,7 +254,7 @@ int32_t zkcnn_session_new_image(void *session, uint64_t picture_seed, const doub
 }
 
 int64_t zkcnn_session_synthetic_picture(void *session, uint64_t picture_seed, double *pixels, uint64_t cap) {
-    if (!session || !((gpuSession *) session)->nn) return -1;
+    if (!session || !((gpuSession *) session)->nn || (!pixels && cap)) return -1;
     vector<double> px = ((gpuSession *) session)->nn->syntheticPicture(picture_seed);
     for (size_t i = 0; i < px.size() && i < cap; ++i) pixels[i] = px[i];
     return (int64_t) px.size();
@@ -253,6 +269,7 @@ int64_t zkcnn_session_layer_size(void *session, int32_t layer, int32_t *type) {
 }
 int32_t zkcnn_session_poke(void *session, int32_t layer, uint64_t index, const uint64_t value[4]) {
     if (!session || !value) return -1;
+    if (!test_hooks_enabled()) return -4;
     gpuSession *s = (gpuSession *) session;
     return zk_poke_layer_value(s->p.context(), layer, index, value) == ZK_OK ? 0 : -2;
 }

@@ -459,6 +459,7 @@ int neuralNetwork::nextScaleBits(i64 layer_id) {
     return logged(scaleFromRange(range, x_bit + w_bit));
 }
 int neuralNetwork::scaleFromRange(i64 range, int bits) const {
+    if (range <= 0) range = 1;          // a layer of zeros: the largest finite scale (the reference divides by zero here and casts the infinity)
     double real_scale = range / std::exp2(bits);
     return (int) std::log2(((1 << (Q - 1)) - 1) / real_scale);
 }

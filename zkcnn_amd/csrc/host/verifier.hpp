@@ -9,6 +9,7 @@
 // option to re-use generators, and a "drive only" mode that draws the same challenges and makes the
 // same prover calls but skips the verifier's own (gate-walking) work so a bench can time the prover.
 #pragma once
+#include <stdexcept>
 #include "circuit.h"
 #include "polynomial.h"
 #include "utils.hpp"
@@ -28,7 +29,12 @@ struct proofTranscript : public hyrax_bls12_381::transcriptSink {
         size_t o = bytes.size();
         bytes.resize(o + 32);
         x.toBytesLE(&bytes[o]);
-        if (tap) tap->absorbFr(x);
+        if (tap) {
+            // the tap (and the GPU's copy of the chain, hip/fs_tail.cuh) hashes the limbs as they lie in memory: that is a function of the field
+            // element only while every emitted value is fully reduced -- checked here, at the boundary, not assumed
+            if (Fr::geMod(x.v)) throw std::runtime_error("transcript: a field element left the prover unreduced (limbs >= r)");
+            tap->absorbFr(x);
+        }
     }
     void put(const G1 &p) override {
         size_t o = bytes.size();
