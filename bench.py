@@ -94,7 +94,7 @@ def self_launch_if_needed(args, argv):
     if args.gpus <= 1 or "RANK" in os.environ:
         return
     have = visible_gpus()
-    if have < args.gpus:
+    if have < args.gpus and not (args.rehearse_shared_gpu and have >= 1):
         raise SystemExit(f"bench.py --gpus {args.gpus}: this box has {have} GPU(s); one rank per GPU is needed (no CPU fallback, no oversubscription)")
     cmd = launch_command(argv, args.gpus)
     print("[bench] launching the ranks: " + " ".join(cmd), file=sys.stderr, flush=True)
@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--fiat-shamir", action="store_true", help="timed proofs non-interactive (device-side rounds; experiment)")
     ap.add_argument("--no-companions", action="store_true", help="skip the extra single-stream measurements of other modes (profiling runs)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel-class table of one extra proof to stderr")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="REHEARSAL of the multi-rank path on a box with fewer GPUs than ranks: ranks share GPUs (rank %% GPUs) and exchange over gloo "
+                         "(RCCL refuses two ranks on one device). Not a scaling measurement; the line says so")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -164,6 +167,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.rehearse_shared_gpu:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     pin_to_gpu_numa_node(torch, local_rank)
     dist = None
@@ -173,7 +178,9 @@ def main():
         # no device_id: the RCCL communicator (its streams and hardware queues) is then created by the first collective -- the barrier in front of
         # the timed region, AFTER the sessions and their streams exist. Created first it costs the proving streams a fifth of their throughput
         # (71.7 vs 88.1 proofs/s on one rank; the same creation-order effect as for the sessions themselves).
-        if os.environ.get("ZKCNN_BENCH_EAGER_RCCL"):
+        if args.rehearse_shared_gpu:
+            dist.init_process_group(backend="gloo")
+        elif os.environ.get("ZKCNN_BENCH_EAGER_RCCL"):
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="nccl")
@@ -293,12 +300,16 @@ def main():
         sess.profile(None)
 
     # ---- timed region: `steps` steps, a step = K proofs in flight on this GPU (one per stream) ----
-    if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+    coll_dev = "cpu" if args.rehearse_shared_gpu else "cuda"        # gloo exchanges host tensors
+
+    def barrier():
+        if dist is not None:
+            dist.barrier() if args.rehearse_shared_gpu else dist.barrier(device_ids=[local_rank])
+    barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     prove_s = poly_s = 0.0
-    gatherer = dp.AsyncGather(dist, "cuda", K << 19) if dist is not None and not os.environ.get("ZKCNN_BENCH_NOGATHER") else None
+    gatherer = dp.AsyncGather(dist, coll_dev, K << 19) if dist is not None and not os.environ.get("ZKCNN_BENCH_NOGATHER") else None
     done = [queue.Queue() for _ in range(K)]
     fail = []
 
@@ -338,16 +349,15 @@ def main():
             assert len(gathered) == args.steps and all(len(g) == world for g in gathered)
             assert all(len(dp.unpack(blob)) == K for g in gathered for _, blob in g)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+    barrier()
     elapsed = time.perf_counter() - t_start
     per_rank = [{"rank": 0, "proofs_per_s": round(K * args.steps / rank_busy_s, 3), "streams": K, "gather_wait_s": round(gather_wait_s, 4)}]
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        te = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
         # attribution of a sub-linear scaling figure: every rank's own rate, its stream count and how long it waited for the gather
-        mine = torch.tensor([rank_busy_s, float(K), gather_wait_s], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([rank_busy_s, float(K), gather_wait_s], dtype=torch.float64, device=coll_dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "proofs_per_s": round(float(t[1]) * args.steps / max(float(t[0]), 1e-9), 3), "streams": int(t[1]),
@@ -534,14 +544,14 @@ def main():
         "metric": f"proofs/s (GKR prover, {args.workload} pic_cnt={pp} proofs, {K} in flight per GPU; modes SEEDED|DRIVE_ONLY|REUSE_GENS: public generators "
                   "with a resident byte table, IPA cut at 256" + ("; EXPERIMENT: hybrid host tail" if args.hybrid_tail else "") + ("; EXPERIMENT: Fiat-Shamir, device-side rounds" if args.fiat_shamir else "") +
                   "); prover_ms_per_image = single-stream latency; conservative companions alongside",
-        "value": round(world * K * steps / elapsed, 4),
+        "value": round(sum(p["streams"] for p in per_rank) * steps / elapsed, 4),         # every rank's proofs (a rank may hold fewer streams than asked for)
         "unit": "proofs/s",
         "n_gpus": world, "steps": steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u256 (BLS12-381 Fr, 8x32-bit Montgomery limbs)", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {model} {pic[0]}x{pic[1]}x{pic[2]} pic_cnt={pp}, one proof per image, {K} images in flight per GPU",
-                   "images_per_step": world * K, "streams_per_gpu": K,
+                   "images_per_step": sum(p["streams"] for p in per_rank), "streams_per_gpu": K,
                    "layers": first.n_layers, "input_size": first.input_size, "rounds": first.n_rounds,
                    "mul_gates": first.gate_cnt_bin, "add_gates": first.gate_cnt_uni, "parallelism": f"dp{world} x {K} streams (independent proofs, RCCL gather)"},
         "prover_ms_per_image": round(1e3 * (lat_prove + lat_poly), 3),
@@ -553,6 +563,8 @@ def main():
     }
     out.update(parity)
     out["per_rank"] = per_rank
+    if args.rehearse_shared_gpu:
+        out["rehearsal"] = f"{world} ranks share {torch.cuda.device_count()} GPU(s), gloo exchange: a rehearsal of the launch / gather / timing path, NOT a scaling measurement"
     out["host_rss_gb_all_sessions"] = host_rss_gb
     out["host_peak_rss_gb_while_building"] = host_peak_gb
     out.update(extras)
