@@ -42,26 +42,6 @@ def test_device_rounds_give_the_host_transcript(built, model, pic, pp):
         print(f"{model}: {r1 - r0} of {res.n_rounds} rounds in {p1 - p0} device phases")
 
 
-@pytest.mark.parametrize("model,pic,pp", [CASES[3], CASES[4], CASES[5]])
-def test_chained_rounds_give_the_same_transcript(built, monkeypatch, model, pic, pp):
-    """ZKCNN_FS_CHAIN=1: rounds on tables of up to 2^16 entries also run without the host -- one launch per round, the next challenge derived
-    in the launch's last block (k_round_chain), the tail kernel behind them. Off by default (measured: no faster than host-driven rounds);
-    the transcript must not depend on it."""
-    with zkcnn_amd.Session(model, pic, pp) as s:
-        _, want = s.prove(mode=FS)
-        r0, _ = s.fs_stats()
-        s.prove(mode=FS, want_transcript=False)
-        plain = s.fs_stats()[0] - r0
-        monkeypatch.setenv("ZKCNN_FS_CHAIN", "1")
-        r1, _ = s.fs_stats()
-        res, got = s.prove(mode=FS)
-        chained = s.fs_stats()[0] - r1
-        assert res.accepted == 1 and got == want
-        assert chained > plain, "no additional round ran on the device with chaining switched on"
-        assert s.verify(got, mode=FS).accepted == 1
-        print(f"{model}: {plain} -> {chained} device rounds of {res.n_rounds}")
-
-
 def test_full_size_vgg11_fiat_shamir_latency(built):
     with zkcnn_amd.Session("vgg11", (32, 32, 3), 1) as s:
         s.prove(mode=FS | DRIVE, want_transcript=False)           # tables of the public generators

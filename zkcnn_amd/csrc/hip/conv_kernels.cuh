@@ -14,33 +14,8 @@
 
 #define CONV_TAB_STRIDE 4096u           // entries per small eq table
 // table numbers inside the context's small-table buffer
+// (the tables are built by the phase's k_prep launch: prep_kernels.cuh, prep_small_block -- eq(r[0..n), .) * init for n <= 12)
 enum { CT_S0 = 0, CT_A0, CT_P0, CT_S1, CT_A1, CT_P1, CT_D, CT_C, CT_PU, CT_COUNT };
-
-// one block per table: eq(r[0..n), .) * init for n <= 12 -- the two half tables (<= 64 entries each) by doubling in LDS, then the products
-__global__ void __launch_bounds__(1024) k_eq_small_multi(fr_t *full, const liu_table *tabs) {
-    __shared__ fr_t h[2][64];
-    const liu_table &a = tabs[blockIdx.x];
-    if (a.n < 0) return;
-    const int n = a.n, fh = n >> 1, sh = n - fh;
-    const int side = threadIdx.x >> 6, t = threadIdx.x & 63;
-    if (threadIdx.x < 128 && t == 0) h[side][0] = side ? fr_one() : fr_load(&a.init);
-    __syncthreads();
-    for (int i = 0; i < 6; ++i) {
-        if (threadIdx.x < 128) {
-            const int steps = side ? sh : fh, base = side ? fh : 0, half = 1 << i;
-            if (i < steps && t < half) {
-                const fr_t cur = h[side][t];
-                const fr_t x = fr_mul(cur, fr_load(&a.r.v[base + i]));
-                h[side][t | half] = x;
-                h[side][t] = fr_sub(cur, x);
-            }
-        }
-        __syncthreads();
-    }
-    fr_t *T = full + (size_t) blockIdx.x * CONV_TAB_STRIDE;
-    const uint32_t N = 1u << n, mask = (1u << fh) - 1;
-    for (uint32_t j = threadIdx.x; j < N; j += 1024) fr_store(T + j, fr_mul(h[0][j & mask], h[1][j >> fh]));
-}
 
 // part[(chunk * K + k) * len + o] = sum over the chunk's co of A_k[co] * W[co * len + o];  len = CI * m^2; grid (ceil(len / 256), chunks)
 __global__ void __launch_bounds__(ZK_BLOCK) k_conv_wa(fr_t *part, const fr_t *W, const fr_t *tabs, uint32_t len, uint32_t CO, uint32_t per, int K) {

@@ -101,7 +101,7 @@ struct zk_ctx {
     // per-round hand-over: mapped pinned host slot written by the last block of a fused round kernel
     struct host_slot_h { HFr v[12]; volatile unsigned long long seq; } *h_slot = nullptr;
     void *d_slot = nullptr;        // device address of h_slot
-    // second slot: the two sums behind a phase's add_term (k_sum_partials_slot); read lazily, behind the phase's first round
+    // second slot: the two sums behind a phase's add_term (k_gate_multi's constant-term job); read lazily, behind the phase's first round
     host_slot_h *h_aux = nullptr; void *d_aux = nullptr;
     unsigned long long aux_seq = 0;
     bool add_pending = false;
@@ -143,8 +143,6 @@ struct zk_ctx {
     const uint32_t *fs_state = nullptr;
     const uint64_t *fs_pending = nullptr;
     void *h_tail = nullptr, *d_tail = nullptr;     // tail_out, pinned + mapped
-    void *d_chain = nullptr;                        // chain_state: challenge, add_term, chain state handed from one chained round launch to the next
-    uint64_t chain_rounds_total = 0;
     bool tail_active = false;
     int tail_count = 0, tail_cursor = 0, phase_rounds = 0;
     unsigned long long tail_seq = 0;

@@ -22,11 +22,6 @@
 #define FS_TAIL_QUADS 512              // quads (both table pairs together) the kernel takes: its first two rounds then make 4 and 2 passes over the slots
 #define FS_TAIL_MAX_ROUNDS ZK_MAX_VARS
 
-struct chain_state {                  // device memory: what one launch of a chained segment hands to the next (k_round_chain -> k_round_chain -> k_fs_tail)
-    fr_t r, add_term;
-    uint32_t fs[8];
-};
-
 struct tail_out {                     // pinned, mapped host memory
     fr_t poly[FS_TAIL_MAX_ROUNDS][3]; // round polynomials (a, b, c) as the host's quad_round returns them
     fr_t chal[FS_TAIL_MAX_ROUNDS];    // challenge derived after each of them
@@ -48,8 +43,6 @@ struct tail_args {
     uint32_t fs_state[8];
     tail_out *out;
     unsigned long long seq;
-    const chain_state *cs;            // not NULL: prev_r, add_term and the chain state come from the chained round kernels that ran just before
-    int32_t k0, pad_;                 // index of this kernel's first round in out->poly / out->chal (rounds before it: the chained kernels')
 };
 
 __device__ __forceinline__ bool fr_raw_ge_mod(const uint32_t t[8]) {
@@ -99,10 +92,10 @@ __global__ void __launch_bounds__(FS_TAIL_THREADS) k_fs_tail(tail_args a) {
     bool first = a.first != 0;
     uint32_t pstate[2] = {n[0] ? 1u : 0u, n[1] ? 1u : 0u};
     if (tid == 0) {
-        s_r = a.cs ? fr_load(&a.cs->r) : a.prev_r;
-        s_add = a.cs ? fr_load(&a.cs->add_term) : a.add_term;
+        s_r = a.prev_r;
+        s_add = a.add_term;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s_state[i] = a.cs ? a.cs->fs[i] : a.fs_state[i];
+        for (int i = 0; i < 8; ++i) s_state[i] = a.fs_state[i];
     }
     __syncthreads();
     for (int k = 0; k < a.rounds; ++k) {
@@ -196,16 +189,16 @@ __global__ void __launch_bounds__(FS_TAIL_THREADS) k_fs_tail(tail_args a) {
                     if (collapse[b]) add_term = fr_add(add_term, s_prod[b]);
                 s_add = add_term;
                 if (a.with_add_term) { cb = fr_sub(cb, add_term); cc = fr_add(cc, add_term); }
-                fr_store(&a.out->poly[a.k0 + k][0], ca);
-                fr_store(&a.out->poly[a.k0 + k][1], cb);
-                fr_store(&a.out->poly[a.k0 + k][2], cc);
+                fr_store(&a.out->poly[k][0], ca);
+                fr_store(&a.out->poly[k][1], cb);
+                fr_store(&a.out->poly[k][2], cc);
                 // chain step on the 96 bytes of (a, b, c) as they lie in memory, then the challenge
                 uint32_t st[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) st[i] = s_state[i];
                 const fr_t ch = fs_round_challenge(st, ca, cb, cc);
                 s_r = ch;
-                fr_store(&a.out->chal[a.k0 + k], ch);
+                fr_store(&a.out->chal[k], ch);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s_state[i] = st[i];
             }
@@ -240,133 +233,6 @@ __global__ void __launch_bounds__(FS_TAIL_THREADS) k_fs_tail(tail_args a) {
     }
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// Chained rounds: the rounds of a phase whose tables are too large for the single-workgroup kernel above (up to 2^16 entries) but which, in the
-// non-interactive mode, need no host either. One launch per round, the work layout of k_round_quad_fine (4 lanes per quad); the block that
-// finishes LAST adds the block sums and does what the host does between two rounds -- add_term (1 - r), the coefficient b, the chain step, the
-// next challenge -- and leaves challenge, add_term and chain state in device memory for the next launch. The host enqueues all rounds of a
-// segment (and the tail kernel behind them) at once and reads every round polynomial afterwards. Only rounds in which no table collapses
-// and none is down to its last pair are chained (the host plans the segment): no special cases here.
-// ------------------------------------------------------------------------------------------------
-struct chain_args {
-    const fr_t *Vin[2], *Min[2];
-    fr_t *Vout[2], *Mout[2];
-    uint64_t n[2];                    // pre-fold lengths; 0 = absent
-    int32_t first, with_add_term;
-    int32_t from_args;                // the segment's first launch: prev_r / add_term / fs_state below; later ones read *cs
-    int32_t k, last;                  // index in out->poly / out->chal; last launch of a segment WITHOUT a tail kernel behind it: publish seq
-    fr_t prev_r, add_term;
-    uint32_t fs_state[8];
-    chain_state *cs;
-    fr_t *partials;
-    uint32_t *counter;
-    tail_out *out;
-    unsigned long long seq;
-};
-
-__global__ void __launch_bounds__(ZK_BLOCK) k_round_chain(chain_args a) {
-    __shared__ fr_t s_role[3][ZK_BLOCK / 64];
-    __shared__ int s_last;
-    uint64_t items[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) items[b] = !a.n[b] ? 0 : (a.first ? a.n[b] / 2 : a.n[b] / 4);
-    const fr_t r = a.from_args ? a.prev_r : fr_load(&a.cs->r);
-    const uint64_t gi = blockIdx.x * (uint64_t) (ZK_BLOCK / 4) + (threadIdx.x >> 2);
-    const uint32_t role = threadIdx.x & 3;
-    const bool live = gi < items[0] + items[1];
-    const int b = (live && gi >= items[0]) ? 1 : 0;
-    const uint64_t q = b ? gi - items[0] : gi;
-    const fr_t *Vin = b ? a.Vin[1] : a.Vin[0], *Min = b ? a.Min[1] : a.Min[0];
-    fr_t X = fr_zero(), opA = fr_zero(), opB = fr_zero();
-    if (a.first) {
-        if (live && role < 3) {
-            const fr_t v0 = fr_load(Vin + 2 * q), v1 = fr_load(Vin + 2 * q + 1), m0 = fr_load(Min + 2 * q), m1 = fr_load(Min + 2 * q + 1);
-            opA = role == 0 ? v0 : role == 1 ? v1 : fr_sub(v1, v0);
-            opB = role == 0 ? m0 : role == 1 ? m1 : fr_sub(m1, m0);
-        }
-    } else {
-        if (live) {
-            const fr_t *src = (role < 2 ? Vin : Min) + 4 * q + 2 * (role & 1);
-            X = fr_lerp(fr_load(src), fr_load(src + 1), r);
-            fr_t *dst = role < 2 ? (b ? a.Vout[1] : a.Vout[0]) : (b ? a.Mout[1] : a.Mout[0]);
-            fr_store(dst + 2 * q + (role & 1), X);
-        }
-        fr_t y1, y2, y3;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            y1.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 2, 64);
-            y2.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 1, 64);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y3.v[i] = (uint32_t) __shfl_xor((int) y1.v[i], 1, 64);
-        opA = role == 2 ? fr_sub(y3, y1) : X;
-        opB = role == 2 ? fr_sub(y2, X) : y1;
-        if (role == 3 || !live) { opA = fr_zero(); opB = fr_zero(); }
-    }
-    fr_t prod = fr_mul(opA, opB);
-#pragma unroll
-    for (int off = 4; off < 64; off <<= 1) {
-        fr_t o;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o.v[i] = (uint32_t) __shfl_xor((int) prod.v[i], off, 64);
-        prod = fr_add(prod, o);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane < 3) s_role[lane][wave] = prod;          // role 0: c, role 1: p(1), role 2: a
-    __syncthreads();
-    // block sums -> partials (visible across the chip), ticket, last block adds them up
-    if (threadIdx.x < 3) {
-        fr_t t = fr_zero();
-#pragma unroll
-        for (int w = 0; w < ZK_BLOCK / 64; ++w) t = fr_add(t, s_role[threadIdx.x][w]);
-        if (gridDim.x > 1) {
-            fr_store_scoped(a.partials + (size_t) 3 * blockIdx.x + threadIdx.x, t, false);
-            ZK_WAIT_STORES();
-        } else s_role[threadIdx.x][0] = t;
-    }
-    __syncthreads();
-    if (gridDim.x > 1) {
-        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-        __syncthreads();
-        if (!s_last) return;
-        if (wave < 3) {
-            fr_t tot = fr_zero();
-            for (uint32_t blk = lane; blk < gridDim.x; blk += 64) tot = fr_add(tot, fr_load_agent(a.partials + (size_t) 3 * blk + wave));
-            tot = fr_wave_sum(tot);
-            if (lane == 0) s_role[wave][0] = tot;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    if (gridDim.x > 1) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // ---- what the host does between two rounds (quad_round in sumcheck.hip, reference src/prover.cpp:368-383) ----
-    fr_t cc = s_role[0][0], p1 = s_role[1][0], ca = s_role[2][0];
-    fr_t add_term = a.from_args ? a.add_term : fr_load(&a.cs->add_term);
-    if (a.with_add_term && !a.first) add_term = fr_mul(add_term, fr_sub(fr_one(), r));
-    fr_t cb = fr_sub(fr_sub(p1, ca), cc);
-    if (a.with_add_term) { cb = fr_sub(cb, add_term); cc = fr_add(cc, add_term); }
-    fr_store(&a.out->poly[a.k][0], ca);
-    fr_store(&a.out->poly[a.k][1], cb);
-    fr_store(&a.out->poly[a.k][2], cc);
-    uint32_t st[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) st[i] = a.from_args ? a.fs_state[i] : a.cs->fs[i];
-    const fr_t ch = fs_round_challenge(st, ca, cb, cc);
-    fr_store(&a.out->chal[a.k], ch);
-    fr_store(&a.cs->r, ch);
-    fr_store(&a.cs->add_term, add_term);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a.cs->fs[i] = st[i];
-    if (a.last) {
-        fr_store(&a.out->add_term, add_term);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a.out->fs_state[i] = st[i];
-        a.out->pair_state[0] = a.out->pair_state[1] = 3;          // "still live": the host keeps folding these tables
-        __threadfence_system();
-        *((volatile unsigned long long *) &a.out->seq) = a.seq;
-    }
-}
 
 // Hybrid tail: the live tables of a phase (at most 256 entries each) to mapped host memory in one small launch; seq is written last.
 struct export_out { fr_t V[2][256], M[2][256]; unsigned long long seq; };

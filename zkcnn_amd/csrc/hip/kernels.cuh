@@ -39,44 +39,6 @@ __global__ void k_bench_copy(uint4 *dst, const uint4 *src, uint64_t n16) {
 // ------------------------------------------------------------------------------------------------
 // K1: eq ("beta") tables.  reference src/utils.cpp:32-51 (half tables), 147-180 (expansion)
 // ------------------------------------------------------------------------------------------------
-struct eq_args {
-    fr_vec r[2];
-    fr_t init[2];
-    int32_t npoints, fh, sh;
-};
-
-// one block per (point, half): lo[p] = init_p * eq(r_p[0..fh), .),  hi[p] = eq(r_p[fh..fh+sh), .)
-// lo tables are `lo_stride` apart, hi tables `hi_stride` apart. The four doubling chains are independent.
-// The table of `steps` variables is the outer product of two quarter tables (variables [0, qa) and [qa, steps)) that the two halves
-// of the block build side by side in LDS by doubling: the dependent chain is ceil(steps / 2) + 1 products instead of `steps`.
-__global__ void __launch_bounds__(1024) k_eq_halves(fr_t *lo, fr_t *hi, uint32_t lo_stride, uint32_t hi_stride, eq_args a) {
-    __shared__ fr_t q[2][256];
-    const int p = blockIdx.x >> 1, is_hi = blockIdx.x & 1;
-    fr_t *T = is_hi ? hi + (size_t) p * hi_stride : lo + (size_t) p * lo_stride;
-    const int steps = is_hi ? a.sh : a.fh, base = is_hi ? a.fh : 0;
-    const int qa = (steps + 1) >> 1, qb = steps - qa;              // qa <= 8 for the 2^15-entry tables this kernel is sized for
-    const int side = threadIdx.x >> 9, t = threadIdx.x & 511;      // threads 0..511 build quarter 0, 512..1023 quarter 1
-    const int nq = side ? qb : qa, qbase = base + (side ? qa : 0);
-    if (t == 0) q[side][0] = side ? fr_one() : (is_hi ? fr_one() : a.init[p]);
-    __syncthreads();
-    for (int i = 0; i < qa; ++i) {                                 // qa >= qb: both sides run qa barrier steps
-        const uint32_t half = 1u << i;
-        if (i < nq && (uint32_t) t < half) {
-            const fr_t cur = q[side][t];
-            const fr_t x = fr_mul(cur, a.r[p].v[qbase + i]);
-            q[side][t | half] = x;
-            q[side][t] = fr_sub(cur, x);
-        }
-        __syncthreads();
-    }
-    const uint32_t n = 1u << steps, ma = (1u << qa) - 1;
-    if (qb == 0) {
-        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) fr_store(T + j, q[0][j]);
-        return;
-    }
-    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) fr_store(T + j, fr_mul(q[0][j & ma], q[1][j >> qa]));
-}
-
 // ---- layer-0 combine in two launches (reference src/prover.cpp:334-354 loops over every layer: an eq table and a scatter each) ----
 // M[x] = sum over layers i and sides of  sig * eq(r_{u|v}[i], h)  for every (i, side, h) with ori_id[h] == x. The pairs are known when the
 // circuit is uploaded (a CSR by x); eq(r, h) = lo[h & mask] * hi[h >> fh] needs only the two HALF tables of each (layer, side), so the full
@@ -86,61 +48,51 @@ struct liu_table { fr_vec r; fr_t init; int32_t n, fh, sh, pad_; };      // one 
 // grid (2, ntables): block (is_hi, t) builds one half table of table t in LDS (same doubling as k_eq_halves) and stores it
 __global__ void __launch_bounds__(1024) k_eq_halves_multi(fr_t *halves, const liu_table *tabs) {
     __shared__ fr_t q[2][256];
+    __shared__ fr_t s_r[ZK_MAX_VARS + 1];
     const int is_hi = blockIdx.x, tb = blockIdx.y;
-    const liu_table &a = tabs[tb];
-    if (a.n < 0) return;
+    const liu_table &a = tabs[tb];               // mapped host memory: everything the block needs comes over in ONE batch of loads
+    const int n = a.n;
+    if (n < 0) return;
+    if ((int) threadIdx.x < n) s_r[threadIdx.x] = fr_load(&a.r.v[threadIdx.x]);
+    if (threadIdx.x == ZK_MAX_VARS) s_r[ZK_MAX_VARS] = fr_load(&a.init);
+    const int fh = n >> 1, sh = n - fh;
     fr_t *T = halves + ((size_t) tb * 2 + is_hi) * LIU_HALF_STRIDE;
-    const int steps = is_hi ? a.sh : a.fh, base = is_hi ? a.fh : 0;
+    const int steps = is_hi ? sh : fh, base = is_hi ? fh : 0;
     const int qa = (steps + 1) >> 1, qb = steps - qa;
     const int side = threadIdx.x >> 9, t = threadIdx.x & 511;
     const int nq = side ? qb : qa, qbase = base + (side ? qa : 0);
-    if (t == 0) q[side][0] = side ? fr_one() : (is_hi ? fr_one() : fr_load(&a.init));
+    __syncthreads();
+    if (t == 0) q[side][0] = side ? fr_one() : (is_hi ? fr_one() : s_r[ZK_MAX_VARS]);
     __syncthreads();
     for (int i = 0; i < qa; ++i) {
         const uint32_t half = 1u << i;
         if (i < nq && (uint32_t) t < half) {
             const fr_t cur = q[side][t];
-            const fr_t x = fr_mul(cur, fr_load(&a.r.v[qbase + i]));
+            const fr_t x = fr_mul(cur, s_r[qbase + i]);
             q[side][t | half] = x;
             q[side][t] = fr_sub(cur, x);
         }
         __syncthreads();
     }
-    const uint32_t n = 1u << steps, ma = (1u << qa) - 1;
+    const uint32_t cnt = 1u << steps, ma = (1u << qa) - 1;
     if (qb == 0) {
-        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) fr_store(T + j, q[0][j]);
+        for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x) fr_store(T + j, q[0][j]);
         return;
     }
-    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) fr_store(T + j, fr_mul(q[0][j & ma], q[1][j >> qa]));
+    for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x) fr_store(T + j, fr_mul(q[0][j & ma], q[1][j >> qa]));
 }
-struct liu_entry { uint32_t h, t; };                                        // index inside table t
+struct liu_entry { uint32_t h, t; };                                        // index h inside table (t & 0xffffff); t >> 24 = bits of the table's low half
 // one thread per layer-0 index x: sums its entries (CSR rows are contiguous, so a wave reads them coalesced)
-__global__ void __launch_bounds__(ZK_BLOCK) k_liu_gather(fr_t *M, const uint32_t *row_ptr, const liu_entry *ent, const fr_t *halves,
-                                                         const liu_table *tabs, uint64_t n) {
+__global__ void __launch_bounds__(ZK_BLOCK) k_liu_gather(fr_t *M, const uint32_t *row_ptr, const liu_entry *ent, const fr_t *halves, uint64_t n) {
     for (uint64_t x = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x; x < n; x += (uint64_t) gridDim.x * ZK_BLOCK) {
         fr_t acc = fr_zero();
         for (uint32_t e = row_ptr[x]; e < row_ptr[x + 1]; ++e) {
             const liu_entry en = ent[e];
-            const int fh = tabs[en.t].fh;
-            const fr_t *lo = halves + (size_t) en.t * 2 * LIU_HALF_STRIDE;
+            const uint32_t fh = en.t >> 24;
+            const fr_t *lo = halves + (size_t) (en.t & 0xffffffu) * 2 * LIU_HALF_STRIDE;
             acc = fr_add(acc, fr_mul(fr_load(lo + (en.h & ((1u << fh) - 1))), fr_load(lo + LIU_HALF_STRIDE + (en.h >> fh))));
         }
         fr_store(M + x, acc);
-    }
-}
-
-// out[i] = sum_p lo_p[i & mask] * hi_p[i >> fh]; entries >= tail_start are additionally scaled
-// (the relu_rou factor on the constraint rows, reference src/prover.cpp:221-222)
-__global__ void k_eq_expand(fr_t *out, const fr_t *lo, const fr_t *hi, uint32_t lo_stride, uint32_t hi_stride, int npoints,
-                            int fh, uint64_t n, uint64_t tail_start, fr_t tail_scale) {
-    const uint64_t mask = (1ull << fh) - 1;
-    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
-        fr_t acc = fr_zero();
-        if (npoints >= 1) acc = fr_mul(fr_load(lo + (i & mask)), fr_load(hi + (i >> fh)));
-        if (npoints >= 2)
-            acc = fr_add(acc, fr_mul(fr_load(lo + lo_stride + (i & mask)), fr_load(hi + hi_stride + (i >> fh))));
-        if (i >= tail_start) acc = fr_mul(acc, tail_scale);
-        fr_store(out + i, acc);
     }
 }
 
@@ -149,26 +101,6 @@ __global__ void k_outer_expand(fr_t *out, const fr_t *coarse, const fr_t *fine, 
     const uint64_t mask = (1ull << bits) - 1;
     for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
         fr_store(out + i, fr_mul(fr_load(coarse + (i >> bits)), fr_load(fine + (i & mask))));
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3: table gather.  reference src/prover.cpp:205-212, 291-296 (getCirValue :499)
-// ------------------------------------------------------------------------------------------------
-__global__ void k_gather(fr_t *dst, const fr_t *src, const uint32_t *idx, uint64_t n_valid, uint64_t n_total) {
-    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n_total; i += (uint64_t) gridDim.x * blockDim.x) {
-        fr_t x = fr_zero();
-        if (i < n_valid) x = fr_load(src + (idx ? idx[i] : i));
-        fr_store(dst + i, x);
-    }
-}
-
-// K12: layer-0 combine, M[ori[h]] += beta[h]; ori is injective inside one launch.
-// reference src/prover.cpp:334-354
-__global__ void k_scatter_add_unique(fr_t *M, const uint32_t *ori, const fr_t *beta, uint64_t n) {
-    for (uint64_t h = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; h < n; h += (uint64_t) gridDim.x * blockDim.x) {
-        fr_t *dst = M + ori[h];
-        fr_store(dst, fr_add(fr_load(dst), fr_load(beta + h)));
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -189,25 +121,14 @@ struct gate_args {
     fr_t post;
 };
 
-__device__ __forceinline__ fr_t gate_term(const gate_rec &rc, const gate_args &a) {
-    if (GATE_DUMMY(rc.meta)) return fr_zero();
-    fr_t t = fr_load(a.beta_g + rc.g);
-    if (a.phase == 1) {
-        if (GATE_HAS_VAL(rc.meta)) t = fr_mul(t, fr_load((GATE_IN_PREV(rc.meta) ? a.val_prev : a.val0) + rc.aux));
-    } else {
-        t = fr_mul(t, fr_load(a.beta_u + rc.aux));
-        if (!a.post_scale) t = fr_mul(t, GATE_IN_PREV(rc.meta) ? a.Vu1 : a.Vu0);
-    }
-    const uint32_t sc = GATE_SC(rc.meta);
-    if (sc) t = fr_mul(t, fr_load(a.two_mul + sc));
-    return t;
-}
-
 // One gate per thread. Wave-level segmented scan with cross-lane moves, cross-wave carry through
 // LDS. Segments that lie inside a block are stored straight to `out`; the block's first and last
 // segment go to `carry` (2 slots per block) and are combined by k_gate_fixup.
+// lb: index of the block inside its list (k_gate_multi runs several lists in one launch; idx counts inside the list). direct: the list
+// fits this one block, so its first and last segment are complete too and are stored like the others (no carry slots, no fix-up launch).
 __device__ __forceinline__ void gate_segment_store(uint32_t key, fr_t val, bool live, uint64_t idx, uint64_t n, fr_t *out,
-                                                   uint32_t *carry_key, fr_t *carry_val, bool post_scale, const fr_t &post) {
+                                                   uint32_t *carry_key, fr_t *carry_val, bool post_scale, const fr_t &post,
+                                                   uint32_t lb, bool direct = false) {
     __shared__ uint32_t s_head[ZK_BLOCK / 64], s_tail[ZK_BLOCK / 64];
     __shared__ fr_t s_tailval[ZK_BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -228,20 +149,24 @@ __device__ __forceinline__ void gate_segment_store(uint32_t key, fr_t val, bool 
         }
     }
     if (!live) return;
-    const uint64_t blk_last = min(n, (blockIdx.x + 1) * (uint64_t) ZK_BLOCK) - 1;
+    const uint64_t blk_last = min(n, (lb + 1) * (uint64_t) ZK_BLOCK) - 1;
     uint32_t next_key = (uint32_t) __shfl_down((int) key, 1, 64);
     if (lane == 63) next_key = (wave + 1 < ZK_BLOCK / 64) ? s_head[wave + 1] : GATE_NOKEY;
     const uint32_t kf = s_head[0];
     if (post_scale && (idx == blk_last || next_key != key)) val = fr_mul(val, post);   // segment (or block-partial) total
+    if (direct) {
+        if (idx == blk_last || next_key != key) fr_store(out + key, val);
+        return;
+    }
     if (idx == blk_last) {
         const int slot = (key == kf) ? 0 : 1;
-        carry_key[2 * blockIdx.x + slot] = key;
-        fr_store(carry_val + 2 * blockIdx.x + slot, val);
-        if (slot == 0) carry_key[2 * blockIdx.x + 1] = GATE_NOKEY;
+        carry_key[2 * lb + slot] = key;
+        fr_store(carry_val + 2 * lb + slot, val);
+        if (slot == 0) carry_key[2 * lb + 1] = GATE_NOKEY;
     } else if (next_key != key) {
         if (key == kf) {
-            carry_key[2 * blockIdx.x] = key;
-            fr_store(carry_val + 2 * blockIdx.x, val);
+            carry_key[2 * lb] = key;
+            fr_store(carry_val + 2 * lb, val);
         } else fr_store(out + key, val);
     }
 }
@@ -277,34 +202,6 @@ __device__ __forceinline__ fr_t frw_reduce(fr_wide a) {          // a < 2^LOG2G 
     return z;
 }
 
-// G consecutive records per thread: the upload pads every run of equal keys to a multiple of G, so the records of one thread always
-// share their key and are summed (lazily reduced) before the comparatively expensive cross-lane scan. a.n counts groups. G is chosen
-// per list at upload: lists whose runs are long (a convolution's gates per input pixel or per weight) take 32 terms per thread, which
-// leaves ~10 VALU instructions per term around the Montgomery product instead of ~180 with 4.
-template <int G>
-__global__ void __launch_bounds__(ZK_BLOCK) k_gate_reduce(fr_t *out, uint32_t *carry_key, fr_t *carry_val, gate_args a) {
-    const uint64_t idx = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x;
-    const bool live = idx < a.n;
-    uint32_t key = GATE_NOKEY;
-    fr_t val = fr_zero();
-    if (live) {
-        // records of one wave are stored lane-interleaved: the k-th record of lane l sits at slot k * 64 + l of the wave's chunk
-        const gate_rec *rp = a.recs + (idx >> 6) * (64 * G) + (idx & 63);
-        key = rp[0].key;
-        fr_wide acc;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) acc.v[i] = 0;
-#pragma unroll 4
-        for (uint32_t k = 0; k < G; ++k) {
-            const gate_rec rc = rp[k * 64];
-            frw_add(acc, gate_term(rc, a));
-        }
-        constexpr int LOG2G = G == 4 ? 2 : G == 8 ? 3 : G == 16 ? 4 : 5;
-        val = frw_reduce<LOG2G>(acc);
-    }
-    gate_segment_store(key, val, live, idx, a.n, out, carry_key, carry_val, a.post_scale != 0, a.post);
-}
-
 // ---- witness: value of every gate of a generic layer (reference src/neuralNetwork.cpp:918-935, calcNormalLayer) ----
 // Gate lists exactly as the circuit stores them; gates of one output must be adjacent (the generator emits them so; the
 // entry point regroups a list that is not). out[g] = sum of the list's terms; outputs without a gate are not written.
@@ -322,7 +219,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_eval_uni(fr_t *out, uint32_t *carr
         val = fr_load((gt.lu ? val_prev : val0) + gt.u);
         if (gt.sc) val = fr_mul(val, fr_load(two_mul + gt.sc));
     }
-    gate_segment_store(key, val, live, idx, n, out, carry_key, carry_val, false, val);
+    gate_segment_store(key, val, live, idx, n, out, carry_key, carry_val, false, val, blockIdx.x);
 }
 __global__ void __launch_bounds__(ZK_BLOCK) k_eval_bin(fr_t *out, uint32_t *carry_key, fr_t *carry_val, const bin_gate_dev *gates, uint64_t n,
                                                        const fr_t *val0, const fr_t *val_prev, const fr_t *two_mul) {
@@ -337,7 +234,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_eval_bin(fr_t *out, uint32_t *carr
         val = fr_mul(fr_load((gt.l == 0 ? val0 : val_prev) + gt.u), fr_load(((gt.l & 1) ? val_prev : val0) + gt.v));
         if (gt.sc) val = fr_mul(val, fr_load(two_mul + gt.sc));
     }
-    gate_segment_store(key, val, live, idx, n, out, carry_key, carry_val, false, val);
+    gate_segment_store(key, val, live, idx, n, out, carry_key, carry_val, false, val, blockIdx.x);
 }
 // out = (a + b) * scale
 __global__ void k_eval_combine(fr_t *out, const fr_t *a, const fr_t *b, fr_t scale, int scaled, uint64_t n) {
@@ -456,12 +353,11 @@ struct host_slot {
     unsigned long long seq;     // written last
 };
 
-// Hand-over without cache-wide fences (default; ZKCNN_FINISH_LIGHT=0 at context creation restores the fence version below): the per-block partial sums and the
-// host slot are written with scope-qualified atomic stores (write-through past the XCD's L2 / uncached to the host), ordered by
-// waiting for their acknowledgement (s_waitcnt vmcnt(0)) before the ticket / the sequence number; the last block reads the
-// partials with agent-scope loads. A release / acquire fence here would write back or invalidate the whole L2 of the XCD --
-// which holds the table halves this kernel has just written -- once per block.
-__device__ int g_finish_light = 1;
+// Hand-over without cache-wide fences: the per-block partial sums and the host slot are written with scope-qualified atomic stores
+// (write-through past the XCD's L2 / uncached to the host), ordered by waiting for their acknowledgement (s_waitcnt vmcnt(0)) before the
+// ticket / the sequence number; the last block reads the partials with agent-scope loads. A release / acquire fence here would write back
+// or invalidate the whole L2 of the XCD -- which holds the table halves this kernel has just written -- once per block (round 1 measured
+// both: 36-38 -> 44 proofs/s at four streams; the fence version and its switch are gone since round 3).
 __device__ __forceinline__ void fr_store_scoped(fr_t *p, const fr_t &a, bool system) {
     unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
 #pragma unroll
@@ -483,101 +379,50 @@ __device__ __forceinline__ fr_t fr_load_agent(const fr_t *p) {
     return z;
 }
 // Outside the HIP memory model: correct where vector-memory STORES are counted by vmcnt, i.e. the gfx9 family this library is built for
-// (gfx10+ counts them in vscnt, where this wait would order nothing). Any other target must use the fence path (g_finish_light = 0).
+// (gfx10+ counts them in vscnt, where this wait would order nothing).
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
-#error "grid_finish: the light hand-over relies on s_waitcnt vmcnt(0) ordering stores (gfx9 family only)"
+#error "grid_finish: the hand-over relies on s_waitcnt vmcnt(0) ordering stores (gfx9 family only)"
 #endif
 #define ZK_WAIT_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
+// acc[] of thread 0 of every block -> grid total in slot->v[0..K), then slot->seq = seq. nblk / lb: the blocks that take part and this
+// block's index among them (a launch that runs several jobs hands over only one of them: k_gate_multi).
 template <int K>
 __device__ __forceinline__ void grid_finish(fr_t (&acc)[K], fr_t *partials, uint32_t *counter, host_slot *slot,
-                                            unsigned long long seq, fr_t *smem, bool wrote_slot = false) {
+                                            unsigned long long seq, fr_t *smem, bool wrote_slot = false, uint32_t nblk = 0, uint32_t lb = 0) {
     __shared__ int s_last;
-    (void) smem;
-    if (g_finish_light) {
-        if (gridDim.x == 1) {
-            if (threadIdx.x == 0) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) fr_store_scoped(&slot->v[k], acc[k], true);
-                ZK_WAIT_STORES();
-                __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            return;
-        }
+    (void) smem; (void) wrote_slot;
+    if (nblk == 0) { nblk = gridDim.x; lb = blockIdx.x; }
+    if (nblk == 1) {                                     // small tables: this block already holds the grid total
         if (threadIdx.x == 0) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) fr_store_scoped(partials + (size_t) K * blockIdx.x + k, acc[k], false);
-            ZK_WAIT_STORES();
-            const uint32_t t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = (t == gridDim.x - 1);
-        }
-        __syncthreads();
-        if (!s_last) return;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (wave < K) {
-            fr_t tot = fr_zero();
-            for (uint32_t b = lane; b < gridDim.x; b += 64) tot = fr_add(tot, fr_load_agent(partials + (size_t) K * b + wave));
-            tot = fr_wave_sum(tot);
-            if (lane == 0) fr_store_scoped(&slot->v[wave], tot, true);
-            ZK_WAIT_STORES();
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < K; ++k) fr_store_scoped(&slot->v[k], acc[k], true);
             ZK_WAIT_STORES();
             __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
-    if (gridDim.x == 1) {                                // small tables: this block already holds the grid total
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) fr_store(&slot->v[k], acc[k]);
-            __threadfence_system();
-            *((volatile unsigned long long *) &slot->seq) = seq;
-        }
-        return;
-    }
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) fr_store(partials + (size_t) K * blockIdx.x + k, acc[k]);
-        if (wrote_slot) __threadfence_system();          // release (host-visible values were written by this block)
-        else __threadfence();                            // release: partials before the ticket
-        const uint32_t t = atomicAdd(counter, 1u);
-        s_last = (t == gridDim.x - 1);
+        for (int k = 0; k < K; ++k) fr_store_scoped(partials + (size_t) K * lb + k, acc[k], false);
+        ZK_WAIT_STORES();
+        const uint32_t t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == nblk - 1);
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();                                     // acquire: this CU's L1 may hold last round's partials
     // wave k sums accumulator k over all blocks (lane-strided), one 6-step butterfly each
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave < K) {
         fr_t tot = fr_zero();
-        for (uint32_t b = lane; b < gridDim.x; b += 64) tot = fr_add(tot, fr_load(partials + (size_t) K * b + wave));
+        for (uint32_t b = lane; b < nblk; b += 64) tot = fr_add(tot, fr_load_agent(partials + (size_t) K * b + wave));
         tot = fr_wave_sum(tot);
-        if (lane == 0) fr_store(&slot->v[wave], tot);
+        if (lane == 0) fr_store_scoped(&slot->v[wave], tot, true);
+        ZK_WAIT_STORES();
     }
-    __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-        *counter = 0;
-        __threadfence_system();
-        *((volatile unsigned long long *) &slot->seq) = seq;
-    }
-}
-
-// sum of 2 partials per block straight into a mapped host slot (v[0], v[1], then seq): the host reads them when it needs them, no copy, no stream wait
-__global__ void __launch_bounds__(ZK_BLOCK) k_sum_partials_slot(host_slot *slot, const fr_t *partials, uint32_t nblocks, unsigned long long seq) {
-    __shared__ fr_t smem[2 * ZK_BLOCK / 64];
-    fr_t acc[2] = {fr_zero(), fr_zero()};
-    for (uint32_t b = threadIdx.x; b < nblocks; b += ZK_BLOCK) {
-        acc[0] = fr_add(acc[0], fr_load(partials + (size_t) b * 2));
-        acc[1] = fr_add(acc[1], fr_load(partials + (size_t) b * 2 + 1));
-    }
-    fr_block_sum<2>(acc, smem);
-    if (threadIdx.x == 0) {
-        fr_store_scoped(&slot->v[0], acc[0], true);
-        fr_store_scoped(&slot->v[1], acc[1], true);
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ZK_WAIT_STORES();
         __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -619,14 +464,9 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad2(round2_args a) {
                 fr_store(Vout, v);
                 fr_store(Mout, m);
             }
-            if (g_finish_light) {
-                fr_store_scoped(&a.slot->v[4 + 2 * b], v, true);
-                fr_store_scoped(&a.slot->v[5 + 2 * b], m, true);
-                ZK_WAIT_STORES();
-            } else {
-                fr_store(&a.slot->v[4 + 2 * b], v);
-                fr_store(&a.slot->v[5 + 2 * b], m);
-            }
+            fr_store_scoped(&a.slot->v[4 + 2 * b], v, true);
+            fr_store_scoped(&a.slot->v[5 + 2 * b], m, true);
+            ZK_WAIT_STORES();
         }
     } else {
         const uint64_t tid = lb * (uint64_t) ZK_BLOCK + threadIdx.x, stride = (uint64_t) nblk * ZK_BLOCK;
@@ -702,10 +542,8 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad_fine(round2_args a) {
                 v = fr_lerp(v, fr_load(src + 1), a.r);
                 fr_store(role == 0 ? a.Vout[b] : a.Mout[b], v);
             }
-            if (g_finish_light) {
-                fr_store_scoped(&a.slot->v[4 + 2 * b + (role >> 1)], v, true);
-                ZK_WAIT_STORES();
-            } else fr_store(&a.slot->v[4 + 2 * b + (role >> 1)], v);
+            fr_store_scoped(&a.slot->v[4 + 2 * b + (role >> 1)], v, true);
+            ZK_WAIT_STORES();
         }
     } else if (a.first) {
         if (live && role < 3) {
@@ -723,10 +561,8 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad_fine(round2_args a) {
     const bool tail = live && !special && items[b] == 1 && role < 2;
     if (tail) {
         const fr_t tv = a.first ? opA : X;
-        if (g_finish_light) {
-            fr_store_scoped(&a.slot->v[8 + 2 * b + role], tv, true);
-            ZK_WAIT_STORES();
-        } else fr_store(&a.slot->v[8 + 2 * b + role], tv);
+        fr_store_scoped(&a.slot->v[8 + 2 * b + role], tv, true);
+        ZK_WAIT_STORES();
     }
     if (!a.first) {
         fr_t y1, y2, y3;
@@ -779,17 +615,11 @@ __global__ void k_eval_pairs(eval_args a) {
         const fr_t *p = a.p[threadIdx.x];
         fr_t v = fr_load(p);
         if (a.n[threadIdx.x] == 2) v = fr_lerp(v, fr_load(p + 1), a.r);
-        if (g_finish_light) {
-            fr_store_scoped(&a.slot->v[threadIdx.x], v, true);
-            ZK_WAIT_STORES();
-        } else fr_store(&a.slot->v[threadIdx.x], v);
+        fr_store_scoped(&a.slot->v[threadIdx.x], v, true);
+        ZK_WAIT_STORES();
     }
-    if (!g_finish_light) __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) {
-        if (g_finish_light) __hip_atomic_store(&a.slot->seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        else *((volatile unsigned long long *) &a.slot->seq) = a.seq;
-    }
+    if (threadIdx.x == 0) __hip_atomic_store(&a.slot->seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // plain fold (tables shorter than one quad, the periodic table of the cubic rounds, Vres)

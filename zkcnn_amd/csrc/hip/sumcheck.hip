@@ -14,6 +14,7 @@
 #include "fs_tail.cuh"
 #include "witness_kernels.cuh"
 #include "conv_kernels.cuh"
+#include "prep_kernels.cuh"
 
 static std::string g_create_err;
 
@@ -78,7 +79,6 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
     if (zk_dev_alloc(ctx, (void **) &ctx->eq_lo, 2 * (size_t) ctx->eq_stride * 32) ||
         zk_dev_alloc(ctx, (void **) &ctx->eq_hi, 2 * (size_t) ctx->eq_stride * 32) ||
         zk_dev_alloc(ctx, (void **) &ctx->partials, (size_t) ctx->partial_blocks * 4 * 32) ||
-        zk_dev_alloc(ctx, &ctx->d_chain, sizeof(chain_state)) ||
         zk_dev_alloc(ctx, (void **) &ctx->d_result, 32 * 32) ||
         zk_dev_alloc(ctx, (void **) &ctx->d_counter, 64) ||
         hipHostMalloc((void **) &ctx->h_slot, sizeof(*ctx->h_slot), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -96,14 +96,6 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
     std::memset((void *) ctx->h_slot, 0, sizeof(*ctx->h_slot));
     std::memset((void *) ctx->h_aux, 0, sizeof(*ctx->h_aux));
     std::memset(ctx->h_tail, 0, std::max(sizeof(tail_out), sizeof(export_out)));
-    {
-        const int light = getenv("ZKCNN_FINISH_LIGHT") ? atoi(getenv("ZKCNN_FINISH_LIGHT")) : 1;
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_finish_light), &light, sizeof(int)) != hipSuccess) {
-            g_create_err = "finish switch";
-            zk_ctx_destroy(ctx);
-            return ZK_ERR_HIP;
-        }
-    }
     *out = ctx;
     return ZK_OK;
 }
@@ -217,8 +209,6 @@ static uint64_t padded_size(const std::vector<gate_rec> &recs, uint32_t G) {
 }
 // records per thread for a list: the largest of 32 / 16 / 8 / 4 whose padding costs less than 1/8 of the list
 static uint32_t choose_group(const std::vector<gate_rec> &recs) {
-    static const int forced = getenv("ZKCNN_GATE_GROUP") ? atoi(getenv("ZKCNN_GATE_GROUP")) : 0;
-    if (forced == 4 || forced == 8 || forced == 16 || forced == 32) return (uint32_t) forced;
     for (uint32_t G = 32; G > GATE_GROUP; G >>= 1)
         if (padded_size(recs, G) <= recs.size() + recs.size() / 8) return G;
     return GATE_GROUP;
@@ -273,8 +263,7 @@ static int log2_exact(uint32_t x) {          // -1 unless x is a power of two
 }
 // does layer S (with its predecessor P) consist of exactly the gates a direct convolution with these parameters emits?
 static bool conv_hint_matches(const zk_conv_hint &h, const zk_layer_desc &S, const zk_layer_desc &P, conv_desc &c) {
-    static const bool enabled = !(getenv("ZKCNN_CONV_STRUCT") && atoi(getenv("ZKCNN_CONV_STRUCT")) == 0);
-    if (!enabled || S.ty != ZK_NCONV) return false;
+    if (S.ty != ZK_NCONV) return false;
     c.pp = h.pic_parallel; c.CO = h.channel_out; c.CI = h.channel_in; c.nxi = h.nx_in; c.nyi = h.ny_in; c.nxo = h.nx_out; c.nyo = h.ny_out;
     c.m = h.m; c.pad = h.padding; c.ls = h.log_stride; c.wstart = h.weight_start;
     c.bx_i = log2_exact(c.nxi); c.by_i = log2_exact(c.nyi); c.bc_i = log2_exact(c.CI);
@@ -528,7 +517,7 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
                 total += sz;
             }
         }
-        if (total >= 0xffffffffull) { ctx->err = "too many layer-0 references"; return ZK_ERR_ARG; }
+        if (total >= 0xffffffffull || ctx->liu_tab_layer.size() >= (1u << 24)) { ctx->err = "too many layer-0 references"; return ZK_ERR_ARG; }
         for (uint64_t x = 0; x < n0; ++x) cnt[x + 1] += cnt[x];
         std::vector<liu_entry> ent(total);
         {
@@ -538,8 +527,9 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
                 const int side = ctx->liu_tab_side[tb];
                 const uint32_t sz = side ? S.size_v[0] : S.size_u[0];
                 const uint32_t *ori = side ? S.ori_id_v : S.ori_id_u;
+                const int bl = side ? S.bit_length_v[0] : S.bit_length_u[0];
                 for (uint32_t h = 0; h < sz; ++h) {
-                    liu_entry e = {h, (uint32_t) tb};
+                    liu_entry e = {h, (uint32_t) tb | ((uint32_t) (bl >> 1) << 24)};      // table number, and the split of its index into half-table indices
                     ent[pos[ori[h]]++] = e;
                 }
             }
@@ -550,8 +540,8 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
         ctx->liu_ent = d_ent;
         const uint32_t nt = std::max<uint32_t>(ctx->liu_ntabs, 1);
         if ((rc = zk_dev_alloc(ctx, (void **) &ctx->liu_halves, (size_t) nt * 2 * LIU_HALF_STRIDE * 32))) return rc;
-        if ((rc = zk_dev_alloc(ctx, &ctx->liu_tabs, (size_t) nt * sizeof(liu_table)))) return rc;
-        ZK_HIP(hipHostMalloc(&ctx->h_liu_tabs, (size_t) nt * sizeof(liu_table)));
+        ZK_HIP(hipHostMalloc(&ctx->h_liu_tabs, (size_t) nt * sizeof(liu_table), hipHostMallocMapped));
+        ZK_HIP(hipHostGetDevicePointer(&ctx->liu_tabs, ctx->h_liu_tabs, 0));        // the kernels read the descriptors in place
     }
     {
         uint64_t max_wa = 0, max_part = 0, max_ae = 0;
@@ -565,11 +555,11 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
         }
         if (ctx->conv_layers) {
             if ((rc = zk_dev_alloc(ctx, (void **) &ctx->conv_small, (size_t) CT_COUNT * CONV_TAB_STRIDE * 32)) ||
-                (rc = zk_dev_alloc(ctx, &ctx->conv_tabs, 2 * CT_COUNT * sizeof(liu_table))) ||
                 (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_wa, max_wa * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_part, max_part * 32)) ||
                 (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_e, 2 * 16 * 16 * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_ae, max_ae * 32)))
                 return rc;
-            ZK_HIP(hipHostMalloc(&ctx->h_conv_tabs, 2 * CT_COUNT * sizeof(liu_table)));
+            ZK_HIP(hipHostMalloc(&ctx->h_conv_tabs, 2 * CT_COUNT * sizeof(liu_table), hipHostMallocMapped));
+            ZK_HIP(hipHostGetDevicePointer(&ctx->conv_tabs, ctx->h_conv_tabs, 0));
         }
     }
     if (getenv("ZKCNN_DUMP_TABLES"))
@@ -592,7 +582,7 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
     ctx->beta_gs_cap = max_gs;
     if ((rc = zk_dev_alloc(ctx, (void **) &ctx->beta_gs, max_gs * 32))) return rc;
     for (int k = 0; k < 2; ++k) if ((rc = zk_dev_alloc(ctx, (void **) &ctx->small[k], max_gs * 32))) return rc;
-    ctx->carry_slots = 2 * ((max_list + ZK_BLOCK - 1) / ZK_BLOCK) + 2;
+    ctx->carry_slots = 4 * ((max_list + ZK_BLOCK - 1) / ZK_BLOCK) + 4;          // two lists per launch (k_gate_multi), two slots per block
     if ((rc = zk_dev_alloc(ctx, (void **) &ctx->carry_key, ctx->carry_slots * 4))) return rc;
     if ((rc = zk_dev_alloc(ctx, (void **) &ctx->carry_val, ctx->carry_slots * 32))) return rc;
     if ((rc = zk_scratch(ctx, (size_t) 1 << 24))) return rc;
@@ -629,33 +619,75 @@ extern "C" int32_t zk_poke_layer_value(zk_ctx *ctx, int32_t layer, uint64_t inde
 // ------------------------------------------------------------------------------------------------
 // building blocks
 // ------------------------------------------------------------------------------------------------
-// out[i] = a * eq(r0, i) + b * eq(r1, i), i < 2^n; entries >= tail_start additionally scaled
-// `limit`: only entries [0, limit) are needed (a layer whose size is not a power of two: nothing refers to the rest)
+// ---- one launch for all table builders of a phase (prep_kernels.cuh) ----
+struct prep_plan {
+    prep_args A;
+    uint32_t blocks = 0;
+    int npts = 0;
+    bool overflow = false;
+    prep_plan() { std::memset(&A, 0, sizeof(A)); }
+    bool empty() const { return blocks == 0; }
+    int point(const HFr *r, int n) {
+        if (npts >= 2) { overflow = true; return 0; }
+        for (int i = 0; i < n; ++i) A.r[npts].v[i] = to_dev(r[i]);
+        return npts++;
+    }
+    void zero(fr_t *p, uint64_t n) {
+        if (!n) return;
+        if (A.n_z >= PREP_MAX_ZERO) { overflow = true; return; }
+        prep_zero_job &J = A.z[A.n_z++];
+        J.p = p; J.n = n; J.blk0 = blocks; J.nblk = grid_for(n, 1024);
+        blocks += J.nblk;
+    }
+    // dst[i] = i < n_valid ? src[idx ? idx[i] : i] : 0, i < n_total
+    void gather(fr_t *dst, const fr_t *src, const uint32_t *idx, uint64_t n_valid, uint64_t n_total) {
+        if (!n_total) return;
+        if (A.n_g >= PREP_MAX_GATHER) { overflow = true; return; }
+        prep_gather_job &J = A.g[A.n_g++];
+        J.dst = dst; J.src = src; J.idx = idx; J.n_valid = n_valid; J.n_total = n_total; J.blk0 = blocks; J.nblk = grid_for(n_total, 1024);
+        blocks += J.nblk;
+    }
+    // out[i] = a * eq(r0, i) + b * eq(r1, i), i < min(2^n, limit); entries >= tail_start additionally scaled (the relu_rou factor on the
+    // constraint rows, reference src/prover.cpp:221-222). `limit`: a layer whose size is not a power of two -- nothing refers to the rest
+    void eq(fr_t *out, int n, const HFr *r0, const HFr &a, const HFr *r1, const HFr &b, uint64_t tail_start, const HFr &tail_scale, uint64_t limit = ~0ull) {
+        if (n < 0) return;
+        if (n > ZK_MAX_VARS) { overflow = true; return; }
+        const uint64_t len = std::min<uint64_t>(1ull << n, std::max<uint64_t>(limit, 1));
+        const bool has_a = !a.isZero() && r0, has_b = !b.isZero() && r1;
+        if (!has_a && !has_b) { zero(out, len); return; }
+        if (A.n_eq >= PREP_MAX_EQ) { overflow = true; return; }
+        prep_eq_job &J = A.eq[A.n_eq++];
+        J.out = out; J.n = n; J.limit = len; J.tail_start = tail_start; J.tail_scale = to_dev(tail_scale);
+        J.npoints = 0;
+        if (has_b) { J.pt[J.npoints] = point(r1, n); J.init[J.npoints++] = to_dev(b); }
+        if (has_a) { J.pt[J.npoints] = point(r0, n); J.init[J.npoints++] = to_dev(a); }
+        // entries per block: small tables are latency bound (one entry per thread, short quarter tables), large ones amortise the block's prelude
+        J.c = std::min(n, n <= 16 ? 8 : n <= 20 ? 10 : 12);
+        J.blk0 = blocks;
+        J.nblk = (uint32_t) ((len + (1ull << J.c) - 1) >> J.c);
+        blocks += J.nblk;
+    }
+    void eq1(fr_t *out, int n, const HFr *r, const HFr &init, uint64_t limit = ~0ull) { eq(out, n, r, init, nullptr, HFr(0LL), ~0ull, HFr::one(), limit); }
+    void small_tables(fr_t *full, const liu_table *tabs, uint32_t count) {
+        A.sm.full = full; A.sm.tabs = tabs; A.sm.blk0 = blocks; A.sm.nblk = count;
+        blocks += count;
+    }
+    int32_t launch(zk_ctx *ctx) {
+        if (overflow) { ctx->err = "phase preparation: too many jobs for one launch"; return ZK_ERR_STATE; }
+        if (!blocks) return ZK_OK;
+        ZK_LAUNCH(PC_EQ, 0.0, k_prep, dim3(blocks), dim3(ZK_BLOCK), A);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+};
+
 static int32_t eq_table(zk_ctx *ctx, fr_t *out, int n, const HFr *r0, const HFr &a, const HFr *r1, const HFr &b,
                         uint64_t tail_start, const HFr &tail_scale, uint64_t limit = ~0ull) {
     if (n < 0) return ZK_OK;
     if (n > ZK_MAX_VARS) { ctx->err = "eq table too large"; return ZK_ERR_ARG; }
-    const uint64_t len = std::min<uint64_t>(1ull << n, std::max<uint64_t>(limit, 1));
-    eq_args A;
-    A.npoints = 0;
-    A.fh = n >> 1;
-    A.sh = n - A.fh;
-    if (!b.isZero()) {
-        for (int i = 0; i < n; ++i) A.r[A.npoints].v[i] = to_dev(r1[i]);
-        A.init[A.npoints++] = to_dev(b);
-    }
-    if (!a.isZero()) {
-        for (int i = 0; i < n; ++i) A.r[A.npoints].v[i] = to_dev(r0[i]);
-        A.init[A.npoints++] = to_dev(a);
-    }
-    if (A.npoints == 0) {
-        ZK_HIP(hipMemsetAsync(out, 0, len * 32, ctx->stream));
-        return ZK_OK;
-    }
-    ZK_LAUNCH(PC_EQ, 0.0, k_eq_halves, dim3(2 * A.npoints), dim3(1024), ctx->eq_lo, ctx->eq_hi, ctx->eq_stride, ctx->eq_stride, A);
-    ZK_LAUNCH(PC_EQ, 0.0, k_eq_expand, dim3(grid_for(len)), dim3(ZK_BLOCK), out, ctx->eq_lo, ctx->eq_hi, ctx->eq_stride, ctx->eq_stride, A.npoints, A.fh, len, tail_start, to_dev(tail_scale));
-    ZK_HIP(hipGetLastError());
-    return ZK_OK;
+    prep_plan P;
+    P.eq(out, n, r0, a, r1, b, tail_start, tail_scale, limit);
+    return P.launch(ctx);
 }
 static int32_t eq_table1(zk_ctx *ctx, fr_t *out, int n, const HFr *r, const HFr &init, uint64_t limit = ~0ull) {
     return eq_table(ctx, out, n, r, init, nullptr, HFr(0LL), ~0ull, HFr::one(), limit);
@@ -710,66 +742,83 @@ static int32_t wait_slot(zk_ctx *ctx, unsigned long long seq) {
     return ZK_OK;
 }
 
-// n = records in the padded list (a multiple of GATE_GROUP), n_real = gates among them
-static int32_t gate_scatter(zk_ctx *ctx, fr_t *out, const gate_rec *recs, uint64_t n, uint64_t n_real, int phase, const dev_layer &cur,
-                            const dev_layer &prev, uint64_t n_uni_in_list, uint64_t out_len, uint32_t G, int uniform_u = -1) {
-    if (!n) return ZK_OK;
-    const double gate_bytes = 44.0 * (double) n_uni_in_list + 80.0 * (double) (n_real - n_uni_in_list) + 32.0 * (double) out_len;
-    gate_args A;
-    A.recs = recs;
-    A.n = n / G;
-    A.beta_g = ctx->beta_g[ctx->beta_g_cur];
-    A.beta_u = ctx->beta_u;
-    A.val0 = ctx->L[0].val;
-    A.val_prev = prev.val;
-    A.two_mul = ctx->two_mul;
-    A.Vu0 = to_dev(ctx->V_u0);
-    A.Vu1 = to_dev(ctx->V_u1);
-    A.phase = phase;
-    A.post_scale = (phase == 2 && uniform_u >= 0) ? 1 : 0;
-    A.post = uniform_u == 1 ? A.Vu1 : A.Vu0;
-    (void) cur;
-    const uint32_t blocks = (uint32_t) ((A.n + ZK_BLOCK - 1) / ZK_BLOCK);
-    if (2ull * blocks > ctx->carry_slots) { ctx->err = "carry buffer too small"; return ZK_ERR_STATE; }
-    switch (G) {
-        case 32: ZK_LAUNCH(PC_GATE, gate_bytes, k_gate_reduce<32>, dim3(blocks), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, A); break;
-        case 16: ZK_LAUNCH(PC_GATE, gate_bytes, k_gate_reduce<16>, dim3(blocks), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, A); break;
-        case 8: ZK_LAUNCH(PC_GATE, gate_bytes, k_gate_reduce<8>, dim3(blocks), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, A); break;
-        default: ZK_LAUNCH(PC_GATE, gate_bytes, k_gate_reduce<4>, dim3(blocks), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, A); break;
+// ---- both gate scatters of a phase (and the phase-2 constant term) in one launch; a fix-up launch only if a list spans blocks ----
+struct gate_job {
+    fr_t *out;
+    const gate_rec *recs;
+    uint64_t n, n_real, n_uni;      // records in the padded list (a multiple of G), gates among them, uni gates among those
+    uint32_t G;
+    int uniform_u;                   // phase 2: every gate's u operand in layer 0 (0) / the previous layer (1), else -1
+    uint64_t out_len;
+};
+// algorithmic bytes of one scatter: per uni gate 12 B record + 32 B gather, per bin gate 16 B record + 2 x 32 B gathers,
+// + 32 B per output entry
+static int32_t gate_multi(zk_ctx *ctx, int phase, const dev_layer &prev, const gate_job *jobs, int njobs, const dev_layer *sum_layer) {
+    gate_multi_args A;
+    std::memset(&A, 0, sizeof(A));
+    double gate_bytes = 0;
+    uint32_t blocks = 0, carry = 0;
+    bool need_fix = false;
+    for (int k = 0; k < njobs; ++k) {
+        const gate_job &j = jobs[k];
+        if (!j.n) continue;
+        gate_list &L = A.L[A.nlists++];
+        L.recs = j.recs; L.n = j.n / j.G; L.out = j.out; L.G = j.G;
+        L.blk0 = blocks; L.nblk = (uint32_t) ((L.n + ZK_BLOCK - 1) / ZK_BLOCK);
+        L.carry0 = carry;
+        L.direct = L.nblk == 1 ? 1 : 0;
+        L.post_scale = (phase == 2 && j.uniform_u >= 0) ? 1 : 0;
+        L.post = to_dev(j.uniform_u == 1 ? ctx->V_u1 : ctx->V_u0);
+        blocks += L.nblk;
+        if (!L.direct) { carry += 2 * L.nblk; need_fix = true; }
+        gate_bytes += 44.0 * (double) j.n_uni + 80.0 * (double) (j.n_real - j.n_uni) + 32.0 * (double) j.out_len;
     }
-    ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup, dim3(grid_for(2ull * blocks)), dim3(ZK_BLOCK), out, ctx->carry_key, ctx->carry_val, 2ull * blocks);
+    if (carry > ctx->carry_slots) { ctx->err = "carry buffer too small"; return ZK_ERR_STATE; }
+    if (sum_layer && sum_layer->n_uni2) {
+        // the two sums go to a mapped host slot; add_term = V_u0 s0 + V_u1 s1 is formed when the first round needs it (resolve_add_term)
+        A.uni2 = sum_layer->uni2; A.n_uni2 = sum_layer->n_uni2;
+        A.sum_blk0 = blocks; A.sum_nblk = std::min<uint32_t>(grid_for(A.n_uni2, 1024), ctx->partial_blocks);
+        blocks += A.sum_nblk;
+        A.partials = ctx->partials; A.counter = ctx->d_counter + 1;
+        A.aux = (host_slot *) ctx->d_aux; A.aux_seq = ++ctx->aux_seq;
+        ctx->add_pending = true;
+    }
+    if (!blocks) return ZK_OK;
+    A.phase = phase;
+    A.beta_g = ctx->beta_g[ctx->beta_g_cur]; A.beta_u = ctx->beta_u;
+    A.val0 = ctx->L[0].val; A.val_prev = prev.val; A.two_mul = ctx->two_mul;
+    A.Vu0 = to_dev(ctx->V_u0); A.Vu1 = to_dev(ctx->V_u1);
+    A.carry_key = ctx->carry_key; A.carry_val = ctx->carry_val;
+    ZK_LAUNCH(PC_GATE, gate_bytes, k_gate_multi, dim3(blocks), dim3(ZK_BLOCK), A);
+    if (need_fix) {
+        const uint64_t n0 = (A.nlists > 0 && !A.L[0].direct) ? 2ull * A.L[0].nblk : 0, n1 = (A.nlists > 1 && !A.L[1].direct) ? 2ull * A.L[1].nblk : 0;
+        // (carry slots are handed out in list order: a direct list takes none)
+        fr_t *o0 = n0 ? A.L[0].out : (n1 ? A.L[1].out : nullptr), *o1 = n0 && n1 ? A.L[1].out : nullptr;
+        ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup2, dim3(grid_for(n0 + n1)), dim3(ZK_BLOCK), o0, o1, ctx->carry_key, ctx->carry_val, n0 ? n0 : n1, n0 ? n1 : 0);
+    }
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
 
-// the large-table round kernel stops at the live prefix of its tables (ZKCNN_LIVE_PREFIX=0: A/B switch, everything is read and written)
-static bool live_prefix_on() {
-    static const bool on = !(getenv("ZKCNN_LIVE_PREFIX") && atoi(getenv("ZKCNN_LIVE_PREFIX")) == 0);
-    return on;
+// a table of more than 2^16 entries is first read by the round kernel that stops at the live prefix (rounded up to whole quads): its builders
+// stop there too (one guard quad behind it); smaller tables are read whole
+static inline uint64_t table_end(uint64_t len, uint64_t live) {
+    return len <= (1ull << 16) ? len : std::min<uint64_t>(len, ((live + 3) & ~3ull) + 4);
 }
 
 // V-table of one side: layer-0 subset through ori ids, or the previous layer as it is
 static inline const fr_t *vin(const table_pair &t) { return t.Vsrc ? t.Vsrc : t.V[t.cur]; }
 
-static int32_t load_v_table(zk_ctx *ctx, table_pair &t, int b, int bl, uint32_t size, const uint32_t *ori, const dev_layer &prev) {
-    if (bl < 0) return ZK_OK;
+static void load_v_table(zk_ctx *ctx, prep_plan &P, table_pair &t, int b, int bl, uint32_t size, const uint32_t *ori, const dev_layer &prev) {
+    if (bl < 0) return;
     const uint64_t len = 1ull << bl;
     fr_t *dst = t.V[0];
     if (b == 1 && prev.val_len >= len) {            // the previous layer as it is: read in place until the first fold
         t.Vsrc = prev.val;
-        return ZK_OK;
+        return;
     }
-    if (b == 0) {
-        // a large table is first read by the round kernel that stops at the live prefix (rounded up to whole quads): no zeros needed behind it
-        const uint64_t fill = (len <= (1ull << 16) || !live_prefix_on()) ? len : std::min<uint64_t>(len, (((uint64_t) size + 3) & ~3ull) + 4);
-        ZK_LAUNCH(PC_GATHER, 0.0, k_gather, dim3(grid_for(fill)), dim3(ZK_BLOCK), dst, ctx->L[0].val, ori, (uint64_t) size, fill);
-        ZK_HIP(hipGetLastError());
-    } else {
-        const uint64_t have = std::min<uint64_t>(len, prev.val_len);
-        ZK_HIP(hipMemcpyAsync(dst, prev.val, have * 32, hipMemcpyDeviceToDevice, ctx->stream));
-        if (have < len) ZK_HIP(hipMemsetAsync(dst + have, 0, (len - have) * 32, ctx->stream));
-    }
-    return ZK_OK;
+    if (b == 0) P.gather(dst, ctx->L[0].val, ori, (uint64_t) size, table_end(len, size));
+    else P.gather(dst, prev.val, nullptr, std::min<uint64_t>(len, prev.val_len), len);       // (a table longer than the layer: zero extended)
 }
 
 static void reset_pairs(zk_ctx *ctx, int bl0, int bl1) {
@@ -914,15 +963,9 @@ static void conv_tab(liu_table &T, const HFr *r, int from, int n, const HFr &ini
     for (int j = 0; j < n; ++j) T.r.v[j] = to_dev(r[from + j]);
     T.init = to_dev(init);
 }
-static int32_t conv_small_tables(zk_ctx *ctx, int set) {
-    liu_table *h = (liu_table *) ctx->h_conv_tabs + set * CT_COUNT;
-    liu_table *d = (liu_table *) ctx->conv_tabs + set * CT_COUNT;
-    ZK_HIP(hipMemcpyAsync(d, h, CT_COUNT * sizeof(liu_table), hipMemcpyHostToDevice, ctx->stream));
-    ZK_LAUNCH(PC_EQ, 0.0, k_eq_small_multi, dim3(CT_COUNT), dim3(1024), ctx->conv_small, (const liu_table *) d);
-    return ZK_OK;
-}
-// phase 1: M over the previous layer's table. false in *done if the layer's claims are both zero (the generic path then writes zeros)
-static int32_t conv_phase1(zk_ctx *ctx, const dev_layer &cur, fr_t *M, uint64_t len, const HFr &a0, const HFr &a1, bool *done) {
+// phase 1, descriptors: the small eq tables S, A, P of the layer's one or two claim points (built by the phase's k_prep launch).
+// Returns K = number of points with a non-zero weight (0: every sum is zero, the caller zero-fills M)
+static int conv_phase1_tables(zk_ctx *ctx, const dev_layer &cur, const HFr &a0, const HFr &a1) {
     const conv_desc &c = cur.conv;
     liu_table *T = (liu_table *) ctx->h_conv_tabs;
     for (int t = 0; t < CT_COUNT; ++t) T[t].n = -1;
@@ -937,11 +980,12 @@ static int32_t conv_phase1(zk_ctx *ctx, const dev_layer &cur, fr_t *M, uint64_t 
         conv_tab(T[K ? CT_P1 : CT_P0], pts[k], bpos + c.bc_o, bl - bpos - c.bc_o, inits[k]);
         ++K;
     }
-    ctx->conv_K = K;
-    *done = K > 0;
-    if (!K) return ZK_OK;
-    int32_t rc;
-    if ((rc = conv_small_tables(ctx, 0))) return rc;
+    return K;
+}
+// phase 1, sums: M over the previous layer's table
+static int32_t conv_phase1(zk_ctx *ctx, const dev_layer &cur, fr_t *M, uint64_t len) {
+    const conv_desc &c = cur.conv;
+    const int K = ctx->conv_K;
     const uint32_t wlen = c.CI * c.m * c.m, per = 8, chunks = (c.CO + per - 1) / per;
     fr_t *part = chunks == 1 ? ctx->conv_wa : ctx->conv_part;
     ZK_LAUNCH(PC_GATE, 0.0, k_conv_wa, dim3((wlen + ZK_BLOCK - 1) / ZK_BLOCK, chunks), dim3(ZK_BLOCK), part, (const fr_t *) ctx->L[0].val + c.wstart,
@@ -952,18 +996,20 @@ static int32_t conv_phase1(zk_ctx *ctx, const dev_layer &cur, fr_t *M, uint64_t 
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
-// phase 2: M over the layer-0 subset table of the weights (needs the phase-1 tables of the same layer: S, A, P stay in conv_small)
-static int32_t conv_phase2(zk_ctx *ctx, const dev_layer &cur, fr_t *M, uint64_t len, const HFr *ru) {
+// phase 2, descriptors (second set: D, C, Pu over the phase-1 point; S, A, P of the same layer stay in conv_small)
+static void conv_phase2_tables(zk_ctx *ctx, const dev_layer &cur, const HFr *ru) {
     const conv_desc &c = cur.conv;
-    const int K = ctx->conv_K;
     liu_table *T = (liu_table *) ctx->h_conv_tabs + CT_COUNT;
     for (int t = 0; t < CT_COUNT; ++t) T[t].n = -1;
     const int bpos = c.bx_i + c.by_i;
     conv_tab(T[CT_D], ru, 0, bpos, HFr::one());
     conv_tab(T[CT_C], ru, bpos, c.bc_i, HFr::one());
     conv_tab(T[CT_PU], ru, bpos + c.bc_i, cur.d.max_bl_u - bpos - c.bc_i, HFr::one());
-    int32_t rc;
-    if ((rc = conv_small_tables(ctx, 1))) return rc;
+}
+// phase 2, sums: M over the layer-0 subset table of the weights
+static int32_t conv_phase2(zk_ctx *ctx, const dev_layer &cur, fr_t *M, uint64_t len) {
+    const conv_desc &c = cur.conv;
+    const int K = ctx->conv_K;
     const uint32_t mm = c.m * c.m;
     ZK_LAUNCH(PC_GATE, 0.0, k_conv_e, dim3(mm, K), dim3(ZK_BLOCK), ctx->conv_e, (const fr_t *) ctx->conv_small, c);
     ZK_LAUNCH(PC_GATE, 0.0, k_conv_ae, dim3((c.CO * mm + c.CI + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), ctx->conv_ae, (const fr_t *) ctx->conv_e,
@@ -990,7 +1036,9 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
     ctx->add_term.clear();
     ctx->add_pending = false;
     ctx->round = 0;
+    ctx->conv_K = 0;
     const HFr scale = H(d.scale);
+    prep_plan P;
 
     if (d.ty == ZK_FFT || d.ty == ZK_IFFT) {
         const bool fwd = d.ty == ZK_FFT;
@@ -998,9 +1046,9 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
         const int cnt_bl = fwd ? d.bit_length - fft_bl : d.bit_length - fft_blh;
         const uint32_t cnt_len = d.size >> (fwd ? fft_bl : fft_blh);
         fr_t *bg = ctx->beta_g[ctx->beta_g_cur];
-        if (fwd) rc = eq_table(ctx, bg, cnt_bl, ctx->r_0 + fft_bl, ctx->alpha, ctx->r_1, ctx->beta, ~0ull, HFr::one());
-        else rc = eq_table1(ctx, bg, cnt_bl, ctx->r_0 + fft_blh, ctx->alpha);
-        if (rc) return rc;
+        if (fwd) P.eq(bg, cnt_bl, ctx->r_0 + fft_bl, ctx->alpha, ctx->r_1, ctx->beta, ~0ull, HFr::one());
+        else P.eq1(bg, cnt_bl, ctx->r_0 + fft_blh, ctx->alpha);
+        if ((rc = P.launch(ctx))) return rc;
         table_pair &t = ctx->tp[1];
         const uint32_t len = (uint32_t) t.len;
         if ((rc = strided_matvec(ctx, t.V[0], prev.val, bg, len, 1u << d.max_bl_u, cnt_len))) return rc;
@@ -1008,51 +1056,56 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
         return ZK_OK;
     }
 
-    for (int b = 0; b < 2; ++b)
-        if ((rc = load_v_table(ctx, ctx->tp[b], b, d.bit_length_u[b], d.size_u[b], cur.ori_u, prev))) return rc;
+    // where both tables of a pair end: M has no gate behind p1_live (the factored convolution: behind the tensor it reads); V is the layer-0
+    // subset (size_u[0] entries) or the previous layer (non-zero up to val_live: a RELU / pooling layer's constraint rows are zero for a valid witness)
+    const uint64_t live[2] = {std::min<uint64_t>(ctx->tp[0].len, d.size_u[0]),
+                              std::min<uint64_t>(ctx->tp[1].len, std::max<uint64_t>(cur.p1_live[1], prev.val_live))};
+    for (int b = 0; b < 2; ++b) load_v_table(ctx, P, ctx->tp[b], b, d.bit_length_u[b], d.size_u[b], cur.ori_u, prev);
 
-    if (d.ty == ZK_PADDING) {
+    const bool padding = d.ty == ZK_PADDING;
+    if (padding) {
         // beta_g[g] = beta_g_fft[g >> (n-1)] * eq(r_0[0..n-1), g & mask): the table left by the FFT layer above
         // is expanded (reference src/prover.cpp:214-219; hidden cross-layer state)
-        const int fft_blh = d.fft_bit_length - 1;
-        if ((rc = eq_table1(ctx, ctx->beta_gs, fft_blh, ctx->r_0, HFr::one()))) return rc;
-        fr_t *src = ctx->beta_g[ctx->beta_g_cur], *dst = ctx->beta_g[ctx->beta_g_cur ^ 1];
-        ZK_LAUNCH(PC_EQ, 0.0, k_outer_expand, dim3(grid_for(cur.val_len)), dim3(ZK_BLOCK), dst, src, ctx->beta_gs, fft_blh, cur.val_len);
-        ZK_HIP(hipGetLastError());
-        ctx->beta_g_cur ^= 1;
         if (d.zero_start_id < d.size) { ctx->err = "PADDING layer with constraint rows is not supported"; return ZK_ERR_ARG; }
+        P.eq1(ctx->beta_gs, d.fft_bit_length - 1, ctx->r_0, HFr::one());
     } else {
         const bool tail = d.zero_start_id < d.size;
         // (gates only refer to outputs below the layer's size; the FFT-convolution layer types hand their table on to the next layer: whole table)
         const bool plain = d.ty == ZK_RELU || d.ty == ZK_MAX_POOL || d.ty == ZK_AVG_POOL || d.ty == ZK_NCONV || d.ty == ZK_FCONN;
-        rc = eq_table(ctx, ctx->beta_g[ctx->beta_g_cur], d.bit_length, ctx->r_0, ctx->alpha * scale, ctx->r_1, ctx->beta * scale,
-                      tail ? d.zero_start_id : ~0ull, tail ? ctx->relu_rou : HFr::one(), plain ? (uint64_t) d.size : ~0ull);
-        if (rc) return rc;
+        P.eq(ctx->beta_g[ctx->beta_g_cur], d.bit_length, ctx->r_0, ctx->alpha * scale, ctx->r_1, ctx->beta * scale,
+             tail ? d.zero_start_id : ~0ull, tail ? ctx->relu_rou : HFr::one(), plain ? (uint64_t) d.size : ~0ull);
     }
+    gate_job jobs[2];
+    int njobs = 0;
+    uint64_t conv_end = 0;
     for (int b = 0; b < 2; ++b) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
-        ctx->conv_K = 0;
+        const uint64_t end = table_end(t.len, live[b]);
         if (b == 1 && cur.conv_ok) {
-            bool done = false;
-            const uint64_t lv1 = std::max<uint64_t>(cur.p1_live[1], prev.val_live);
-            const uint64_t end1 = (t.len <= (1ull << 16) || !live_prefix_on()) ? t.len : std::min<uint64_t>(t.len, ((lv1 + 3) & ~3ull) + 4);
-            if ((rc = conv_phase1(ctx, cur, t.M[0], end1, ctx->alpha * scale, ctx->beta * scale, &done))) return rc;
-            if (!done) ZK_HIP(hipMemsetAsync(t.M[0], 0, end1 * 32, ctx->stream));       // both claims weighted with zero: every sum is zero
+            ctx->conv_K = conv_phase1_tables(ctx, cur, ctx->alpha * scale, ctx->beta * scale);
+            conv_end = end;
+            if (ctx->conv_K) P.small_tables(ctx->conv_small, (const liu_table *) ctx->conv_tabs, CT_COUNT);
+            else P.zero(t.M[0], end);             // both claims weighted with zero: every sum is zero
             continue;
         }
-        {
-            // zeros behind the gates' keys: a large table is only ever read up to its live prefix (rounded up to whole quads)
-            const uint64_t lv = b ? std::max<uint64_t>(cur.p1_live[1], prev.val_live) : d.size_u[0];
-            const uint64_t end = (t.len <= (1ull << 16) || !live_prefix_on()) ? t.len : std::min<uint64_t>(t.len, ((lv + 3) & ~3ull) + 4);
-            if (cur.p1_cov[b] < end) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p1_cov[b], 0, (end - cur.p1_cov[b]) * 32, ctx->stream));
-        }
-        if ((rc = gate_scatter(ctx, t.M[0], cur.p1[b], cur.n_p1[b], cur.n_p1_real[b], 1, cur, prev, cur.n_p1_uni[b], t.len, cur.p1_G[b]))) return rc;
+        // zeros where no gate stores: behind the covered prefix of keys, up to where the first reader stops
+        if (cur.p1_cov[b] < end) P.zero(t.M[0] + cur.p1_cov[b], end - cur.p1_cov[b]);
+        gate_job j = {t.M[0], cur.p1[b], cur.n_p1[b], cur.n_p1_real[b], cur.n_p1_uni[b], cur.p1_G[b], -1, t.len};
+        jobs[njobs++] = j;
     }
-    // where both tables of a pair end: M has no gate behind p1_live (the factored convolution: behind the tensor it reads); V is the layer-0
-    // subset (size_u[0] entries) or the previous layer (non-zero up to val_live: a RELU / pooling layer's constraint rows are zero for a valid witness)
-    ctx->tp[0].live = std::min<uint64_t>(ctx->tp[0].len, d.size_u[0]);
-    ctx->tp[1].live = std::min<uint64_t>(ctx->tp[1].len, std::max<uint64_t>(cur.p1_live[1], prev.val_live));
+    if ((rc = P.launch(ctx))) return rc;
+    if (padding) {
+        const int fft_blh = d.fft_bit_length - 1;
+        fr_t *src = ctx->beta_g[ctx->beta_g_cur], *dst = ctx->beta_g[ctx->beta_g_cur ^ 1];
+        ZK_LAUNCH(PC_EQ, 0.0, k_outer_expand, dim3(grid_for(cur.val_len)), dim3(ZK_BLOCK), dst, src, ctx->beta_gs, fft_blh, cur.val_len);
+        ZK_HIP(hipGetLastError());
+        ctx->beta_g_cur ^= 1;
+    }
+    if (ctx->conv_K && (rc = conv_phase1(ctx, cur, ctx->tp[1].M[0], conv_end))) return rc;
+    if ((rc = gate_multi(ctx, 1, prev, jobs, njobs, nullptr))) return rc;
+    ctx->tp[0].live = live[0];
+    ctx->tp[1].live = live[1];
     return ZK_OK;
 }
 
@@ -1075,9 +1128,13 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
     ctx->small_len = 1u << fft_bl;
     ctx->small_cur = 0;
     const uint64_t N = ctx->tp[1].len;
-    if ((rc = eq_table1(ctx, ctx->small[0], fft_bl, ctx->r_0, HFr::one()))) return rc;
-    if ((rc = load_v_table(ctx, ctx->tp[1], 1, d.bit_length_u[1], d.size_u[1], nullptr, prev))) return rc;
-    ZK_HIP(hipMemsetAsync(ctx->tp[0].V[0], 0, N * 32, ctx->stream));
+    prep_plan P;
+    P.eq1(ctx->small[0], fft_bl, ctx->r_0, HFr::one());
+    load_v_table(ctx, P, ctx->tp[1], 1, d.bit_length_u[1], d.size_u[1], nullptr, prev);
+    // (k_dot_v0 writes the rows that have gates; the rest of V0 is zero)
+    const uint64_t covered = (uint64_t) cur.d1_rows << fft_bl;
+    if (covered < N) P.zero(ctx->tp[0].V[0] + covered, N - covered);
+    if ((rc = P.launch(ctx))) return rc;
     if (cur.d1_rows) {
         dim3 grid(((1u << fft_bl) + ZK_BLOCK - 1) / ZK_BLOCK, cur.d1_rows);
         ZK_LAUNCH(PC_DOT, 0.0, k_dot_v0, grid, dim3(ZK_BLOCK), ctx->tp[0].V[0], prev.val, ctx->beta_g[ctx->beta_g_cur], cur.d1, cur.d1_rowptr, fft_bl);
@@ -1167,54 +1224,53 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
     ctx->add_pending = false;
     ctx->round = 0;
     const HFr *ru = ctx->r_u[id].data();
+    prep_plan P;
 
     if (d.ty == ZK_DOT_PROD) {
         const int fft_bl = d.fft_bit_length, cnt_bl = d.max_bl_v;
-        if ((rc = eq_table1(ctx, ctx->beta_u, cnt_bl, ru + fft_bl, HFr::one()))) return rc;
-        if ((rc = eq_table1(ctx, ctx->beta_gs, fft_bl, ru, HFr::one()))) return rc;
         table_pair &t = ctx->tp[1];
-        ZK_HIP(hipMemsetAsync(t.V[0], 0, t.len * 32, ctx->stream));
         const uint32_t rows = d.size_v[1];
+        P.eq1(ctx->beta_u, cnt_bl, ru + fft_bl, HFr::one());
+        P.eq1(ctx->beta_gs, fft_bl, ru, HFr::one());
+        if (rows < t.len) P.zero(t.V[0] + rows, t.len - rows);              // (k_row_dot writes one entry per row)
+        if (cur.p2_cov[1] < t.len) P.zero(t.M[0] + cur.p2_cov[1], t.len - cur.p2_cov[1]);
+        if ((rc = P.launch(ctx))) return rc;
         ZK_LAUNCH(PC_DOT, 0.0, k_row_dot, dim3((rows + 3) / 4), dim3(ZK_BLOCK), t.V[0], prev.val, ctx->beta_gs, rows, fft_bl);
         ZK_HIP(hipGetLastError());
-        if (cur.p2_cov[1] < t.len) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p2_cov[1], 0, (t.len - cur.p2_cov[1]) * 32, ctx->stream));
-        return gate_scatter(ctx, t.M[0], cur.p2[1], cur.n_p2[1], cur.n_p2_real[1], 2, cur, prev, 0, t.len, cur.p2_G[1], cur.p2_uniform[1]);
+        gate_job j = {t.M[0], cur.p2[1], cur.n_p2[1], cur.n_p2_real[1], 0, cur.p2_G[1], cur.p2_uniform[1], t.len};
+        return gate_multi(ctx, 2, prev, &j, 1, nullptr);
     }
 
+    const uint64_t live[2] = {std::min<uint64_t>(ctx->tp[0].len, d.size_v[0]),
+                              std::min<uint64_t>(ctx->tp[1].len, std::max<uint64_t>(cur.p2_live[1], prev.val_live))};
     // (the u operands of the layer's gates: the layer-0 subset and / or the previous layer, both referred to below their sizes)
-    if ((rc = eq_table1(ctx, ctx->beta_u, d.max_bl_u, ru, HFr::one(), std::max<uint64_t>(d.size_u[0], d.bit_length_u[1] >= 0 ? prev.d.size : 0)))) return rc;
-    for (int b = 0; b < 2; ++b)
-        if ((rc = load_v_table(ctx, ctx->tp[b], b, d.bit_length_v[b], d.size_v[b], cur.ori_v, prev))) return rc;
-    if (cur.n_uni2) {
-        gate_args A;
-        A.recs = cur.uni2; A.n = cur.n_uni2;
-        A.beta_g = ctx->beta_g[ctx->beta_g_cur]; A.beta_u = ctx->beta_u;
-        A.val0 = nullptr; A.val_prev = nullptr; A.two_mul = ctx->two_mul;
-        A.Vu0 = to_dev(ctx->V_u0); A.Vu1 = to_dev(ctx->V_u1); A.phase = 2; A.post_scale = 0; A.post = A.Vu0;
-        const uint32_t g = std::min<uint32_t>(grid_for(cur.n_uni2, 1024), ctx->partial_blocks);
-        ZK_LAUNCH(PC_GATE_SUM, 0.0, k_gate_sum2, dim3(g), dim3(ZK_BLOCK), ctx->partials, A);
-        // the two sums go to a mapped host slot; add_term = V_u0 s0 + V_u1 s1 is formed when the first round needs it (resolve_add_term)
-        ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials_slot, dim3(1), dim3(ZK_BLOCK), (host_slot *) ctx->d_aux, (const fr_t *) ctx->partials, g, ++ctx->aux_seq);
-        ZK_HIP(hipGetLastError());
-        ctx->add_pending = true;
-    }
+    P.eq1(ctx->beta_u, d.max_bl_u, ru, HFr::one(), std::max<uint64_t>(d.size_u[0], d.bit_length_u[1] >= 0 ? prev.d.size : 0));
+    for (int b = 0; b < 2; ++b) load_v_table(ctx, P, ctx->tp[b], b, d.bit_length_v[b], d.size_v[b], cur.ori_v, prev);
+    gate_job jobs[2];
+    int njobs = 0;
+    uint64_t conv_end = 0;
+    bool conv = false;
     for (int b = 0; b < 2; ++b) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
+        const uint64_t end = table_end(t.len, live[b]);
         if (b == 0 && cur.conv_ok && ctx->conv_K > 0) {
-            const uint64_t end0 = (t.len <= (1ull << 16) || !live_prefix_on()) ? t.len : std::min<uint64_t>(t.len, (((uint64_t) d.size_v[0] + 3) & ~3ull) + 4);
-            if ((rc = conv_phase2(ctx, cur, t.M[0], end0, ru))) return rc;
+            conv_phase2_tables(ctx, cur, ru);
+            P.small_tables(ctx->conv_small, (const liu_table *) ctx->conv_tabs + CT_COUNT, CT_COUNT);
+            conv_end = end;
+            conv = true;
             continue;
         }
-        {
-            const uint64_t lv = b ? std::max<uint64_t>(cur.p2_live[1], prev.val_live) : d.size_v[0];
-            const uint64_t end = (t.len <= (1ull << 16) || !live_prefix_on()) ? t.len : std::min<uint64_t>(t.len, ((lv + 3) & ~3ull) + 4);
-            if (cur.p2_cov[b] < end) ZK_HIP(hipMemsetAsync(t.M[0] + cur.p2_cov[b], 0, (end - cur.p2_cov[b]) * 32, ctx->stream));
-        }
-        if ((rc = gate_scatter(ctx, t.M[0], cur.p2[b], cur.n_p2[b], cur.n_p2_real[b], 2, cur, prev, 0, t.len, cur.p2_G[b], cur.p2_uniform[b]))) return rc;
+        if (cur.p2_cov[b] < end) P.zero(t.M[0] + cur.p2_cov[b], end - cur.p2_cov[b]);
+        gate_job j = {t.M[0], cur.p2[b], cur.n_p2[b], cur.n_p2_real[b], 0, cur.p2_G[b], cur.p2_uniform[b], t.len};
+        jobs[njobs++] = j;
     }
-    ctx->tp[0].live = std::min<uint64_t>(ctx->tp[0].len, d.size_v[0]);
-    ctx->tp[1].live = std::min<uint64_t>(ctx->tp[1].len, std::max<uint64_t>(cur.p2_live[1], prev.val_live));
+    if ((rc = P.launch(ctx))) return rc;
+    if (conv && (rc = conv_phase2(ctx, cur, ctx->tp[0].M[0], conv_end))) return rc;
+    // both scatters and the constant term sum_{uni gates} beta_g beta_u two_mul (reference src/prover.cpp:297-300) in one launch
+    if ((rc = gate_multi(ctx, 2, prev, jobs, njobs, &cur))) return rc;
+    ctx->tp[0].live = live[0];
+    ctx->tp[1].live = live[1];
     return ZK_OK;
 }
 
@@ -1241,72 +1297,31 @@ static int32_t resolve_add_term(zk_ctx *ctx) {
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // Non-interactive mode: all remaining rounds of the phase in one single-workgroup kernel (fs_tail.cuh). Called at the start of a round
 // whose live tables are small; fills the context's tail record and leaves every table pair either collapsed or down to its last pair.
-// Non-interactive mode: rounds the device runs by itself. `chain` rounds (planned by the caller: tables of at most 2^16 entries, no table
-// collapsing or down to its last pair) are one launch each, enqueued back to back, each deriving the next challenge in its last block
-// (k_round_chain); behind them -- or alone -- the single-workgroup kernel runs ALL remaining rounds of the phase once the tables are small
-// (k_fs_tail, `with_tail`). The host waits once, fills the record the following calls are answered from, and leaves every table pair
-// collapsed, down to its last pair, or (chain only) where the last chained round left it.
-static int32_t run_device_rounds(zk_ctx *ctx, const HFr &r, bool with_add_term, int chain, bool with_tail) {
-    const bool first0 = ctx->round == 0;
+// (Round 2 also had CHAINED launches for tables of up to 2^16 entries -- one launch per round, the next challenge derived in its last block;
+// transcripts identical, 0.5 ms per vgg11 proof slower than host-driven rounds: removed in round 3.)
+static int32_t run_device_rounds(zk_ctx *ctx, const HFr &r, bool with_add_term) {
+    const bool first = ctx->round == 0;
     const unsigned long long seq = ++ctx->tail_seq;
-    for (int j = 0; j < chain; ++j) {
-        const bool f = first0 && j == 0;
-        chain_args C;
-        std::memset(&C, 0, sizeof(C));
-        uint64_t items = 0;
-        for (int b = 0; b < 2; ++b) {
-            table_pair &t = ctx->tp[b];
-            if (!t.len) continue;
-            C.Vin[b] = vin(t); C.Min[b] = t.M[t.cur];
-            C.Vout[b] = t.V[t.cur ^ 1]; C.Mout[b] = t.M[t.cur ^ 1];
-            C.n[b] = t.len;
-            items += f ? t.len / 2 : t.len / 4;
-        }
-        C.first = f ? 1 : 0;
-        C.with_add_term = with_add_term ? 1 : 0;
-        C.from_args = j == 0 ? 1 : 0;
-        C.k = j;
-        C.last = (j == chain - 1 && !with_tail) ? 1 : 0;
-        C.prev_r = to_dev(r);
-        C.add_term = to_dev(ctx->add_term);
-        std::memcpy(C.fs_state, ctx->fs_state, 32);
-        C.cs = (chain_state *) ctx->d_chain;
-        C.partials = ctx->partials;
-        C.counter = ctx->d_counter;
-        C.out = (tail_out *) ctx->d_tail;
-        C.seq = seq;
-        const uint32_t blocks = (uint32_t) ((items + ZK_BLOCK / 4 - 1) / (ZK_BLOCK / 4));
-        ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_round_chain, dim3(blocks), dim3(ZK_BLOCK), C);
-        for (int b = 0; b < 2; ++b) {
-            table_pair &t = ctx->tp[b];
-            if (t.len && !f) { t.cur ^= 1; t.len >>= 1; t.Vsrc = nullptr; t.live = t.len; }
-        }
-    }
     tail_args A;
     std::memset(&A, 0, sizeof(A));
-    if (with_tail) {
-        const bool first = first0 && chain == 0;
-        for (int b = 0; b < 2; ++b) {
-            table_pair &t = ctx->tp[b];
-            if (!t.len) continue;
-            A.Vin[b] = vin(t); A.Min[b] = t.M[t.cur];
-            A.Vbuf[b][0] = t.V[0]; A.Vbuf[b][1] = t.V[1];
-            A.Mbuf[b][0] = t.M[0]; A.Mbuf[b][1] = t.M[1];
-            A.out_idx[b] = t.cur ^ 1;
-            A.n[b] = t.len;
-        }
-        A.first = first ? 1 : 0;
-        A.rounds = ctx->phase_rounds - ctx->round - chain;
-        A.with_add_term = with_add_term ? 1 : 0;
-        A.prev_r = to_dev(r);
-        A.add_term = to_dev(ctx->add_term);
-        std::memcpy(A.fs_state, ctx->fs_state, 32);
-        A.out = (tail_out *) ctx->d_tail;
-        A.seq = seq;
-        A.cs = chain ? (const chain_state *) ctx->d_chain : nullptr;
-        A.k0 = chain;
-        ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_fs_tail, dim3(1), dim3(FS_TAIL_THREADS), A);
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        if (!t.len) continue;
+        A.Vin[b] = vin(t); A.Min[b] = t.M[t.cur];
+        A.Vbuf[b][0] = t.V[0]; A.Vbuf[b][1] = t.V[1];
+        A.Mbuf[b][0] = t.M[0]; A.Mbuf[b][1] = t.M[1];
+        A.out_idx[b] = t.cur ^ 1;
+        A.n[b] = t.len;
     }
+    A.first = first ? 1 : 0;
+    A.rounds = ctx->phase_rounds - ctx->round;
+    A.with_add_term = with_add_term ? 1 : 0;
+    A.prev_r = to_dev(r);
+    A.add_term = to_dev(ctx->add_term);
+    std::memcpy(A.fs_state, ctx->fs_state, 32);
+    A.out = (tail_out *) ctx->d_tail;
+    A.seq = seq;
+    ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_fs_tail, dim3(1), dim3(FS_TAIL_THREADS), A);
     ZK_HIP(hipGetLastError());
     volatile unsigned long long *p = &((tail_out *) ctx->h_tail)->seq;
     for (uint64_t spins = 0; *p != seq; ++spins) {
@@ -1319,30 +1334,28 @@ static int32_t run_device_rounds(zk_ctx *ctx, const HFr &r, bool with_add_term, 
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const tail_out *o = (const tail_out *) ctx->h_tail;
-    if (with_tail)
-        for (int b = 0; b < 2; ++b) {
-            table_pair &t = ctx->tp[b];
-            if (!t.len) continue;
-            t.Vsrc = nullptr;
-            if (o->pair_state[b] == 1) {
-                t.len = 2;
-                std::memcpy(&t.tail_v[0], &o->tail_v[b][0], 32);
-                std::memcpy(&t.tail_v[1], &o->tail_v[b][1], 32);
-                t.tail_valid = true;
-            } else {
-                t.len = 0;
-                t.absorbed = true;
-                std::memcpy(&t.final_v, &o->final_v[b], 32);
-            }
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        if (!t.len) continue;
+        t.Vsrc = nullptr;
+        if (o->pair_state[b] == 1) {
+            t.len = 2;
+            std::memcpy(&t.tail_v[0], &o->tail_v[b][0], 32);
+            std::memcpy(&t.tail_v[1], &o->tail_v[b][1], 32);
+            t.tail_valid = true;
+        } else {
+            t.len = 0;
+            t.absorbed = true;
+            std::memcpy(&t.final_v, &o->final_v[b], 32);
         }
+    }
     std::memcpy(&ctx->add_term, &o->add_term, 32);
     ctx->tail_active = true;
-    ctx->tail_count = chain + (with_tail ? A.rounds : 0);
+    ctx->tail_count = A.rounds;
     ctx->tail_cursor = 0;
     ctx->last_poly_valid = false;          // (the rounds answered from the record do not maintain the running claim)
     ctx->tail_rounds_total += (uint64_t) ctx->tail_count;
-    ctx->chain_rounds_total += (uint64_t) chain;
-    if (with_tail) ++ctx->tail_phases_total;
+    ++ctx->tail_phases_total;
     return ZK_OK;
 }
 
@@ -1438,35 +1451,15 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         host_tail_round(ctx, r, with_add_term, out_abc);
         return ZK_OK;
     }
-    // (measured on vgg11: the kernel taking over at 256 quads -- two passes over its 128 quad slots in its first round -- is 1 ms per proof faster than at 128 or 512)
-    static const uint64_t tail_quads = getenv("ZKCNN_TAIL_QUADS") ? std::min<uint64_t>(FS_TAIL_QUADS, (uint64_t) atoll(getenv("ZKCNN_TAIL_QUADS"))) : 256;
+    // device-side rounds: the tail kernel takes over at 256 quads -- two passes over its 128 quad slots in its first round (measured on vgg11:
+    // 1 ms per proof faster than taking over at 128 or at 512)
+    const uint64_t tail_quads = 256;
     // quads of this round over both pairs (a first round works on pairs, not quads): small enough for one thread each?
     const uint64_t round_quads = ctx->round == 0 ? (ctx->tp[0].len + ctx->tp[1].len) / 2 : (ctx->tp[0].len + ctx->tp[1].len) / 4;
-    if (ctx->fs_state && !ctx->tail_active && ctx->phase_rounds > ctx->round && *ctx->fs_pending == 0 && ctx->tp[0].len + ctx->tp[1].len > 0) {
-        // plan: chained rounds (one launch each, no host in between) while the tables are too large for the tail kernel, then the tail kernel.
-        // A round is chained if every table has at most 2^16 entries and at least two quads (nothing collapses, no last pair to hand over).
-        // (chaining is OFF unless ZKCNN_FS_CHAIN=1: measured on vgg11 it is 0.5 ms per proof SLOWER than letting the host drive these rounds --
-        // the last block's epilogue, partial sums reloaded across the chip plus two BLAKE2s compressions on one lane, costs what the host turn-around cost)
-        const char *ce = getenv("ZKCNN_FS_CHAIN");
-        const bool chain_on = ce && atoi(ce) != 0;
-        uint64_t L[2] = {ctx->tp[0].len, ctx->tp[1].len};
-        int chain = 0;
-        bool with_tail = false;
-        for (int j = 0; ctx->round + j < ctx->phase_rounds; ++j) {
-            const bool f = ctx->round == 0 && j == 0;
-            const uint64_t q = f ? (L[0] + L[1]) / 2 : (L[0] + L[1]) / 4;
-            if (q <= tail_quads) { with_tail = true; break; }
-            bool ok = chain_on && std::max(L[0], L[1]) <= (1ull << 16) && 2 * (std::max(L[0], L[1]) / 4 / (ZK_BLOCK / 4) + 1) <= ctx->partial_blocks;
-            for (int b = 0; b < 2 && ok; ++b)
-                if (L[b] && (f ? L[b] / 2 : L[b] / 4) < 2) ok = false;
-            if (!ok) break;
-            ++chain;
-            if (!f) { L[0] >>= 1; L[1] >>= 1; }
-        }
-        if (chain || (with_tail && round_quads <= tail_quads)) {
-            int32_t rc = run_device_rounds(ctx, r, with_add_term, chain, with_tail);
-            if (rc) return rc;
-        }
+    if (ctx->fs_state && !ctx->tail_active && ctx->phase_rounds > ctx->round && *ctx->fs_pending == 0 && ctx->tp[0].len + ctx->tp[1].len > 0 &&
+        round_quads <= tail_quads) {
+        int32_t rc = run_device_rounds(ctx, r, with_add_term);
+        if (rc) return rc;
     }
     if (ctx->tail_active) {
         const tail_out *o = (const tail_out *) ctx->h_tail;
@@ -1493,12 +1486,11 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
     double alg_bytes = 0;
     // From the second round of a phase on, the claim this round's polynomial must meet is known: p(0) + p(1) = p_prev(r). The kernels then
     // skip the sum of v1 m1 (one product per pair of 7) and b follows from the claim -- the same field element the direct sum gives.
-    static const bool use_claim = !(getenv("ZKCNN_ROUND_CLAIM") && atoi(getenv("ZKCNN_ROUND_CLAIM")) == 0);
-    const bool skip_p1 = use_claim && !first && ctx->last_poly_valid;
+    const bool skip_p1 = !first && ctx->last_poly_valid;
     HFr claim(0LL);
     if (skip_p1) claim = (ctx->last_poly[0] * r + ctx->last_poly[1]) * r + ctx->last_poly[2];
     // small tables are latency bound: spread each quad over 4 lanes (k_round_quad2, `fine`)
-    static const int fine_log = getenv("ZKCNN_FINE_LOG") ? atoi(getenv("ZKCNN_FINE_LOG")) : 16;
+    const int fine_log = 16;
     // (one block per 64 quads and 3 partial sums per block: both pairs together must stay within the partials buffer)
     const uint64_t longest = std::max(ctx->tp[0].len, ctx->tp[1].len);
     const bool fine = longest <= (1ull << fine_log) && 2 * (longest / 4 / (ZK_BLOCK / 4) + 1) <= ctx->partial_blocks;
@@ -1514,12 +1506,12 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         const uint64_t npairs = first ? t.len / 2 : t.len / 4;
         // the large-table kernel skips the pairs behind the live prefix; once this table's output is small enough for the other kernels
         // (which read whole tables) the zeros are stored
-        const uint64_t live = live_prefix_on() ? std::min(t.live, t.len) : t.len;
+        const uint64_t live = std::min(t.live, t.len);
         A.nl[b] = live;
         A.fill[b] = (t.len / 2 <= (1ull << std::max(fine_log, 16))) ? 1 : 0;
         const uint64_t work = fine ? npairs : std::max<uint64_t>(first ? (live + 1) / 2 : (live + 3) / 4, first ? 1 : (A.fill[b] ? npairs / 8 : 1));
         // (k_round_quad2 holds 3 waves per SIMD: 768 blocks of 4 waves are exactly one resident set of the 1 024 SIMDs -- no partial second wave of blocks)
-        static const uint32_t quad_cap = getenv("ZKCNN_QUAD_BLOCKS") ? (uint32_t) std::max(1, atoi(getenv("ZKCNN_QUAD_BLOCKS"))) : 768;
+        const uint32_t quad_cap = 768;
         A.blocks[b] = collapsed[b] ? 1 : std::min<uint32_t>(grid_for(work, fine ? 1024 : quad_cap), ctx->partial_blocks / 2);
         fine_items += collapsed[b] ? 1 : npairs;
         alg_bytes += (first ? 64.0 : 96.0) * (double) (fine ? t.len : live);      // entries the launch has to read: the live prefix
@@ -1690,50 +1682,24 @@ extern "C" int32_t zk_sumcheck_liu_init(zk_ctx *ctx, const uint64_t *s_u, const 
     table_pair &t = ctx->tp[1];
     t.Vsrc = L0.val;
     t.live = std::min<uint64_t>(t.len, L0.d.size);          // layer 0 is zero padded behind its size, and no layer refers to entries there
-    static const bool batched = !(getenv("ZKCNN_LIU_BATCHED") && atoi(getenv("ZKCNN_LIU_BATCHED")) == 0);
-    if (batched) {
-        // descriptors of every (layer, side) table: point, sigma, bit split; then two launches (k_eq_halves_multi, k_liu_gather)
-        liu_table *T = (liu_table *) ctx->h_liu_tabs;
-        for (uint32_t tb = 0; tb < ctx->liu_ntabs; ++tb) {
-            const int i = ctx->liu_tab_layer[tb], side = ctx->liu_tab_side[tb];
-            const dev_layer &Li = ctx->L[i];
-            const int bl = side ? Li.d.bit_length_v[0] : Li.d.bit_length_u[0];
-            const std::vector<HFr> &pt = side ? ctx->r_v[i] : ctx->r_u[i];
-            if ((int) pt.size() < bl) return ZK_ERR_STATE;
-            for (int j = 0; j < bl; ++j) T[tb].r.v[j] = to_dev(pt[j]);
-            T[tb].init = to_dev(H((side ? s_v : s_u) + 4 * (i - 1)));
-            T[tb].n = bl;
-            T[tb].fh = bl >> 1;
-            T[tb].sh = bl - (bl >> 1);
-            T[tb].pad_ = 0;
-        }
-        if (ctx->liu_ntabs) {
-            ZK_HIP(hipMemcpyAsync(ctx->liu_tabs, T, (size_t) ctx->liu_ntabs * sizeof(liu_table), hipMemcpyHostToDevice, ctx->stream));
-            ZK_LAUNCH(PC_EQ, 0.0, k_eq_halves_multi, dim3(2, ctx->liu_ntabs), dim3(1024), ctx->liu_halves, (const liu_table *) ctx->liu_tabs);
-        }
-        ZK_LAUNCH(PC_LIU, 0.0, k_liu_gather, dim3(grid_for(t.len)), dim3(ZK_BLOCK), t.M[0], ctx->liu_ptr, (const liu_entry *) ctx->liu_ent, ctx->liu_halves,
-                  (const liu_table *) ctx->liu_tabs, t.len);
-        ZK_HIP(hipGetLastError());
-        return ZK_OK;
-    }
-    ZK_HIP(hipMemsetAsync(t.M[0], 0, t.len * 32, ctx->stream));
-    fr_t *bg = ctx->beta_g[ctx->beta_g_cur];
-    int32_t rc;
-    for (size_t i = 1; i < ctx->L.size(); ++i) {
+    // descriptors of every (layer, side) table: point, sigma, bit split (mapped host memory, read by the kernel in place); then two launches
+    liu_table *T = (liu_table *) ctx->h_liu_tabs;
+    for (uint32_t tb = 0; tb < ctx->liu_ntabs; ++tb) {
+        const int i = ctx->liu_tab_layer[tb], side = ctx->liu_tab_side[tb];
         const dev_layer &Li = ctx->L[i];
-        if (Li.d.bit_length_u[0] >= 0) {
-            if ((int) ctx->r_u[i].size() < Li.d.bit_length_u[0]) return ZK_ERR_STATE;
-            if ((rc = eq_table1(ctx, bg, Li.d.bit_length_u[0], ctx->r_u[i].data(), H(s_u + 4 * (i - 1))))) return rc;
-            if (Li.d.size_u[0])
-                ZK_LAUNCH(PC_LIU, 0.0, k_scatter_add_unique, dim3(grid_for(Li.d.size_u[0])), dim3(ZK_BLOCK), t.M[0], Li.ori_u, bg, (uint64_t) Li.d.size_u[0]);
-        }
-        if (Li.d.bit_length_v[0] >= 0) {
-            if ((int) ctx->r_v[i].size() < Li.d.bit_length_v[0]) return ZK_ERR_STATE;
-            if ((rc = eq_table1(ctx, bg, Li.d.bit_length_v[0], ctx->r_v[i].data(), H(s_v + 4 * (i - 1))))) return rc;
-            if (Li.d.size_v[0])
-                ZK_LAUNCH(PC_LIU, 0.0, k_scatter_add_unique, dim3(grid_for(Li.d.size_v[0])), dim3(ZK_BLOCK), t.M[0], Li.ori_v, bg, (uint64_t) Li.d.size_v[0]);
-        }
+        const int bl = side ? Li.d.bit_length_v[0] : Li.d.bit_length_u[0];
+        const std::vector<HFr> &pt = side ? ctx->r_v[i] : ctx->r_u[i];
+        if ((int) pt.size() < bl) return ZK_ERR_STATE;
+        for (int j = 0; j < bl; ++j) T[tb].r.v[j] = to_dev(pt[j]);
+        T[tb].init = to_dev(H((side ? s_v : s_u) + 4 * (i - 1)));
+        T[tb].n = bl;
+        T[tb].fh = bl >> 1;
+        T[tb].sh = bl - (bl >> 1);
+        T[tb].pad_ = 0;
     }
+    if (ctx->liu_ntabs)
+        ZK_LAUNCH(PC_EQ, 0.0, k_eq_halves_multi, dim3(2, ctx->liu_ntabs), dim3(1024), ctx->liu_halves, (const liu_table *) ctx->liu_tabs);
+    ZK_LAUNCH(PC_LIU, 0.0, k_liu_gather, dim3(grid_for(t.len)), dim3(ZK_BLOCK), t.M[0], ctx->liu_ptr, (const liu_entry *) ctx->liu_ent, ctx->liu_halves, t.len);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
