@@ -38,7 +38,8 @@ typedef struct {
                                      known challenge stream is a debugging aid, never evidence that a statement is true */
 #define ZKCNN_MODE_FULL_IPA  128u  /* inner-product argument down to length 1 (log2(m) rounds) instead of sending the last 256 scalars in the clear */
 #define ZKCNN_MODE_ZK  (1u << 24)  /* zero-knowledge masking: blinded commitments, masked round polynomials, proofs of dot product */
-#define ZKCNN_MODE_HOST_ROUNDS (1u << 25)  /* Fiat-Shamir with every round driven from the host (A/B and parity of the device-side rounds) */
+#define ZKCNN_MODE_HOST_ROUNDS (1u << 25)  /* every sumcheck round is a kernel launch driven from the host: no resident round kernel (interactive), no device-side
+                                              rounds (Fiat-Shamir) -- A/B and parity of both */
 #define ZKCNN_MODE_HOST_TAIL (1u << 26)    /* hybrid tail (off by default): once a phase's tables have <= 64 entries they travel to the host and its last
                                             ~6 rounds run there (a few hundred host multiplications instead of six latency-bound launches) */
 #define ZKCNN_MODE_CROSS_PRED 16u  /* both, and the verifier rejects if they differ (parity check of zk_verifier_*) */

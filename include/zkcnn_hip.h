@@ -128,6 +128,11 @@ int32_t zk_fs_attach(zk_ctx *ctx, const uint32_t *state, const uint64_t *pending
  * reaches them and its last rounds run there -- O(2^log_entries) host multiplications per round instead of a latency-bound launch and
  * hand-over. Same field elements either way. log_entries < 0 switches it off. */
 int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries);
+/* Persistent rounds of the interactive protocol (on by default): once the live tables of a phase hold at most 1024 quads, ONE resident
+ * single-workgroup kernel runs all remaining rounds of the phase; zk_sumcheck_update1/2 and zk_sumcheck_liu_update then exchange a round
+ * polynomial and the verifier's next challenge with it through two mapped host mailboxes instead of launching a kernel per round
+ * (reference src/prover.cpp:368-426 is called once per round either way: same field elements). on = 0: every round is a launch. */
+int32_t zk_set_live_rounds(zk_ctx *ctx, int32_t on);
 /* rounds / phases served by the tail kernel since the context was created (tests, bench) */
 int32_t zk_fs_stats(zk_ctx *ctx, uint64_t *rounds, uint64_t *phases);
 

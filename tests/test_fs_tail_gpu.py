@@ -42,6 +42,37 @@ def test_device_rounds_give_the_host_transcript(built, model, pic, pp):
         print(f"{model}: {r1 - r0} of {res.n_rounds} rounds in {p1 - p0} device phases")
 
 
+@pytest.mark.parametrize("model,pic,pp", CASES)
+def test_resident_round_kernel_equals_launch_per_round(built, model, pic, pp):
+    """Interactive protocol: by default the small rounds of every phase run in ONE resident kernel that trades polynomials and challenges with
+    the host through mailboxes (k_tail<true>); ZKCNN_MODE_HOST_ROUNDS launches a kernel per round instead. Same transcripts, equal to the
+    oracle's; a verifier that rejects in the middle of a phase sends the resident kernel home and the session keeps working."""
+    with oracle_ffi.OracleSession(model, pic, pp) as o:
+        _, want = o.prove(seed=0x5EED0051, mode=REUSE)
+        _, want_zk = o.prove(seed=0x5EED0052, mode=REUSE | zkcnn_amd.MODE_ZK)
+    with zkcnn_amd.Session(model, pic, pp) as s:
+        r0, p0 = s.fs_stats()
+        res, tr = s.prove(seed=0x5EED0051, mode=REUSE)
+        r1, p1 = s.fs_stats()
+        assert res.accepted == 1, res.message.decode()
+        assert tr == want, "resident round kernel: transcript differs from the oracle's"
+        assert r1 > r0 and p1 > p0, "no round ran in the resident kernel"
+        res2, tr2 = s.prove(seed=0x5EED0051, mode=REUSE | HOST)
+        assert s.fs_stats() == (r1, p1), "ZKCNN_MODE_HOST_ROUNDS must keep every round a launch"
+        assert res2.accepted == 1 and tr2 == want
+        # masked round polynomials (the masks are added on the host) on top of the resident kernel
+        res3, tr3 = s.prove(seed=0x5EED0052, mode=REUSE | zkcnn_amd.MODE_ZK)
+        assert res3.accepted == 1 and tr3 == want_zk
+        # a corrupted message in the middle of the proof: the verifier stops calling in the middle of a phase
+        n = res.n_messages
+        for k in (n // 3, n // 2, n - 5):
+            bad, _ = s.prove(seed=0x5EED0051, mode=REUSE | zkcnn_amd.MODE_TAMPER | (k << 8))
+            assert bad.accepted == 0
+            again, tr4 = s.prove(seed=0x5EED0051, mode=REUSE | DRIVE)
+            assert again.accepted == -1 and tr4 == want
+        print(f"{model}: {r1 - r0} of {res.n_rounds} rounds in {p1 - p0} resident kernels")
+
+
 def test_full_size_vgg11_fiat_shamir_latency(built):
     with zkcnn_amd.Session("vgg11", (32, 32, 3), 1) as s:
         s.prove(mode=FS | DRIVE, want_transcript=False)           # tables of the public generators

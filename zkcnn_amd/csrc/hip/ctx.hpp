@@ -68,10 +68,10 @@ struct msm_state;                  // hyrax.hip
 
 // kernel classes of the built-in profiler (HIP events on the context's stream)
 enum prof_class { PC_EQ = 0, PC_GATHER, PC_GATE, PC_GATE_FIX, PC_GATE_SUM, PC_SUM, PC_ROUND_QUAD, PC_ROUND_CUBIC, PC_FOLD, PC_MATVEC,
-                  PC_PHI, PC_DOT, PC_LIU, PC_MSM_PLANES, PC_MSM_FINISH, PC_MSM_TABLES, PC_IPA, PC_MISC, PC_COUNT };
+                  PC_PHI, PC_DOT, PC_LIU, PC_MSM_PLANES, PC_MSM_FINISH, PC_MSM_TABLES, PC_IPA, PC_MISC, PC_TAIL, PC_COUNT };
 static const char *const prof_names[PC_COUNT] = {"eq_table", "gather", "gate_reduce", "gate_fixup", "gate_sum", "sum_partials", "round_quad",
                                                  "round_cubic", "fold", "matvec", "phi", "dot_prod", "liu_scatter", "msm_planes",
-                                                 "msm_finish", "msm_tables", "ipa", "misc"};
+                                                 "msm_finish", "msm_tables", "ipa", "misc", "round_tail"};
 struct prof_pending { hipEvent_t e0, e1; int cls; double bytes; };
 
 struct zk_ctx {
@@ -144,6 +144,13 @@ struct zk_ctx {
     const uint64_t *fs_pending = nullptr;
     void *h_tail = nullptr, *d_tail = nullptr;     // tail_out, pinned + mapped
     bool tail_active = false;
+    // persistent rounds of the interactive protocol (k_tail<true>): challenge mailbox (pinned + mapped), the running kernel's round window
+    void *h_live_in = nullptr, *d_live_in = nullptr;
+    bool live_rounds = true;       // zk_set_live_rounds
+    bool live_active = false;
+    int live_count = 0, live_cursor = 0;
+    uint32_t live_seq32 = 16;
+    uint64_t live_rounds_total = 0, live_phases_total = 0;
     int tail_count = 0, tail_cursor = 0, phase_rounds = 0;
     unsigned long long tail_seq = 0;
     uint64_t tail_rounds_total = 0, tail_phases_total = 0;
@@ -235,3 +242,5 @@ void zk_msm_destroy(zk_ctx *ctx);
 // device-side helpers implemented in sumcheck.hip and re-used by hyrax.hip
 int32_t zk_eq_table1_dev(zk_ctx *ctx, fr_t *out, int n, const HFr *r, const HFr &init);
 int32_t zk_col_combine_dev(zk_ctx *ctx, fr_t *out, const fr_t *Z, const fr_t *L, uint32_t cols, uint32_t rows);
+// a resident round kernel whose phase nobody finishes (a verifier that rejected mid-phase) must leave before anything else uses the stream
+int32_t zk_live_abort(zk_ctx *ctx);

@@ -1,36 +1,50 @@
-// Device-side Fiat-Shamir rounds ("removes the ~10^3 host round-trips per proof").
+// The small rounds of a sumcheck phase in ONE persistent single-workgroup kernel (reference src/prover.cpp:368-426, one call per round there).
 //
-// In the interactive protocol the verifier draws each round's challenge after seeing the round polynomial, so every sumcheck round is a
-// launch, a hand-over to the host and a host turn-around (~25-30 us, of which the kernel is ~10). In the NON-interactive mode the next
-// challenge is a hash of the transcript, which the prover can compute itself: once the live tables of a phase are small (<= 2^12 entries,
-// which is 12 of the ~15-21 rounds of every vgg11 phase) ONE single-workgroup kernel runs all remaining rounds of the phase -- fold, round
-// sums, the O(1) add_term bookkeeping of reference src/prover.cpp:360-426, the BLAKE2s chain step on the round polynomial and the
-// derivation of the next challenge -- and hands all round polynomials, challenges and final table entries to the host at once. The host
-// prover then answers the verifier's calls from that record and checks that the verifier's challenges are the ones the device derived
-// (they are the same function of the same transcript: host/replay.hpp fiatShamir). The interactive path is untouched.
-//
-// Chain step (identical on both sides): state' = BLAKE2s-256(state || message), message of a quadratic round = the three coefficients as
-// they lie in memory (Montgomery limbs, 96 bytes: a bijection of the field elements, so equally binding, and no conversion on the
-// critical path) -- 128 bytes, two compressions. Challenge = state' with bit 255 cleared, taken AS Montgomery limbs if below r, else one
-// more chain step with an empty message.
+// A round on a small table is a launch, a hand-over to the host and a host turn-around: ~25 us, of which the arithmetic is two dependent
+// field products. Once the live tables of a phase hold at most TAIL_QUADS quads, k_tail runs ALL remaining rounds of the phase -- fold,
+// round sums, the O(1) add_term bookkeeping of reference src/prover.cpp:360-426 -- and only the challenge differs by mode:
+//   * LIVE (interactive protocol, round 3): the verifier still draws every challenge after seeing the round polynomial. The kernel posts the
+//     polynomial in a mapped host mailbox and polls a second mailbox for the challenge; the host side of a round is "read 128 bytes, call
+//     the verifier, write 48 bytes". No launch, no dispatch, no stream event per round. Every 16-byte chunk of either mailbox carries the
+//     round's sequence number, and a chunk is written / read with ONE 16-byte access, so a message is complete when all its chunks show the
+//     expected number: no ordering between stores is assumed and nobody waits for a write acknowledgement across PCIe.
+//     The kernel leaves by itself after the phase's last round; if the host stops talking (a verifier that rejected mid-phase) it is told to
+//     (abort word), and as a last resort it gives up after TAIL_TIMEOUT_TICKS of the constant 100 MHz clock.
+//   * FS: non-interactive mode, the next challenge is a hash of the transcript, which the kernel computes itself:
+//     chain step state' = BLAKE2s-256(state || a || b || c) on the 96 bytes as they lie in memory (Montgomery limbs: a bijection of the field
+//     elements), challenge = state' with bit 255 cleared, taken AS Montgomery limbs if below r, else one more step with an empty message
+//     (host twin: host/replay.hpp fiatShamir). All round polynomials, challenges and final table entries go to the host at once; the host
+//     prover answers the verifier's calls from that record and checks that the verifier's challenges are the ones derived here.
 #pragma once
 #include "kernels.cuh"
 #include "../ff/blake2s.hpp"
 
-#define FS_TAIL_THREADS 576            // 8 waves of quads + one wave of scalar bookkeeping
-#define FS_TAIL_SLOTS 128              // quads in flight: four lanes each on 8 waves
-#define FS_TAIL_QUADS 512              // quads (both table pairs together) the kernel takes: its first two rounds then make 4 and 2 passes over the slots
+#define TAIL_THREADS 1024              // 16 waves, four lanes per quad
+#define TAIL_SLOTS 256                 // quads in flight per pass
+#define TAIL_QUADS 1024                // quads (both table pairs together) the kernel accepts: its first rounds then make 4 and 2 passes over the slots
 #define FS_TAIL_MAX_ROUNDS ZK_MAX_VARS
+#define TAIL_TIMEOUT_TICKS 300000000ull   // 3 s of s_memrealtime (100 MHz): a live kernel nobody talks to gives up
+#define TAIL_ABORT 0xffffffffu
+
+struct __align__(16) live_in {        // mapped host memory, written by the host: chunk j = {challenge words 3j, 3j+1, 3j+2, seq} (chunk 2: words 6, 7, 0)
+    uint32_t c[3][4];
+    uint32_t pad_[4];
+};
+struct __align__(16) live_out {       // mapped host memory, written by the kernel: chunk j = {words 3j .. 3j+2 of (a, b, c), seq}
+    uint32_t c[8][4];
+};
 
 struct tail_out {                     // pinned, mapped host memory
-    fr_t poly[FS_TAIL_MAX_ROUNDS][3]; // round polynomials (a, b, c) as the host's quad_round returns them
-    fr_t chal[FS_TAIL_MAX_ROUNDS];    // challenge derived after each of them
+    fr_t poly[FS_TAIL_MAX_ROUNDS][3]; // FS: round polynomials (a, b, c) as the host's quad_round returns them
+    fr_t chal[FS_TAIL_MAX_ROUNDS];    // FS: challenge derived after each of them
     fr_t add_term;                    // bookkeeping scalar after the last round
     fr_t tail_v[2][2];                // the two entries left in each V table ...
     fr_t final_v[2];                  // ... or the value it collapsed to
     uint32_t pair_state[2];           // 0 absent, 1 two entries left (tail_v), 2 collapsed (final_v)
-    uint32_t fs_state[8];             // chain state after the last challenge
-    unsigned long long seq;           // written last
+    uint32_t fs_state[8];             // FS: chain state after the last challenge
+    uint32_t status, pad_;            // LIVE: 0 running / finished, 1 aborted by the host, 2 timed out
+    unsigned long long seq;           // FS: written last
+    live_out live;                    // LIVE: the round mailbox
 };
 
 struct tail_args {
@@ -38,11 +52,13 @@ struct tail_args {
     fr_t *Vbuf[2][2], *Mbuf[2][2];    // ping-pong buffers; out_idx[b] = the one the next fold writes
     int32_t out_idx[2];
     uint64_t n[2];                    // pre-fold length of each pair; 0 = absent
-    int32_t first, rounds, with_add_term;
+    int32_t first, rounds, with_add_term, pad_;
     fr_t prev_r, add_term;
     uint32_t fs_state[8];
     tail_out *out;
-    unsigned long long seq;
+    unsigned long long seq;           // FS: published when everything is written
+    const live_in *in;                // LIVE: challenge mailbox
+    uint32_t seq32, pad2_;            // LIVE: round k is posted with seq32 + k; the challenge that follows it is expected with seq32 + k + 1
 };
 
 __device__ __forceinline__ bool fr_raw_ge_mod(const uint32_t t[8]) {
@@ -76,16 +92,33 @@ __device__ __forceinline__ fr_t fs_round_challenge(uint32_t st[8], const fr_t &c
     }
 }
 
-// Work layout of a round: quad q of the concatenated list [pair 0 | pair 1] belongs to lanes 4q .. 4q + 3 (no loop: the tables hold at
-// most FS_TAIL_QUADS quads together when the kernel starts); the last wave does the scalar bookkeeping at the same time --
-// add_term (1 - r), the final values of a pair that collapses this round and their product -- so that after the block reduction thread 0
-// only combines, hashes and derives the challenge.
-__global__ void __launch_bounds__(FS_TAIL_THREADS) k_fs_tail(tail_args a) {
-    __shared__ fr_t s_part[FS_TAIL_THREADS / 64][3];
-    __shared__ fr_t s_r, s_fin[2][2], s_prod[2], s_tail[2][2], s_add;
+typedef uint32_t zk_u32x4 __attribute__((ext_vector_type(4)));
+// one 16-byte access that goes to the host every time (system scope: sc0 sc1 on gfx94x / gfx950)
+__device__ __forceinline__ void store16_sys(void *p, zk_u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void load48_sys(const void *p, zk_u32x4 &c0, zk_u32x4 &c1, zk_u32x4 &c2) {
+    asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16 sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:32 sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(c0), "=&v"(c1), "=&v"(c2) : "v"(p) : "memory");
+}
+
+// Work layout of a round: item i of the list [quads of pair 0 | quads of pair 1 | a pair that collapses this round, one item each] belongs
+// to lanes 4 (i mod TAIL_SLOTS) .. + 3, in passes of TAIL_SLOTS items. Four lanes per quad (the layout of k_round_quad_fine: a lone wave
+// issues its products one after the other, so the chain per lane is what counts):
+//     fold     role 0: v0   1: v1   2: m0   3: m1                                 (one product)
+//     product  role 0: c = v0 m0   1: p(1) = v1 m1   2: a = (v1 - v0)(m1 - m0)      (one more)
+// A collapsing pair (the reference's `total == 1` case, prover.cpp:400-404) is a degenerate quad: role 0 / 2 fold its last V / M pair and
+// role 0's product is the term add_term takes over. add_term (1 - r) is the product of the one lane that is idle in the product step.
+template <bool LIVE>
+__global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
+    __shared__ fr_t s_part[TAIL_THREADS / 64][3];
+    __shared__ fr_t s_r, s_fin[2], s_prod[2], s_tail[2][2], s_add, s_addm;
     __shared__ uint32_t s_state[8];
+    __shared__ int s_stop;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int scalar_wave = FS_TAIL_THREADS / 64 - 1;
     uint64_t n[2] = {a.n[0], a.n[1]};
     const fr_t *Vin[2] = {a.Vin[0], a.Vin[1]}, *Min[2] = {a.Min[0], a.Min[1]};
     int oi[2] = {a.out_idx[0], a.out_idx[1]};
@@ -94,8 +127,11 @@ __global__ void __launch_bounds__(FS_TAIL_THREADS) k_fs_tail(tail_args a) {
     if (tid == 0) {
         s_r = a.prev_r;
         s_add = a.add_term;
+        s_stop = 0;
+        if (!LIVE) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s_state[i] = a.fs_state[i];
+            for (int i = 0; i < 8; ++i) s_state[i] = a.fs_state[i];
+        }
     }
     __syncthreads();
     for (int k = 0; k < a.rounds; ++k) {
@@ -107,31 +143,29 @@ __global__ void __launch_bounds__(FS_TAIL_THREADS) k_fs_tail(tail_args a) {
             collapse[b] = n[b] && (first ? n[b] == 1 : n[b] == 2);
             quads[b] = (!n[b] || collapse[b]) ? 0u : (uint32_t) (first ? n[b] / 2 : n[b] / 4);
         }
-        if (wave == scalar_wave) {
-            // scalar bookkeeping, concurrent with the quads: lane 0/1 (2/3): V and M of a collapsing pair 0 (1); lane 4: add_term (1 - r)
-            if (lane < 4 && (lane < 2 ? collapse[0] : collapse[1])) {
-                const int b = lane >> 1;                 // (constant indices below: a runtime index into a local array would live in scratch memory)
-                const fr_t *src = (lane & 1) ? (b ? Min[1] : Min[0]) : (b ? Vin[1] : Vin[0]);
-                fr_t x = fr_load(src);
-                if (!first) x = fr_lerp(x, fr_load(src + 1), r);
-                s_fin[b][lane & 1] = x;
-            }
-            if (lane == 4 && a.with_add_term && !first) s_add = fr_mul(s_add, fr_sub(fr_one(), r));
-        }
-        // Four lanes per quad (the layout of k_round_quad_fine: a lone wave issues its products one after the other, so the chain per
-        // lane is what counts):   fold     role 0: v0   1: v1   2: m0   3: m1        (one product)
-        //                         product  role 0: c = v0 m0   1: p(1) = v1 m1   2: a = (v1 - v0)(m1 - m0)     (one more)
-        const uint32_t role = (uint32_t) tid & 3, total_quads = quads[0] + quads[1];
+        const uint32_t role = (uint32_t) tid & 3, nq = quads[0] + quads[1];
+        const uint32_t total_items = nq + (collapse[0] ? 1u : 0u) + (collapse[1] ? 1u : 0u);
         fr_t prod = fr_zero();
-        for (uint32_t base = 0; base == 0 || base < total_quads; base += FS_TAIL_SLOTS) {
+        for (uint32_t base = 0; base == 0 || base < total_items; base += TAIL_SLOTS) {
             const uint32_t item = base + ((uint32_t) tid >> 2);
-            const bool live = wave != scalar_wave && item < total_quads;
-            const int b = (live && item >= quads[0]) ? 1 : 0;
-            const uint32_t q = b ? item - quads[0] : item, quads_b = b ? quads[1] : quads[0];
+            const bool live = item < total_items;
+            const bool special = live && item >= nq;
+            // which pair: quads of pair 0, then of pair 1, then the collapsing pairs in pair order
+            int b = 0;
+            uint32_t q = item;
+            if (special) b = (collapse[0] && item == nq) ? 0 : 1;
+            else if (live && item >= quads[0]) { b = 1; q = item - quads[0]; }
+            const uint32_t quads_b = b ? quads[1] : quads[0];
             const fr_t *Vb = b ? Vin[1] : Vin[0], *Mb = b ? Min[1] : Min[0];
             const int oib = b ? oi[1] : oi[0];
             fr_t X = fr_zero(), opA = fr_zero(), opB = fr_zero();
-            if (live && first) {
+            if (special) {
+                if (role == 0 || role == 2) {
+                    const fr_t *src = role == 0 ? Vb : Mb;
+                    X = fr_load(src);
+                    if (!first) X = fr_lerp(X, fr_load(src + 1), r);
+                }
+            } else if (live && first) {
                 if (role < 3) {
                     const fr_t v0 = fr_load(Vb + 2 * q), v1 = fr_load(Vb + 2 * q + 1), m0 = fr_load(Mb + 2 * q), m1 = fr_load(Mb + 2 * q + 1);
                     opA = role == 0 ? v0 : role == 1 ? v1 : fr_sub(v1, v0);
@@ -144,7 +178,7 @@ __global__ void __launch_bounds__(FS_TAIL_THREADS) k_fs_tail(tail_args a) {
                 fr_store((role < 2 ? a.Vbuf[b][oib] : a.Mbuf[b][oib]) + 2 * q + (role & 1), X);
                 if (quads_b == 1 && role < 2) s_tail[b][role] = X;           // the pair the phase may end with
             }
-            if (!first && wave != scalar_wave) {
+            if (!first || special) {
                 fr_t y1, y2, y3;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -153,57 +187,120 @@ __global__ void __launch_bounds__(FS_TAIL_THREADS) k_fs_tail(tail_args a) {
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) y3.v[i] = (uint32_t) __shfl_xor((int) y1.v[i], 1, 64);
-                // role 0: X = v0, y1 = m0;  role 1: X = v1, y1 = m1;  role 2: X = m0, y1 = v0, y2 = m1, y3 = v1
-                opA = role == 2 ? fr_sub(y3, y1) : X;
-                opB = role == 2 ? fr_sub(y2, X) : y1;
-                if (role == 3 || !live) { opA = fr_zero(); opB = fr_zero(); }
+                if (special) {
+                    // role 0: X = V's last value, y1 = M's (role 2's X): their product goes to add_term
+                    opA = role == 0 ? X : fr_zero();
+                    opB = role == 0 ? y1 : fr_zero();
+                    if (role == 0) s_fin[b] = X;
+                } else if (!first) {
+                    // role 0: X = v0, y1 = m0;  role 1: X = v1, y1 = m1;  role 2: X = m0, y1 = v0, y2 = m1, y3 = v1
+                    opA = role == 2 ? fr_sub(y3, y1) : X;
+                    opB = role == 2 ? fr_sub(y2, X) : y1;
+                    if (role == 3 || !live) { opA = fr_zero(); opB = fr_zero(); }
+                }
             }
-            if (wave != scalar_wave && (base == 0 || live)) prod = fr_add(prod, fr_mul(opA, opB));
+            // the bookkeeping product add_term (1 - r) rides on a lane that is idle in this step (reference src/prover.cpp:375)
+            const bool addm = base == 0 && tid == 3 && a.with_add_term;
+            if (addm) { opA = s_add; opB = fr_sub(fr_one(), r); }
+            fr_t x = fr_mul(opA, opB);
+            if (addm) { s_addm = x; x = fr_zero(); }
+            if (special && role == 0) { s_prod[b] = x; x = fr_zero(); }
+            prod = fr_add(prod, x);
         }
-        // reduction: lanes of equal role by butterflies, lanes 0..2 of every wave that holds quads leave the wave's sums, threads 0..2 add those
-        const int nw = (int) std::min<uint32_t>(FS_TAIL_THREADS / 64 - 1, (4 * total_quads + 63) / 64);
-        if (wave < nw) {
+        // reduction: lanes of equal role by butterflies; lanes 0..2 of every wave leave the wave's sums
 #pragma unroll
-            for (int off = 4; off < 64; off <<= 1) {
-                fr_t o;
+        for (int off = 4; off < 64; off <<= 1) {
+            fr_t o;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o.v[i] = (uint32_t) __shfl_xor((int) prod.v[i], off, 64);
-                prod = fr_add(prod, o);
-            }
-            if (lane < 3) s_part[wave][lane == 2 ? 0 : lane + 1] = prod;       // accumulator order a, c, p(1)
+            for (int i = 0; i < 8; ++i) o.v[i] = (uint32_t) __shfl_xor((int) prod.v[i], off, 64);
+            prod = fr_add(prod, o);
         }
-        __syncthreads();
-        if (wave == scalar_wave && (lane == 0 ? collapse[0] : lane == 2 ? collapse[1] : false)) s_prod[lane >> 1] = fr_mul(s_fin[lane >> 1][0], s_fin[lane >> 1][1]);
-        fr_t tot = fr_zero();
-        if (tid < 3)
-            for (int w = 0; w < nw; ++w) tot = fr_add(tot, s_part[w][tid]);
+        if (lane < 3) s_part[wave][lane == 2 ? 0 : lane + 1] = prod;       // accumulator order a, c, p(1)
         __syncthreads();
         if (wave == 0) {
-            fr_t ca = tot, cc = fr_shfl_down(tot, 1), p1 = fr_shfl_down(tot, 2);
+            // lane 16 t + w holds accumulator t of wave w; a 4-step butterfly over w
+            const int t = lane >> 4, w = lane & 15;
+            fr_t tot = t < 3 ? s_part[w][t] : fr_zero();
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                fr_t o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o.v[i] = (uint32_t) __shfl_xor((int) tot.v[i], off, 64);
+                tot = fr_add(tot, o);
+            }
+            fr_t ca = tot, cc = fr_shfl_down(tot, 16), p1 = fr_shfl_down(tot, 32);
             if (tid == 0) {
                 // host bookkeeping of quad_round (sumcheck.hip), reference src/prover.cpp:368-383
-                fr_t add_term = s_add;
+                fr_t add_term = a.with_add_term ? s_addm : s_add;
                 fr_t cb = fr_sub(fr_sub(p1, ca), cc);
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     if (collapse[b]) add_term = fr_add(add_term, s_prod[b]);
                 s_add = add_term;
                 if (a.with_add_term) { cb = fr_sub(cb, add_term); cc = fr_add(cc, add_term); }
-                fr_store(&a.out->poly[k][0], ca);
-                fr_store(&a.out->poly[k][1], cb);
-                fr_store(&a.out->poly[k][2], cc);
-                // chain step on the 96 bytes of (a, b, c) as they lie in memory, then the challenge
-                uint32_t st[8];
+                const bool last = k == a.rounds - 1;
+                if (LIVE) {
+                    tail_out *o = a.out;
+                    if (last) {
+                        // what the host needs after the phase: posted (and acknowledged) BEFORE the last round's mailbox message
+                        fr_store_scoped(&o->add_term, add_term, true);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) st[i] = s_state[i];
-                const fr_t ch = fs_round_challenge(st, ca, cb, cc);
-                s_r = ch;
-                fr_store(&a.out->chal[k], ch);
+                        for (int b = 0; b < 2; ++b) {
+                            uint32_t ps = pstate[b];
+                            if (collapse[b]) ps = 2;
+                            __hip_atomic_store(&o->pair_state[b], ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            if (ps == 1) { fr_store_scoped(&o->tail_v[b][0], s_tail[b][0], true); fr_store_scoped(&o->tail_v[b][1], s_tail[b][1], true); }
+                            if (ps == 2) fr_store_scoped(&o->final_v[b], s_fin[b], true);
+                        }
+                        ZK_WAIT_STORES();
+                    }
+                    uint32_t w24[24];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) s_state[i] = st[i];
+                    for (int i = 0; i < 8; ++i) { w24[i] = ca.v[i]; w24[8 + i] = cb.v[i]; w24[16 + i] = cc.v[i]; }
+                    const uint32_t sq = a.seq32 + (uint32_t) k;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        zk_u32x4 ch = {w24[3 * j], w24[3 * j + 1], w24[3 * j + 2], sq};
+                        store16_sys(&o->live.c[j][0], ch);
+                    }
+                    if (!last) {
+                        // the verifier's challenge for this polynomial
+                        const uint32_t want = sq + 1;
+                        const unsigned long long t0 = wall_clock64();
+                        for (;;) {
+                            zk_u32x4 c0, c1, c2;
+                            load48_sys(a.in, c0, c1, c2);
+                            if (c0.w == want && c1.w == want && c2.w == want) {
+                                fr_t ch;
+                                ch.v[0] = c0.x; ch.v[1] = c0.y; ch.v[2] = c0.z; ch.v[3] = c1.x; ch.v[4] = c1.y; ch.v[5] = c1.z; ch.v[6] = c2.x; ch.v[7] = c2.y;
+                                s_r = ch;
+                                break;
+                            }
+                            if (c0.w == TAIL_ABORT) { s_stop = 1; break; }
+                            if (wall_clock64() - t0 > TAIL_TIMEOUT_TICKS) { s_stop = 2; break; }
+                        }
+                    }
+                } else {
+                    fr_store(&a.out->poly[k][0], ca);
+                    fr_store(&a.out->poly[k][1], cb);
+                    fr_store(&a.out->poly[k][2], cc);
+                    // chain step on the 96 bytes of (a, b, c) as they lie in memory, then the challenge
+                    uint32_t st[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) st[i] = s_state[i];
+                    const fr_t ch = fs_round_challenge(st, ca, cb, cc);
+                    s_r = ch;
+                    fr_store(&a.out->chal[k], ch);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) s_state[i] = st[i];
+                }
             }
         }
         __syncthreads();
+        if (LIVE && s_stop) {
+            if (tid == 0) __hip_atomic_store(&a.out->status, (uint32_t) s_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             if (!n[b]) continue;
@@ -217,14 +314,14 @@ __global__ void __launch_bounds__(FS_TAIL_THREADS) k_fs_tail(tail_args a) {
         }
         first = false;
     }
-    if (tid == 0) {
+    if (!LIVE && tid == 0) {
         tail_out *o = a.out;
         fr_store(&o->add_term, s_add);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             o->pair_state[b] = pstate[b];
             if (pstate[b] == 1) { fr_store(&o->tail_v[b][0], s_tail[b][0]); fr_store(&o->tail_v[b][1], s_tail[b][1]); }
-            if (pstate[b] == 2) fr_store(&o->final_v[b], s_fin[b][0]);
+            if (pstate[b] == 2) fr_store(&o->final_v[b], s_fin[b]);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) o->fs_state[i] = s_state[i];
@@ -232,7 +329,6 @@ __global__ void __launch_bounds__(FS_TAIL_THREADS) k_fs_tail(tail_args a) {
         *((volatile unsigned long long *) &o->seq) = a.seq;
     }
 }
-
 
 // Hybrid tail: the live tables of a phase (at most 256 entries each) to mapped host memory in one small launch; seq is written last.
 struct export_out { fr_t V[2][256], M[2][256]; unsigned long long seq; };

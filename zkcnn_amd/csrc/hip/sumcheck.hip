@@ -9,6 +9,7 @@
 #include <cmath>
 #include <atomic>
 #include <cstring>
+#include <emmintrin.h>
 #include "ctx.hpp"
 #include "kernels.cuh"
 #include "fs_tail.cuh"
@@ -88,7 +89,9 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
         hipMemsetAsync(ctx->d_counter, 0, 64, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
         hipHostMalloc((void **) &ctx->h_result, 32 * 32) != hipSuccess ||
         hipHostMalloc((void **) &ctx->h_tail, std::max(sizeof(tail_out), sizeof(export_out)), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-        hipHostGetDevicePointer(&ctx->d_tail, ctx->h_tail, 0) != hipSuccess) {
+        hipHostGetDevicePointer(&ctx->d_tail, ctx->h_tail, 0) != hipSuccess ||
+        hipHostMalloc((void **) &ctx->h_live_in, sizeof(live_in), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&ctx->d_live_in, ctx->h_live_in, 0) != hipSuccess) {
         g_create_err = ctx->err.empty() ? "allocation failed" : ctx->err;
         zk_ctx_destroy(ctx);
         return ZK_ERR_NOMEM;
@@ -96,6 +99,7 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
     std::memset((void *) ctx->h_slot, 0, sizeof(*ctx->h_slot));
     std::memset((void *) ctx->h_aux, 0, sizeof(*ctx->h_aux));
     std::memset(ctx->h_tail, 0, std::max(sizeof(tail_out), sizeof(export_out)));
+    std::memset(ctx->h_live_in, 0, sizeof(live_in));
     *out = ctx;
     return ZK_OK;
 }
@@ -103,6 +107,7 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
 extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (ctx->live_active) (void) zk_live_abort(ctx);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->n_seg) fprintf(stderr, "[zkcnn timing] quadratic round call: %.2f us between calls (verifier + wrappers), %.2f plan + launch, %.2f waiting for the result, %.2f after (averages over %llu rounds)\n",
                             1e6 * ctx->t_seg[0] / ctx->n_seg, 1e6 * ctx->t_seg[1] / ctx->n_seg, 1e6 * ctx->t_seg[2] / ctx->n_seg, 1e6 * ctx->t_seg[3] / ctx->n_seg, (unsigned long long) ctx->n_seg);
@@ -117,6 +122,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     if (ctx->h_slot) hipHostFree((void *) ctx->h_slot);
     if (ctx->h_aux) hipHostFree((void *) ctx->h_aux);
     if (ctx->h_tail) hipHostFree(ctx->h_tail);
+    if (ctx->h_live_in) hipHostFree(ctx->h_live_in);
     if (ctx->h_liu_tabs) hipHostFree(ctx->h_liu_tabs);
     if (ctx->h_wp_ranges) hipHostFree(ctx->h_wp_ranges);
     if (ctx->h_conv_tabs) hipHostFree(ctx->h_conv_tabs);
@@ -173,10 +179,16 @@ extern "C" int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries) {
     ctx->host_tail_log = log_entries < 0 ? -1 : log_entries;
     return ZK_OK;
 }
+extern "C" int32_t zk_set_live_rounds(zk_ctx *ctx, int32_t on) {
+    if (!ctx) return ZK_ERR_ARG;
+    if (ctx->live_active) { int32_t rc = zk_live_abort(ctx); if (rc) return rc; }
+    ctx->live_rounds = on != 0;
+    return ZK_OK;
+}
 extern "C" int32_t zk_fs_stats(zk_ctx *ctx, uint64_t *rounds, uint64_t *phases) {
     if (!ctx || !rounds || !phases) return ZK_ERR_ARG;
-    *rounds = ctx->tail_rounds_total;
-    *phases = ctx->tail_phases_total;
+    *rounds = ctx->tail_rounds_total + ctx->live_rounds_total;
+    *phases = ctx->tail_phases_total + ctx->live_phases_total;
     return ZK_OK;
 }
 
@@ -901,7 +913,9 @@ static int32_t fold_pair(zk_ctx *ctx, table_pair &t, const HFr &r, bool with_m) 
 // ------------------------------------------------------------------------------------------------
 // state machine
 // ------------------------------------------------------------------------------------------------
-#define CHECK_READY() do { if (!ctx || !ctx->circuit_ready) return ZK_ERR_STATE; ZK_HIP(hipSetDevice(ctx->device)); } while (0)
+// every entry point but the three round calls first sends a resident round kernel home (its phase was abandoned)
+#define CHECK_READY_ROUND() do { if (!ctx || !ctx->circuit_ready) return ZK_ERR_STATE; ZK_HIP(hipSetDevice(ctx->device)); } while (0)
+#define CHECK_READY() do { CHECK_READY_ROUND(); if (ctx->live_active) { int32_t rc_ = zk_live_abort(ctx); if (rc_) return rc_; } } while (0)
 static inline const HFr &H(const uint64_t *p) { return *reinterpret_cast<const HFr *>(p); }
 static inline void put(uint64_t *dst, const HFr &x) { std::memcpy(dst, &x, 32); }
 
@@ -1321,7 +1335,7 @@ static int32_t run_device_rounds(zk_ctx *ctx, const HFr &r, bool with_add_term) 
     std::memcpy(A.fs_state, ctx->fs_state, 32);
     A.out = (tail_out *) ctx->d_tail;
     A.seq = seq;
-    ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_fs_tail, dim3(1), dim3(FS_TAIL_THREADS), A);
+    ZK_LAUNCH(PC_TAIL, 0.0, k_tail<false>, dim3(1), dim3(TAIL_THREADS), A);
     ZK_HIP(hipGetLastError());
     volatile unsigned long long *p = &((tail_out *) ctx->h_tail)->seq;
     for (uint64_t spins = 0; *p != seq; ++spins) {
@@ -1356,6 +1370,124 @@ static int32_t run_device_rounds(zk_ctx *ctx, const HFr &r, bool with_add_term) 
     ctx->last_poly_valid = false;          // (the rounds answered from the record do not maintain the running claim)
     ctx->tail_rounds_total += (uint64_t) ctx->tail_count;
     ++ctx->tail_phases_total;
+    return ZK_OK;
+}
+
+// ---- persistent rounds of the INTERACTIVE protocol (k_tail<true>, fs_tail.cuh): the kernel is resident for the rest of the phase, a round is
+// "challenge into the mailbox, polynomial out of the mailbox" ----
+static inline void live_post(zk_ctx *ctx, const HFr &r, uint32_t seq) {
+    uint32_t w[8];
+    std::memcpy(w, &r, 32);
+    live_in *m = (live_in *) ctx->h_live_in;
+    // one 16-byte store per chunk (the kernel reads a chunk with one 16-byte load and checks the number in each)
+    _mm_store_si128((__m128i *) m->c[0], _mm_set_epi32((int) seq, (int) w[2], (int) w[1], (int) w[0]));
+    _mm_store_si128((__m128i *) m->c[1], _mm_set_epi32((int) seq, (int) w[5], (int) w[4], (int) w[3]));
+    _mm_store_si128((__m128i *) m->c[2], _mm_set_epi32((int) seq, 0, (int) w[7], (int) w[6]));
+    _mm_sfence();
+}
+int32_t zk_live_abort(zk_ctx *ctx) {
+    if (!ctx->live_active) return ZK_OK;
+    live_post(ctx, HFr(0LL), TAIL_ABORT);
+    ctx->live_active = false;
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    std::memset(ctx->h_live_in, 0, sizeof(live_in));
+    for (int b = 0; b < 2; ++b) ctx->tp[b].len = 0;
+    return ZK_OK;
+}
+// waits for the polynomial of round k of the running kernel; false if the kernel has left (status) or nothing arrives
+static int32_t live_wait(zk_ctx *ctx, int k, uint64_t out_abc[12]) {
+    const tail_out *o = (const tail_out *) ctx->h_tail;
+    const uint32_t want = ctx->live_seq32 + (uint32_t) k;
+    uint32_t w[24];
+    for (uint64_t spins = 0;; ++spins) {
+        bool ok = true;
+        for (int j = 0; j < 8; ++j) {
+            const __m128i c = _mm_load_si128((const __m128i *) o->live.c[j]);
+            alignas(16) uint32_t t[4];
+            _mm_store_si128((__m128i *) t, c);
+            if (t[3] != want) { ok = false; break; }
+            w[3 * j] = t[0]; w[3 * j + 1] = t[1]; w[3 * j + 2] = t[2];
+        }
+        if (ok) break;
+        if (spins > (1ull << 16) && (spins & 1023) == 0) {
+            if (*(volatile const uint32_t *) &o->status != 0 || hipStreamQuery(ctx->stream) == hipSuccess) {
+                // (a kernel that has left: one last look, its final message may have landed after the check above)
+                bool late = true;
+                for (int j = 0; j < 8; ++j) if (((volatile const uint32_t *) o->live.c[j])[3] != want) late = false;
+                if (late) continue;
+                ctx->live_active = false;
+                ctx->err = "the resident round kernel left before the phase was over";
+                return ZK_ERR_STATE;
+            }
+            if (spins > (1ull << 22)) sched_yield();
+        } else __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    std::memcpy(out_abc, w, 96);
+    return ZK_OK;
+}
+static int32_t live_start(zk_ctx *ctx, const HFr &r, bool with_add_term) {
+    tail_args A;
+    std::memset(&A, 0, sizeof(A));
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        if (!t.len) continue;
+        A.Vin[b] = vin(t); A.Min[b] = t.M[t.cur];
+        A.Vbuf[b][0] = t.V[0]; A.Vbuf[b][1] = t.V[1];
+        A.Mbuf[b][0] = t.M[0]; A.Mbuf[b][1] = t.M[1];
+        A.out_idx[b] = t.cur ^ 1;
+        A.n[b] = t.len;
+    }
+    A.first = ctx->round == 0 ? 1 : 0;
+    A.rounds = ctx->phase_rounds - ctx->round;
+    A.with_add_term = with_add_term ? 1 : 0;
+    A.prev_r = to_dev(r);
+    A.add_term = to_dev(ctx->add_term);
+    A.out = (tail_out *) ctx->d_tail;
+    A.in = (const live_in *) ctx->d_live_in;
+    // sequence numbers of this kernel's rounds: never 0 (a cleared mailbox), never the abort word, never one of the previous kernel's
+    ctx->live_seq32 += 64;
+    if (ctx->live_seq32 > 0xf0000000u) ctx->live_seq32 = 64;
+    A.seq32 = ctx->live_seq32;
+    ((tail_out *) ctx->h_tail)->status = 0;
+    ZK_LAUNCH(PC_TAIL, 0.0, k_tail<true>, dim3(1), dim3(TAIL_THREADS), A);
+    ZK_HIP(hipGetLastError());
+    ctx->live_active = true;
+    ctx->live_count = A.rounds;
+    ctx->live_cursor = 0;
+    ctx->last_poly_valid = false;          // (these rounds do not maintain the running claim)
+    ctx->live_rounds_total += (uint64_t) A.rounds;
+    ++ctx->live_phases_total;
+    return ZK_OK;
+}
+// one round of the resident kernel: r is the verifier's challenge for the previous polynomial (round 0 of the kernel got it as a launch argument)
+static int32_t live_round(zk_ctx *ctx, const HFr &r, uint64_t out_abc[12]) {
+    const int k = ctx->live_cursor;
+    if (k > 0) live_post(ctx, r, ctx->live_seq32 + (uint32_t) k);
+    int32_t rc = live_wait(ctx, k, out_abc);
+    if (rc) return rc;
+    ++ctx->round;
+    ctx->proof_size += 32 * 3;
+    if (++ctx->live_cursor < ctx->live_count) return ZK_OK;
+    // the phase is over: the kernel has posted the bookkeeping scalar and what is left of the tables before its last polynomial, and leaves
+    const tail_out *o = (const tail_out *) ctx->h_tail;
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        if (!t.len) continue;
+        t.Vsrc = nullptr;
+        if (o->pair_state[b] == 1) {
+            t.len = 2;
+            std::memcpy(&t.tail_v[0], &o->tail_v[b][0], 32);
+            std::memcpy(&t.tail_v[1], &o->tail_v[b][1], 32);
+            t.tail_valid = true;
+        } else {
+            t.len = 0;
+            t.absorbed = true;
+            std::memcpy(&t.final_v, &o->final_v[b], 32);
+        }
+    }
+    std::memcpy(&ctx->add_term, &o->add_term, 32);
+    ctx->live_active = false;
     return ZK_OK;
 }
 
@@ -1461,6 +1593,14 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         int32_t rc = run_device_rounds(ctx, r, with_add_term);
         if (rc) return rc;
     }
+    // interactive protocol: a resident kernel for the rest of the phase once the tables are small (zk_set_live_rounds)
+    if (ctx->live_rounds && !ctx->fs_state && ctx->host_tail_log < 0 && !ctx->live_active && ctx->phase_rounds > ctx->round &&
+        ctx->tp[0].len + ctx->tp[1].len > 0 && round_quads <= TAIL_QUADS) {
+        int32_t rc = resolve_add_term(ctx);
+        if (!rc) rc = live_start(ctx, r, with_add_term);
+        if (rc) return rc;
+    }
+    if (ctx->live_active) return live_round(ctx, r, out_abc);
     if (ctx->tail_active) {
         const tail_out *o = (const tail_out *) ctx->h_tail;
         const int k = ctx->tail_cursor;
@@ -1590,17 +1730,17 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
 }
 
 extern "C" int32_t zk_sumcheck_update1(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t out_abc[12]) {
-    CHECK_READY();
+    CHECK_READY_ROUND();
     if (ctx->round) ctx->r_u[ctx->sumcheck_id].at(ctx->round - 1) = H(prev_r);
     return quad_round(ctx, H(prev_r), true, out_abc);
 }
 extern "C" int32_t zk_sumcheck_update2(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t out_abc[12]) {
-    CHECK_READY();
+    CHECK_READY_ROUND();
     if (ctx->round) ctx->r_v[ctx->sumcheck_id].at(ctx->round - 1) = H(prev_r);
     return quad_round(ctx, H(prev_r), true, out_abc);
 }
 extern "C" int32_t zk_sumcheck_liu_update(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t out_abc[12]) {
-    CHECK_READY();
+    CHECK_READY_ROUND();
     return quad_round(ctx, H(prev_r), false, out_abc);
 }
 
@@ -1720,7 +1860,7 @@ extern "C" int32_t zk_sumcheck_liu_finalize(zk_ctx *ctx, const uint64_t prev_r[4
 // ------------------------------------------------------------------------------------------------
 // kernel-level entry points (host arrays in / out)
 // ------------------------------------------------------------------------------------------------
-#define CHECK_CTX() do { if (!ctx) return ZK_ERR_ARG; ZK_HIP(hipSetDevice(ctx->device)); } while (0)
+#define CHECK_CTX() do { if (!ctx) return ZK_ERR_ARG; ZK_HIP(hipSetDevice(ctx->device)); if (ctx->live_active) { int32_t rc_ = zk_live_abort(ctx); if (rc_) return rc_; } } while (0)
 
 template <int OP>
 static int32_t binop(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n) {

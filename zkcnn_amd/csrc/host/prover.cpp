@@ -52,6 +52,9 @@ void prover::attachFiatShamir(const uint32_t *state, const uint64_t *pending) {
     if (!ctx) return;
     check(zk_fs_attach(ctx, state, pending), "zk_fs_attach");
 }
+void prover::setLiveRounds(bool on) {
+    if (ctx) check(zk_set_live_rounds(ctx, on ? 1 : 0), "zk_set_live_rounds");
+}
 void prover::setHostTail(int log_entries) {
     if (ctx) check(zk_set_host_tail(ctx, log_entries), "zk_set_host_tail");
 }

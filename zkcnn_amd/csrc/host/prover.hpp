@@ -71,6 +71,7 @@ public:
     void attachFiatShamir(const uint32_t *state, const uint64_t *pending);
     void tailStats(uint64_t &rounds, uint64_t &phases) const;
     void setHostTail(int log_entries);          // hybrid tail (include/zkcnn_hip.h: zk_set_host_tail); < 0 = off
+    void setLiveRounds(bool on);                // resident round kernel of the interactive protocol (include/zkcnn_hip.h: zk_set_live_rounds)
 
     // ---- the next picture on the resident circuit (include/zkcnn_hip.h: zk_witness_program_upload / zk_witness_rerun). The program is
     // what the circuit generator recorded (host/neuralNetwork.hpp: witnessProgram, records layout-equal to the C-ABI's). After a rerun
@@ -104,6 +105,7 @@ private:
 // session.hpp calls this for whatever prover type it drives; only the HIP-backed prover can continue the chain on its own
 inline void attachFsChain(prover &p, const uint32_t *state, const uint64_t *pending) { p.attachFiatShamir(state, pending); }
 inline void setHostTail(prover &p, int log_entries) { p.setHostTail(log_entries); }
+inline void setLiveRounds(prover &p, bool on) { p.setLiveRounds(on); }
 template <class H> inline void setConvHints(prover &p, const std::vector<H> &hints) {
     static_assert(sizeof(H) == sizeof(zk_conv_hint), "convolution hints cross the C-ABI as they are");
     p.setConvHints(reinterpret_cast<const zk_conv_hint *>(hints.data()), hints.size());

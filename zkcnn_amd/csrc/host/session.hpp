@@ -12,6 +12,7 @@
 // provers that can continue the Fiat-Shamir chain themselves (the HIP-backed one: prover.hpp) overload this; everybody else ignores it
 template <class P> inline void attachFsChain(P &, const uint32_t *, const uint64_t *) {}
 template <class P> inline void setHostTail(P &, int) {}
+template <class P> inline void setLiveRounds(P &, bool) {}
 template <class P, class H> inline void setConvHints(P &, const std::vector<H> &) {}
 
 template <class ProverT>
@@ -93,6 +94,8 @@ struct sessionT {
         if (mode & ZKCNN_MODE_SEEDED) { Fr::seedCSPRNG(challenge_seed); zkff::privateCoins().seed(challenge_seed); }
         else { Fr::useOsRandom(); zkff::privateCoins().useOsRandom(); }
         v.zk = zk;
+        // ZKCNN_MODE_HOST_ROUNDS: every sumcheck round is a kernel launch driven from here (no resident round kernel, no device-side Fiat-Shamir rounds)
+        setLiveRounds(p, !(mode & ZKCNN_MODE_HOST_ROUNDS));
         setHostTail(p, (mode & ZKCNN_MODE_HOST_TAIL) ? 6 : -1);      // hybrid tail: tables of <= 64 entries finish their phase on the host
         const zkff::publicGenerators *pg = nullptr;
         if (public_gens) {
