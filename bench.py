@@ -49,13 +49,7 @@ WORKLOADS = {
     # vgg11 with every channel width halved (1/4 of the multiplication gates): ~7 s of CPU prover time on one core
     "vgg11_half": ("vgg:32 M 64 M 128 128 M 256 256 M 256 256 M", (32, 32, 3), 1),
 }
-# HBM bytes per launch of a kernel class from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, separate passes,
-# scripts/pmc_proof.sh): r02t_vgg11_pmc_traffic.md: (5.10 + 1.83 + 53.74 + 20.32) GB over 7976 + 1067 launches of k_round_quad_fine / 2;
-# r01g_vgg11_pp8_pmc_traffic.md likewise. None where no PMC pass exists for the (workload, class). Constants of those passes, not measured in a bench run.
-PMC_TRAFFIC_PER_LAUNCH = {("vgg11", "round_quad"): (5.10 + 1.83 + 53.74 + 20.32) * 1e9 / (7976 + 1067),      # profiles/r02t_vgg11_pmc_traffic.md
-                           ("vgg11_pp8", "round_quad"): (6.50 + 2.55 + 299.46 + 105.63) * 1e9 / (10000 + 2312)}
 # kernel classes whose algorithmic byte count is defined; the dominant one is reported
-STREAMING_PMC_BYTES = 1.7037e9      # profiles/r01_round_quad_kernel.md (FETCH_SIZE x2 + WRITE_SIZE) for 2 x 2^24 entries
 ROOFLINE_CLASSES = ["gate_reduce", "round_quad", "round_cubic", "msm_planes"]
 DATA_SEED = 20260928         # synthetic picture + weights
 PARITY_SEED = 0x5EED0001     # challenge stream of the proof whose transcript is compared with the CPU oracle's, byte for byte
@@ -70,6 +64,59 @@ def launch_command(argv, n_gpus, port=None, python=None):
             port = sk.getsockname()[1]
     return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
             "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+# kernels behind each byte-counted class of the built-in profiler (names as rocprofv3 reports them)
+CLASS_KERNELS = {"round_quad": ("k_round_quad2", "k_round_quad_fine"), "round_tail": ("k_tail",), "round_cubic": ("k_round_cubic",),
+                 "gate_reduce": ("k_gate_multi", "k_conv_wa", "k_conv_m1", "k_conv_e", "k_conv_ae", "k_conv_m2"),
+                 "msm_planes": ("k_msm_codes", "k_msm_windows", "k_msm_planes", "k_scalar_codes", "k_scalar_mags", "k_bit_masks", "k_compact_flags")}
+
+
+def measure_pmc_traffic(workload, kernels, timeout_s=240):
+    """HBM bytes per launch of `kernels`, measured NOW: two short child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE
+    in separate passes, as MI355X_MICROARCH.md prescribes: they do not fit one pass; KB counters; FETCH_SIZE doubled -- gfx950 tallies the 128-byte
+    requests of wide coalesced reads at 64 bytes). One session, a few proofs. None if rocprofv3 is missing or anything goes wrong."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    total, launches = {}, 0
+    try:
+        for counter, scale in (("FETCH_SIZE", 2 * 1024.0), ("WRITE_SIZE", 1024.0)):
+            with tempfile.TemporaryDirectory(prefix="zkcnn_pmc_") as tmp:
+                cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
+                       sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", workload]
+                env = dict(os.environ, TMPDIR=tmp)
+                env.pop("RANK", None)
+                subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
+                val, n = 0.0, 0
+                for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if r.get("Counter_Name") != counter:
+                            continue
+                        name = r["Kernel_Name"].replace("void ", "")
+                        if any(name.startswith(k) for k in kernels):
+                            val += float(r["Counter_Value"])
+                            n += 1
+                if not n:
+                    return None
+                total[counter], launches = val * scale, n
+        return {"bytes_per_launch": (total["FETCH_SIZE"] + total["WRITE_SIZE"]) / launches, "fetch_bytes_x2": total["FETCH_SIZE"], "write_bytes": total["WRITE_SIZE"],
+                "launches": launches, "kernels": list(kernels)}
+    except Exception:       # noqa: BLE001 - an optional measurement
+        return None
+
+
+def pmc_child(workload):
+    """what measure_pmc_traffic profiles: one session, four proofs in the modes of the timed steps"""
+    import zkcnn_amd
+    model, pic, pp = WORKLOADS[workload]
+    with zkcnn_amd.Session(model, pic, pp, data_seed=DATA_SEED) as s:
+        for k in range(4):
+            s.prove(seed=0x5EED3000 + k, mode=zkcnn_amd.MODE_DRIVE_ONLY | zkcnn_amd.MODE_REUSE_GENS, want_transcript=False)
 
 
 HOST_BYTES_PER_SESSION = 6e9      # a vgg11 session holds 2.7 GB on the host, 4.3 GB at its peak while it is built (host_peak_rss_gb_while_building)
@@ -147,13 +194,18 @@ def main():
     ap.add_argument("--cpu-sample", default=None, choices=sorted(WORKLOADS), help="CPU baseline workload (default: the bench workload itself)")
     ap.add_argument("--cpu-procs", type=int, default=8, help="independent CPU provers run side by side for the host throughput figure (0 = skip)")
     ap.add_argument("--hybrid-tail", action="store_true", help="timed proofs with ZKCNN_MODE_HOST_TAIL (experiment; not the headline configuration)")
+    ap.add_argument("--host-rounds", action="store_true", help="timed proofs with ZKCNN_MODE_HOST_ROUNDS: a kernel launch per round, no resident round kernel (experiment)")
     ap.add_argument("--fiat-shamir", action="store_true", help="timed proofs non-interactive (device-side rounds; experiment)")
     ap.add_argument("--no-companions", action="store_true", help="skip the extra single-stream measurements of other modes (profiling runs)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel-class table of one extra proof to stderr")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="REHEARSAL of the multi-rank path on a box with fewer GPUs than ranks: ranks share GPUs (rank %% GPUs) and exchange over gloo "
                          "(RCCL refuses two ranks on one device). Not a scaling measurement; the line says so")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args.workload)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     self_launch_if_needed(args, sys.argv[1:])
@@ -202,6 +254,8 @@ def main():
         drive |= zkcnn_amd.MODE_HOST_TAIL
     if args.fiat_shamir:
         drive |= zkcnn_amd.MODE_FIAT_SHAMIR
+    if args.host_rounds:
+        drive |= zkcnn_amd.MODE_HOST_ROUNDS
 
     def in_threads(fn):
         """fn(i) for every stream i on its own host thread (the C calls release the GIL); re-raises the first failure"""
@@ -222,25 +276,36 @@ def main():
     t0 = time.time()
     sessions = [None] * K
 
+    # One model = one circuit: every session of the job proves pictures under the SAME weights (data seed) and quantisation scales. Session 0 is
+    # built from the data; the others are built for the same statement (calibrated: circuit + witness under session 0's scales) and ATTACH to the
+    # circuit already resident on the GPU -- no second gate sort / upload, one set of generator tables per GPU -- and then take pictures of their
+    # own through new_image below. (Rounds 1-2 built K unrelated circuits per GPU: K uploads of 1.9 GB, K byte tables of 3.2 GB.)
     def build(i):
-        sessions[i] = zkcnn_amd.Session(model, pic, pp, data_seed=DATA_SEED + rank * K + i, device=local_rank)
-    # Large single-circuit workloads do not fit 8 times: a probe session measures what one costs in HBM (tables + circuit now; the MSM
-    # byte table and scratch come with the first proofs, hence the margin) and is closed again. All K sessions are then built side by
-    # side -- with the sessions created one after the other the same 8 streams reach 51 instead of 59 proofs/s, reproducibly
-    # (scripts/exp/bench_variants.py: plain vs allseq; GPU_MAX_HW_QUEUES = 1 / 2 / 3 / 4 / 8 gives 28 / 44 / 51 / 59 / 45-51, so how
-    # HIP maps the streams to hardware queues matters, but the creation-order effect itself is not explained).
-    if pp > 1 or "vgg16" in model:
-        free0, _ = torch.cuda.mem_get_info(local_rank)
-        build(0)
-        free1, _ = torch.cuda.mem_get_info(local_rank)
-        sessions[0].close()
-        sessions[0] = None
-        per_session = max(free0 - free1, 1) * 1.6 + 4e9
-        K_fit = max(1, int(0.9 * free0 / per_session))
+        sessions[i] = zkcnn_amd.Session(model, pic, pp, data_seed=DATA_SEED, device=local_rank, calibrated=stmt if i else None)
+    # Large single-circuit workloads: a probe of what one more session costs in HBM (values, tables, scratch: the circuit is shared)
+    stmt = None
+    free0, _ = torch.cuda.mem_get_info(local_rank)
+    build(0)
+    stmt = sessions[0].statement()
+    first_session_s = time.time() - t0
+    free1, _ = torch.cuda.mem_get_info(local_rank)
+    if K > 1:
+        build(1)
+        free2, _ = torch.cuda.mem_get_info(local_rank)
+        per_extra = max(free1 - free2, 1)
+        K_fit = 2 + max(0, int((0.85 * free2 - 8e9) / (per_extra * 1.3)))          # margin: MSM scratch and the byte table come with the first proofs
         if K_fit < K:
+            print(f"[bench] HBM allows {K_fit} sessions of this workload, not the {K} asked for", file=sys.stderr)
             K = K_fit
             sessions = sessions[:K]
-    in_threads(build)
+    else:
+        free2, per_extra = free1, 0
+    hbm_first_gb, hbm_extra_gb = round((free0 - free1) / 1e9, 2), round(per_extra / 1e9, 2)
+
+    def build_rest(i):
+        if i >= 2:
+            build(i)
+    in_threads(build_rest)
     if any(x is None for x in sessions):
         raise SystemExit("a session could not be built")
     setup_s = time.time() - t0
@@ -252,6 +317,37 @@ def main():
         host_peak_gb = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024 / 1e9, 2)     # peak while they were being built side by side
     except Exception:       # noqa: BLE001
         host_rss_gb = host_peak_gb = None
+
+    # ---- a picture of its own for every session but the first (which keeps the data stream's picture: the parity proof below is compared with
+    # the CPU oracle's): the recorded witness program replays in HBM (zkcnn_session_new_image); pictures whose activation ranges ask for other
+    # quantisation scales than the circuit's are refused and the next seed is tried ----
+    valid = [[] for _ in range(K)]
+    tried = [0] * K
+
+    def scan(i):
+        p = 0
+        while len(valid[i]) < 2 and p < 32:
+            p += 1
+            seed = 100000 * (rank * K + i + 1) + p
+            if sessions[i].new_image(seed)[0] == 0:
+                valid[i].append(seed)
+        tried[i] = p
+        if len(valid[i]) < 2:
+            raise RuntimeError("no two pictures with the circuit's quantisation scales among 32")
+        sessions[i].new_image(valid[i][0])
+
+    def scan_rest(i):
+        if i:
+            scan(i)
+    t_scan = time.time()
+    if pp == 1:                         # (new pictures for one-picture circuits; a pic_cnt > 1 circuit keeps the batch it was built for)
+        try:
+            in_threads(scan_rest)
+        except Exception as e:          # noqa: BLE001 - the sessions then all prove the first picture: say so
+            print(f"[bench] no distinct pictures: {e}", file=sys.stderr)
+            valid = [[] for _ in range(K)]
+    t_scan = time.time() - t_scan
+    distinct_pictures = all(len(v) >= 2 for v in valid[1:])
 
     # ---- warm-up: first step with the full verifier on every image (acceptance), the rest as the timed steps run ----
     firsts = [None] * K
@@ -382,22 +478,9 @@ def main():
     new_image = {}
     if rank == 0 and world == 1 and not args.no_companions:          # companions belong to the single-GPU line (like the CPU baseline)
         try:
-            valid = [[] for _ in range(K)]
-            tried = [0] * K
-
-            def scan(i):
-                p = 0
-                while len(valid[i]) < 2 and p < 24:
-                    p += 1
-                    seed = 100000 * (i + 1) + p
-                    if sessions[i].new_image(seed)[0] == 0:
-                        valid[i].append(seed)
-                tried[i] = p
-                if len(valid[i]) < 2:
-                    raise RuntimeError("no two pictures with the circuit's quantisation scales among 24")
-            t_scan = time.time()
-            in_threads(scan)
-            t_scan = time.time() - t_scan
+            if not distinct_pictures or pp != 1:
+                raise RuntimeError("no pictures with the circuit's scales were found")
+            scan(0)                   # (session 0 kept the data stream's picture until here: its parity proof is behind us)
             single = sorted(sess.new_image(valid[0][k % 2])[1] for k in range(7))
             ni_last = [None] * K
 
@@ -427,8 +510,7 @@ def main():
         sec = prof["ms"] * 1e-3 / prof["launches"]
         achieved = prof["bytes"] / prof["launches"] / sec / 1e9
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_PER_LAUNCH.get((args.workload, dominant)),
-                    "traffic_source": "PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; see PMC_TRAFFIC_PER_LAUNCH) -- a constant from that pass, not measured in this run",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "avg_launch_ms": round(sec * 1e3, 4), "launches_per_step": prof["launches"] / EVENT_STEPS,
                     "note": f"HIP events on stream 0 of {K} streams during its first {EVENT_STEPS} timed proofs: launch durations include contention between the streams",
                     "algorithmic_bytes_per_launch": prof["bytes"] / prof["launches"],
@@ -450,7 +532,6 @@ def main():
             roofline["streaming_launch"] = {"kernel": "k_round_quad2 (the product round kernel: fold + sums + grid finish + host slot), V and M of 2^24 entries", "ms": round(sec * 1e3, 4),
                                             "algorithmic_bytes": nbytes, "achieved": round(nbytes / sec / 1e9, 1),
                                             "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
-                                            "traffic_pmc_bytes": STREAMING_PMC_BYTES, "traffic_source": "profiles/ PMC pass of this launch (constant, not measured in this run)",
                                             "fr_mul_ceiling_G_per_s": round((1 << 20) * 256 / mul_sec / 1e9, 1)}
         except Exception as e:      # the headline numbers do not depend on this extra measurement
             roofline["streaming_launch"] = {"error": str(e)}
@@ -497,6 +578,43 @@ def main():
         extras["companions_error"] = str(e)
     sess.close()
     sess = None
+
+    # ---- the roof that binds: this is integer modular arithmetic, and on this workload (a CIFAR-sized circuit: ~1.1 k interactive rounds, most
+    # of them on small tables) the dominant class is bound by LATENCY -- dependent field products and the round hand-over -- not by HBM or by
+    # the multiplier. Reported: HBM fraction of the dominant class (above), measured HBM traffic of that class, and the fraction of the
+    # integer-multiplier ceiling the whole proof reaches (Fr-multiply equivalents per proof / proofs per second / measured ceiling). ----
+    if roofline is not None:
+        mul_ceiling = (roofline.get("streaming_launch") or {}).get("fr_mul_ceiling_G_per_s")
+        bytes_of = {c: table[c]["bytes"] for c in ROOFLINE_CLASSES}
+        # Fr-multiply equivalents of one proof from the algorithmic byte counts the library keeps per launch -- a LOWER bound, classes
+        # without a byte count (small convolution kernels, the opening's tiny MSMs) are left out:
+        #   fold rounds: 96 B per entry per round = 1.5 products (4 lerps + 2..3 products per 4-entry quad); cubic rounds 1.75
+        #   gate sums: 80 B per multiplication gate = ~1.5 products (the gather operand, the scale)
+        #   eq tables: ~2 products per entry of every layer table (one per claim point); commitment: one mixed addition = 11 Fp products
+        #   (12-limb: 288 + 288 MACs against the 136 + 136 of an Fr product = 2.12 Fr equivalents) per non-zero scalar byte, ~0.72 of the scalars
+        fr_muls = (bytes_of["round_quad"] / 96.0 * 1.5 + bytes_of["round_cubic"] / 96.0 * 1.75 + bytes_of["gate_reduce"] / 80.0 * 1.5 +
+                   2.0 * float(first.table_entries) + bytes_of["msm_planes"] / 32.0 * 0.72 * 11 * 2.12)
+        per_gpu = K * args.steps / elapsed
+        if mul_ceiling:
+            roofline["alu"] = {"fr_mul_equiv_per_proof": round(fr_muls), "ceiling_G_per_s": mul_ceiling,
+                               "frac": round(fr_muls * per_gpu / (mul_ceiling * 1e9), 4),
+                               "frac_single_stream": round(fr_muls / max(lat_prove + lat_poly, 1e-9) / (mul_ceiling * 1e9), 4),
+                               "note": "Fr-multiply equivalents per proof (lower bound from the per-launch algorithmic counts) x proofs/s per GPU over the multiplier "
+                                       "ceiling measured in this run (k_bench_fr_mul: dependent Montgomery products, 8 waves per SIMD)"}
+        small = roofline["frac"] < 0.15 and (not roofline.get("alu") or roofline["alu"]["frac_single_stream"] < 0.5)
+        roofline["bound"] = "latency" if small else roofline["bound"]
+        roofline["bound_note"] = ("per launch the dominant class reaches a few percent of the HBM roof and the proof a fraction of the multiplier ceiling: its launches are "
+                                  "short dependent chains (two to seven Fr products) behind a launch and a host hand-over; the SAME kernel on a 2 x 2^24-entry launch "
+                                  "(streaming_launch) runs at the multiplier ceiling") if small else "see streaming_launch"
+        if world == 1 and not args.no_pmc and dominant in CLASS_KERNELS:
+            pmc = measure_pmc_traffic(args.workload, CLASS_KERNELS[dominant])
+            if pmc:
+                roofline["traffic"] = round(pmc["bytes_per_launch"], 1)
+                roofline["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH doubled, the gfx950 correction of "
+                                              f"MI355X_MICROARCH.md) over {pmc['launches']} launches of {', '.join(pmc['kernels'])} in four single-stream proofs")
+                roofline["traffic_over_algorithmic"] = round(pmc["bytes_per_launch"] / max(lat_prof["bytes"] / max(lat_prof["launches"], 1), 1.0), 3)
+            else:
+                roofline["traffic_source"] = "rocprofv3 not available (or the counter pass failed): not measured"
 
     # ---- CPU baseline: the oracle (port of the reference prover) on the same workload ----
     cpu = None
@@ -559,6 +677,8 @@ def main():
         "prover_ms_per_image_in_flight": round(1e3 * (prove_s + poly_s) / (steps * K), 3),
         "verifier_pass": bool(accepted), "timed_proofs_replay_verified": K, "proof_kb": round(first.proof_kb + first.poly_proof_kb, 1),
         "setup_s": round(setup_s, 1), "witness_s": round(first.witness_s, 1), "upload_sort_s": round(first.upload_s, 2),
+        "upload_sort_s_attached_session": round(firsts[-1].upload_s, 2) if K > 1 else None, "first_session_s": round(first_session_s, 1),
+        "hbm_gb_first_session": hbm_first_gb, "hbm_gb_per_extra_session": hbm_extra_gb, "sharing": zkcnn_amd.sharing_stats(), "distinct_picture_per_session": bool(distinct_pictures),
         "roofline": roofline, "cpu_baseline": cpu,
     }
     out.update(parity)

@@ -347,7 +347,19 @@ class _SessionBase:
 
 
 PROFILE_CLASSES = ["eq_table", "gather", "gate_reduce", "gate_fixup", "gate_sum", "sum_partials", "round_quad", "round_cubic", "fold",
-                   "matvec", "phi", "dot_prod", "liu_scatter", "msm_planes", "msm_finish", "msm_tables", "ipa", "misc"]
+                   "matvec", "phi", "dot_prod", "liu_scatter", "msm_planes", "msm_finish", "msm_tables", "ipa", "misc", "round_tail"]
+
+
+def sharing_stats():
+    """what the sessions of this process share per GPU: resident circuits built / attached to, generator window tables / byte tables built
+    (include/zkcnn_hip.h: zk_sharing_stats, zk_generator_table_stats)"""
+    lib = hip_lib()
+    v = [ctypes.c_uint64() for _ in range(4)]
+    lib.zk_sharing_stats.restype = None
+    lib.zk_generator_table_stats.restype = None
+    lib.zk_sharing_stats(ctypes.byref(v[0]), ctypes.byref(v[1]))
+    lib.zk_generator_table_stats(ctypes.byref(v[2]), ctypes.byref(v[3]))
+    return {"circuit_builds": v[0].value, "circuit_attaches": v[1].value, "window_table_builds": v[2].value, "byte_table_builds": v[3].value}
 
 
 class Session(_SessionBase):

@@ -64,6 +64,14 @@ struct table_pair {
     HFr final_v;                   // value of V when it collapsed
 };
 
+// buffer sizes (in field elements) a circuit asks of each of its sessions; computed once per circuit
+struct circuit_sizes {
+    uint64_t tp_cap[2] = {1, 1};   // longest bookkeeping table of each pair
+    uint64_t v0_cap[2] = {1, 1};   // longest V table that is built (not read in place)
+    uint64_t bg = 1, bu = 1, gs = 1, max_list = 1;
+    uint64_t conv_wa = 0, conv_part = 0, conv_ae = 0;
+};
+
 struct msm_state;                  // hyrax.hip
 
 // kernel classes of the built-in profiler (HIP events on the context's stream)
@@ -82,11 +90,13 @@ struct zk_ctx {
     std::vector<dev_layer> L;
     fr_t *two_mul = nullptr;
     int n_two_mul = 0;
-    std::vector<void *> owned;     // every device allocation, freed in zk_ctx_destroy
+    std::vector<void *> owned;     // every device allocation of this context, freed in zk_ctx_destroy
+    std::vector<void *> *alloc_sink = nullptr;   // while the static part of a circuit is built: its registry entry's list instead
+    void *circuit = nullptr;       // shared_circuit (sumcheck.hip): gate lists, subset maps, layer-0 CSR -- shared by the sessions of one GPU
+    circuit_sizes sz;
 
     // work buffers
     table_pair tp[2];
-    uint64_t max_table = 0;
     fr_t *beta_g[2] = {nullptr, nullptr};   // ping-pong (the PADDING layer expands the FFT layer's table)
     int beta_g_cur = 0;
     uint64_t beta_g_cap = 0;
@@ -94,7 +104,6 @@ struct zk_ctx {
     fr_t *beta_gs = nullptr; uint64_t beta_gs_cap = 0;
     fr_t *small[2] = {nullptr, nullptr};    // periodic table of the cubic rounds (ping-pong)
     uint32_t small_len = 0; int small_cur = 0;
-    fr_t *eq_lo = nullptr, *eq_hi = nullptr; uint32_t eq_stride = 0;
     fr_t *partials = nullptr; uint32_t partial_blocks = 0;
     fr_t *d_result = nullptr;      // 32 elements
     HFr *h_result = nullptr;       // pinned, 32 elements
@@ -148,9 +157,13 @@ struct zk_ctx {
     void *h_live_in = nullptr, *d_live_in = nullptr;
     bool live_rounds = true;       // zk_set_live_rounds
     bool live_active = false;
+    bool live_now = true;          // decided per proof (zk_proof_begin): does this proof have a hardware queue to itself?
+    bool counted_active = false;
     int live_count = 0, live_cursor = 0;
     uint32_t live_seq32 = 16;
     uint64_t live_rounds_total = 0, live_phases_total = 0;
+    double live_t_gpu = 0, live_t_host = 0, live_t_exit = 0;          // ZKCNN_TIMING: waiting for the kernel / between two round calls
+    uint64_t live_ticks_wait = 0, live_ticks_total = 0, live_timed_rounds = 0;
     int tail_count = 0, tail_cursor = 0, phase_rounds = 0;
     unsigned long long tail_seq = 0;
     uint64_t tail_rounds_total = 0, tail_phases_total = 0;

@@ -21,7 +21,8 @@
 
 #define TAIL_THREADS 1024              // 16 waves, four lanes per quad
 #define TAIL_SLOTS 256                 // quads in flight per pass
-#define TAIL_QUADS 1024                // quads (both table pairs together) the kernel accepts: its first rounds then make 4 and 2 passes over the slots
+#define TAIL_QUADS 256                 // quads (both table pairs together) the kernel accepts: one pass over the slots. (A single workgroup is one CU:
+                                       // 16 waves share 4 SIMDs, so a 256-quad round costs 4 x 2 products per SIMD -- beyond that a launch over many CUs wins)
 #define FS_TAIL_MAX_ROUNDS ZK_MAX_VARS
 #define TAIL_TIMEOUT_TICKS 300000000ull   // 3 s of s_memrealtime (100 MHz): a live kernel nobody talks to gives up
 #define TAIL_ABORT 0xffffffffu
@@ -43,6 +44,7 @@ struct tail_out {                     // pinned, mapped host memory
     uint32_t pair_state[2];           // 0 absent, 1 two entries left (tail_v), 2 collapsed (final_v)
     uint32_t fs_state[8];             // FS: chain state after the last challenge
     uint32_t status, pad_;            // LIVE: 0 running / finished, 1 aborted by the host, 2 timed out
+    unsigned long long ticks_wait, ticks_total;   // LIVE: 100 MHz ticks spent polling for challenges / in the whole kernel (diagnostics, written with the final state)
     unsigned long long seq;           // FS: written last
     live_out live;                    // LIVE: the round mailbox
 };
@@ -118,6 +120,8 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
     __shared__ fr_t s_r, s_fin[2], s_prod[2], s_tail[2][2], s_add, s_addm;
     __shared__ uint32_t s_state[8];
     __shared__ int s_stop;
+    unsigned long long t_wait = 0;
+    const unsigned long long t_begin = LIVE ? wall_clock64() : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint64_t n[2] = {a.n[0], a.n[1]};
     const fr_t *Vin[2] = {a.Vin[0], a.Vin[1]}, *Min[2] = {a.Min[0], a.Min[1]};
@@ -146,7 +150,12 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
         const uint32_t role = (uint32_t) tid & 3, nq = quads[0] + quads[1];
         const uint32_t total_items = nq + (collapse[0] ? 1u : 0u) + (collapse[1] ? 1u : 0u);
         fr_t prod = fr_zero();
+        bool worked = false;
         for (uint32_t base = 0; base == 0 || base < total_items; base += TAIL_SLOTS) {
+            // a wave without items sits the pass out (wave-uniform): the SIMDs then serve only the waves that hold quads -- in the last rounds of
+            // a phase that is wave 0 alone, and a product costs its 1.1 us instead of four times that
+            if (base + 16u * (uint32_t) wave >= total_items && !(base == 0 && wave == 0)) continue;
+            worked = true;
             const uint32_t item = base + ((uint32_t) tid >> 2);
             const bool live = item < total_items;
             const bool special = live && item >= nq;
@@ -208,14 +217,16 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
             prod = fr_add(prod, x);
         }
         // reduction: lanes of equal role by butterflies; lanes 0..2 of every wave leave the wave's sums
+        if (worked) {
 #pragma unroll
-        for (int off = 4; off < 64; off <<= 1) {
-            fr_t o;
+            for (int off = 4; off < 64; off <<= 1) {
+                fr_t o;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o.v[i] = (uint32_t) __shfl_xor((int) prod.v[i], off, 64);
-            prod = fr_add(prod, o);
+                for (int i = 0; i < 8; ++i) o.v[i] = (uint32_t) __shfl_xor((int) prod.v[i], off, 64);
+                prod = fr_add(prod, o);
+            }
         }
-        if (lane < 3) s_part[wave][lane == 2 ? 0 : lane + 1] = prod;       // accumulator order a, c, p(1)
+        if (lane < 3) s_part[wave][lane == 2 ? 0 : lane + 1] = prod;       // accumulator order a, c, p(1); zero from a wave that sat out
         __syncthreads();
         if (wave == 0) {
             // lane 16 t + w holds accumulator t of wave w; a 4-step butterfly over w
@@ -244,6 +255,8 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
                     if (last) {
                         // what the host needs after the phase: posted (and acknowledged) BEFORE the last round's mailbox message
                         fr_store_scoped(&o->add_term, add_term, true);
+                        __hip_atomic_store(&o->ticks_wait, t_wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(&o->ticks_total, wall_clock64() - t_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll
                         for (int b = 0; b < 2; ++b) {
                             uint32_t ps = pstate[b];
@@ -279,6 +292,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
                             if (c0.w == TAIL_ABORT) { s_stop = 1; break; }
                             if (wall_clock64() - t0 > TAIL_TIMEOUT_TICKS) { s_stop = 2; break; }
                         }
+                        t_wait += wall_clock64() - t0;
                     }
                 } else {
                     fr_store(&a.out->poly[k][0], ca);

@@ -10,7 +10,9 @@
 //     block sums the selected table points (thread-sequential, then an LDS tree), and the row result
 //     is sum_k 2^k S_k (7 doublings). No buckets, no sorting, no atomics on 144-byte points.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <mutex>
 #include "ctx.hpp"
 #include "msm_kernels.cuh"
 #include "../ff/g1.hpp"
@@ -18,6 +20,7 @@
 struct msm_state {
     g1a_t *tables = nullptr;           // [MSM_WINDOWS][m]
     uint64_t m = 0;
+    struct gen_tables *gt = nullptr;   // the (shared, ref-counted) tables of the generator set in use; the pointers / flags below are copies
     std::vector<uint64_t> gens_host;   // generators the tables were built for
     g1j_t *partials = nullptr; size_t partials_cap = 0;
     g1j_t *rowsJ = nullptr; g1a_t *rowsA = nullptr; size_t rows_cap = 0;
@@ -35,8 +38,8 @@ struct msm_state {
     void *aff_scratch = nullptr; size_t aff_cap = 0;
     // generators seen again: full byte table F[w][d][j] = d * 2^(8w) * g_j (d = 1..255), so that EVERY non-zero scalar byte is
     // one mixed addition and no bit planes / doublings are left (3.2 GB for 4096 generators; built on the second use of a set)
-    g1a_t *full = nullptr; uint64_t full_m = 0; bool full_ready = false, full_failed = false;
-    uint32_t gens_hits = 0;
+    g1a_t *full = nullptr; uint64_t full_m = 0; bool full_ready = false;
+    bool no_full = false;              // this state never takes a byte table (the verifier's second set: points that change with every proof)
     g1j_t *parts2 = nullptr; size_t parts2_cap = 0;
     bool host_rows_valid = false;      // few-row MSMs end with a short sum on the host (like the single inversion of fetch_points)
     zkff::G1 host_rows[8];
@@ -53,6 +56,49 @@ struct msm_state {
 #define MSM_WIDE_CAP 128u          // rows with wide scalars whose higher windows ride along as virtual rows of the commitment's launches
 #define ZK_RETRY_SAFE 0x5afe       // internal status: repeat the batch with the SAFE kernels
 
+// ---- one set of tables per generator set and GPU, shared by the contexts that use the set (round 3: eight sessions of one model used to
+// build eight 3.2 GB byte tables of the same public generators) ----
+struct gen_tables {
+    int device = 0;
+    uint64_t m = 0;
+    std::vector<uint64_t> gens;        // the affine generators (C-ABI layout): the key
+    int refs = 0;
+    uint32_t uses = 0;                 // times a context selected the set: the byte table is built when a set is used AGAIN
+    std::mutex mtx;                    // held while a table is built
+    g1a_t *tables = nullptr;           // window tables T[w][j] = 2^(8w) g_j
+    g1a_t *digit = nullptr; bool digit_ready = false;
+    g1a_t *full = nullptr; bool full_ready = false, full_failed = false;
+    g1a_t *t8 = nullptr; bool t8_ready = false;
+};
+static std::mutex g_gen_mtx;
+static std::vector<gen_tables *> g_gen_sets;
+static std::atomic<uint64_t> g_gen_builds{0}, g_gen_full_builds{0};
+extern "C" void zk_generator_table_stats(uint64_t *window_table_builds, uint64_t *byte_table_builds) {
+    if (window_table_builds) *window_table_builds = g_gen_builds.load();
+    if (byte_table_builds) *byte_table_builds = g_gen_full_builds.load();
+}
+// copies of the entry's pointers / flags in the context's state (what the launch sites read)
+static void gen_adopt(msm_state *s) {
+    gen_tables *e = s->gt;
+    s->tables = e->tables;
+    s->digit = e->digit; s->digit_ready = e->digit_ready; s->digit_m = e->m;
+    s->full = e->full; s->full_ready = e->full_ready && !s->no_full; s->full_m = e->m;
+    s->t8 = e->t8; s->t8_ready = e->t8_ready && s->full_ready; s->t8_m = e->m;
+}
+static void gen_release(zk_ctx *ctx, msm_state *s) {
+    gen_tables *e = s->gt;
+    s->gt = nullptr;
+    s->tables = nullptr; s->digit = nullptr; s->full = nullptr; s->t8 = nullptr;
+    s->digit_ready = s->full_ready = s->t8_ready = false;
+    if (!e) return;
+    if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+    std::lock_guard<std::mutex> g(g_gen_mtx);
+    if (--e->refs > 0) return;
+    for (void *p : {(void *) e->tables, (void *) e->digit, (void *) e->full, (void *) e->t8}) if (p) hipFree(p);
+    g_gen_sets.erase(std::remove(g_gen_sets.begin(), g_gen_sets.end(), e), g_gen_sets.end());
+    delete e;
+}
+
 static void msm_destroy_one(zk_ctx *ctx);
 void zk_msm_destroy(zk_ctx *ctx) {
     msm_destroy_one(ctx);
@@ -62,8 +108,9 @@ void zk_msm_destroy(zk_ctx *ctx) {
 static void msm_destroy_one(zk_ctx *ctx) {
     if (!ctx->msm) return;
     msm_state *s = ctx->msm;
-    void *bufs[] = {s->tables, s->partials, s->rowsJ, s->rowsA, s->a, s->b, s->coef, s->Lrow, s->sL, s->idxL, s->d_y, s->tbl_scratch,
-                    s->digit, s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch, s->full, s->parts2, s->codes, s->mag, s->exc, s->masks, s->t8};
+    gen_release(ctx, s);
+    void *bufs[] = {s->partials, s->rowsJ, s->rowsA, s->a, s->b, s->coef, s->Lrow, s->sL, s->idxL, s->d_y, s->tbl_scratch,
+                    s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch, s->parts2, s->codes, s->mag, s->exc, s->masks};
     for (void *p : bufs) if (p) hipFree(p);
     delete s;
     ctx->msm = nullptr;
@@ -90,31 +137,49 @@ static int32_t ensure_state(zk_ctx *ctx) {
     return ZK_OK;
 }
 
-// window tables for `m` affine generators (host pointer, C-ABI layout); cached while the generators stay the same
+// window tables for `m` affine generators (host pointer, C-ABI layout): looked up in / added to the registry of generator sets
 static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
     msm_state *s = ctx->msm;
-    if (s->m == m && s->gens_host.size() == m * 12 && std::memcmp(s->gens_host.data(), gens, m * 96) == 0) {
-        ++s->gens_hits;
+    if (s->gt && s->m == m && s->gens_host.size() == m * 12 && std::memcmp(s->gens_host.data(), gens, m * 96) == 0) {
+        std::lock_guard<std::mutex> g(s->gt->mtx);
+        ++s->gt->uses;
         return ZK_OK;
     }
-    s->gens_hits = 0;
-    s->full_ready = false;
-    s->t8_ready = false;
-    if (s->m != m) {
-        if (s->tables) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->tables)); s->tables = nullptr; }
-        ZK_HIP(hipMalloc((void **) &s->tables, (size_t) MSM_WINDOWS * m * sizeof(g1a_t)));
-        s->m = m;
+    ZK_HIP(hipStreamSynchronize(ctx->stream));          // (nothing of this context may still read the set that is let go)
+    gen_release(ctx, s);
+    gen_tables *e = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_gen_mtx);
+        for (gen_tables *c : g_gen_sets)
+            if (c->device == ctx->device && c->m == m && std::memcmp(c->gens.data(), gens, m * 96) == 0) { e = c; break; }
+        if (!e) {
+            e = new gen_tables();
+            e->device = ctx->device;
+            e->m = m;
+            e->gens.assign(gens, gens + m * 12);
+            g_gen_sets.push_back(e);
+        }
+        ++e->refs;
     }
+    s->gt = e;
     s->gens_host.assign(gens, gens + m * 12);
-    s->digit_ready = false;
-    ZK_HIP(hipMemcpyAsync(s->tables, gens, m * sizeof(g1a_t), hipMemcpyHostToDevice, ctx->stream));
-    const size_t need = (size_t) (MSM_WINDOWS - 1) * m * (sizeof(g1j_t) + sizeof(fp_t));
-    int32_t rc = regrow(ctx, &s->tbl_scratch, &s->tbl_scratch_cap, need);
-    if (rc) return rc;
-    g1j_t *J = (g1j_t *) s->tbl_scratch;
-    fp_t *pre = (fp_t *) (J + (size_t) (MSM_WINDOWS - 1) * m);
-    ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_window_tables, dim3((uint32_t) ((m + 63) / 64)), dim3(64), s->tables, J, pre, (uint32_t) m);
-    ZK_HIP(hipGetLastError());
+    s->m = m;
+    std::lock_guard<std::mutex> g(e->mtx);
+    ++e->uses;
+    if (!e->tables) {
+        ZK_HIP(hipMalloc((void **) &e->tables, (size_t) MSM_WINDOWS * m * sizeof(g1a_t)));
+        ZK_HIP(hipMemcpyAsync(e->tables, gens, m * sizeof(g1a_t), hipMemcpyHostToDevice, ctx->stream));
+        const size_t need = (size_t) (MSM_WINDOWS - 1) * m * (sizeof(g1j_t) + sizeof(fp_t));
+        int32_t rc = regrow(ctx, &s->tbl_scratch, &s->tbl_scratch_cap, need);
+        if (rc) return rc;
+        g1j_t *J = (g1j_t *) s->tbl_scratch;
+        fp_t *pre = (fp_t *) (J + (size_t) (MSM_WINDOWS - 1) * m);
+        ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_window_tables, dim3((uint32_t) ((m + 63) / 64)), dim3(64), e->tables, J, pre, (uint32_t) m);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipStreamSynchronize(ctx->stream));      // other contexts read the tables from their own streams
+        ++g_gen_builds;
+    }
+    gen_adopt(s);
     return ZK_OK;
 }
 
@@ -144,58 +209,59 @@ static int32_t build_digit_table(zk_ctx *ctx, g1a_t *dst, const g1a_t *base, uin
     return ZK_OK;
 }
 
-// full byte table for a generator set that is being used again (ZKCNN_MSM_FULL=0 keeps the bit-plane path)
+// full byte table for a generator set that is being used again -- by this context or by any other of the process: the table belongs to the
+// set's registry entry, whoever needs it first builds it
 static int32_t ensure_full_table(zk_ctx *ctx) {
     msm_state *s = ctx->msm;
-    static const bool enabled = !(getenv("ZKCNN_MSM_FULL") && atoi(getenv("ZKCNN_MSM_FULL")) == 0);
-    if (!enabled || s->full_ready || s->full_failed || s->gens_hits < 1 || s->m > MSM_FULL_MAX_M) return ZK_OK;
-    const uint32_t m = (uint32_t) s->m;
-    if (s->full_m != s->m) {
-        if (s->full) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->full)); s->full = nullptr; s->full_m = 0; }
-        if (hipMalloc((void **) &s->full, (size_t) MSM_WINDOWS * 256 * m * sizeof(g1a_t)) != hipSuccess) {
+    gen_tables *e = s->gt;
+    if (!e || s->full_ready || s->no_full || s->m > MSM_FULL_MAX_M) return ZK_OK;
+    std::lock_guard<std::mutex> g(e->mtx);
+    if (!e->full_ready && !e->full_failed && e->uses >= 2) {
+        const uint32_t m = (uint32_t) e->m;
+        if (hipMalloc((void **) &e->full, (size_t) MSM_WINDOWS * 256 * m * sizeof(g1a_t)) != hipSuccess) {
             (void) hipGetLastError();
-            s->full = nullptr;
-            s->full_failed = true;             // not enough memory for the table: stay on the bit-plane path
-            return ZK_OK;
+            e->full = nullptr;
+            e->full_failed = true;             // not enough memory for the table: stay on the bit-plane path
+        } else {
+            for (uint32_t w = 0; w < MSM_WINDOWS; ++w) {
+                int32_t rc = build_digit_table(ctx, e->full + (size_t) w * 256 * m, e->tables + (size_t) w * m, m);
+                if (rc) return rc;
+            }
+            // subset sums of 8 generators (rows of bits in commit_rows): 256 x m / 8 points
+            if (m % 512 == 0 && m <= 64 * MSM_BLOCK) {
+                const uint32_t n8 = m / 8;
+                if (hipMalloc((void **) &e->t8, (size_t) 256 * n8 * sizeof(g1a_t)) != hipSuccess) { (void) hipGetLastError(); e->t8 = nullptr; }
+                else {
+                    ZK_HIP(hipMemsetAsync(e->t8, 0, (size_t) n8 * sizeof(g1a_t), ctx->stream));            // mask 0: the point at infinity, never looked up
+                    ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_subset_table, dim3((n8 + 63) / 64, 255), dim3(64), e->t8, (const g1a_t *) (e->full + (size_t) 1 * m), n8);
+                    ZK_HIP(hipGetLastError());
+                    e->t8_ready = true;
+                }
+            }
+            ZK_HIP(hipStreamSynchronize(ctx->stream));
+            e->full_ready = true;
+            ++g_gen_full_builds;
         }
-        s->full_m = s->m;
     }
-    for (uint32_t w = 0; w < MSM_WINDOWS; ++w) {
-        int32_t rc = build_digit_table(ctx, s->full + (size_t) w * 256 * m, s->tables + (size_t) w * m, m);
-        if (rc) return rc;
-    }
-    s->full_ready = true;
-    // subset sums of 8 generators (rows of bits in commit_rows): 256 x m / 8 points
-    static const bool bits_on = !(getenv("ZKCNN_MSM_BITS") && atoi(getenv("ZKCNN_MSM_BITS")) == 0);
-    s->t8_ready = false;
-    if (bits_on && m % 512 == 0 && m <= 64 * MSM_BLOCK) {
-        const uint32_t n8 = m / 8;
-        if (s->t8_m != s->m) {
-            if (s->t8) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->t8)); s->t8 = nullptr; }
-            if (hipMalloc((void **) &s->t8, (size_t) 256 * n8 * sizeof(g1a_t)) != hipSuccess) { (void) hipGetLastError(); s->t8 = nullptr; s->t8_m = 0; return ZK_OK; }
-            s->t8_m = s->m;
-        }
-        ZK_HIP(hipMemsetAsync(s->t8, 0, (size_t) n8 * sizeof(g1a_t), ctx->stream));            // mask 0: the point at infinity, never looked up
-        ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_subset_table, dim3((n8 + 63) / 64, 255), dim3(64), s->t8, (const g1a_t *) (s->full + (size_t) 1 * m), n8);
-        ZK_HIP(hipGetLastError());
-        s->t8_ready = true;
-    }
+    gen_adopt(s);
     return ZK_OK;
 }
 
 // digit table D[d][j] = d g_j for the cached generators
 static int32_t ensure_digit_table(zk_ctx *ctx) {
     msm_state *s = ctx->msm;
-    if (s->digit_ready && s->digit_m == s->m) return ZK_OK;
-    const uint32_t m = (uint32_t) s->m;
-    if (s->digit_m != s->m) {
-        if (s->digit) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->digit)); s->digit = nullptr; }
-        ZK_HIP(hipMalloc((void **) &s->digit, (size_t) 256 * m * sizeof(g1a_t)));
-        s->digit_m = s->m;
+    gen_tables *e = s->gt;
+    if (s->digit_ready) return ZK_OK;
+    std::lock_guard<std::mutex> g(e->mtx);
+    if (!e->digit_ready) {
+        const uint32_t m = (uint32_t) e->m;
+        ZK_HIP(hipMalloc((void **) &e->digit, (size_t) 256 * m * sizeof(g1a_t)));
+        int32_t rc = build_digit_table(ctx, e->digit, e->tables, m);
+        if (rc) return rc;
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        e->digit_ready = true;
     }
-    int32_t rc = build_digit_table(ctx, s->digit, s->tables, m);
-    if (rc) return rc;
-    s->digit_ready = true;
+    gen_adopt(s);
     return ZK_OK;
 }
 
@@ -524,7 +590,7 @@ extern "C" int32_t zk_commit_vector(zk_ctx *ctx, const uint64_t *scalars, uint64
         return ZK_ERR_ARG;
     }
     int32_t rc;
-    ++s->gens_hits;                                   // the cached set is in use again: worth its byte table
+    { std::lock_guard<std::mutex> g(s->gt->mtx); ++s->gt->uses; }      // the cached set is in use again: worth its byte table
     fr_t *d_v = nullptr;                              // its own buffer: commit_rows and add_blinds use the context's scratch
     ZK_HIP(hipMalloc((void **) &d_v, (size_t) n_rows * cols * 32));
     hipError_t e = hipMemcpyAsync(d_v, scalars, (size_t) n_rows * cols * 32, hipMemcpyHostToDevice, ctx->stream);
@@ -638,7 +704,7 @@ extern "C" int32_t zk_verifier_msm(zk_ctx *ctx, uint64_t out[12], const uint64_t
     if (bases_are_generators) {
         msm_state *s = ctx->msm;
         if (!s || !s->tables || n > s->m || std::memcmp(s->gens_host.data(), bases, n * 96) != 0) { ctx->err = "verifier MSM: these are not the cached generators"; return ZK_ERR_STATE; }
-        ++s->gens_hits;
+        { std::lock_guard<std::mutex> g(s->gt->mtx); ++s->gt->uses; }
         if ((rc = zk_scratch(ctx, n * 32))) return rc;
         ZK_HIP(hipMemcpyAsync(ctx->scratch.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
         return with_safe_retry(ctx, [&]() -> int32_t {
@@ -648,7 +714,7 @@ extern "C" int32_t zk_verifier_msm(zk_ctx *ctx, uint64_t out[12], const uint64_t
     }
     std::swap(ctx->msm, ctx->vmsm);                     // the verifier's own tables: the prover's cached generator set is left alone
     rc = ensure_state(ctx);
-    if (!rc) ctx->msm->full_failed = true;              // never a 3 GB byte table for points that change with every proof
+    if (!rc) ctx->msm->no_full = true;                  // never a 3 GB byte table for points that change with every proof
     if (!rc) rc = ensure_tables(ctx, bases, n);
     if (!rc) rc = zk_scratch(ctx, n * 32);
     if (!rc) {

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <atomic>
+#include <mutex>
 #include <cstring>
 #include <emmintrin.h>
 #include "ctx.hpp"
@@ -18,6 +19,7 @@
 #include "prep_kernels.cuh"
 
 static std::string g_create_err;
+static void circuit_release(zk_ctx *ctx);
 
 // ------------------------------------------------------------------------------------------------
 // memory helpers
@@ -25,7 +27,7 @@ static std::string g_create_err;
 int32_t zk_dev_alloc(zk_ctx *ctx, void **p, size_t bytes) {
     if (bytes == 0) bytes = 32;
     ZK_HIP(hipMalloc(p, bytes));
-    ctx->owned.push_back(*p);
+    (ctx->alloc_sink ? *ctx->alloc_sink : ctx->owned).push_back(*p);       // (the static part of a circuit belongs to its registry entry)
     return ZK_OK;
 }
 int32_t zk_scratch(zk_ctx *ctx, size_t bytes) {
@@ -75,11 +77,8 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
         return ZK_ERR_HIP;
     }
     // fixed-size work buffers
-    ctx->eq_stride = 1u << 15;
     ctx->partial_blocks = 4096;
-    if (zk_dev_alloc(ctx, (void **) &ctx->eq_lo, 2 * (size_t) ctx->eq_stride * 32) ||
-        zk_dev_alloc(ctx, (void **) &ctx->eq_hi, 2 * (size_t) ctx->eq_stride * 32) ||
-        zk_dev_alloc(ctx, (void **) &ctx->partials, (size_t) ctx->partial_blocks * 4 * 32) ||
+    if (zk_dev_alloc(ctx, (void **) &ctx->partials, (size_t) ctx->partial_blocks * 4 * 32) ||
         zk_dev_alloc(ctx, (void **) &ctx->d_result, 32 * 32) ||
         zk_dev_alloc(ctx, (void **) &ctx->d_counter, 64) ||
         hipHostMalloc((void **) &ctx->h_slot, sizeof(*ctx->h_slot), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -108,13 +107,21 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->live_active) (void) zk_live_abort(ctx);
+    (void) zk_proof_end(ctx);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->n_seg) fprintf(stderr, "[zkcnn timing] quadratic round call: %.2f us between calls (verifier + wrappers), %.2f plan + launch, %.2f waiting for the result, %.2f after (averages over %llu rounds)\n",
                             1e6 * ctx->t_seg[0] / ctx->n_seg, 1e6 * ctx->t_seg[1] / ctx->n_seg, 1e6 * ctx->t_seg[2] / ctx->n_seg, 1e6 * ctx->t_seg[3] / ctx->n_seg, (unsigned long long) ctx->n_seg);
+    if (ctx->live_timed_rounds)
+        fprintf(stderr, "[zkcnn timing] resident round kernel: %.2f us per round from posting the challenge to reading the polynomial, %.2f us on the host between "
+                        "two round calls (%llu rounds after a kernel's first); kernel clock: %.2f us per round in total, %.2f of them polling for the challenge (%llu rounds, %llu kernels)\n",
+                1e6 * ctx->live_t_gpu / ctx->live_timed_rounds, 1e6 * ctx->live_t_host / ctx->live_timed_rounds, (unsigned long long) ctx->live_timed_rounds,
+                0.01 * ctx->live_ticks_total / std::max<uint64_t>(ctx->live_rounds_total, 1), 0.01 * ctx->live_ticks_wait / std::max<uint64_t>(ctx->live_rounds_total, 1),
+                (unsigned long long) ctx->live_rounds_total, (unsigned long long) ctx->live_phases_total);
     zk_msm_destroy(ctx);
     for (prof_pending &p : ctx->prof_q) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
     for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
     for (void *p : ctx->owned) hipFree(p);
+    circuit_release(ctx);
     if (ctx->scratch.p) hipFree(ctx->scratch.p);
     if (ctx->w_val0.p) hipFree(ctx->w_val0.p);
     for (dev_buf &b : ctx->w_stage) if (b.p) hipFree(b.p);
@@ -177,6 +184,23 @@ extern "C" int32_t zk_fs_attach(zk_ctx *ctx, const uint32_t *state, const uint64
 extern "C" int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries) {
     if (!ctx || log_entries > 8) return ZK_ERR_ARG;
     ctx->host_tail_log = log_entries < 0 ? -1 : log_entries;
+    return ZK_OK;
+}
+static std::atomic<int> g_active_proofs[64];
+static int hw_queue_count() {
+    static const int n = getenv("GPU_MAX_HW_QUEUES") ? std::max(1, atoi(getenv("GPU_MAX_HW_QUEUES"))) : 4;      // (HIP's own default)
+    return n;
+}
+extern "C" int32_t zk_proof_begin(zk_ctx *ctx) {
+    if (!ctx) return ZK_ERR_ARG;
+    if (!ctx->counted_active) { ++g_active_proofs[ctx->device & 63]; ctx->counted_active = true; }
+    ctx->live_now = g_active_proofs[ctx->device & 63].load() <= hw_queue_count();
+    return ZK_OK;
+}
+extern "C" int32_t zk_proof_end(zk_ctx *ctx) {
+    if (!ctx) return ZK_ERR_ARG;
+    if (ctx->counted_active) { --g_active_proofs[ctx->device & 63]; ctx->counted_active = false; }
+    ctx->live_now = true;
     return ZK_OK;
 }
 extern "C" int32_t zk_set_live_rounds(zk_ctx *ctx, int32_t on) {
@@ -359,11 +383,149 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
     return zk_upload_circuit_hinted(ctx, layers, n_layers, two_mul, n_two_mul, nullptr, 0);
 }
 
+// ---- one resident circuit per GPU, shared by its sessions (reference src/prover.hpp:47-48: one layeredCircuit per prover) ----
+// Everything a circuit's upload produces that does not depend on the witness -- sorted and padded gate lists, subset maps, the layer-0 CSR,
+// the checked convolution patterns, buffer sizes -- lives in a ref-counted registry entry keyed by a digest of the upload's input. The
+// first context that uploads a circuit builds the entry (counting sort of 1.2e8 gates + 1.9 GB of lists for vgg11); every later context of
+// the same process and device that uploads the SAME circuit attaches to it and only allocates its own values, tables and scratch.
+struct shared_circuit {
+    int device = 0;
+    uint64_t key[2] = {0, 0};
+    int refs = 0;
+    bool ready = false, failed = false;
+    std::mutex mtx;                 // held while the entry is being built
+    std::vector<void *> owned;      // device allocations of the static part
+    std::vector<dev_layer> L;       // (val == nullptr)
+    fr_t *two_mul = nullptr;
+    int n_two_mul = 0;
+    uint32_t *liu_ptr = nullptr; void *liu_ent = nullptr; uint32_t liu_ntabs = 0;
+    std::vector<int> liu_tab_layer, liu_tab_side;
+    uint32_t conv_layers = 0;
+    circuit_sizes sz;
+};
+static std::mutex g_circ_mtx;
+static std::vector<shared_circuit *> g_circuits;
+static std::atomic<uint64_t> g_circ_builds{0}, g_circ_attaches{0};
+
+extern "C" void zk_sharing_stats(uint64_t *circuit_builds, uint64_t *circuit_attaches) {
+    if (circuit_builds) *circuit_builds = g_circ_builds.load();
+    if (circuit_attaches) *circuit_attaches = g_circ_attaches.load();
+}
+
+// 128-bit digest of a byte range: four 64-bit multiply-rotate lanes (NOT cryptographic: the registry is process-local, a collision would
+// attach a context to another circuit's lists and its proofs would be rejected -- a safe failure)
+static void fast_digest(uint64_t h[4], const void *data, size_t n) {
+    const uint8_t *p = (const uint8_t *) data;
+    const uint64_t k0 = 0x9e3779b97f4a7c15ull, k1 = 0xc2b2ae3d27d4eb4full, k2 = 0x165667b19e3779f9ull, k3 = 0x27d4eb2f165667c5ull;
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, p + i, 32);
+        h[0] = ((h[0] ^ w[0]) * k0); h[0] = (h[0] << 29) | (h[0] >> 35);
+        h[1] = ((h[1] ^ w[1]) * k1); h[1] = (h[1] << 31) | (h[1] >> 33);
+        h[2] = ((h[2] ^ w[2]) * k2); h[2] = (h[2] << 27) | (h[2] >> 37);
+        h[3] = ((h[3] ^ w[3]) * k3); h[3] = (h[3] << 33) | (h[3] >> 31);
+    }
+    uint64_t tail[4] = {0, 0, 0, (uint64_t) n};
+    std::memcpy(tail, p + i, n - i);
+    for (int j = 0; j < 4; ++j) { h[j] = (h[j] ^ tail[j]) * k1; h[j] ^= h[j] >> 32; }
+}
+static void circuit_key(uint64_t key[2], const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul, int32_t n_two_mul,
+                        const zk_conv_hint *hints, uint32_t n_hints) {
+    uint64_t h[4] = {0x243f6a8885a308d3ull, 0x13198a2e03707344ull, 0xa4093822299f31d0ull, 0x082efa98ec4e6c89ull};
+    for (int i = 0; i < n_layers; ++i) {
+        const zk_layer_desc &S = layers[i];
+        const int64_t rec[20] = {S.ty, (int64_t) S.size, S.bit_length, S.fft_bit_length, (int64_t) S.zero_start_id, (int64_t) S.n_uni, (int64_t) S.n_bin,
+                                 (int64_t) S.size_u[0], (int64_t) S.size_u[1], (int64_t) S.size_v[0], (int64_t) S.size_v[1], S.bit_length_u[0], S.bit_length_u[1],
+                                 S.bit_length_v[0], S.bit_length_v[1], S.max_bl_u, S.max_bl_v, S.need_phase2, 0, 0};
+        fast_digest(h, rec, sizeof(rec));
+        fast_digest(h, S.scale, 32);
+        if (S.n_uni) fast_digest(h, S.uni_gates, (size_t) S.n_uni * sizeof(zk_uni_gate));
+        if (S.n_bin) fast_digest(h, S.bin_gates, (size_t) S.n_bin * sizeof(zk_bin_gate));
+        if (S.size_u[0] && S.ori_id_u) fast_digest(h, S.ori_id_u, (size_t) S.size_u[0] * 4);
+        if (S.size_v[0] && S.ori_id_v) fast_digest(h, S.ori_id_v, (size_t) S.size_v[0] * 4);
+    }
+    fast_digest(h, two_mul, (size_t) n_two_mul * 32);
+    if (n_hints) fast_digest(h, hints, (size_t) n_hints * sizeof(zk_conv_hint));
+    key[0] = h[0] ^ (h[2] * 0x9e3779b97f4a7c15ull);
+    key[1] = h[1] ^ (h[3] * 0xc2b2ae3d27d4eb4full);
+}
+
+static int32_t build_static(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul, int32_t n_two_mul,
+                            const zk_conv_hint *hints, uint32_t n_hints);
+static int32_t alloc_session(zk_ctx *ctx);
+
+static void circuit_release(zk_ctx *ctx) {
+    shared_circuit *e = (shared_circuit *) ctx->circuit;
+    if (!e) return;
+    ctx->circuit = nullptr;
+    std::lock_guard<std::mutex> g(g_circ_mtx);
+    if (--e->refs > 0) return;
+    for (void *p : e->owned) hipFree(p);
+    g_circuits.erase(std::remove(g_circuits.begin(), g_circuits.end(), e), g_circuits.end());
+    delete e;
+}
+
 extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul,
                                             int32_t n_two_mul, const zk_conv_hint *hints, uint32_t n_hints) {
     if (!ctx || !layers || n_layers < 2 || !two_mul || n_two_mul > 512 || (n_hints && !hints)) return ZK_ERR_ARG;
     ZK_HIP(hipSetDevice(ctx->device));
     if (ctx->circuit_ready) { ctx->err = "circuit already uploaded; create a new context"; return ZK_ERR_STATE; }
+    for (int i = 0; i < n_layers; ++i)
+        if (layers[i].bit_length < 0 || layers[i].bit_length > ZK_MAX_VARS) { ctx->err = "layer bit length out of range"; return ZK_ERR_ARG; }
+    uint64_t key[2];
+    circuit_key(key, layers, n_layers, two_mul, n_two_mul, hints, n_hints);
+    shared_circuit *e = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_circ_mtx);
+        for (shared_circuit *c : g_circuits)
+            if (c->device == ctx->device && c->key[0] == key[0] && c->key[1] == key[1] && !c->failed) { e = c; break; }
+        if (!e) {
+            e = new shared_circuit();
+            e->device = ctx->device;
+            e->key[0] = key[0]; e->key[1] = key[1];
+            g_circuits.push_back(e);
+        }
+        ++e->refs;
+    }
+    ctx->circuit = e;
+    int32_t rc = ZK_OK;
+    {
+        std::lock_guard<std::mutex> g(e->mtx);         // (a second context uploading the same circuit at the same time waits here, then attaches)
+        if (!e->ready && !e->failed) {
+            ctx->alloc_sink = &e->owned;
+            rc = build_static(ctx, layers, n_layers, two_mul, n_two_mul, hints, n_hints);
+            ctx->alloc_sink = nullptr;
+            if (rc == ZK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "upload failed"; rc = ZK_ERR_HIP; }
+            if (rc == ZK_OK) {
+                e->L = ctx->L;
+                e->two_mul = ctx->two_mul; e->n_two_mul = ctx->n_two_mul;
+                e->liu_ptr = ctx->liu_ptr; e->liu_ent = ctx->liu_ent; e->liu_ntabs = ctx->liu_ntabs;
+                e->liu_tab_layer = ctx->liu_tab_layer; e->liu_tab_side = ctx->liu_tab_side;
+                e->conv_layers = ctx->conv_layers;
+                e->sz = ctx->sz;
+                e->ready = true;
+                ++g_circ_builds;
+            } else e->failed = true;
+        } else if (e->ready) {
+            ctx->L = e->L;
+            ctx->two_mul = e->two_mul; ctx->n_two_mul = e->n_two_mul;
+            ctx->liu_ptr = e->liu_ptr; ctx->liu_ent = e->liu_ent; ctx->liu_ntabs = e->liu_ntabs;
+            ctx->liu_tab_layer = e->liu_tab_layer; ctx->liu_tab_side = e->liu_tab_side;
+            ctx->conv_layers = e->conv_layers;
+            ctx->sz = e->sz;
+            ++g_circ_attaches;
+        } else { ctx->err = "the circuit's first upload failed"; rc = ZK_ERR_STATE; }
+    }
+    if (rc == ZK_OK) rc = alloc_session(ctx);
+    if (rc != ZK_OK) { circuit_release(ctx); return rc; }
+    ctx->circuit_ready = true;
+    return ZK_OK;
+}
+
+// the witness-independent part of a circuit (runs once per circuit and device)
+static int32_t build_static(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul, int32_t n_two_mul,
+                            const zk_conv_hint *hints, uint32_t n_hints) {
     int32_t rc;
     ctx->n_two_mul = n_two_mul;
     if ((rc = zk_dev_alloc(ctx, (void **) &ctx->two_mul, (size_t) n_two_mul * 32))) return rc;
@@ -390,28 +552,34 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
         D.conv_ok = true;
         ++ctx->conv_layers;
     }
-    uint64_t max_table = 1, max_bg = 1, max_bu = 1, max_gs = 1, max_list = 1;
+    circuit_sizes &Z = ctx->sz;
+    Z = circuit_sizes();
+    uint64_t max_list = 1;
     for (int i = 0; i < n_layers; ++i) {
         dev_layer &D = ctx->L[i];
         const zk_layer_desc &S = layers[i];
         D.d = S;
         D.d.uni_gates = nullptr; D.d.bin_gates = nullptr; D.d.ori_id_u = nullptr; D.d.ori_id_v = nullptr;
-        if (S.bit_length < 0 || S.bit_length > ZK_MAX_VARS) { ctx->err = "layer bit length out of range"; return ZK_ERR_ARG; }
         D.val_len = 1ull << S.bit_length;
         D.val_live = D.val_len;          // until the values arrive
-        if ((rc = zk_dev_alloc(ctx, (void **) &D.val, D.val_len * 32))) return rc;
-        ZK_HIP(hipMemsetAsync(D.val, 0, D.val_len * 32, ctx->stream));
-        max_table = std::max<uint64_t>(max_table, D.val_len);
-        if (i == 0) continue;
-        max_bg = std::max<uint64_t>(max_bg, D.val_len);
+        if (i == 0) { Z.tp_cap[1] = std::max<uint64_t>(Z.tp_cap[1], D.val_len); continue; }      // the layer-0 combine runs on pair 1
+        if (i == n_layers - 1) Z.tp_cap[0] = std::max<uint64_t>(Z.tp_cap[0], D.val_len);          // Vres folds the output layer on pair 0
+        Z.bg = std::max<uint64_t>(Z.bg, D.val_len);
+        // exact sizes of the bookkeeping buffers (round 3: a session's buffers used to be eight times the LARGEST table of the circuit)
+        const uint64_t prev_len = 1ull << layers[i - 1].bit_length;
+        const bool dotp = S.ty == ZK_DOT_PROD, xform = S.ty == ZK_FFT || S.ty == ZK_IFFT;
         for (int b = 0; b < 2; ++b) {
-            if (S.bit_length_u[b] >= 0) max_table = std::max<uint64_t>(max_table, 1ull << S.bit_length_u[b]);
-            if (S.bit_length_v[b] >= 0) max_table = std::max<uint64_t>(max_table, 1ull << S.bit_length_v[b]);
+            const int blu = dotp ? S.bit_length_u[1] : S.bit_length_u[b], blv = S.bit_length_v[b];
+            for (int bl : {blu, blv}) {
+                if (bl < 0) continue;
+                const uint64_t len = 1ull << bl;
+                Z.tp_cap[b] = std::max(Z.tp_cap[b], len);
+                // V[0] of pair 1 is only written when the previous layer cannot be read in place, by the transform layers and by DOT_PROD
+                if (b == 0 || len > prev_len || xform || dotp) Z.v0_cap[b] = std::max(Z.v0_cap[b], len);
+            }
         }
-        if (S.bit_length_u[0] >= 0) max_bg = std::max<uint64_t>(max_bg, 1ull << S.bit_length_u[0]);
-        if (S.bit_length_v[0] >= 0) max_bg = std::max<uint64_t>(max_bg, 1ull << S.bit_length_v[0]);
-        max_bu = std::max<uint64_t>(max_bu, 1ull << std::max<int>(S.max_bl_u, S.max_bl_v));
-        if (S.fft_bit_length >= 0) max_gs = std::max<uint64_t>(max_gs, 1ull << S.fft_bit_length);
+        Z.bu = std::max<uint64_t>(Z.bu, 1ull << std::max<int>(std::max<int>(S.max_bl_u, S.max_bl_v), 0));
+        if (S.fft_bit_length >= 0) Z.gs = std::max<uint64_t>(Z.gs, 1ull << S.fft_bit_length);
 
         if (S.size_u[0]) {
             std::vector<uint32_t> t(S.ori_id_u, S.ori_id_u + S.size_u[0]);
@@ -550,56 +718,70 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
         liu_entry *d_ent = nullptr;
         if ((rc = upload(ctx, &ctx->liu_ptr, cnt)) || (rc = upload(ctx, &d_ent, ent))) return rc;
         ctx->liu_ent = d_ent;
-        const uint32_t nt = std::max<uint32_t>(ctx->liu_ntabs, 1);
-        if ((rc = zk_dev_alloc(ctx, (void **) &ctx->liu_halves, (size_t) nt * 2 * LIU_HALF_STRIDE * 32))) return rc;
-        ZK_HIP(hipHostMalloc(&ctx->h_liu_tabs, (size_t) nt * sizeof(liu_table), hipHostMallocMapped));
-        ZK_HIP(hipHostGetDevicePointer(&ctx->liu_tabs, ctx->h_liu_tabs, 0));        // the kernels read the descriptors in place
     }
-    {
-        uint64_t max_wa = 0, max_part = 0, max_ae = 0;
-        for (const dev_layer &D : ctx->L) {
-            if (!D.conv_ok) continue;
-            const conv_desc &c = D.conv;
-            const uint64_t len = (uint64_t) c.CI * c.m * c.m, chunks = (c.CO + 7) / 8;
-            max_wa = std::max(max_wa, 2 * len);
-            max_part = std::max(max_part, chunks * 2 * len);
-            max_ae = std::max<uint64_t>(max_ae, (uint64_t) c.CO * c.m * c.m + c.CI);
-        }
-        if (ctx->conv_layers) {
-            if ((rc = zk_dev_alloc(ctx, (void **) &ctx->conv_small, (size_t) CT_COUNT * CONV_TAB_STRIDE * 32)) ||
-                (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_wa, max_wa * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_part, max_part * 32)) ||
-                (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_e, 2 * 16 * 16 * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_ae, max_ae * 32)))
-                return rc;
-            ZK_HIP(hipHostMalloc(&ctx->h_conv_tabs, 2 * CT_COUNT * sizeof(liu_table), hipHostMallocMapped));
-            ZK_HIP(hipHostGetDevicePointer(&ctx->conv_tabs, ctx->h_conv_tabs, 0));
-        }
+    for (const dev_layer &D : ctx->L) {
+        if (!D.conv_ok) continue;
+        const conv_desc &c = D.conv;
+        const uint64_t len = (uint64_t) c.CI * c.m * c.m, chunks = (c.CO + 7) / 8;
+        Z.conv_wa = std::max(Z.conv_wa, 2 * len);
+        Z.conv_part = std::max(Z.conv_part, chunks * 2 * len);
+        Z.conv_ae = std::max<uint64_t>(Z.conv_ae, (uint64_t) c.CO * c.m * c.m + c.CI);
     }
+    Z.max_list = max_list;
     if (getenv("ZKCNN_DUMP_TABLES"))
         for (int i = 1; i < n_layers; ++i) {
             const dev_layer &D = ctx->L[i];
             fprintf(stderr, "[tables] layer %d ty %d size %u | u0 bl %d live %u | u1 bl %d live %u | v0 bl %d live %u | v1 bl %d live %u\n", i, D.d.ty, D.d.size,
                     D.d.bit_length_u[0], D.p1_live[0], D.d.bit_length_u[1], D.p1_live[1], D.d.bit_length_v[0], D.p2_live[0], D.d.bit_length_v[1], D.p2_live[1]);
         }
-    // work buffers sized for the largest layer
-    ctx->max_table = max_table;
-    for (int b = 0; b < 2; ++b)
-        for (int k = 0; k < 2; ++k) {
-            if ((rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].V[k], max_table * 32))) return rc;
-            if ((rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].M[k], max_table * 32))) return rc;
-        }
-    ctx->beta_g_cap = max_bg;
-    for (int k = 0; k < 2; ++k) if ((rc = zk_dev_alloc(ctx, (void **) &ctx->beta_g[k], max_bg * 32))) return rc;
-    ctx->beta_u_cap = max_bu;
-    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->beta_u, max_bu * 32))) return rc;
-    ctx->beta_gs_cap = max_gs;
-    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->beta_gs, max_gs * 32))) return rc;
-    for (int k = 0; k < 2; ++k) if ((rc = zk_dev_alloc(ctx, (void **) &ctx->small[k], max_gs * 32))) return rc;
-    ctx->carry_slots = 4 * ((max_list + ZK_BLOCK - 1) / ZK_BLOCK) + 4;          // two lists per launch (k_gate_multi), two slots per block
+    return ZK_OK;
+}
+
+// what every session of a circuit has for itself: layer values, bookkeeping tables, scratch
+static int32_t alloc_session(zk_ctx *ctx) {
+    int32_t rc;
+    const circuit_sizes &Z = ctx->sz;
+    for (dev_layer &D : ctx->L) {
+        D.val = nullptr;
+        D.val_live = D.val_len;          // until the values arrive
+        if ((rc = zk_dev_alloc(ctx, (void **) &D.val, D.val_len * 32))) return rc;
+        ZK_HIP(hipMemsetAsync(D.val, 0, D.val_len * 32, ctx->stream));
+        D.ev_uni = D.ev_bin = nullptr; D.ev_dot = nullptr; D.ev_dot_ptr = nullptr; D.n_ev_uni = D.n_ev_bin = 0; D.ev_conv = false;
+    }
+    {
+        const uint32_t nt = std::max<uint32_t>(ctx->liu_ntabs, 1);
+        if ((rc = zk_dev_alloc(ctx, (void **) &ctx->liu_halves, (size_t) nt * 2 * LIU_HALF_STRIDE * 32))) return rc;
+        ZK_HIP(hipHostMalloc(&ctx->h_liu_tabs, (size_t) nt * sizeof(liu_table), hipHostMallocMapped));
+        ZK_HIP(hipHostGetDevicePointer(&ctx->liu_tabs, ctx->h_liu_tabs, 0));        // the kernels read the descriptors in place
+    }
+    if (ctx->conv_layers) {
+        if ((rc = zk_dev_alloc(ctx, (void **) &ctx->conv_small, (size_t) CT_COUNT * CONV_TAB_STRIDE * 32)) ||
+            (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_wa, Z.conv_wa * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_part, Z.conv_part * 32)) ||
+            (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_e, 2 * 16 * 16 * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_ae, Z.conv_ae * 32)))
+            return rc;
+        ZK_HIP(hipHostMalloc(&ctx->h_conv_tabs, 2 * CT_COUNT * sizeof(liu_table), hipHostMallocMapped));
+        ZK_HIP(hipHostGetDevicePointer(&ctx->conv_tabs, ctx->h_conv_tabs, 0));
+    }
+    // bookkeeping tables: [0] takes a pair's tables as they are built, [1] only ever what a fold leaves (half, plus the guard quad)
+    for (int b = 0; b < 2; ++b) {
+        const uint64_t cap = std::max<uint64_t>(Z.tp_cap[b], 4), half = cap / 2 + 8;
+        if ((rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].V[0], std::max<uint64_t>(Z.v0_cap[b], 4) * 32)) ||
+            (rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].M[0], cap * 32)) ||
+            (rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].V[1], half * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].M[1], half * 32)))
+            return rc;
+    }
+    ctx->beta_g_cap = std::max<uint64_t>(Z.bg, 1);
+    for (int k = 0; k < 2; ++k) if ((rc = zk_dev_alloc(ctx, (void **) &ctx->beta_g[k], ctx->beta_g_cap * 32))) return rc;
+    ctx->beta_u_cap = std::max<uint64_t>(Z.bu, 1);
+    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->beta_u, ctx->beta_u_cap * 32))) return rc;
+    ctx->beta_gs_cap = std::max<uint64_t>(Z.gs, 1);
+    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->beta_gs, ctx->beta_gs_cap * 32))) return rc;
+    for (int k = 0; k < 2; ++k) if ((rc = zk_dev_alloc(ctx, (void **) &ctx->small[k], ctx->beta_gs_cap * 32))) return rc;
+    ctx->carry_slots = 4 * ((Z.max_list + ZK_BLOCK - 1) / ZK_BLOCK) + 4;          // two lists per launch (k_gate_multi), two slots per block
     if ((rc = zk_dev_alloc(ctx, (void **) &ctx->carry_key, ctx->carry_slots * 4))) return rc;
     if ((rc = zk_dev_alloc(ctx, (void **) &ctx->carry_val, ctx->carry_slots * 32))) return rc;
     if ((rc = zk_scratch(ctx, (size_t) 1 << 24))) return rc;
     ZK_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->circuit_ready = true;
     return ZK_OK;
 }
 
@@ -1462,10 +1644,17 @@ static int32_t live_start(zk_ctx *ctx, const HFr &r, bool with_add_term) {
 }
 // one round of the resident kernel: r is the verifier's challenge for the previous polynomial (round 0 of the kernel got it as a launch argument)
 static int32_t live_round(zk_ctx *ctx, const HFr &r, uint64_t out_abc[12]) {
+    static const bool timing = getenv("ZKCNN_TIMING") != nullptr;
     const int k = ctx->live_cursor;
+    const double t0 = timing ? now_s() : 0;
+    if (timing && k > 0) ctx->live_t_host += t0 - ctx->live_t_exit;
     if (k > 0) live_post(ctx, r, ctx->live_seq32 + (uint32_t) k);
     int32_t rc = live_wait(ctx, k, out_abc);
     if (rc) return rc;
+    if (timing) {
+        ctx->live_t_exit = now_s();
+        if (k > 0) { ctx->live_t_gpu += ctx->live_t_exit - t0; ++ctx->live_timed_rounds; }
+    }
     ++ctx->round;
     ctx->proof_size += 32 * 3;
     if (++ctx->live_cursor < ctx->live_count) return ZK_OK;
@@ -1487,6 +1676,8 @@ static int32_t live_round(zk_ctx *ctx, const HFr &r, uint64_t out_abc[12]) {
         }
     }
     std::memcpy(&ctx->add_term, &o->add_term, 32);
+    ctx->live_ticks_wait += o->ticks_wait;
+    ctx->live_ticks_total += o->ticks_total;
     ctx->live_active = false;
     return ZK_OK;
 }
@@ -1594,7 +1785,7 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         if (rc) return rc;
     }
     // interactive protocol: a resident kernel for the rest of the phase once the tables are small (zk_set_live_rounds)
-    if (ctx->live_rounds && !ctx->fs_state && ctx->host_tail_log < 0 && !ctx->live_active && ctx->phase_rounds > ctx->round &&
+    if (ctx->live_rounds && ctx->live_now && !ctx->fs_state && ctx->host_tail_log < 0 && !ctx->live_active && ctx->phase_rounds > ctx->round &&
         ctx->tp[0].len + ctx->tp[1].len > 0 && round_quads <= TAIL_QUADS) {
         int32_t rc = resolve_add_term(ctx);
         if (!rc) rc = live_start(ctx, r, with_add_term);

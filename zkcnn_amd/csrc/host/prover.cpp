@@ -52,6 +52,8 @@ void prover::attachFiatShamir(const uint32_t *state, const uint64_t *pending) {
     if (!ctx) return;
     check(zk_fs_attach(ctx, state, pending), "zk_fs_attach");
 }
+void prover::proofBegin() { if (ctx) check(zk_proof_begin(ctx), "zk_proof_begin"); }
+void prover::proofEnd() { if (ctx) (void) zk_proof_end(ctx); }
 void prover::setLiveRounds(bool on) {
     if (ctx) check(zk_set_live_rounds(ctx, on ? 1 : 0), "zk_set_live_rounds");
 }

@@ -71,6 +71,8 @@ public:
     void attachFiatShamir(const uint32_t *state, const uint64_t *pending);
     void tailStats(uint64_t &rounds, uint64_t &phases) const;
     void setHostTail(int log_entries);          // hybrid tail (include/zkcnn_hip.h: zk_set_host_tail); < 0 = off
+    void proofBegin();                          // bracket of one proof (include/zkcnn_hip.h: zk_proof_begin / zk_proof_end)
+    void proofEnd();
     void setLiveRounds(bool on);                // resident round kernel of the interactive protocol (include/zkcnn_hip.h: zk_set_live_rounds)
 
     // ---- the next picture on the resident circuit (include/zkcnn_hip.h: zk_witness_program_upload / zk_witness_rerun). The program is
@@ -106,6 +108,8 @@ private:
 inline void attachFsChain(prover &p, const uint32_t *state, const uint64_t *pending) { p.attachFiatShamir(state, pending); }
 inline void setHostTail(prover &p, int log_entries) { p.setHostTail(log_entries); }
 inline void setLiveRounds(prover &p, bool on) { p.setLiveRounds(on); }
+inline void proofBegin(prover &p) { p.proofBegin(); }
+inline void proofEnd(prover &p) { p.proofEnd(); }
 template <class H> inline void setConvHints(prover &p, const std::vector<H> &hints) {
     static_assert(sizeof(H) == sizeof(zk_conv_hint), "convolution hints cross the C-ABI as they are");
     p.setConvHints(reinterpret_cast<const zk_conv_hint *>(hints.data()), hints.size());

@@ -13,6 +13,8 @@
 template <class P> inline void attachFsChain(P &, const uint32_t *, const uint64_t *) {}
 template <class P> inline void setHostTail(P &, int) {}
 template <class P> inline void setLiveRounds(P &, bool) {}
+template <class P> inline void proofBegin(P &) {}
+template <class P> inline void proofEnd(P &) {}
 template <class P, class H> inline void setConvHints(P &, const std::vector<H> &) {}
 
 template <class ProverT>
@@ -141,6 +143,7 @@ struct sessionT {
         fiatShamir fs;
         std::unique_ptr<challengeScope> scope;
         attachFsChain(p, nullptr, nullptr);            // whatever an earlier run left behind
+        struct scope { ProverT &q; explicit scope(ProverT &x) : q(x) { proofBegin(q); } ~scope() { proofEnd(q); } } active(p);      // this proof counts as in flight on its GPU
         bool ok = false;
         try {
             configure(v, challenge_seed, mode, fs, scope, true);
