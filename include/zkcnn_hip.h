@@ -139,6 +139,7 @@ int32_t zk_set_live_rounds(zk_ctx *ctx, int32_t on);
  * queues (GPU_MAX_HW_QUEUES, default 4) -- K > 4 proofs in flight on one GPU keep launching a kernel per round, which interleaves better. */
 /* how many circuit uploads of this process built a resident circuit, and how many attached to one that was already there (tests, bench) */
 void zk_sharing_stats(uint64_t *circuit_builds, uint64_t *circuit_attaches);
+uint64_t zk_shared_circuit_bytes(void);      /* device memory of the resident circuits (gate lists, subset maps, layer-0 CSR) alive now */
 /* generator sets whose window tables / 3.2 GB byte tables this process has built (one per set and device, shared by the contexts that use it) */
 void zk_generator_table_stats(uint64_t *window_table_builds, uint64_t *byte_table_builds);
 int32_t zk_proof_begin(zk_ctx *ctx);

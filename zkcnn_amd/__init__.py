@@ -359,7 +359,8 @@ def sharing_stats():
     lib.zk_generator_table_stats.restype = None
     lib.zk_sharing_stats(ctypes.byref(v[0]), ctypes.byref(v[1]))
     lib.zk_generator_table_stats(ctypes.byref(v[2]), ctypes.byref(v[3]))
-    return {"circuit_builds": v[0].value, "circuit_attaches": v[1].value, "window_table_builds": v[2].value, "byte_table_builds": v[3].value}
+    lib.zk_shared_circuit_bytes.restype = ctypes.c_uint64
+    return {"shared_circuit_gb": round(lib.zk_shared_circuit_bytes() / 1e9, 3), "circuit_builds": v[0].value, "circuit_attaches": v[1].value, "window_table_builds": v[2].value, "byte_table_builds": v[3].value}
 
 
 class Session(_SessionBase):

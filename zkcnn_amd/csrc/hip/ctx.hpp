@@ -69,6 +69,7 @@ struct circuit_sizes {
     uint64_t tp_cap[2] = {1, 1};   // longest bookkeeping table of each pair
     uint64_t v0_cap[2] = {1, 1};   // longest V table that is built (not read in place)
     uint64_t bg = 1, bu = 1, gs = 1, max_list = 1;
+    uint64_t sub = 1;              // longest layer-0 subset table (the verifier's layer-0 check builds eq tables over them)
     uint64_t conv_wa = 0, conv_part = 0, conv_ae = 0;
 };
 
@@ -91,6 +92,7 @@ struct zk_ctx {
     fr_t *two_mul = nullptr;
     int n_two_mul = 0;
     std::vector<void *> owned;     // every device allocation of this context, freed in zk_ctx_destroy
+    uint64_t sink_bytes = 0;
     std::vector<void *> *alloc_sink = nullptr;   // while the static part of a circuit is built: its registry entry's list instead
     void *circuit = nullptr;       // shared_circuit (sumcheck.hip): gate lists, subset maps, layer-0 CSR -- shared by the sessions of one GPU
     circuit_sizes sz;
@@ -157,6 +159,9 @@ struct zk_ctx {
     void *h_live_in = nullptr, *d_live_in = nullptr;
     bool live_rounds = true;       // zk_set_live_rounds
     bool live_active = false;
+    bool live_mid = false;         // the running kernel is k_mid (a segment of mid-size rounds): the host tracks tables and add_term itself
+    bool live_with_add = false;
+    void *d_bcast = nullptr;       // mid_bcast: k_mid's challenge line in device memory
     bool live_now = true;          // decided per proof (zk_proof_begin): does this proof have a hardware queue to itself?
     bool counted_active = false;
     int live_count = 0, live_cursor = 0;

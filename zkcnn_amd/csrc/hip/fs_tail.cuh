@@ -344,6 +344,217 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Resident MULTI-workgroup rounds of the interactive protocol: the middle of a phase, tables of 2^11 .. 2^16 entries (too large for the one
+// workgroup of k_tail, too small to amortise a launch: ~28 us per round as launches, of which ~10 are the kernel). One launch runs a SEGMENT
+// of consecutive rounds in which no table collapses or reaches its last pair (the host plans segments; such rounds stay launches).
+// Work layout of k_round_quad_fine (4 lanes per quad, 64 quads per block); a round needs ceil(quads / 64) blocks, and a block whose quads
+// are gone leaves for good (tables only shrink). Per round:
+//   every block   waits for the challenge (broadcast line in device memory), folds its quads, block sums -> partials, arrival ticket
+//   last arriver  ("leader" of the round) adds the partials, finishes the polynomial (add_term: every block tracks it, no hand-over), posts it
+//                 in the host mailbox, polls the host mailbox for the verifier's challenge and broadcasts it
+// Tables written in one round are read by OTHER workgroups (other XCDs) in the next: every table access, the partials and the broadcast line
+// are 16-byte sc1 (agent-scope) accesses -- the documented alternative to release / acquire fences, which would write back and invalidate
+// whole L2s once per block and round. Workgroups wait for one another, so all of them must be resident: at most 256 blocks of 256 threads,
+// and the resident kernels are only used while at most GPU_MAX_HW_QUEUES proofs are active (zk_proof_begin).
+// ------------------------------------------------------------------------------------------------
+struct __align__(16) mid_bcast { uint32_t c[3][4]; uint32_t pad_[4]; };      // challenge chunks {3 words, seq}, like live_in
+
+struct mid_args {
+    const fr_t *Vin[2], *Min[2];
+    fr_t *Vbuf[2][2], *Mbuf[2][2];
+    int32_t out_idx[2];
+    uint64_t n[2];                    // pre-fold length of each pair; 0 = absent; a present pair has >= 8 entries in every round of the segment
+    int32_t rounds, with_add_term;
+    fr_t prev_r, add_term;            // challenge of the segment's first fold; add_term BEFORE that round's (1 - r) factor
+    fr_t *partials;                   // 3 per block
+    uint32_t *arrive;                 // zero at launch; cumulative arrivals
+    mid_bcast *bc;
+    tail_out *out;
+    const live_in *in;
+    uint32_t seq32, pad_;
+};
+
+__device__ __forceinline__ fr_t fr_load_sc1(const fr_t *p) {
+    zk_u32x4 lo, hi;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(lo), "=&v"(hi) : "v"(p) : "memory");
+    fr_t z;
+    z.v[0] = lo.x; z.v[1] = lo.y; z.v[2] = lo.z; z.v[3] = lo.w; z.v[4] = hi.x; z.v[5] = hi.y; z.v[6] = hi.z; z.v[7] = hi.w;
+    return z;
+}
+// two consecutive elements (64 bytes): four loads in flight, one wait
+__device__ __forceinline__ void fr_load2_sc1(const fr_t *p, fr_t &x, fr_t &y) {
+    zk_u32x4 a0, a1, b0, b1;
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(p) : "memory");
+    x.v[0] = a0.x; x.v[1] = a0.y; x.v[2] = a0.z; x.v[3] = a0.w; x.v[4] = a1.x; x.v[5] = a1.y; x.v[6] = a1.z; x.v[7] = a1.w;
+    y.v[0] = b0.x; y.v[1] = b0.y; y.v[2] = b0.z; y.v[3] = b0.w; y.v[4] = b1.x; y.v[5] = b1.y; y.v[6] = b1.z; y.v[7] = b1.w;
+}
+__device__ __forceinline__ void fr_store_sc1(fr_t *p, const fr_t &a) {
+    const zk_u32x4 lo = {a.v[0], a.v[1], a.v[2], a.v[3]}, hi = {a.v[4], a.v[5], a.v[6], a.v[7]};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(p), "v"(lo), "v"(hi) : "memory");
+}
+__device__ __forceinline__ void load48_sc1(const void *p, zk_u32x4 &c0, zk_u32x4 &c1, zk_u32x4 &c2) {
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:32 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(c0), "=&v"(c1), "=&v"(c2) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void store16_sc1(void *p, zk_u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+
+__global__ void __launch_bounds__(ZK_BLOCK) k_mid(mid_args a) {
+    __shared__ fr_t s_role[3][ZK_BLOCK / 64];
+    __shared__ fr_t s_r, s_add, s_tot[3];
+    __shared__ int s_flag;            // 0 go on, 1 this block is the round's leader, 2 stop (abort / time-out)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t lb = blockIdx.x, role = (uint32_t) tid & 3;
+    uint64_t n[2] = {a.n[0], a.n[1]};
+    const fr_t *Vin[2] = {a.Vin[0], a.Vin[1]}, *Min[2] = {a.Min[0], a.Min[1]};
+    int oi[2] = {a.out_idx[0], a.out_idx[1]};
+    uint32_t arrived_before = 0;      // arrivals of all earlier rounds (every block computes the same numbers)
+    if (tid == 0) { s_r = a.prev_r; s_add = a.add_term; s_flag = 0; }
+    __syncthreads();
+    for (int k = 0; k < a.rounds; ++k) {
+        const uint32_t q0 = (uint32_t) (n[0] / 4), q1 = (uint32_t) (n[1] / 4), total = q0 + q1, nblk = (total + 63) / 64;
+        if (64u * lb >= total) return;                                  // this block's quads are gone (uniform: every later round is smaller)
+        const fr_t r = s_r;
+        // add_term (1 - r): every block tracks the scalar (one product on a wave that idles otherwise), so whoever leads the round has it
+        if (tid == 64 && a.with_add_term) s_add = fr_mul(s_add, fr_sub(fr_one(), r));
+        const uint32_t item = 64u * lb + ((uint32_t) tid >> 2);
+        const bool live = item < total;
+        const int b = (live && item >= q0) ? 1 : 0;
+        const uint32_t q = b ? item - q0 : item;
+        fr_t X = fr_zero();
+        if (live) {
+            const fr_t *src = (role < 2 ? (b ? Vin[1] : Vin[0]) : (b ? Min[1] : Min[0])) + 4 * (size_t) q + 2 * (role & 1);
+            fr_t e0, e1;
+            fr_load2_sc1(src, e0, e1);
+            X = fr_lerp(e0, e1, r);
+            fr_t *dst = role < 2 ? (b ? a.Vbuf[1][oi[1]] : a.Vbuf[0][oi[0]]) : (b ? a.Mbuf[1][oi[1]] : a.Mbuf[0][oi[0]]);
+            fr_store_sc1(dst + 2 * (size_t) q + (role & 1), X);
+        }
+        fr_t y1, y2, y3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            y1.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 2, 64);
+            y2.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 1, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y3.v[i] = (uint32_t) __shfl_xor((int) y1.v[i], 1, 64);
+        // role 0: X = v0, y1 = m0;  role 1: X = v1, y1 = m1;  role 2: X = m0, y1 = v0, y2 = m1, y3 = v1
+        fr_t opA = role == 2 ? fr_sub(y3, y1) : X, opB = role == 2 ? fr_sub(y2, X) : y1;
+        if (role == 3 || !live) { opA = fr_zero(); opB = fr_zero(); }
+        fr_t prod = fr_mul(opA, opB);
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1) {
+            fr_t o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] = (uint32_t) __shfl_xor((int) prod.v[i], off, 64);
+            prod = fr_add(prod, o);
+        }
+        if (lane < 3) s_role[lane][wave] = prod;          // role 0: c, role 1: p(1), role 2: a
+        ZK_WAIT_STORES();                                  // this thread's table stores are out before the block reports in
+        __syncthreads();
+        if (tid < 3) {
+            fr_t t = s_role[tid][0];
+#pragma unroll
+            for (int w = 1; w < ZK_BLOCK / 64; ++w) t = fr_add(t, s_role[tid][w]);
+            fr_store_sc1(a.partials + (size_t) 3 * lb + tid, t);
+            ZK_WAIT_STORES();
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t t = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_flag = (t == arrived_before + nblk - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        const bool last_round = k == a.rounds - 1;
+        const uint32_t sq = a.seq32 + (uint32_t) k;
+        if (s_flag == 1) {
+            // ---- leader of the round: grid sums, the polynomial, the host, the next challenge ----
+            if (wave < 3) {
+                fr_t tot = fr_zero();
+                for (uint32_t blk = lane; blk < nblk; blk += 64) tot = fr_add(tot, fr_load_sc1(a.partials + (size_t) 3 * blk + wave));
+                tot = fr_wave_sum(tot);
+                if (lane == 0) s_tot[wave] = tot;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                fr_t cc = s_tot[0], p1 = s_tot[1], ca = s_tot[2];
+                fr_t cb = fr_sub(fr_sub(p1, ca), cc);
+                if (a.with_add_term) { cb = fr_sub(cb, s_add); cc = fr_add(cc, s_add); }
+                uint32_t w24[24];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { w24[i] = ca.v[i]; w24[8 + i] = cb.v[i]; w24[16 + i] = cc.v[i]; }
+                if (last_round) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (everybody has arrived: the counter is free for the next launch)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    zk_u32x4 ch = {w24[3 * j], w24[3 * j + 1], w24[3 * j + 2], sq};
+                    store16_sys(&a.out->live.c[j][0], ch);
+                }
+                if (!last_round) {
+                    const uint32_t want = sq + 1;
+                    const unsigned long long t0 = wall_clock64();
+                    zk_u32x4 c0, c1, c2;
+                    int stop = 0;
+                    for (;;) {
+                        load48_sys(a.in, c0, c1, c2);
+                        if (c0.w == want && c1.w == want && c2.w == want) break;
+                        if (c0.w == TAIL_ABORT) { stop = 1; break; }
+                        if (wall_clock64() - t0 > TAIL_TIMEOUT_TICKS) { stop = 2; break; }
+                    }
+                    if (stop) {
+                        c0.w = c1.w = c2.w = TAIL_ABORT;
+                        __hip_atomic_store(&a.out->status, (uint32_t) stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_flag = 2;
+                    } else {
+                        fr_t ch;
+                        ch.v[0] = c0.x; ch.v[1] = c0.y; ch.v[2] = c0.z; ch.v[3] = c1.x; ch.v[4] = c1.y; ch.v[5] = c1.z; ch.v[6] = c2.x; ch.v[7] = c2.y;
+                        s_r = ch;
+                    }
+                    // the broadcast line: the same three chunks
+                    store16_sc1(&a.bc->c[0][0], c0);
+                    store16_sc1(&a.bc->c[1][0], c1);
+                    store16_sc1(&a.bc->c[2][0], c2);
+                }
+            }
+        } else if (!last_round) {
+            if (tid == 0) {
+                const uint32_t want = sq + 1;
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    zk_u32x4 c0, c1, c2;
+                    load48_sc1(a.bc, c0, c1, c2);
+                    if (c0.w == want && c1.w == want && c2.w == want) {
+                        fr_t ch;
+                        ch.v[0] = c0.x; ch.v[1] = c0.y; ch.v[2] = c0.z; ch.v[3] = c1.x; ch.v[4] = c1.y; ch.v[5] = c1.z; ch.v[6] = c2.x; ch.v[7] = c2.y;
+                        s_r = ch;
+                        break;
+                    }
+                    if (c0.w == TAIL_ABORT || wall_clock64() - t0 > 2 * TAIL_TIMEOUT_TICKS) { s_flag = 2; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+        }
+        __syncthreads();
+        if (s_flag == 2) return;
+        arrived_before += nblk;
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            if (!n[bb]) continue;
+            Vin[bb] = a.Vbuf[bb][oi[bb]];
+            Min[bb] = a.Mbuf[bb][oi[bb]];
+            oi[bb] ^= 1;
+            n[bb] >>= 1;
+        }
+    }
+}
+
 // Hybrid tail: the live tables of a phase (at most 256 entries each) to mapped host memory in one small launch; seq is written last.
 struct export_out { fr_t V[2][256], M[2][256]; unsigned long long seq; };
 struct export_args { const fr_t *V[2], *M[2]; uint32_t n[2]; export_out *out; unsigned long long seq; };

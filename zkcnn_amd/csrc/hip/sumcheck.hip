@@ -28,6 +28,7 @@ int32_t zk_dev_alloc(zk_ctx *ctx, void **p, size_t bytes) {
     if (bytes == 0) bytes = 32;
     ZK_HIP(hipMalloc(p, bytes));
     (ctx->alloc_sink ? *ctx->alloc_sink : ctx->owned).push_back(*p);       // (the static part of a circuit belongs to its registry entry)
+    if (ctx->alloc_sink) ctx->sink_bytes += bytes;
     return ZK_OK;
 }
 int32_t zk_scratch(zk_ctx *ctx, size_t bytes) {
@@ -80,6 +81,7 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
     ctx->partial_blocks = 4096;
     if (zk_dev_alloc(ctx, (void **) &ctx->partials, (size_t) ctx->partial_blocks * 4 * 32) ||
         zk_dev_alloc(ctx, (void **) &ctx->d_result, 32 * 32) ||
+        zk_dev_alloc(ctx, &ctx->d_bcast, sizeof(mid_bcast)) || hipMemsetAsync(ctx->d_bcast, 0, sizeof(mid_bcast), ctx->stream) != hipSuccess ||
         zk_dev_alloc(ctx, (void **) &ctx->d_counter, 64) ||
         hipHostMalloc((void **) &ctx->h_slot, sizeof(*ctx->h_slot), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer(&ctx->d_slot, ctx->h_slot, 0) != hipSuccess ||
@@ -393,6 +395,7 @@ struct shared_circuit {
     uint64_t key[2] = {0, 0};
     int refs = 0;
     bool ready = false, failed = false;
+    uint64_t bytes = 0;             // device memory of the static part
     std::mutex mtx;                 // held while the entry is being built
     std::vector<void *> owned;      // device allocations of the static part
     std::vector<dev_layer> L;       // (val == nullptr)
@@ -405,12 +408,13 @@ struct shared_circuit {
 };
 static std::mutex g_circ_mtx;
 static std::vector<shared_circuit *> g_circuits;
-static std::atomic<uint64_t> g_circ_builds{0}, g_circ_attaches{0};
+static std::atomic<uint64_t> g_circ_builds{0}, g_circ_attaches{0}, g_circ_bytes{0};
 
 extern "C" void zk_sharing_stats(uint64_t *circuit_builds, uint64_t *circuit_attaches) {
     if (circuit_builds) *circuit_builds = g_circ_builds.load();
     if (circuit_attaches) *circuit_attaches = g_circ_attaches.load();
 }
+extern "C" uint64_t zk_shared_circuit_bytes(void) { return g_circ_bytes.load(); }
 
 // 128-bit digest of a byte range: four 64-bit multiply-rotate lanes (NOT cryptographic: the registry is process-local, a collision would
 // attach a context to another circuit's lists and its proofs would be rejected -- a safe failure)
@@ -462,6 +466,7 @@ static void circuit_release(zk_ctx *ctx) {
     std::lock_guard<std::mutex> g(g_circ_mtx);
     if (--e->refs > 0) return;
     for (void *p : e->owned) hipFree(p);
+    g_circ_bytes -= e->bytes;
     g_circuits.erase(std::remove(g_circuits.begin(), g_circuits.end(), e), g_circuits.end());
     delete e;
 }
@@ -494,6 +499,7 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
         std::lock_guard<std::mutex> g(e->mtx);         // (a second context uploading the same circuit at the same time waits here, then attaches)
         if (!e->ready && !e->failed) {
             ctx->alloc_sink = &e->owned;
+            ctx->sink_bytes = 0;
             rc = build_static(ctx, layers, n_layers, two_mul, n_two_mul, hints, n_hints);
             ctx->alloc_sink = nullptr;
             if (rc == ZK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "upload failed"; rc = ZK_ERR_HIP; }
@@ -505,6 +511,8 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
                 e->conv_layers = ctx->conv_layers;
                 e->sz = ctx->sz;
                 e->ready = true;
+                e->bytes = ctx->sink_bytes;
+                g_circ_bytes += e->bytes;
                 ++g_circ_builds;
             } else e->failed = true;
         } else if (e->ready) {
@@ -579,6 +587,7 @@ static int32_t build_static(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_
             }
         }
         Z.bu = std::max<uint64_t>(Z.bu, 1ull << std::max<int>(std::max<int>(S.max_bl_u, S.max_bl_v), 0));
+        for (int bl : {(int) S.bit_length_u[0], (int) S.bit_length_v[0]}) if (bl >= 0) Z.sub = std::max<uint64_t>(Z.sub, 1ull << bl);
         if (S.fft_bit_length >= 0) Z.gs = std::max<uint64_t>(Z.gs, 1ull << S.fft_bit_length);
 
         if (S.size_u[0]) {
@@ -765,7 +774,8 @@ static int32_t alloc_session(zk_ctx *ctx) {
     // bookkeeping tables: [0] takes a pair's tables as they are built, [1] only ever what a fold leaves (half, plus the guard quad)
     for (int b = 0; b < 2; ++b) {
         const uint64_t cap = std::max<uint64_t>(Z.tp_cap[b], 4), half = cap / 2 + 8;
-        if ((rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].V[0], std::max<uint64_t>(Z.v0_cap[b], 4) * 32)) ||
+        // (V[0] of a pair whose V table is read in place still takes every SECOND fold: a quarter of the table)
+        if ((rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].V[0], std::max<uint64_t>(Z.v0_cap[b], cap / 4 + 8) * 32)) ||
             (rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].M[0], cap * 32)) ||
             (rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].V[1], half * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].M[1], half * 32)))
             return rc;
@@ -1571,7 +1581,9 @@ int32_t zk_live_abort(zk_ctx *ctx) {
     if (!ctx->live_active) return ZK_OK;
     live_post(ctx, HFr(0LL), TAIL_ABORT);
     ctx->live_active = false;
+    ctx->live_mid = false;
     ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_HIP(hipMemsetAsync(ctx->d_counter, 0, 64, ctx->stream));          // (a segment kernel that was sent home may have left arrivals behind)
     std::memset(ctx->h_live_in, 0, sizeof(live_in));
     for (int b = 0; b < 2; ++b) ctx->tp[b].len = 0;
     return ZK_OK;
@@ -1642,13 +1654,55 @@ static int32_t live_start(zk_ctx *ctx, const HFr &r, bool with_add_term) {
     ++ctx->live_phases_total;
     return ZK_OK;
 }
+// a segment of mid-size rounds (k_mid): `rounds` consecutive rounds in which every present pair keeps at least two quads
+static int32_t mid_start(zk_ctx *ctx, const HFr &r, bool with_add_term, int rounds, uint32_t blocks) {
+    mid_args A;
+    std::memset(&A, 0, sizeof(A));
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        if (!t.len) continue;
+        A.Vin[b] = vin(t); A.Min[b] = t.M[t.cur];
+        A.Vbuf[b][0] = t.V[0]; A.Vbuf[b][1] = t.V[1];
+        A.Mbuf[b][0] = t.M[0]; A.Mbuf[b][1] = t.M[1];
+        A.out_idx[b] = t.cur ^ 1;
+        A.n[b] = t.len;
+    }
+    A.rounds = rounds;
+    A.with_add_term = with_add_term ? 1 : 0;
+    A.prev_r = to_dev(r);
+    A.add_term = to_dev(ctx->add_term);
+    A.partials = ctx->partials;
+    A.arrive = ctx->d_counter + 2;
+    A.bc = (mid_bcast *) ctx->d_bcast;
+    A.out = (tail_out *) ctx->d_tail;
+    A.in = (const live_in *) ctx->d_live_in;
+    ctx->live_seq32 += 64;
+    if (ctx->live_seq32 > 0xf0000000u) ctx->live_seq32 = 64;
+    A.seq32 = ctx->live_seq32;
+    ((tail_out *) ctx->h_tail)->status = 0;
+    ZK_LAUNCH(PC_TAIL, 0.0, k_mid, dim3(blocks), dim3(ZK_BLOCK), A);
+    ZK_HIP(hipGetLastError());
+    if (with_add_term) ctx->add_term = ctx->add_term * (HFr::one() - r);      // (the kernel's blocks apply the same factors to their copy)
+    ctx->live_active = true;
+    ctx->live_mid = true;
+    ctx->live_with_add = with_add_term;
+    ctx->live_count = rounds;
+    ctx->live_cursor = 0;
+    ctx->last_poly_valid = false;
+    ctx->live_rounds_total += (uint64_t) rounds;
+    ++ctx->live_phases_total;
+    return ZK_OK;
+}
 // one round of the resident kernel: r is the verifier's challenge for the previous polynomial (round 0 of the kernel got it as a launch argument)
 static int32_t live_round(zk_ctx *ctx, const HFr &r, uint64_t out_abc[12]) {
     static const bool timing = getenv("ZKCNN_TIMING") != nullptr;
     const int k = ctx->live_cursor;
     const double t0 = timing ? now_s() : 0;
     if (timing && k > 0) ctx->live_t_host += t0 - ctx->live_t_exit;
-    if (k > 0) live_post(ctx, r, ctx->live_seq32 + (uint32_t) k);
+    if (k > 0) {
+        live_post(ctx, r, ctx->live_seq32 + (uint32_t) k);
+        if (ctx->live_mid && ctx->live_with_add) ctx->add_term = ctx->add_term * (HFr::one() - r);
+    }
     int32_t rc = live_wait(ctx, k, out_abc);
     if (rc) return rc;
     if (timing) {
@@ -1658,6 +1712,20 @@ static int32_t live_round(zk_ctx *ctx, const HFr &r, uint64_t out_abc[12]) {
     ++ctx->round;
     ctx->proof_size += 32 * 3;
     if (++ctx->live_cursor < ctx->live_count) return ZK_OK;
+    if (ctx->live_mid) {
+        // the segment is over: every table was folded live_count times (nothing collapsed, nothing is down to its last pair)
+        for (int b = 0; b < 2; ++b) {
+            table_pair &t = ctx->tp[b];
+            if (!t.len) continue;
+            t.Vsrc = nullptr;
+            if (ctx->live_count & 1) t.cur ^= 1;
+            t.len >>= ctx->live_count;
+            t.live = t.len;
+        }
+        ctx->live_active = false;
+        ctx->live_mid = false;
+        return ZK_OK;
+    }
     // the phase is over: the kernel has posted the bookkeeping scalar and what is left of the tables before its last polynomial, and leaves
     const tail_out *o = (const tail_out *) ctx->h_tail;
     for (int b = 0; b < 2; ++b) {
@@ -1783,6 +1851,22 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         round_quads <= tail_quads) {
         int32_t rc = run_device_rounds(ctx, r, with_add_term);
         if (rc) return rc;
+    }
+    // interactive protocol, the middle of a phase (tables of at most 2^16 entries, more quads than the tail kernel takes): a segment of
+    // rounds in one resident multi-workgroup kernel (k_mid), as long as no table collapses or reaches its last pair
+    if (ctx->live_rounds && ctx->live_now && !ctx->fs_state && ctx->host_tail_log < 0 && !ctx->live_active && ctx->round > 0 &&
+        round_quads > TAIL_QUADS && round_quads <= 16384 && std::max(ctx->tp[0].len, ctx->tp[1].len) <= (1ull << 16)) {
+        uint64_t L0 = ctx->tp[0].len, L1 = ctx->tp[1].len;
+        int rounds = 0;
+        while (ctx->round + rounds < ctx->phase_rounds && (L0 + L1) / 4 > TAIL_QUADS && (!L0 || L0 >= 8) && (!L1 || L1 >= 8)) {
+            ++rounds;
+            L0 >>= 1; L1 >>= 1;
+        }
+        if (rounds >= 2) {
+            int32_t rc = resolve_add_term(ctx);
+            if (!rc) rc = mid_start(ctx, r, with_add_term, rounds, (uint32_t) ((round_quads + 63) / 64));
+            if (rc) return rc;
+        }
     }
     // interactive protocol: a resident kernel for the rest of the phase once the tables are small (zk_set_live_rounds)
     if (ctx->live_rounds && ctx->live_now && !ctx->fs_state && ctx->host_tail_log < 0 && !ctx->live_active && ctx->phase_rounds > ctx->round &&
@@ -2219,7 +2303,7 @@ extern "C" int32_t zk_witness_dotprod(zk_ctx *ctx, uint64_t *out, uint64_t n_out
 static int32_t verifier_buffers(zk_ctx *ctx) {
     if (ctx->v_bg) return ZK_OK;
     int32_t rc;
-    const uint64_t cap_uv = std::max(ctx->beta_u_cap, ctx->beta_g_cap);
+    const uint64_t cap_uv = std::max(std::max(ctx->beta_u_cap, ctx->beta_g_cap), ctx->sz.sub);
     const uint64_t cap_g = std::max<uint64_t>(ctx->beta_g_cap, ctx->L[0].val_len);      // the layer-0 check needs eq over all of layer 0
     if ((rc = zk_dev_alloc(ctx, (void **) &ctx->v_bg, cap_g * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->v_bu, cap_uv * 32)) ||
         (rc = zk_dev_alloc(ctx, (void **) &ctx->v_bv, cap_uv * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->v_gs, ctx->beta_gs_cap * 32)))
