@@ -680,7 +680,7 @@ def main():
         "prover_ms_per_image_in_flight": round(1e3 * (prove_s + poly_s) / (steps * K), 3),
         "verifier_pass": bool(accepted), "timed_proofs_replay_verified": K, "proof_kb": round(first.proof_kb + first.poly_proof_kb, 1),
         "setup_s": round(setup_s, 1), "witness_s": round(first.witness_s, 1), "upload_sort_s": round(max(f.upload_s for f in firsts), 2),
-        "hbm_gb_all_sessions": hbm_all_gb, "hbm_gb_first_session": hbm_first_gb, "hbm_gb_per_extra_session": hbm_extra_gb, "sharing": zkcnn_amd.sharing_stats(), "distinct_picture_per_session": bool(distinct_pictures),
+        "hbm_gb_all_sessions": hbm_all_gb, "hbm_gb_first_session": hbm_first_gb, "hbm_gb_per_extra_session": hbm_extra_gb, "sharing": dict(zkcnn_amd.sharing_stats(), shared_circuit_gb=shared_gb), "distinct_picture_per_session": bool(distinct_pictures),
         "roofline": roofline, "cpu_baseline": cpu,
     }
     out.update(parity)

@@ -1583,7 +1583,8 @@ int32_t zk_live_abort(zk_ctx *ctx) {
     ctx->live_active = false;
     ctx->live_mid = false;
     ZK_HIP(hipStreamSynchronize(ctx->stream));
-    ZK_HIP(hipMemsetAsync(ctx->d_counter, 0, 64, ctx->stream));          // (a segment kernel that was sent home may have left arrivals behind)
+    ZK_HIP(hipMemsetAsync(ctx->d_counter, 0, 64, ctx->stream));          // (a segment kernel that was sent home may have left arrivals behind ...
+    ZK_HIP(hipMemsetAsync(ctx->d_bcast, 0, sizeof(mid_bcast), ctx->stream));   //  ... and the abort word in its broadcast line)
     std::memset(ctx->h_live_in, 0, sizeof(live_in));
     for (int b = 0; b < 2; ++b) ctx->tp[b].len = 0;
     return ZK_OK;
