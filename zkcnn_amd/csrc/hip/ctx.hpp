@@ -160,7 +160,7 @@ struct zk_ctx {
     bool live_rounds = true;       // zk_set_live_rounds
     bool live_active = false;
     bool live_mid = false;         // the running kernel is k_mid (a segment of mid-size rounds): the host tracks tables and add_term itself
-    bool live_with_add = false;
+    bool live_with_add = false, live_first = false;
     void *d_bcast = nullptr;       // mid_bcast: k_mid's challenge line in device memory
     bool live_now = true;          // decided per proof (zk_proof_begin): does this proof have a hardware queue to itself?
     bool counted_active = false;

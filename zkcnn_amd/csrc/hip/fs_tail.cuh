@@ -366,6 +366,7 @@ struct mid_args {
     int32_t out_idx[2];
     uint64_t n[2];                    // pre-fold length of each pair; 0 = absent; a present pair has >= 8 entries in every round of the segment
     int32_t rounds, with_add_term;
+    int32_t first, pad0_;             // the segment starts with the phase's first round (pairs, nothing is folded)
     fr_t prev_r, add_term;            // challenge of the segment's first fold; add_term BEFORE that round's (1 - r) factor
     fr_t *partials;                   // 3 per block
     uint32_t *arrive;                 // zero at launch; cumulative arrivals
@@ -418,8 +419,9 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_mid(mid_args a) {
     uint32_t arrived_before = 0;      // arrivals of all earlier rounds (every block computes the same numbers)
     if (tid == 0) { s_r = a.prev_r; s_add = a.add_term; s_flag = 0; }
     __syncthreads();
+    bool first = a.first != 0;
     for (int k = 0; k < a.rounds; ++k) {
-        const uint32_t q0 = (uint32_t) (n[0] / 4), q1 = (uint32_t) (n[1] / 4), total = q0 + q1, nblk = (total + 63) / 64;
+        const uint32_t q0 = (uint32_t) (first ? n[0] / 2 : n[0] / 4), q1 = (uint32_t) (first ? n[1] / 2 : n[1] / 4), total = q0 + q1, nblk = (total + 63) / 64;
         if (64u * lb >= total) return;                                  // this block's quads are gone (uniform: every later round is smaller)
         const fr_t r = s_r;
         // add_term (1 - r): every block tracks the scalar (one product on a wave that idles otherwise), so whoever leads the round has it
@@ -428,26 +430,39 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_mid(mid_args a) {
         const bool live = item < total;
         const int b = (live && item >= q0) ? 1 : 0;
         const uint32_t q = b ? item - q0 : item;
-        fr_t X = fr_zero();
-        if (live) {
-            const fr_t *src = (role < 2 ? (b ? Vin[1] : Vin[0]) : (b ? Min[1] : Min[0])) + 4 * (size_t) q + 2 * (role & 1);
-            fr_t e0, e1;
-            fr_load2_sc1(src, e0, e1);
-            X = fr_lerp(e0, e1, r);
-            fr_t *dst = role < 2 ? (b ? a.Vbuf[1][oi[1]] : a.Vbuf[0][oi[0]]) : (b ? a.Mbuf[1][oi[1]] : a.Mbuf[0][oi[0]]);
-            fr_store_sc1(dst + 2 * (size_t) q + (role & 1), X);
-        }
-        fr_t y1, y2, y3;
+        fr_t opA = fr_zero(), opB = fr_zero();
+        if (first) {
+            // the phase's first round: pairs as they are (reference src/prover.cpp:396-426 with nothing to fold yet)
+            if (live && role < 3) {
+                fr_t v0, v1, m0, m1;
+                fr_load2_sc1((b ? Vin[1] : Vin[0]) + 2 * (size_t) q, v0, v1);
+                fr_load2_sc1((b ? Min[1] : Min[0]) + 2 * (size_t) q, m0, m1);
+                opA = role == 0 ? v0 : role == 1 ? v1 : fr_sub(v1, v0);
+                opB = role == 0 ? m0 : role == 1 ? m1 : fr_sub(m1, m0);
+            }
+        } else {
+            fr_t X = fr_zero();
+            if (live) {
+                const fr_t *src = (role < 2 ? (b ? Vin[1] : Vin[0]) : (b ? Min[1] : Min[0])) + 4 * (size_t) q + 2 * (role & 1);
+                fr_t e0, e1;
+                fr_load2_sc1(src, e0, e1);
+                X = fr_lerp(e0, e1, r);
+                fr_t *dst = role < 2 ? (b ? a.Vbuf[1][oi[1]] : a.Vbuf[0][oi[0]]) : (b ? a.Mbuf[1][oi[1]] : a.Mbuf[0][oi[0]]);
+                fr_store_sc1(dst + 2 * (size_t) q + (role & 1), X);
+            }
+            fr_t y1, y2, y3;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            y1.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 2, 64);
-            y2.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 1, 64);
-        }
+            for (int i = 0; i < 8; ++i) {
+                y1.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 2, 64);
+                y2.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 1, 64);
+            }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) y3.v[i] = (uint32_t) __shfl_xor((int) y1.v[i], 1, 64);
-        // role 0: X = v0, y1 = m0;  role 1: X = v1, y1 = m1;  role 2: X = m0, y1 = v0, y2 = m1, y3 = v1
-        fr_t opA = role == 2 ? fr_sub(y3, y1) : X, opB = role == 2 ? fr_sub(y2, X) : y1;
-        if (role == 3 || !live) { opA = fr_zero(); opB = fr_zero(); }
+            for (int i = 0; i < 8; ++i) y3.v[i] = (uint32_t) __shfl_xor((int) y1.v[i], 1, 64);
+            // role 0: X = v0, y1 = m0;  role 1: X = v1, y1 = m1;  role 2: X = m0, y1 = v0, y2 = m1, y3 = v1
+            opA = role == 2 ? fr_sub(y3, y1) : X;
+            opB = role == 2 ? fr_sub(y2, X) : y1;
+            if (role == 3 || !live) { opA = fr_zero(); opB = fr_zero(); }
+        }
         fr_t prod = fr_mul(opA, opB);
 #pragma unroll
         for (int off = 4; off < 64; off <<= 1) {
@@ -457,15 +472,14 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_mid(mid_args a) {
             prod = fr_add(prod, o);
         }
         if (lane < 3) s_role[lane][wave] = prod;          // role 0: c, role 1: p(1), role 2: a
-        ZK_WAIT_STORES();                                  // this thread's table stores are out before the block reports in
         __syncthreads();
         if (tid < 3) {
             fr_t t = s_role[tid][0];
 #pragma unroll
             for (int w = 1; w < ZK_BLOCK / 64; ++w) t = fr_add(t, s_role[tid][w]);
             fr_store_sc1(a.partials + (size_t) 3 * lb + tid, t);
-            ZK_WAIT_STORES();
         }
+        ZK_WAIT_STORES();                                  // ONE wait per round: this thread's table stores and partial sums are out before the block reports in
         __syncthreads();
         if (tid == 0) {
             const uint32_t t = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -509,7 +523,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_mid(mid_args a) {
                     }
                     if (stop) {
                         c0.w = c1.w = c2.w = TAIL_ABORT;
-                        __hip_atomic_store(&a.out->status, (uint32_t) stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(&a.out->status, ((uint32_t) stop << 8) | (uint32_t) k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         s_flag = 2;
                     } else {
@@ -536,7 +550,12 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_mid(mid_args a) {
                         s_r = ch;
                         break;
                     }
-                    if (c0.w == TAIL_ABORT || wall_clock64() - t0 > 2 * TAIL_TIMEOUT_TICKS) { s_flag = 2; break; }
+                    if (c0.w == TAIL_ABORT) { s_flag = 2; break; }
+                    if (wall_clock64() - t0 > 2 * TAIL_TIMEOUT_TICKS) {
+                        s_flag = 2;
+                        __hip_atomic_store(&a.out->status, 0x300u | (uint32_t) k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // a follower never saw the round's challenge
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(4);
                 }
             }
@@ -544,14 +563,17 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_mid(mid_args a) {
         __syncthreads();
         if (s_flag == 2) return;
         arrived_before += nblk;
+        if (!first) {
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-            if (!n[bb]) continue;
-            Vin[bb] = a.Vbuf[bb][oi[bb]];
-            Min[bb] = a.Mbuf[bb][oi[bb]];
-            oi[bb] ^= 1;
-            n[bb] >>= 1;
+            for (int bb = 0; bb < 2; ++bb) {
+                if (!n[bb]) continue;
+                Vin[bb] = a.Vbuf[bb][oi[bb]];
+                Min[bb] = a.Mbuf[bb][oi[bb]];
+                oi[bb] ^= 1;
+                n[bb] >>= 1;
+            }
         }
+        first = false;
     }
 }
 

@@ -189,14 +189,12 @@ extern "C" int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries) {
     return ZK_OK;
 }
 static std::atomic<int> g_active_proofs[64];
-static int hw_queue_count() {
-    static const int n = getenv("GPU_MAX_HW_QUEUES") ? std::max(1, atoi(getenv("GPU_MAX_HW_QUEUES"))) : 4;      // (HIP's own default)
-    return n;
-}
 extern "C" int32_t zk_proof_begin(zk_ctx *ctx) {
     if (!ctx) return ZK_ERR_ARG;
     if (!ctx->counted_active) { ++g_active_proofs[ctx->device & 63]; ctx->counted_active = true; }
-    ctx->live_now = g_active_proofs[ctx->device & 63].load() <= hw_queue_count();
+    // resident kernels only for a proof that is alone on its GPU when it starts: their workgroups wait for one another (k_mid) and for the host,
+    // which is only safe -- and only profitable -- while nothing else competes for the CUs and the hardware queue for long
+    ctx->live_now = g_active_proofs[ctx->device & 63].load() <= 1;
     return ZK_OK;
 }
 extern "C" int32_t zk_proof_end(zk_ctx *ctx) {
@@ -1004,10 +1002,11 @@ static int32_t gate_multi(zk_ctx *ctx, int phase, const dev_layer &prev, const g
     return ZK_OK;
 }
 
-// a table of more than 2^16 entries is first read by the round kernel that stops at the live prefix (rounded up to whole quads): its builders
+// a table of more than 2^18 entries is first read by the round kernel that stops at the live prefix (rounded up to whole quads): its builders
 // stop there too (one guard quad behind it); smaller tables are read whole
+#define ZK_FULL_TABLE_LOG 18          // tables of up to 2^18 entries are always complete: their readers (k_round_quad_fine, k_mid, k_tail) know no bound
 static inline uint64_t table_end(uint64_t len, uint64_t live) {
-    return len <= (1ull << 16) ? len : std::min<uint64_t>(len, ((live + 3) & ~3ull) + 4);
+    return len <= (1ull << ZK_FULL_TABLE_LOG) ? len : std::min<uint64_t>(len, ((live + 3) & ~3ull) + 4);
 }
 
 // V-table of one side: layer-0 subset through ori ids, or the previous layer as it is
@@ -1611,7 +1610,13 @@ static int32_t live_wait(zk_ctx *ctx, int k, uint64_t out_abc[12]) {
                 for (int j = 0; j < 8; ++j) if (((volatile const uint32_t *) o->live.c[j])[3] != want) late = false;
                 if (late) continue;
                 ctx->live_active = false;
-                ctx->err = "the resident round kernel left before the phase was over";
+                char msg[256];
+                const live_in *mi = (const live_in *) ctx->h_live_in;
+                std::snprintf(msg, sizeof(msg), "the resident round kernel left before the phase was over (%s, round %d of %d, status %#x, waiting for %#x, mailbox out %#x in %#x, stream %s)",
+                              ctx->live_mid ? "k_mid" : "k_tail", k, ctx->live_count, (unsigned) o->status, (unsigned) want, (unsigned) o->live.c[0][3], (unsigned) mi->c[0][3],
+                              hipStreamQuery(ctx->stream) == hipSuccess ? "idle" : "busy");
+                ctx->err = msg;
+                ctx->live_mid = false;
                 return ZK_ERR_STATE;
             }
             if (spins > (1ull << 22)) sched_yield();
@@ -1670,6 +1675,7 @@ static int32_t mid_start(zk_ctx *ctx, const HFr &r, bool with_add_term, int roun
     }
     A.rounds = rounds;
     A.with_add_term = with_add_term ? 1 : 0;
+    A.first = ctx->round == 0 ? 1 : 0;
     A.prev_r = to_dev(r);
     A.add_term = to_dev(ctx->add_term);
     A.partials = ctx->partials;
@@ -1686,6 +1692,7 @@ static int32_t mid_start(zk_ctx *ctx, const HFr &r, bool with_add_term, int roun
     if (with_add_term) ctx->add_term = ctx->add_term * (HFr::one() - r);      // (the kernel's blocks apply the same factors to their copy)
     ctx->live_active = true;
     ctx->live_mid = true;
+    ctx->live_first = A.first != 0;
     ctx->live_with_add = with_add_term;
     ctx->live_count = rounds;
     ctx->live_cursor = 0;
@@ -1718,10 +1725,13 @@ static int32_t live_round(zk_ctx *ctx, const HFr &r, uint64_t out_abc[12]) {
         for (int b = 0; b < 2; ++b) {
             table_pair &t = ctx->tp[b];
             if (!t.len) continue;
-            t.Vsrc = nullptr;
-            if (ctx->live_count & 1) t.cur ^= 1;
-            t.len >>= ctx->live_count;
-            t.live = t.len;
+            const int folds = ctx->live_count - (ctx->live_first ? 1 : 0);
+            if (folds > 0) {
+                t.Vsrc = nullptr;
+                if (folds & 1) t.cur ^= 1;
+                t.len >>= folds;
+                t.live = t.len;
+            }
         }
         ctx->live_active = false;
         ctx->live_mid = false;
@@ -1855,13 +1865,15 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
     }
     // interactive protocol, the middle of a phase (tables of at most 2^16 entries, more quads than the tail kernel takes): a segment of
     // rounds in one resident multi-workgroup kernel (k_mid), as long as no table collapses or reaches its last pair
-    if (ctx->live_rounds && ctx->live_now && !ctx->fs_state && ctx->host_tail_log < 0 && !ctx->live_active && ctx->round > 0 &&
-        round_quads > TAIL_QUADS && round_quads <= 16384 && std::max(ctx->tp[0].len, ctx->tp[1].len) <= (1ull << 16)) {
+    if (ctx->live_rounds && ctx->live_now && !ctx->fs_state && ctx->host_tail_log < 0 && !ctx->live_active &&
+        round_quads > TAIL_QUADS && round_quads <= 65536 && std::max(ctx->tp[0].len, ctx->tp[1].len) <= (1ull << 18)) {
         uint64_t L0 = ctx->tp[0].len, L1 = ctx->tp[1].len;
         int rounds = 0;
-        while (ctx->round + rounds < ctx->phase_rounds && (L0 + L1) / 4 > TAIL_QUADS && (!L0 || L0 >= 8) && (!L1 || L1 >= 8)) {
+        bool f = ctx->round == 0;          // (a first round works on pairs and folds nothing)
+        while (ctx->round + rounds < ctx->phase_rounds && (L0 + L1) / (f ? 2 : 4) > TAIL_QUADS && (!L0 || L0 >= (f ? 4u : 8u)) && (!L1 || L1 >= (f ? 4u : 8u))) {
             ++rounds;
-            L0 >>= 1; L1 >>= 1;
+            if (!f) { L0 >>= 1; L1 >>= 1; }
+            f = false;
         }
         if (rounds >= 2) {
             int32_t rc = resolve_add_term(ctx);
@@ -1924,7 +1936,7 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         // (which read whole tables) the zeros are stored
         const uint64_t live = std::min(t.live, t.len);
         A.nl[b] = live;
-        A.fill[b] = (t.len / 2 <= (1ull << std::max(fine_log, 16))) ? 1 : 0;
+        A.fill[b] = (t.len / 2 <= (1ull << ZK_FULL_TABLE_LOG)) ? 1 : 0;
         const uint64_t work = fine ? npairs : std::max<uint64_t>(first ? (live + 1) / 2 : (live + 3) / 4, first ? 1 : (A.fill[b] ? npairs / 8 : 1));
         // (k_round_quad2 holds 3 waves per SIMD: 768 blocks of 4 waves are exactly one resident set of the 1 024 SIMDs -- no partial second wave of blocks)
         const uint32_t quad_cap = 768;
