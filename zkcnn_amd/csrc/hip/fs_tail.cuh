@@ -94,6 +94,84 @@ __device__ __forceinline__ fr_t fs_round_challenge(uint32_t st[8], const fr_t &c
     }
 }
 
+// ---- the same chain step on FOUR lanes (a quad): BLAKE2s' column step is four independent G functions and so is its diagonal step. Lane c of the
+// quad owns column c of the 4 x 4 state (v[c], v[c+4], v[c+8], v[c+12]); between the two steps rows 1..3 rotate by 1..3 lanes (DPP quad
+// permutes, one full-rate instruction each). Inputs and outputs are REPLICATED on the four lanes; ~46 instructions per round instead of 112 on
+// one lane, so a challenge costs ~1.5 us instead of ~4.5 (host twin and test vector: ff/blake2s.hpp, tests/test_wire_cpu.py via the transcripts). ----
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t x) { return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t quad_sel(uint32_t c, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) { return c == 0 ? w0 : c == 1 ? w1 : c == 2 ? w2 : w3; }
+__device__ __forceinline__ void blake2s_compress4(uint32_t h[8], const uint32_t m[16], uint32_t t0, bool last, uint32_t c) {
+    uint32_t va = quad_sel(c, h[0], h[1], h[2], h[3]), vb = quad_sel(c, h[4], h[5], h[6], h[7]);
+    uint32_t vc = quad_sel(c, zkff::Blake2s::iv(0), zkff::Blake2s::iv(1), zkff::Blake2s::iv(2), zkff::Blake2s::iv(3));
+    uint32_t vd = quad_sel(c, zkff::Blake2s::iv(4) ^ t0, zkff::Blake2s::iv(5), last ? ~zkff::Blake2s::iv(6) : zkff::Blake2s::iv(6), zkff::Blake2s::iv(7));
+#define ZK_G4(x, y)                                                                       \
+    va = va + vb + (x); vd = zkff::Blake2s::rotr(vd ^ va, 16);                            \
+    vc = vc + vd;       vb = zkff::Blake2s::rotr(vb ^ vc, 12);                            \
+    va = va + vb + (y); vd = zkff::Blake2s::rotr(vd ^ va, 8);                             \
+    vc = vc + vd;       vb = zkff::Blake2s::rotr(vb ^ vc, 7);
+#define ZK_R4(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)       \
+    ZK_G4(quad_sel(c, m[s0], m[s2], m[s4], m[s6]), quad_sel(c, m[s1], m[s3], m[s5], m[s7]))             \
+    vb = quad_perm<0x39>(vb); vc = quad_perm<0x4E>(vc); vd = quad_perm<0x93>(vd);                         \
+    ZK_G4(quad_sel(c, m[s8], m[s10], m[s12], m[s14]), quad_sel(c, m[s9], m[s11], m[s13], m[s15]))       \
+    vb = quad_perm<0x93>(vb); vc = quad_perm<0x4E>(vc); vd = quad_perm<0x39>(vd);
+    ZK_R4(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    ZK_R4(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+    ZK_R4(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+    ZK_R4(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+    ZK_R4(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+    ZK_R4(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+    ZK_R4(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+    ZK_R4(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+    ZK_R4(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+    ZK_R4(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+#undef ZK_R4
+#undef ZK_G4
+    const uint32_t x0 = quad_sel(c, h[0], h[1], h[2], h[3]) ^ va ^ vc, x1 = quad_sel(c, h[4], h[5], h[6], h[7]) ^ vb ^ vd;
+    h[0] = quad_perm<0x00>(x0); h[1] = quad_perm<0x55>(x0); h[2] = quad_perm<0xAA>(x0); h[3] = quad_perm<0xFF>(x0);
+    h[4] = quad_perm<0x00>(x1); h[5] = quad_perm<0x55>(x1); h[6] = quad_perm<0xAA>(x1); h[7] = quad_perm<0xFF>(x1);
+}
+// state' = BLAKE2s-256(state || msg) on a quad (blake2s_chain_words of ff/blake2s.hpp)
+__device__ __forceinline__ void blake2s_chain_words4(uint32_t state[8], const uint32_t *msg, int n_words, uint32_t c) {
+    uint32_t h[8], m[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = zkff::Blake2s::iv(i);
+    h[0] ^= 0x01010020u;
+    const int total = 8 + n_words;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = i < 8 ? state[i] : (i - 8 < n_words ? msg[i - 8] : 0u);
+    if (total <= 16) {
+        blake2s_compress4(h, m, (uint32_t) total * 4, true, c);
+    } else {
+        blake2s_compress4(h, m, 64, false, c);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m[i] = (16 + i - 8 < n_words) ? msg[16 + i - 8] : 0u;
+        blake2s_compress4(h, m, (uint32_t) total * 4, true, c);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) state[i] = h[i];
+}
+// fs_round_challenge on a quad: every lane of the quad passes the same st / coefficients and gets the same challenge
+__device__ __forceinline__ fr_t fs_round_challenge4(uint32_t st[8], const fr_t &ca, const fr_t &cb, const fr_t &cc, uint32_t c) {
+    uint32_t msg[24];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { msg[i] = ca.v[i]; msg[8 + i] = cb.v[i]; msg[16 + i] = cc.v[i]; }
+    blake2s_chain_words4(st, msg, 24, c);
+    for (;;) {
+        uint32_t cand[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cand[i] = st[i];
+        cand[7] &= 0x7fffffffu;
+        if (!fr_raw_ge_mod(cand)) {
+            fr_t ch;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ch.v[i] = cand[i];
+            return ch;
+        }
+        blake2s_chain_words4(st, st, 0, c);                // rejected (probability ~9%): one more step, empty message
+    }
+}
+
 typedef uint32_t zk_u32x4 __attribute__((ext_vector_type(4)));
 // one 16-byte access that goes to the host every time (system scope: sc0 sc1 on gfx94x / gfx950)
 __device__ __forceinline__ void store16_sys(void *p, zk_u32x4 v) {
@@ -239,18 +317,41 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
                 for (int i = 0; i < 8; ++i) o.v[i] = (uint32_t) __shfl_xor((int) tot.v[i], off, 64);
                 tot = fr_add(tot, o);
             }
-            fr_t ca = tot, cc = fr_shfl_down(tot, 16), p1 = fr_shfl_down(tot, 32);
-            if (tid == 0) {
+            fr_t ca, cc, p1;                                   // every lane of wave 0 gets the three sums (lanes 0, 16, 32 hold them)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                ca.v[i] = (uint32_t) __shfl((int) tot.v[i], 0, 64);
+                cc.v[i] = (uint32_t) __shfl((int) tot.v[i], 16, 64);
+                p1.v[i] = (uint32_t) __shfl((int) tot.v[i], 32, 64);
+            }
+            if (tid < (LIVE ? 1 : 4)) {                          // (non-interactive: the quad of lanes 0..3 shares the hash, all four carry the same values)
                 // host bookkeeping of quad_round (sumcheck.hip), reference src/prover.cpp:368-383
                 fr_t add_term = a.with_add_term ? s_addm : s_add;
                 fr_t cb = fr_sub(fr_sub(p1, ca), cc);
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     if (collapse[b]) add_term = fr_add(add_term, s_prod[b]);
-                s_add = add_term;
                 if (a.with_add_term) { cb = fr_sub(cb, add_term); cc = fr_add(cc, add_term); }
                 const bool last = k == a.rounds - 1;
+                if (!LIVE) {
+                    // chain step on the 96 bytes of (a, b, c) as they lie in memory, then the challenge
+                    uint32_t st[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) st[i] = s_state[i];
+                    const fr_t ch = fs_round_challenge4(st, ca, cb, cc, (uint32_t) tid);
+                    if (tid == 0) {
+                        s_add = add_term;
+                        fr_store(&a.out->poly[k][0], ca);
+                        fr_store(&a.out->poly[k][1], cb);
+                        fr_store(&a.out->poly[k][2], cc);
+                        s_r = ch;
+                        fr_store(&a.out->chal[k], ch);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) s_state[i] = st[i];
+                    }
+                }
                 if (LIVE) {
+                    s_add = add_term;
                     tail_out *o = a.out;
                     if (last) {
                         // what the host needs after the phase: posted (and acknowledged) BEFORE the last round's mailbox message
@@ -294,19 +395,6 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
                         }
                         t_wait += wall_clock64() - t0;
                     }
-                } else {
-                    fr_store(&a.out->poly[k][0], ca);
-                    fr_store(&a.out->poly[k][1], cb);
-                    fr_store(&a.out->poly[k][2], cc);
-                    // chain step on the 96 bytes of (a, b, c) as they lie in memory, then the challenge
-                    uint32_t st[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) st[i] = s_state[i];
-                    const fr_t ch = fs_round_challenge(st, ca, cb, cc);
-                    s_r = ch;
-                    fr_store(&a.out->chal[k], ch);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) s_state[i] = st[i];
                 }
             }
         }
@@ -358,7 +446,11 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
 // whole L2s once per block and round. Workgroups wait for one another, so all of them must be resident: at most 256 blocks of 256 threads,
 // and the resident kernels are only used while at most GPU_MAX_HW_QUEUES proofs are active (zk_proof_begin).
 // ------------------------------------------------------------------------------------------------
-struct __align__(16) mid_bcast { uint32_t c[3][4]; uint32_t pad_[4]; };      // challenge chunks {3 words, seq}, like live_in
+struct __align__(16) mid_bcast {
+    uint32_t c[3][4];                 // challenge chunks {3 words, seq}, like live_in
+    uint32_t st[8];                   // Fiat-Shamir: chain state after the challenge (written BEFORE the chunks: whoever sees the challenge sees the state)
+    uint32_t pad_[4];
+};
 
 struct mid_args {
     const fr_t *Vin[2], *Min[2];
@@ -374,6 +466,8 @@ struct mid_args {
     tail_out *out;
     const live_in *in;
     uint32_t seq32, pad_;
+    uint32_t fs_state[8];             // Fiat-Shamir (k_mid<false>): chain state at the segment's start
+    unsigned long long seq;           // Fiat-Shamir: published in out->seq when the segment is over
 };
 
 __device__ __forceinline__ fr_t fr_load_sc1(const fr_t *p) {
@@ -407,6 +501,9 @@ __device__ __forceinline__ void store16_sc1(void *p, zk_u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
 }
 
+// LIVE: the verifier's challenges through the host mailboxes (interactive protocol). !LIVE: the non-interactive mode -- the round's leader continues
+// the BLAKE2s chain itself (state handed from leader to leader through the broadcast line) and the host reads all polynomials afterwards.
+template <bool LIVE>
 __global__ void __launch_bounds__(ZK_BLOCK) k_mid(mid_args a) {
     __shared__ fr_t s_role[3][ZK_BLOCK / 64];
     __shared__ fr_t s_r, s_add, s_tot[3];
@@ -497,20 +594,59 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_mid(mid_args a) {
                 if (lane == 0) s_tot[wave] = tot;
             }
             __syncthreads();
-            if (tid == 0) {
+            if (tid < (LIVE ? 1 : 4)) {                          // (non-interactive: the quad of lanes 0..3 shares the hash)
                 fr_t cc = s_tot[0], p1 = s_tot[1], ca = s_tot[2];
                 fr_t cb = fr_sub(fr_sub(p1, ca), cc);
                 if (a.with_add_term) { cb = fr_sub(cb, s_add); cc = fr_add(cc, s_add); }
+                if (last_round && tid == 0) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (everybody has arrived: the counter is free for the next launch)
+                if (!LIVE) {
+                    // non-interactive: record the polynomial, continue the chain, broadcast the challenge derived from it
+                    if (tid == 0) {
+                        fr_store(&a.out->poly[k][0], ca);
+                        fr_store(&a.out->poly[k][1], cb);
+                        fr_store(&a.out->poly[k][2], cc);
+                    }
+                    uint32_t st[8];
+                    if (k == 0) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) st[i] = a.fs_state[i];
+                    } else {
+                        zk_u32x4 s0, s1, s2;
+                        load48_sc1(&a.bc->st[0], s0, s1, s2);
+                        st[0] = s0.x; st[1] = s0.y; st[2] = s0.z; st[3] = s0.w; st[4] = s1.x; st[5] = s1.y; st[6] = s1.z; st[7] = s1.w;
+                    }
+                    const fr_t ch = fs_round_challenge4(st, ca, cb, cc, (uint32_t) tid);
+                    if (tid == 0) fr_store(&a.out->chal[k], ch);
+                    ZK_WAIT_STORES();
+                    if (tid != 0) {
+                        // (lanes 1..3 only helped with the hash)
+                    } else if (last_round) {
+                        __threadfence_system();
+                        *((volatile unsigned long long *) &a.out->seq) = a.seq;
+                    } else {
+                        const zk_u32x4 s0 = {st[0], st[1], st[2], st[3]}, s1 = {st[4], st[5], st[6], st[7]};
+                        store16_sc1(&a.bc->st[0], s0);
+                        store16_sc1(&a.bc->st[4], s1);
+                        ZK_WAIT_STORES();
+                        s_r = ch;
+                        const uint32_t want = sq + 1;
+                        const zk_u32x4 c0 = {ch.v[0], ch.v[1], ch.v[2], want}, c1 = {ch.v[3], ch.v[4], ch.v[5], want}, c2 = {ch.v[6], ch.v[7], 0u, want};
+                        store16_sc1(&a.bc->c[0][0], c0);
+                        store16_sc1(&a.bc->c[1][0], c1);
+                        store16_sc1(&a.bc->c[2][0], c2);
+                    }
+                }
                 uint32_t w24[24];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { w24[i] = ca.v[i]; w24[8 + i] = cb.v[i]; w24[16 + i] = cc.v[i]; }
-                if (last_round) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (everybody has arrived: the counter is free for the next launch)
+                if (LIVE) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    zk_u32x4 ch = {w24[3 * j], w24[3 * j + 1], w24[3 * j + 2], sq};
-                    store16_sys(&a.out->live.c[j][0], ch);
+                    for (int j = 0; j < 8; ++j) {
+                        zk_u32x4 ch = {w24[3 * j], w24[3 * j + 1], w24[3 * j + 2], sq};
+                        store16_sys(&a.out->live.c[j][0], ch);
+                    }
                 }
-                if (!last_round) {
+                if (LIVE && !last_round) {
                     const uint32_t want = sq + 1;
                     const unsigned long long t0 = wall_clock64();
                     zk_u32x4 c0, c1, c2;

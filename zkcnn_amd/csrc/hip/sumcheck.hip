@@ -1687,7 +1687,7 @@ static int32_t mid_start(zk_ctx *ctx, const HFr &r, bool with_add_term, int roun
     if (ctx->live_seq32 > 0xf0000000u) ctx->live_seq32 = 64;
     A.seq32 = ctx->live_seq32;
     ((tail_out *) ctx->h_tail)->status = 0;
-    ZK_LAUNCH(PC_TAIL, 0.0, k_mid, dim3(blocks), dim3(ZK_BLOCK), A);
+    ZK_LAUNCH(PC_TAIL, 0.0, k_mid<true>, dim3(blocks), dim3(ZK_BLOCK), A);
     ZK_HIP(hipGetLastError());
     if (with_add_term) ctx->add_term = ctx->add_term * (HFr::one() - r);      // (the kernel's blocks apply the same factors to their copy)
     ctx->live_active = true;
@@ -1699,6 +1699,71 @@ static int32_t mid_start(zk_ctx *ctx, const HFr &r, bool with_add_term, int roun
     ctx->last_poly_valid = false;
     ctx->live_rounds_total += (uint64_t) rounds;
     ++ctx->live_phases_total;
+    return ZK_OK;
+}
+// the same segment in the non-interactive mode (k_mid<false>): the kernel derives the challenges itself, the host waits once and answers
+// the verifier's following calls from the record (like run_device_rounds)
+static int32_t run_device_mid(zk_ctx *ctx, const HFr &r, bool with_add_term, int rounds, uint32_t blocks) {
+    mid_args A;
+    std::memset(&A, 0, sizeof(A));
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        if (!t.len) continue;
+        A.Vin[b] = vin(t); A.Min[b] = t.M[t.cur];
+        A.Vbuf[b][0] = t.V[0]; A.Vbuf[b][1] = t.V[1];
+        A.Mbuf[b][0] = t.M[0]; A.Mbuf[b][1] = t.M[1];
+        A.out_idx[b] = t.cur ^ 1;
+        A.n[b] = t.len;
+    }
+    const bool first = ctx->round == 0;
+    A.rounds = rounds;
+    A.with_add_term = with_add_term ? 1 : 0;
+    A.first = first ? 1 : 0;
+    A.prev_r = to_dev(r);
+    A.add_term = to_dev(ctx->add_term);
+    A.partials = ctx->partials;
+    A.arrive = ctx->d_counter + 2;
+    A.bc = (mid_bcast *) ctx->d_bcast;
+    A.out = (tail_out *) ctx->d_tail;
+    ctx->live_seq32 += 64;
+    if (ctx->live_seq32 > 0xf0000000u) ctx->live_seq32 = 64;
+    A.seq32 = ctx->live_seq32;
+    std::memcpy(A.fs_state, ctx->fs_state, 32);
+    const unsigned long long seq = ++ctx->tail_seq;
+    A.seq = seq;
+    ZK_LAUNCH(PC_TAIL, 0.0, k_mid<false>, dim3(blocks), dim3(ZK_BLOCK), A);
+    ZK_HIP(hipGetLastError());
+    volatile unsigned long long *p = &((tail_out *) ctx->h_tail)->seq;
+    for (uint64_t spins = 0; *p != seq; ++spins) {
+        if (spins > (1ull << 24)) {
+            ZK_HIP(hipStreamSynchronize(ctx->stream));
+            if (*p != seq) { ctx->err = "device rounds were not published"; return ZK_ERR_STATE; }
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const tail_out *o = (const tail_out *) ctx->h_tail;
+    // what the kernel's blocks did to their copies: add_term (1 - r) per round, one fold per round but the phase's first
+    if (with_add_term) {
+        ctx->add_term = ctx->add_term * (HFr::one() - r);
+        for (int k = 1; k < rounds; ++k) { HFr c; std::memcpy(&c, &o->chal[k - 1], 32); ctx->add_term = ctx->add_term * (HFr::one() - c); }
+    }
+    const int folds = rounds - (first ? 1 : 0);
+    for (int b = 0; b < 2; ++b) {
+        table_pair &t = ctx->tp[b];
+        if (!t.len || folds <= 0) continue;
+        t.Vsrc = nullptr;
+        if (folds & 1) t.cur ^= 1;
+        t.len >>= folds;
+        t.live = t.len;
+    }
+    ctx->tail_active = true;
+    ctx->tail_count = rounds;
+    ctx->tail_cursor = 0;
+    ctx->last_poly_valid = false;
+    ctx->tail_rounds_total += (uint64_t) rounds;
+    ++ctx->tail_phases_total;
     return ZK_OK;
 }
 // one round of the resident kernel: r is the verifier's challenge for the previous polynomial (round 0 of the kernel got it as a launch argument)
@@ -1853,20 +1918,14 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         host_tail_round(ctx, r, with_add_term, out_abc);
         return ZK_OK;
     }
-    // device-side rounds: the tail kernel takes over at 256 quads -- two passes over its 128 quad slots in its first round (measured on vgg11:
-    // 1 ms per proof faster than taking over at 128 or at 512)
-    const uint64_t tail_quads = 256;
-    // quads of this round over both pairs (a first round works on pairs, not quads): small enough for one thread each?
+    // quads of this round over both pairs (a first round works on pairs, not quads)
     const uint64_t round_quads = ctx->round == 0 ? (ctx->tp[0].len + ctx->tp[1].len) / 2 : (ctx->tp[0].len + ctx->tp[1].len) / 4;
-    if (ctx->fs_state && !ctx->tail_active && ctx->phase_rounds > ctx->round && *ctx->fs_pending == 0 && ctx->tp[0].len + ctx->tp[1].len > 0 &&
-        round_quads <= tail_quads) {
-        int32_t rc = run_device_rounds(ctx, r, with_add_term);
-        if (rc) return rc;
-    }
-    // interactive protocol, the middle of a phase (tables of at most 2^16 entries, more quads than the tail kernel takes): a segment of
-    // rounds in one resident multi-workgroup kernel (k_mid), as long as no table collapses or reaches its last pair
-    if (ctx->live_rounds && ctx->live_now && !ctx->fs_state && ctx->host_tail_log < 0 && !ctx->live_active &&
-        round_quads > TAIL_QUADS && round_quads <= 65536 && std::max(ctx->tp[0].len, ctx->tp[1].len) <= (1ull << 18)) {
+    const bool in_phase = !ctx->live_active && !ctx->tail_active && ctx->phase_rounds > ctx->round && ctx->tp[0].len + ctx->tp[1].len > 0;
+    const bool resident_ok = ctx->live_rounds && ctx->live_now && ctx->host_tail_log < 0 && in_phase;
+    // The middle of a phase (more quads than the single-workgroup kernel takes, tables of at most 2^18 entries): a SEGMENT of rounds in one
+    // resident multi-workgroup kernel (k_mid), as long as no table collapses or reaches its last pair. Returns the segment's length (0: none).
+    auto plan_segment = [&]() -> int {
+        if (!resident_ok || round_quads <= TAIL_QUADS || round_quads > 65536 || std::max(ctx->tp[0].len, ctx->tp[1].len) > (1ull << ZK_FULL_TABLE_LOG)) return 0;
         uint64_t L0 = ctx->tp[0].len, L1 = ctx->tp[1].len;
         int rounds = 0;
         bool f = ctx->round == 0;          // (a first round works on pairs and folds nothing)
@@ -1875,17 +1934,27 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
             if (!f) { L0 >>= 1; L1 >>= 1; }
             f = false;
         }
-        if (rounds >= 2) {
-            int32_t rc = resolve_add_term(ctx);
-            if (!rc) rc = mid_start(ctx, r, with_add_term, rounds, (uint32_t) ((round_quads + 63) / 64));
+        return rounds >= 2 ? rounds : 0;
+    };
+    if (ctx->fs_state) {
+        // non-interactive mode: the device derives the challenges itself -- a segment (k_mid<false>), or all remaining rounds of the phase once
+        // the tables are small (k_tail<false>: it takes over at TAIL_QUADS quads); the host answers the following calls from the record
+        if (in_phase && *ctx->fs_pending == 0) {
+            int32_t rc = ZK_OK;
+            if (const int rounds = plan_segment()) rc = run_device_mid(ctx, r, with_add_term, rounds, (uint32_t) ((round_quads + 63) / 64));
+            else if (round_quads <= TAIL_QUADS) rc = run_device_rounds(ctx, r, with_add_term);
             if (rc) return rc;
         }
-    }
-    // interactive protocol: a resident kernel for the rest of the phase once the tables are small (zk_set_live_rounds)
-    if (ctx->live_rounds && ctx->live_now && !ctx->fs_state && ctx->host_tail_log < 0 && !ctx->live_active && ctx->phase_rounds > ctx->round &&
-        ctx->tp[0].len + ctx->tp[1].len > 0 && round_quads <= TAIL_QUADS) {
-        int32_t rc = resolve_add_term(ctx);
-        if (!rc) rc = live_start(ctx, r, with_add_term);
+    } else if (resident_ok) {
+        // interactive protocol: the same two kernels, trading polynomials and challenges with the verifier through mailboxes
+        int32_t rc = ZK_OK;
+        if (const int rounds = plan_segment()) {
+            rc = resolve_add_term(ctx);
+            if (!rc) rc = mid_start(ctx, r, with_add_term, rounds, (uint32_t) ((round_quads + 63) / 64));
+        } else if (round_quads <= TAIL_QUADS) {
+            rc = resolve_add_term(ctx);
+            if (!rc) rc = live_start(ctx, r, with_add_term);
+        }
         if (rc) return rc;
     }
     if (ctx->live_active) return live_round(ctx, r, out_abc);
