@@ -16,7 +16,7 @@ flt = sys.argv[1] if len(sys.argv) > 1 else ""
 print("| kernel | vgpr | agpr | sgpr | vgpr spills | scratch B/lane | LDS B | waves/SIMD |")
 print("|---|---|---|---|---|---|---|---|")
 with tempfile.TemporaryDirectory() as tmp:
-    for src in ("hip/sumcheck.hip", "hip/hyrax.hip"):
+    for src in ("hip/sumcheck.hip", "hip/witness.hip", "hip/verifier.hip", "hip/hyrax.hip"):
         co = os.path.join(tmp, "x.co")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "--cuda-device-only", "--no-gpu-bundle-output", "-O3", "-std=c++17",
                                "-Wno-unused-value", "-I" + CSRC, "-c", os.path.join(CSRC, src), "-o", co])

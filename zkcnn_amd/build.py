@@ -17,7 +17,7 @@ LIB = os.path.join(ROOT, "zkcnn_amd", "lib")
 OBJ = os.path.join(ROOT, "zkcnn_amd", "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HIP_SRCS = ["hip/sumcheck.hip", "hip/hyrax.hip"]
+HIP_SRCS = ["hip/context.hip", "hip/upload.hip", "hip/sumcheck.hip", "hip/witness.hip", "hip/verifier.hip", "hip/hyrax.hip"]
 HOST_SRCS = ["host/circuit.cpp", "host/utils.cpp", "host/neuralNetwork.cpp", "host/models.cpp", "host/prover.cpp",
              "host/polyProver.cpp", "host/api.cpp"]
 

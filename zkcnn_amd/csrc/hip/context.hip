@@ -1,0 +1,200 @@
+// libzkcnn_hip.so: the prover context -- allocation, work buffers, hand-over slots and mailboxes, the built-in profiler, the run-time
+// options of a context (Fiat-Shamir chain, hybrid tail, resident rounds) and the per-proof bracket behind the resident-kernel policy.
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include "ctx.hpp"
+#include "tail_types.hpp"
+
+static std::string g_create_err;
+void zk_set_create_error(const std::string &msg) { g_create_err = msg; }
+
+// ------------------------------------------------------------------------------------------------
+// memory helpers
+// ------------------------------------------------------------------------------------------------
+int32_t zk_dev_alloc(zk_ctx *ctx, void **p, size_t bytes) {
+    if (bytes == 0) bytes = 32;
+    ZK_HIP(hipMalloc(p, bytes));
+    (ctx->alloc_sink ? *ctx->alloc_sink : ctx->owned).push_back(*p);       // (the static part of a circuit belongs to its registry entry)
+    if (ctx->alloc_sink) ctx->sink_bytes += bytes;
+    return ZK_OK;
+}
+int32_t zk_scratch(zk_ctx *ctx, size_t bytes) {
+    if (ctx->scratch.bytes >= bytes) return ZK_OK;
+    if (ctx->scratch.p) {
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        ZK_HIP(hipFree(ctx->scratch.p));
+        ctx->scratch.p = nullptr;
+        ctx->scratch.bytes = 0;
+    }
+    size_t want = bytes + bytes / 4;
+    ZK_HIP(hipMalloc(&ctx->scratch.p, want));
+    ctx->scratch.bytes = want;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
+    if (!out) return ZK_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_err = std::string("no HIP device: ") + hipGetErrorString(e);
+        return ZK_ERR_HIP;
+    }
+    if (device < 0 || device >= n) { g_create_err = "device index out of range"; return ZK_ERR_ARG; }
+    zk_ctx *ctx = new zk_ctx();
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_err = hipGetErrorString(e);
+        delete ctx;
+        return ZK_ERR_HIP;
+    }
+    // fixed-size work buffers
+    ctx->partial_blocks = 4096;
+    if (zk_dev_alloc(ctx, (void **) &ctx->partials, (size_t) ctx->partial_blocks * 4 * 32) ||
+        zk_dev_alloc(ctx, (void **) &ctx->d_result, 32 * 32) ||
+        zk_dev_alloc(ctx, &ctx->d_bcast, sizeof(mid_bcast)) || hipMemsetAsync(ctx->d_bcast, 0, sizeof(mid_bcast), ctx->stream) != hipSuccess ||
+        zk_dev_alloc(ctx, (void **) &ctx->d_counter, 64) ||
+        hipHostMalloc((void **) &ctx->h_slot, sizeof(*ctx->h_slot), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&ctx->d_slot, ctx->h_slot, 0) != hipSuccess ||
+        hipHostMalloc((void **) &ctx->h_aux, sizeof(*ctx->h_aux), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&ctx->d_aux, ctx->h_aux, 0) != hipSuccess ||
+        hipMemsetAsync(ctx->d_counter, 0, 64, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipHostMalloc((void **) &ctx->h_result, 32 * 32) != hipSuccess ||
+        hipHostMalloc((void **) &ctx->h_tail, std::max(sizeof(tail_out), sizeof(export_out)), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&ctx->d_tail, ctx->h_tail, 0) != hipSuccess ||
+        hipHostMalloc((void **) &ctx->h_live_in, sizeof(live_in), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&ctx->d_live_in, ctx->h_live_in, 0) != hipSuccess) {
+        g_create_err = ctx->err.empty() ? "allocation failed" : ctx->err;
+        zk_ctx_destroy(ctx);
+        return ZK_ERR_NOMEM;
+    }
+    std::memset((void *) ctx->h_slot, 0, sizeof(*ctx->h_slot));
+    std::memset((void *) ctx->h_aux, 0, sizeof(*ctx->h_aux));
+    std::memset(ctx->h_tail, 0, std::max(sizeof(tail_out), sizeof(export_out)));
+    std::memset(ctx->h_live_in, 0, sizeof(live_in));
+    *out = ctx;
+    return ZK_OK;
+}
+
+extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->live_active) (void) zk_live_abort(ctx);
+    (void) zk_proof_end(ctx);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->n_seg) fprintf(stderr, "[zkcnn timing] quadratic round call: %.2f us between calls (verifier + wrappers), %.2f plan + launch, %.2f waiting for the result, %.2f after (averages over %llu rounds)\n",
+                            1e6 * ctx->t_seg[0] / ctx->n_seg, 1e6 * ctx->t_seg[1] / ctx->n_seg, 1e6 * ctx->t_seg[2] / ctx->n_seg, 1e6 * ctx->t_seg[3] / ctx->n_seg, (unsigned long long) ctx->n_seg);
+    if (ctx->live_timed_rounds)
+        fprintf(stderr, "[zkcnn timing] resident round kernel: %.2f us per round from posting the challenge to reading the polynomial, %.2f us on the host between "
+                        "two round calls (%llu rounds after a kernel's first); kernel clock: %.2f us per round in total, %.2f of them polling for the challenge (%llu rounds, %llu kernels)\n",
+                1e6 * ctx->live_t_gpu / ctx->live_timed_rounds, 1e6 * ctx->live_t_host / ctx->live_timed_rounds, (unsigned long long) ctx->live_timed_rounds,
+                0.01 * ctx->live_ticks_total / std::max<uint64_t>(ctx->live_rounds_total, 1), 0.01 * ctx->live_ticks_wait / std::max<uint64_t>(ctx->live_rounds_total, 1),
+                (unsigned long long) ctx->live_rounds_total, (unsigned long long) ctx->live_phases_total);
+    zk_msm_destroy(ctx);
+    for (prof_pending &p : ctx->prof_q) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
+    for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
+    for (void *p : ctx->owned) hipFree(p);
+    zk_circuit_release(ctx);
+    if (ctx->scratch.p) hipFree(ctx->scratch.p);
+    if (ctx->w_val0.p) hipFree(ctx->w_val0.p);
+    for (dev_buf &b : ctx->w_stage) if (b.p) hipFree(b.p);
+    if (ctx->h_result) hipHostFree(ctx->h_result);
+    if (ctx->h_slot) hipHostFree((void *) ctx->h_slot);
+    if (ctx->h_aux) hipHostFree((void *) ctx->h_aux);
+    if (ctx->h_tail) hipHostFree(ctx->h_tail);
+    if (ctx->h_live_in) hipHostFree(ctx->h_live_in);
+    if (ctx->h_liu_tabs) hipHostFree(ctx->h_liu_tabs);
+    if (ctx->h_wp_ranges) hipHostFree(ctx->h_wp_ranges);
+    if (ctx->h_conv_tabs) hipHostFree(ctx->h_conv_tabs);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int32_t zk_profile_enable(zk_ctx *ctx, uint32_t class_mask) {
+    if (!ctx) return ZK_ERR_ARG;
+    ctx->prof_mask = class_mask;
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_profile_report(zk_ctx *ctx, char *buf, uint64_t cap, int32_t reset) {
+    if (!ctx || !buf || !cap) return ZK_ERR_ARG;
+    ZK_HIP(hipSetDevice(ctx->device));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    for (prof_pending &p : ctx->prof_q) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            ctx->prof_ms[p.cls] += ms;
+            ctx->prof_bytes[p.cls] += p.bytes;
+            ++ctx->prof_cnt[p.cls];
+        }
+        ctx->prof_pool.push_back(p.e0);
+        ctx->prof_pool.push_back(p.e1);
+    }
+    ctx->prof_q.clear();
+    std::string js = "{";
+    for (int c = 0; c < PC_COUNT; ++c) {
+        char line[256];
+        std::snprintf(line, sizeof(line), "%s\"%s\": {\"ms\": %.6f, \"launches\": %llu, \"bytes\": %.0f}", c ? ", " : "", prof_names[c],
+                      ctx->prof_ms[c], (unsigned long long) ctx->prof_cnt[c], ctx->prof_bytes[c]);
+        js += line;
+    }
+    js += "}";
+    std::snprintf(buf, cap, "%s", js.c_str());
+    if (reset)
+        for (int c = 0; c < PC_COUNT; ++c) { ctx->prof_ms[c] = 0; ctx->prof_bytes[c] = 0; ctx->prof_cnt[c] = 0; }
+    return ZK_OK;
+}
+
+extern "C" int32_t zk_fs_attach(zk_ctx *ctx, const uint32_t *state, const uint64_t *pending) {
+    if (!ctx || ((state == nullptr) != (pending == nullptr))) return ZK_ERR_ARG;
+    ctx->fs_state = state;
+    ctx->fs_pending = pending;
+    ctx->tail_active = false;
+    ctx->host_tail_active = false;
+    ctx->last_poly_valid = false;
+    return ZK_OK;
+}
+extern "C" int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries) {
+    if (!ctx || log_entries > 8) return ZK_ERR_ARG;
+    ctx->host_tail_log = log_entries < 0 ? -1 : log_entries;
+    return ZK_OK;
+}
+static std::atomic<int> g_active_proofs[64];
+extern "C" int32_t zk_proof_begin(zk_ctx *ctx) {
+    if (!ctx) return ZK_ERR_ARG;
+    if (!ctx->counted_active) { ++g_active_proofs[ctx->device & 63]; ctx->counted_active = true; }
+    // resident kernels only for a proof that is alone on its GPU when it starts: their workgroups wait for one another (k_mid) and for the host,
+    // which is only safe -- and only profitable -- while nothing else competes for the CUs and the hardware queue for long
+    ctx->live_now = g_active_proofs[ctx->device & 63].load() <= 1;
+    return ZK_OK;
+}
+extern "C" int32_t zk_proof_end(zk_ctx *ctx) {
+    if (!ctx) return ZK_ERR_ARG;
+    if (ctx->counted_active) { --g_active_proofs[ctx->device & 63]; ctx->counted_active = false; }
+    ctx->live_now = true;
+    return ZK_OK;
+}
+extern "C" int32_t zk_set_live_rounds(zk_ctx *ctx, int32_t on) {
+    if (!ctx) return ZK_ERR_ARG;
+    if (ctx->live_active) { int32_t rc = zk_live_abort(ctx); if (rc) return rc; }
+    ctx->live_rounds = on != 0;
+    return ZK_OK;
+}
+extern "C" int32_t zk_fs_stats(zk_ctx *ctx, uint64_t *rounds, uint64_t *phases) {
+    if (!ctx || !rounds || !phases) return ZK_ERR_ARG;
+    *rounds = ctx->tail_rounds_total + ctx->live_rounds_total;
+    *phases = ctx->tail_phases_total + ctx->live_phases_total;
+    return ZK_OK;
+}
+
+extern "C" const char *zk_last_error(const zk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+extern "C" uint64_t zk_proof_bytes(const zk_ctx *ctx) { return ctx->proof_size; }
+

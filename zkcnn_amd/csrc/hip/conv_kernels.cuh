@@ -10,12 +10,7 @@
 // instead of that times the number of positions. The upload checks the layer's gate list against this pattern record by record
 // before it enables the path (zk_upload_circuit_hinted); otherwise the generic segmented reduction runs.
 #pragma once
-#include "fr_dev.cuh"
-
-#define CONV_TAB_STRIDE 4096u           // entries per small eq table
-// table numbers inside the context's small-table buffer
-// (the tables are built by the phase's k_prep launch: prep_kernels.cuh, prep_small_block -- eq(r[0..n), .) * init for n <= 12)
-enum { CT_S0 = 0, CT_A0, CT_P0, CT_S1, CT_A1, CT_P1, CT_D, CT_C, CT_PU, CT_COUNT };
+#include "types.cuh"
 
 // part[(chunk * K + k) * len + o] = sum over the chunk's co of A_k[co] * W[co * len + o];  len = CI * m^2; grid (ceil(len / 256), chunks)
 __global__ void __launch_bounds__(ZK_BLOCK) k_conv_wa(fr_t *part, const fr_t *W, const fr_t *tabs, uint32_t len, uint32_t CO, uint32_t per, int K) {
@@ -113,34 +108,3 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_conv_m2(fr_t *M, const uint32_t *o
     }
 }
 
-// ---- witness of a direct convolution (zk_witness_rerun, conv layers whose pattern was checked at upload): the bin-gate part of
-// out[(p, co, X, Y)] = sum_{ci, dx, dy} in[(p, ci, tx, ty)] * W[(co, ci, dx, dy)], straight from the two tensors instead of from 16-byte gate
-// records with two gathers each (reference src/neuralNetwork.cpp:918-935 walks the gates). grid (ceil(n_out / 256), channel_in chunks);
-// part[chunk * n_out + g] = the chunk's share, summed by k_sum_rows; the bias additions stay on the (short) uni-gate list.
-__global__ void __launch_bounds__(ZK_BLOCK) k_conv_eval(fr_t *part, const fr_t *in, const fr_t *W, conv_desc c, uint32_t per) {
-    const uint64_t n_out = (uint64_t) c.pp * c.CO * c.nxo * c.nyo;
-    // lanes run over the output channel, so a wave shares its output position: the border tests are wave-uniform (no lane idles through a
-    // neighbour's taps) and the input value is one broadcast load; only the weights differ from lane to lane
-    const uint64_t t = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x;
-    if (t >= n_out) return;
-    const uint32_t co = (uint32_t) t & (c.CO - 1), pos = (uint32_t) (t >> c.bc_o) & (c.nxo * c.nyo - 1), p = (uint32_t) (t >> (c.bc_o + c.bx_o + c.by_o));
-    const uint32_t Y = pos & (c.nyo - 1), X = pos >> c.by_o;
-    const uint64_t g = (((uint64_t) p * c.CO + co) << (c.bx_o + c.by_o)) | pos;
-    const uint32_t ci0 = blockIdx.y * per, ci1 = min(c.CI, ci0 + per), mm = c.m * c.m;
-    const int32_t x0 = (int32_t) (X << c.ls) - (int32_t) c.pad, y0 = (int32_t) (Y << c.ls) - (int32_t) c.pad;
-    fr_t acc = fr_zero();
-    for (uint32_t ci = ci0; ci < ci1; ++ci) {
-        const fr_t *ip = in + ((size_t) p * c.CI + ci) * c.nxi * c.nyi;
-        const fr_t *wp = W + ((size_t) co * c.CI + ci) * mm;
-        for (uint32_t dx = 0; dx < c.m; ++dx) {
-            const int32_t tx = x0 + (int32_t) dx;
-            if (tx < 0 || tx >= (int32_t) c.nxi) continue;
-            for (uint32_t dy = 0; dy < c.m; ++dy) {
-                const int32_t ty = y0 + (int32_t) dy;
-                if (ty < 0 || ty >= (int32_t) c.nyi) continue;
-                acc = fr_add(acc, fr_mul(fr_load(ip + ((size_t) tx << c.by_i) + ty), fr_load(wp + dx * c.m + dy)));
-            }
-        }
-    }
-    fr_store(part + (size_t) blockIdx.y * n_out + g, acc);
-}

@@ -1,6 +1,7 @@
 // Internal state of one prover context (one GPU). Shared by sumcheck.hip and hyrax.hip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <string>
 #include <vector>
 #include "../../../include/zkcnn_hip.h"
@@ -254,6 +255,16 @@ static inline uint32_t grid_for(uint64_t work, uint32_t cap = 2048) {
     return (uint32_t) (b > cap ? cap : b);
 }
 
+// ---- helpers shared by the translation units of libzkcnn_hip.so: context.hip (context, profiler, switches), upload.hip (residency: gate
+// sort, pattern checks, the registry of resident circuits), sumcheck.hip (the prover's state machine and its kernels), witness.hip (witness
+// generation on the GPU), verifier.hip (the verifier's wiring predicates), hyrax.hip (commitment) ----
+#define ZK_CHECK_READY_ROUND() do { if (!ctx || !ctx->circuit_ready) return ZK_ERR_STATE; ZK_HIP(hipSetDevice(ctx->device)); } while (0)
+// every entry point but the three round calls first sends a resident round kernel home (its phase was abandoned)
+#define ZK_CHECK_READY() do { ZK_CHECK_READY_ROUND(); if (ctx->live_active) { int32_t rc_ = zk_live_abort(ctx); if (rc_) return rc_; } } while (0)
+#define ZK_CHECK_CTX() do { if (!ctx) return ZK_ERR_ARG; ZK_HIP(hipSetDevice(ctx->device)); if (ctx->live_active) { int32_t rc_ = zk_live_abort(ctx); if (rc_) return rc_; } } while (0)
+static inline const HFr &H(const uint64_t *p) { return *reinterpret_cast<const HFr *>(p); }
+static inline void put(uint64_t *dst, const HFr &x) { std::memcpy(dst, &x, 32); }
+
 int32_t zk_dev_alloc(zk_ctx *ctx, void **p, size_t bytes);          // tracked allocation
 int32_t zk_scratch(zk_ctx *ctx, size_t bytes);                       // grow ctx->scratch
 void zk_msm_destroy(zk_ctx *ctx);
@@ -262,3 +273,19 @@ int32_t zk_eq_table1_dev(zk_ctx *ctx, fr_t *out, int n, const HFr *r, const HFr 
 int32_t zk_col_combine_dev(zk_ctx *ctx, fr_t *out, const fr_t *Z, const fr_t *L, uint32_t cols, uint32_t rows);
 // a resident round kernel whose phase nobody finishes (a verifier that rejected mid-phase) must leave before anything else uses the stream
 int32_t zk_live_abort(zk_ctx *ctx);
+template <class T>
+static inline int32_t zk_upload(zk_ctx *ctx, T **dst, const std::vector<T> &src) {
+    *dst = nullptr;
+    if (src.empty()) return ZK_OK;
+    int32_t rc = zk_dev_alloc(ctx, (void **) dst, src.size() * sizeof(T));
+    if (rc) return rc;
+    ZK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return ZK_OK;
+}
+void zk_circuit_release(zk_ctx *ctx);                                                 // upload.hip
+void zk_set_create_error(const std::string &msg);                                     // context.hip
+// sumcheck.hip
+int32_t zk_eq_table_dev(zk_ctx *ctx, fr_t *out, int n, const HFr *r0, const HFr &a, const HFr *r1, const HFr &b, uint64_t tail_start, const HFr &tail_scale, uint64_t limit);
+int32_t zk_phi_table_dev(zk_ctx *ctx, fr_t *out, const HFr *rx, const HFr &scale, int n, bool inverse);
+fr_t *zk_powers_of_root(zk_ctx *ctx, int n, bool inverse);
+int32_t zk_wait_slot(zk_ctx *ctx, unsigned long long seq);

@@ -17,37 +17,8 @@
 //     prover answers the verifier's calls from that record and checks that the verifier's challenges are the ones derived here.
 #pragma once
 #include "kernels.cuh"
+#include "tail_types.hpp"
 #include "../ff/blake2s.hpp"
-
-#define TAIL_THREADS 1024              // 16 waves, four lanes per quad
-#define TAIL_SLOTS 256                 // quads in flight per pass
-#define TAIL_QUADS 256                 // quads (both table pairs together) the kernel accepts: one pass over the slots. (A single workgroup is one CU:
-                                       // 16 waves share 4 SIMDs, so a 256-quad round costs 4 x 2 products per SIMD -- beyond that a launch over many CUs wins)
-#define FS_TAIL_MAX_ROUNDS ZK_MAX_VARS
-#define TAIL_TIMEOUT_TICKS 300000000ull   // 3 s of s_memrealtime (100 MHz): a live kernel nobody talks to gives up
-#define TAIL_ABORT 0xffffffffu
-
-struct __align__(16) live_in {        // mapped host memory, written by the host: chunk j = {challenge words 3j, 3j+1, 3j+2, seq} (chunk 2: words 6, 7, 0)
-    uint32_t c[3][4];
-    uint32_t pad_[4];
-};
-struct __align__(16) live_out {       // mapped host memory, written by the kernel: chunk j = {words 3j .. 3j+2 of (a, b, c), seq}
-    uint32_t c[8][4];
-};
-
-struct tail_out {                     // pinned, mapped host memory
-    fr_t poly[FS_TAIL_MAX_ROUNDS][3]; // FS: round polynomials (a, b, c) as the host's quad_round returns them
-    fr_t chal[FS_TAIL_MAX_ROUNDS];    // FS: challenge derived after each of them
-    fr_t add_term;                    // bookkeeping scalar after the last round
-    fr_t tail_v[2][2];                // the two entries left in each V table ...
-    fr_t final_v[2];                  // ... or the value it collapsed to
-    uint32_t pair_state[2];           // 0 absent, 1 two entries left (tail_v), 2 collapsed (final_v)
-    uint32_t fs_state[8];             // FS: chain state after the last challenge
-    uint32_t status, pad_;            // LIVE: 0 running / finished, 1 aborted by the host, 2 timed out
-    unsigned long long ticks_wait, ticks_total;   // LIVE: 100 MHz ticks spent polling for challenges / in the whole kernel (diagnostics, written with the final state)
-    unsigned long long seq;           // FS: written last
-    live_out live;                    // LIVE: the round mailbox
-};
 
 struct tail_args {
     const fr_t *Vin[2], *Min[2];      // current tables (V may still be a layer's values: first round)
@@ -446,12 +417,6 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
 // whole L2s once per block and round. Workgroups wait for one another, so all of them must be resident: at most 256 blocks of 256 threads,
 // and the resident kernels are only used while at most GPU_MAX_HW_QUEUES proofs are active (zk_proof_begin).
 // ------------------------------------------------------------------------------------------------
-struct __align__(16) mid_bcast {
-    uint32_t c[3][4];                 // challenge chunks {3 words, seq}, like live_in
-    uint32_t st[8];                   // Fiat-Shamir: chain state after the challenge (written BEFORE the chunks: whoever sees the challenge sees the state)
-    uint32_t pad_[4];
-};
-
 struct mid_args {
     const fr_t *Vin[2], *Min[2];
     fr_t *Vbuf[2][2], *Mbuf[2][2];
@@ -714,7 +679,6 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_mid(mid_args a) {
 }
 
 // Hybrid tail: the live tables of a phase (at most 256 entries each) to mapped host memory in one small launch; seq is written last.
-struct export_out { fr_t V[2][256], M[2][256]; unsigned long long seq; };
 struct export_args { const fr_t *V[2], *M[2]; uint32_t n[2]; export_out *out; unsigned long long seq; };
 __global__ void __launch_bounds__(512) k_export_tables(export_args a) {
     const uint32_t b = threadIdx.x >> 8, i = threadIdx.x & 255;

@@ -533,8 +533,7 @@ static int32_t with_safe_retry(zk_ctx *ctx, Body body) {
 
 static_assert(sizeof(zkff::G1) == sizeof(g1j_t) && sizeof(zkff::G1Affine) == sizeof(g1a_t), "host / device point layouts must agree");
 
-#define CHECK_READY() do { if (!ctx || !ctx->circuit_ready) return ZK_ERR_STATE; ZK_HIP(hipSetDevice(ctx->device)); if (ctx->live_active) { int32_t rc_ = zk_live_abort(ctx); if (rc_) return rc_; } } while (0)
-static inline const HFr &H(const uint64_t *p) { return *reinterpret_cast<const HFr *>(p); }
+#define CHECK_READY() ZK_CHECK_READY()
 
 // rowsJ[i] += blinds[i] * H for i < rows, H = generator number h_index of the cached set (zero-knowledge mode). The blinds are host
 // scalars; they go through the generic window kernels as a one-column matrix whose only column is H.

@@ -1,822 +1,20 @@
-// libzkcnn_hip.so, part 1: context, residency and the GKR sumcheck state machine on the GPU.
-// Each extern "C" function is the binding of one reference prover method (see include/zkcnn_hip.h);
-// the O(1)-per-round scalar bookkeeping (add_term, round counters, proof-size counter) stays in
-// host code here exactly as in the reference, everything that is O(table) or O(gates) is a kernel.
+// libzkcnn_hip.so: the GKR sumcheck state machine on the GPU. Each extern "C" function is the binding of one reference prover method
+// (see include/zkcnn_hip.h); the O(1)-per-round scalar bookkeeping (add_term, round counters, proof-size counter) stays in host code here
+// exactly as in the reference, everything that is O(table) or O(gates) is a kernel. (Context: context.hip; residency: upload.hip; witness:
+// witness.hip; verifier predicates: verifier.hip; commitment: hyrax.hip.)
 #include <chrono>
 #include <sched.h>
 #include <time.h>
 #include <algorithm>
 #include <cmath>
 #include <atomic>
-#include <mutex>
 #include <cstring>
 #include <emmintrin.h>
 #include "ctx.hpp"
 #include "kernels.cuh"
 #include "fs_tail.cuh"
-#include "witness_kernels.cuh"
 #include "conv_kernels.cuh"
 #include "prep_kernels.cuh"
-
-static std::string g_create_err;
-static void circuit_release(zk_ctx *ctx);
-
-// ------------------------------------------------------------------------------------------------
-// memory helpers
-// ------------------------------------------------------------------------------------------------
-int32_t zk_dev_alloc(zk_ctx *ctx, void **p, size_t bytes) {
-    if (bytes == 0) bytes = 32;
-    ZK_HIP(hipMalloc(p, bytes));
-    (ctx->alloc_sink ? *ctx->alloc_sink : ctx->owned).push_back(*p);       // (the static part of a circuit belongs to its registry entry)
-    if (ctx->alloc_sink) ctx->sink_bytes += bytes;
-    return ZK_OK;
-}
-int32_t zk_scratch(zk_ctx *ctx, size_t bytes) {
-    if (ctx->scratch.bytes >= bytes) return ZK_OK;
-    if (ctx->scratch.p) {
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
-        ZK_HIP(hipFree(ctx->scratch.p));
-        ctx->scratch.p = nullptr;
-        ctx->scratch.bytes = 0;
-    }
-    size_t want = bytes + bytes / 4;
-    ZK_HIP(hipMalloc(&ctx->scratch.p, want));
-    ctx->scratch.bytes = want;
-    return ZK_OK;
-}
-template <class T>
-static int32_t upload(zk_ctx *ctx, T **dst, const std::vector<T> &src) {
-    *dst = nullptr;
-    if (src.empty()) return ZK_OK;
-    int32_t rc = zk_dev_alloc(ctx, (void **) dst, src.size() * sizeof(T));
-    if (rc) return rc;
-    ZK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
-    return ZK_OK;
-}
-
-extern "C" int32_t zk_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
-
-extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
-    if (!out) return ZK_ERR_ARG;
-    *out = nullptr;
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) {
-        g_create_err = std::string("no HIP device: ") + hipGetErrorString(e);
-        return ZK_ERR_HIP;
-    }
-    if (device < 0 || device >= n) { g_create_err = "device index out of range"; return ZK_ERR_ARG; }
-    zk_ctx *ctx = new zk_ctx();
-    ctx->device = device;
-    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
-        g_create_err = hipGetErrorString(e);
-        delete ctx;
-        return ZK_ERR_HIP;
-    }
-    // fixed-size work buffers
-    ctx->partial_blocks = 4096;
-    if (zk_dev_alloc(ctx, (void **) &ctx->partials, (size_t) ctx->partial_blocks * 4 * 32) ||
-        zk_dev_alloc(ctx, (void **) &ctx->d_result, 32 * 32) ||
-        zk_dev_alloc(ctx, &ctx->d_bcast, sizeof(mid_bcast)) || hipMemsetAsync(ctx->d_bcast, 0, sizeof(mid_bcast), ctx->stream) != hipSuccess ||
-        zk_dev_alloc(ctx, (void **) &ctx->d_counter, 64) ||
-        hipHostMalloc((void **) &ctx->h_slot, sizeof(*ctx->h_slot), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-        hipHostGetDevicePointer(&ctx->d_slot, ctx->h_slot, 0) != hipSuccess ||
-        hipHostMalloc((void **) &ctx->h_aux, sizeof(*ctx->h_aux), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-        hipHostGetDevicePointer(&ctx->d_aux, ctx->h_aux, 0) != hipSuccess ||
-        hipMemsetAsync(ctx->d_counter, 0, 64, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
-        hipHostMalloc((void **) &ctx->h_result, 32 * 32) != hipSuccess ||
-        hipHostMalloc((void **) &ctx->h_tail, std::max(sizeof(tail_out), sizeof(export_out)), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-        hipHostGetDevicePointer(&ctx->d_tail, ctx->h_tail, 0) != hipSuccess ||
-        hipHostMalloc((void **) &ctx->h_live_in, sizeof(live_in), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-        hipHostGetDevicePointer(&ctx->d_live_in, ctx->h_live_in, 0) != hipSuccess) {
-        g_create_err = ctx->err.empty() ? "allocation failed" : ctx->err;
-        zk_ctx_destroy(ctx);
-        return ZK_ERR_NOMEM;
-    }
-    std::memset((void *) ctx->h_slot, 0, sizeof(*ctx->h_slot));
-    std::memset((void *) ctx->h_aux, 0, sizeof(*ctx->h_aux));
-    std::memset(ctx->h_tail, 0, std::max(sizeof(tail_out), sizeof(export_out)));
-    std::memset(ctx->h_live_in, 0, sizeof(live_in));
-    *out = ctx;
-    return ZK_OK;
-}
-
-extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
-    if (!ctx) return;
-    hipSetDevice(ctx->device);
-    if (ctx->live_active) (void) zk_live_abort(ctx);
-    (void) zk_proof_end(ctx);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    if (ctx->n_seg) fprintf(stderr, "[zkcnn timing] quadratic round call: %.2f us between calls (verifier + wrappers), %.2f plan + launch, %.2f waiting for the result, %.2f after (averages over %llu rounds)\n",
-                            1e6 * ctx->t_seg[0] / ctx->n_seg, 1e6 * ctx->t_seg[1] / ctx->n_seg, 1e6 * ctx->t_seg[2] / ctx->n_seg, 1e6 * ctx->t_seg[3] / ctx->n_seg, (unsigned long long) ctx->n_seg);
-    if (ctx->live_timed_rounds)
-        fprintf(stderr, "[zkcnn timing] resident round kernel: %.2f us per round from posting the challenge to reading the polynomial, %.2f us on the host between "
-                        "two round calls (%llu rounds after a kernel's first); kernel clock: %.2f us per round in total, %.2f of them polling for the challenge (%llu rounds, %llu kernels)\n",
-                1e6 * ctx->live_t_gpu / ctx->live_timed_rounds, 1e6 * ctx->live_t_host / ctx->live_timed_rounds, (unsigned long long) ctx->live_timed_rounds,
-                0.01 * ctx->live_ticks_total / std::max<uint64_t>(ctx->live_rounds_total, 1), 0.01 * ctx->live_ticks_wait / std::max<uint64_t>(ctx->live_rounds_total, 1),
-                (unsigned long long) ctx->live_rounds_total, (unsigned long long) ctx->live_phases_total);
-    zk_msm_destroy(ctx);
-    for (prof_pending &p : ctx->prof_q) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
-    for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
-    for (void *p : ctx->owned) hipFree(p);
-    circuit_release(ctx);
-    if (ctx->scratch.p) hipFree(ctx->scratch.p);
-    if (ctx->w_val0.p) hipFree(ctx->w_val0.p);
-    for (dev_buf &b : ctx->w_stage) if (b.p) hipFree(b.p);
-    if (ctx->h_result) hipHostFree(ctx->h_result);
-    if (ctx->h_slot) hipHostFree((void *) ctx->h_slot);
-    if (ctx->h_aux) hipHostFree((void *) ctx->h_aux);
-    if (ctx->h_tail) hipHostFree(ctx->h_tail);
-    if (ctx->h_live_in) hipHostFree(ctx->h_live_in);
-    if (ctx->h_liu_tabs) hipHostFree(ctx->h_liu_tabs);
-    if (ctx->h_wp_ranges) hipHostFree(ctx->h_wp_ranges);
-    if (ctx->h_conv_tabs) hipHostFree(ctx->h_conv_tabs);
-    if (ctx->stream) hipStreamDestroy(ctx->stream);
-    delete ctx;
-}
-
-extern "C" int32_t zk_profile_enable(zk_ctx *ctx, uint32_t class_mask) {
-    if (!ctx) return ZK_ERR_ARG;
-    ctx->prof_mask = class_mask;
-    return ZK_OK;
-}
-
-extern "C" int32_t zk_profile_report(zk_ctx *ctx, char *buf, uint64_t cap, int32_t reset) {
-    if (!ctx || !buf || !cap) return ZK_ERR_ARG;
-    ZK_HIP(hipSetDevice(ctx->device));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    for (prof_pending &p : ctx->prof_q) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
-            ctx->prof_ms[p.cls] += ms;
-            ctx->prof_bytes[p.cls] += p.bytes;
-            ++ctx->prof_cnt[p.cls];
-        }
-        ctx->prof_pool.push_back(p.e0);
-        ctx->prof_pool.push_back(p.e1);
-    }
-    ctx->prof_q.clear();
-    std::string js = "{";
-    for (int c = 0; c < PC_COUNT; ++c) {
-        char line[256];
-        std::snprintf(line, sizeof(line), "%s\"%s\": {\"ms\": %.6f, \"launches\": %llu, \"bytes\": %.0f}", c ? ", " : "", prof_names[c],
-                      ctx->prof_ms[c], (unsigned long long) ctx->prof_cnt[c], ctx->prof_bytes[c]);
-        js += line;
-    }
-    js += "}";
-    std::snprintf(buf, cap, "%s", js.c_str());
-    if (reset)
-        for (int c = 0; c < PC_COUNT; ++c) { ctx->prof_ms[c] = 0; ctx->prof_bytes[c] = 0; ctx->prof_cnt[c] = 0; }
-    return ZK_OK;
-}
-
-extern "C" int32_t zk_fs_attach(zk_ctx *ctx, const uint32_t *state, const uint64_t *pending) {
-    if (!ctx || ((state == nullptr) != (pending == nullptr))) return ZK_ERR_ARG;
-    ctx->fs_state = state;
-    ctx->fs_pending = pending;
-    ctx->tail_active = false;
-    ctx->host_tail_active = false;
-    ctx->last_poly_valid = false;
-    return ZK_OK;
-}
-extern "C" int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries) {
-    if (!ctx || log_entries > 8) return ZK_ERR_ARG;
-    ctx->host_tail_log = log_entries < 0 ? -1 : log_entries;
-    return ZK_OK;
-}
-static std::atomic<int> g_active_proofs[64];
-extern "C" int32_t zk_proof_begin(zk_ctx *ctx) {
-    if (!ctx) return ZK_ERR_ARG;
-    if (!ctx->counted_active) { ++g_active_proofs[ctx->device & 63]; ctx->counted_active = true; }
-    // resident kernels only for a proof that is alone on its GPU when it starts: their workgroups wait for one another (k_mid) and for the host,
-    // which is only safe -- and only profitable -- while nothing else competes for the CUs and the hardware queue for long
-    ctx->live_now = g_active_proofs[ctx->device & 63].load() <= 1;
-    return ZK_OK;
-}
-extern "C" int32_t zk_proof_end(zk_ctx *ctx) {
-    if (!ctx) return ZK_ERR_ARG;
-    if (ctx->counted_active) { --g_active_proofs[ctx->device & 63]; ctx->counted_active = false; }
-    ctx->live_now = true;
-    return ZK_OK;
-}
-extern "C" int32_t zk_set_live_rounds(zk_ctx *ctx, int32_t on) {
-    if (!ctx) return ZK_ERR_ARG;
-    if (ctx->live_active) { int32_t rc = zk_live_abort(ctx); if (rc) return rc; }
-    ctx->live_rounds = on != 0;
-    return ZK_OK;
-}
-extern "C" int32_t zk_fs_stats(zk_ctx *ctx, uint64_t *rounds, uint64_t *phases) {
-    if (!ctx || !rounds || !phases) return ZK_ERR_ARG;
-    *rounds = ctx->tail_rounds_total + ctx->live_rounds_total;
-    *phases = ctx->tail_phases_total + ctx->live_phases_total;
-    return ZK_OK;
-}
-
-extern "C" const char *zk_last_error(const zk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
-extern "C" uint64_t zk_proof_bytes(const zk_ctx *ctx) { return ctx->proof_size; }
-
-// ------------------------------------------------------------------------------------------------
-// residency
-// ------------------------------------------------------------------------------------------------
-// number of leading keys 0, 1, 2, ... that occur in a list sorted by key
-static uint32_t covered_prefix(const std::vector<gate_rec> &recs) {
-    uint32_t k = 0;
-    for (const gate_rec &r : recs) {
-        if (r.key == k) ++k;
-        else if (r.key > k) break;
-    }
-    return k;
-}
-// records after padding every run of equal keys (list sorted by key) to a multiple of G
-static uint64_t padded_size(const std::vector<gate_rec> &recs, uint32_t G) {
-    uint64_t total = 0;
-    size_t i = 0;
-    while (i < recs.size()) {
-        size_t j = i;
-        while (j < recs.size() && recs[j].key == recs[i].key) ++j;
-        total += ((j - i + G - 1) / G) * G;
-        i = j;
-    }
-    return total;
-}
-// records per thread for a list: the largest of 32 / 16 / 8 / 4 whose padding costs less than 1/8 of the list
-static uint32_t choose_group(const std::vector<gate_rec> &recs) {
-    for (uint32_t G = 32; G > GATE_GROUP; G >>= 1)
-        if (padded_size(recs, G) <= recs.size() + recs.size() / 8) return G;
-    return GATE_GROUP;
-}
-// pads every run of equal keys (list sorted by key) to a multiple of G records with padding records of the same key
-static void pad_runs(std::vector<gate_rec> &recs, uint32_t G) {
-    std::vector<gate_rec> out;
-    out.reserve(recs.size() + recs.size() / 8 + 64 * G);
-    size_t i = 0;
-    while (i < recs.size()) {
-        size_t j = i;
-        while (j < recs.size() && recs[j].key == recs[i].key) ++j;
-        out.insert(out.end(), recs.begin() + i, recs.begin() + j);
-        for (size_t k = j - i; k % G; ++k) {
-            gate_rec d = {0, recs[i].key, 0, 1u << 11};
-            out.push_back(d);
-        }
-        i = j;
-    }
-    // whole waves: the list is padded to a multiple of 64 groups with records of the last key, and inside every chunk of
-    // 64 x G records the k-th record of lane l is stored at slot k * 64 + l, so that each of the kernel's G loads is one
-    // contiguous 1 KB access of the wave
-    const size_t chunk = 64 * (size_t) G;
-    while (!out.empty() && out.size() % chunk) {
-        gate_rec d = {0, out.back().key, 0, 1u << 11};
-        out.push_back(d);
-    }
-    recs.resize(out.size());
-    for (size_t base = 0; base < out.size(); base += chunk)
-        for (size_t l = 0; l < 64; ++l)
-            for (size_t k = 0; k < G; ++k) recs[base + k * 64 + l] = out[base + l * G + k];
-}
-static void counting_sort(std::vector<gate_rec> &recs, uint32_t nkeys) {
-    std::vector<uint32_t> cnt((size_t) nkeys + 1, 0);
-    for (const gate_rec &r : recs) ++cnt[r.key + 1];
-    for (uint32_t k = 0; k < nkeys; ++k) cnt[k + 1] += cnt[k];
-    std::vector<gate_rec> out(recs.size());
-    for (const gate_rec &r : recs) out[cnt[r.key]++] = r;
-    recs.swap(out);
-}
-
-static uint32_t ceil_log2(uint32_t x) {
-    uint32_t b = 0;
-    while ((1ull << b) < x) ++b;
-    return b;
-}
-static int log2_exact(uint32_t x) {          // -1 unless x is a power of two
-    if (!x || (x & (x - 1))) return -1;
-    int b = 0;
-    while ((1u << b) < x) ++b;
-    return b;
-}
-// does layer S (with its predecessor P) consist of exactly the gates a direct convolution with these parameters emits?
-static bool conv_hint_matches(const zk_conv_hint &h, const zk_layer_desc &S, const zk_layer_desc &P, conv_desc &c) {
-    if (S.ty != ZK_NCONV) return false;
-    c.pp = h.pic_parallel; c.CO = h.channel_out; c.CI = h.channel_in; c.nxi = h.nx_in; c.nyi = h.ny_in; c.nxo = h.nx_out; c.nyo = h.ny_out;
-    c.m = h.m; c.pad = h.padding; c.ls = h.log_stride; c.wstart = h.weight_start;
-    c.bx_i = log2_exact(c.nxi); c.by_i = log2_exact(c.nyi); c.bc_i = log2_exact(c.CI);
-    c.bx_o = log2_exact(c.nxo); c.by_o = log2_exact(c.nyo); c.bc_o = log2_exact(c.CO);
-    if (c.bx_i < 0 || c.by_i < 0 || c.bc_i < 0 || c.bx_o < 0 || c.by_o < 0 || c.bc_o < 0 || !c.pp || !c.m || c.m > 16 || c.ls > 4 || c.pad > 16) return false;
-    if (c.bx_i + c.by_i > 12 || c.bx_o + c.by_o > 12 || c.bc_i > 12 || c.bc_o > 12 || c.pp > 4096) return false;
-    const uint64_t n_out = (uint64_t) c.pp * c.CO * c.nxo * c.nyo, n_in = (uint64_t) c.pp * c.CI * c.nxi * c.nyi;
-    // (the previous layer may be longer than the tensor the convolution reads: a RELU / pooling layer keeps its constraint rows behind its outputs)
-    if (n_out != S.size || n_in > P.size || S.size_u[1] != P.size || S.size_v[0] != (uint64_t) c.CO * c.CI * c.m * c.m) return false;
-    if (S.bit_length != c.bx_o + c.by_o + c.bc_o + (int) ceil_log2(c.pp) || S.bit_length_u[1] != P.bit_length) return false;
-    if (S.max_bl_u - (c.bx_i + c.by_i + c.bc_i) > 12 || S.bit_length - (c.bx_o + c.by_o + c.bc_o) > 12) return false;
-    if (((c.nxi + 2 * c.pad - c.m) >> c.ls) + 1 != c.nxo || ((c.nyi + 2 * c.pad - c.m) >> c.ls) + 1 != c.nyo) return false;
-    // every bin gate, in emission order (p, co, ci, window origin, offset inside the window); operands: u in the previous layer, v in layer 0
-    const int64_t lo = -(int64_t) c.pad, Rx = (int64_t) c.nxi + c.pad, Ry = (int64_t) c.nyi + c.pad, st = 1ll << c.ls;
-    uint64_t k = 0;
-    for (uint32_t p = 0; p < c.pp; ++p)
-        for (uint32_t co = 0; co < c.CO; ++co)
-            for (uint32_t ci = 0; ci < c.CI; ++ci)
-                for (int64_t x = lo; x + c.m <= Rx; x += st)
-                    for (int64_t y = lo; y + c.m <= Ry; y += st) {
-                        const uint64_t g = (((uint64_t) p * c.CO + co) * c.nxo + ((x - lo) >> c.ls)) * c.nyo + ((y - lo) >> c.ls);
-                        for (int64_t tx = x; tx < x + c.m; ++tx)
-                            for (int64_t ty = y; ty < y + c.m; ++ty) {
-                                if (tx < 0 || tx >= c.nxi || ty < 0 || ty >= c.nyi) continue;
-                                if (k >= S.n_bin) return false;
-                                const zk_bin_gate &gt = S.bin_gates[k++];
-                                const uint64_t u = (((uint64_t) p * c.CI + ci) * c.nxi + tx) * c.nyi + ty;
-                                const uint64_t v = (uint64_t) c.wstart + (((uint64_t) co * c.CI + ci) * c.m + (tx - x)) * c.m + (ty - y);
-                                if (gt.g != g || gt.u != u || gt.sc != 0 || gt.l != 2 || gt.v >= S.size_v[0] || S.ori_id_v[gt.v] != v) return false;
-                            }
-                    }
-    if (k != S.n_bin) return false;
-    // the only other gates may be uni gates whose operand lives in layer 0 (the biases): they stay on the generic lists
-    for (uint64_t j = 0; j < S.n_uni; ++j)
-        if (S.uni_gates[j].lu != 0) return false;
-    return true;
-}
-
-// No hint for an NCONV layer (e.g. the reference's unmodified circuit generator drives this library): look for the parameters. The number
-// of distinct bias operands gives channel_out, the smallest weight index the first weight, the subset size channel_out * channel_in * m^2;
-// kernel size, padding, stride and the number of pictures are tried (square pictures), and every candidate has to reproduce the gate list
-// in conv_hint_matches -- a wrong guess fails on its first gates.
-static bool conv_infer(const zk_layer_desc &S, const zk_layer_desc &P, int layer, conv_desc &c) {
-    if (S.ty != ZK_NCONV || !S.n_bin || !S.n_uni || !S.size_v[0] || S.n_uni > S.size) return false;
-    uint32_t lo_u = 0xffffffffu, hi_u = 0;
-    for (uint64_t j = 0; j < S.n_uni; ++j) {
-        if (S.uni_gates[j].lu != 0 || S.uni_gates[j].u >= S.size_u[0]) return false;
-        const uint32_t raw = S.ori_id_u[S.uni_gates[j].u];
-        lo_u = std::min(lo_u, raw);
-        hi_u = std::max(hi_u, raw);
-    }
-    const uint32_t CO = hi_u - lo_u + 1;                    // the biases are consecutive layer-0 entries
-    if (!CO || S.size % CO || S.size_v[0] % CO) return false;
-    uint32_t wstart = 0xffffffffu;
-    for (uint32_t v = 0; v < S.size_v[0]; ++v) wstart = std::min(wstart, S.ori_id_v[v]);
-    const uint64_t per_co = S.size / CO;                    // pictures * output positions
-    for (uint32_t m = 1; m <= 7; m += 2) {
-        if ((S.size_v[0] / CO) % (m * m)) continue;
-        const uint32_t CI = S.size_v[0] / CO / (m * m);
-        for (uint32_t pp = 1; pp <= 64; ++pp) {
-            if (per_co % pp) continue;
-            const uint64_t pos = per_co / pp;
-            const uint32_t nxo = (uint32_t) std::llround(std::sqrt((double) pos));
-            if ((uint64_t) nxo * nxo != pos) continue;
-            for (uint32_t ls = 0; ls <= 2; ++ls)
-                for (uint32_t pad = 0; pad < m; ++pad) {
-                    const int64_t nxi = ((int64_t) (nxo - 1) << ls) + m - 2 * (int64_t) pad;
-                    if (nxi < 1 || (uint64_t) pp * CI * nxi * nxi > P.size) continue;
-                    zk_conv_hint h = {layer, pp, CO, CI, (uint32_t) nxi, (uint32_t) nxi, nxo, nxo, m, pad, ls, wstart};
-                    if (conv_hint_matches(h, S, P, c)) return true;
-                }
-        }
-    }
-    return false;
-}
-
-extern "C" int32_t zk_structured_layers(const zk_ctx *ctx) { return ctx ? (int32_t) ctx->conv_layers : 0; }
-
-extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul,
-                                     int32_t n_two_mul) {
-    return zk_upload_circuit_hinted(ctx, layers, n_layers, two_mul, n_two_mul, nullptr, 0);
-}
-
-// ---- one resident circuit per GPU, shared by its sessions (reference src/prover.hpp:47-48: one layeredCircuit per prover) ----
-// Everything a circuit's upload produces that does not depend on the witness -- sorted and padded gate lists, subset maps, the layer-0 CSR,
-// the checked convolution patterns, buffer sizes -- lives in a ref-counted registry entry keyed by a digest of the upload's input. The
-// first context that uploads a circuit builds the entry (counting sort of 1.2e8 gates + 1.9 GB of lists for vgg11); every later context of
-// the same process and device that uploads the SAME circuit attaches to it and only allocates its own values, tables and scratch.
-struct shared_circuit {
-    int device = 0;
-    uint64_t key[2] = {0, 0};
-    int refs = 0;
-    bool ready = false, failed = false;
-    uint64_t bytes = 0;             // device memory of the static part
-    std::mutex mtx;                 // held while the entry is being built
-    std::vector<void *> owned;      // device allocations of the static part
-    std::vector<dev_layer> L;       // (val == nullptr)
-    fr_t *two_mul = nullptr;
-    int n_two_mul = 0;
-    uint32_t *liu_ptr = nullptr; void *liu_ent = nullptr; uint32_t liu_ntabs = 0;
-    std::vector<int> liu_tab_layer, liu_tab_side;
-    uint32_t conv_layers = 0;
-    circuit_sizes sz;
-};
-static std::mutex g_circ_mtx;
-static std::vector<shared_circuit *> g_circuits;
-static std::atomic<uint64_t> g_circ_builds{0}, g_circ_attaches{0}, g_circ_bytes{0};
-
-extern "C" void zk_sharing_stats(uint64_t *circuit_builds, uint64_t *circuit_attaches) {
-    if (circuit_builds) *circuit_builds = g_circ_builds.load();
-    if (circuit_attaches) *circuit_attaches = g_circ_attaches.load();
-}
-extern "C" uint64_t zk_shared_circuit_bytes(void) { return g_circ_bytes.load(); }
-
-// 128-bit digest of a byte range: four 64-bit multiply-rotate lanes (NOT cryptographic: the registry is process-local, a collision would
-// attach a context to another circuit's lists and its proofs would be rejected -- a safe failure)
-static void fast_digest(uint64_t h[4], const void *data, size_t n) {
-    const uint8_t *p = (const uint8_t *) data;
-    const uint64_t k0 = 0x9e3779b97f4a7c15ull, k1 = 0xc2b2ae3d27d4eb4full, k2 = 0x165667b19e3779f9ull, k3 = 0x27d4eb2f165667c5ull;
-    size_t i = 0;
-    for (; i + 32 <= n; i += 32) {
-        uint64_t w[4];
-        std::memcpy(w, p + i, 32);
-        h[0] = ((h[0] ^ w[0]) * k0); h[0] = (h[0] << 29) | (h[0] >> 35);
-        h[1] = ((h[1] ^ w[1]) * k1); h[1] = (h[1] << 31) | (h[1] >> 33);
-        h[2] = ((h[2] ^ w[2]) * k2); h[2] = (h[2] << 27) | (h[2] >> 37);
-        h[3] = ((h[3] ^ w[3]) * k3); h[3] = (h[3] << 33) | (h[3] >> 31);
-    }
-    uint64_t tail[4] = {0, 0, 0, (uint64_t) n};
-    std::memcpy(tail, p + i, n - i);
-    for (int j = 0; j < 4; ++j) { h[j] = (h[j] ^ tail[j]) * k1; h[j] ^= h[j] >> 32; }
-}
-static void circuit_key(uint64_t key[2], const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul, int32_t n_two_mul,
-                        const zk_conv_hint *hints, uint32_t n_hints) {
-    uint64_t h[4] = {0x243f6a8885a308d3ull, 0x13198a2e03707344ull, 0xa4093822299f31d0ull, 0x082efa98ec4e6c89ull};
-    for (int i = 0; i < n_layers; ++i) {
-        const zk_layer_desc &S = layers[i];
-        const int64_t rec[20] = {S.ty, (int64_t) S.size, S.bit_length, S.fft_bit_length, (int64_t) S.zero_start_id, (int64_t) S.n_uni, (int64_t) S.n_bin,
-                                 (int64_t) S.size_u[0], (int64_t) S.size_u[1], (int64_t) S.size_v[0], (int64_t) S.size_v[1], S.bit_length_u[0], S.bit_length_u[1],
-                                 S.bit_length_v[0], S.bit_length_v[1], S.max_bl_u, S.max_bl_v, S.need_phase2, 0, 0};
-        fast_digest(h, rec, sizeof(rec));
-        fast_digest(h, S.scale, 32);
-        if (S.n_uni) fast_digest(h, S.uni_gates, (size_t) S.n_uni * sizeof(zk_uni_gate));
-        if (S.n_bin) fast_digest(h, S.bin_gates, (size_t) S.n_bin * sizeof(zk_bin_gate));
-        if (S.size_u[0] && S.ori_id_u) fast_digest(h, S.ori_id_u, (size_t) S.size_u[0] * 4);
-        if (S.size_v[0] && S.ori_id_v) fast_digest(h, S.ori_id_v, (size_t) S.size_v[0] * 4);
-    }
-    fast_digest(h, two_mul, (size_t) n_two_mul * 32);
-    if (n_hints) fast_digest(h, hints, (size_t) n_hints * sizeof(zk_conv_hint));
-    key[0] = h[0] ^ (h[2] * 0x9e3779b97f4a7c15ull);
-    key[1] = h[1] ^ (h[3] * 0xc2b2ae3d27d4eb4full);
-}
-
-static int32_t build_static(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul, int32_t n_two_mul,
-                            const zk_conv_hint *hints, uint32_t n_hints);
-static int32_t alloc_session(zk_ctx *ctx);
-
-static void circuit_release(zk_ctx *ctx) {
-    shared_circuit *e = (shared_circuit *) ctx->circuit;
-    if (!e) return;
-    ctx->circuit = nullptr;
-    std::lock_guard<std::mutex> g(g_circ_mtx);
-    if (--e->refs > 0) return;
-    for (void *p : e->owned) hipFree(p);
-    g_circ_bytes -= e->bytes;
-    g_circuits.erase(std::remove(g_circuits.begin(), g_circuits.end(), e), g_circuits.end());
-    delete e;
-}
-
-extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul,
-                                            int32_t n_two_mul, const zk_conv_hint *hints, uint32_t n_hints) {
-    if (!ctx || !layers || n_layers < 2 || !two_mul || n_two_mul > 512 || (n_hints && !hints)) return ZK_ERR_ARG;
-    ZK_HIP(hipSetDevice(ctx->device));
-    if (ctx->circuit_ready) { ctx->err = "circuit already uploaded; create a new context"; return ZK_ERR_STATE; }
-    for (int i = 0; i < n_layers; ++i)
-        if (layers[i].bit_length < 0 || layers[i].bit_length > ZK_MAX_VARS) { ctx->err = "layer bit length out of range"; return ZK_ERR_ARG; }
-    uint64_t key[2];
-    circuit_key(key, layers, n_layers, two_mul, n_two_mul, hints, n_hints);
-    shared_circuit *e = nullptr;
-    {
-        std::lock_guard<std::mutex> g(g_circ_mtx);
-        for (shared_circuit *c : g_circuits)
-            if (c->device == ctx->device && c->key[0] == key[0] && c->key[1] == key[1] && !c->failed) { e = c; break; }
-        if (!e) {
-            e = new shared_circuit();
-            e->device = ctx->device;
-            e->key[0] = key[0]; e->key[1] = key[1];
-            g_circuits.push_back(e);
-        }
-        ++e->refs;
-    }
-    ctx->circuit = e;
-    int32_t rc = ZK_OK;
-    {
-        std::lock_guard<std::mutex> g(e->mtx);         // (a second context uploading the same circuit at the same time waits here, then attaches)
-        if (!e->ready && !e->failed) {
-            ctx->alloc_sink = &e->owned;
-            ctx->sink_bytes = 0;
-            rc = build_static(ctx, layers, n_layers, two_mul, n_two_mul, hints, n_hints);
-            ctx->alloc_sink = nullptr;
-            if (rc == ZK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "upload failed"; rc = ZK_ERR_HIP; }
-            if (rc == ZK_OK) {
-                e->L = ctx->L;
-                e->two_mul = ctx->two_mul; e->n_two_mul = ctx->n_two_mul;
-                e->liu_ptr = ctx->liu_ptr; e->liu_ent = ctx->liu_ent; e->liu_ntabs = ctx->liu_ntabs;
-                e->liu_tab_layer = ctx->liu_tab_layer; e->liu_tab_side = ctx->liu_tab_side;
-                e->conv_layers = ctx->conv_layers;
-                e->sz = ctx->sz;
-                e->ready = true;
-                e->bytes = ctx->sink_bytes;
-                g_circ_bytes += e->bytes;
-                ++g_circ_builds;
-            } else e->failed = true;
-        } else if (e->ready) {
-            ctx->L = e->L;
-            ctx->two_mul = e->two_mul; ctx->n_two_mul = e->n_two_mul;
-            ctx->liu_ptr = e->liu_ptr; ctx->liu_ent = e->liu_ent; ctx->liu_ntabs = e->liu_ntabs;
-            ctx->liu_tab_layer = e->liu_tab_layer; ctx->liu_tab_side = e->liu_tab_side;
-            ctx->conv_layers = e->conv_layers;
-            ctx->sz = e->sz;
-            ++g_circ_attaches;
-        } else { ctx->err = "the circuit's first upload failed"; rc = ZK_ERR_STATE; }
-    }
-    if (rc == ZK_OK) rc = alloc_session(ctx);
-    if (rc != ZK_OK) { circuit_release(ctx); return rc; }
-    ctx->circuit_ready = true;
-    return ZK_OK;
-}
-
-// the witness-independent part of a circuit (runs once per circuit and device)
-static int32_t build_static(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul, int32_t n_two_mul,
-                            const zk_conv_hint *hints, uint32_t n_hints) {
-    int32_t rc;
-    ctx->n_two_mul = n_two_mul;
-    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->two_mul, (size_t) n_two_mul * 32))) return rc;
-    ZK_HIP(hipMemcpy(ctx->two_mul, two_mul, (size_t) n_two_mul * 32, hipMemcpyHostToDevice));
-
-    ctx->L.assign(n_layers, dev_layer());
-    // structured convolution layers: a hint that reproduces the layer's gate list switches the factored sums on (and the layer's phase-1 list
-    // of those gates is then not built at all)
-    for (uint32_t k = 0; k < n_hints; ++k) {
-        const int i = hints[k].layer;
-        if (i < 2 || i >= n_layers) continue;
-        dev_layer &D = ctx->L[i];
-        conv_desc c;
-        if (D.conv_ok || !conv_hint_matches(hints[k], layers[i], layers[i - 1], c)) continue;
-        D.conv = c;
-        D.conv_ok = true;
-        ++ctx->conv_layers;
-    }
-    for (int i = 2; i < n_layers; ++i) {                    // layers nobody described
-        dev_layer &D = ctx->L[i];
-        conv_desc c;
-        if (D.conv_ok || layers[i].ty != ZK_NCONV || !conv_infer(layers[i], layers[i - 1], i, c)) continue;
-        D.conv = c;
-        D.conv_ok = true;
-        ++ctx->conv_layers;
-    }
-    circuit_sizes &Z = ctx->sz;
-    Z = circuit_sizes();
-    uint64_t max_list = 1;
-    for (int i = 0; i < n_layers; ++i) {
-        dev_layer &D = ctx->L[i];
-        const zk_layer_desc &S = layers[i];
-        D.d = S;
-        D.d.uni_gates = nullptr; D.d.bin_gates = nullptr; D.d.ori_id_u = nullptr; D.d.ori_id_v = nullptr;
-        D.val_len = 1ull << S.bit_length;
-        D.val_live = D.val_len;          // until the values arrive
-        if (i == 0) { Z.tp_cap[1] = std::max<uint64_t>(Z.tp_cap[1], D.val_len); continue; }      // the layer-0 combine runs on pair 1
-        if (i == n_layers - 1) Z.tp_cap[0] = std::max<uint64_t>(Z.tp_cap[0], D.val_len);          // Vres folds the output layer on pair 0
-        Z.bg = std::max<uint64_t>(Z.bg, D.val_len);
-        // exact sizes of the bookkeeping buffers (round 3: a session's buffers used to be eight times the LARGEST table of the circuit)
-        const uint64_t prev_len = 1ull << layers[i - 1].bit_length;
-        const bool dotp = S.ty == ZK_DOT_PROD, xform = S.ty == ZK_FFT || S.ty == ZK_IFFT;
-        for (int b = 0; b < 2; ++b) {
-            const int blu = dotp ? S.bit_length_u[1] : S.bit_length_u[b], blv = S.bit_length_v[b];
-            for (int bl : {blu, blv}) {
-                if (bl < 0) continue;
-                const uint64_t len = 1ull << bl;
-                Z.tp_cap[b] = std::max(Z.tp_cap[b], len);
-                // V[0] of pair 1 is only written when the previous layer cannot be read in place, by the transform layers and by DOT_PROD
-                if (b == 0 || len > prev_len || xform || dotp) Z.v0_cap[b] = std::max(Z.v0_cap[b], len);
-            }
-        }
-        Z.bu = std::max<uint64_t>(Z.bu, 1ull << std::max<int>(std::max<int>(S.max_bl_u, S.max_bl_v), 0));
-        for (int bl : {(int) S.bit_length_u[0], (int) S.bit_length_v[0]}) if (bl >= 0) Z.sub = std::max<uint64_t>(Z.sub, 1ull << bl);
-        if (S.fft_bit_length >= 0) Z.gs = std::max<uint64_t>(Z.gs, 1ull << S.fft_bit_length);
-
-        if (S.size_u[0]) {
-            std::vector<uint32_t> t(S.ori_id_u, S.ori_id_u + S.size_u[0]);
-            if ((rc = upload(ctx, &D.ori_u, t))) return rc;
-        }
-        if (S.size_v[0]) {
-            std::vector<uint32_t> t(S.ori_id_v, S.ori_id_v + S.size_v[0]);
-            if ((rc = upload(ctx, &D.ori_v, t))) return rc;
-        }
-        const bool dot = S.ty == ZK_DOT_PROD, xf = S.ty == ZK_FFT || S.ty == ZK_IFFT;
-        if (xf) continue;          // no gates: the transform layers are proved through the DFT-matrix MLE
-
-        // phase-2 list of the bin gates, keyed by v (also used by DOT_PROD)
-        std::vector<gate_rec> q[2];
-        for (uint64_t k = 0; k < S.n_bin; ++k) {
-            const zk_bin_gate &g = S.bin_gates[k];
-            const uint32_t v_prev = g.l & 1, u_prev = g.l != 0;
-            gate_rec r = {g.g, g.v, g.u, (uint32_t) g.sc | (u_prev << 10)};
-            q[v_prev].push_back(r);
-        }
-        for (int b = 0; b < 2; ++b) {
-            if (q[b].empty()) continue;
-            if (S.bit_length_v[b] < 0) { ctx->err = "bin gate refers to an absent v table"; return ZK_ERR_ARG; }
-            counting_sort(q[b], 1u << S.bit_length_v[b]);
-            D.p2_cov[b] = covered_prefix(q[b]);
-            D.p2_live[b] = q[b].empty() ? 0 : q[b].back().key + 1;
-            {
-                const uint32_t f0 = GATE_IN_PREV(q[b][0].meta);
-                bool same = true;
-                for (const gate_rec &r : q[b]) if (GATE_IN_PREV(r.meta) != f0) { same = false; break; }
-                D.p2_uniform[b] = same ? (int) f0 : -1;
-            }
-            D.n_p2_real[b] = q[b].size();
-            D.p2_G[b] = choose_group(q[b]);
-            pad_runs(q[b], D.p2_G[b]);
-            D.n_p2[b] = q[b].size();
-            max_list = std::max<uint64_t>(max_list, q[b].size());
-            if ((rc = upload(ctx, &D.p2[b], q[b]))) return rc;
-            std::vector<gate_rec>().swap(q[b]);
-        }
-        if (dot) {
-            std::vector<gate_rec> d;
-            d.reserve(S.n_bin);
-            uint32_t rows = S.size_u[1] >> S.fft_bit_length;
-            for (uint64_t k = 0; k < S.n_bin; ++k) {
-                const zk_bin_gate &g = S.bin_gates[k];
-                if (g.u >= rows) { ctx->err = "DOT_PROD gate out of range"; return ZK_ERR_ARG; }
-                gate_rec r = {g.g, g.u, g.v, 0};
-                d.push_back(r);
-            }
-            counting_sort(d, rows);
-            std::vector<uint32_t> ptr((size_t) rows + 1, 0);
-            for (const gate_rec &r : d) ++ptr[r.key + 1];
-            for (uint32_t k = 0; k < rows; ++k) ptr[k + 1] += ptr[k];
-            D.d1_rows = rows;
-            if ((rc = upload(ctx, &D.d1, d)) || (rc = upload(ctx, &D.d1_rowptr, ptr))) return rc;
-            continue;
-        }
-        // phase-1 lists keyed by u; uni and bin gates of one table merged into one sorted list
-        std::vector<gate_rec> p[2], un;
-        un.reserve(S.n_uni);
-        for (uint64_t k = 0; k < S.n_uni; ++k) {
-            const zk_uni_gate &g = S.uni_gates[k];
-            const uint32_t in_prev = g.lu != 0;
-            gate_rec r = {g.g, g.u, 0, (uint32_t) g.sc};
-            p[in_prev].push_back(r);
-            ++D.n_p1_uni[in_prev];
-            gate_rec r2 = {g.g, 0, g.u, (uint32_t) g.sc | (in_prev << 10)};
-            un.push_back(r2);
-        }
-        for (uint64_t k = 0; k < S.n_bin && !D.conv_ok; ++k) {          // (a structured convolution: every bin gate is covered by the factored sum)
-            const zk_bin_gate &g = S.bin_gates[k];
-            const uint32_t v_prev = g.l & 1, u_prev = g.l != 0;
-            const uint32_t vres = v_prev ? g.v : S.ori_id_v[g.v];     // resolve the layer-0 subset index once
-            gate_rec r = {g.g, g.u, vres, (uint32_t) g.sc | (1u << 9) | (v_prev << 10)};
-            p[u_prev].push_back(r);
-        }
-        if (D.conv_ok) D.p1_live[1] = (uint32_t) std::min<uint64_t>((uint64_t) D.conv.pp * D.conv.CI * D.conv.nxi * D.conv.nyi, 0xffffffffu);
-        for (int b = 0; b < 2; ++b) {
-            if (p[b].empty()) continue;
-            if (S.bit_length_u[b] < 0) { ctx->err = "gate refers to an absent u table"; return ZK_ERR_ARG; }
-            counting_sort(p[b], 1u << S.bit_length_u[b]);
-            D.p1_cov[b] = covered_prefix(p[b]);
-            D.p1_live[b] = p[b].empty() ? 0 : p[b].back().key + 1;
-            D.n_p1_real[b] = p[b].size();
-            D.p1_G[b] = choose_group(p[b]);
-            pad_runs(p[b], D.p1_G[b]);
-            D.n_p1[b] = p[b].size();
-            max_list = std::max<uint64_t>(max_list, p[b].size());
-            if ((rc = upload(ctx, &D.p1[b], p[b]))) return rc;
-            std::vector<gate_rec>().swap(p[b]);
-        }
-        D.n_uni2 = un.size();
-        if ((rc = upload(ctx, &D.uni2, un))) return rc;
-    }
-    // layer-0 combine: every (layer, side) whose operands reach into layer 0 is a table; CSR of its (index h -> layer-0 index ori[h]) pairs by x
-    {
-        const uint64_t n0 = 1ull << layers[0].bit_length;
-        std::vector<uint32_t> cnt(n0 + 1, 0);
-        uint64_t total = 0;
-        for (int i = 1; i < n_layers; ++i) {
-            const zk_layer_desc &S = layers[i];
-            for (int side = 0; side < 2; ++side) {
-                const int bl = side ? S.bit_length_v[0] : S.bit_length_u[0];
-                const uint32_t sz = side ? S.size_v[0] : S.size_u[0];
-                const uint32_t *ori = side ? S.ori_id_v : S.ori_id_u;
-                if (bl < 0 || !sz) continue;
-                if (bl > 24) { ctx->err = "layer-0 subset table too large for the combined gather"; return ZK_ERR_ARG; }
-                ctx->liu_tab_layer.push_back(i);
-                ctx->liu_tab_side.push_back(side);
-                for (uint32_t h = 0; h < sz; ++h) {
-                    if (ori[h] >= n0) { ctx->err = "ori_id out of range"; return ZK_ERR_ARG; }
-                    ++cnt[ori[h] + 1];
-                }
-                total += sz;
-            }
-        }
-        if (total >= 0xffffffffull || ctx->liu_tab_layer.size() >= (1u << 24)) { ctx->err = "too many layer-0 references"; return ZK_ERR_ARG; }
-        for (uint64_t x = 0; x < n0; ++x) cnt[x + 1] += cnt[x];
-        std::vector<liu_entry> ent(total);
-        {
-            std::vector<uint32_t> pos(cnt.begin(), cnt.end() - 1);
-            for (size_t tb = 0; tb < ctx->liu_tab_layer.size(); ++tb) {
-                const zk_layer_desc &S = layers[ctx->liu_tab_layer[tb]];
-                const int side = ctx->liu_tab_side[tb];
-                const uint32_t sz = side ? S.size_v[0] : S.size_u[0];
-                const uint32_t *ori = side ? S.ori_id_v : S.ori_id_u;
-                const int bl = side ? S.bit_length_v[0] : S.bit_length_u[0];
-                for (uint32_t h = 0; h < sz; ++h) {
-                    liu_entry e = {h, (uint32_t) tb | ((uint32_t) (bl >> 1) << 24)};      // table number, and the split of its index into half-table indices
-                    ent[pos[ori[h]]++] = e;
-                }
-            }
-        }
-        ctx->liu_ntabs = (uint32_t) ctx->liu_tab_layer.size();
-        liu_entry *d_ent = nullptr;
-        if ((rc = upload(ctx, &ctx->liu_ptr, cnt)) || (rc = upload(ctx, &d_ent, ent))) return rc;
-        ctx->liu_ent = d_ent;
-    }
-    for (const dev_layer &D : ctx->L) {
-        if (!D.conv_ok) continue;
-        const conv_desc &c = D.conv;
-        const uint64_t len = (uint64_t) c.CI * c.m * c.m, chunks = (c.CO + 7) / 8;
-        Z.conv_wa = std::max(Z.conv_wa, 2 * len);
-        Z.conv_part = std::max(Z.conv_part, chunks * 2 * len);
-        Z.conv_ae = std::max<uint64_t>(Z.conv_ae, (uint64_t) c.CO * c.m * c.m + c.CI);
-    }
-    Z.max_list = max_list;
-    if (getenv("ZKCNN_DUMP_TABLES"))
-        for (int i = 1; i < n_layers; ++i) {
-            const dev_layer &D = ctx->L[i];
-            fprintf(stderr, "[tables] layer %d ty %d size %u | u0 bl %d live %u | u1 bl %d live %u | v0 bl %d live %u | v1 bl %d live %u\n", i, D.d.ty, D.d.size,
-                    D.d.bit_length_u[0], D.p1_live[0], D.d.bit_length_u[1], D.p1_live[1], D.d.bit_length_v[0], D.p2_live[0], D.d.bit_length_v[1], D.p2_live[1]);
-        }
-    return ZK_OK;
-}
-
-// what every session of a circuit has for itself: layer values, bookkeeping tables, scratch
-static int32_t alloc_session(zk_ctx *ctx) {
-    int32_t rc;
-    const circuit_sizes &Z = ctx->sz;
-    for (dev_layer &D : ctx->L) {
-        D.val = nullptr;
-        D.val_live = D.val_len;          // until the values arrive
-        if ((rc = zk_dev_alloc(ctx, (void **) &D.val, D.val_len * 32))) return rc;
-        ZK_HIP(hipMemsetAsync(D.val, 0, D.val_len * 32, ctx->stream));
-        D.ev_uni = D.ev_bin = nullptr; D.ev_dot = nullptr; D.ev_dot_ptr = nullptr; D.n_ev_uni = D.n_ev_bin = 0; D.ev_conv = false;
-    }
-    {
-        const uint32_t nt = std::max<uint32_t>(ctx->liu_ntabs, 1);
-        if ((rc = zk_dev_alloc(ctx, (void **) &ctx->liu_halves, (size_t) nt * 2 * LIU_HALF_STRIDE * 32))) return rc;
-        ZK_HIP(hipHostMalloc(&ctx->h_liu_tabs, (size_t) nt * sizeof(liu_table), hipHostMallocMapped));
-        ZK_HIP(hipHostGetDevicePointer(&ctx->liu_tabs, ctx->h_liu_tabs, 0));        // the kernels read the descriptors in place
-    }
-    if (ctx->conv_layers) {
-        if ((rc = zk_dev_alloc(ctx, (void **) &ctx->conv_small, (size_t) CT_COUNT * CONV_TAB_STRIDE * 32)) ||
-            (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_wa, Z.conv_wa * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_part, Z.conv_part * 32)) ||
-            (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_e, 2 * 16 * 16 * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->conv_ae, Z.conv_ae * 32)))
-            return rc;
-        ZK_HIP(hipHostMalloc(&ctx->h_conv_tabs, 2 * CT_COUNT * sizeof(liu_table), hipHostMallocMapped));
-        ZK_HIP(hipHostGetDevicePointer(&ctx->conv_tabs, ctx->h_conv_tabs, 0));
-    }
-    // bookkeeping tables: [0] takes a pair's tables as they are built, [1] only ever what a fold leaves (half, plus the guard quad)
-    for (int b = 0; b < 2; ++b) {
-        const uint64_t cap = std::max<uint64_t>(Z.tp_cap[b], 4), half = cap / 2 + 8;
-        // (V[0] of a pair whose V table is read in place still takes every SECOND fold: a quarter of the table)
-        if ((rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].V[0], std::max<uint64_t>(Z.v0_cap[b], cap / 4 + 8) * 32)) ||
-            (rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].M[0], cap * 32)) ||
-            (rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].V[1], half * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->tp[b].M[1], half * 32)))
-            return rc;
-    }
-    ctx->beta_g_cap = std::max<uint64_t>(Z.bg, 1);
-    for (int k = 0; k < 2; ++k) if ((rc = zk_dev_alloc(ctx, (void **) &ctx->beta_g[k], ctx->beta_g_cap * 32))) return rc;
-    ctx->beta_u_cap = std::max<uint64_t>(Z.bu, 1);
-    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->beta_u, ctx->beta_u_cap * 32))) return rc;
-    ctx->beta_gs_cap = std::max<uint64_t>(Z.gs, 1);
-    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->beta_gs, ctx->beta_gs_cap * 32))) return rc;
-    for (int k = 0; k < 2; ++k) if ((rc = zk_dev_alloc(ctx, (void **) &ctx->small[k], ctx->beta_gs_cap * 32))) return rc;
-    ctx->carry_slots = 4 * ((Z.max_list + ZK_BLOCK - 1) / ZK_BLOCK) + 4;          // two lists per launch (k_gate_multi), two slots per block
-    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->carry_key, ctx->carry_slots * 4))) return rc;
-    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->carry_val, ctx->carry_slots * 32))) return rc;
-    if ((rc = zk_scratch(ctx, (size_t) 1 << 24))) return rc;
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    return ZK_OK;
-}
-
-extern "C" int32_t zk_upload_layer_values(zk_ctx *ctx, int32_t layer, const uint64_t *values, uint64_t n) {
-    if (!ctx || !ctx->circuit_ready || layer < 0 || layer >= (int) ctx->L.size()) return ZK_ERR_ARG;
-    dev_layer &D = ctx->L[layer];
-    if (n > D.val_len) { ctx->err = "more values than the layer holds"; return ZK_ERR_ARG; }
-    ZK_HIP(hipSetDevice(ctx->device));
-    if (n) ZK_HIP(hipMemcpyAsync(D.val, values, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    if (n < D.val_len) ZK_HIP(hipMemsetAsync(D.val + n, 0, (D.val_len - n) * 32, ctx->stream));
-    uint64_t last = n;
-    while (last && !(values[4 * last - 4] | values[4 * last - 3] | values[4 * last - 2] | values[4 * last - 1])) --last;
-    D.val_live = last;
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    return ZK_OK;
-}
-
-extern "C" int32_t zk_poke_layer_value(zk_ctx *ctx, int32_t layer, uint64_t index, const uint64_t value[4]) {
-    if (!ctx || !ctx->circuit_ready || layer < 0 || layer >= (int) ctx->L.size() || !value) return ZK_ERR_ARG;
-    dev_layer &D = ctx->L[layer];
-    if (index >= D.d.size) { ctx->err = "poke: index behind the layer"; return ZK_ERR_ARG; }
-    ZK_HIP(hipSetDevice(ctx->device));
-    ZK_HIP(hipMemcpyAsync(D.val + index, value, 32, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    if ((value[0] | value[1] | value[2] | value[3]) && index + 1 > D.val_live) D.val_live = index + 1;      // (an upper bound stays an upper bound)
-    return ZK_OK;
-}
 
 // ------------------------------------------------------------------------------------------------
 // building blocks
@@ -896,6 +94,9 @@ static int32_t eq_table1(zk_ctx *ctx, fr_t *out, int n, const HFr *r, const HFr 
 }
 
 int32_t zk_eq_table1_dev(zk_ctx *ctx, fr_t *out, int n, const HFr *r, const HFr &init) { return eq_table1(ctx, out, n, r, init); }
+int32_t zk_eq_table_dev(zk_ctx *ctx, fr_t *out, int n, const HFr *r0, const HFr &a, const HFr *r1, const HFr &b, uint64_t tail_start, const HFr &tail_scale, uint64_t limit) {
+    return eq_table(ctx, out, n, r0, a, r1, b, tail_start, tail_scale, limit);
+}
 
 // out[j] = sum_i L[i] * Z[i * cols + j]  (Hyrax opening vector w = L^T Z)
 int32_t zk_col_combine_dev(zk_ctx *ctx, fr_t *out, const fr_t *Z, const fr_t *L, uint32_t cols, uint32_t rows) {
@@ -926,6 +127,8 @@ static int32_t fetch_result(zk_ctx *ctx, int count) {
 // Waits until the fused round kernel has published sequence number `seq` in the mapped host slot. Spinning on the
 // slot keeps a stream synchronisation (and a D2H copy) off the critical path of every round; if the value does not
 // show up quickly the stream is synchronised instead (long kernels, or host memory that is not fine-grained).
+static int32_t wait_slot(zk_ctx *ctx, unsigned long long seq);
+int32_t zk_wait_slot(zk_ctx *ctx, unsigned long long seq) { return wait_slot(ctx, seq); }
 static int32_t wait_slot(zk_ctx *ctx, unsigned long long seq) {
     volatile unsigned long long *p = &ctx->h_slot->seq;
     for (uint64_t spins = 0; *p != seq; ++spins) {
@@ -1037,6 +240,8 @@ static void reset_pairs(zk_ctx *ctx, int bl0, int bl1) {
     }
 }
 
+static fr_t *powers_of_root(zk_ctx *ctx, int n, bool inverse);
+fr_t *zk_powers_of_root(zk_ctx *ctx, int n, bool inverse) { return powers_of_root(ctx, n, inverse); }
 static fr_t *powers_of_root(zk_ctx *ctx, int n, bool inverse) {
     auto &tab = ctx->root_pw[inverse ? 1 : 0];
     if ((int) tab.size() <= n) tab.resize(n + 1, nullptr);
@@ -1058,6 +263,8 @@ static fr_t *powers_of_root(zk_ctx *ctx, int n, bool inverse) {
     return d;
 }
 
+static int32_t phi_table(zk_ctx *ctx, fr_t *out, const HFr *rx, const HFr &scale, int n, bool inverse);
+int32_t zk_phi_table_dev(zk_ctx *ctx, fr_t *out, const HFr *rx, const HFr &scale, int n, bool inverse) { return phi_table(ctx, out, rx, scale, n, inverse); }
 static int32_t phi_table(zk_ctx *ctx, fr_t *out, const HFr *rx, const HFr &scale, int n, bool inverse) {
     fr_t *pw = powers_of_root(ctx, n, inverse);
     if (!pw) { ctx->err = "root table allocation failed"; return ZK_ERR_NOMEM; }
@@ -1104,11 +311,8 @@ static int32_t fold_pair(zk_ctx *ctx, table_pair &t, const HFr &r, bool with_m) 
 // ------------------------------------------------------------------------------------------------
 // state machine
 // ------------------------------------------------------------------------------------------------
-// every entry point but the three round calls first sends a resident round kernel home (its phase was abandoned)
-#define CHECK_READY_ROUND() do { if (!ctx || !ctx->circuit_ready) return ZK_ERR_STATE; ZK_HIP(hipSetDevice(ctx->device)); } while (0)
-#define CHECK_READY() do { CHECK_READY_ROUND(); if (ctx->live_active) { int32_t rc_ = zk_live_abort(ctx); if (rc_) return rc_; } } while (0)
-static inline const HFr &H(const uint64_t *p) { return *reinterpret_cast<const HFr *>(p); }
-static inline void put(uint64_t *dst, const HFr &x) { std::memcpy(dst, &x, 32); }
+#define CHECK_READY_ROUND() ZK_CHECK_READY_ROUND()
+#define CHECK_READY() ZK_CHECK_READY()
 
 extern "C" int32_t zk_prover_init(zk_ctx *ctx) {
     CHECK_READY();
@@ -2217,7 +1421,7 @@ extern "C" int32_t zk_sumcheck_liu_finalize(zk_ctx *ctx, const uint64_t prev_r[4
 // ------------------------------------------------------------------------------------------------
 // kernel-level entry points (host arrays in / out)
 // ------------------------------------------------------------------------------------------------
-#define CHECK_CTX() do { if (!ctx) return ZK_ERR_ARG; ZK_HIP(hipSetDevice(ctx->device)); if (ctx->live_active) { int32_t rc_ = zk_live_abort(ctx); if (rc_) return rc_; } } while (0)
+#define CHECK_CTX() ZK_CHECK_CTX()
 
 template <int OP>
 static int32_t binop(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n) {
@@ -2302,579 +1506,6 @@ extern "C" int32_t zk_k_round_quadratic(zk_ctx *ctx, uint64_t *V, uint64_t *M, u
     put(out_abc + 4, p1 - a - c);
     put(out_abc + 8, c);
     *n_out = nn;
-    return ZK_OK;
-}
-
-// ---- witness kernels of the FFT convolution (host arrays in / out) ----
-extern "C" int32_t zk_witness_ntt(zk_ctx *ctx, uint64_t *dst, const uint64_t *src, int32_t logn, int32_t inverse, uint64_t count) {
-    CHECK_CTX();
-    if (logn < 1 || logn > 12 || !count) return ZK_ERR_ARG;        // 2^12 x 32 B = 128 KiB is what fits in LDS
-    const uint32_t len = 1u << logn, in_len = inverse ? len : len / 2, out_len = inverse ? len / 2 : len;
-    fr_t *pw = powers_of_root(ctx, logn, inverse != 0);
-    if (!pw) { ctx->err = "root table allocation failed"; return ZK_ERR_NOMEM; }
-    const size_t in_bytes = (size_t) count * in_len * 32, out_bytes = (size_t) count * out_len * 32;
-    int32_t rc = zk_scratch(ctx, in_bytes + out_bytes);
-    if (rc) return rc;
-    fr_t *d_in = (fr_t *) ctx->scratch.p, *d_out = d_in + (size_t) count * in_len;
-    ZK_HIP(hipMemcpyAsync(d_in, src, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-    HFr ilen;
-    HFr::inv(ilen, HFr((unsigned long long) len));
-    const size_t lds = (size_t) len * 32;
-    static bool attr_set = false;
-    if (!attr_set) {
-        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_batch), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-    }
-    const uint32_t threads = std::min<uint32_t>(1024, std::max<uint32_t>(64, len / 2));
-    for (uint64_t b0 = 0; b0 < count; b0 += 1u << 30) {
-        const uint32_t nb = (uint32_t) std::min<uint64_t>(1u << 30, count - b0);
-        prof_begin(ctx, PC_MISC, 64.0 * len * nb);
-        hipLaunchKernelGGL(k_ntt_batch, dim3(nb), dim3(threads), lds, ctx->stream, d_out + b0 * out_len, d_in + b0 * in_len, pw, logn, in_len,
-                           out_len, to_dev(ilen), inverse ? 1 : 0);
-        prof_end(ctx, PC_MISC);
-    }
-    ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpyAsync(dst, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    return ZK_OK;
-}
-
-extern "C" int32_t zk_witness_dotprod(zk_ctx *ctx, uint64_t *out, uint64_t n_out, const uint64_t *F, uint64_t n_in,
-                                      const zk_bin_gate *gates, uint64_t n_gates, int32_t fft_bl) {
-    CHECK_CTX();
-    if (fft_bl < 1 || fft_bl > 20 || !n_out || !n_in) return ZK_ERR_ARG;
-    std::vector<gate_rec> recs(n_gates);
-    for (uint64_t k = 0; k < n_gates; ++k) {
-        if (gates[k].g >= n_out || gates[k].u >= n_in || gates[k].v >= n_in) { ctx->err = "dot-prod gate out of range"; return ZK_ERR_ARG; }
-        gate_rec r = {gates[k].g, gates[k].u, gates[k].v, 0};      // key = u, aux = v for this kernel
-        recs[k] = r;
-    }
-    // CSR by output vector g (stable: order inside a row does not matter, the sum is exact)
-    std::vector<uint32_t> ptr(n_out + 1, 0);
-    for (const gate_rec &r : recs) ++ptr[r.g + 1];
-    for (uint64_t g = 0; g < n_out; ++g) ptr[g + 1] += ptr[g];
-    std::vector<gate_rec> sorted(n_gates);
-    {
-        std::vector<uint32_t> pos(ptr.begin(), ptr.end() - 1);
-        for (const gate_rec &r : recs) sorted[pos[r.g]++] = r;
-    }
-    const size_t len = (size_t) 1 << fft_bl;
-    const size_t bytes = (n_in + n_out) * len * 32 + n_gates * sizeof(gate_rec) + (n_out + 1) * 4 + 64;
-    int32_t rc = zk_scratch(ctx, bytes);
-    if (rc) return rc;
-    fr_t *dF = (fr_t *) ctx->scratch.p, *dO = dF + n_in * len;
-    gate_rec *dR = (gate_rec *) (dO + n_out * len);
-    uint32_t *dP = (uint32_t *) (dR + n_gates);
-    ZK_HIP(hipMemcpyAsync(dF, F, n_in * len * 32, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(dR, sorted.data(), n_gates * sizeof(gate_rec), hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(dP, ptr.data(), (n_out + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    for (uint64_t g0 = 0; g0 < n_out; g0 += 32768) {
-        const uint32_t ng = (uint32_t) std::min<uint64_t>(32768, n_out - g0);
-        dim3 grid((uint32_t) ((len + ZK_BLOCK - 1) / ZK_BLOCK), ng);
-        ZK_LAUNCH(PC_DOT, 0.0, k_dot_witness, grid, dim3(ZK_BLOCK), dO + g0 * len, dF, dR, dP + g0, fft_bl);
-    }
-    ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpyAsync(out, dO, n_out * len * 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    return ZK_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// verifier side: wiring predicates over the resident gate lists (reference src/verifier.cpp:36-116, 304-325)
-// ------------------------------------------------------------------------------------------------
-static int32_t verifier_buffers(zk_ctx *ctx) {
-    if (ctx->v_bg) return ZK_OK;
-    int32_t rc;
-    const uint64_t cap_uv = std::max(std::max(ctx->beta_u_cap, ctx->beta_g_cap), ctx->sz.sub);
-    const uint64_t cap_g = std::max<uint64_t>(ctx->beta_g_cap, ctx->L[0].val_len);      // the layer-0 check needs eq over all of layer 0
-    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->v_bg, cap_g * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->v_bu, cap_uv * 32)) ||
-        (rc = zk_dev_alloc(ctx, (void **) &ctx->v_bv, cap_uv * 32)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->v_gs, ctx->beta_gs_cap * 32)))
-        return rc;
-    return ZK_OK;
-}
-
-extern "C" int32_t zk_verifier_predicates(zk_ctx *ctx, int32_t layer, const uint64_t *r_0, const uint64_t *r_1, const uint64_t alpha[4],
-                                          const uint64_t beta[4], const uint64_t relu_rou[4], const uint64_t *r_u, const uint64_t *r_v,
-                                          const uint64_t *r_u2, const uint64_t *r_v2, uint64_t uni[8], uint64_t bin[12]) {
-    CHECK_READY();
-    if (layer < 1 || layer >= (int) ctx->L.size()) return ZK_ERR_ARG;
-    int32_t rc;
-    if ((rc = verifier_buffers(ctx))) return rc;
-    const dev_layer &cur = ctx->L[layer];
-    const zk_layer_desc &d = cur.d;
-    const HFr *R0 = reinterpret_cast<const HFr *>(r_0), *R1 = reinterpret_cast<const HFr *>(r_1), *RU = reinterpret_cast<const HFr *>(r_u),
-              *RV = reinterpret_cast<const HFr *>(r_v), *RU2 = reinterpret_cast<const HFr *>(r_u2), *RV2 = reinterpret_cast<const HFr *>(r_v2);
-    const HFr al = H(alpha), be = H(beta), scale = H(d.scale);
-    const int bl = d.bit_length, fft_bl = d.fft_bit_length, fft_blh = fft_bl - 1;
-    fr_t *res = ctx->d_result + 16;                       // [0,1] uni, [2,3] bin list 0, [4,5] bin list 1, [6] table dot
-    ZK_HIP(hipMemsetAsync(res, 0, 8 * 32, ctx->stream));
-    const bool xf = d.ty == ZK_FFT || d.ty == ZK_IFFT, dot = d.ty == ZK_DOT_PROD;
-    if (xf) {
-        if ((rc = phi_table(ctx, ctx->v_gs, R0, scale, fft_bl, d.ty == ZK_IFFT))) return rc;
-        if ((rc = eq_table1(ctx, ctx->v_bu, d.max_bl_u, RU, HFr::one()))) return rc;
-        const uint64_t n = 1ull << d.max_bl_u;
-        const uint32_t g = std::min<uint32_t>(grid_for(n, 1024), ctx->partial_blocks);
-        ZK_LAUNCH(PC_GATE_SUM, 0.0, k_dot_indexed, dim3(g), dim3(ZK_BLOCK), ctx->partials, ctx->v_gs, (const uint32_t *) nullptr, ctx->v_bu, n);
-        ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials<1>, dim3(1), dim3(ZK_BLOCK), res + 6, ctx->partials, g, 0);
-    } else if (d.ty == ZK_PADDING) {
-        if (!RU2) return ZK_ERR_ARG;
-        if ((rc = eq_table(ctx, ctx->v_bv, bl - fft_blh, RU2 + fft_bl, al, RV2, be, ~0ull, HFr::one()))) return rc;
-        if ((rc = eq_table1(ctx, ctx->v_gs, fft_blh, R0, HFr::one()))) return rc;
-        ZK_LAUNCH(PC_EQ, 0.0, k_outer_expand, dim3(grid_for(cur.val_len)), dim3(ZK_BLOCK), ctx->v_bg, ctx->v_bv, ctx->v_gs, fft_blh, cur.val_len);
-        if ((rc = eq_table1(ctx, ctx->v_bu, d.max_bl_u, RU, HFr::one()))) return rc;
-    } else if (dot) {
-        if (!RU2) return ZK_ERR_ARG;
-        const int cnt_bl = bl - fft_bl, cnt_bl2 = d.max_bl_u - fft_bl;
-        if ((rc = eq_table1(ctx, ctx->v_bg, cnt_bl, RU2 + fft_bl - 1, al))) return rc;
-        HFr same = HFr::one();                            // eq(r_0, r_u) on the frequency bits
-        for (int j = 0; j < fft_bl; ++j) same = same * (R0[j] * RU[j] + (HFr::one() - R0[j]) * (HFr::one() - RU[j]));
-        if ((rc = eq_table1(ctx, ctx->v_bu, cnt_bl2, RU + fft_bl, same))) return rc;
-    } else {
-        const bool tail = d.zero_start_id < d.size;
-        if ((rc = eq_table(ctx, ctx->v_bg, bl, R0, al * scale, R1, be * scale, tail ? d.zero_start_id : ~0ull, tail ? H(relu_rou) : HFr::one())))
-            return rc;
-        if ((rc = eq_table1(ctx, ctx->v_bu, d.max_bl_u, RU, HFr::one()))) return rc;
-    }
-    if (!xf && cur.n_uni2) {
-        gate_args A;
-        std::memset(&A, 0, sizeof(A));
-        A.recs = cur.uni2; A.n = cur.n_uni2;
-        A.beta_g = ctx->v_bg; A.beta_u = ctx->v_bu; A.two_mul = ctx->two_mul; A.phase = 2;
-        const uint32_t g = std::min<uint32_t>(grid_for(cur.n_uni2, 1024), ctx->partial_blocks);
-        ZK_LAUNCH(PC_GATE_SUM, 0.0, k_gate_sum2, dim3(g), dim3(ZK_BLOCK), ctx->partials, A);
-        ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials<2>, dim3(1), dim3(ZK_BLOCK), res, ctx->partials, g, 0);
-    }
-    HFr bv0 = HFr::one();
-    if (d.need_phase2) {
-        if ((rc = eq_table1(ctx, ctx->v_bv, d.max_bl_v, RV, HFr::one()))) return rc;
-        for (int j = 0; j < d.max_bl_v; ++j) bv0 = bv0 * (HFr::one() - RV[j]);          // beta_v[0]
-        for (int b = 0; b < 2; ++b) {
-            if (!cur.n_p2[b]) continue;
-            const uint32_t g = std::min<uint32_t>(grid_for(cur.n_p2[b], 1024), ctx->partial_blocks);
-            ZK_LAUNCH(PC_GATE_SUM, 0.0, k_pred_bin, dim3(g), dim3(ZK_BLOCK), ctx->partials, cur.p2[b], cur.n_p2[b], ctx->v_bg, ctx->v_bu,
-                      ctx->v_bv, ctx->two_mul, dot ? 0 : 1);
-            ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials<2>, dim3(1), dim3(ZK_BLOCK), res + 2 + 2 * b, ctx->partials, g, 0);
-        }
-    }
-    ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpyAsync(ctx->h_result + 16, res, 8 * 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    const HFr *h = ctx->h_result + 16;
-    HFr u0 = h[0], u1 = xf ? h[6] : h[1];
-    if (d.need_phase2) { u0 = u0 * bv0; u1 = u1 * bv0; }
-    put(uni, u0);
-    put(uni + 4, u1);
-    put(bin, h[2]);                 // l = 0: u and v in layer 0
-    put(bin + 4, h[5]);             // l = 1: both in the previous layer
-    put(bin + 8, h[3]);             // l = 2: u in the previous layer, v in layer 0
-    if (!h[4].isZero()) { ctx->err = "bin gate with u in layer 0 and v in the previous layer"; return ZK_ERR_STATE; }
-    return ZK_OK;
-}
-
-// g(r_u0) of the layer-0 check: sum over layers of sum_j eq(r_u0, ori_id[j]) * sig * eq(r_{u,v}[layer], j)  (reference src/verifier.cpp:304-325)
-extern "C" int32_t zk_verifier_input_predicate(zk_ctx *ctx, const uint64_t *r_u0, const uint64_t *const *r_u, const uint64_t *const *r_v,
-                                               const uint64_t *sig_u, const uint64_t *sig_v, uint32_t n, uint64_t out[4]) {
-    CHECK_READY();
-    if (n + 1 != ctx->L.size()) return ZK_ERR_ARG;
-    int32_t rc;
-    if ((rc = verifier_buffers(ctx))) return rc;
-    fr_t *res = ctx->d_result + 16;
-    ZK_HIP(hipMemsetAsync(res, 0, 32, ctx->stream));
-    if ((rc = eq_table1(ctx, ctx->v_bg, ctx->L[0].d.bit_length, reinterpret_cast<const HFr *>(r_u0), HFr::one()))) return rc;
-    for (size_t i = 1; i < ctx->L.size(); ++i) {
-        const dev_layer &Li = ctx->L[i];
-        for (int side = 0; side < 2; ++side) {
-            const int bl = side ? Li.d.bit_length_v[0] : Li.d.bit_length_u[0];
-            const uint32_t cnt = side ? Li.d.size_v[0] : Li.d.size_u[0];
-            const uint64_t *pt = side ? r_v[i] : r_u[i];
-            if (bl < 0 || !cnt) continue;
-            if (!pt) return ZK_ERR_ARG;
-            if ((rc = eq_table1(ctx, ctx->v_bu, bl, reinterpret_cast<const HFr *>(pt), H((side ? sig_v : sig_u) + 4 * (i - 1))))) return rc;
-            const uint32_t g = std::min<uint32_t>(grid_for(cnt, 1024), ctx->partial_blocks);
-            ZK_LAUNCH(PC_LIU, 0.0, k_dot_indexed, dim3(g), dim3(ZK_BLOCK), ctx->partials, ctx->v_bg, side ? Li.ori_v : Li.ori_u, ctx->v_bu, (uint64_t) cnt);
-            ZK_LAUNCH(PC_SUM, 0.0, k_sum_partials<1>, dim3(1), dim3(ZK_BLOCK), res, ctx->partials, g, 1);
-        }
-    }
-    ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpyAsync(ctx->h_result + 16, res, 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    put(out, ctx->h_result[16]);
-    return ZK_OK;
-}
-
-// ---- witness of a generic layer: every gate evaluated on the GPU (reference src/neuralNetwork.cpp:918-935) ----
-static int32_t grow_buf(zk_ctx *ctx, dev_buf &b, size_t bytes, size_t keep = 0) {
-    if (b.bytes >= bytes) return ZK_OK;
-    size_t want = std::max(bytes, b.bytes + b.bytes / 2);
-    void *np = nullptr;
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    if (hipMalloc(&np, want) != hipSuccess) {
-        (void) hipGetLastError();
-        want = bytes;
-        ZK_HIP(hipMalloc(&np, want));
-    }
-    if (keep && b.p) {
-        ZK_HIP(hipMemcpyAsync(np, b.p, keep, hipMemcpyDeviceToDevice, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    if (b.p) ZK_HIP(hipFree(b.p));
-    b.p = np;
-    b.bytes = want;
-    return ZK_OK;
-}
-
-extern "C" int32_t zk_witness_release(zk_ctx *ctx) {
-    CHECK_CTX();
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->w_val0.p) { ZK_HIP(hipFree(ctx->w_val0.p)); ctx->w_val0 = dev_buf(); }
-    for (dev_buf &b : ctx->w_stage) if (b.p) { ZK_HIP(hipFree(b.p)); b = dev_buf(); }
-    ctx->w_val0_len = 0;
-    return ZK_OK;
-}
-
-extern "C" int32_t zk_witness_input(zk_ctx *ctx, uint64_t offset, const uint64_t *values, uint64_t n) {
-    CHECK_CTX();
-    if (offset == 0) ctx->w_val0_len = 0;                            // a new layer 0 starts
-    if (offset > ctx->w_val0_len) return ZK_ERR_ARG;                 // the copy has no holes
-    int32_t rc = grow_buf(ctx, ctx->w_val0, (offset + n) * 32, ctx->w_val0_len * 32);
-    if (rc) return rc;
-    if (n) ZK_HIP(hipMemcpyAsync((fr_t *) ctx->w_val0.p + offset, values, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    ctx->w_val0_len = std::max<uint64_t>(ctx->w_val0_len, offset + n);
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    return ZK_OK;
-}
-
-// true when equal g are adjacent; range-checks the list on the way
-template <class G, class Check>
-static int grouped_by_output(const G *gates, uint64_t n, uint64_t n_out, std::vector<uint8_t> &seen, Check in_range) {
-    std::fill(seen.begin(), seen.end(), 0);
-    bool grouped = true;
-    uint32_t prev = 0xffffffffu;
-    for (uint64_t k = 0; k < n; ++k) {
-        const G &gt = gates[k];
-        if (gt.g >= n_out || !in_range(gt)) return -1;
-        if (gt.g != prev) {
-            if (seen[gt.g]) grouped = false;
-            seen[gt.g] = 1;
-            prev = gt.g;
-        }
-    }
-    return grouped ? 1 : 0;
-}
-template <class G>
-static void regroup(std::vector<G> &dst, const G *gates, uint64_t n, uint64_t n_out) {
-    std::vector<uint64_t> pos(n_out + 1, 0);
-    for (uint64_t k = 0; k < n; ++k) ++pos[gates[k].g + 1];
-    for (uint64_t g = 0; g < n_out; ++g) pos[g + 1] += pos[g];
-    dst.resize(n);
-    for (uint64_t k = 0; k < n; ++k) dst[pos[gates[k].g]++] = gates[k];
-}
-
-extern "C" int32_t zk_witness_gates(zk_ctx *ctx, uint64_t *out, uint64_t n_out, const zk_uni_gate *uni, uint64_t n_uni,
-                                    const zk_bin_gate *bin, uint64_t n_bin, const uint64_t *prev, uint64_t n_prev,
-                                    const uint64_t *two_mul, uint32_t n_two_mul, const uint64_t scale[4]) {
-    CHECK_CTX();
-    if (!n_out || n_out > 0xfffffffeull || !n_two_mul) return ZK_ERR_ARG;
-    static_assert(sizeof(uni_gate_dev) == sizeof(zk_uni_gate) && sizeof(bin_gate_dev) == sizeof(zk_bin_gate), "gate layout");
-    const uint64_t n0 = ctx->w_val0_len;
-    if (!prev) n_prev = n0;                                          // layer 1: the previous layer IS layer 0
-    std::vector<uint8_t> seen(n_out);
-    std::vector<zk_uni_gate> uni_sorted;
-    std::vector<zk_bin_gate> bin_sorted;
-    int g1 = grouped_by_output(uni, n_uni, n_out, seen, [&](const zk_uni_gate &gt) {
-        return gt.sc < n_two_mul && gt.u < (gt.lu ? n_prev : n0); });
-    int g2 = g1 < 0 ? -1 : grouped_by_output(bin, n_bin, n_out, seen, [&](const zk_bin_gate &gt) {
-        return gt.sc < n_two_mul && gt.l <= 2 && gt.u < (gt.l == 0 ? n0 : n_prev) && gt.v < ((gt.l & 1) ? n_prev : n0); });
-    if (g1 < 0 || g2 < 0) { ctx->err = "witness gate operand out of range"; return ZK_ERR_ARG; }
-    if (!g1) { regroup(uni_sorted, uni, n_uni, n_out); uni = uni_sorted.data(); }
-    if (!g2) { regroup(bin_sorted, bin, n_bin, n_out); bin = bin_sorted.data(); }
-
-    const uint64_t blocks_u = (n_uni + ZK_BLOCK - 1) / ZK_BLOCK, blocks_b = (n_bin + ZK_BLOCK - 1) / ZK_BLOCK;
-    const uint64_t slots = 2 * std::max<uint64_t>(std::max(blocks_u, blocks_b), 1);
-    int32_t rc;
-    dev_buf &bG = ctx->w_stage[0], &bP = ctx->w_stage[1], &bO = ctx->w_stage[2], &bC = ctx->w_stage[3], &bT = ctx->w_stage[4];
-    if ((rc = grow_buf(ctx, bG, std::max<size_t>(n_uni * sizeof(zk_uni_gate), n_bin * sizeof(zk_bin_gate)) + 16)) ||
-        (rc = grow_buf(ctx, bP, (prev ? std::max<uint64_t>(n_prev, 1) : 1) * 32)) || (rc = grow_buf(ctx, bO, 3 * n_out * 32)) ||
-        (rc = grow_buf(ctx, bC, slots * (32 + 4))) || (rc = grow_buf(ctx, bT, (size_t) n_two_mul * 32)))
-        return rc;
-    fr_t *dA = (fr_t *) bO.p, *dB = dA + n_out, *dO = dB + n_out;
-    fr_t *carry_val = (fr_t *) bC.p;
-    uint32_t *carry_key = (uint32_t *) (carry_val + slots);
-    const fr_t *v0 = (const fr_t *) ctx->w_val0.p, *vp = prev ? (const fr_t *) bP.p : v0, *tm = (const fr_t *) bT.p;
-    if (prev && n_prev) ZK_HIP(hipMemcpyAsync(bP.p, prev, n_prev * 32, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(bT.p, two_mul, (size_t) n_two_mul * 32, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipMemsetAsync(dA, 0, 2 * n_out * 32, ctx->stream));
-    if (n_uni) {
-        ZK_HIP(hipMemcpyAsync(bG.p, uni, n_uni * sizeof(zk_uni_gate), hipMemcpyHostToDevice, ctx->stream));
-        ZK_LAUNCH(PC_GATE, 44.0 * (double) n_uni, k_eval_uni, dim3((uint32_t) blocks_u), dim3(ZK_BLOCK), dA, carry_key, carry_val,
-                  (const uni_gate_dev *) bG.p, n_uni, v0, vp, tm);
-        ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup, dim3(grid_for(2 * blocks_u)), dim3(ZK_BLOCK), dA, carry_key, carry_val, 2 * blocks_u);
-    }
-    if (n_bin) {
-        ZK_HIP(hipMemcpyAsync(bG.p, bin, n_bin * sizeof(zk_bin_gate), hipMemcpyHostToDevice, ctx->stream));
-        ZK_LAUNCH(PC_GATE, 80.0 * (double) n_bin, k_eval_bin, dim3((uint32_t) blocks_b), dim3(ZK_BLOCK), dB, carry_key, carry_val,
-                  (const bin_gate_dev *) bG.p, n_bin, v0, vp, tm);
-        ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup, dim3(grid_for(2 * blocks_b)), dim3(ZK_BLOCK), dB, carry_key, carry_val, 2 * blocks_b);
-    }
-    const HFr sc = H(scale);
-    ZK_LAUNCH(PC_MISC, 0.0, k_eval_combine, dim3(grid_for(n_out)), dim3(ZK_BLOCK), dO, dA, dB, to_dev(sc), sc == HFr::one() ? 0 : 1, n_out);
-    ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpyAsync(out, dO, n_out * 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    return ZK_OK;
-}
-
-// channel_in chunks of k_conv_eval: about 2^20 threads per launch, so that layers with few outputs (2 x 2 pictures, 512 channels) still fill the GPU
-static uint32_t conv_eval_chunks(const conv_desc &c, uint64_t n_out) {
-    const uint64_t want = std::max<uint64_t>(1, ((1ull << 20) + n_out - 1) / n_out);
-    const uint32_t per = (uint32_t) std::max<uint64_t>(1, (c.CI + want - 1) / want);
-    return (c.CI + per - 1) / per;
-}
-
-// ------------------------------------------------------------------------------------------------
-// resident witness program: the next picture without the host round trip of the layer values
-// ------------------------------------------------------------------------------------------------
-extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *ops, uint64_t n_ops, const uint32_t *windows, uint64_t n_windows,
-                                             const zk_witness_step *steps, uint32_t n_steps, const zk_layer_desc *layers, int32_t n_layers) {
-    CHECK_READY();
-    static_assert(sizeof(zk_witness_op) == sizeof(wit_op) && sizeof(zk_witness_op) == 12 && sizeof(zk_witness_step) == 48, "program records");
-    if (ctx->wp_ready) { ctx->err = "witness program already uploaded"; return ZK_ERR_STATE; }
-    if (n_layers != (int32_t) ctx->L.size() || !steps || !n_steps || (n_ops && !ops) || (n_windows && !windows)) return ZK_ERR_ARG;
-    const uint64_t n0 = ctx->L[0].d.size;
-    int32_t rc;
-    // ---- the steps: every index an operation touches must exist ----
-    uint32_t n_ranges = 0;
-    std::vector<uint8_t> evaluated(n_layers, 0);
-    evaluated[0] = 1;
-    for (uint32_t k = 0; k < n_steps; ++k) {
-        const zk_witness_step &st = steps[k];
-        if (st.layer < 0 || st.layer >= n_layers) { ctx->err = "witness step: layer out of range"; return ZK_ERR_ARG; }
-        if (st.what == 1) {
-            if (st.layer < 1 || !evaluated[st.layer - 1]) { ctx->err = "witness step: layer evaluated before its inputs"; return ZK_ERR_ARG; }
-            evaluated[st.layer] = 1;
-        } else if (st.what == 2) {
-            if (!evaluated[st.layer]) { ctx->err = "witness step: range of a layer not yet evaluated"; return ZK_ERR_ARG; }
-            ++n_ranges;
-        } else if (st.what == 0) {
-            if (st.op_begin > st.op_end || st.op_end > n_ops || !evaluated[st.layer]) { ctx->err = "witness step: bad operation span"; return ZK_ERR_ARG; }
-            const uint64_t src_n = ctx->L[st.layer].d.size;
-            const bool sum = st.op_begin < st.op_end && ops[st.op_begin].op == 3;
-            uint64_t n_win = 0;
-            if (sum) {
-                if (st.win < 1 || st.win_begin > n_windows) { ctx->err = "witness step: bad window table"; return ZK_ERR_ARG; }
-                n_win = (n_windows - st.win_begin) / (uint64_t) st.win;
-            }
-            uint64_t used_win = 0;
-            for (uint64_t j = st.op_begin; j < st.op_end; ++j) {
-                const zk_witness_op &op = ops[j];
-                if (op.op > 3 || op.dst >= n0 || op.shift > 63 || (op.op == 3) != sum || ((op.op == 2) != (ops[st.op_begin].op == 2)) ||
-                    (sum ? op.src >= n_win : op.src >= src_n)) { ctx->err = "witness operation out of range"; return ZK_ERR_ARG; }
-                if (sum) used_win = std::max<uint64_t>(used_win, (uint64_t) op.src + 1);
-            }
-            for (uint64_t w = st.win_begin; w < st.win_begin + used_win * (uint64_t) (sum ? st.win : 0); ++w)
-                if (windows[w] >= src_n) { ctx->err = "witness window entry out of range"; return ZK_ERR_ARG; }
-        } else {
-            ctx->err = "witness step: unknown kind";
-            return ZK_ERR_ARG;
-        }
-    }
-    for (int i = 1; i < n_layers; ++i)
-        if (!evaluated[i]) { ctx->err = "witness program does not evaluate every layer"; return ZK_ERR_ARG; }
-    // ---- gate lists grouped by output, operands in layer 0 as raw layer-0 indices ----
-    uint64_t max_out = 1, max_blocks = 1, max_conv_part = 0;
-    for (int i = 1; i < n_layers; ++i) {
-        const zk_layer_desc &S = layers[i];
-        dev_layer &D = ctx->L[i];
-        if (S.size != D.d.size || S.ty != D.d.ty) { ctx->err = "witness program: layer descriptors differ from the uploaded circuit"; return ZK_ERR_ARG; }
-        const uint64_t n_out = S.size, n_prev = ctx->L[i - 1].d.size;
-        if (S.ty == ZK_FFT || S.ty == ZK_IFFT) {
-            if (S.fft_bit_length < 1 || S.fft_bit_length > 12) { ctx->err = "witness program: transform longer than 2^12"; return ZK_ERR_ARG; }
-            continue;
-        }
-        if (S.ty == ZK_DOT_PROD) {
-            const int fb = S.fft_bit_length;
-            if (fb < 1 || fb > 20) return ZK_ERR_ARG;
-            const uint64_t vec_out = n_out >> fb, vec_in = n_prev >> fb;
-            std::vector<uint32_t> ptr(vec_out + 1, 0);
-            for (uint64_t k = 0; k < S.n_bin; ++k) {
-                const zk_bin_gate &gt = S.bin_gates[k];
-                if (gt.g >= vec_out || gt.u >= vec_in || gt.v >= vec_in) { ctx->err = "dot-prod gate out of range"; return ZK_ERR_ARG; }
-                ++ptr[gt.g + 1];
-            }
-            for (uint64_t g = 0; g < vec_out; ++g) ptr[g + 1] += ptr[g];
-            std::vector<gate_rec> sorted(S.n_bin);
-            std::vector<uint32_t> pos(ptr.begin(), ptr.end() - 1);
-            for (uint64_t k = 0; k < S.n_bin; ++k) {
-                const zk_bin_gate &gt = S.bin_gates[k];
-                gate_rec r = {gt.g, gt.u, gt.v, 0};
-                sorted[pos[gt.g]++] = r;
-            }
-            if ((rc = upload(ctx, &D.ev_dot, sorted)) || (rc = upload(ctx, &D.ev_dot_ptr, ptr))) return rc;
-            continue;
-        }
-        std::vector<zk_uni_gate> uni(S.uni_gates, S.uni_gates + S.n_uni);
-        // a convolution whose pattern was checked at upload is evaluated from its two tensors (k_conv_eval): its bin gates are not kept
-        static const bool conv_eval_on = !(getenv("ZKCNN_CONV_EVAL") && atoi(getenv("ZKCNN_CONV_EVAL")) == 0);
-        const bool conv_eval = D.conv_ok && conv_eval_on;
-        std::vector<zk_bin_gate> bin;
-        if (!conv_eval) bin.assign(S.bin_gates, S.bin_gates + S.n_bin);
-        else max_conv_part = std::max<uint64_t>(max_conv_part, (uint64_t) conv_eval_chunks(D.conv, n_out) * n_out);
-        bool ok = true;
-        for (zk_uni_gate &gt : uni) {
-            if (gt.lu == 0) { if (gt.u >= S.size_u[0]) { ok = false; break; } gt.u = S.ori_id_u[gt.u]; }
-        }
-        for (zk_bin_gate &gt : bin) {
-            if (!ok || gt.l > 2) { ok = false; break; }
-            if (gt.l == 0) { if (gt.u >= S.size_u[0]) { ok = false; break; } gt.u = S.ori_id_u[gt.u]; }
-            if (!(gt.l & 1)) { if (gt.v >= S.size_v[0]) { ok = false; break; } gt.v = S.ori_id_v[gt.v]; }
-        }
-        if (!ok) { ctx->err = "witness program: gate operand outside its subset"; return ZK_ERR_ARG; }
-        std::vector<uint8_t> seen(n_out);
-        int g1 = grouped_by_output(uni.data(), uni.size(), n_out, seen, [&](const zk_uni_gate &gt) {
-            return (int) gt.sc < ctx->n_two_mul && gt.u < (gt.lu ? n_prev : n0); });
-        int g2 = g1 < 0 ? -1 : grouped_by_output(bin.data(), bin.size(), n_out, seen, [&](const zk_bin_gate &gt) {
-            return (int) gt.sc < ctx->n_two_mul && gt.u < (gt.l == 0 ? n0 : n_prev) && gt.v < ((gt.l & 1) ? n_prev : n0); });
-        if (g1 < 0 || g2 < 0) { ctx->err = "witness gate operand out of range"; return ZK_ERR_ARG; }
-        if (!g1) { std::vector<zk_uni_gate> t; regroup(t, uni.data(), uni.size(), n_out); uni.swap(t); }
-        if (!g2) { std::vector<zk_bin_gate> t; regroup(t, bin.data(), bin.size(), n_out); bin.swap(t); }
-        zk_uni_gate *du = nullptr;
-        zk_bin_gate *db = nullptr;
-        if ((rc = upload(ctx, &du, uni)) || (rc = upload(ctx, &db, bin))) return rc;
-        D.ev_uni = du; D.n_ev_uni = uni.size();
-        D.ev_bin = db; D.n_ev_bin = bin.size();
-        D.ev_conv = conv_eval;
-        max_out = std::max(max_out, n_out);
-        max_blocks = std::max<uint64_t>(max_blocks, (std::max(uni.size(), bin.size()) + ZK_BLOCK - 1) / ZK_BLOCK);
-    }
-    std::vector<zk_witness_op> vops(ops, ops + n_ops);
-    std::vector<uint32_t> vwin(windows, windows + n_windows);
-    zk_witness_op *d_ops = nullptr;
-    if ((rc = upload(ctx, &d_ops, vops)) || (rc = upload(ctx, &ctx->wp_windows, vwin))) return rc;
-    ctx->wp_ops = d_ops;
-    ctx->wp_n_ops = n_ops;
-    ctx->wp_n_windows = n_windows;
-    if (max_conv_part && (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_conv_part, max_conv_part * 32))) return rc;
-    if ((rc = zk_dev_alloc(ctx, (void **) &ctx->wp_tmp, 2 * max_out * 32)) ||
-        (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_carry_val, 2 * max_blocks * 32)) ||
-        (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_carry_key, 2 * max_blocks * 4)) ||
-        (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_ranges, (2 * (size_t) n_ranges + 1 + n_layers) * 8)))
-        return rc;
-    ZK_HIP(hipHostMalloc((void **) &ctx->h_wp_ranges, (2 * (size_t) n_ranges + 1 + n_layers) * 8));
-    {
-        std::vector<wit_segment> seg(n_layers);
-        for (int i = 0; i < n_layers; ++i) { seg[i].p = ctx->L[i].val; seg[i].n = ctx->L[i].d.size; }
-        wit_segment *d_seg = nullptr;
-        if ((rc = upload(ctx, &d_seg, seg))) return rc;
-        ctx->wp_segments = d_seg;
-    }
-    ctx->wp_n_ranges = n_ranges;
-    ctx->wp_steps.assign(steps, steps + n_steps);
-    ctx->wp_ready = true;
-    return ZK_OK;
-}
-
-// FFT / IFFT layer between two resident value tables (the host-array variant is zk_witness_ntt)
-static int32_t resident_ntt(zk_ctx *ctx, const dev_layer &D, const dev_layer &P) {
-    const int logn = D.d.fft_bit_length;
-    const bool inverse = D.d.ty == ZK_IFFT;
-    const uint32_t len = 1u << logn, in_len = inverse ? len : len / 2, out_len = inverse ? len / 2 : len;
-    const uint64_t count = D.d.size / out_len;
-    if (!count || (uint64_t) count * in_len > P.val_len) { ctx->err = "transform layer larger than its input"; return ZK_ERR_ARG; }
-    fr_t *pw = powers_of_root(ctx, logn, inverse);
-    if (!pw) { ctx->err = "root table allocation failed"; return ZK_ERR_NOMEM; }
-    HFr ilen;
-    HFr::inv(ilen, HFr((unsigned long long) len));
-    static bool attr_set = false;
-    if (!attr_set) {
-        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_batch), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-    }
-    const uint32_t threads = std::min<uint32_t>(1024, std::max<uint32_t>(64, len / 2));
-    prof_begin(ctx, PC_MISC, 64.0 * len * count);
-    hipLaunchKernelGGL(k_ntt_batch, dim3((uint32_t) count), dim3(threads), (size_t) len * 32, ctx->stream, D.val, P.val, pw, logn, in_len, out_len,
-                       to_dev(ilen), inverse ? 1 : 0);
-    prof_end(ctx, PC_MISC);
-    return ZK_OK;
-}
-
-extern "C" int32_t zk_witness_rerun(zk_ctx *ctx, const uint64_t *picture, uint64_t n_picture, uint64_t *ranges, uint32_t n_ranges,
-                                    uint64_t *last_layer, uint64_t n_last) {
-    CHECK_READY();
-    if (!ctx->wp_ready) { ctx->err = "no witness program on this context"; return ZK_ERR_STATE; }
-    dev_layer &L0 = ctx->L[0];
-    if (!picture || !n_picture || n_picture > L0.d.size || n_ranges != ctx->wp_n_ranges || (n_ranges && !ranges) ||
-        (last_layer && n_last > ctx->L.back().d.size))
-        return ZK_ERR_ARG;
-    int32_t rc;
-    ZK_HIP(hipMemcpyAsync(L0.val, picture, n_picture * 32, hipMemcpyHostToDevice, ctx->stream));
-    const size_t n_lay = ctx->L.size(), wp_words = 2 * (size_t) n_ranges + 1 + n_lay;
-    ZK_HIP(hipMemsetAsync(ctx->wp_ranges, 0, wp_words * 8, ctx->stream));
-    uint32_t *flags = (uint32_t *) (ctx->wp_ranges + 2 * (size_t) n_ranges);
-    uint32_t range_k = 0;
-    for (const zk_witness_step &st : ctx->wp_steps) {
-        dev_layer &D = ctx->L[st.layer];
-        if (st.what == 0) {
-            const uint64_t n = st.op_end - st.op_begin;
-            if (!n) continue;
-            ZK_LAUNCH(PC_MISC, 0.0, k_witness_aux, dim3(grid_for(n)), dim3(ZK_BLOCK), L0.val, (const fr_t *) D.val, (const wit_op *) ctx->wp_ops + st.op_begin, n,
-                      ctx->wp_windows ? ctx->wp_windows + st.win_begin : nullptr, (uint32_t) st.win, flags);
-        } else if (st.what == 2) {
-            ZK_LAUNCH(PC_MISC, 0.0, k_witness_range, dim3(grid_for(D.d.size, 512)), dim3(ZK_BLOCK), ctx->wp_ranges + 2 * (size_t) range_k, (const fr_t *) D.val,
-                      (uint64_t) D.d.size, flags);
-            ++range_k;
-        } else {
-            const dev_layer &P = ctx->L[st.layer - 1];
-            if (D.d.ty == ZK_FFT || D.d.ty == ZK_IFFT) {
-                if ((rc = resident_ntt(ctx, D, P))) return rc;
-            } else if (D.d.ty == ZK_DOT_PROD) {
-                const int fb = D.d.fft_bit_length;
-                const uint64_t len = 1ull << fb, n_out = D.d.size >> fb;
-                for (uint64_t g0 = 0; g0 < n_out; g0 += 32768) {
-                    const uint32_t ng = (uint32_t) std::min<uint64_t>(32768, n_out - g0);
-                    dim3 grid((uint32_t) ((len + ZK_BLOCK - 1) / ZK_BLOCK), ng);
-                    ZK_LAUNCH(PC_DOT, 0.0, k_dot_witness, grid, dim3(ZK_BLOCK), D.val + g0 * len, (const fr_t *) P.val, (const gate_rec *) D.ev_dot, D.ev_dot_ptr + g0, fb);
-                }
-            } else {
-                const uint64_t n_out = D.d.size;
-                fr_t *dA = ctx->wp_tmp, *dB = dA + n_out;
-                ZK_HIP(hipMemsetAsync(dA, 0, 2 * n_out * 32, ctx->stream));
-                if (D.n_ev_uni) {
-                    const uint64_t blocks = (D.n_ev_uni + ZK_BLOCK - 1) / ZK_BLOCK;
-                    ZK_LAUNCH(PC_GATE, 44.0 * (double) D.n_ev_uni, k_eval_uni, dim3((uint32_t) blocks), dim3(ZK_BLOCK), dA, ctx->wp_carry_key, ctx->wp_carry_val,
-                              (const uni_gate_dev *) D.ev_uni, D.n_ev_uni, (const fr_t *) L0.val, (const fr_t *) P.val, (const fr_t *) ctx->two_mul);
-                    ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup, dim3(grid_for(2 * blocks)), dim3(ZK_BLOCK), dA, ctx->wp_carry_key, ctx->wp_carry_val, 2 * blocks);
-                }
-                if (D.ev_conv) {
-                    const conv_desc &c = D.conv;
-                    const uint32_t chunks = conv_eval_chunks(c, n_out), per = (c.CI + chunks - 1) / chunks;
-                    fr_t *part = chunks == 1 ? dB : ctx->wp_conv_part;
-                    ZK_LAUNCH(PC_GATE, 80.0 * (double) n_out * c.CI * c.m * c.m, k_conv_eval, dim3((uint32_t) ((n_out + ZK_BLOCK - 1) / ZK_BLOCK), chunks), dim3(ZK_BLOCK), part,
-                              (const fr_t *) P.val, (const fr_t *) L0.val + c.wstart, c, per);
-                    if (chunks > 1)
-                        ZK_LAUNCH(PC_GATE, 0.0, k_sum_rows, dim3((uint32_t) ((n_out + 63) / 64)), dim3(1024), dB, (const fr_t *) part, (uint32_t) n_out, chunks);
-                }
-                if (D.n_ev_bin) {
-                    const uint64_t blocks = (D.n_ev_bin + ZK_BLOCK - 1) / ZK_BLOCK;
-                    ZK_LAUNCH(PC_GATE, 80.0 * (double) D.n_ev_bin, k_eval_bin, dim3((uint32_t) blocks), dim3(ZK_BLOCK), dB, ctx->wp_carry_key, ctx->wp_carry_val,
-                              (const bin_gate_dev *) D.ev_bin, D.n_ev_bin, (const fr_t *) L0.val, (const fr_t *) P.val, (const fr_t *) ctx->two_mul);
-                    ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup, dim3(grid_for(2 * blocks)), dim3(ZK_BLOCK), dB, ctx->wp_carry_key, ctx->wp_carry_val, 2 * blocks);
-                }
-                const HFr sc = H(D.d.scale);
-                ZK_LAUNCH(PC_MISC, 0.0, k_eval_combine, dim3(grid_for(n_out)), dim3(ZK_BLOCK), D.val, (const fr_t *) dA, (const fr_t *) dB, to_dev(sc),
-                          sc == HFr::one() ? 0 : 1, n_out);
-            }
-        }
-    }
-    // where every layer's values end (the round kernels skip the zero tails of the tables they fold)
-    ZK_LAUNCH(PC_MISC, 0.0, k_last_nonzero, dim3(64, (uint32_t) n_lay), dim3(ZK_BLOCK), ctx->wp_ranges + 2 * (size_t) n_ranges + 1, (const wit_segment *) ctx->wp_segments);
-    ZK_HIP(hipGetLastError());
-    for (dev_layer &D : ctx->L) D.val_live = D.val_len;          // until the copy below is back
-    ZK_HIP(hipMemcpyAsync(ctx->h_wp_ranges, ctx->wp_ranges, wp_words * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (last_layer && n_last) ZK_HIP(hipMemcpyAsync(last_layer, ctx->L.back().val, n_last * 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    for (uint32_t k = 0; k < 2 * n_ranges; ++k) ranges[k] = ctx->h_wp_ranges[k];
-    for (size_t i = 0; i < n_lay; ++i) ctx->L[i].val_live = ctx->h_wp_ranges[2 * (size_t) n_ranges + 1 + i];
-    if (ctx->h_wp_ranges[2 * (size_t) n_ranges] & WIT_FLAG_WIDE) { ctx->err = "a layer value does not fit 63 bits"; return ZK_ERR_STATE; }
     return ZK_OK;
 }
 
@@ -2966,3 +1597,4 @@ extern "C" int32_t zk_bench_round_quadratic(zk_ctx *ctx, uint32_t log_n, uint32_
     if (rc) return rc;
     return wait_slot(ctx, ctx->slot_seq);
 }
+

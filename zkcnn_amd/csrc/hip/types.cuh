@@ -28,3 +28,13 @@ struct conv_desc {
     uint32_t pp, CO, CI, nxi, nyi, nxo, nyo, m, pad, ls, wstart;
     int32_t bx_i, by_i, bc_i, bx_o, by_o, bc_o;
 };
+
+// ---- layer-0 combine (k_eq_halves_multi / k_liu_gather) and the small eq tables of the structured convolutions ----
+struct liu_table { fr_vec r; fr_t init; int32_t n, fh, sh, pad_; };      // one per (layer, side) that touches layer 0
+#define LIU_HALF_STRIDE 4096u                                               // entries per half table (bit length of a subset table <= 24)
+struct liu_entry { uint32_t h, t; };                                        // index h inside table (t & 0xffffff); t >> 24 = bits of the table's low half
+#define CONV_TAB_STRIDE 4096u           // entries per small eq table
+// table numbers inside the context's small-table buffer
+// (the tables are built by the phase's k_prep launch: prep_kernels.cuh, prep_small_block -- eq(r[0..n), .) * init for n <= 12)
+enum { CT_S0 = 0, CT_A0, CT_P0, CT_S1, CT_A1, CT_P1, CT_D, CT_C, CT_PU, CT_COUNT };
+
