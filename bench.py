@@ -664,7 +664,8 @@ def main():
     out = {
         "metric": f"proofs/s (GKR prover, {args.workload} pic_cnt={pp} proofs, {K} in flight per GPU; modes SEEDED|DRIVE_ONLY|REUSE_GENS: public generators "
                   "with a resident byte table, IPA cut at 256" + ("; EXPERIMENT: hybrid host tail" if args.hybrid_tail else "") + ("; EXPERIMENT: Fiat-Shamir, device-side rounds" if args.fiat_shamir else "") +
-                  "); prover_ms_per_image = single-stream latency; conservative companions alongside",
+                  "; sessions share one resident circuit, a picture each); prover_ms_per_image = single-stream latency (a lone proof runs its rounds in resident "
+                  "kernels, with several in flight every round is a launch); conservative companions alongside",
         "value": round(sum(p["streams"] for p in per_rank) * steps / elapsed, 4),         # every rank's proofs (a rank may hold fewer streams than asked for)
         "unit": "proofs/s",
         "n_gpus": world, "steps": steps, "warmup": args.warmup,
