@@ -255,7 +255,7 @@ def main():
         drive |= zkcnn_amd.MODE_HOST_TAIL
     if args.fiat_shamir:
         drive |= zkcnn_amd.MODE_FIAT_SHAMIR
-    if args.host_rounds:
+    if args.host_rounds or args.rehearse_shared_gpu:       # (ranks that share a GPU are not alone on it: the policy counts proofs per PROCESS)
         drive |= zkcnn_amd.MODE_HOST_ROUNDS
 
     def in_threads(fn):

@@ -483,49 +483,55 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_mid(mid_args a) {
     __syncthreads();
     bool first = a.first != 0;
     for (int k = 0; k < a.rounds; ++k) {
-        const uint32_t q0 = (uint32_t) (first ? n[0] / 2 : n[0] / 4), q1 = (uint32_t) (first ? n[1] / 2 : n[1] / 4), total = q0 + q1, nblk = (total + 63) / 64;
-        if (64u * lb >= total) return;                                  // this block's quads are gone (uniform: every later round is smaller)
+        // chunks of 64 quads; block lb takes chunks lb, lb + G, ... (G = gridDim.x <= MID_MAX_BLOCKS: the kernel's footprint is bounded whatever the
+        // table size, because its blocks wait for one another and must all be resident)
+        const uint32_t q0 = (uint32_t) (first ? n[0] / 2 : n[0] / 4), q1 = (uint32_t) (first ? n[1] / 2 : n[1] / 4), total = q0 + q1;
+        const uint32_t nchunks = (total + 63) / 64, nblk = min(nchunks, gridDim.x);
+        if (lb >= nchunks) return;                                     // this block's chunks are gone (uniform: every later round is smaller)
         const fr_t r = s_r;
         // add_term (1 - r): every block tracks the scalar (one product on a wave that idles otherwise), so whoever leads the round has it
         if (tid == 64 && a.with_add_term) s_add = fr_mul(s_add, fr_sub(fr_one(), r));
-        const uint32_t item = 64u * lb + ((uint32_t) tid >> 2);
-        const bool live = item < total;
-        const int b = (live && item >= q0) ? 1 : 0;
-        const uint32_t q = b ? item - q0 : item;
-        fr_t opA = fr_zero(), opB = fr_zero();
-        if (first) {
-            // the phase's first round: pairs as they are (reference src/prover.cpp:396-426 with nothing to fold yet)
-            if (live && role < 3) {
-                fr_t v0, v1, m0, m1;
-                fr_load2_sc1((b ? Vin[1] : Vin[0]) + 2 * (size_t) q, v0, v1);
-                fr_load2_sc1((b ? Min[1] : Min[0]) + 2 * (size_t) q, m0, m1);
-                opA = role == 0 ? v0 : role == 1 ? v1 : fr_sub(v1, v0);
-                opB = role == 0 ? m0 : role == 1 ? m1 : fr_sub(m1, m0);
-            }
-        } else {
-            fr_t X = fr_zero();
-            if (live) {
-                const fr_t *src = (role < 2 ? (b ? Vin[1] : Vin[0]) : (b ? Min[1] : Min[0])) + 4 * (size_t) q + 2 * (role & 1);
-                fr_t e0, e1;
-                fr_load2_sc1(src, e0, e1);
-                X = fr_lerp(e0, e1, r);
-                fr_t *dst = role < 2 ? (b ? a.Vbuf[1][oi[1]] : a.Vbuf[0][oi[0]]) : (b ? a.Mbuf[1][oi[1]] : a.Mbuf[0][oi[0]]);
-                fr_store_sc1(dst + 2 * (size_t) q + (role & 1), X);
-            }
-            fr_t y1, y2, y3;
+        fr_t prod = fr_zero();
+        for (uint32_t chunk = lb; chunk < nchunks; chunk += gridDim.x) {
+            const uint32_t item = 64u * chunk + ((uint32_t) tid >> 2);
+            const bool live = item < total;
+            const int b = (live && item >= q0) ? 1 : 0;
+            const uint32_t q = b ? item - q0 : item;
+            fr_t opA = fr_zero(), opB = fr_zero();
+            if (first) {
+                // the phase's first round: pairs as they are (reference src/prover.cpp:396-426 with nothing to fold yet)
+                if (live && role < 3) {
+                    fr_t v0, v1, m0, m1;
+                    fr_load2_sc1((b ? Vin[1] : Vin[0]) + 2 * (size_t) q, v0, v1);
+                    fr_load2_sc1((b ? Min[1] : Min[0]) + 2 * (size_t) q, m0, m1);
+                    opA = role == 0 ? v0 : role == 1 ? v1 : fr_sub(v1, v0);
+                    opB = role == 0 ? m0 : role == 1 ? m1 : fr_sub(m1, m0);
+                }
+            } else {
+                fr_t X = fr_zero();
+                if (live) {
+                    const fr_t *src = (role < 2 ? (b ? Vin[1] : Vin[0]) : (b ? Min[1] : Min[0])) + 4 * (size_t) q + 2 * (role & 1);
+                    fr_t e0, e1;
+                    fr_load2_sc1(src, e0, e1);
+                    X = fr_lerp(e0, e1, r);
+                    fr_t *dst = role < 2 ? (b ? a.Vbuf[1][oi[1]] : a.Vbuf[0][oi[0]]) : (b ? a.Mbuf[1][oi[1]] : a.Mbuf[0][oi[0]]);
+                    fr_store_sc1(dst + 2 * (size_t) q + (role & 1), X);
+                }
+                fr_t y1, y2, y3;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                y1.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 2, 64);
-                y2.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 1, 64);
-            }
+                for (int i = 0; i < 8; ++i) {
+                    y1.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 2, 64);
+                    y2.v[i] = (uint32_t) __shfl_xor((int) X.v[i], 1, 64);
+                }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) y3.v[i] = (uint32_t) __shfl_xor((int) y1.v[i], 1, 64);
-            // role 0: X = v0, y1 = m0;  role 1: X = v1, y1 = m1;  role 2: X = m0, y1 = v0, y2 = m1, y3 = v1
-            opA = role == 2 ? fr_sub(y3, y1) : X;
-            opB = role == 2 ? fr_sub(y2, X) : y1;
-            if (role == 3 || !live) { opA = fr_zero(); opB = fr_zero(); }
+                for (int i = 0; i < 8; ++i) y3.v[i] = (uint32_t) __shfl_xor((int) y1.v[i], 1, 64);
+                // role 0: X = v0, y1 = m0;  role 1: X = v1, y1 = m1;  role 2: X = m0, y1 = v0, y2 = m1, y3 = v1
+                opA = role == 2 ? fr_sub(y3, y1) : X;
+                opB = role == 2 ? fr_sub(y2, X) : y1;
+                if (role == 3 || !live) { opA = fr_zero(); opB = fr_zero(); }
+            }
+            prod = fr_add(prod, fr_mul(opA, opB));
         }
-        fr_t prod = fr_mul(opA, opB);
 #pragma unroll
         for (int off = 4; off < 64; off <<= 1) {
             fr_t o;

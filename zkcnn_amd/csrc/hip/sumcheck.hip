@@ -25,7 +25,9 @@ struct prep_plan {
     uint32_t blocks = 0;
     int npts = 0;
     bool overflow = false;
+    bool latency = true;             // a proof that is alone on its GPU: many small blocks (short chains); several in flight: fewer, larger ones
     prep_plan() { std::memset(&A, 0, sizeof(A)); }
+    explicit prep_plan(const zk_ctx *ctx) : latency(ctx->live_now) { std::memset(&A, 0, sizeof(A)); }
     bool empty() const { return blocks == 0; }
     int point(const HFr *r, int n) {
         if (npts >= 2) { overflow = true; return 0; }
@@ -62,7 +64,9 @@ struct prep_plan {
         if (has_b) { J.pt[J.npoints] = point(r1, n); J.init[J.npoints++] = to_dev(b); }
         if (has_a) { J.pt[J.npoints] = point(r0, n); J.init[J.npoints++] = to_dev(a); }
         // entries per block: small tables are latency bound (one entry per thread, short quarter tables), large ones amortise the block's prelude
-        J.c = std::min(n, n <= 16 ? 8 : n <= 20 ? 10 : 12);
+        // Alone on the GPU one entry per thread and short quarter tables win; with several proofs in flight every block's prelude (the doubling steps, the
+        // tree product) is SIMD time the others wait for, so blocks are four times larger.
+        J.c = latency ? std::min(n, n <= 16 ? 8 : n <= 20 ? 10 : 12) : std::min(n, n <= 18 ? 10 : 12);
         J.blk0 = blocks;
         J.nblk = (uint32_t) ((len + (1ull << J.c) - 1) >> J.c);
         blocks += J.nblk;
@@ -85,7 +89,7 @@ static int32_t eq_table(zk_ctx *ctx, fr_t *out, int n, const HFr *r0, const HFr 
                         uint64_t tail_start, const HFr &tail_scale, uint64_t limit = ~0ull) {
     if (n < 0) return ZK_OK;
     if (n > ZK_MAX_VARS) { ctx->err = "eq table too large"; return ZK_ERR_ARG; }
-    prep_plan P;
+    prep_plan P(ctx);
     P.eq(out, n, r0, a, r1, b, tail_start, tail_scale, limit);
     return P.launch(ctx);
 }
@@ -447,7 +451,7 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
     ctx->round = 0;
     ctx->conv_K = 0;
     const HFr scale = H(d.scale);
-    prep_plan P;
+    prep_plan P(ctx);
 
     if (d.ty == ZK_FFT || d.ty == ZK_IFFT) {
         const bool fwd = d.ty == ZK_FFT;
@@ -537,7 +541,7 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
     ctx->small_len = 1u << fft_bl;
     ctx->small_cur = 0;
     const uint64_t N = ctx->tp[1].len;
-    prep_plan P;
+    prep_plan P(ctx);
     P.eq1(ctx->small[0], fft_bl, ctx->r_0, HFr::one());
     load_v_table(ctx, P, ctx->tp[1], 1, d.bit_length_u[1], d.size_u[1], nullptr, prev);
     // (k_dot_v0 writes the rows that have gates; the rest of V0 is zero)
@@ -633,7 +637,7 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
     ctx->add_pending = false;
     ctx->round = 0;
     const HFr *ru = ctx->r_u[id].data();
-    prep_plan P;
+    prep_plan P(ctx);
 
     if (d.ty == ZK_DOT_PROD) {
         const int fft_bl = d.fft_bit_length, cnt_bl = d.max_bl_v;
@@ -1145,7 +1149,7 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         // the tables are small (k_tail<false>: it takes over at TAIL_QUADS quads); the host answers the following calls from the record
         if (in_phase && *ctx->fs_pending == 0) {
             int32_t rc = ZK_OK;
-            if (const int rounds = plan_segment()) rc = run_device_mid(ctx, r, with_add_term, rounds, (uint32_t) ((round_quads + 63) / 64));
+            if (const int rounds = plan_segment()) rc = run_device_mid(ctx, r, with_add_term, rounds, (uint32_t) std::min<uint64_t>((round_quads + 63) / 64, MID_MAX_BLOCKS));
             else if (round_quads <= TAIL_QUADS) rc = run_device_rounds(ctx, r, with_add_term);
             if (rc) return rc;
         }
@@ -1154,7 +1158,7 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         int32_t rc = ZK_OK;
         if (const int rounds = plan_segment()) {
             rc = resolve_add_term(ctx);
-            if (!rc) rc = mid_start(ctx, r, with_add_term, rounds, (uint32_t) ((round_quads + 63) / 64));
+            if (!rc) rc = mid_start(ctx, r, with_add_term, rounds, (uint32_t) std::min<uint64_t>((round_quads + 63) / 64, MID_MAX_BLOCKS));
         } else if (round_quads <= TAIL_QUADS) {
             rc = resolve_add_term(ctx);
             if (!rc) rc = live_start(ctx, r, with_add_term);

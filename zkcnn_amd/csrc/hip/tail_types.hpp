@@ -10,6 +10,7 @@
 #define FS_TAIL_MAX_ROUNDS ZK_MAX_VARS
 #define TAIL_TIMEOUT_TICKS 300000000ull   // 3 s of s_memrealtime (100 MHz): a live kernel nobody talks to gives up
 #define TAIL_ABORT 0xffffffffu
+#define MID_MAX_BLOCKS 256u           // k_mid's grid: its workgroups wait for one another, so the footprint is bounded (1024 waves) whatever the table size
 
 struct __align__(16) live_in {        // mapped host memory, written by the host: chunk j = {challenge words 3j, 3j+1, 3j+2, seq} (chunk 2: words 6, 7, 0)
     uint32_t c[3][4];
