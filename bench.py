@@ -73,7 +73,7 @@ CLASS_KERNELS = {"round_quad": ("k_round_quad2", "k_round_quad_fine"), "round_ta
                  "msm_planes": ("k_msm_codes", "k_msm_windows", "k_msm_planes", "k_scalar_codes", "k_scalar_mags", "k_bit_masks", "k_compact_flags")}
 
 
-def measure_pmc_traffic(workload, kernels, timeout_s=240):
+def measure_pmc_traffic(workload, kernels, timeout_s=150):
     """HBM bytes per launch of `kernels`, measured NOW: two short child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE
     in separate passes, as MI355X_MICROARCH.md prescribes: they do not fit one pass; KB counters; FETCH_SIZE doubled -- gfx950 tallies the 128-byte
     requests of wide coalesced reads at 64 bytes). One session, a few proofs. None if rocprofv3 is missing or anything goes wrong."""

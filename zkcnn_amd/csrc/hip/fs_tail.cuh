@@ -169,12 +169,15 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
     __shared__ fr_t s_r, s_fin[2], s_prod[2], s_tail[2][2], s_add, s_addm;
     __shared__ uint32_t s_state[8];
     __shared__ int s_stop;
+    // the folded tables live in LDS from the kernel's first fold on ([0]: V, [1]: M; pair 0 at the front, pair 1 behind it): a round's operands are
+    // ~100 ns away instead of a trip through L2. Ping-pong: a fold's outputs are half its inputs (<= 2 * TAIL_QUADS entries after the first fold).
+    __shared__ fr_t s_buf0[2][2 * TAIL_QUADS], s_buf1[2][TAIL_QUADS];
+    int folds = 0;
     unsigned long long t_wait = 0;
     const unsigned long long t_begin = LIVE ? wall_clock64() : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint64_t n[2] = {a.n[0], a.n[1]};
     const fr_t *Vin[2] = {a.Vin[0], a.Vin[1]}, *Min[2] = {a.Min[0], a.Min[1]};
-    int oi[2] = {a.out_idx[0], a.out_idx[1]};
     bool first = a.first != 0;
     uint32_t pstate[2] = {n[0] ? 1u : 0u, n[1] ? 1u : 0u};
     if (tid == 0) {
@@ -215,7 +218,8 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
             else if (live && item >= quads[0]) { b = 1; q = item - quads[0]; }
             const uint32_t quads_b = b ? quads[1] : quads[0];
             const fr_t *Vb = b ? Vin[1] : Vin[0], *Mb = b ? Min[1] : Min[0];
-            const int oib = b ? oi[1] : oi[0];
+            fr_t *wV = (folds & 1) ? s_buf1[0] : s_buf0[0], *wM = (folds & 1) ? s_buf1[1] : s_buf0[1];
+            const uint32_t wbase = b ? 2 * quads[0] : 0;               // where this pair's outputs start in the LDS buffers
             fr_t X = fr_zero(), opA = fr_zero(), opB = fr_zero();
             if (special) {
                 if (role == 0 || role == 2) {
@@ -233,7 +237,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
             } else if (live) {
                 const fr_t *src = (role < 2 ? Vb : Mb) + 4 * q + 2 * (role & 1);
                 X = fr_lerp(fr_load(src), fr_load(src + 1), r);
-                fr_store((role < 2 ? a.Vbuf[b][oib] : a.Mbuf[b][oib]) + 2 * q + (role & 1), X);
+                (role < 2 ? wV : wM)[wbase + 2 * q + (role & 1)] = X;
                 if (quads_b == 1 && role < 2) s_tail[b][role] = X;           // the pair the phase may end with
             }
             if (!first || special) {
@@ -379,12 +383,13 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
             if (!n[b]) continue;
             if (collapse[b]) { n[b] = 0; pstate[b] = 2; continue; }
             if (!first) {
-                Vin[b] = a.Vbuf[b][oi[b]];
-                Min[b] = a.Mbuf[b][oi[b]];
-                oi[b] ^= 1;
+                const uint32_t wbase = b ? 2 * quads[0] : 0;
+                Vin[b] = ((folds & 1) ? s_buf1[0] : s_buf0[0]) + wbase;
+                Min[b] = ((folds & 1) ? s_buf1[1] : s_buf0[1]) + wbase;
                 n[b] >>= 1;
             }
         }
+        if (!first) ++folds;
         first = false;
     }
     if (!LIVE && tid == 0) {
