@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B runs of bench.py over library builds kept under ab/<name>/ (scratch, not tracked): prints the prover split per variant.
-# usage: scripts/ab_bench.sh "<name>[:ENV=VAL]" ...   e.g.  scripts/ab_bench.sh lib_old lib_new:ZKCNN_PRELAUNCH=0 lib_new
+# usage: scripts/ab_bench.sh "<name>[:ENV=VAL]" ...   e.g.  scripts/ab_bench.sh lib_old lib_new:GPU_MAX_HW_QUEUES=8 lib_new
 cd "$(dirname "$0")/.."
 WL=${WORKLOAD:-vgg11}
 for v in "$@"; do
