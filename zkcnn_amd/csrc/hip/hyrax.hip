@@ -412,7 +412,7 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
     if ((rc = regrow(ctx, (void **) &s->codes, &s->codes_cap, (size_t) rows_all * cols * 2))) return rc;
     // columns per lane: 64 would give one wave per row, but the ~2 250 full rows of a vgg11 commitment do not divide evenly over 1 024 SIMDs
     // (some get three such waves, some two: the kernel lasts as long as three); with half rows the spread is 5 against 4.4 on average
-    static const uint32_t cpt_max = getenv("ZKCNN_MSM_CPT") ? std::max(1, atoi(getenv("ZKCNN_MSM_CPT"))) : 32;
+    const uint32_t cpt_max = 32;
     const uint32_t cpt = std::max<uint32_t>(1, std::min<uint32_t>(cpt_max, (cols + MSM_BLOCK - 1) / MSM_BLOCK));
     const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt), n = chunks * MSM_BLOCK;
     if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows_all * n * sizeof(g1j_t)))) return rc;

@@ -292,8 +292,7 @@ extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *o
         }
         std::vector<zk_uni_gate> uni(S.uni_gates, S.uni_gates + S.n_uni);
         // a convolution whose pattern was checked at upload is evaluated from its two tensors (k_conv_eval): its bin gates are not kept
-        static const bool conv_eval_on = !(getenv("ZKCNN_CONV_EVAL") && atoi(getenv("ZKCNN_CONV_EVAL")) == 0);
-        const bool conv_eval = D.conv_ok && conv_eval_on;
+        const bool conv_eval = D.conv_ok;
         std::vector<zk_bin_gate> bin;
         if (!conv_eval) bin.assign(S.bin_gates, S.bin_gates + S.n_bin);
         else max_conv_part = std::max<uint64_t>(max_conv_part, (uint64_t) conv_eval_chunks(D.conv, n_out) * n_out);
