@@ -397,15 +397,23 @@ __global__ void k_fold(const fr_t *in, fr_t *out, uint64_t n, fr_t r) {
 // ls == 1 means it has collapsed to a constant). Coefficients c3..c0 of
 //   sum_i (V0 pair)(x) * (V1 pair)(x) * (Ms pair[i mod ls/2])(x)
 // ------------------------------------------------------------------------------------------------
+// Ms_raw / Ms_out (round 3): when Ms_raw is given, the periodic table has NOT been folded yet -- entry i of this round's table is
+// lerp(Ms_raw[2i], Ms_raw[2i + 1], r), taken on the fly (two extra products per thread), and block 0 stores the folded table in Ms_out for
+// the next round: the separate k_fold launch per cubic round is gone.
+__device__ __forceinline__ fr_t cubic_ms(const fr_t *Ms, const fr_t *Ms_raw, uint32_t i, const fr_t &r) {
+    return Ms_raw ? fr_lerp(fr_load(Ms_raw + 2 * (size_t) i), fr_load(Ms_raw + 2 * (size_t) i + 1), r) : fr_load(Ms + i);
+}
 __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, const fr_t *V1in, fr_t *V0out, fr_t *V1out,
                                                           const fr_t *Ms, uint32_t ls, uint64_t n, fr_t r, int first,
                                                           fr_t *partials, uint32_t *counter, host_slot *slot,
-                                                          unsigned long long seq) {
+                                                          unsigned long long seq, const fr_t *Ms_raw, fr_t *Ms_out) {
     __shared__ fr_t smem[4 * ZK_BLOCK / 64];
     fr_t acc[4] = {fr_zero(), fr_zero(), fr_zero(), fr_zero()};      // c3, c2, c1, c0
     const uint64_t tid = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x, stride = (uint64_t) gridDim.x * ZK_BLOCK;
     const uint64_t npairs = first ? n / 2 : n / 4;
     const uint32_t mpairs = ls >> 1;
+    if (Ms_raw && blockIdx.x == 0)
+        for (uint32_t j = threadIdx.x; j < ls; j += ZK_BLOCK) fr_store(Ms_out + j, cubic_ms(Ms, Ms_raw, j, r));
     // The periodic factor depends on the pair only through p mod mpairs. When the grid stride is a multiple of mpairs, all pairs
     // of a thread share it: the thread accumulates the QUADRATIC sum_p X_p(t) Y_p(t) (3 products per pair) and multiplies by its
     // one periodic factor at the end -- 7 products per pair instead of 13.
@@ -432,10 +440,10 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, cons
             fr_t m0, dm;
             if (mpairs) {
                 const uint32_t mi = (uint32_t) (tid & (mpairs - 1));
-                m0 = fr_load(Ms + 2 * mi);
-                dm = fr_sub(fr_load(Ms + 2 * mi + 1), m0);
+                m0 = cubic_ms(Ms, Ms_raw, 2 * mi, r);
+                dm = fr_sub(cubic_ms(Ms, Ms_raw, 2 * mi + 1, r), m0);
             } else {
-                m0 = fr_load(Ms);
+                m0 = cubic_ms(Ms, Ms_raw, 0, r);
                 dm = fr_zero();
             }
             const fr_t q1 = fr_sub(fr_sub(s11, sdd), s00);
@@ -461,10 +469,10 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, cons
         fr_t m0, dm;
         if (mpairs) {
             const uint32_t mi = (uint32_t) (p & (mpairs - 1));
-            m0 = fr_load(Ms + 2 * mi);
-            dm = fr_sub(fr_load(Ms + 2 * mi + 1), m0);
+            m0 = cubic_ms(Ms, Ms_raw, 2 * mi, r);
+            dm = fr_sub(cubic_ms(Ms, Ms_raw, 2 * mi + 1, r), m0);
         } else {
-            m0 = fr_load(Ms);
+            m0 = cubic_ms(Ms, Ms_raw, 0, r);
             dm = fr_zero();
         }
         const fr_t dx = fr_sub(x1, x0), dy = fr_sub(y1, y0);

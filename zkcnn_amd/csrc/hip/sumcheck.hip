@@ -563,8 +563,13 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
     const bool first = ctx->round == 0;
     if (!first) ctx->r_u[id].at(ctx->round - 1) = r;
     ++ctx->round;
+    // the periodic table is folded INSIDE the round kernel (entry i = lerp of the unfolded pair, taken on the fly; block 0 stores the folded table
+    // for the next round): one launch per cubic round instead of two
+    const fr_t *ms_raw = nullptr;
+    fr_t *ms_out = nullptr;
     if (!first && ctx->small_len >= 2) {
-        ZK_LAUNCH(PC_FOLD, 0.0, k_fold, dim3(grid_for(ctx->small_len / 2)), dim3(ZK_BLOCK), ctx->small[ctx->small_cur], ctx->small[ctx->small_cur ^ 1], (uint64_t) ctx->small_len, to_dev(r));
+        ms_raw = ctx->small[ctx->small_cur];
+        ms_out = ctx->small[ctx->small_cur ^ 1];
         ctx->small_cur ^= 1;
         ctx->small_len >>= 1;
     }
@@ -575,8 +580,8 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
     const uint32_t g = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks);
     const unsigned long long seq = ++ctx->slot_seq;
     ZK_LAUNCH(PC_ROUND_CUBIC, (first ? 64.0 : 96.0) * (double) n, k_round_cubic, dim3(g), dim3(ZK_BLOCK), t0.V[t0.cur], vin(t1),
-              t0.V[t0.cur ^ 1], t1.V[t1.cur ^ 1], ctx->small[ctx->small_cur], ctx->small_len, n, to_dev(r), first ? 1 : 0, ctx->partials,
-              ctx->d_counter, (host_slot *) ctx->d_slot, seq);
+              t0.V[t0.cur ^ 1], t1.V[t1.cur ^ 1], (const fr_t *) ctx->small[ctx->small_cur], ctx->small_len, n, to_dev(r), first ? 1 : 0, ctx->partials,
+              ctx->d_counter, (host_slot *) ctx->d_slot, seq, ms_raw, ms_out);
     ZK_HIP(hipGetLastError());
     if (!first) {
         t0.cur ^= 1; t1.cur ^= 1;
