@@ -210,6 +210,7 @@ struct round2_args {
 
 // reference src/prover.cpp:368-426 for both table pairs of a layer in one launch
 __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad2(round2_args a) {
+    ZK_LATENCY_PRIO();
     __shared__ fr_t smem[3 * ZK_BLOCK / 64];
     const int b = blockIdx.x < a.blocks[0] ? 0 : 1;
     const uint32_t lb = b ? blockIdx.x - a.blocks[0] : blockIdx.x, nblk = a.blocks[b];
@@ -280,6 +281,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad2(round2_args a) {
 // followed by a 4-step butterfly over lanes of equal role. A pair that collapses this round is one item whose
 // roles 0 and 2 produce the final V and M values (the reference's `total == 1` case).
 __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad_fine(round2_args a) {
+    ZK_LATENCY_PRIO();
     __shared__ fr_t smem[3 * ZK_BLOCK / 64];
     __shared__ fr_t s_role[3][ZK_BLOCK / 64];
     uint64_t items[2];
@@ -374,6 +376,7 @@ struct eval_args {
     unsigned long long seq;
 };
 __global__ void k_eval_pairs(eval_args a) {
+    ZK_LATENCY_PRIO();
     if (threadIdx.x < 4 && a.n[threadIdx.x]) {
         const fr_t *p = a.p[threadIdx.x];
         fr_t v = fr_load(p);
@@ -407,6 +410,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, cons
                                                           const fr_t *Ms, uint32_t ls, uint64_t n, fr_t r, int first,
                                                           fr_t *partials, uint32_t *counter, host_slot *slot,
                                                           unsigned long long seq, const fr_t *Ms_raw, fr_t *Ms_out) {
+    ZK_LATENCY_PRIO();
     __shared__ fr_t smem[4 * ZK_BLOCK / 64];
     fr_t acc[4] = {fr_zero(), fr_zero(), fr_zero(), fr_zero()};      // c3, c2, c1, c0
     const uint64_t tid = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x, stride = (uint64_t) gridDim.x * ZK_BLOCK;

@@ -125,6 +125,7 @@ __device__ __forceinline__ void prep_small_block(const prep_small_job &J, uint32
 }
 
 __global__ void __launch_bounds__(ZK_BLOCK) k_prep(prep_args a) {
+    ZK_LATENCY_PRIO();
     const uint32_t blk = blockIdx.x;
     for (int k = 0; k < a.n_eq; ++k)
         if (blk >= a.eq[k].blk0 && blk < a.eq[k].blk0 + a.eq[k].nblk) { prep_eq_block(a.eq[k], a.r, blk - a.eq[k].blk0); return; }
@@ -193,6 +194,7 @@ __device__ __forceinline__ fr_t gate_term2(const gate_rec &rc, const gate_multi_
 }
 
 __global__ void __launch_bounds__(ZK_BLOCK) k_gate_multi(gate_multi_args a) {
+    ZK_LATENCY_PRIO();
     const uint32_t blk = blockIdx.x;
     if (a.sum_nblk && blk >= a.sum_blk0 && blk < a.sum_blk0 + a.sum_nblk) {
         __shared__ fr_t smem[2 * ZK_BLOCK / 64];
@@ -237,6 +239,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_gate_multi(gate_multi_args a) {
 
 // carries of up to two lists: slots [0, n0) belong to out0, [n0, n0 + n1) to out1
 __global__ void k_gate_fixup2(fr_t *out0, fr_t *out1, const uint32_t *carry_key, const fr_t *carry_val, uint64_t n0, uint64_t n1) {
+    ZK_LATENCY_PRIO();
     for (uint64_t s = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; s < n0 + n1; s += (uint64_t) gridDim.x * blockDim.x) {
         const uint64_t lo = s < n0 ? 0 : n0, hi = s < n0 ? n0 : n0 + n1;
         fr_t *out = s < n0 ? out0 : out1;

@@ -4,6 +4,10 @@
 
 #define ZK_BLOCK 256
 #define ZK_MAX_VARS 30
+// A launch of few workgroups is a link of a proof's dependent chain (a small round, a phase's initialisation): its waves ask for issue priority
+// over the bulk kernels of OTHER proofs that share their SIMDs (multi-scalar multiplications, streaming rounds). Wide launches are bulk themselves.
+#define ZK_LATENCY_GRID 128u
+#define ZK_LATENCY_PRIO() do { if (gridDim.x <= ZK_LATENCY_GRID) __builtin_amdgcn_s_setprio(3); } while (0)
 
 struct fr_vec {                       // challenge vector passed by value in the kernel argument block
     fr_t v[ZK_MAX_VARS];
