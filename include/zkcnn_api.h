@@ -109,6 +109,9 @@ void zkcnn_session_destroy(void *session);
 /* The reference CLI's 16-column result row of the last prove call ("a, b, c, ..."), NUL terminated. */
 int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap);
 
+/* Product library only, test hook (include/zkcnn_hip.h: zk_witness_conv_paths): out[0] = convolutions new_image evaluates from their tensors,
+ * out[1] = those the last new_image evaluated in 64-bit integers, out[2] = index in layer 0 of the first one's weights; force_field = 1 / 0 / < 0: field arithmetic for all / by the bounds / unchanged. */
+int32_t zkcnn_session_conv_paths(void *session, int32_t force_field, uint64_t out[3]);
 /* Product library only: sumcheck rounds / phases the GPU has run by itself in Fiat-Shamir mode so far (include/zkcnn_hip.h: zk_fs_attach) */
 int32_t zkcnn_session_fs_stats(void *session, uint64_t *rounds, uint64_t *phases);
 

@@ -204,6 +204,11 @@ int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *ops, uint64_
  * first n_last values of the output layer. ZK_ERR_STATE if a value exceeded 63 bits (the int64 view of the reference would differ). */
 int32_t zk_witness_rerun(zk_ctx *ctx, const uint64_t *picture, uint64_t n_picture, uint64_t *ranges, uint32_t n_ranges,
                          uint64_t *last_layer, uint64_t n_last);
+/* Convolutions whose gate pattern was checked at upload are evaluated from their two tensors, in 64-bit integers when a device-side bound test
+ * shows the sums cannot wrap (quantised activations and weights are small integers), in field arithmetic otherwise; both give the same field
+ * elements. Test hook: out[0] = such convolutions, out[1] = those the last zk_witness_rerun evaluated in integers, out[2] = index in layer 0 of the first one's weights; force_field = 1 / 0 keeps
+ * every convolution in the field / lets the bounds decide from now on, < 0 changes nothing. */
+int32_t zk_witness_conv_paths(zk_ctx *ctx, int32_t force_field, uint64_t out[3]);
 
 /* frees the device copy of layer 0 and the staging buffers of zk_witness_* (the witness is complete) */
 int32_t zk_witness_release(zk_ctx *ctx);

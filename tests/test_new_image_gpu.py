@@ -104,3 +104,31 @@ def test_new_image_full_vgg11(built):
         assert fresh.statement() == stmt
         assert fresh.prove(seed=SEED, mode=REUSE)[1] == tr
     print("new_image ms:", times)
+
+
+@pytest.mark.parametrize("model,pic,pp", [("custom:C4:3:1:s C8:3:1:s M C8:3:1:s F5", (8, 8, 2), 3),
+                                          ("custom:C4:3:0:s C4:5:2:s A F3", (18, 18, 1), 2), MODELS[4]])
+def test_convolutions_in_integers_equal_field_arithmetic(built, model, pic, pp):
+    """new_image evaluates a direct convolution from its two tensors in 64-bit integers when a device-side bound test allows it
+    (witness_kernels.cuh: k_conv_eval_i64), in field arithmetic otherwise: same layer values, hence same transcripts, either way -- also for a
+    weight that is no small integer, which sends exactly that convolution back to the field."""
+    DRIVE = zkcnn_amd.MODE_DRIVE_ONLY
+    with zkcnn_amd.Session(model, pic, pp, data_seed=W, picture_seed=1) as s:
+        p = next(q for q in range(2, 34) if s.new_image(q)[0] == 0)
+        n_conv, n_int, wstart = s.conv_paths()
+        assert n_conv > 0 and n_int == n_conv, "quantised tensors did not take the integer path"
+        res, tr_int = s.prove(seed=SEED, mode=REUSE)
+        assert res.accepted == 1
+        s.conv_paths(force_field=1)
+        assert s.new_image(p)[0] == 0 and s.conv_paths()[1] == 0
+        assert s.prove(seed=SEED, mode=REUSE | DRIVE)[1] == tr_int
+        # an invalid witness on purpose: one weight becomes a field element of ~255 bits. Whatever becomes of the picture (its values no longer
+        # fit anything), the device-side test must have sent exactly that convolution back to field arithmetic
+        s.conv_paths(force_field=0)
+        assert s.new_image(p)[0] == 0 and s.conv_paths()[:2] == (n_conv, n_conv)
+        s.poke(0, wstart, (1, 2, 3, 4))
+        try:
+            s.new_image(p)
+        except RuntimeError:
+            pass
+        assert s.conv_paths()[:2] == (n_conv, n_conv - 1), "the convolution with a wide weight must fall back to field arithmetic"

@@ -329,6 +329,15 @@ class _SessionBase:
         if rc != 0:
             raise RuntimeError(f"{self._prefix}session_poke failed ({rc})")
 
+    def conv_paths(self, force_field=-1):
+        """test hook: (convolutions new_image evaluates from their tensors, those the last new_image ran in 64-bit integers, index in layer 0 of the first one's weights); force_field = 1 / 0
+        keeps them all in field arithmetic / lets the device-side bounds decide from now on"""
+        out = (ctypes.c_uint64 * 3)()
+        rc = self._fn("session_conv_paths")(ctypes.c_void_p(self.h), ctypes.c_int32(force_field), out)
+        if rc != 0:
+            raise RuntimeError(f"{self._prefix}session_conv_paths failed ({rc})")
+        return int(out[0]), int(out[1]), int(out[2])
+
     def row(self):
         buf = ctypes.create_string_buffer(1024)
         self._fn("session_row")(ctypes.c_void_p(self.h), buf, ctypes.c_uint64(1024))

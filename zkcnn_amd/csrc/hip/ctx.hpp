@@ -46,6 +46,7 @@ struct dev_layer {
     gate_rec *ev_dot = nullptr;
     uint32_t *ev_dot_ptr = nullptr;
     bool ev_conv = false;          // the bin gates of this (structured) convolution are evaluated by k_conv_eval, not from a list
+    long long *ev_w64 = nullptr;   // ... and its weights as 64-bit integers (k_conv_eval_i64), inside zk_ctx::wp_w64
     // direct convolution whose gate list matches the structured pattern (zk_upload_circuit_hinted): its two big gate sums are factored
     bool conv_ok = false;
     conv_desc conv;
@@ -201,6 +202,10 @@ struct zk_ctx {
     unsigned long long *h_wp_ranges = nullptr;  // pinned copy
     uint32_t wp_n_ranges = 0;
     fr_t *wp_conv_part = nullptr;               // channel chunks of k_conv_eval
+    long long *wp_in64 = nullptr, *wp_w64 = nullptr;   // integer copies of a convolution's input tensor (per layer, per picture) and of all weights
+    unsigned long long *wp_cb_in = nullptr, *wp_cb_w = nullptr;    // per layer: {largest magnitude, wide flag} of the two (witness_kernels.cuh)
+    bool wp_w64_valid = false;                  // false after layer 0 was written from outside: the weights are converted again
+    int wp_force_field = 0;                     // test hook: convolutions in field arithmetic whatever the bounds say
     void *wp_segments = nullptr;                // one wit_segment per layer (k_last_nonzero)
 
     // profiler: when a class bit is set in prof_mask every launch of that class is bracketed by events

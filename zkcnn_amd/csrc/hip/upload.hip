@@ -592,6 +592,7 @@ extern "C" int32_t zk_upload_layer_values(zk_ctx *ctx, int32_t layer, const uint
     uint64_t last = n;
     while (last && !(values[4 * last - 4] | values[4 * last - 3] | values[4 * last - 2] | values[4 * last - 1])) --last;
     D.val_live = last;
+    if (layer == 0) ctx->wp_w64_valid = false;
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     return ZK_OK;
 }
@@ -604,6 +605,7 @@ extern "C" int32_t zk_poke_layer_value(zk_ctx *ctx, int32_t layer, uint64_t inde
     ZK_HIP(hipMemcpyAsync(D.val + index, value, 32, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     if ((value[0] | value[1] | value[2] | value[3]) && index + 1 > D.val_live) D.val_live = index + 1;      // (an upper bound stays an upper bound)
+    if (layer == 0) ctx->wp_w64_valid = false;
     return ZK_OK;
 }
 

@@ -259,7 +259,8 @@ extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *o
     for (int i = 1; i < n_layers; ++i)
         if (!evaluated[i]) { ctx->err = "witness program does not evaluate every layer"; return ZK_ERR_ARG; }
     // ---- gate lists grouped by output, operands in layer 0 as raw layer-0 indices ----
-    uint64_t max_out = 1, max_blocks = 1, max_conv_part = 0;
+    uint64_t max_out = 1, max_blocks = 1, max_conv_part = 0, max_conv_in = 0, conv_w_total = 0;
+    std::vector<uint64_t> conv_w_off(n_layers, 0);
     for (int i = 1; i < n_layers; ++i) {
         const zk_layer_desc &S = layers[i];
         dev_layer &D = ctx->L[i];
@@ -295,7 +296,15 @@ extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *o
         const bool conv_eval = D.conv_ok;
         std::vector<zk_bin_gate> bin;
         if (!conv_eval) bin.assign(S.bin_gates, S.bin_gates + S.n_bin);
-        else max_conv_part = std::max<uint64_t>(max_conv_part, (uint64_t) conv_eval_chunks(D.conv, n_out) * n_out);
+        else {
+            const conv_desc &c = D.conv;
+            const uint64_t n_in = (uint64_t) c.pp * c.CI * c.nxi * c.nyi, n_w = (uint64_t) c.CO * c.CI * c.m * c.m;
+            if (n_in > ctx->L[i - 1].val_len || c.wstart + n_w > ctx->L[0].val_len) { ctx->err = "witness program: convolution tensors outside their layers"; return ZK_ERR_ARG; }
+            max_conv_part = std::max<uint64_t>(max_conv_part, (uint64_t) conv_eval_chunks(c, n_out) * n_out);
+            max_conv_in = std::max(max_conv_in, n_in);
+            conv_w_off[i] = conv_w_total;
+            conv_w_total += n_w;
+        }
         bool ok = true;
         for (zk_uni_gate &gt : uni) {
             if (gt.lu == 0) { if (gt.u >= S.size_u[0]) { ok = false; break; } gt.u = S.ori_id_u[gt.u]; }
@@ -331,6 +340,14 @@ extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *o
     ctx->wp_n_ops = n_ops;
     ctx->wp_n_windows = n_windows;
     if (max_conv_part && (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_conv_part, max_conv_part * 32))) return rc;
+    if (conv_w_total) {
+        if ((rc = zk_dev_alloc(ctx, (void **) &ctx->wp_in64, max_conv_in * 8)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_w64, conv_w_total * 8)) ||
+            (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_cb_in, 2 * (size_t) n_layers * 8)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_cb_w, 2 * (size_t) n_layers * 8)))
+            return rc;
+        for (int i = 1; i < n_layers; ++i)
+            if (ctx->L[i].ev_conv) ctx->L[i].ev_w64 = ctx->wp_w64 + conv_w_off[i];
+        ctx->wp_w64_valid = false;
+    }
     if ((rc = zk_dev_alloc(ctx, (void **) &ctx->wp_tmp, 2 * max_out * 32)) ||
         (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_carry_val, 2 * max_blocks * 32)) ||
         (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_carry_key, 2 * max_blocks * 4)) ||
@@ -388,6 +405,20 @@ extern "C" int32_t zk_witness_rerun(zk_ctx *ctx, const uint64_t *picture, uint64
     ZK_HIP(hipMemsetAsync(ctx->wp_ranges, 0, wp_words * 8, ctx->stream));
     uint32_t *flags = (uint32_t *) (ctx->wp_ranges + 2 * (size_t) n_ranges);
     uint32_t range_k = 0;
+    if (ctx->wp_w64) {
+        ZK_HIP(hipMemsetAsync(ctx->wp_cb_in, 0, 2 * n_lay * 8, ctx->stream));
+        if (!ctx->wp_w64_valid) {           // first picture, or layer 0 was written from outside since: the weights as integers
+            ZK_HIP(hipMemsetAsync(ctx->wp_cb_w, 0, 2 * n_lay * 8, ctx->stream));
+            for (size_t i = 1; i < n_lay; ++i) {
+                const dev_layer &C = ctx->L[i];
+                if (!C.ev_conv) continue;
+                const uint64_t n_w = (uint64_t) C.conv.CO * C.conv.CI * C.conv.m * C.conv.m;
+                ZK_LAUNCH(PC_MISC, 40.0 * (double) n_w, k_fr_to_i64, dim3(grid_for(n_w)), dim3(ZK_BLOCK), C.ev_w64, (const fr_t *) L0.val + C.conv.wstart, n_w, ctx->wp_cb_w + 2 * i,
+                          C.conv.CO, C.conv.CI * C.conv.m * C.conv.m);
+            }
+            ctx->wp_w64_valid = true;
+        }
+    }
     for (const zk_witness_step &st : ctx->wp_steps) {
         dev_layer &D = ctx->L[st.layer];
         if (st.what == 0) {
@@ -425,8 +456,15 @@ extern "C" int32_t zk_witness_rerun(zk_ctx *ctx, const uint64_t *picture, uint64
                     const conv_desc &c = D.conv;
                     const uint32_t chunks = conv_eval_chunks(c, n_out), per = (c.CI + chunks - 1) / chunks;
                     fr_t *part = chunks == 1 ? dB : ctx->wp_conv_part;
-                    ZK_LAUNCH(PC_GATE, 80.0 * (double) n_out * c.CI * c.m * c.m, k_conv_eval, dim3((uint32_t) ((n_out + ZK_BLOCK - 1) / ZK_BLOCK), chunks), dim3(ZK_BLOCK), part,
-                              (const fr_t *) P.val, (const fr_t *) L0.val + c.wstart, c, per);
+                    // in 64-bit integers when the tensors allow it (decided on the device: witness_kernels.cuh), in the field otherwise
+                    const uint64_t n_in = (uint64_t) c.pp * c.CI * c.nxi * c.nyi;
+                    unsigned long long *cb_in = ctx->wp_cb_in + 2 * (size_t) st.layer, *cb_w = ctx->wp_cb_w + 2 * (size_t) st.layer;
+                    const dim3 cgrid((uint32_t) ((n_out + ZK_BLOCK - 1) / ZK_BLOCK), chunks);
+                    ZK_LAUNCH(PC_MISC, 40.0 * (double) n_in, k_fr_to_i64, dim3(grid_for(n_in)), dim3(ZK_BLOCK), ctx->wp_in64, (const fr_t *) P.val, n_in, cb_in, 0u, 0u);
+                    ZK_LAUNCH(PC_GATE, 16.0 * (double) n_out * c.CI * c.m * c.m, k_conv_eval_i64, cgrid, dim3(ZK_BLOCK), part, (const long long *) ctx->wp_in64,
+                              (const long long *) D.ev_w64, c, per, (const unsigned long long *) cb_in, (const unsigned long long *) cb_w, ctx->wp_force_field);
+                    ZK_LAUNCH(PC_GATE, 0.0, k_conv_eval, cgrid, dim3(ZK_BLOCK), part, (const fr_t *) P.val, (const fr_t *) L0.val + c.wstart, c, per,
+                              (const unsigned long long *) cb_in, (const unsigned long long *) cb_w, ctx->wp_force_field);
                     if (chunks > 1)
                         ZK_LAUNCH(PC_GATE, 0.0, k_sum_rows, dim3((uint32_t) ((n_out + 63) / 64)), dim3(1024), dB, (const fr_t *) part, (uint32_t) n_out, chunks);
                 }
@@ -455,3 +493,27 @@ extern "C" int32_t zk_witness_rerun(zk_ctx *ctx, const uint64_t *picture, uint64
     return ZK_OK;
 }
 
+// Test hook: which arithmetic the structured convolutions of the LAST zk_witness_rerun were evaluated in. out[0] = convolutions evaluated from
+// their tensors, out[1] = of those, the ones that went through k_conv_eval_i64, out[2] = where the first one's weights start in layer 0. force_field >= 0 sets the switch that
+// keeps every convolution in field arithmetic (1) or lets the bounds decide (0) for the following calls; < 0 leaves it alone.
+extern "C" int32_t zk_witness_conv_paths(zk_ctx *ctx, int32_t force_field, uint64_t out[3]) {
+    ZK_CHECK_READY();
+    if (!out) return ZK_ERR_ARG;
+    out[0] = out[1] = out[2] = 0;
+    if (force_field >= 0) ctx->wp_force_field = force_field ? 1 : 0;
+    if (!ctx->wp_ready || !ctx->wp_w64) return ZK_OK;
+    const size_t n_lay = ctx->L.size();
+    std::vector<unsigned long long> cin(2 * n_lay), cw(2 * n_lay);
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_HIP(hipMemcpy(cin.data(), ctx->wp_cb_in, 2 * n_lay * 8, hipMemcpyDeviceToHost));
+    ZK_HIP(hipMemcpy(cw.data(), ctx->wp_cb_w, 2 * n_lay * 8, hipMemcpyDeviceToHost));
+    auto bits = [](unsigned long long x) { int b = 0; while (x) { ++b; x >>= 1; } return b; };
+    for (size_t i = 1; i < n_lay; ++i) {
+        const dev_layer &D = ctx->L[i];
+        if (!D.ev_conv) continue;
+        if (!out[0]++) out[2] = D.conv.wstart;
+        const bool fits = !(cin[2 * i + 1] | cw[2 * i + 1]) && bits(cin[2 * i]) + bits(cw[2 * i]) + bits((unsigned long long) D.conv.CI * D.conv.m * D.conv.m) <= 62;
+        if (fits && ctx->wp_w64_valid && !ctx->wp_force_field) ++out[1];
+    }
+    return ZK_OK;
+}

@@ -95,19 +95,32 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_witness_range(unsigned long long *
     if (any_wide) atomicOr(flags, WIT_FLAG_WIDE);
 }
 
-// out[y] = 1 + index of the last non-zero entry of segment y (0 if it is all zero); out zeroed by the caller. grid (blocks, segments)
+// out[y] = 1 + index of the last non-zero entry of segment y (0 if it is all zero); out zeroed by the caller. grid (blocks, segments).
+// The tables are scanned from their END, a chunk of LNZ_CHUNK entries per block and step; a block stops as soon as somebody has found a non-zero
+// entry behind the chunk it would read next -- a layer's values end close to its size, so a call reads a few chunks per layer, not the tables
+// (the whole tables of vgg11 are 1.2 GB: 0.4 ms of the 2 ms of a new picture).
 struct wit_segment { const fr_t *p; uint64_t n; };
+#define LNZ_CHUNK (4u * ZK_BLOCK)
 __global__ void __launch_bounds__(ZK_BLOCK) k_last_nonzero(unsigned long long *out, const wit_segment *seg) {
     const wit_segment s = seg[blockIdx.y];
-    unsigned long long last = 0;
-    for (uint64_t i = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x; i < s.n; i += (uint64_t) gridDim.x * ZK_BLOCK)
-        if (!fr_is_zero(fr_load(s.p + i))) last = i + 1;
+    const uint64_t chunks = (s.n + LNZ_CHUNK - 1) / LNZ_CHUNK;
+    __shared__ int s_done;
+    for (uint64_t k = blockIdx.x; k < chunks; k += gridDim.x) {              // chunk k counted from the end
+        const uint64_t hi = s.n - k * LNZ_CHUNK, lo = hi > LNZ_CHUNK ? hi - LNZ_CHUNK : 0;
+        if (threadIdx.x == 0) s_done = __hip_atomic_load(out + blockIdx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hi;
+        __syncthreads();
+        if (s_done) return;
+        unsigned long long last = 0;
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += ZK_BLOCK)
+            if (!fr_is_zero(fr_load(s.p + i))) last = i + 1;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long o = __shfl_down(last, d);
-        last = o > last ? o : last;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_down(last, d);
+            last = o > last ? o : last;
+        }
+        if ((threadIdx.x & 63) == 0 && last) atomicMax(out + blockIdx.y, last);
+        __syncthreads();
     }
-    if ((threadIdx.x & 63) == 0 && last) atomicMax(out + blockIdx.y, last);
 }
 
 // ---- witness: value of every gate of a generic layer (reference src/neuralNetwork.cpp:918-935, calcNormalLayer) ----
@@ -227,7 +240,82 @@ __global__ void k_dot_witness(fr_t *out, const fr_t *F, const gate_rec *recs, co
 // out[(p, co, X, Y)] = sum_{ci, dx, dy} in[(p, ci, tx, ty)] * W[(co, ci, dx, dy)], straight from the two tensors instead of from 16-byte gate
 // records with two gathers each (reference src/neuralNetwork.cpp:918-935 walks the gates). grid (ceil(n_out / 256), channel_in chunks);
 // part[chunk * n_out + g] = the chunk's share, summed by k_sum_rows; the bias additions stay on the (short) uni-gate list.
-__global__ void __launch_bounds__(ZK_BLOCK) k_conv_eval(fr_t *part, const fr_t *in, const fr_t *W, conv_desc c, uint32_t per) {
+// ---- the same sums in 64-bit integers ----
+// Activations and weights of a quantised network are small integers that happen to be stored as field elements: a tap is then one 64-bit
+// multiply-add (3 v_mad_u64_u32) instead of a Montgomery product (~130 of them), and the operands are 8 bytes instead of 32. k_fr_to_i64 takes
+// a tensor out of Montgomery form into signed 64-bit integers and records its largest magnitude; the sum of `terms` products is exact in int64
+// when bits(max |in|) + bits(max |w|) + bits(terms) <= 62. The test is made ON THE DEVICE by both kernels of a layer (k_conv_eval_i64 and the
+// field kernel k_conv_eval are launched one after the other, exactly one of them does the work), so nothing waits for the host and a tensor
+// that does not qualify -- a value of more than 63 bits, a sum that could wrap -- is evaluated in the field as before.
+// bound words: cb[0] = largest magnitude, cb[1] = non-zero if some value needs more than 63 bits
+// co_stride != 0: `in` is a weight tensor [co][ci * m * m] and `out` becomes [ci * m * m][co] -- the lanes of k_conv_eval_i64 run over co, so a
+// wave's 64 weights of one tap are then one 512-byte load instead of 64 sectors
+__global__ void __launch_bounds__(ZK_BLOCK) k_fr_to_i64(long long *out, const fr_t *in, uint64_t n, unsigned long long *cb, uint32_t CO, uint32_t per_co) {
+    unsigned long long mx = 0;
+    bool any_wide = false;
+    for (uint64_t i = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x; i < n; i += (uint64_t) gridDim.x * ZK_BLOCK) {
+        bool neg, wide;
+        const uint64_t mag = fr_signed_u64(fr_load(in + i), neg, wide);
+        any_wide |= wide;
+        mx = mag > mx ? mag : mx;
+        const uint64_t o = CO ? (i % per_co) * CO + i / per_co : i;
+        out[o] = neg ? -(long long) mag : (long long) mag;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long a = __shfl_down(mx, d);
+        mx = a > mx ? a : mx;
+    }
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(cb, mx);
+    if (any_wide) atomicOr(cb + 1, 1ull);
+}
+__device__ __forceinline__ bool conv_fits_i64(const unsigned long long *cb_in, const unsigned long long *cb_w, uint32_t terms) {
+    if (cb_in[1] | cb_w[1]) return false;
+    return (64 - __clzll((long long) cb_in[0])) + (64 - __clzll((long long) cb_w[0])) + (32 - __clz((int) terms)) <= 62;
+}
+// x (|x| < 2^63) as a field element in Montgomery form
+__device__ __forceinline__ fr_t fr_from_i64(long long x) {
+    const uint32_t r2[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu, 0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};      // 2^512 mod r
+    const unsigned long long mag = x < 0 ? 0ull - (unsigned long long) x : (unsigned long long) x;
+    fr_t t = fr_zero(), rr;
+    t.v[0] = (uint32_t) mag; t.v[1] = (uint32_t) (mag >> 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rr.v[i] = r2[i];
+    t = fr_mul(t, rr);
+    return x < 0 ? fr_neg(t) : t;
+}
+// k_conv_eval on integer copies of the two tensors (same grid, same chunks of channel_in, same output layout); force_field: test hook
+__global__ void __launch_bounds__(ZK_BLOCK) k_conv_eval_i64(fr_t *part, const long long *in, const long long *W, conv_desc c, uint32_t per,
+                                                            const unsigned long long *cb_in, const unsigned long long *cb_w, int force_field) {
+    if (force_field || !conv_fits_i64(cb_in, cb_w, c.CI * c.m * c.m)) return;
+    const uint64_t n_out = (uint64_t) c.pp * c.CO * c.nxo * c.nyo;
+    const uint64_t t = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x;
+    if (t >= n_out) return;
+    const uint32_t co = (uint32_t) t & (c.CO - 1), pos = (uint32_t) (t >> c.bc_o) & (c.nxo * c.nyo - 1), p = (uint32_t) (t >> (c.bc_o + c.bx_o + c.by_o));
+    const uint32_t Y = pos & (c.nyo - 1), X = pos >> c.by_o;
+    const uint64_t g = (((uint64_t) p * c.CO + co) << (c.bx_o + c.by_o)) | pos;
+    const uint32_t ci0 = blockIdx.y * per, ci1 = min(c.CI, ci0 + per), mm = c.m * c.m;
+    const int32_t x0 = (int32_t) (X << c.ls) - (int32_t) c.pad, y0 = (int32_t) (Y << c.ls) - (int32_t) c.pad;
+    long long acc = 0;
+    for (uint32_t ci = ci0; ci < ci1; ++ci) {
+        const long long *ip = in + ((size_t) p * c.CI + ci) * c.nxi * c.nyi;
+        const long long *wp = W + (size_t) ci * mm * c.CO + co;              // [ci][tap][co]
+        for (uint32_t dx = 0; dx < c.m; ++dx) {
+            const int32_t tx = x0 + (int32_t) dx;
+            if (tx < 0 || tx >= (int32_t) c.nxi) continue;
+            for (uint32_t dy = 0; dy < c.m; ++dy) {
+                const int32_t ty = y0 + (int32_t) dy;
+                if (ty < 0 || ty >= (int32_t) c.nyi) continue;
+                acc += ip[((size_t) tx << c.by_i) + ty] * wp[(size_t) (dx * c.m + dy) * c.CO];
+            }
+        }
+    }
+    fr_store(part + (size_t) blockIdx.y * n_out + g, fr_from_i64(acc));
+}
+
+__global__ void __launch_bounds__(ZK_BLOCK) k_conv_eval(fr_t *part, const fr_t *in, const fr_t *W, conv_desc c, uint32_t per,
+                                                        const unsigned long long *cb_in, const unsigned long long *cb_w, int force_field) {
+    if (!force_field && conv_fits_i64(cb_in, cb_w, c.CI * c.m * c.m)) return;          // k_conv_eval_i64 has written this layer
     const uint64_t n_out = (uint64_t) c.pp * c.CO * c.nxo * c.nyo;
     // lanes run over the output channel, so a wave shares its output position: the border tests are wave-uniform (no lane idles through a
     // neighbour's taps) and the input value is one broadcast load; only the weights differ from lane to lane

@@ -274,6 +274,12 @@ int32_t zkcnn_session_poke(void *session, int32_t layer, uint64_t index, const u
     return zk_poke_layer_value(s->p.context(), layer, index, value) == ZK_OK ? 0 : -2;
 }
 
+int32_t zkcnn_session_conv_paths(void *session, int32_t force_field, uint64_t out[3]) {
+    if (!session || !out) return -1;
+    if (!test_hooks_enabled()) return -4;
+    gpuSession *s = (gpuSession *) session;
+    return zk_witness_conv_paths(s->p.context(), force_field, out) == ZK_OK ? 0 : -2;
+}
 void zkcnn_session_destroy(void *session) { delete (gpuSession *) session; }
 
 int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap) {
