@@ -117,6 +117,8 @@ int32_t zkcnn_session_fs_stats(void *session, uint64_t *rounds, uint64_t *phases
 
 /* Product library only: how many direct-convolution layers of the session's circuit run the factored gate sums (include/zkcnn_hip.h: zk_conv_hint) */
 int32_t zkcnn_session_structured_layers(void *session);
+/* ... and DOT_PROD layers of FFT convolutions over several pictures whose phase-1 table is built in factored form (zk_factored_dot_layers) */
+int32_t zkcnn_session_factored_dot_layers(void *session);
 
 /* Product library only: HIP-event profiler of the GPU kernels (see zk_profile_enable / zk_profile_report in zkcnn_hip.h). */
 int32_t zkcnn_session_profile(void *session, uint32_t class_mask);

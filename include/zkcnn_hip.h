@@ -76,6 +76,9 @@ int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *layers, int32
 int32_t zk_poke_layer_value(zk_ctx *ctx, int32_t layer, uint64_t index, const uint64_t value[4]);
 /* how many layers run the factored path (after an upload) */
 int32_t zk_structured_layers(const zk_ctx *ctx);
+/* DOT_PROD layers (FFT convolutions over pic_cnt >= 2 pictures, channel_out a power of two) whose gate list is the generator's full pattern
+ * (checked gate by gate at upload): their phase-1 table is built in factored form, summed once over channel_out instead of once per picture */
+int32_t zk_factored_dot_layers(const zk_ctx *ctx);
 /* val[layer] (n = layer size); stored zero-padded to 2^bit_length */
 int32_t zk_upload_layer_values(zk_ctx *ctx, int32_t layer, const uint64_t *values, uint64_t n);
 

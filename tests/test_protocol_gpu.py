@@ -48,6 +48,16 @@ def test_gpu_transcript_identical_to_oracle(built, model, pic, pp):
     assert abs(res.proof_kb - ores.proof_kb) < 1e-9 and abs(res.poly_proof_kb - ores.poly_proof_kb) < 1e-9
 
 
+@pytest.mark.parametrize("case,want", [(7, 1), (8, 1), (10, 1), (9, 0), (6, 0)])
+def test_dot_prod_tables_of_several_pictures_in_factored_form(built, case, want):
+    """FFT convolutions over pic_cnt >= 2 pictures with a power-of-two channel_out: the DOT_PROD layer's phase-1 table is beta_hi[p] * S[ci, t]
+    (upload.hip checks the gate pattern; kernels.cuh k_dot_s) -- the transcripts of these circuits are compared with the oracle's above, here:
+    that the factored builder is what ran (3 pictures: pp need not be a power of two; channel_out = 3 or one picture: generic builder)."""
+    model, pic, pp = CASES[case]
+    with zkcnn_amd.Session(model, pic, pp) as s:
+        assert s.factored_dot_layers() == want
+
+
 def test_full_size_vgg11_accepted_and_deterministic(built):
     """BASELINE.json configs[2] at full size (1.16e8 multiplication gates, 2^24 inputs): the verifier -- which checks the sumcheck
     round identity p(0) + p(1) == claim in every one of the 1129 rounds, every layer's wiring predicate and the Hyrax opening --

@@ -401,6 +401,10 @@ class Session(_SessionBase):
         """direct-convolution layers whose gate sums run in factored form (hint checked against the gate list at upload)"""
         return int(self.lib.zkcnn_session_structured_layers(ctypes.c_void_p(self.h)))
 
+    def factored_dot_layers(self):
+        """DOT_PROD layers (FFT convolutions over pic_cnt >= 2 pictures) whose phase-1 table is summed once over channel_out, not once per picture"""
+        return int(self.lib.zkcnn_session_factored_dot_layers(ctypes.c_void_p(self.h)))
+
     def synthetic_picture(self, picture_seed):
         n = self.pic[0] * self.pic[1] * self.pic[2]
         arr = (ctypes.c_double * n)()

@@ -39,6 +39,10 @@ struct dev_layer {
     gate_rec *d1 = nullptr;
     uint32_t *d1_rowptr = nullptr;
     uint32_t d1_rows = 0;
+    // ... whose gates are exactly {(g, u, v) = (p CO + co, p CI + ci, (pp + co) CI + ci)} with CO a power of two and pp >= 2 pictures: the phase-1
+    // table is then beta_hi[p] * S[ci, t], S summed ONCE over co instead of once per picture (sumcheck.hip: zk_sumcheck_dotprod_init_phase1)
+    bool dot_ok = false;
+    uint32_t dot_pp = 0, dot_CO = 0, dot_CI = 0;
     // resident witness program (zk_witness_program_upload): gate lists grouped by output with layer-0 operands as raw layer-0 indices;
     // DOT_PROD: CSR by output vector
     void *ev_uni = nullptr, *ev_bin = nullptr;
@@ -129,6 +133,14 @@ struct zk_ctx {
     const HFr *r_0 = nullptr, *r_1 = nullptr;
     HFr alpha, beta, relu_rou, add_term, V_u0, V_u1;
     HFr small_final;               // collapsed periodic table (DOT_PROD)
+    // the beta_g table an IFFT layer leaves for the DOT_PROD layer below it is alpha * eq(bg_r, .): kept so that the DOT_PROD layer can split it
+    std::vector<HFr> bg_r;
+    HFr bg_alpha;
+    int bg_layer = -1;             // the IFFT layer that built it
+    fr_t *dot_tabs = nullptr;      // beta_lo (4096 entries), beta_hi (4096 entries)
+    fr_t *dot_part = nullptr;      // channel_out chunks of S
+    uint64_t dot_part_cap = 0;
+    uint32_t dot_layers = 0;       // DOT_PROD layers with the factored table (zk_factored_dot_layers)
     uint64_t proof_size = 0;
     int sumcheck_id = 0, round = 0;
     HFr last_poly[3];              // the quadratic the previous round returned (a, b, c): p(0) + p(1) of this round must equal it at the challenge

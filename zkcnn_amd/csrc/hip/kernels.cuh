@@ -539,6 +539,27 @@ __global__ void k_dot_v0(fr_t *V0, const fr_t *F, const fr_t *beta_g, const gate
     }
     fr_store(V0 + (((size_t) u) << fft_bl) + t, acc);
 }
+// The same table for a layer whose gates are the full pattern (g, u, v) = (p CO + co, p CI + ci, (pp + co) CI + ci), CO = 2^k, over pp pictures:
+// beta_g[p CO + co] = beta_hi[p] beta_lo[co] (an eq table is a product over the bits of its index), so
+//     V0[(p CI + ci, t)] = beta_hi[p] * S[ci, t],   S[ci, t] = sum_co beta_lo[co] F[((pp + co) CI + ci, t)]
+// and S is summed once instead of once per picture: CO CI 2^fb + pp CI 2^fb products instead of pp CO CI 2^fb.
+// k_dot_s: grid (t tiles, CI, chunks of co): part[(chunk CI + ci) << fb | t]; k_dot_v0s: grid (t tiles, CI) adds the chunks and writes the pp rows.
+__global__ void __launch_bounds__(ZK_BLOCK) k_dot_s(fr_t *part, const fr_t *F, const fr_t *beta_lo, uint32_t pp, uint32_t CO, uint32_t CI, uint32_t per, int fft_bl) {
+    const uint32_t t = blockIdx.x * ZK_BLOCK + threadIdx.x, ci = blockIdx.y;
+    if (t >= (1u << fft_bl)) return;
+    const uint32_t co0 = blockIdx.z * per, co1 = min(CO, co0 + per);
+    fr_t acc = fr_zero();
+    for (uint32_t co = co0; co < co1; ++co)
+        acc = fr_add(acc, fr_mul(fr_load(beta_lo + co), fr_load(F + (((size_t) (pp + co) * CI + ci) << fft_bl) + t)));
+    fr_store(part + (((size_t) blockIdx.z * CI + ci) << fft_bl) + t, acc);
+}
+__global__ void __launch_bounds__(ZK_BLOCK) k_dot_v0s(fr_t *V0, const fr_t *part, const fr_t *beta_hi, uint32_t pp, uint32_t CI, uint32_t chunks, int fft_bl) {
+    const uint32_t t = blockIdx.x * ZK_BLOCK + threadIdx.x, ci = blockIdx.y;
+    if (t >= (1u << fft_bl)) return;
+    fr_t s = fr_load(part + ((size_t) ci << fft_bl) + t);
+    for (uint32_t c = 1; c < chunks; ++c) s = fr_add(s, fr_load(part + (((size_t) c * CI + ci) << fft_bl) + t));
+    for (uint32_t p = 0; p < pp; ++p) fr_store(V0 + (((size_t) p * CI + ci) << fft_bl) + t, fr_mul(fr_load(beta_hi + p), s));
+}
 // one wave per row v
 __global__ void __launch_bounds__(ZK_BLOCK) k_row_dot(fr_t *out, const fr_t *F, const fr_t *w, uint32_t rows, int fft_bl) {
     const uint32_t v = blockIdx.x * (ZK_BLOCK / 64) + (threadIdx.x >> 6);

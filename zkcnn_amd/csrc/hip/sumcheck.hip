@@ -460,7 +460,12 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
         const uint32_t cnt_len = d.size >> (fwd ? fft_bl : fft_blh);
         fr_t *bg = ctx->beta_g[ctx->beta_g_cur];
         if (fwd) P.eq(bg, cnt_bl, ctx->r_0 + fft_bl, ctx->alpha, ctx->r_1, ctx->beta, ~0ull, HFr::one());
-        else P.eq1(bg, cnt_bl, ctx->r_0 + fft_blh, ctx->alpha);
+        else {
+            P.eq1(bg, cnt_bl, ctx->r_0 + fft_blh, ctx->alpha);
+            ctx->bg_r.assign(ctx->r_0 + fft_blh, ctx->r_0 + fft_blh + cnt_bl);     // (the DOT_PROD layer below splits this table: dotprod_init_phase1)
+            ctx->bg_alpha = ctx->alpha;
+            ctx->bg_layer = id;
+        }
         if ((rc = P.launch(ctx))) return rc;
         table_pair &t = ctx->tp[1];
         const uint32_t len = (uint32_t) t.len;
@@ -544,11 +549,43 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
     prep_plan P(ctx);
     P.eq1(ctx->small[0], fft_bl, ctx->r_0, HFr::one());
     load_v_table(ctx, P, ctx->tp[1], 1, d.bit_length_u[1], d.size_u[1], nullptr, prev);
-    // (k_dot_v0 writes the rows that have gates; the rest of V0 is zero)
-    const uint64_t covered = (uint64_t) cur.d1_rows << fft_bl;
+    // the factored table (kernels.cuh: k_dot_s): the beta_g table in place is the one the IFFT layer above left, alpha * eq(bg_r, .)
+    int k_lo = 0;
+    while ((1u << k_lo) < cur.dot_CO) ++k_lo;
+    const bool factored = cur.dot_ok && ctx->bg_layer == id + 1 && (int) ctx->bg_r.size() >= k_lo && (ctx->bg_r.size() - k_lo) <= 12 &&
+                          ((uint64_t) cur.dot_pp - 1) >> (ctx->bg_r.size() - k_lo) == 0;
+    // (k_dot_v0 writes the rows that have gates, the factored kernels the pictures' rows; the rest of V0 is zero)
+    const uint64_t covered = (uint64_t) (factored ? cur.dot_pp * cur.dot_CI : cur.d1_rows) << fft_bl;
     if (covered < N) P.zero(ctx->tp[0].V[0] + covered, N - covered);
     if ((rc = P.launch(ctx))) return rc;
-    if (cur.d1_rows) {
+    if (factored) {
+        const uint32_t pp = cur.dot_pp, CO = cur.dot_CO, CI = cur.dot_CI, len = 1u << fft_bl;
+        // chunks of channel_out so that a launch has ~2^18 threads even where the transforms are short
+        const uint32_t want = (uint32_t) std::max<uint64_t>(1, (1ull << 18) / ((uint64_t) CI * len));
+        const uint32_t per = std::max<uint32_t>(8, (CO + want - 1) / want), chunks = (CO + per - 1) / per;
+        if (!ctx->dot_tabs && (rc = zk_dev_alloc(ctx, (void **) &ctx->dot_tabs, 2 * 4096 * sizeof(fr_t)))) return rc;
+        if (!ctx->dot_part) {                 // the largest any DOT_PROD layer of this circuit asks for: one allocation per session
+            uint64_t cap = 1;
+            for (const dev_layer &D : ctx->L)
+                if (D.dot_ok) {
+                    const uint64_t l = 1ull << D.d.fft_bit_length, w = std::max<uint64_t>(1, (1ull << 18) / ((uint64_t) D.dot_CI * l));
+                    const uint64_t pr = std::max<uint64_t>(8, (D.dot_CO + w - 1) / w);
+                    cap = std::max(cap, ((D.dot_CO + pr - 1) / pr) * D.dot_CI * l);
+                }
+            if ((rc = zk_dev_alloc(ctx, (void **) &ctx->dot_part, cap * sizeof(fr_t)))) return rc;
+            ctx->dot_part_cap = cap;
+        }
+        if ((uint64_t) chunks * CI * len > ctx->dot_part_cap) { ctx->err = "DOT_PROD partial sums larger than planned"; return ZK_ERR_STATE; }
+        prep_plan P2(ctx);
+        fr_t *lo = ctx->dot_tabs, *hi = ctx->dot_tabs + 4096;
+        P2.eq1(lo, k_lo, ctx->bg_r.data(), HFr::one());
+        P2.eq1(hi, (int) ctx->bg_r.size() - k_lo, ctx->bg_r.data() + k_lo, ctx->bg_alpha);
+        if ((rc = P2.launch(ctx))) return rc;
+        const uint32_t tiles = (len + ZK_BLOCK - 1) / ZK_BLOCK;
+        ZK_LAUNCH(PC_DOT, 0.0, k_dot_s, dim3(tiles, CI, chunks), dim3(ZK_BLOCK), ctx->dot_part, (const fr_t *) prev.val, (const fr_t *) lo, pp, CO, CI, per, fft_bl);
+        ZK_LAUNCH(PC_DOT, 0.0, k_dot_v0s, dim3(tiles, CI), dim3(ZK_BLOCK), ctx->tp[0].V[0], (const fr_t *) ctx->dot_part, (const fr_t *) hi, pp, CI, chunks, fft_bl);
+        ZK_HIP(hipGetLastError());
+    } else if (cur.d1_rows) {
         dim3 grid(((1u << fft_bl) + ZK_BLOCK - 1) / ZK_BLOCK, cur.d1_rows);
         ZK_LAUNCH(PC_DOT, 0.0, k_dot_v0, grid, dim3(ZK_BLOCK), ctx->tp[0].V[0], prev.val, ctx->beta_g[ctx->beta_g_cur], cur.d1, cur.d1_rowptr, fft_bl);
         ZK_HIP(hipGetLastError());

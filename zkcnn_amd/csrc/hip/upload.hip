@@ -166,6 +166,7 @@ static bool conv_infer(const zk_layer_desc &S, const zk_layer_desc &P, int layer
 }
 
 extern "C" int32_t zk_structured_layers(const zk_ctx *ctx) { return ctx ? (int32_t) ctx->conv_layers : 0; }
+extern "C" int32_t zk_factored_dot_layers(const zk_ctx *ctx) { return ctx ? (int32_t) ctx->dot_layers : 0; }
 
 extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul,
                                      int32_t n_two_mul) {
@@ -314,6 +315,8 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
     }
     if (rc == ZK_OK) rc = alloc_session(ctx);
     if (rc != ZK_OK) { zk_circuit_release(ctx); return rc; }
+    ctx->dot_layers = 0;
+    for (const dev_layer &D : ctx->L) ctx->dot_layers += D.dot_ok ? 1 : 0;
     ctx->circuit_ready = true;
     return ZK_OK;
 }
@@ -431,6 +434,32 @@ static int32_t build_static(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_
             for (const gate_rec &r : d) ++ptr[r.key + 1];
             for (uint32_t k = 0; k < rows; ++k) ptr[k + 1] += ptr[k];
             D.d1_rows = rows;
+            // the generator's pattern (host/neuralNetwork.cpp emitDotProd; reference src/neuralNetwork.cpp dotProdLayer): checked gate by gate, every
+            // triple exactly once -- a list that deviates anywhere keeps the generic table builder
+            {
+                const uint64_t G = S.n_bin, out_vecs = S.size >> S.fft_bit_length;
+                uint64_t CI = 0, vmin = ~0ull;
+                for (uint64_t k = 0; k < G; ++k) {
+                    if (S.bin_gates[k].g == 0) ++CI;
+                    vmin = std::min<uint64_t>(vmin, S.bin_gates[k].v);
+                }
+                const uint64_t pp = CI ? vmin / CI : 0, CO = pp ? out_vecs / pp : 0;
+                bool ok = CI && pp >= 2 && CO >= 2 && (CO & (CO - 1)) == 0 && CO <= 4096 && pp * CO == out_vecs && vmin == pp * CI && pp * CO * CI == G &&
+                          (pp + CO) * CI <= rows && G < (1ull << 32);
+                if (ok) {
+                    std::vector<uint8_t> seen((G + 7) / 8, 0);
+                    for (uint64_t k = 0; k < G && ok; ++k) {
+                        const zk_bin_gate &g = S.bin_gates[k];
+                        const uint64_t p = g.g / CO, co = g.g % CO;
+                        if (p >= pp || g.u < p * CI || g.u >= (p + 1) * CI) { ok = false; break; }
+                        const uint64_t ci = g.u - p * CI, id = (p * CO + co) * CI + ci;
+                        if (g.v != (pp + co) * CI + ci || (seen[id >> 3] >> (id & 7)) & 1) { ok = false; break; }
+                        seen[id >> 3] |= (uint8_t) (1u << (id & 7));
+                    }
+                }
+                D.dot_ok = ok;
+                if (ok) { D.dot_pp = (uint32_t) pp; D.dot_CO = (uint32_t) CO; D.dot_CI = (uint32_t) CI; }
+            }
             if ((rc = zk_upload(ctx, &D.d1, d)) || (rc = zk_upload(ctx, &D.d1_rowptr, ptr))) return rc;
             continue;
         }

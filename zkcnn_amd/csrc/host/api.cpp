@@ -298,6 +298,10 @@ int32_t zkcnn_session_structured_layers(void *session) {
     if (!session) return -1;
     return ((gpuSession *) session)->p.structuredLayers();
 }
+int32_t zkcnn_session_factored_dot_layers(void *session) {
+    if (!session) return -1;
+    return ((gpuSession *) session)->p.factoredDotLayers();
+}
 
 int32_t zkcnn_session_profile(void *session, uint32_t class_mask) {
     if (!session) return -1;
