@@ -132,7 +132,12 @@ struct zk_ctx {
     std::vector<std::vector<HFr>> r_u, r_v;
     const HFr *r_0 = nullptr, *r_1 = nullptr;
     HFr alpha, beta, relu_rou, add_term, V_u0, V_u1;
-    HFr small_final;               // collapsed periodic table (DOT_PROD)
+    HFr small_final;               // collapsed periodic table (DOT_PROD): the scalar m of the rounds behind the transform's variables
+    bool small_final_valid = false;
+    // DOT_PROD phase 1 behind the collapse: sum X Y m is a QUADRATIC sumcheck of the pair (V = Y, M = X) times the scalar m -- its rounds go through
+    // quad_round (resident kernels, latency kernel) with pair 1's M pointers borrowed from pair 0's V buffers until the phase is finalized
+    bool dot_quad = false;
+    fr_t *dot_saved_M[2] = {nullptr, nullptr};
     // the beta_g table an IFFT layer leaves for the DOT_PROD layer below it is alpha * eq(bg_r, .): kept so that the DOT_PROD layer can split it
     std::vector<HFr> bg_r;
     HFr bg_alpha;
@@ -276,7 +281,7 @@ static inline uint32_t grid_for(uint64_t work, uint32_t cap = 2048) {
 // sort, pattern checks, the registry of resident circuits), sumcheck.hip (the prover's state machine and its kernels), witness.hip (witness
 // generation on the GPU), verifier.hip (the verifier's wiring predicates), hyrax.hip (commitment) ----
 #define ZK_CHECK_READY_ROUND() do { if (!ctx || !ctx->circuit_ready) return ZK_ERR_STATE; ZK_HIP(hipSetDevice(ctx->device)); } while (0)
-// every entry point but the three round calls first sends a resident round kernel home (its phase was abandoned)
+// every entry point but the four round calls first sends a resident round kernel home (its phase was abandoned)
 #define ZK_CHECK_READY() do { ZK_CHECK_READY_ROUND(); if (ctx->live_active) { int32_t rc_ = zk_live_abort(ctx); if (rc_) return rc_; } } while (0)
 #define ZK_CHECK_CTX() do { if (!ctx) return ZK_ERR_ARG; ZK_HIP(hipSetDevice(ctx->device)); if (ctx->live_active) { int32_t rc_ = zk_live_abort(ctx); if (rc_) return rc_; } } while (0)
 static inline const HFr &H(const uint64_t *p) { return *reinterpret_cast<const HFr *>(p); }

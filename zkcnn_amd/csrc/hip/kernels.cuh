@@ -418,6 +418,9 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, cons
     const uint32_t mpairs = ls >> 1;
     if (Ms_raw && blockIdx.x == 0)
         for (uint32_t j = threadIdx.x; j < ls; j += ZK_BLOCK) fr_store(Ms_out + j, cubic_ms(Ms, Ms_raw, j, r));
+    // the round in which the periodic table collapses hands the scalar to the host as well (acknowledged before this block's ticket / the slot's
+    // sequence number): the following rounds are quadratic in X and Y and leave through the quadratic round kernels (sumcheck.hip)
+    if (Ms_raw && ls == 1 && blockIdx.x == 0 && threadIdx.x == 0) fr_store_scoped(&slot->v[4], cubic_ms(Ms, Ms_raw, 0, r), true);
     // The periodic factor depends on the pair only through p mod mpairs. When the grid stride is a multiple of mpairs, all pairs
     // of a thread share it: the thread accumulates the QUADRATIC sum_p X_p(t) Y_p(t) (3 products per pair) and multiplies by its
     // one periodic factor at the end -- 7 products per pair instead of 13.

@@ -233,6 +233,11 @@ static void load_v_table(zk_ctx *ctx, prep_plan &P, table_pair &t, int b, int bl
 
 static void reset_pairs(zk_ctx *ctx, int bl0, int bl1) {
     const int bl[2] = {bl0, bl1};
+    if (ctx->dot_quad) {               // (a DOT_PROD phase that was abandoned behind its hand-over: pair 1 gets its own M buffers back)
+        ctx->tp[1].M[0] = ctx->dot_saved_M[0];
+        ctx->tp[1].M[1] = ctx->dot_saved_M[1];
+        ctx->dot_quad = false;
+    }
     for (int b = 0; b < 2; ++b) {
         ctx->tp[b].cur = 0;
         ctx->tp[b].tail_valid = false;
@@ -538,7 +543,10 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
     const int fft_bl = d.fft_bit_length;
     reset_pairs(ctx, d.bit_length_u[1], d.bit_length_u[1]);       // V0 and V1 both span the whole FFT layer
     ctx->r_u[id].assign(d.max_bl_u, HFr(0LL));
-    ctx->phase_rounds = 0;                  // cubic rounds are always driven from the host
+    ctx->phase_rounds = d.bit_length_u[1];  // (the rounds behind the periodic table's collapse go through quad_round: it counts them)
+    ctx->small_final_valid = false;
+    ctx->add_term.clear();
+    ctx->add_pending = false;
     ctx->tail_active = false;
     ctx->host_tail_active = false;
     ctx->last_poly_valid = false;
@@ -593,12 +601,38 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
     return ZK_OK;
 }
 
+static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]);
+
 extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t out_abcd[16]) {
-    CHECK_READY();
+    CHECK_READY_ROUND();
     const int id = ctx->sumcheck_id;
     const HFr r = H(prev_r);
     const bool first = ctx->round == 0;
     if (!first) ctx->r_u[id].at(ctx->round - 1) = r;
+    // Behind the collapse of the periodic table the sum is X Y m with a scalar m the host knows: a quadratic sumcheck of the pair (V = Y, M = X),
+    // its polynomial times m, cubic coefficient zero (reference src/prover.cpp:103-144 keeps multiplying by the folded 1-entry table). Those rounds
+    // -- all rounds on at most (pictures + channel_out) channel_in entries -- take the quadratic path: resident kernels for a lone proof, the
+    // latency kernel otherwise. (Not with the device-side Fiat-Shamir chain: it would hash the unscaled three coefficients.)
+    if (!ctx->dot_quad && !first && ctx->small_len == 1 && ctx->small_final_valid && !ctx->fs_state && ctx->tp[1].len >= 4 && ctx->tp[0].len == ctx->tp[1].len) {
+        table_pair &x = ctx->tp[0], &y = ctx->tp[1];
+        ctx->dot_saved_M[0] = y.M[0];
+        ctx->dot_saved_M[1] = y.M[1];
+        y.M[y.cur] = x.V[x.cur];
+        y.M[y.cur ^ 1] = x.V[x.cur ^ 1];
+        y.live = y.len;
+        y.tail_valid = false;
+        x.len = 0;
+        ctx->dot_quad = true;
+        ctx->last_poly_valid = false;
+    }
+    if (ctx->dot_quad) {
+        uint64_t abc[12];
+        int32_t rc = quad_round(ctx, r, false, abc);
+        if (rc) return rc;
+        put(out_abcd, HFr(0LL));
+        for (int k = 0; k < 3; ++k) put(out_abcd + 4 * (k + 1), H(abc + 4 * k) * ctx->small_final);
+        return ZK_OK;
+    }
     ++ctx->round;
     // the periodic table is folded INSIDE the round kernel (entry i = lerp of the unfolded pair, taken on the fly; block 0 stores the folded table
     // for the next round): one launch per cubic round instead of two
@@ -628,6 +662,7 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
     int32_t rc = wait_slot(ctx, seq);
     if (rc) return rc;
     for (int k = 0; k < 4; ++k) ctx->h_result[k] = ctx->h_slot->v[k];
+    if (ms_raw && ctx->small_len == 1) { ctx->small_final = ctx->h_slot->v[4]; ctx->small_final_valid = true; }
     for (int k = 0; k < 4; ++k) put(out_abcd + 4 * k, ctx->h_result[k]);
     ctx->proof_size += 32 * (3 + (ctx->h_result[0].isZero() ? 0 : 1));
     return ZK_OK;
@@ -641,6 +676,20 @@ extern "C" int32_t zk_sumcheck_dotprod_finalize1(zk_ctx *ctx, const uint64_t pre
     ctx->r_u[id].at(ctx->round - 1) = r;
     table_pair &t1 = ctx->tp[1];
     int32_t rc;
+    if (ctx->dot_quad) {               // the phase is over: pair 1 gets its own M buffers back
+        t1.M[0] = ctx->dot_saved_M[0];
+        t1.M[1] = ctx->dot_saved_M[1];
+        ctx->dot_quad = false;
+        if (t1.len == 2 && t1.tail_valid && ctx->small_len == 1) {          // Y's last pair came along with the last round: O(1) on the host
+            ctx->h_result[0] = t1.tail_v[0] + r * (t1.tail_v[1] - t1.tail_v[0]);
+            ctx->h_result[1] = ctx->small_final;
+            t1.len = 0;
+            put(claim_1, ctx->h_result[0]);
+            ctx->V_u1 = ctx->h_result[0] * ctx->h_result[1];
+            ctx->proof_size += 32;
+            return ZK_OK;
+        }
+    }
     eval_args E;
     std::memset(&E, 0, sizeof(E));
     E.p[0] = vin(t1); E.n[0] = (uint32_t) std::min<uint64_t>(t1.len, 2);
