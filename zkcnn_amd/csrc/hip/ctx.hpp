@@ -39,6 +39,7 @@ struct dev_layer {
     gate_rec *d1 = nullptr;
     uint32_t *d1_rowptr = nullptr;
     uint32_t d1_rows = 0;
+    uint32_t d1_live_rows = 0;     // 1 + the last row that has a gate: the phase-1 table is zero behind it (never built, never read: k_round_cubic's x_live)
     // ... whose gates are exactly {(g, u, v) = (p CO + co, p CI + ci, (pp + co) CI + ci)} with CO a power of two and pp >= 2 pictures: the phase-1
     // table is then beta_hi[p] * S[ci, t], S summed ONCE over co instead of once per picture (sumcheck.hip: zk_sumcheck_dotprod_init_phase1)
     bool dot_ok = false;

@@ -409,12 +409,15 @@ __device__ __forceinline__ fr_t cubic_ms(const fr_t *Ms, const fr_t *Ms_raw, uin
 __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, const fr_t *V1in, fr_t *V0out, fr_t *V1out,
                                                           const fr_t *Ms, uint32_t ls, uint64_t n, fr_t r, int first,
                                                           fr_t *partials, uint32_t *counter, host_slot *slot,
-                                                          unsigned long long seq, const fr_t *Ms_raw, fr_t *Ms_out) {
+                                                          unsigned long long seq, const fr_t *Ms_raw, fr_t *Ms_out, uint64_t x_live, int fill) {
     ZK_LATENCY_PRIO();
     __shared__ fr_t smem[4 * ZK_BLOCK / 64];
     fr_t acc[4] = {fr_zero(), fr_zero(), fr_zero(), fr_zero()};      // c3, c2, c1, c0
     const uint64_t tid = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x, stride = (uint64_t) gridDim.x * ZK_BLOCK;
     const uint64_t npairs = first ? n / 2 : n / 4;
+    // X (V0) is zero from entry x_live on -- the rows of the weight vectors, which have no gate: most of the table. Pairs behind it add nothing to the
+    // sums; only Y is folded there (2 of the 7 products, half the traffic), and X's output is left alone, or zeroed once the tables are small (fill)
+    const uint64_t pl = min(npairs, first ? (x_live + 1) / 2 : (x_live + 3) / 4);
     const uint32_t mpairs = ls >> 1;
     if (Ms_raw && blockIdx.x == 0)
         for (uint32_t j = threadIdx.x; j < ls; j += ZK_BLOCK) fr_store(Ms_out + j, cubic_ms(Ms, Ms_raw, j, r));
@@ -426,7 +429,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, cons
     // one periodic factor at the end -- 7 products per pair instead of 13.
     if (mpairs == 0 || stride % mpairs == 0) {
         fr_t s00 = fr_zero(), s11 = fr_zero(), sdd = fr_zero();     // sum x0 y0, sum x1 y1, sum dx dy
-        for (uint64_t p = tid; p < npairs; p += stride) {
+        for (uint64_t p = tid; p < pl; p += stride) {
             fr_t x0, x1, y0, y1;
             if (first) {
                 x0 = fr_load(V0in + 2 * p); x1 = fr_load(V0in + 2 * p + 1);
@@ -443,7 +446,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, cons
             s00 = fr_add(s00, fr_mul(x0, y0));
             s11 = fr_add(s11, fr_mul(x1, y1));
         }
-        if (tid < npairs) {
+        if (tid < pl) {
             fr_t m0, dm;
             if (mpairs) {
                 const uint32_t mi = (uint32_t) (tid & (mpairs - 1));
@@ -460,7 +463,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, cons
             acc[3] = fr_mul(s00, m0);
         }
     } else
-    for (uint64_t p = tid; p < npairs; p += stride) {
+    for (uint64_t p = tid; p < pl; p += stride) {
         fr_t x0, x1, y0, y1;
         if (first) {
             x0 = fr_load(V0in + 2 * p); x1 = fr_load(V0in + 2 * p + 1);
@@ -490,6 +493,12 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, cons
         acc[2] = fr_add(acc[2], fr_add(fr_mul(q1, m0), fr_mul(q0, dm)));
         acc[3] = fr_add(acc[3], fr_mul(q0, m0));
     }
+    if (!first)
+        for (uint64_t p = pl + tid; p < npairs; p += stride) {
+            fr_store(V1out + 2 * p, fr_lerp(fr_load(V1in + 4 * p), fr_load(V1in + 4 * p + 1), r));
+            fr_store(V1out + 2 * p + 1, fr_lerp(fr_load(V1in + 4 * p + 2), fr_load(V1in + 4 * p + 3), r));
+            if (fill) { fr_store(V0out + 2 * p, fr_zero()); fr_store(V0out + 2 * p + 1, fr_zero()); }
+        }
     fr_block_sum<4>(acc, smem);
     __syncthreads();
     grid_finish<4>(acc, partials, counter, slot, seq, smem);

@@ -562,9 +562,11 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
     while ((1u << k_lo) < cur.dot_CO) ++k_lo;
     const bool factored = cur.dot_ok && ctx->bg_layer == id + 1 && (int) ctx->bg_r.size() >= k_lo && (ctx->bg_r.size() - k_lo) <= 12 &&
                           ((uint64_t) cur.dot_pp - 1) >> (ctx->bg_r.size() - k_lo) == 0;
-    // (k_dot_v0 writes the rows that have gates, the factored kernels the pictures' rows; the rest of V0 is zero)
-    const uint64_t covered = (uint64_t) (factored ? cur.dot_pp * cur.dot_CI : cur.d1_rows) << fft_bl;
-    if (covered < N) P.zero(ctx->tp[0].V[0] + covered, N - covered);
+    // k_dot_v0 writes the rows up to the last one that has a gate, the factored kernels the pictures' rows. The rest of V0 -- the rows of the
+    // weight vectors: (channel_out / (pictures + channel_out)) of the table -- is zero and is neither written nor read: the round kernel gets
+    // the live prefix (k_round_cubic: x_live) and folds only Y behind it
+    const uint64_t covered = std::min<uint64_t>(N, (uint64_t) (factored ? cur.dot_pp * cur.dot_CI : cur.d1_live_rows) << fft_bl);
+    ctx->tp[0].live = covered;
     if ((rc = P.launch(ctx))) return rc;
     if (factored) {
         const uint32_t pp = cur.dot_pp, CO = cur.dot_CO, CI = cur.dot_CI, len = 1u << fft_bl;
@@ -593,8 +595,8 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
         ZK_LAUNCH(PC_DOT, 0.0, k_dot_s, dim3(tiles, CI, chunks), dim3(ZK_BLOCK), ctx->dot_part, (const fr_t *) prev.val, (const fr_t *) lo, pp, CO, CI, per, fft_bl);
         ZK_LAUNCH(PC_DOT, 0.0, k_dot_v0s, dim3(tiles, CI), dim3(ZK_BLOCK), ctx->tp[0].V[0], (const fr_t *) ctx->dot_part, (const fr_t *) hi, pp, CI, chunks, fft_bl);
         ZK_HIP(hipGetLastError());
-    } else if (cur.d1_rows) {
-        dim3 grid(((1u << fft_bl) + ZK_BLOCK - 1) / ZK_BLOCK, cur.d1_rows);
+    } else if (cur.d1_live_rows) {
+        dim3 grid(((1u << fft_bl) + ZK_BLOCK - 1) / ZK_BLOCK, cur.d1_live_rows);
         ZK_LAUNCH(PC_DOT, 0.0, k_dot_v0, grid, dim3(ZK_BLOCK), ctx->tp[0].V[0], prev.val, ctx->beta_g[ctx->beta_g_cur], cur.d1, cur.d1_rowptr, fft_bl);
         ZK_HIP(hipGetLastError());
     }
@@ -613,7 +615,8 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
     // its polynomial times m, cubic coefficient zero (reference src/prover.cpp:103-144 keeps multiplying by the folded 1-entry table). Those rounds
     // -- all rounds on at most (pictures + channel_out) channel_in entries -- take the quadratic path: resident kernels for a lone proof, the
     // latency kernel otherwise. (Not with the device-side Fiat-Shamir chain: it would hash the unscaled three coefficients.)
-    if (!ctx->dot_quad && !first && ctx->small_len == 1 && ctx->small_final_valid && !ctx->fs_state && ctx->tp[1].len >= 4 && ctx->tp[0].len == ctx->tp[1].len) {
+    if (!ctx->dot_quad && !first && ctx->small_len == 1 && ctx->small_final_valid && !ctx->fs_state && ctx->tp[1].len >= 4 && ctx->tp[0].len == ctx->tp[1].len &&
+        ctx->tp[0].live >= ctx->tp[0].len) {
         table_pair &x = ctx->tp[0], &y = ctx->tp[1];
         ctx->dot_saved_M[0] = y.M[0];
         ctx->dot_saved_M[1] = y.M[1];
@@ -650,14 +653,18 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
     if (npairs == 0) return ZK_ERR_STATE;
     const uint32_t g = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks);
     const unsigned long long seq = ++ctx->slot_seq;
-    ZK_LAUNCH(PC_ROUND_CUBIC, (first ? 64.0 : 96.0) * (double) n, k_round_cubic, dim3(g), dim3(ZK_BLOCK), t0.V[t0.cur], vin(t1),
+    // X's live prefix (entries, pre-fold); once the folded tables are small the zeros behind it are written out (the quadratic rounds read whole tables)
+    const uint64_t x_live = std::min<uint64_t>(t0.live, n);
+    const int fill = (!first && n / 2 <= (1ull << 20)) ? 1 : 0;
+    ZK_LAUNCH(PC_ROUND_CUBIC, (first ? 32.0 : 48.0) * (double) (n + x_live), k_round_cubic, dim3(g), dim3(ZK_BLOCK), t0.V[t0.cur], vin(t1),
               t0.V[t0.cur ^ 1], t1.V[t1.cur ^ 1], (const fr_t *) ctx->small[ctx->small_cur], ctx->small_len, n, to_dev(r), first ? 1 : 0, ctx->partials,
-              ctx->d_counter, (host_slot *) ctx->d_slot, seq, ms_raw, ms_out);
+              ctx->d_counter, (host_slot *) ctx->d_slot, seq, ms_raw, ms_out, x_live, fill);
     ZK_HIP(hipGetLastError());
     if (!first) {
         t0.cur ^= 1; t1.cur ^= 1;
         t0.len >>= 1; t1.len >>= 1;
         t1.Vsrc = nullptr;
+        t0.live = fill ? t0.len : std::min<uint64_t>(t0.len, 2 * ((x_live + 3) / 4));
     }
     int32_t rc = wait_slot(ctx, seq);
     if (rc) return rc;

@@ -434,6 +434,8 @@ static int32_t build_static(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_
             for (const gate_rec &r : d) ++ptr[r.key + 1];
             for (uint32_t k = 0; k < rows; ++k) ptr[k + 1] += ptr[k];
             D.d1_rows = rows;
+            D.d1_live_rows = 0;
+            for (const gate_rec &r : d) D.d1_live_rows = std::max<uint32_t>(D.d1_live_rows, r.key + 1);
             // the generator's pattern (host/neuralNetwork.cpp emitDotProd; reference src/neuralNetwork.cpp dotProdLayer): checked gate by gate, every
             // triple exactly once -- a list that deviates anywhere keeps the generic table builder
             {
