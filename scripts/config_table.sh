@@ -5,7 +5,7 @@ TAG=${1:-configs}
 OUT=$ROOT/gpurun_out/${TAG}_configs.jsonl
 mkdir -p $ROOT/gpurun_out; : > $OUT
 cd $ROOT
-for spec in "lenet 1" "lenet 8" "vgg11 1" "vgg11 8" "vgg16 1" "vgg16 8" "vgg11_pp8 1" "vgg16_pp4 1"; do
+for spec in "lenet 1" "lenet 8" "vgg11 1" "vgg11 8" "vgg16 1" "vgg16 8" "vgg11_pp8 1" "vgg11_pp8 8" "vgg16_pp4 1" "vgg16_pp4 8"; do
   set -- $spec
   timeout 900 python bench.py --workload $1 --streams $2 --steps 5 --warmup 2 --no-cpu-baseline --no-companions 2>/dev/null | tail -1 >> $OUT
 done
