@@ -493,11 +493,11 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, cons
         acc[2] = fr_add(acc[2], fr_add(fr_mul(q1, m0), fr_mul(q0, dm)));
         acc[3] = fr_add(acc[3], fr_mul(q0, m0));
     }
-    if (!first)
+    if (!first && !(fill & 2))            // (fill & 2: a streaming k_fold launch ahead of this one has folded Y behind the live prefix)
         for (uint64_t p = pl + tid; p < npairs; p += stride) {
             fr_store(V1out + 2 * p, fr_lerp(fr_load(V1in + 4 * p), fr_load(V1in + 4 * p + 1), r));
             fr_store(V1out + 2 * p + 1, fr_lerp(fr_load(V1in + 4 * p + 2), fr_load(V1in + 4 * p + 3), r));
-            if (fill) { fr_store(V0out + 2 * p, fr_zero()); fr_store(V0out + 2 * p + 1, fr_zero()); }
+            if (fill & 1) { fr_store(V0out + 2 * p, fr_zero()); fr_store(V0out + 2 * p + 1, fr_zero()); }
         }
     fr_block_sum<4>(acc, smem);
     __syncthreads();

@@ -651,11 +651,20 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
     const uint64_t n = t1.len;
     const uint64_t npairs = first ? n / 2 : n / 4;
     if (npairs == 0) return ZK_ERR_STATE;
-    const uint32_t g = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks);
     const unsigned long long seq = ++ctx->slot_seq;
     // X's live prefix (entries, pre-fold); once the folded tables are small the zeros behind it are written out (the quadratic rounds read whole tables)
     const uint64_t x_live = std::min<uint64_t>(t0.live, n);
-    const int fill = (!first && n / 2 <= (1ull << 20)) ? 1 : 0;
+    int fill = (!first && n / 2 <= (1ull << 20)) ? 1 : 0;
+    // Behind X's live prefix only Y is folded: for large tables that is a plain streaming fold (one output per thread, 64 contiguous bytes in, 32
+    // out) in a launch of its own ahead of the round kernel, which then works on the live pairs alone
+    const uint64_t pl = std::min<uint64_t>(npairs, (x_live + 3) / 4);
+    if (!first && npairs - pl >= (1ull << 17)) {
+        const uint64_t n_in = n - 4 * pl;
+        ZK_LAUNCH(PC_FOLD, 48.0 * (double) n_in, k_fold, dim3(grid_for(n_in / 2, 8192)), dim3(ZK_BLOCK), vin(t1) + 4 * pl, t1.V[t1.cur ^ 1] + 2 * pl, n_in, to_dev(r));
+        if (fill) ZK_HIP(hipMemsetAsync(t0.V[t0.cur ^ 1] + 2 * pl, 0, (n / 2 - 2 * pl) * sizeof(fr_t), ctx->stream));
+        fill |= 2;
+    }
+    const uint32_t g = std::min<uint32_t>(grid_for((fill & 2) || first ? std::max<uint64_t>(first ? std::min<uint64_t>(npairs, (x_live + 1) / 2) : pl, 1) : npairs, 1024), ctx->partial_blocks);
     ZK_LAUNCH(PC_ROUND_CUBIC, (first ? 32.0 : 48.0) * (double) (n + x_live), k_round_cubic, dim3(g), dim3(ZK_BLOCK), t0.V[t0.cur], vin(t1),
               t0.V[t0.cur ^ 1], t1.V[t1.cur ^ 1], (const fr_t *) ctx->small[ctx->small_cur], ctx->small_len, n, to_dev(r), first ? 1 : 0, ctx->partials,
               ctx->d_counter, (host_slot *) ctx->d_slot, seq, ms_raw, ms_out, x_live, fill);
@@ -664,7 +673,7 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
         t0.cur ^= 1; t1.cur ^= 1;
         t0.len >>= 1; t1.len >>= 1;
         t1.Vsrc = nullptr;
-        t0.live = fill ? t0.len : std::min<uint64_t>(t0.len, 2 * ((x_live + 3) / 4));
+        t0.live = (fill & 1) ? t0.len : std::min<uint64_t>(t0.len, 2 * ((x_live + 3) / 4));
     }
     int32_t rc = wait_slot(ctx, seq);
     if (rc) return rc;
