@@ -574,7 +574,8 @@ def main():
             return round(min(1e3 * (x.prove_s + x.poly_prove_s) for x in (sess.prove(seed=0x5EED0300 + k, mode=mode, want_transcript=False)[0] for k in range(3))), 3)
         extras["prover_ms_hybrid_tail"] = best(drive | zkcnn_amd.MODE_HOST_TAIL)          # tables of <= 64 entries finish their phase on the host
         fs = zkcnn_amd.MODE_FIAT_SHAMIR | zkcnn_amd.MODE_DRIVE_ONLY
-        extras["prover_ms_fiat_shamir_device_rounds"] = best(fs)                          # non-interactive: small rounds run on the GPU by themselves
+        extras["prover_ms_fiat_shamir"] = best(fs)                                        # non-interactive: challenges hashed on the host, rounds in the resident kernels
+        extras["prover_ms_fiat_shamir_device_rounds"] = best(fs | zkcnn_amd.MODE_FS_DEVICE)  # ... small rounds and their hash chain on the GPU by themselves
         extras["prover_ms_fiat_shamir_host_rounds"] = best(fs | zkcnn_amd.MODE_HOST_ROUNDS)
         extras["prover_ms_zero_knowledge"] = best(drive | zkcnn_amd.MODE_ZK)              # blinded commitments, masked rounds, proofs of dot product
         extras["fs_device_rounds_phases"] = list(sess.fs_stats())
@@ -673,7 +674,7 @@ def main():
     steps = args.steps
     out = {
         "metric": f"proofs/s (GKR prover, {args.workload} pic_cnt={pp} proofs, {K} in flight per GPU; modes SEEDED|DRIVE_ONLY|REUSE_GENS: public generators "
-                  "with a resident byte table, IPA cut at 256" + ("; EXPERIMENT: hybrid host tail" if args.hybrid_tail else "") + ("; EXPERIMENT: Fiat-Shamir, device-side rounds" if args.fiat_shamir else "") +
+                  "with a resident byte table, IPA cut at 256" + ("; EXPERIMENT: hybrid host tail" if args.hybrid_tail else "") + ("; EXPERIMENT: Fiat-Shamir (challenges hashed on the host)" if args.fiat_shamir else "") +
                   "; sessions share one resident circuit, a picture each); prover_ms_per_image = single-stream latency (a lone proof runs its rounds in resident "
                   "kernels, with several in flight every round is a launch); conservative companions alongside",
         "value": round(sum(p["streams"] for p in per_rank) * steps / elapsed, 4),         # every rank's proofs (a rank may hold fewer streams than asked for)

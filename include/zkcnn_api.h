@@ -29,8 +29,8 @@ typedef struct {
 #define ZKCNN_MODE_REUSE_GENS  2u  /* public commitment generators (hash-to-curve, nobody knows a discrete log) instead of fresh random multiples of G */
 #define ZKCNN_MODE_TAMPER      4u  /* test hook: the verifier corrupts message number ((mode >> 8) & 0xffff) before checking it; flags continue at bit 24 */
 #define ZKCNN_MODE_HOST_PRED   8u  /* verifier's wiring predicates on the host (reference src/verifier.cpp:89-116) instead of the GPU */
-#define ZKCNN_MODE_FIAT_SHAMIR 32u /* non-interactive: challenges are a BLAKE2s chain over the statement and every message so far (the seed is ignored); the GPU
-                                     runs the small rounds of each phase by itself (ZKCNN_MODE_HOST_ROUNDS keeps every round on the host <-> GPU path);
+#define ZKCNN_MODE_FIAT_SHAMIR 32u /* non-interactive: challenges are a BLAKE2s chain over the statement and every message so far (the seed is ignored), derived by
+                                     the verifier object on the host while the rounds run as in the interactive protocol (ZKCNN_MODE_FS_DEVICE: on the GPU);
                                      always on the public hash-to-curve generators, whose digest is part of the hashed statement */
 #define ZKCNN_MODE_SEEDED      64u /* reproducible run for parity tests / benches: challenges (and, without REUSE_GENS, generator scalars) come from a
                                      xoshiro stream seeded with challenge_seed. NOT secure -- every challenge is predictable from the seed.
@@ -42,6 +42,10 @@ typedef struct {
                                               rounds (Fiat-Shamir) -- A/B and parity of both */
 #define ZKCNN_MODE_HOST_TAIL (1u << 26)    /* hybrid tail (off by default): once a phase's tables have <= 64 entries they travel to the host and its last
                                             ~6 rounds run there (a few hundred host multiplications instead of six latency-bound launches) */
+#define ZKCNN_MODE_FS_DEVICE (1u << 27)    /* with ZKCNN_MODE_FIAT_SHAMIR: the GPU derives the challenges of the small and mid-size rounds itself
+                                            (BLAKE2s chain on the device) instead of trading polynomials and challenges with the
+                                            host, which hashes by default. Same transcript; slower since round 3 (the resident kernels' mailbox
+                                            round trip costs less than the serial hash on four lanes): kept as an option and for the tests */
 #define ZKCNN_MODE_CROSS_PRED 16u  /* both, and the verifier rejects if they differ (parity check of zk_verifier_*) */
 
 typedef struct {

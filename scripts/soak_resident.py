@@ -31,7 +31,7 @@ for model, pic, pp in MODELS:
             _, host = s.prove(seed=seed, mode=REUSE | DRIVE | HOST)
             if live != host:
                 sys.exit(f"{model} iteration {it}: resident kernels and launch-per-round transcripts differ")
-            _, fs_dev = s.prove(mode=FS | DRIVE)
+            _, fs_dev = s.prove(mode=FS | zkcnn_amd.MODE_FS_DEVICE | DRIVE)
             _, fs_host = s.prove(mode=FS | DRIVE | HOST)
             if fs_dev != fs_host:
                 sys.exit(f"{model} iteration {it}: Fiat-Shamir device rounds and host rounds differ")

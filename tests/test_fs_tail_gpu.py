@@ -1,6 +1,7 @@
-"""Device-side Fiat-Shamir rounds (hip/fs_tail.cuh): in the non-interactive mode the GPU runs the small rounds of every
-phase by itself -- fold, round sums, add_term bookkeeping, BLAKE2s chain step, next challenge. The transcript must be the one of the
-host-driven rounds (ZKCNN_MODE_HOST_ROUNDS) and of the CPU oracle, whose verifier derives every challenge on the host."""
+"""Device-side Fiat-Shamir rounds (hip/fs_tail.cuh): with ZKCNN_MODE_FS_DEVICE the GPU runs the small rounds of every
+phase of a non-interactive proof by itself -- fold, round sums, add_term bookkeeping, BLAKE2s chain step, next challenge. The transcript must be
+the one of the default mode (challenges derived on the host, rounds in the resident kernels), of the host-driven rounds
+(ZKCNN_MODE_HOST_ROUNDS) and of the CPU oracle, whose verifier derives every challenge on the host."""
 import hashlib
 import time
 
@@ -11,6 +12,7 @@ from tests import oracle_ffi
 
 pytestmark = pytest.mark.gpu
 FS, HOST, REUSE, DRIVE = zkcnn_amd.MODE_FIAT_SHAMIR, zkcnn_amd.MODE_HOST_ROUNDS, zkcnn_amd.MODE_REUSE_GENS, zkcnn_amd.MODE_DRIVE_ONLY
+FSD = FS | zkcnn_amd.MODE_FS_DEVICE
 
 CASES = [
     ("custom:F8 F4", (4, 4, 1), 1),                                   # every table tiny: whole phases on the device, from round 0
@@ -29,11 +31,14 @@ def test_device_rounds_give_the_host_transcript(built, model, pic, pp):
         assert ores.accepted == 1
     with zkcnn_amd.Session(model, pic, pp) as s:
         r0, p0 = s.fs_stats()
-        res, tr = s.prove(mode=FS)
+        res, tr = s.prove(mode=FSD)
         r1, p1 = s.fs_stats()
         assert res.accepted == 1, res.message.decode()
         assert tr == want, "device-side rounds changed the Fiat-Shamir transcript"
         assert p1 > p0 and r1 - r0 >= p1 - p0, "no phase ran on the device"
+        resd, trd = s.prove(mode=FS)                              # default: host-derived challenges, resident round kernels
+        r1, p1 = s.fs_stats()
+        assert resd.accepted == 1 and trd == want
         res2, tr2 = s.prove(mode=FS | HOST)
         assert s.fs_stats() == (r1, p1) and tr2 == want          # every round driven from the host: same bytes
         res3, tr3 = s.prove(mode=FS | DRIVE)
@@ -79,16 +84,18 @@ def test_full_size_vgg11_fiat_shamir_latency(built):
         s.prove(mode=FS | DRIVE, want_transcript=False)           # tables of the public generators
         s.prove(mode=FS | DRIVE, want_transcript=False)
         lat = {}
-        for name, mode in (("device", FS | DRIVE), ("host", FS | DRIVE | HOST)):
+        for name, mode in (("device", FSD | DRIVE), ("resident", FS | DRIVE), ("host", FS | DRIVE | HOST)):
             best = 1e9
             for _ in range(3):
                 r, tr = s.prove(mode=mode)
                 best = min(best, 1e3 * (r.prove_s + r.poly_prove_s))
             lat[name] = (best, hashlib.sha256(tr).hexdigest(), 1e3 * r.prove_s)
         rounds, phases = s.fs_stats()
-        print(f"vgg11 Fiat-Shamir prover latency: {lat['device'][0]:.1f} ms with device-side rounds (sumcheck {lat['device'][2]:.1f}), "
-              f"{lat['host'][0]:.1f} ms host-driven; {rounds} rounds in {phases} device phases so far")
-        assert lat["device"][1] == lat["host"][1]
+        print(f"vgg11 Fiat-Shamir prover latency: {lat['resident'][0]:.1f} ms with host-derived challenges over the resident kernels (default), "
+              f"{lat['device'][0]:.1f} ms with device-side rounds (sumcheck {lat['device'][2]:.1f}), {lat['host'][0]:.1f} ms with a launch per round; "
+              f"{rounds} rounds in {phases} device / resident phases so far")
+        assert lat["device"][1] == lat["host"][1] == lat["resident"][1]
+        assert lat["resident"][0] < lat["host"][0] * 1.05
         full, _ = s.prove(mode=FS)
         assert full.accepted == 1, full.message.decode()
         assert lat["device"][0] < lat["host"][0] * 1.05          # (a few percent of run-to-run noise either way)

@@ -22,6 +22,7 @@ MODE_VERIFY, MODE_DRIVE_ONLY, MODE_REUSE_GENS, MODE_TAMPER, MODE_HOST_PRED, MODE
 MODE_ZK = 1 << 24
 MODE_HOST_ROUNDS = 1 << 25
 MODE_HOST_TAIL = 1 << 26
+MODE_FS_DEVICE = 1 << 27      # with MODE_FIAT_SHAMIR: BLAKE2s chain on the GPU (device-side rounds) instead of host-derived challenges over the resident kernels
 
 
 class ModelDesc(ctypes.Structure):

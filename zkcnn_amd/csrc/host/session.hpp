@@ -121,9 +121,12 @@ struct sessionT {
             v.transcript.tap = &fs;
             v.lazy_challenges = true;
             scope.reset(new challengeScope(&fs));
-            // the prover may run the small rounds of every phase ahead of the verifier: the challenges are a function of the transcript.
-            // Not with masked round polynomials (the masks are added on the host) and not when a message is corrupted on purpose.
-            if (for_prover && !zk && !(mode & (ZKCNN_MODE_TAMPER | ZKCNN_MODE_HOST_ROUNDS))) attachFsChain(p, fs.stateWords(), fs.pendingBytes());
+            // By default the rounds run like the interactive protocol's (resident kernels for a lone proof, launches otherwise) and the verifier
+            // object here derives every challenge from the transcript on the host. ZKCNN_MODE_FS_DEVICE: the prover runs the small rounds of
+            // every phase ahead of the verifier, hashing on the device -- the challenges are a function of the transcript. Not with masked round
+            // polynomials (the masks are added on the host) and not when a message is corrupted on purpose.
+            if (for_prover && (mode & ZKCNN_MODE_FS_DEVICE) && !zk && !(mode & (ZKCNN_MODE_TAMPER | ZKCNN_MODE_HOST_ROUNDS)))
+                attachFsChain(p, fs.stateWords(), fs.pendingBytes());
         }
     }
 
