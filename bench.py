@@ -149,6 +149,25 @@ def self_launch_if_needed(args, argv):
     os.execv(cmd[0], cmd)
 
 
+def supervise(argv):
+    """N = 1 without a launcher: the measurement runs in a child process that leaves its line in a file -- a provisional one as soon as the timed
+    region and its replay verification are behind it, updated after every later stage (companions, roofline, PMC passes, CPU baseline), the final
+    one at the end. This process touches no GPU and prints the last line the child left: a failure in a LATE, optional stage (seen once: a GPU
+    memory fault 2.5 minutes into a run, after the timed region) costs the stages behind it -- named in "incomplete_after" -- not the line."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="zkcnn_bench_") as tmp:
+        res = os.path.join(tmp, "line.json")
+        rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--inner"] + list(argv), env=dict(os.environ, ZKCNN_BENCH_RESULT=res))
+        line = open(res).read().strip() if os.path.exists(res) else ""
+    if line:
+        if rc != 0:
+            print(f"[bench] the measuring process ended with code {rc}; printing the last line it left", file=sys.stderr, flush=True)
+        print(line, flush=True)
+        return 0
+    raise SystemExit(rc if rc else 1)
+
+
 def _cpu_prover_worker(args):
     """one single-threaded CPU prover (the oracle) on the workload: returns (prover seconds, wall seconds incl. circuit + witness, ...,
     sha256 of the canonical transcript -- the GPU proof of the same picture, challenge seed and modes must hash to the same value)"""
@@ -204,12 +223,15 @@ def main():
                          "(RCCL refuses two ranks on one device). Not a scaling measurement; the line says so")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args.workload)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     self_launch_if_needed(args, sys.argv[1:])
+    if args.gpus == 1 and "RANK" not in os.environ and not args.inner:
+        return supervise(sys.argv[1:])
 
     import torch
     import zkcnn_amd
@@ -257,6 +279,25 @@ def main():
         drive |= zkcnn_amd.MODE_FIAT_SHAMIR
     if args.host_rounds or args.rehearse_shared_gpu:       # (ranks that share a GPU are not alone on it: the policy counts proofs per PROCESS)
         drive |= zkcnn_amd.MODE_HOST_ROUNDS
+
+    def stage(name):
+        """progress on stderr: if a run dies, the log says where"""
+        if rank == 0:
+            print(f"[bench] {time.strftime('%H:%M:%S')} {name}", file=sys.stderr, flush=True)
+        if os.environ.get("ZKCNN_BENCH_ABORT_AT") == name:       # test hook of the supervising process: die here
+            os.abort()
+
+    result_file = os.environ.get("ZKCNN_BENCH_RESULT") if args.inner else None
+
+    def leave(make, incomplete_after=None):
+        """the line so far (or the final one) for the supervising process"""
+        if result_file and rank == 0:
+            out = make()
+            if incomplete_after:
+                out = dict(out, incomplete_after=incomplete_after)
+            with open(result_file + ".tmp", "w") as f:
+                f.write(json.dumps(out))
+            os.replace(result_file + ".tmp", result_file)
 
     def in_threads(fn):
         """fn(i) for every stream i on its own host thread (the C calls release the GIL); re-raises the first failure"""
@@ -322,6 +363,7 @@ def main():
     except Exception:       # noqa: BLE001
         host_rss_gb = host_peak_gb = None
 
+    stage("pictures")
     # ---- a picture of its own for every session but the first (which keeps the data stream's picture: the parity proof below is compared with
     # the CPU oracle's): the recorded witness program replays in HBM (zkcnn_session_new_image); pictures whose activation ranges ask for other
     # quantisation scales than the circuit's are refused and the next seed is tried ----
@@ -353,6 +395,7 @@ def main():
     t_scan = time.time() - t_scan
     distinct_pictures = all(len(v) >= 2 for v in valid[1:])
 
+    stage("warm-up")
     # ---- warm-up: first step with the full verifier on every image (acceptance), the rest as the timed steps run ----
     firsts = [None] * K
 
@@ -401,6 +444,7 @@ def main():
     if os.environ.get("ZKCNN_BENCH_NOEVENTS"):
         sess.profile(None)
 
+    stage("timed steps")
     # ---- timed region: `steps` steps, a step = K proofs in flight on this GPU (one per stream) ----
     coll_dev = "cpu" if args.rehearse_shared_gpu else "cuda"        # gloo exchanges host tensors
 
@@ -477,6 +521,45 @@ def main():
         prof[key] += pr[key]
     sess.profile(None)
 
+    roofline, cpu, parity, extras = None, None, {}, {}
+
+    def build_out():
+        """the bench line from what has been measured so far (stages that have not run yet leave their defaults)"""
+        steps = args.steps
+        out = {
+            "metric": f"proofs/s (GKR prover, {args.workload} pic_cnt={pp} proofs, {K} in flight per GPU; modes SEEDED|DRIVE_ONLY|REUSE_GENS: public generators "
+                      "with a resident byte table, IPA cut at 256" + ("; EXPERIMENT: hybrid host tail" if args.hybrid_tail else "") + ("; EXPERIMENT: Fiat-Shamir (challenges hashed on the host)" if args.fiat_shamir else "") +
+                      "; sessions share one resident circuit, a picture each); prover_ms_per_image = single-stream latency (a lone proof runs its rounds in resident "
+                      "kernels, with several in flight every round is a launch); conservative companions alongside",
+            "value": round(sum(p["streams"] for p in per_rank) * steps / elapsed, 4),         # every rank's proofs (a rank may hold fewer streams than asked for)
+            "unit": "proofs/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u256 (BLS12-381 Fr, 8x32-bit Montgomery limbs)", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {model} {pic[0]}x{pic[1]}x{pic[2]} pic_cnt={pp}, one proof per image, {K} images in flight per GPU",
+                       "images_per_step": sum(p["streams"] for p in per_rank), "streams_per_gpu": K,
+                       "layers": first.n_layers, "input_size": first.input_size, "rounds": first.n_rounds,
+                       "mul_gates": first.gate_cnt_bin, "add_gates": first.gate_cnt_uni, "parallelism": f"dp{world} x {K} streams (independent proofs, RCCL gather)"},
+            "prover_ms_per_image": round(1e3 * (lat_prove + lat_poly), 3),
+            "prover_ms_sumcheck": round(1e3 * lat_prove, 3), "prover_ms_commit": round(1e3 * lat_poly, 3),
+            "prover_ms_per_image_in_flight": round(1e3 * (prove_s + poly_s) / (steps * K), 3),
+            "verifier_pass": bool(accepted), "timed_proofs_replay_verified": K, "proof_kb": round(first.proof_kb + first.poly_proof_kb, 1),
+            "setup_s": round(setup_s, 1), "witness_s": round(first.witness_s, 1), "upload_sort_s": round(max(f.upload_s for f in firsts), 2),
+            "hbm_gb_all_sessions": hbm_all_gb, "hbm_gb_first_session": hbm_first_gb, "hbm_gb_per_extra_session": hbm_extra_gb, "sharing": dict(zkcnn_amd.sharing_stats(), shared_circuit_gb=shared_gb), "distinct_picture_per_session": bool(distinct_pictures),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        out.update(parity)
+        out["per_rank"] = per_rank
+        if args.rehearse_shared_gpu:
+            out["rehearsal"] = f"{world} ranks share {torch.cuda.device_count()} GPU(s), gloo exchange: a rehearsal of the launch / gather / timing path, NOT a scaling measurement"
+        out["host_rss_gb_all_sessions"] = host_rss_gb
+        out["host_peak_rss_gb_while_building"] = host_peak_gb
+        out.update(extras)
+        return out
+
+    leave(build_out, "timed region (replay-verified); companions, roofline, PMC passes and CPU baseline not run yet")
+    stage("new-picture companion")
     # ---- companion: a NEW picture for every proof (the timed steps above re-prove K resident witnesses). zkcnn_session_new_image replays
     # the recorded witness program in HBM: quantise the picture on the host, recompute every layer value and auxiliary witness on the GPU.
     # Same K streams, same modes; each step = new_image + prove per stream. Pictures whose activation ranges ask for other quantisation
@@ -555,8 +638,10 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- conservative companions of the headline (not timed steps): nothing pre-built, nothing cut ----
     extras = dict(new_image)
+    leave(build_out, "new-picture companion")
+    stage("companions")
+    # ---- conservative companions of the headline (not timed steps): nothing pre-built, nothing cut ----
     try:
         if args.no_companions or world > 1:
             raise KeyboardInterrupt
@@ -571,6 +656,7 @@ def main():
         extras["prover_ms_session_gens_full_ipa"] = round(1e3 * (r.prove_s + r.poly_prove_s), 3)
         # other modes of the same prover, single stream, best of 3 (all with the session's public generators)
         def best(mode):
+            print(f"[bench] companion mode {mode:#x}", file=sys.stderr, flush=True)
             return round(min(1e3 * (x.prove_s + x.poly_prove_s) for x in (sess.prove(seed=0x5EED0300 + k, mode=mode, want_transcript=False)[0] for k in range(3))), 3)
         extras["prover_ms_hybrid_tail"] = best(drive | zkcnn_amd.MODE_HOST_TAIL)          # tables of <= 64 entries finish their phase on the host
         fs = zkcnn_amd.MODE_FIAT_SHAMIR | zkcnn_amd.MODE_DRIVE_ONLY
@@ -586,6 +672,8 @@ def main():
     sess.close()
     sess = None
 
+    leave(build_out, "companions")
+    stage("roofline")
     # ---- the roof that binds: this is integer modular arithmetic, and on this workload (a CIFAR-sized circuit: ~1.1 k interactive rounds, most
     # of them on small tables) the dominant class is bound by LATENCY -- dependent field products and the round hand-over -- not by HBM or by
     # the multiplier. Reported: HBM fraction of the dominant class (above), measured HBM traffic of that class, and the fraction of the
@@ -621,6 +709,8 @@ def main():
                                   "short dependent chains (two to seven Fr products) behind a launch and a host hand-over; the SAME kernel on a 2 x 2^24-entry launch "
                                   "(streaming_launch) runs at the multiplier ceiling") if small else "see streaming_launch"
         if world == 1 and not args.no_pmc and dominant in CLASS_KERNELS:
+            leave(build_out, "roofline (HIP events); PMC traffic and CPU baseline not run yet")
+            stage("pmc passes")
             pmc = measure_pmc_traffic(args.workload, CLASS_KERNELS[dominant])
             if pmc:
                 roofline["traffic"] = round(pmc["bytes_per_launch"], 1)
@@ -630,6 +720,8 @@ def main():
             else:
                 roofline["traffic_source"] = "rocprofv3 not available (or the counter pass failed): not measured"
 
+    leave(build_out, "PMC passes; CPU baseline and the transcript comparison with it not run yet")
+    stage("cpu baseline")
     # ---- CPU baseline: the oracle (port of the reference prover) on the same workload ----
     cpu = None
     parity = {}
@@ -671,38 +763,10 @@ def main():
                                     "note": f"{n_proc} independent oracle processes at once (prover time only, contention included); the all-cores figure "
                                             f"extrapolates to {cores} processes and needs ~{cores * 10} GB of host memory -- an upper bound for the host"}
 
-    steps = args.steps
-    out = {
-        "metric": f"proofs/s (GKR prover, {args.workload} pic_cnt={pp} proofs, {K} in flight per GPU; modes SEEDED|DRIVE_ONLY|REUSE_GENS: public generators "
-                  "with a resident byte table, IPA cut at 256" + ("; EXPERIMENT: hybrid host tail" if args.hybrid_tail else "") + ("; EXPERIMENT: Fiat-Shamir (challenges hashed on the host)" if args.fiat_shamir else "") +
-                  "; sessions share one resident circuit, a picture each); prover_ms_per_image = single-stream latency (a lone proof runs its rounds in resident "
-                  "kernels, with several in flight every round is a launch); conservative companions alongside",
-        "value": round(sum(p["streams"] for p in per_rank) * steps / elapsed, 4),         # every rank's proofs (a rank may hold fewer streams than asked for)
-        "unit": "proofs/s",
-        "n_gpus": world, "steps": steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u256 (BLS12-381 Fr, 8x32-bit Montgomery limbs)", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {model} {pic[0]}x{pic[1]}x{pic[2]} pic_cnt={pp}, one proof per image, {K} images in flight per GPU",
-                   "images_per_step": sum(p["streams"] for p in per_rank), "streams_per_gpu": K,
-                   "layers": first.n_layers, "input_size": first.input_size, "rounds": first.n_rounds,
-                   "mul_gates": first.gate_cnt_bin, "add_gates": first.gate_cnt_uni, "parallelism": f"dp{world} x {K} streams (independent proofs, RCCL gather)"},
-        "prover_ms_per_image": round(1e3 * (lat_prove + lat_poly), 3),
-        "prover_ms_sumcheck": round(1e3 * lat_prove, 3), "prover_ms_commit": round(1e3 * lat_poly, 3),
-        "prover_ms_per_image_in_flight": round(1e3 * (prove_s + poly_s) / (steps * K), 3),
-        "verifier_pass": bool(accepted), "timed_proofs_replay_verified": K, "proof_kb": round(first.proof_kb + first.poly_proof_kb, 1),
-        "setup_s": round(setup_s, 1), "witness_s": round(first.witness_s, 1), "upload_sort_s": round(max(f.upload_s for f in firsts), 2),
-        "hbm_gb_all_sessions": hbm_all_gb, "hbm_gb_first_session": hbm_first_gb, "hbm_gb_per_extra_session": hbm_extra_gb, "sharing": dict(zkcnn_amd.sharing_stats(), shared_circuit_gb=shared_gb), "distinct_picture_per_session": bool(distinct_pictures),
-        "roofline": roofline, "cpu_baseline": cpu,
-    }
-    out.update(parity)
-    out["per_rank"] = per_rank
-    if args.rehearse_shared_gpu:
-        out["rehearsal"] = f"{world} ranks share {torch.cuda.device_count()} GPU(s), gloo exchange: a rehearsal of the launch / gather / timing path, NOT a scaling measurement"
-    out["host_rss_gb_all_sessions"] = host_rss_gb
-    out["host_peak_rss_gb_while_building"] = host_peak_gb
-    out.update(extras)
-    print(json.dumps(out), flush=True)
+    out = build_out()
+    leave(lambda: out)
+    if not result_file:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

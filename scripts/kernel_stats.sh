@@ -10,13 +10,13 @@ cd /tmp && export TMPDIR=/tmp
 for S in 1 8; do
   D=$OUT/${TAG}_s$S
   rm -rf $D
-  rocprofv3 --kernel-trace --stats -d $D -o trace -- python $ROOT/bench.py --steps 5 --warmup 2 --streams $S --no-cpu-baseline --no-companions > $OUT/${TAG}_s$S.log 2>&1 || true
+  rocprofv3 --kernel-trace --stats -d $D -o trace -- python $ROOT/bench.py --inner --steps 5 --warmup 2 --streams $S --no-cpu-baseline --no-companions > $OUT/${TAG}_s$S.log 2>&1 || true
   python - <<PY
 import glob, sqlite3, json
 dbs = glob.glob("$D/**/*.db", recursive=True)
 out = open("$OUT/${TAG}_s$S.md", "w")
 line = [l for l in open("$OUT/${TAG}_s$S.log") if l.startswith("{")]
-out.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --streams $S --no-cpu-baseline --no-companions\n\n")
+out.write("# rocprofv3 --kernel-trace --stats -- python bench.py --inner --steps 5 --warmup 2 --streams $S --no-cpu-baseline --no-companions\n\n")
 if line:
     d = json.loads(line[-1])
     out.write("bench line under the profiler: value %.2f proofs/s, prover_ms_per_image %.1f, roofline %s\n\n" % (d["value"], d["prover_ms_per_image"], json.dumps({k: d["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")})))

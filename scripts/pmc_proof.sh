@@ -7,7 +7,7 @@ WL=${1:-vgg11_pp8}; TAG=${2:-pmc_proof}
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --workload $WL --streams 1 --steps 2 --warmup 2 --no-cpu-baseline --no-companions"
+CMD="python $ROOT/bench.py --inner --workload $WL --streams 1 --steps 2 --warmup 2 --no-cpu-baseline --no-companions"
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1 || true
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- $CMD > $OUT/$C.log 2>&1 || true
