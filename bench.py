@@ -92,7 +92,15 @@ def measure_pmc_traffic(workload, kernels, timeout_s=150):
                        sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", workload]
                 env = dict(os.environ, TMPDIR=tmp)
                 env.pop("RANK", None)
-                subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
+                # (its own process group: a pass that does not come back is killed WITH the python process rocprofv3 started)
+                proc = subprocess.Popen(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+                try:
+                    proc.wait(timeout=timeout_s)
+                except subprocess.TimeoutExpired:
+                    import signal
+                    os.killpg(proc.pid, signal.SIGKILL)
+                    proc.wait()
+                    return None
                 val, n = 0.0, 0
                 for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                     for r in csv.DictReader(open(f)):
@@ -708,19 +716,8 @@ def main():
         roofline["bound_note"] = ("per launch the dominant class reaches a few percent of the HBM roof and the proof a fraction of the multiplier ceiling: its launches are "
                                   "short dependent chains (two to seven Fr products) behind a launch and a host hand-over; the SAME kernel on a 2 x 2^24-entry launch "
                                   "(streaming_launch) runs at the multiplier ceiling") if small else "see streaming_launch"
-        if world == 1 and not args.no_pmc and dominant in CLASS_KERNELS:
-            leave(build_out, "roofline (HIP events); PMC traffic and CPU baseline not run yet")
-            stage("pmc passes")
-            pmc = measure_pmc_traffic(args.workload, CLASS_KERNELS[dominant])
-            if pmc:
-                roofline["traffic"] = round(pmc["bytes_per_launch"], 1)
-                roofline["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH doubled, the gfx950 correction of "
-                                              f"MI355X_MICROARCH.md) over {pmc['launches']} launches of {', '.join(pmc['kernels'])} in four single-stream proofs")
-                roofline["traffic_over_algorithmic"] = round(pmc["bytes_per_launch"] / max(lat_prof["bytes"] / max(lat_prof["launches"], 1), 1.0), 3)
-            else:
-                roofline["traffic_source"] = "rocprofv3 not available (or the counter pass failed): not measured"
 
-    leave(build_out, "PMC passes; CPU baseline and the transcript comparison with it not run yet")
+    leave(build_out, "roofline (HIP events); CPU baseline, the transcript comparison with it and the PMC traffic passes not run yet")
     stage("cpu baseline")
     # ---- CPU baseline: the oracle (port of the reference prover) on the same workload ----
     cpu = None
@@ -762,6 +759,19 @@ def main():
                                     "gpu_proofs_per_s_over_that": round((world * K * args.steps / elapsed) / max(cores / per, 1e-9), 2),
                                     "note": f"{n_proc} independent oracle processes at once (prover time only, contention included); the all-cores figure "
                                             f"extrapolates to {cores} processes and needs ~{cores * 10} GB of host memory -- an upper bound for the host"}
+
+    # ---- last, because it is the stage most likely to go wrong (counter collection on this platform): HBM traffic of the dominant class ----
+    if roofline is not None and world == 1 and not args.no_pmc and dominant in CLASS_KERNELS:
+        leave(build_out, "CPU baseline; PMC traffic passes not run yet (roofline.traffic is null)")
+        stage("pmc passes")
+        pmc = measure_pmc_traffic(args.workload, CLASS_KERNELS[dominant])
+        if pmc:
+            roofline["traffic"] = round(pmc["bytes_per_launch"], 1)
+            roofline["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH doubled, the gfx950 correction of "
+                                          f"MI355X_MICROARCH.md) over {pmc['launches']} launches of {', '.join(pmc['kernels'])} in four single-stream proofs")
+            roofline["traffic_over_algorithmic"] = round(pmc["bytes_per_launch"] / max(lat_prof["bytes"] / max(lat_prof["launches"], 1), 1.0), 3)
+        else:
+            roofline["traffic_source"] = "rocprofv3 not available (or the counter pass failed): not measured"
 
     out = build_out()
     leave(lambda: out)
