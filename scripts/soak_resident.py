@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak test of the resident round kernels: one session per model, N iterations of
    interactive proof on the resident kernels (fully verified)  ==  the same seed with a launch per round (ZKCNN_MODE_HOST_ROUNDS)
-   Fiat-Shamir proof with device-side rounds                   ==  the same with host-driven rounds
+   Fiat-Shamir proof with device-side rounds (MODE_FS_DEVICE)  ==  the same with host-driven rounds  ==  the default (host hash, resident kernels)
    a proof with a corrupted message (the verifier stops calling in the middle of a phase: the resident kernel is sent home)
 and, in a second part, K sessions proving side by side (a launch per round by policy) against their single-stream transcripts.
 usage: soak_resident.py [iterations] [K]     exit code 1 on the first difference"""
@@ -35,6 +35,9 @@ for model, pic, pp in MODELS:
             _, fs_host = s.prove(mode=FS | DRIVE | HOST)
             if fs_dev != fs_host:
                 sys.exit(f"{model} iteration {it}: Fiat-Shamir device rounds and host rounds differ")
+            _, fs_res = s.prove(mode=FS | DRIVE)          # the default: challenges hashed on the host, rounds in the resident kernels
+            if fs_res != fs_host:
+                sys.exit(f"{model} iteration {it}: Fiat-Shamir over the resident kernels and host rounds differ")
             bad, _ = s.prove(seed=seed, mode=REUSE | TAMPER | (((it * 37) % max(n_msg - 4, 1) + 2) << 8))
             _, again = s.prove(seed=seed, mode=REUSE | DRIVE)
             if again != live:
