@@ -157,16 +157,28 @@ def self_launch_if_needed(args, argv):
     os.execv(cmd[0], cmd)
 
 
+def _run_child(cmd, env):
+    """the measuring process; a SIGTERM / SIGINT sent to this process (a driver's time limit) ends it too, so that it does not keep the GPU"""
+    import signal
+    import subprocess
+    proc = subprocess.Popen(cmd, env=env)
+    old = {sig: signal.signal(sig, lambda signum, frame: proc.kill()) for sig in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        return proc.wait()
+    finally:
+        for sig, h in old.items():
+            signal.signal(sig, h)
+
+
 def supervise(argv):
     """N = 1 without a launcher: the measurement runs in a child process that leaves its line in a file -- a provisional one as soon as the timed
     region and its replay verification are behind it, updated after every later stage (companions, roofline, PMC passes, CPU baseline), the final
     one at the end. This process touches no GPU and prints the last line the child left: a failure in a LATE, optional stage (seen once: a GPU
     memory fault 2.5 minutes into a run, after the timed region) costs the stages behind it -- named in "incomplete_after" -- not the line."""
-    import subprocess
     import tempfile
     with tempfile.TemporaryDirectory(prefix="zkcnn_bench_") as tmp:
         res = os.path.join(tmp, "line.json")
-        rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--inner"] + list(argv), env=dict(os.environ, ZKCNN_BENCH_RESULT=res))
+        rc = _run_child([sys.executable, os.path.abspath(__file__), "--inner"] + list(argv), dict(os.environ, ZKCNN_BENCH_RESULT=res))
         line = open(res).read().strip() if os.path.exists(res) else ""
     if line:
         if rc != 0:

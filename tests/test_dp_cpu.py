@@ -260,20 +260,19 @@ def test_bench_launches_its_own_ranks(tmp_path):
 def test_bench_parent_prints_the_last_line_its_child_left(monkeypatch, capsys):
     """`python bench.py` at N = 1 measures in a child process that leaves its line in a file after every stage; the parent prints the last one --
     also when the child dies in a late stage (seen once on the GPU box: a memory fault behind the timed region) -- and fails only if there is none"""
-    import subprocess
     import bench
 
-    def child_that_dies_late(cmd, env=None, **kw):
+    def child_that_dies_late(cmd, env):
         assert "--inner" in cmd and cmd[-2:] == ["--steps", "3"]
         with open(env["ZKCNN_BENCH_RESULT"], "w") as f:
             f.write('{"metric": "m", "value": 1.5, "incomplete_after": "companions"}')
         return -6
 
-    monkeypatch.setattr(subprocess, "call", child_that_dies_late)
+    monkeypatch.setattr(bench, "_run_child", child_that_dies_late)
     assert bench.supervise(["--steps", "3"]) == 0
     out = capsys.readouterr()
     assert out.out.strip() == '{"metric": "m", "value": 1.5, "incomplete_after": "companions"}' and "-6" in out.err
-    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None, **kw: 3)            # a child that left nothing (no GPU, bad arguments)
+    monkeypatch.setattr(bench, "_run_child", lambda cmd, env: 3)            # a child that left nothing (no GPU, bad arguments)
     with pytest.raises(SystemExit) as e:
         bench.supervise([])
     assert e.value.code == 3
