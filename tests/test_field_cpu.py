@@ -152,3 +152,73 @@ def test_msm_vs_python(oracle):
     for k, pt in zip(sc, pts):
         acc = _padd(acc, _pmul(k, pt))
     assert got == acc
+
+
+def test_dot_prod_layer_identities_of_design_4i():
+    """The three identities the GPU's DOT_PROD phase 1 relies on, against the definition of the reference's loop
+    (src/prover.cpp:86-91 builds X, :103-144 the cubic rounds) in Python integers:
+      (1) X[(p CI + ci, t)] = sum_co beta_g[p CO + co] F[((pp + co) CI + ci, t)] = beta_hi[p] S[ci, t] when beta_g = alpha eq(r, .) and CO = 2^k;
+      (2) behind X's live prefix a round's pairs add nothing, and folding X there gives zeros;
+      (3) once the periodic table is a scalar m, the round polynomial is m times the quadratic of (X, Y) with cubic coefficient zero."""
+    rnd = random.Random(41)
+    pp, CO, CI, fb = 3, 4, 2, 2
+    ln, k = 1 << fb, 2
+    gbits = 4                                             # pp CO = 12 outputs, padded to 16
+    r = [rnd.randrange(R_MOD) for _ in range(gbits)]
+    alpha = rnd.randrange(R_MOD)
+    beta_g = [alpha * _eq(r, g) % R_MOD for g in range(1 << gbits)]
+    rows = (pp + CO) * CI
+    F = [[rnd.randrange(R_MOD) for _ in range(ln)] for _ in range(rows)]
+    X = [[0] * ln for _ in range(rows)]
+    for p in range(pp):
+        for co in range(CO):
+            for ci in range(CI):
+                g, u, v = p * CO + co, p * CI + ci, (pp + co) * CI + ci
+                for t in range(ln):
+                    X[u][t] = (X[u][t] + beta_g[g] * F[v][t]) % R_MOD
+    beta_lo = [_eq(r[:k], co) for co in range(CO)]
+    beta_hi = [alpha * _eq(r[k:], p) % R_MOD for p in range(1 << (gbits - k))]
+    S = [[sum(beta_lo[co] * F[(pp + co) * CI + ci][t] for co in range(CO)) % R_MOD for t in range(ln)] for ci in range(CI)]
+    for p in range(pp):
+        for ci in range(CI):
+            assert X[p * CI + ci] == [beta_hi[p] * S[ci][t] % R_MOD for t in range(ln)]
+    assert all(x == 0 for row in X[pp * CI:] for x in row)            # the weight vectors' rows have no gate: X's live prefix ends at pp CI rows
+    # flat tables, padded to a power of two; Y = the FFT layer itself
+    N = 1
+    while N < rows * ln:
+        N <<= 1
+    xs = [x for row in X for x in row] + [0] * (N - rows * ln)
+    ys = [y for row in F for y in row] + [0] * (N - rows * ln)
+    ms = [rnd.randrange(R_MOD) for _ in range(ln)]                    # periodic in t
+
+    def lerp(a, b, c):
+        return (a + c * (b - a)) % R_MOD
+
+    def cubic(xs, ys, ms):
+        """coefficients (c3, c2, c1, c0) of sum_i X_i(x) Y_i(x) M_{i mod |M|/2}(x) over the pairs (2i, 2i + 1)"""
+        c = [0, 0, 0, 0]
+        mp = max(len(ms) // 2, 1)
+        for i in range(len(xs) // 2):
+            x0, dx, y0, dy = xs[2 * i], xs[2 * i + 1] - xs[2 * i], ys[2 * i], ys[2 * i + 1] - ys[2 * i]
+            m0, dm = (ms[2 * (i % mp)], ms[2 * (i % mp) + 1] - ms[2 * (i % mp)]) if len(ms) > 1 else (ms[0], 0)
+            q2, q1, q0 = dx * dy, x0 * dy + dx * y0, x0 * y0
+            c[0] += q2 * dm; c[1] += q2 * m0 + q1 * dm; c[2] += q1 * m0 + q0 * dm; c[3] += q0 * m0
+        return [v % R_MOD for v in c]
+
+    live = pp * CI * ln
+    while len(xs) > 2:
+        full = cubic(xs, ys, ms)
+        pl = (live + 1) // 2
+        assert full == cubic(xs[:2 * pl], ys[:2 * pl], ms)             # (2) pairs behind the live prefix add nothing
+        if len(ms) == 1:                                               # (3) a scalar m: m times the quadratic, no cubic term
+            a = sum((xs[2 * i + 1] - xs[2 * i]) * (ys[2 * i + 1] - ys[2 * i]) for i in range(len(xs) // 2)) % R_MOD
+            c0 = sum(xs[2 * i] * ys[2 * i] for i in range(len(xs) // 2)) % R_MOD
+            p1 = sum(xs[2 * i + 1] * ys[2 * i + 1] for i in range(len(xs) // 2)) % R_MOD
+            assert full == [0, ms[0] * a % R_MOD, ms[0] * (p1 - a - c0) % R_MOD, ms[0] * c0 % R_MOD]
+        c = rnd.randrange(R_MOD)
+        xs = [lerp(xs[2 * i], xs[2 * i + 1], c) for i in range(len(xs) // 2)]
+        ys = [lerp(ys[2 * i], ys[2 * i + 1], c) for i in range(len(ys) // 2)]
+        if len(ms) > 1:
+            ms = [lerp(ms[2 * i], ms[2 * i + 1], c) for i in range(len(ms) // 2)]
+        live = (live + 1) // 2
+        assert all(x == 0 for x in xs[live:])                          # (2) the fold of zeros
