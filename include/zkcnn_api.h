@@ -105,6 +105,21 @@ void *zkcnn_verifier_create(const zkcnn_model_desc *desc, const int32_t *scales,
 int32_t zkcnn_session_new_image(void *session, uint64_t picture_seed, const double *pixels, uint64_t n_pixels, double *ms);
 /* the pixel values of synthetic picture `picture_seed` for this session's model (cap >= channel * x * y); returns their number */
 int64_t zkcnn_session_synthetic_picture(void *session, uint64_t picture_seed, double *pixels, uint64_t cap);
+/* ---- lock-step batches (product library; the oracle exports oracle_batch_prove over its CPU sessions for the host-logic tests) ----
+ * K sessions of ONE model on ONE GPU (same data_seed => same weights => one resident circuit; their pictures differ: picture_seed, or
+ * zkcnn_session_new_image) become the lanes of a batch: one host thread drives their K verifier loops together and every sumcheck round of
+ * the K proofs is ONE kernel launch (include/zkcnn_hip.h: zk_batch_*). The sessions stay owned by the caller, must outlive the batch and must
+ * not be proved individually from other threads while it exists. n <= 8. NULL on error (a session on another device or circuit). */
+void *zkcnn_batch_create(void *const *sessions, int32_t n);
+/* One proof per lane: seeds[k], transcripts[k] (may be NULL) / caps[k], out[k] as in zkcnn_session_prove; `mode` is shared. Each lane's
+ * transcript is byte for byte what zkcnn_session_prove(sessions[k], seeds[k], mode) returns. The per-lane timers in out[k] (prove_s ...)
+ * include the time the thread spent in other lanes; *wall_s (may be NULL) is the wall clock of the whole batch. */
+int32_t zkcnn_batch_prove(void *batch, const uint64_t *seeds, uint32_t mode, uint8_t *const *transcripts, const uint64_t *caps,
+                          zkcnn_result *out, double *wall_s);
+/* out[0] = fused launches, out[1] = lane launches they stood for, out[2] = flushes, out[3] = lanes, out[4] = passes of the driver loop */
+int32_t zkcnn_batch_stats(void *batch, uint64_t out[5]);
+void zkcnn_batch_destroy(void *batch);
+
 /* Test hooks (both libraries): size of layer `layer` of the session's circuit (its layerType in *type), and overwriting one value of the
  * witness -- an INVALID witness on purpose: proofs must then be rejected, and a seeded GPU proof must still equal the oracle's. */
 int64_t zkcnn_session_layer_size(void *session, int32_t layer, int32_t *type);

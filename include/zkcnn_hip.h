@@ -145,6 +145,37 @@ int32_t zk_proof_end(zk_ctx *ctx);
 /* rounds / phases served by the tail kernel since the context was created (tests, bench) */
 int32_t zk_fs_stats(zk_ctx *ctx, uint64_t *rounds, uint64_t *phases);
 
+/* ---- lock-step batches: K proofs on one resident circuit, ONE launch per round for all of them ------------------------------------------
+ * The reference proves one picture per process (reference src/main_demo_vgg.cpp:20-43); its prover is driven round by round by the verifier
+ * (reference src/verifier.cpp:149-264), one call of sumcheckUpdate1/2 (reference src/prover.cpp:360-426) per round. K contexts that hold the
+ * SAME resident circuit (same upload: they share its gate lists) with K different witnesses make exactly the same sequence of calls with
+ * different challenges, so their launches can be fused: a context attached to a batch becomes a LANE of it, moves onto the batch's stream,
+ * and every launch of a lane that has a batched kernel form (the round kernels first of all) is deferred until all lanes have reached the
+ * same point, then issued as one launch over all lanes (blockIdx.y = lane). Results, transcripts and every zk_sumcheck_* signature are
+ * unchanged -- a lane is driven through the same per-context calls above.
+ *
+ * Driving model: the lanes of a batch are driven by ONE host thread that runs their K protocol loops cooperatively (the host library's
+ * batchSession does so with one fiber per lane). The yield function is how a lane hands the thread on: the library calls it wherever a lane
+ * has deferred a launch or would wait for the GPU; the driver runs the other lanes up to their own such points, calls zk_batch_flush and
+ * resumes them. Without a yield function each lane flushes for itself (correct, nothing is fused). Resident round kernels
+ * (zk_set_live_rounds) and the device-side Fiat-Shamir chain (zk_fs_attach) are not used by a lane. */
+typedef struct zk_batch zk_batch;
+#define ZK_BATCH_MAX_LANES 8
+typedef void (*zk_yield_fn)(void *user, int32_t lane);
+int32_t zk_batch_create(int32_t device, zk_batch **out);
+/* detaches every lane (each goes back to its own stream) and frees the batch */
+void zk_batch_destroy(zk_batch *b);
+/* ctx becomes the next lane (its index is returned in *lane, may be NULL). ZK_ERR_ARG: other device, already a lane, batch full;
+ * ZK_ERR_STATE: no circuit yet, or not the resident circuit of lane 0. */
+int32_t zk_batch_attach(zk_batch *b, zk_ctx *ctx, int32_t *lane);
+int32_t zk_batch_detach(zk_batch *b, zk_ctx *ctx);
+int32_t zk_batch_set_yield(zk_batch *b, zk_yield_fn fn, void *user);
+/* issues every deferred launch: one launch per kernel class over all lanes that deferred one */
+int32_t zk_batch_flush(zk_batch *b);
+/* out[0] = launches issued by flushes, out[1] = lane launches they stood for, out[2] = flushes, out[3] = lanes */
+int32_t zk_batch_stats(const zk_batch *b, uint64_t out[4]);
+const char *zk_batch_last_error(const zk_batch *b);
+
 /* ---- zero-knowledge mode of the commitment (no reference counterpart: reference README.md:5 "not fully
  * zero-knowledge"): the generator set has one more entry H = gens[n_gens - 1] and every commitment is blinded, Com(v; s) = <v, g> + s H -- */
 /* zk_commit_input with n_gens = 2^cb + 1 generators and one blinding factor per row: out_comm[i] = <row_i, g> + blinds[i] H */

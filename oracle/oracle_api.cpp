@@ -4,9 +4,23 @@
 #include "../zkcnn_amd/csrc/ff/sha256.hpp"
 #include "../zkcnn_amd/csrc/ff/blake2s.hpp"
 #include "ref_prover.hpp"
+#define ZKFIBER_IMPLEMENTATION
 #include "session.hpp"
 
 typedef sessionT<oracle::prover> oracleSession;
+
+// For the host-logic test of batchSessionT (session.hpp) without a GPU: the CPU prover, except that every round call first gives up the thread when
+// it runs on a fiber -- the points at which the HIP-backed prover's lanes yield. K such sessions driven by one batchSessionT must produce
+// the transcripts they produce one by one.
+struct yieldingProver : public oracle::prover {
+    cubic_poly sumcheckDotProdUpdate1(const F &r) { zkfiber::fiber::yield(); return oracle::prover::sumcheckDotProdUpdate1(r); }
+    quadratic_poly sumcheckUpdate1(const F &r) { zkfiber::fiber::yield(); return oracle::prover::sumcheckUpdate1(r); }
+    quadratic_poly sumcheckUpdate2(const F &r) { zkfiber::fiber::yield(); return oracle::prover::sumcheckUpdate2(r); }
+    quadratic_poly sumcheckLiuUpdate(const F &r) { zkfiber::fiber::yield(); return oracle::prover::sumcheckLiuUpdate(r); }
+    void sumcheckInitPhase1(const F &x) { zkfiber::fiber::yield(); oracle::prover::sumcheckInitPhase1(x); }
+    void sumcheckFinalize1(const F &r, F &c0, F &c1) { zkfiber::fiber::yield(); oracle::prover::sumcheckFinalize1(r, c0, c1); }
+};
+typedef sessionT<yieldingProver> yieldingSession;
 
 // field elements cross the ABI as 4 x u64 Montgomery limbs
 static inline Fr &FR(uint64_t *p, size_t i) { return *reinterpret_cast<Fr *>(p + 4 * i); }
@@ -31,6 +45,24 @@ void *oracle_session_create_calibrated(const zkcnn_model_desc *desc, const int32
 int32_t oracle_session_prove(void *session, uint64_t seed, uint32_t mode, uint8_t *transcript, uint64_t cap,
                              zkcnn_result *out) {
     return ((oracleSession *) session)->prove(seed, mode, transcript, cap, out);
+}
+// K yielding sessions (oracle_session_create_yielding) in one batchSessionT; returns the driver's pass count in *passes
+void *oracle_session_create_yielding(const zkcnn_model_desc *desc) {
+    yieldingSession *s = new yieldingSession();
+    if (!s->build(desc)) { delete s; return nullptr; }
+    return s;
+}
+void oracle_session_destroy_yielding(void *session) { delete (yieldingSession *) session; }
+int32_t oracle_session_prove_yielding(void *session, uint64_t seed, uint32_t mode, uint8_t *transcript, uint64_t cap, zkcnn_result *out) {
+    return ((yieldingSession *) session)->prove(seed, mode, transcript, cap, out);       // (not on a fiber: the yields do nothing)
+}
+int32_t oracle_batch_prove(void *const *sessions, int32_t n, const uint64_t *seeds, uint32_t mode, uint8_t *const *transcripts, const uint64_t *caps,
+                           zkcnn_result *out, uint64_t *passes) {
+    batchSessionT<yieldingSession> b;
+    for (int32_t k = 0; k < n; ++k) b.lanes.push_back((yieldingSession *) sessions[k]);
+    const int rc = b.prove(seeds, mode, transcripts, caps, out, []() {});
+    if (passes) *passes = b.rounds_of_flushes;
+    return rc;
 }
 int64_t oracle_session_statement(void *session, int32_t *scales, uint64_t cap) {
     const vector<int> &v = ((oracleSession *) session)->statementScales();

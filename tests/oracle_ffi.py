@@ -169,3 +169,43 @@ def load():
             raise RuntimeError("oracle/liboracle.so missing: run `make -C oracle`")
         _oracle = Oracle(ctypes.CDLL(path))
     return _oracle
+
+
+class YieldingOracleSession:
+    """CPU session whose prover gives up the thread at every round call when it runs on a fiber (oracle_api.cpp: yieldingProver): the
+    stand-in for a GPU lane in the host-logic tests of batchSessionT (zkcnn_amd/csrc/host/session.hpp)."""
+
+    def __init__(self, model, pic, pic_cnt=1, data_seed=20260928, picture_seed=0):
+        self.lib = load().lib
+        self.desc = zkcnn_amd.ModelDesc(model.encode(), pic[0], pic[1], pic[2], pic_cnt, data_seed, picture_seed)
+        self.lib.oracle_session_create_yielding.restype = ctypes.c_void_p
+        self.h = self.lib.oracle_session_create_yielding(ctypes.byref(self.desc))
+        if not self.h:
+            raise RuntimeError("oracle_session_create_yielding failed")
+
+    def prove(self, seed, mode):
+        buf = (ctypes.c_uint8 * (1 << 20))()
+        res = zkcnn_amd.Result()
+        rc = self.lib.oracle_session_prove_yielding(ctypes.c_void_p(self.h), ctypes.c_uint64(seed), ctypes.c_uint32(mode), buf, ctypes.c_uint64(len(buf)), ctypes.byref(res))
+        assert rc == 0, res.message
+        return res, ctypes.string_at(buf, res.transcript_len)
+
+    def close(self):
+        if self.h:
+            self.lib.oracle_session_destroy_yielding(ctypes.c_void_p(self.h))
+            self.h = None
+
+
+def oracle_batch_prove(sessions, seeds, mode):
+    """K yielding sessions as the lanes of one batchSessionT, driven by this thread; returns ([(Result, bytes)], driver passes)"""
+    lib = load().lib
+    k = len(sessions)
+    bufs = [(ctypes.c_uint8 * (1 << 20))() for _ in range(k)]
+    ptrs = (ctypes.c_void_p * k)(*[ctypes.addressof(b) for b in bufs])
+    caps = (ctypes.c_uint64 * k)(*[len(b) for b in bufs])
+    hs = (ctypes.c_void_p * k)(*[s.h for s in sessions])
+    res = (zkcnn_amd.Result * k)()
+    passes = ctypes.c_uint64(0)
+    rc = lib.oracle_batch_prove(hs, ctypes.c_int32(k), (ctypes.c_uint64 * k)(*seeds), ctypes.c_uint32(mode), ptrs, caps, res, ctypes.byref(passes))
+    assert rc == 0, [r.message for r in res]
+    return [(zkcnn_amd.Result.from_buffer_copy(res[i]), ctypes.string_at(bufs[i], res[i].transcript_len)) for i in range(k)], passes.value

@@ -1,0 +1,190 @@
+"""Lock-step batches on the GPU (include/zkcnn_hip.h: zk_batch_*; include/zkcnn_api.h: zkcnn_batch_*): K sessions of one model become the lanes
+of a batch -- one host thread drives their K verifier loops (reference src/verifier.cpp:149-264, unchanged), the sumcheck rounds of the K proofs
+(reference src/prover.cpp:360-426) are ONE kernel launch each -- and every lane's canonical transcript must be byte for byte the CPU oracle's
+for that lane's picture and challenge seed: K = 2, 8 and a ragged 3, direct and FFT convolutions, every protocol mode."""
+import numpy as np
+import pytest
+
+import zkcnn_amd
+from tests import oracle_ffi
+
+pytestmark = pytest.mark.gpu
+M = zkcnn_amd
+REUSE, DRIVE = M.MODE_REUSE_GENS, M.MODE_DRIVE_ONLY
+
+QUARTER_VGG11 = "vgg:16 M 32 M 64 64 M 128 128 M 128 128 M"
+CASES = [
+    ("custom:C4:3:1:s C8:3:1:s M C8:3:1:s F5", (8, 8, 2), 1, 2),      # direct convolutions (factored gate sums), max pooling
+    ("custom:C4:3:1:s C8:3:1:s M C8:3:1:s F5", (8, 8, 2), 1, 8),
+    ("lenet", (32, 32, 1), 1, 3),                                      # FFT convolutions of one picture, average pooling; ragged batch
+    ("custom:C2:3:0:f C3:3:1:f M C2:3:1:s A F5 F3", (10, 10, 2), 2, 3),  # FFT convolutions over two pictures per circuit: cubic rounds, factored DOT_PROD table
+    (QUARTER_VGG11, (32, 32, 3), 1, 3),                                # vgg11 at quarter width: tables up to 2^21 entries (the large-table round kernel)
+    (QUARTER_VGG11, (32, 32, 3), 1, 8),
+]
+
+
+def _lanes(model, pic, pp, k):
+    """k sessions on ONE resident circuit (the first one's quantisation scales), each with its own picture"""
+    first = M.Session(model, pic, pp)
+    stmt = first.statement()
+    ss, seeds = [first], [0]
+    try:
+        for i in range(1, k):
+            s = M.Session(model, pic, pp, calibrated=stmt)
+            ss.append(s)
+            for ps in range(1000 * i, 1000 * i + 64):
+                if s.new_image(ps)[0] == 0:
+                    seeds.append(ps)
+                    break
+            else:
+                pytest.skip("no synthetic picture with the circuit's quantisation scales among 64")
+    except BaseException:
+        for s in ss:
+            s.close()
+        raise
+    return ss, seeds, stmt
+
+
+def _oracle(model, pic, pp, stmt, picture_seed, seed, mode):
+    with oracle_ffi.OracleSession(model, pic, pp, picture_seed=picture_seed, calibrated=stmt) as o:
+        res, tr = o.prove(seed=seed, mode=mode)
+    return res, tr
+
+
+@pytest.mark.parametrize("model,pic,pp,k", CASES)
+def test_every_lane_of_a_batch_equals_the_oracle(built, model, pic, pp, k):
+    ss, pics, stmt = _lanes(model, pic, pp, k)
+    try:
+        seeds = [0x5EED0B00 + 3 * i for i in range(k)]
+        want = [_oracle(model, pic, pp, stmt, pics[i], seeds[i], REUSE) for i in range(k)]
+        assert len({t for _, t in want}) == k
+        with M.BatchSession(ss) as B:
+            before = B.stats()
+            for rep in range(2):                 # (the second use of the public generators goes through their byte table: the path bench.py times)
+                got = B.prove(seeds=seeds, mode=REUSE)
+                for i in range(k):
+                    assert got[i][0].accepted == 1, f"lane {i}: {got[i][0].message.decode()}"
+                    assert got[i][1] == want[i][1], f"lane {i} (proof {rep}): transcript differs from the CPU oracle's for its picture and seed"
+                    assert abs(got[i][0].proof_kb - want[i][0].proof_kb) < 1e-9
+            st = B.stats()
+            rounds = got[0][0].n_rounds
+            fused, lane = st["fused_launches"] - before["fused_launches"], st["lane_launches"] - before["lane_launches"]
+            # every round launch of the lock-step lanes was fused: one launch stands for k lane launches
+            assert lane == k * fused and fused > 0, st
+            assert fused <= 2 * rounds, f"{fused} fused launches for 2 x {rounds} rounds"
+            # drive-only (the verifier's checks skipped) makes the same calls: same bytes
+            drv = B.prove(seeds=seeds, mode=REUSE | DRIVE)
+            assert all(drv[i][0].accepted == -1 and drv[i][1] == want[i][1] for i in range(k))
+        # the sessions are their own again: alone, on their own streams (resident round kernels), the same proofs
+        for i in (0, k - 1):
+            res, tr = ss[i].prove(seed=seeds[i], mode=REUSE)
+            assert res.accepted == 1 and tr == want[i][1]
+    finally:
+        for s in ss:
+            s.close()
+
+
+@pytest.mark.parametrize("mode", [0, M.MODE_FULL_IPA, M.MODE_FIAT_SHAMIR, M.MODE_ZK, M.MODE_ZK | M.MODE_FIAT_SHAMIR, REUSE | M.MODE_HOST_TAIL,
+                                  REUSE | M.MODE_CROSS_PRED, M.MODE_FIAT_SHAMIR | M.MODE_FS_DEVICE])
+def test_batch_in_every_protocol_mode(built, mode):
+    """fresh generators per lane (drawn by each lane's verifier from its own seeded stream), the argument down to length 1, challenges hashed
+    from the transcript, masked rounds + blinded commitments (private coins per lane), the hybrid host tail, host + GPU predicates side by side,
+    and the device-side Fiat-Shamir chain (which a lane does not take: its driver hashes -- same bytes)"""
+    model, pic, pp, k = "custom:C2:3:0:f C3:3:1:f M C2:3:1:s A F5 F3", (10, 10, 2), 2, 3
+    ss, pics, stmt = _lanes(model, pic, pp, k)
+    try:
+        seeds = [0x5EED0C00 + 5 * i for i in range(k)]
+        want = [_oracle(model, pic, pp, stmt, pics[i], seeds[i], mode & ~(M.MODE_HOST_TAIL | M.MODE_CROSS_PRED | M.MODE_FS_DEVICE)) for i in range(k)]
+        with M.BatchSession(ss) as B:
+            got = B.prove(seeds=seeds, mode=mode)
+        for i in range(k):
+            assert got[i][0].accepted == 1, f"lane {i}: {got[i][0].message.decode()}"
+            assert got[i][1] == want[i][1], f"lane {i}: transcript differs from the CPU oracle's"
+    finally:
+        for s in ss:
+            s.close()
+
+
+def test_batch_soundness_and_lanes_out_of_step(built):
+    """a corrupted message is rejected in every lane (each lane's verifier leaves its loop early; the batch goes on without it); an INVALID
+    witness in ONE lane (a poked value) is rejected there, accepted elsewhere, and that lane's transcript still equals the oracle's for the
+    same corrupted witness; a new picture in one lane between two batch proofs"""
+    model, pic, pp, k = "custom:C4:3:1:s C8:3:1:s M C8:3:1:s F5", (8, 8, 2), 1, 3
+    ss, pics, stmt = _lanes(model, pic, pp, k)
+    try:
+        seeds = [21, 22, 23]
+        with M.BatchSession(ss) as B:
+            good = B.prove(seeds=seeds, mode=REUSE)
+            assert [r.accepted for r, _ in good] == [1] * k
+            n_msg = good[0][0].n_messages
+            for at in (0, 7, n_msg // 2, n_msg - 1):
+                bad = B.prove(seeds=seeds, mode=REUSE | M.MODE_TAMPER | (at << 8))
+                assert [r.accepted for r, _ in bad] == [0] * k, f"message {at}"
+            assert [t for _, t in B.prove(seeds=seeds, mode=REUSE)] == [t for _, t in good]
+            # lane 1 gets an invalid witness: one value of layer 1 changed
+            one = [int(v) for v in oracle_ffi.load().from_canonical(np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]]
+            ss[1].poke(1, 0, one)
+            mixed = B.prove(seeds=seeds, mode=REUSE)
+            assert [r.accepted for r, _ in mixed] == [1, 0, 1]
+            assert mixed[0][1] == good[0][1] and mixed[2][1] == good[2][1]
+            with oracle_ffi.OracleSession(model, pic, pp, picture_seed=pics[1], calibrated=stmt) as o:
+                o.poke(1, 0, one)
+                ores, otr = o.prove(seed=seeds[1], mode=REUSE)
+            assert ores.accepted == 0 and otr == mixed[1][1]
+            # another picture in lane 1 (the witness is replayed in HBM on the batch's stream), then the batch again
+            for ps in range(7000, 7064):
+                if ss[1].new_image(ps)[0] == 0:
+                    break
+            else:
+                pytest.skip("no fitting picture")
+            again = B.prove(seeds=seeds, mode=REUSE)
+            assert [r.accepted for r, _ in again] == [1] * k
+            assert again[1][1] == _oracle(model, pic, pp, stmt, ps, seeds[1], REUSE)[1]
+            assert again[0][1] == good[0][1]
+    finally:
+        for s in ss:
+            s.close()
+
+
+def test_two_batches_side_by_side(built):
+    """two batches of one model on two host threads (two streams): the deployment shape of bench.py -- while one batch waits for a round the
+    other's kernels run"""
+    import threading
+    model, pic, pp = QUARTER_VGG11, (32, 32, 3), 1
+    ss, pics, stmt = _lanes(model, pic, pp, 4)
+    try:
+        seeds = [31, 32, 33, 34]
+        want = [_oracle(model, pic, pp, stmt, pics[i], seeds[i], REUSE | DRIVE)[1] for i in range(4)]
+        with M.BatchSession(ss[:2]) as A, M.BatchSession(ss[2:]) as B:
+            got, errs = {}, []
+
+            def run(name, batch, sd):
+                try:
+                    for _ in range(3):
+                        got[name] = batch.prove(seeds=sd, mode=REUSE | DRIVE)
+                except BaseException as e:      # noqa: BLE001
+                    errs.append(e)
+            th = [threading.Thread(target=run, args=("a", A, seeds[:2])), threading.Thread(target=run, args=("b", B, seeds[2:]))]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert not errs, errs
+            assert [t for _, t in got["a"]] == want[:2] and [t for _, t in got["b"]] == want[2:]
+    finally:
+        for s in ss:
+            s.close()
+
+
+def test_attach_refuses_other_circuits(built):
+    a = M.Session("custom:F8 F4", (4, 4, 1), 1)
+    b = M.Session("custom:F8 F5", (4, 4, 1), 1)
+    try:
+        with pytest.raises(RuntimeError):
+            M.BatchSession([a, b])
+        with pytest.raises(RuntimeError):
+            M.BatchSession([a, a])
+        # nothing is left attached by the failed attempts
+        res, _ = a.prove(seed=1)
+        assert res.accepted == 1
+    finally:
+        a.close()
+        b.close()

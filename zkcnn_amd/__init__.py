@@ -441,3 +441,63 @@ class Session(_SessionBase):
         if rc != 0:
             raise RuntimeError("zkcnn_session_profile_report failed")
         return json.loads(buf.value.decode())
+
+
+class BatchSession:
+    """K sessions of one model on one GPU proving in lock step (include/zkcnn_api.h: zkcnn_batch_*): one host thread drives the K verifier
+    loops, every sumcheck round of the K proofs is ONE kernel launch. The sessions must share their weights (same data_seed; the pictures
+    differ by picture_seed or new_image), i.e. one resident circuit; they stay usable for new_image between batch proofs and are closed
+    by their owner AFTER the batch."""
+
+    def __init__(self, sessions):
+        self.lib = host_lib()
+        self.sessions = list(sessions)
+        arr = (ctypes.c_void_p * len(self.sessions))(*[s.h for s in self.sessions])
+        self.lib.zkcnn_batch_create.restype = ctypes.c_void_p
+        self.h = self.lib.zkcnn_batch_create(arr, ctypes.c_int32(len(self.sessions)))
+        if not self.h:
+            raise RuntimeError("zkcnn_batch_create failed (sessions of one model on one device, at most 8)")
+        self._bufs = None
+        self.wall_s = 0.0
+
+    def prove(self, seeds=None, mode=MODE_VERIFY, want_transcript=True):
+        """one proof per lane; returns [(Result, transcript bytes)] in lane order. seeds: one integer per lane (reproducible, MODE_SEEDED)
+        or None (operating system's CSPRNG)."""
+        k = len(self.sessions)
+        if seeds is not None:
+            mode |= MODE_SEEDED
+        seed_arr = (ctypes.c_uint64 * k)(*(seeds if seeds is not None else [0] * k))
+        if want_transcript and self._bufs is None:
+            self._bufs = [(ctypes.c_uint8 * (4 << 20))() for _ in range(k)]
+        ptrs = (ctypes.c_void_p * k)(*[ctypes.addressof(b) if want_transcript else None for b in (self._bufs or [None] * k)])
+        caps = (ctypes.c_uint64 * k)(*[len(b) if want_transcript else 0 for b in (self._bufs or [()] * k)])
+        res = (Result * k)()
+        wall = ctypes.c_double(0)
+        rc = self.lib.zkcnn_batch_prove(ctypes.c_void_p(self.h), seed_arr, ctypes.c_uint32(mode), ptrs, caps, res, ctypes.byref(wall))
+        if rc != 0:
+            raise RuntimeError(f"zkcnn_batch_prove failed ({rc}): " + " | ".join(r.message.decode(errors="replace") for r in res))
+        self.wall_s = wall.value
+        out = []
+        for i in range(k):
+            if want_transcript and res[i].transcript_len > caps[i]:
+                raise RuntimeError("transcript buffer too small")
+            r = Result.from_buffer_copy(res[i])
+            out.append((r, ctypes.string_at(self._bufs[i], r.transcript_len) if want_transcript else b""))
+        return out
+
+    def stats(self):
+        v = (ctypes.c_uint64 * 5)()
+        if self.lib.zkcnn_batch_stats(ctypes.c_void_p(self.h), v) != 0:
+            raise RuntimeError("zkcnn_batch_stats failed")
+        return {"fused_launches": int(v[0]), "lane_launches": int(v[1]), "flushes": int(v[2]), "lanes": int(v[3]), "driver_passes": int(v[4])}
+
+    def close(self):
+        if self.h:
+            self.lib.zkcnn_batch_destroy(ctypes.c_void_p(self.h))
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -87,6 +87,7 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
 extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (ctx->batch) (void) zk_batch_detach(ctx->batch, ctx);
     if (ctx->live_active) (void) zk_live_abort(ctx);
     (void) zk_proof_end(ctx);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
@@ -155,6 +156,7 @@ extern "C" int32_t zk_profile_report(zk_ctx *ctx, char *buf, uint64_t cap, int32
 
 extern "C" int32_t zk_fs_attach(zk_ctx *ctx, const uint32_t *state, const uint64_t *pending) {
     if (!ctx || ((state == nullptr) != (pending == nullptr))) return ZK_ERR_ARG;
+    if (ctx->batch) state = nullptr, pending = nullptr;       // a lane of a batch takes its challenges from its driver: same transcript (the chain is a function of the messages)
     ctx->fs_state = state;
     ctx->fs_pending = pending;
     ctx->tail_active = false;
@@ -173,13 +175,13 @@ extern "C" int32_t zk_proof_begin(zk_ctx *ctx) {
     if (!ctx->counted_active) { ++g_active_proofs[ctx->device & 63]; ctx->counted_active = true; }
     // resident kernels only for a proof that is alone on its GPU when it starts: their workgroups wait for one another (k_mid) and for the host,
     // which is only safe -- and only profitable -- while nothing else competes for the CUs and the hardware queue for long
-    ctx->live_now = g_active_proofs[ctx->device & 63].load() <= 1;
+    ctx->live_now = !ctx->batch && g_active_proofs[ctx->device & 63].load() <= 1;       // (a lane of a batch never is: its rounds are fused launches)
     return ZK_OK;
 }
 extern "C" int32_t zk_proof_end(zk_ctx *ctx) {
     if (!ctx) return ZK_ERR_ARG;
     if (ctx->counted_active) { --g_active_proofs[ctx->device & 63]; ctx->counted_active = false; }
-    ctx->live_now = true;
+    ctx->live_now = !ctx->batch;
     return ZK_OK;
 }
 extern "C" int32_t zk_set_live_rounds(zk_ctx *ctx, int32_t on) {
@@ -194,6 +196,103 @@ extern "C" int32_t zk_fs_stats(zk_ctx *ctx, uint64_t *rounds, uint64_t *phases) 
     *phases = ctx->tail_phases_total + ctx->live_phases_total;
     return ZK_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// lock-step batches (ctx.hpp: zk_batch; the kernels' batched forms and the flush of the sumcheck unit: batch.cuh)
+// ------------------------------------------------------------------------------------------------
+static std::string g_batch_err;
+extern "C" int32_t zk_batch_create(int32_t device, zk_batch **out) {
+    if (!out) return ZK_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { g_batch_err = "no such HIP device"; return ZK_ERR_ARG; }
+    zk_batch *b = new zk_batch();
+    b->device = device;
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_batch_err = hipGetErrorString(e);
+        delete b;
+        return ZK_ERR_HIP;
+    }
+    b->pending.reserve(ZK_BATCH_MAX_LANES);
+    *out = b;
+    return ZK_OK;
+}
+extern "C" int32_t zk_batch_attach(zk_batch *b, zk_ctx *ctx, int32_t *lane) {
+    if (!b || !ctx) return ZK_ERR_ARG;
+    if (ctx->batch || ctx->device != b->device || b->lanes.size() >= ZK_BATCH_MAX_LANES) { b->err = "zk_batch_attach: the context is a lane already, lives on another device, or the batch is full"; return ZK_ERR_ARG; }
+    if (!ctx->circuit_ready || !ctx->circuit) { b->err = "zk_batch_attach: the context holds no circuit"; return ZK_ERR_STATE; }
+    if (!b->lanes.empty() && b->lanes[0]->circuit != ctx->circuit) { b->err = "zk_batch_attach: not the resident circuit of lane 0"; return ZK_ERR_STATE; }
+    if (hipSetDevice(ctx->device) != hipSuccess) return ZK_ERR_HIP;
+    if (ctx->live_active) { int32_t rc = zk_live_abort(ctx); if (rc) return rc; }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return ZK_ERR_HIP;
+    ctx->fs_state = nullptr;
+    ctx->fs_pending = nullptr;
+    ctx->own_stream = ctx->stream;
+    ctx->stream = b->stream;
+    ctx->batch = b;
+    ctx->live_now = false;
+    ctx->lane = (int) b->lanes.size();
+    b->lanes.push_back(ctx);
+    if (lane) *lane = ctx->lane;
+    return ZK_OK;
+}
+extern "C" int32_t zk_batch_detach(zk_batch *b, zk_ctx *ctx) {
+    if (!b || !ctx || ctx->batch != b) return ZK_ERR_ARG;
+    (void) hipSetDevice(b->device);
+    (void) zk_batch_flush(b);
+    (void) hipStreamSynchronize(b->stream);
+    ctx->stream = ctx->own_stream;
+    ctx->own_stream = nullptr;
+    ctx->batch = nullptr;
+    ctx->live_now = true;
+    for (size_t i = 0; i < b->lanes.size(); ++i)
+        if (b->lanes[i] == ctx) { b->lanes.erase(b->lanes.begin() + i); break; }
+    for (size_t i = 0; i < b->lanes.size(); ++i) b->lanes[i]->lane = (int) i;
+    ctx->lane = -1;
+    return ZK_OK;
+}
+extern "C" void zk_batch_destroy(zk_batch *b) {
+    if (!b) return;
+    while (!b->lanes.empty()) (void) zk_batch_detach(b, b->lanes.back());
+    (void) hipSetDevice(b->device);
+    if (b->stream) { (void) hipStreamSynchronize(b->stream); (void) hipStreamDestroy(b->stream); }
+    delete b;
+}
+extern "C" int32_t zk_batch_set_yield(zk_batch *b, zk_yield_fn fn, void *user) {
+    if (!b) return ZK_ERR_ARG;
+    b->yield_fn = fn;
+    b->yield_user = user;
+    return ZK_OK;
+}
+extern "C" int32_t zk_batch_flush(zk_batch *b) {
+    if (!b) return ZK_ERR_ARG;
+    ++b->n_flushes;
+    if (b->pending.empty()) { ++b->n_empty_flushes; return ZK_OK; }
+    if (hipSetDevice(b->device) != hipSuccess) { b->err = "hipSetDevice failed"; return ZK_ERR_HIP; }
+    std::vector<batch_item> items;
+    items.swap(b->pending);
+    b->pending.reserve(ZK_BATCH_MAX_LANES);
+    return zk_batch_flush_sumcheck(b, items);
+}
+int32_t zk_batch_sync_point(zk_ctx *ctx) {
+    zk_batch *b = ctx->batch;
+    if (!b) return ZK_OK;
+    if (b->yield_fn) b->yield_fn(b->yield_user, ctx->lane);
+    for (const batch_item &it : b->pending)
+        if (it.ctx == ctx) {                 // nobody has flushed for this lane (no driver): it does so itself
+            int32_t rc = zk_batch_flush(b);
+            if (rc) ctx->err = b->err;
+            return rc;
+        }
+    return ZK_OK;
+}
+extern "C" int32_t zk_batch_stats(const zk_batch *b, uint64_t out[4]) {
+    if (!b || !out) return ZK_ERR_ARG;
+    out[0] = b->n_launches; out[1] = b->n_lane_launches; out[2] = b->n_flushes; out[3] = b->lanes.size();
+    return ZK_OK;
+}
+extern "C" const char *zk_batch_last_error(const zk_batch *b) { return b ? b->err.c_str() : g_batch_err.c_str(); }
 
 extern "C" const char *zk_last_error(const zk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 extern "C" uint64_t zk_proof_bytes(const zk_ctx *ctx) { return ctx->proof_size; }

@@ -81,6 +81,7 @@ struct circuit_sizes {
 };
 
 struct msm_state;                  // hyrax.hip
+struct zk_batch;                   // below: a lock-step batch of contexts on one stream
 
 // kernel classes of the built-in profiler (HIP events on the context's stream)
 enum prof_class { PC_EQ = 0, PC_GATHER, PC_GATE, PC_GATE_FIX, PC_GATE_SUM, PC_SUM, PC_ROUND_QUAD, PC_ROUND_CUBIC, PC_FOLD, PC_MATVEC,
@@ -94,6 +95,10 @@ struct zk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    // lock-step batch (zk_batch_attach): the context is lane `lane` of `batch` and launches on the batch's stream; own_stream is parked meanwhile
+    zk_batch *batch = nullptr;
+    int lane = -1;
+    hipStream_t own_stream = nullptr;
 
     std::vector<dev_layer> L;
     fr_t *two_mul = nullptr;
@@ -257,6 +262,48 @@ static inline void prof_end(zk_ctx *ctx, int cls) {
         hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, __VA_ARGS__);               \
         prof_end(ctx, cls);                                                               \
     } while (0)
+
+// ---- lock-step batches (include/zkcnn_hip.h: zk_batch_*) ---------------------------------------------------------------------------
+// K contexts that prove K pictures on ONE resident circuit share one stream and walk the protocol in lock step. A launch that has a batched
+// form is not issued by its lane: its argument block is DEFERRED into the batch, the lane yields to its driver, and when every lane is parked
+// zk_batch_flush issues ONE launch per kernel class for all of them (blockIdx.y = lane; the argument blocks travel by value in the kernel
+// argument segment). Everything else a lane launches goes straight onto the shared stream -- lanes are independent of one another, so any
+// interleaving of their launches is valid as long as each lane's own order is kept, which deferral keeps: a lane with a deferred launch does
+// nothing else before the flush.
+#define ZK_BATCH_ARG_BYTES 512
+enum batch_kind { BK_ROUND_FINE = 0, BK_ROUND_QUAD2, BK_COUNT };
+struct batch_item {
+    int kind;
+    zk_ctx *ctx;
+    uint32_t blocks;               // grid.x this lane's launch would have had
+    double bytes;                  // its algorithmic bytes (profiler)
+    alignas(16) unsigned char arg[ZK_BATCH_ARG_BYTES];
+};
+struct zk_batch {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<zk_ctx *> lanes;
+    zk_yield_fn yield_fn = nullptr;
+    void *yield_user = nullptr;
+    std::vector<batch_item> pending;
+    std::string err;
+    // statistics: launches issued by flushes, lane launches they stood for, flushes, flushes that found nothing to do
+    uint64_t n_launches = 0, n_lane_launches = 0, n_flushes = 0, n_empty_flushes = 0;
+};
+int32_t zk_batch_flush_sumcheck(zk_batch *b, std::vector<batch_item> &items);        // sumcheck.hip (batch.cuh): kinds of the sumcheck unit
+// a launch whose kernel has a batched form: deferred when the context is a lane, the caller launches it otherwise (returns false)
+static inline bool zk_batch_defer(zk_ctx *ctx, int kind, const void *arg, size_t arg_bytes, uint32_t blocks, double bytes) {
+    if (!ctx->batch) return false;
+    batch_item it;
+    it.kind = kind; it.ctx = ctx; it.blocks = blocks; it.bytes = bytes;
+    static_assert(ZK_BATCH_ARG_BYTES % 16 == 0, "argument blocks are copied as they are");
+    std::memcpy(it.arg, arg, arg_bytes);
+    ctx->batch->pending.push_back(it);
+    return true;
+}
+// Every point where a lane would wait for the GPU (or needs its deferred launch on the stream): hand the thread to the batch's driver, which
+// runs the other lanes up to their own such points and flushes; without a driver (no yield function) the lane flushes for itself.
+int32_t zk_batch_sync_point(zk_ctx *ctx);
 
 #define ZK_HIP(call)                                                                           \
     do {                                                                                       \

@@ -208,12 +208,12 @@ struct round2_args {
     unsigned long long seq;
 };
 
-// reference src/prover.cpp:368-426 for both table pairs of a layer in one launch
-__global__ void __launch_bounds__(ZK_BLOCK) k_round_quad2(round2_args a) {
-    ZK_LATENCY_PRIO();
+// reference src/prover.cpp:368-426 for both table pairs of a layer in one launch. `bid`: this block's index among the a.blocks[0] + a.blocks[1]
+// blocks of the launch (blockIdx.x; a lane of a batched launch -- batch.cuh -- runs the same body on its own argument block)
+__device__ __forceinline__ void round_quad2_body(const round2_args &a, const uint32_t bid) {
     __shared__ fr_t smem[3 * ZK_BLOCK / 64];
-    const int b = blockIdx.x < a.blocks[0] ? 0 : 1;
-    const uint32_t lb = b ? blockIdx.x - a.blocks[0] : blockIdx.x, nblk = a.blocks[b];
+    const int b = bid < a.blocks[0] ? 0 : 1;
+    const uint32_t lb = b ? bid - a.blocks[0] : bid, nblk = a.blocks[b];
     const fr_t *Vin = a.Vin[b], *Min = a.Min[b];
     fr_t *Vout = a.Vout[b], *Mout = a.Mout[b];
     const uint64_t n = a.n[b];
@@ -271,7 +271,11 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad2(round2_args a) {
     }
     fr_block_sum<3>(acc, smem);
     __syncthreads();
-    grid_finish<3>(acc, a.partials, a.counter, a.slot, a.seq, smem, collapse);
+    grid_finish<3>(acc, a.partials, a.counter, a.slot, a.seq, smem, collapse, a.blocks[0] + a.blocks[1], bid);
+}
+__global__ void __launch_bounds__(ZK_BLOCK) k_round_quad2(round2_args a) {
+    ZK_LATENCY_PRIO();
+    round_quad2_body(a, blockIdx.x);
 }
 
 // Latency-oriented variant for the many small rounds of the interactive loop (tables up to 2^16 entries).
@@ -280,8 +284,14 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad2(round2_args a) {
 //   product  role 0: c = v0 m0                   1: p1 = v1 m1                    2: a = (v1 - v0)(m1 - m0)  (one more)
 // followed by a 4-step butterfly over lanes of equal role. A pair that collapses this round is one item whose
 // roles 0 and 2 produce the final V and M values (the reference's `total == 1` case).
-__global__ void __launch_bounds__(ZK_BLOCK) k_round_quad_fine(round2_args a) {
-    ZK_LATENCY_PRIO();
+// number of blocks the launch has: 64 items per block
+__device__ __host__ __forceinline__ uint32_t round_fine_blocks(const round2_args &a) {
+    uint64_t items = 0;
+    for (int b = 0; b < 2; ++b)
+        if (a.n[b]) items += ((a.first ? a.n[b] == 1 : a.n[b] == 2) ? 1 : (a.first ? a.n[b] / 2 : a.n[b] / 4));
+    return (uint32_t) ((items + ZK_BLOCK / 4 - 1) / (ZK_BLOCK / 4));
+}
+__device__ __forceinline__ void round_quad_fine_body(const round2_args &a, const uint32_t bid) {
     __shared__ fr_t smem[3 * ZK_BLOCK / 64];
     __shared__ fr_t s_role[3][ZK_BLOCK / 64];
     uint64_t items[2];
@@ -291,7 +301,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad_fine(round2_args a) {
         collapse[b] = a.n[b] && (a.first ? a.n[b] == 1 : a.n[b] == 2);
         items[b] = !a.n[b] ? 0 : collapse[b] ? 1 : (a.first ? a.n[b] / 2 : a.n[b] / 4);
     }
-    const uint64_t gi = blockIdx.x * (uint64_t) (ZK_BLOCK / 4) + (threadIdx.x >> 2);
+    const uint64_t gi = bid * (uint64_t) (ZK_BLOCK / 4) + (threadIdx.x >> 2);
     const uint32_t role = threadIdx.x & 3;
     const bool live = gi < items[0] + items[1];
     const int b = (live && gi >= items[0]) ? 1 : 0;
@@ -364,7 +374,12 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_quad_fine(round2_args a) {
         }
     }
     grid_finish<3>(acc, a.partials, a.counter, a.slot, a.seq, smem,
-                   collapse[0] || collapse[1] || (items[0] == 1 && a.n[0]) || (items[1] == 1 && a.n[1]));
+                   collapse[0] || collapse[1] || (items[0] == 1 && a.n[0]) || (items[1] == 1 && a.n[1]),
+                   (uint32_t) ((items[0] + items[1] + ZK_BLOCK / 4 - 1) / (ZK_BLOCK / 4)), bid);
+}
+__global__ void __launch_bounds__(ZK_BLOCK) k_round_quad_fine(round2_args a) {
+    ZK_LATENCY_PRIO();
+    round_quad_fine_body(a, blockIdx.x);
 }
 
 // up to four "evaluate the last variable" requests in one tiny launch: out[i] = n == 2 ? lerp(p[0], p[1], r) : p[0]

@@ -15,6 +15,7 @@
 #include "fs_tail.cuh"
 #include "conv_kernels.cuh"
 #include "prep_kernels.cuh"
+#include "batch.cuh"
 
 // ------------------------------------------------------------------------------------------------
 // building blocks
@@ -121,6 +122,7 @@ int32_t zk_col_combine_dev(zk_ctx *ctx, fr_t *out, const fr_t *Z, const fr_t *L,
 
 // copies `count` elements of d_result to the pinned host mirror and waits for the stream
 static int32_t fetch_result(zk_ctx *ctx, int count) {
+    if (ctx->batch) { int32_t rc = zk_batch_sync_point(ctx); if (rc) return rc; }
     ZK_HIP(hipMemcpyAsync(ctx->h_result, ctx->d_result, (size_t) count * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     return ZK_OK;
@@ -134,6 +136,8 @@ static int32_t fetch_result(zk_ctx *ctx, int count) {
 static int32_t wait_slot(zk_ctx *ctx, unsigned long long seq);
 int32_t zk_wait_slot(zk_ctx *ctx, unsigned long long seq) { return wait_slot(ctx, seq); }
 static int32_t wait_slot(zk_ctx *ctx, unsigned long long seq) {
+    // a lane of a batch: its launch may still be deferred -- the driver runs the other lanes up to here and flushes (ctx.hpp)
+    if (ctx->batch) { int32_t rc = zk_batch_sync_point(ctx); if (rc) return rc; }
     volatile unsigned long long *p = &ctx->h_slot->seq;
     for (uint64_t spins = 0; *p != seq; ++spins) {
         if (spins > (1ull << 21)) {
@@ -797,6 +801,7 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
 // add_term of a phase 2 whose two sums are still on their way (zk_sumcheck_init_phase2): waits for the mapped slot like wait_slot does
 static int32_t resolve_add_term(zk_ctx *ctx) {
     if (!ctx->add_pending) return ZK_OK;
+    if (ctx->batch) { int32_t rc = zk_batch_sync_point(ctx); if (rc) return rc; }
     volatile unsigned long long *p = &ctx->h_aux->seq;
     for (uint64_t spins = 0; *p != ctx->aux_seq; ++spins) {
         if (spins > (1ull << 21)) {
@@ -1156,6 +1161,7 @@ static int32_t host_tail_begin(zk_ctx *ctx) {
     ZK_LAUNCH(PC_FOLD, 0.0, k_export_tables, dim3(1), dim3(512), A);
     ZK_HIP(hipGetLastError());
     const export_out *o = (const export_out *) ctx->h_tail;
+    if (ctx->batch) { int32_t rc = zk_batch_sync_point(ctx); if (rc) return rc; }
     volatile const unsigned long long *p = &o->seq;
     for (uint64_t spins = 0; *p != A.seq; ++spins) {
         if (spins > (1ull << 24)) {
@@ -1236,7 +1242,7 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
     // quads of this round over both pairs (a first round works on pairs, not quads)
     const uint64_t round_quads = ctx->round == 0 ? (ctx->tp[0].len + ctx->tp[1].len) / 2 : (ctx->tp[0].len + ctx->tp[1].len) / 4;
     const bool in_phase = !ctx->live_active && !ctx->tail_active && ctx->phase_rounds > ctx->round && ctx->tp[0].len + ctx->tp[1].len > 0;
-    const bool resident_ok = ctx->live_rounds && ctx->live_now && ctx->host_tail_log < 0 && in_phase;
+    const bool resident_ok = ctx->live_rounds && ctx->live_now && !ctx->batch && ctx->host_tail_log < 0 && in_phase;
     // The middle of a phase (more quads than the single-workgroup kernel takes, tables of at most 2^18 entries): a SEGMENT of rounds in one
     // resident multi-workgroup kernel (k_mid), as long as no table collapses or reaches its last pair. Returns the segment's length (0: none).
     auto plan_segment = [&]() -> int {
@@ -1338,10 +1344,13 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         A.counter = ctx->d_counter;
         A.slot = (host_slot *) ctx->d_slot;
         A.seq = ++ctx->slot_seq;
+        // (a lane of a batch defers the launch: one launch runs this round of every lane -- batch.cuh; wait_slot below hands over to the driver)
         if (fine) {
             const uint32_t blocks = (uint32_t) ((fine_items + ZK_BLOCK / 4 - 1) / (ZK_BLOCK / 4));
-            ZK_LAUNCH(PC_ROUND_QUAD, alg_bytes, k_round_quad_fine, dim3(blocks), dim3(ZK_BLOCK), A);
-        } else ZK_LAUNCH(PC_ROUND_QUAD, alg_bytes, k_round_quad2, dim3(A.blocks[0] + A.blocks[1]), dim3(ZK_BLOCK), A);
+            if (!zk_batch_defer(ctx, BK_ROUND_FINE, &A, sizeof(A), blocks, alg_bytes))
+                ZK_LAUNCH(PC_ROUND_QUAD, alg_bytes, k_round_quad_fine, dim3(blocks), dim3(ZK_BLOCK), A);
+        } else if (!zk_batch_defer(ctx, BK_ROUND_QUAD2, &A, sizeof(A), A.blocks[0] + A.blocks[1], alg_bytes))
+            ZK_LAUNCH(PC_ROUND_QUAD, alg_bytes, k_round_quad2, dim3(A.blocks[0] + A.blocks[1]), dim3(ZK_BLOCK), A);
         ZK_HIP(hipGetLastError());
         for (int b = 0; b < 2; ++b) {
             table_pair &t = ctx->tp[b];

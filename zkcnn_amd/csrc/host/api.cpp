@@ -2,6 +2,7 @@
 // prover on the GPU, the reference verifier driving it.
 #include <stdexcept>
 #include <cstddef>
+#define ZKFIBER_IMPLEMENTATION
 #include "session.hpp"
 #include "verifier_alias.hpp"
 
@@ -129,7 +130,74 @@ struct gpuSession : public sessionT<prover> {
     vector<F> good_picture;            // quantised picture of the witness in HBM (what a refused new_image restores)
 };
 
+// Test hooks (a message corrupted on purpose, a resident witness value overwritten) are part of the library because the parity and
+// soundness tests drive the PRODUCT through them -- but a deployment must opt in: ZKCNN_TEST_HOOKS=1 (tests/conftest.py sets it).
+static bool test_hooks_enabled() {
+    static const bool on = getenv("ZKCNN_TEST_HOOKS") && atoi(getenv("ZKCNN_TEST_HOOKS")) != 0;
+    return on;
+}
+
+// K sessions of one model on one GPU as the lanes of a lock-step batch (include/zkcnn_hip.h: zk_batch_*): their contexts share one stream,
+// their verifier loops one host thread (session.hpp: batchSessionT), and every sumcheck round of the K proofs is ONE kernel launch
+struct gpuBatch : public batchSessionT<gpuSession> {
+    zk_batch *b = nullptr;
+    ~gpuBatch() { if (b) zk_batch_destroy(b); }             // (the lanes' contexts go back to their own streams; the sessions stay their owner's)
+    static void yieldLane(void *, int32_t) { zkfiber::fiber::yield(); }
+};
+
 extern "C" {
+
+void *zkcnn_batch_create(void *const *sessions, int32_t n) {
+    if (!sessions || n < 1 || n > ZK_BATCH_MAX_LANES) return nullptr;
+    try {
+        std::unique_ptr<gpuBatch> g(new gpuBatch());
+        for (int32_t k = 0; k < n; ++k) {
+            gpuSession *s = (gpuSession *) sessions[k];
+            if (!s || !s->p.context()) return nullptr;
+            if (!g->b && zk_batch_create(s->dev, &g->b) != ZK_OK) {
+                fprintf(stderr, "zkcnn_batch_create: %s\n", zk_batch_last_error(nullptr));
+                return nullptr;
+            }
+            if (zk_batch_attach(g->b, s->p.context(), nullptr) != ZK_OK) {
+                fprintf(stderr, "zkcnn_batch_create: lane %d: %s\n", (int) k, zk_batch_last_error(g->b));
+                return nullptr;
+            }
+            g->lanes.push_back(s);
+        }
+        zk_batch_set_yield(g->b, &gpuBatch::yieldLane, nullptr);
+        return g.release();
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkcnn_batch_create: %s\n", e.what());
+        return nullptr;
+    }
+}
+
+int32_t zkcnn_batch_prove(void *batch, const uint64_t *seeds, uint32_t mode, uint8_t *const *transcripts, const uint64_t *caps, zkcnn_result *out, double *wall_s) {
+    if (!batch || !out) return -1;
+    gpuBatch *g = (gpuBatch *) batch;
+    if ((mode & ZKCNN_MODE_TAMPER) && !test_hooks_enabled()) return -4;
+    const double t0 = gpuSession::now();
+    int flush_rc = ZK_OK;
+    zk_batch *b = g->b;
+    int rc = g->prove(seeds, mode, transcripts, caps, out, [b, &flush_rc]() { int r = zk_batch_flush(b); if (r != ZK_OK && flush_rc == ZK_OK) flush_rc = r; });
+    for (size_t k = 0; k < g->lanes.size(); ++k) out[k].upload_s = g->lanes[k]->p.uploadTime();
+    if (wall_s) *wall_s = gpuSession::now() - t0;
+    if (flush_rc != ZK_OK) {
+        std::snprintf(out[0].message, sizeof(out[0].message), "zk_batch_flush: %s", zk_batch_last_error(b));
+        return -2;
+    }
+    return rc;
+}
+
+int32_t zkcnn_batch_stats(void *batch, uint64_t out[5]) {
+    if (!batch || !out) return -1;
+    gpuBatch *g = (gpuBatch *) batch;
+    if (zk_batch_stats(g->b, out) != ZK_OK) return -2;
+    out[4] = g->rounds_of_flushes;
+    return 0;
+}
+
+void zkcnn_batch_destroy(void *batch) { delete (gpuBatch *) batch; }
 
 void *zkcnn_session_create(const zkcnn_model_desc *desc, int32_t device) {
     if (!desc) return nullptr;
@@ -180,12 +248,6 @@ void *zkcnn_session_create_calibrated(const zkcnn_model_desc *desc, const int32_
     }
 }
 
-// Test hooks (a message corrupted on purpose, a resident witness value overwritten) are part of the library because the parity and
-// soundness tests drive the PRODUCT through them -- but a deployment must opt in: ZKCNN_TEST_HOOKS=1 (tests/conftest.py sets it).
-static bool test_hooks_enabled() {
-    static const bool on = getenv("ZKCNN_TEST_HOOKS") && atoi(getenv("ZKCNN_TEST_HOOKS")) != 0;
-    return on;
-}
 
 int32_t zkcnn_session_prove(void *session, uint64_t seed, uint32_t mode, uint8_t *transcript, uint64_t cap, zkcnn_result *out) {
     if (!session || !out) return -1;

@@ -7,6 +7,7 @@
 #include "../../../include/zkcnn_api.h"
 #include "models.hpp"
 #include "replay.hpp"
+#include "fiber.hpp"
 #include "../ff/hash_to_curve.hpp"
 
 // provers that can continue the Fiat-Shamir chain themselves (the HIP-backed one: prover.hpp) overload this; everybody else ignores it
@@ -234,6 +235,84 @@ struct sessionT {
         out->transcript_len = len;
         std::snprintf(out->message, sizeof(out->message), "%s", why.c_str());
         out->wall_s = now() - t0;
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// batchSession: K proofs in lock step, driven by ONE host thread.
+//
+// The reference's main() runs one verifier loop against one prover (reference src/main_demo_vgg.cpp:36-41 -> src/verifier.cpp:118-373).
+// K sessions that prove K pictures on the same circuit make the same calls in the same order; here their K verifier loops -- the unchanged
+// verifierT above, one per lane, each with its own challenge stream -- run as fibers of the calling thread (fiber.hpp). A lane runs until
+// its prover would wait for the GPU (the HIP library's yield callback: include/zkcnn_hip.h, zk_batch_set_yield) or, for a prover without
+// a GPU, until it ends; when every lane is parked `flush` issues what they deferred -- ONE kernel launch per round for all lanes -- and the
+// lanes continue. Every protocol mode of sessionT::prove works unchanged (seeded / OS challenges, Fiat-Shamir on the host, masking,
+// tampering), and each lane's transcript is byte for byte what it would be alone: the lanes share nothing but the thread.
+// ------------------------------------------------------------------------------------------------------------------------------------
+
+// the thread-local protocol state of one proof (challenge stream, Fiat-Shamir override, the prover's private coins, the result row): kept
+// per lane and exchanged with the thread's whenever a lane gets or gives up the thread
+struct laneState {
+    zkff::Xoshiro challenge;
+    bool seeded = false;
+    zkff::ChallengeSource *override_src = nullptr;
+    zkff::PrivateCoins coins;
+    vector<string> row;
+    laneState() : row(OUT_COLUMN_CNT, "") { challenge.seed(0); }
+    void exchange() {
+        std::swap(challenge, zkff::challengeStream());
+        std::swap(seeded, zkff::challengeSeeded());
+        std::swap(override_src, zkff::challengeOverride());
+        std::swap(coins, zkff::privateCoins());
+        row.swap(output_tb);
+    }
+};
+
+template <class SessionT>
+struct batchSessionT {
+    std::vector<SessionT *> lanes;          // not owned
+    uint64_t rounds_of_flushes = 0;         // passes of the driver loop (each ends in one flush)
+
+    // One proof per lane. seeds / transcripts / caps / out: one entry per lane (transcripts may be NULL, or hold NULL entries).
+    // flush: called whenever every unfinished lane is parked. Returns 0, or the first lane's non-zero return code (every lane's
+    // result is filled in either way; an exception inside a lane ends that lane only: code -2, message in out[k]).
+    template <class Flush>
+    int prove(const uint64_t *seeds, uint32_t mode, uint8_t *const *transcripts, const uint64_t *caps, zkcnn_result *out, Flush flush) {
+        const size_t K = lanes.size();
+        std::vector<int> rc(K, 0);
+        std::vector<laneState> st(K);
+        std::vector<std::unique_ptr<zkfiber::fiber>> fb(K);
+        for (size_t k = 0; k < K; ++k) {
+            SessionT *s = lanes[k];
+            int *code = &rc[k];
+            zkcnn_result *res = &out[k];
+            uint8_t *tr = transcripts ? transcripts[k] : nullptr;
+            const uint64_t cap = (tr && caps) ? caps[k] : 0, seed = seeds ? seeds[k] : 0;
+            fb[k].reset(new zkfiber::fiber([s, code, res, tr, cap, seed, mode]() {
+                try {
+                    *code = s->prove(seed, mode, tr, cap, res);
+                } catch (const std::exception &e) {
+                    std::memset(res, 0, sizeof(*res));
+                    std::snprintf(res->message, sizeof(res->message), "%s", e.what());
+                    *code = -2;
+                }
+            }));
+        }
+        for (;;) {
+            bool any = false;
+            for (size_t k = 0; k < K; ++k) {
+                if (fb[k]->done()) continue;
+                st[k].exchange();
+                fb[k]->resume();                       // (the lane's function catches everything: nothing propagates from here)
+                st[k].exchange();
+                any = any || !fb[k]->done();
+            }
+            ++rounds_of_flushes;
+            flush();
+            if (!any) break;
+        }
+        for (size_t k = 0; k < K; ++k) if (rc[k]) return rc[k];
         return 0;
     }
 };
