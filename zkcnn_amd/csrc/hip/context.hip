@@ -214,7 +214,12 @@ extern "C" int32_t zk_batch_create(int32_t device, zk_batch **out) {
         delete b;
         return ZK_ERR_HIP;
     }
-    b->pending.reserve(ZK_BATCH_MAX_LANES);
+    b->pending.reserve(16 * ZK_BATCH_MAX_LANES);
+    const size_t ring_bytes = (size_t) ZK_BATCH_RING_SLOTS * ZK_BATCH_MAX_LANES * ZK_BATCH_ARG_BYTES;
+    bool ok = hipHostMalloc((void **) &b->h_ring, ring_bytes, hipHostMallocMapped | hipHostMallocNonCoherent) == hipSuccess &&
+              hipHostGetDevicePointer((void **) &b->d_ring, b->h_ring, 0) == hipSuccess;
+    for (int q = 0; ok && q < 4; ++q) ok = hipEventCreateWithFlags(&b->ring_ev[q], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { g_batch_err = "zk_batch_create: no pinned memory for the argument ring"; zk_batch_destroy(b); return ZK_ERR_NOMEM; }
     *out = b;
     return ZK_OK;
 }
@@ -245,6 +250,7 @@ extern "C" int32_t zk_batch_detach(zk_batch *b, zk_ctx *ctx) {
     ctx->stream = ctx->own_stream;
     ctx->own_stream = nullptr;
     ctx->batch = nullptr;
+    ctx->n_pending = 0;
     ctx->live_now = true;
     for (size_t i = 0; i < b->lanes.size(); ++i)
         if (b->lanes[i] == ctx) { b->lanes.erase(b->lanes.begin() + i); break; }
@@ -257,6 +263,8 @@ extern "C" void zk_batch_destroy(zk_batch *b) {
     while (!b->lanes.empty()) (void) zk_batch_detach(b, b->lanes.back());
     (void) hipSetDevice(b->device);
     if (b->stream) { (void) hipStreamSynchronize(b->stream); (void) hipStreamDestroy(b->stream); }
+    for (int q = 0; q < 4; ++q) if (b->ring_ev[q]) (void) hipEventDestroy(b->ring_ev[q]);
+    if (b->h_ring) (void) hipHostFree(b->h_ring);
     delete b;
 }
 extern "C" int32_t zk_batch_set_yield(zk_batch *b, zk_yield_fn fn, void *user) {
@@ -265,6 +273,29 @@ extern "C" int32_t zk_batch_set_yield(zk_batch *b, zk_yield_fn fn, void *user) {
     b->yield_user = user;
     return ZK_OK;
 }
+// one slot of the pinned argument ring (launch.cuh: argument blocks too large for the kernel argument segment)
+int32_t zk_batch_ring_slot(zk_batch *b, size_t bytes, void **host, void **dev) {
+    const size_t slot_bytes = (size_t) ZK_BATCH_MAX_LANES * ZK_BATCH_ARG_BYTES;
+    if (bytes > slot_bytes) { b->err = "argument ring: block too large"; return ZK_ERR_ARG; }
+    const uint32_t slot = b->ring_next, quarter = ZK_BATCH_RING_SLOTS / 4;
+    // entering a quarter of the ring: whatever read it one lap ago must be done; leaving one: mark the stream
+    if (slot % quarter == 0) {
+        const uint32_t q = slot / quarter, prev = (q + 3) % 4;
+        if (b->ring_ev_set[q] && hipEventSynchronize(b->ring_ev[q]) != hipSuccess) { b->err = "argument ring: event wait failed"; return ZK_ERR_HIP; }
+        if (b->ring_count) {                 // (the quarter just left: its last reader is on the stream by now)
+            if (hipEventRecord(b->ring_ev[prev], b->stream) != hipSuccess) { b->err = "argument ring: event record failed"; return ZK_ERR_HIP; }
+            b->ring_ev_set[prev] = true;
+        }
+    }
+    *host = b->h_ring + (size_t) slot * slot_bytes;
+    *dev = b->d_ring + (size_t) slot * slot_bytes;
+    b->ring_next = (slot + 1) % ZK_BATCH_RING_SLOTS;
+    ++b->ring_count;
+    return ZK_OK;
+}
+
+// every deferred launch, generation by generation: the g-th deferred launch of every lane together, one launch per kernel (lanes in lock
+// step defer the same kernel at the same position; anything else still runs, in as many launches as there are kernels)
 extern "C" int32_t zk_batch_flush(zk_batch *b) {
     if (!b) return ZK_ERR_ARG;
     ++b->n_flushes;
@@ -272,19 +303,45 @@ extern "C" int32_t zk_batch_flush(zk_batch *b) {
     if (hipSetDevice(b->device) != hipSuccess) { b->err = "hipSetDevice failed"; return ZK_ERR_HIP; }
     std::vector<batch_item> items;
     items.swap(b->pending);
-    b->pending.reserve(ZK_BATCH_MAX_LANES);
-    return zk_batch_flush_sumcheck(b, items);
+    b->pending.reserve(16 * ZK_BATCH_MAX_LANES);
+    uint32_t gens = 0;
+    for (const batch_item &it : items) gens = std::max(gens, it.gen + 1);
+    for (zk_ctx *c : b->lanes) c->n_pending = 0;
+    std::vector<char> done(items.size(), 0);
+    int32_t rc = ZK_OK;
+    for (uint32_t g = 0; g < gens && rc == ZK_OK; ++g)
+        for (size_t i = 0; i < items.size() && rc == ZK_OK; ++i) {
+            if (done[i] || items[i].gen != g) continue;
+            const batch_item *group[ZK_BATCH_MAX_LANES];
+            uint32_t n = 0, gx = 1, gy = 1;
+            double bytes = 0;
+            for (size_t j = i; j < items.size() && n < ZK_BATCH_MAX_LANES; ++j)
+                if (!done[j] && items[j].gen == g && items[j].launch == items[i].launch) {
+                    group[n++] = &items[j];
+                    done[j] = 1;
+                    gx = std::max(gx, items[j].gx);
+                    gy = std::max(gy, items[j].gy);
+                    bytes += items[j].bytes;
+                }
+            zk_ctx *ctx = items[i].ctx;          // (the profiler books a fused launch on its first lane)
+            prof_begin(ctx, items[i].prof_class, bytes);
+            rc = items[i].launch(b, group, n, gx, gy);
+            prof_end(ctx, items[i].prof_class);
+            ++b->n_launches;
+            b->n_lane_launches += n;
+        }
+    if (rc != ZK_OK && b->err.empty()) b->err = "a fused launch failed";
+    return rc;
 }
 int32_t zk_batch_sync_point(zk_ctx *ctx) {
     zk_batch *b = ctx->batch;
     if (!b) return ZK_OK;
     if (b->yield_fn) b->yield_fn(b->yield_user, ctx->lane);
-    for (const batch_item &it : b->pending)
-        if (it.ctx == ctx) {                 // nobody has flushed for this lane (no driver): it does so itself
-            int32_t rc = zk_batch_flush(b);
-            if (rc) ctx->err = b->err;
-            return rc;
-        }
+    if (ctx->n_pending) {                    // nobody has flushed for this lane (no driver): it does so itself
+        int32_t rc = zk_batch_flush(b);
+        if (rc) ctx->err = b->err;
+        return rc;
+    }
     return ZK_OK;
 }
 extern "C" int32_t zk_batch_stats(const zk_batch *b, uint64_t out[4]) {

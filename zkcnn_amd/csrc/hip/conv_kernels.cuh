@@ -13,7 +13,9 @@
 #include "types.cuh"
 
 // part[(chunk * K + k) * len + o] = sum over the chunk's co of A_k[co] * W[co * len + o];  len = CI * m^2; grid (ceil(len / 256), chunks)
-__global__ void __launch_bounds__(ZK_BLOCK) k_conv_wa(fr_t *part, const fr_t *W, const fr_t *tabs, uint32_t len, uint32_t CO, uint32_t per, int K) {
+struct k_conv_wa_f {
+    fr_t *part; const fr_t *W; const fr_t *tabs; uint32_t len, CO, per; int K;
+    __device__ __forceinline__ void operator()() const {
     const uint32_t o = blockIdx.x * ZK_BLOCK + threadIdx.x;
     if (o >= len) return;
     const uint32_t c0 = blockIdx.y * per, c1 = min(CO, c0 + per);
@@ -26,7 +28,8 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_conv_wa(fr_t *part, const fr_t *W,
     }
     fr_store(part + ((size_t) blockIdx.y * K) * len + o, acc0);
     if (K > 1) fr_store(part + ((size_t) blockIdx.y * K + 1) * len + o, acc1);
-}
+    }
+};
 
 // window origin -> output coordinate; false if (t - d) is not the origin of a window of the layer
 __device__ __forceinline__ bool conv_out_coord(uint32_t t, uint32_t d, const conv_desc &c, uint32_t n_out, uint32_t &X) {
@@ -37,7 +40,9 @@ __device__ __forceinline__ bool conv_out_coord(uint32_t t, uint32_t d, const con
 }
 
 // phase 1: M[u] for every entry of the previous layer's table (u >= the layer's size: 0)
-__global__ void __launch_bounds__(ZK_BLOCK) k_conv_m1(fr_t *M, const fr_t *WA, const fr_t *tabs, conv_desc c, int K, uint64_t len) {
+struct k_conv_m1_f {
+    fr_t *M; const fr_t *WA; const fr_t *tabs; conv_desc c; int K; uint64_t len;
+    __device__ __forceinline__ void operator()() const {
     const uint64_t n_u = (uint64_t) c.pp * c.CI * c.nxi * c.nyi;
     const uint32_t wlen = c.CI * c.m * c.m;
     for (uint64_t u = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x; u < len; u += (uint64_t) gridDim.x * ZK_BLOCK) {
@@ -61,12 +66,16 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_conv_m1(fr_t *M, const fr_t *WA, c
         }
         fr_store(M + u, acc);
     }
-}
+    }
+};
 
 // phase 2, step 1: E[k * m^2 + dx * m + dy]; grid (m^2, K)
-__global__ void __launch_bounds__(ZK_BLOCK) k_conv_e(fr_t *E, const fr_t *tabs, conv_desc c) {
+struct k_conv_e_f {
+    fr_t *E; const fr_t *tabs; conv_desc c; int K;
+    __device__ __forceinline__ void operator()() const {
     __shared__ fr_t smem[ZK_BLOCK / 64];
     const int k = blockIdx.y;
+    if (k >= K || blockIdx.x >= c.m * c.m) return;               // (rows of a fused grid beyond this lane's own)
     const uint32_t dx = blockIdx.x / c.m, dy = blockIdx.x % c.m;
     const fr_t *S = tabs + (k ? CT_S1 : CT_S0) * CONV_TAB_STRIDE, *D = tabs + CT_D * CONV_TAB_STRIDE;
     fr_t acc[1] = {fr_zero()};
@@ -83,9 +92,12 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_conv_e(fr_t *E, const fr_t *tabs, 
         for (uint32_t p = 0; p < c.pp; ++p) g = fr_add(g, fr_mul(fr_load(P + p), fr_load(Pu + p)));
         fr_store(E + (size_t) k * c.m * c.m + blockIdx.x, fr_mul(acc[0], g));
     }
-}
+    }
+};
 // phase 2, step 2: AE[co * m^2 + d] = sum_k A_k[co] E_k[d]  (CO * m^2 entries), then CV[ci] = Vu * C[ci]  (CI entries) behind them
-__global__ void __launch_bounds__(ZK_BLOCK) k_conv_ae(fr_t *AE, const fr_t *E, const fr_t *tabs, conv_desc c, int K, fr_t Vu) {
+struct k_conv_ae_f {
+    fr_t *AE; const fr_t *E; const fr_t *tabs; conv_desc c; int K; fr_t Vu;
+    __device__ __forceinline__ void operator()() const {
     const uint32_t mm = c.m * c.m, n_ae = c.CO * mm;
     const uint32_t i = blockIdx.x * ZK_BLOCK + threadIdx.x;
     if (i < n_ae) {
@@ -96,9 +108,12 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_conv_ae(fr_t *AE, const fr_t *E, c
     } else if (i < n_ae + c.CI) {
         fr_store(AE + i, fr_mul(Vu, fr_load(tabs + CT_C * CONV_TAB_STRIDE + (i - n_ae))));
     }
-}
+    }
+};
 // phase 2, step 3: M[v'] = CV[ci] * AE[co, d] for the weight v' stands for (ori_v: subset number -> raw layer-0 index); v' >= n_v: 0
-__global__ void __launch_bounds__(ZK_BLOCK) k_conv_m2(fr_t *M, const uint32_t *ori_v, const fr_t *AE, conv_desc c, uint32_t n_v, uint64_t len) {
+struct k_conv_m2_f {
+    fr_t *M; const uint32_t *ori_v; const fr_t *AE; conv_desc c; uint32_t n_v; uint64_t len;
+    __device__ __forceinline__ void operator()() const {
     const uint32_t mm = c.m * c.m;
     const fr_t *CV = AE + (size_t) c.CO * mm;
     for (uint64_t v = blockIdx.x * (uint64_t) ZK_BLOCK + threadIdx.x; v < len; v += (uint64_t) gridDim.x * ZK_BLOCK) {
@@ -106,5 +121,6 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_conv_m2(fr_t *M, const uint32_t *o
         const uint32_t raw = ori_v[v] - c.wstart, d = raw % mm, q = raw / mm;
         fr_store(M + v, fr_mul(fr_load(CV + (q & (c.CI - 1))), fr_load(AE + (size_t) (q >> c.bc_i) * mm + d)));
     }
-}
+    }
+};
 

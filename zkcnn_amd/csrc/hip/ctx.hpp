@@ -98,6 +98,7 @@ struct zk_ctx {
     // lock-step batch (zk_batch_attach): the context is lane `lane` of `batch` and launches on the batch's stream; own_stream is parked meanwhile
     zk_batch *batch = nullptr;
     int lane = -1;
+    uint32_t n_pending = 0;        // launches this lane has deferred since the batch's last flush
     hipStream_t own_stream = nullptr;
 
     std::vector<dev_layer> L;
@@ -258,27 +259,34 @@ static inline void prof_end(zk_ctx *ctx, int cls) {
 }
 #define ZK_LAUNCH(cls, bytes, kern, grid, block, ...)                                    \
     do {                                                                                  \
+        ZK_ORDER();                                                                       \
         prof_begin(ctx, cls, bytes);                                                      \
         hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, __VA_ARGS__);               \
         prof_end(ctx, cls);                                                               \
     } while (0)
 
 // ---- lock-step batches (include/zkcnn_hip.h: zk_batch_*) ---------------------------------------------------------------------------
-// K contexts that prove K pictures on ONE resident circuit share one stream and walk the protocol in lock step. A launch that has a batched
-// form is not issued by its lane: its argument block is DEFERRED into the batch, the lane yields to its driver, and when every lane is parked
-// zk_batch_flush issues ONE launch per kernel class for all of them (blockIdx.y = lane; the argument blocks travel by value in the kernel
-// argument segment). Everything else a lane launches goes straight onto the shared stream -- lanes are independent of one another, so any
-// interleaving of their launches is valid as long as each lane's own order is kept, which deferral keeps: a lane with a deferred launch does
-// nothing else before the flush.
-#define ZK_BATCH_ARG_BYTES 512
-enum batch_kind { BK_ROUND_FINE = 0, BK_ROUND_QUAD2, BK_COUNT };
+// K contexts that prove K pictures on ONE resident circuit share one stream and walk the protocol in lock step. A launch whose kernel is
+// written as a functor (launch.cuh: zk_launch_f) is not issued by a lane: its argument block is DEFERRED into the batch, in the lane's own
+// order (`gen` = how many launches the lane has deferred since the last flush). When every lane is parked -- each has reached a point where
+// it needs a result from the GPU and has handed the thread to the batch's driver -- zk_batch_flush issues, generation by generation, ONE
+// launch per kernel for all lanes that deferred it (blockIdx.z = lane; the argument blocks travel by value in the kernel argument segment,
+// or through a pinned ring when eight of them exceed its 4 KB). Anything else a lane puts on the stream (a kernel without a functor form, a
+// copy, a fill) first flushes what the lane has deferred, so each lane's own order is kept; lanes are independent of one another, so any
+// interleaving between lanes is valid.
+#define ZK_BATCH_ARG_BYTES 2560
+struct batch_item;
+typedef int32_t (*batch_launch_fn)(zk_batch *b, const batch_item *const *items, uint32_t n, uint32_t gx, uint32_t gy);
 struct batch_item {
-    int kind;
+    batch_launch_fn launch;        // launch.cuh: launch_lanes<F, BLOCK> -- also the key fused launches are grouped by
     zk_ctx *ctx;
-    uint32_t blocks;               // grid.x this lane's launch would have had
+    uint32_t gen;                  // position in the lane's own sequence of deferred launches
+    uint32_t gx, gy;               // the grid this lane's launch would have had
+    int prof_class;
     double bytes;                  // its algorithmic bytes (profiler)
     alignas(16) unsigned char arg[ZK_BATCH_ARG_BYTES];
 };
+#define ZK_BATCH_RING_SLOTS 64
 struct zk_batch {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -287,23 +295,22 @@ struct zk_batch {
     void *yield_user = nullptr;
     std::vector<batch_item> pending;
     std::string err;
+    // argument blocks too large for the kernel argument segment: a ring of slots in pinned host memory the kernels read in place (written
+    // before the launch, read-only during it; an event per quarter of the ring guards reuse)
+    unsigned char *h_ring = nullptr, *d_ring = nullptr;
+    uint32_t ring_next = 0;
+    uint64_t ring_count = 0;
+    hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ring_ev_set[4] = {false, false, false, false};
     // statistics: launches issued by flushes, lane launches they stood for, flushes, flushes that found nothing to do
     uint64_t n_launches = 0, n_lane_launches = 0, n_flushes = 0, n_empty_flushes = 0;
 };
-int32_t zk_batch_flush_sumcheck(zk_batch *b, std::vector<batch_item> &items);        // sumcheck.hip (batch.cuh): kinds of the sumcheck unit
-// a launch whose kernel has a batched form: deferred when the context is a lane, the caller launches it otherwise (returns false)
-static inline bool zk_batch_defer(zk_ctx *ctx, int kind, const void *arg, size_t arg_bytes, uint32_t blocks, double bytes) {
-    if (!ctx->batch) return false;
-    batch_item it;
-    it.kind = kind; it.ctx = ctx; it.blocks = blocks; it.bytes = bytes;
-    static_assert(ZK_BATCH_ARG_BYTES % 16 == 0, "argument blocks are copied as they are");
-    std::memcpy(it.arg, arg, arg_bytes);
-    ctx->batch->pending.push_back(it);
-    return true;
-}
-// Every point where a lane would wait for the GPU (or needs its deferred launch on the stream): hand the thread to the batch's driver, which
-// runs the other lanes up to their own such points and flushes; without a driver (no yield function) the lane flushes for itself.
+// Every point where a lane needs its deferred launches on the stream (it is about to wait for a result, or to put something else on the
+// stream): hand the thread to the batch's driver, which runs the other lanes up to their own such points and flushes; without a driver (no
+// yield function) the lane flushes for itself.
 int32_t zk_batch_sync_point(zk_ctx *ctx);
+// before anything that is not deferred goes onto the stream of a context: keep the lane's order
+#define ZK_ORDER() do { if (ctx->batch && ctx->n_pending) { int32_t rc_o_ = zk_batch_sync_point(ctx); if (rc_o_) return rc_o_; } } while (0)
 
 #define ZK_HIP(call)                                                                           \
     do {                                                                                       \
@@ -330,8 +337,8 @@ static inline uint32_t grid_for(uint64_t work, uint32_t cap = 2048) {
 // generation on the GPU), verifier.hip (the verifier's wiring predicates), hyrax.hip (commitment) ----
 #define ZK_CHECK_READY_ROUND() do { if (!ctx || !ctx->circuit_ready) return ZK_ERR_STATE; ZK_HIP(hipSetDevice(ctx->device)); } while (0)
 // every entry point but the four round calls first sends a resident round kernel home (its phase was abandoned)
-#define ZK_CHECK_READY() do { ZK_CHECK_READY_ROUND(); if (ctx->live_active) { int32_t rc_ = zk_live_abort(ctx); if (rc_) return rc_; } } while (0)
-#define ZK_CHECK_CTX() do { if (!ctx) return ZK_ERR_ARG; ZK_HIP(hipSetDevice(ctx->device)); if (ctx->live_active) { int32_t rc_ = zk_live_abort(ctx); if (rc_) return rc_; } } while (0)
+#define ZK_CHECK_READY() do { ZK_CHECK_READY_ROUND(); if (ctx->live_active) { int32_t rc_ = zk_live_abort(ctx); if (rc_) return rc_; } ZK_ORDER(); } while (0)
+#define ZK_CHECK_CTX() do { if (!ctx) return ZK_ERR_ARG; ZK_HIP(hipSetDevice(ctx->device)); if (ctx->live_active) { int32_t rc_ = zk_live_abort(ctx); if (rc_) return rc_; } ZK_ORDER(); } while (0)
 static inline const HFr &H(const uint64_t *p) { return *reinterpret_cast<const HFr *>(p); }
 static inline void put(uint64_t *dst, const HFr &x) { std::memcpy(dst, &x, 32); }
 

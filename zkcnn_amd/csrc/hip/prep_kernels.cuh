@@ -124,8 +124,10 @@ __device__ __forceinline__ void prep_small_block(const prep_small_job &J, uint32
     for (uint32_t j = threadIdx.x; j < N; j += ZK_BLOCK) fr_store(T + j, fr_mul(h[0][j & mask], h[1][j >> fh]));
 }
 
-__global__ void __launch_bounds__(ZK_BLOCK) k_prep(prep_args a) {
-    ZK_LATENCY_PRIO();
+struct k_prep_f {
+    prep_args a;
+    __device__ __forceinline__ void operator()() const {
+    ZK_LATENCY_PRIO_F();
     const uint32_t blk = blockIdx.x;
     for (int k = 0; k < a.n_eq; ++k)
         if (blk >= a.eq[k].blk0 && blk < a.eq[k].blk0 + a.eq[k].nblk) { prep_eq_block(a.eq[k], a.r, blk - a.eq[k].blk0); return; }
@@ -147,7 +149,8 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_prep(prep_args a) {
         return;
     }
     if (a.sm.nblk && blk >= a.sm.blk0 && blk < a.sm.blk0 + a.sm.nblk) prep_small_block(a.sm, blk - a.sm.blk0);
-}
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // gate scatters of a phase in one launch (k_gate_reduce of kernels.cuh with the group size as a run-time bound, one block range per list),
@@ -177,6 +180,7 @@ struct gate_multi_args {
     uint32_t *counter;
     host_slot *aux;
     unsigned long long aux_seq;
+    uint32_t nblocks, pad_;          // blocks of the whole launch
 };
 
 __device__ __forceinline__ fr_t gate_term2(const gate_rec &rc, const gate_multi_args &a, int post_scale) {
@@ -193,9 +197,12 @@ __device__ __forceinline__ fr_t gate_term2(const gate_rec &rc, const gate_multi_
     return t;
 }
 
-__global__ void __launch_bounds__(ZK_BLOCK) k_gate_multi(gate_multi_args a) {
-    ZK_LATENCY_PRIO();
+struct k_gate_multi_f {
+    gate_multi_args a;
+    __device__ __forceinline__ void operator()() const {
+    ZK_LATENCY_PRIO_F();
     const uint32_t blk = blockIdx.x;
+    if (blk >= a.nblocks) return;               // (rows of a fused grid beyond this lane's own)
     if (a.sum_nblk && blk >= a.sum_blk0 && blk < a.sum_blk0 + a.sum_nblk) {
         __shared__ fr_t smem[2 * ZK_BLOCK / 64];
         const uint32_t lb = blk - a.sum_blk0;
@@ -235,11 +242,14 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_gate_multi(gate_multi_args a) {
         val = frw_reduce<5>(acc);
     }
     gate_segment_store(key, val, live, idx, L.n, L.out, a.carry_key + L.carry0, a.carry_val + L.carry0, L.post_scale != 0, L.post, lb, L.direct != 0);
-}
+    }
+};
 
 // carries of up to two lists: slots [0, n0) belong to out0, [n0, n0 + n1) to out1
-__global__ void k_gate_fixup2(fr_t *out0, fr_t *out1, const uint32_t *carry_key, const fr_t *carry_val, uint64_t n0, uint64_t n1) {
-    ZK_LATENCY_PRIO();
+struct k_gate_fixup2_f {
+    fr_t *out0, *out1; const uint32_t *carry_key; const fr_t *carry_val; uint64_t n0, n1;
+    __device__ __forceinline__ void operator()() const {
+    ZK_LATENCY_PRIO_F();
     for (uint64_t s = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; s < n0 + n1; s += (uint64_t) gridDim.x * blockDim.x) {
         const uint64_t lo = s < n0 ? 0 : n0, hi = s < n0 ? n0 : n0 + n1;
         fr_t *out = s < n0 ? out0 : out1;
@@ -261,4 +271,5 @@ __global__ void k_gate_fixup2(fr_t *out0, fr_t *out1, const uint32_t *carry_key,
         }
         fr_store(out + key, total);
     }
-}
+    }
+};

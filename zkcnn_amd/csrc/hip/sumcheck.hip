@@ -15,7 +15,6 @@
 #include "fs_tail.cuh"
 #include "conv_kernels.cuh"
 #include "prep_kernels.cuh"
-#include "batch.cuh"
 
 // ------------------------------------------------------------------------------------------------
 // building blocks
@@ -80,7 +79,7 @@ struct prep_plan {
     int32_t launch(zk_ctx *ctx) {
         if (overflow) { ctx->err = "phase preparation: too many jobs for one launch"; return ZK_ERR_STATE; }
         if (!blocks) return ZK_OK;
-        ZK_LAUNCH(PC_EQ, 0.0, k_prep, dim3(blocks), dim3(ZK_BLOCK), A);
+        zk_launch_f(ctx, PC_EQ, 0.0, dim3(blocks), k_prep_f{A});
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
@@ -202,12 +201,13 @@ static int32_t gate_multi(zk_ctx *ctx, int phase, const dev_layer &prev, const g
     A.val0 = ctx->L[0].val; A.val_prev = prev.val; A.two_mul = ctx->two_mul;
     A.Vu0 = to_dev(ctx->V_u0); A.Vu1 = to_dev(ctx->V_u1);
     A.carry_key = ctx->carry_key; A.carry_val = ctx->carry_val;
-    ZK_LAUNCH(PC_GATE, gate_bytes, k_gate_multi, dim3(blocks), dim3(ZK_BLOCK), A);
+    A.nblocks = blocks;
+    zk_launch_f(ctx, PC_GATE, gate_bytes, dim3(blocks), k_gate_multi_f{A});
     if (need_fix) {
         const uint64_t n0 = (A.nlists > 0 && !A.L[0].direct) ? 2ull * A.L[0].nblk : 0, n1 = (A.nlists > 1 && !A.L[1].direct) ? 2ull * A.L[1].nblk : 0;
         // (carry slots are handed out in list order: a direct list takes none)
         fr_t *o0 = n0 ? A.L[0].out : (n1 ? A.L[1].out : nullptr), *o1 = n0 && n1 ? A.L[1].out : nullptr;
-        ZK_LAUNCH(PC_GATE_FIX, 0.0, k_gate_fixup2, dim3(grid_for(n0 + n1)), dim3(ZK_BLOCK), o0, o1, ctx->carry_key, ctx->carry_val, n0 ? n0 : n1, n0 ? n1 : 0);
+        zk_launch_f(ctx, PC_GATE_FIX, 0.0, dim3(grid_for(n0 + n1)), k_gate_fixup2_f{o0, o1, ctx->carry_key, ctx->carry_val, n0 ? n0 : n1, n0 ? n1 : 0});
     }
     ZK_HIP(hipGetLastError());
     return ZK_OK;
@@ -311,10 +311,10 @@ static int32_t strided_matvec(zk_ctx *ctx, fr_t *out, const fr_t *val, const fr_
 // folds table `b`'s V (and M if with_m) with r; len must be >= 2
 static int32_t fold_pair(zk_ctx *ctx, table_pair &t, const HFr &r, bool with_m) {
     const fr_t rr = to_dev(r);
-    ZK_LAUNCH(PC_FOLD, 0.0, k_fold, dim3(grid_for(t.len / 2)), dim3(ZK_BLOCK), vin(t), t.V[t.cur ^ 1], t.len, rr);
+    zk_launch_f(ctx, PC_FOLD, 0.0, dim3(grid_for(t.len / 2)), k_fold_f{vin(t), t.V[t.cur ^ 1], t.len, rr});
     t.Vsrc = nullptr;
     if (with_m)
-        ZK_LAUNCH(PC_FOLD, 0.0, k_fold, dim3(grid_for(t.len / 2)), dim3(ZK_BLOCK), t.M[t.cur], t.M[t.cur ^ 1], t.len, rr);
+        zk_launch_f(ctx, PC_FOLD, 0.0, dim3(grid_for(t.len / 2)), k_fold_f{(const fr_t *) t.M[t.cur], t.M[t.cur ^ 1], t.len, rr});
     ZK_HIP(hipGetLastError());
     t.cur ^= 1;
     t.len >>= 1;
@@ -348,11 +348,18 @@ extern "C" int32_t zk_vres(zk_ctx *ctx, const uint64_t *r, uint32_t output_size,
         int32_t rc = fold_pair(ctx, t, H(r + 4 * i), false);
         if (rc) return rc;
     }
-    ZK_HIP(hipMemcpyAsync(ctx->d_result, vin(t), 32, hipMemcpyDeviceToDevice, ctx->stream));
+    // the value left goes to the host through the hand-over slot (no copy, no stream synchronisation)
+    eval_args E;
+    std::memset(&E, 0, sizeof(E));
+    E.p[0] = vin(t); E.n[0] = 1;
+    E.slot = (host_slot *) ctx->d_slot;
+    E.seq = ++ctx->slot_seq;
+    zk_launch_f<k_eval_pairs_f, 64>(ctx, PC_FOLD, 0.0, dim3(1), k_eval_pairs_f{E});
+    ZK_HIP(hipGetLastError());
     t.Vsrc = nullptr;
-    int32_t rc = fetch_result(ctx, 1);
+    int32_t rc = wait_slot(ctx, E.seq);
     if (rc) return rc;
-    put(out, ctx->h_result[0]);
+    put(out, ctx->h_slot->v[0]);
     t.len = 0;
     ctx->proof_size += 32;
     return ZK_OK;
@@ -410,11 +417,10 @@ static int32_t conv_phase1(zk_ctx *ctx, const dev_layer &cur, fr_t *M, uint64_t 
     const int K = ctx->conv_K;
     const uint32_t wlen = c.CI * c.m * c.m, per = 8, chunks = (c.CO + per - 1) / per;
     fr_t *part = chunks == 1 ? ctx->conv_wa : ctx->conv_part;
-    ZK_LAUNCH(PC_GATE, 0.0, k_conv_wa, dim3((wlen + ZK_BLOCK - 1) / ZK_BLOCK, chunks), dim3(ZK_BLOCK), part, (const fr_t *) ctx->L[0].val + c.wstart,
-              (const fr_t *) ctx->conv_small, wlen, c.CO, per, K);
+    zk_launch_f(ctx, PC_GATE, 0.0, dim3((wlen + ZK_BLOCK - 1) / ZK_BLOCK, chunks), k_conv_wa_f{part, (const fr_t *) ctx->L[0].val + c.wstart, (const fr_t *) ctx->conv_small, wlen, c.CO, per, K});
     if (chunks > 1)
-        ZK_LAUNCH(PC_GATE, 0.0, k_sum_rows, dim3((K * wlen + 63) / 64), dim3(1024), ctx->conv_wa, (const fr_t *) part, K * wlen, chunks);
-    ZK_LAUNCH(PC_GATE, 0.0, k_conv_m1, dim3(grid_for(len)), dim3(ZK_BLOCK), M, (const fr_t *) ctx->conv_wa, (const fr_t *) ctx->conv_small, c, K, len);
+        zk_launch_f<k_sum_rows_f, 1024>(ctx, PC_GATE, 0.0, dim3((K * wlen + 63) / 64), k_sum_rows_f{ctx->conv_wa, (const fr_t *) part, K * wlen, chunks});
+    zk_launch_f(ctx, PC_GATE, 0.0, dim3(grid_for(len)), k_conv_m1_f{M, (const fr_t *) ctx->conv_wa, (const fr_t *) ctx->conv_small, c, K, len});
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -433,10 +439,9 @@ static int32_t conv_phase2(zk_ctx *ctx, const dev_layer &cur, fr_t *M, uint64_t 
     const conv_desc &c = cur.conv;
     const int K = ctx->conv_K;
     const uint32_t mm = c.m * c.m;
-    ZK_LAUNCH(PC_GATE, 0.0, k_conv_e, dim3(mm, K), dim3(ZK_BLOCK), ctx->conv_e, (const fr_t *) ctx->conv_small, c);
-    ZK_LAUNCH(PC_GATE, 0.0, k_conv_ae, dim3((c.CO * mm + c.CI + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), ctx->conv_ae, (const fr_t *) ctx->conv_e,
-              (const fr_t *) ctx->conv_small, c, K, to_dev(ctx->V_u1));
-    ZK_LAUNCH(PC_GATE, 0.0, k_conv_m2, dim3(grid_for(len)), dim3(ZK_BLOCK), M, (const uint32_t *) cur.ori_v, (const fr_t *) ctx->conv_ae, c, cur.d.size_v[0], len);
+    zk_launch_f(ctx, PC_GATE, 0.0, dim3(mm, K), k_conv_e_f{ctx->conv_e, (const fr_t *) ctx->conv_small, c, K});
+    zk_launch_f(ctx, PC_GATE, 0.0, dim3((c.CO * mm + c.CI + ZK_BLOCK - 1) / ZK_BLOCK), k_conv_ae_f{ctx->conv_ae, (const fr_t *) ctx->conv_e, (const fr_t *) ctx->conv_small, c, K, to_dev(ctx->V_u1)});
+    zk_launch_f(ctx, PC_GATE, 0.0, dim3(grid_for(len)), k_conv_m2_f{M, (const uint32_t *) cur.ori_v, (const fr_t *) ctx->conv_ae, c, cur.d.size_v[0], len});
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -664,7 +669,8 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
     const uint64_t pl = std::min<uint64_t>(npairs, (x_live + 3) / 4);
     if (!first && npairs - pl >= (1ull << 17)) {
         const uint64_t n_in = n - 4 * pl;
-        ZK_LAUNCH(PC_FOLD, 48.0 * (double) n_in, k_fold, dim3(grid_for(n_in / 2, 8192)), dim3(ZK_BLOCK), vin(t1) + 4 * pl, t1.V[t1.cur ^ 1] + 2 * pl, n_in, to_dev(r));
+        zk_launch_f(ctx, PC_FOLD, 48.0 * (double) n_in, dim3(grid_for(n_in / 2, 8192)), k_fold_f{vin(t1) + 4 * pl, t1.V[t1.cur ^ 1] + 2 * pl, n_in, to_dev(r)});
+        ZK_ORDER();
         if (fill) ZK_HIP(hipMemsetAsync(t0.V[t0.cur ^ 1] + 2 * pl, 0, (n / 2 - 2 * pl) * sizeof(fr_t), ctx->stream));
         fill |= 2;
     }
@@ -718,7 +724,7 @@ extern "C" int32_t zk_sumcheck_dotprod_finalize1(zk_ctx *ctx, const uint64_t pre
     E.r = to_dev(r);
     E.slot = (host_slot *) ctx->d_slot;
     E.seq = ++ctx->slot_seq;
-    ZK_LAUNCH(PC_FOLD, 0.0, k_eval_pairs, dim3(1), dim3(64), E);
+    zk_launch_f<k_eval_pairs_f, 64>(ctx, PC_FOLD, 0.0, dim3(1), k_eval_pairs_f{E});
     ZK_HIP(hipGetLastError());
     if ((rc = wait_slot(ctx, E.seq))) return rc;
     ctx->h_result[0] = ctx->h_slot->v[0];
@@ -1344,13 +1350,11 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         A.counter = ctx->d_counter;
         A.slot = (host_slot *) ctx->d_slot;
         A.seq = ++ctx->slot_seq;
-        // (a lane of a batch defers the launch: one launch runs this round of every lane -- batch.cuh; wait_slot below hands over to the driver)
+        // (a lane of a batch defers the launch: one launch runs this round of every lane -- launch.cuh; wait_slot below hands over to the driver)
         if (fine) {
             const uint32_t blocks = (uint32_t) ((fine_items + ZK_BLOCK / 4 - 1) / (ZK_BLOCK / 4));
-            if (!zk_batch_defer(ctx, BK_ROUND_FINE, &A, sizeof(A), blocks, alg_bytes))
-                ZK_LAUNCH(PC_ROUND_QUAD, alg_bytes, k_round_quad_fine, dim3(blocks), dim3(ZK_BLOCK), A);
-        } else if (!zk_batch_defer(ctx, BK_ROUND_QUAD2, &A, sizeof(A), A.blocks[0] + A.blocks[1], alg_bytes))
-            ZK_LAUNCH(PC_ROUND_QUAD, alg_bytes, k_round_quad2, dim3(A.blocks[0] + A.blocks[1]), dim3(ZK_BLOCK), A);
+            zk_launch_f(ctx, PC_ROUND_QUAD, alg_bytes, dim3(blocks), k_round_fine_f{A});
+        } else zk_launch_f(ctx, PC_ROUND_QUAD, alg_bytes, dim3(A.blocks[0] + A.blocks[1]), k_round_quad2_f{A});
         ZK_HIP(hipGetLastError());
         for (int b = 0; b < 2; ++b) {
             table_pair &t = ctx->tp[b];
@@ -1446,7 +1450,7 @@ static int32_t final_claims(zk_ctx *ctx, const HFr &r, const int8_t bl[2], HFr o
         E.r = to_dev(r);
         E.slot = (host_slot *) ctx->d_slot;
         E.seq = ++ctx->slot_seq;
-        ZK_LAUNCH(PC_FOLD, 0.0, k_eval_pairs, dim3(1), dim3(64), E);
+        zk_launch_f<k_eval_pairs_f, 64>(ctx, PC_FOLD, 0.0, dim3(1), k_eval_pairs_f{E});
         ZK_HIP(hipGetLastError());
         int32_t rc = wait_slot(ctx, E.seq);
         if (rc) return rc;
@@ -1519,8 +1523,8 @@ extern "C" int32_t zk_sumcheck_liu_init(zk_ctx *ctx, const uint64_t *s_u, const 
         T[tb].pad_ = 0;
     }
     if (ctx->liu_ntabs)
-        ZK_LAUNCH(PC_EQ, 0.0, k_eq_halves_multi, dim3(2, ctx->liu_ntabs), dim3(1024), ctx->liu_halves, (const liu_table *) ctx->liu_tabs);
-    ZK_LAUNCH(PC_LIU, 0.0, k_liu_gather, dim3(grid_for(t.len)), dim3(ZK_BLOCK), t.M[0], ctx->liu_ptr, (const liu_entry *) ctx->liu_ent, ctx->liu_halves, t.len);
+        zk_launch_f<k_eq_halves_multi_f, 1024>(ctx, PC_EQ, 0.0, dim3(2, ctx->liu_ntabs), k_eq_halves_multi_f{ctx->liu_halves, (const liu_table *) ctx->liu_tabs});
+    zk_launch_f(ctx, PC_LIU, 0.0, dim3(grid_for(t.len)), k_liu_gather_f{t.M[0], (const uint32_t *) ctx->liu_ptr, (const liu_entry *) ctx->liu_ent, (const fr_t *) ctx->liu_halves, t.len});
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
