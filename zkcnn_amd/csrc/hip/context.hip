@@ -316,7 +316,8 @@ extern "C" int32_t zk_batch_flush(zk_batch *b) {
             uint32_t n = 0, gx = 1, gy = 1;
             double bytes = 0;
             for (size_t j = i; j < items.size() && n < ZK_BATCH_MAX_LANES; ++j)
-                if (!done[j] && items[j].gen == g && items[j].launch == items[i].launch) {
+                if (!done[j] && items[j].gen == g && items[j].launch == items[i].launch &&
+                    (!items[i].exact || (items[j].gx == items[i].gx && items[j].gy == items[i].gy))) {
                     group[n++] = &items[j];
                     done[j] = 1;
                     gx = std::max(gx, items[j].gx);

@@ -282,6 +282,7 @@ struct batch_item {
     zk_ctx *ctx;
     uint32_t gen;                  // position in the lane's own sequence of deferred launches
     uint32_t gx, gy;               // the grid this lane's launch would have had
+    bool exact;                    // the body relies on gridDim being its own launch's: fused only with lanes that asked for the same grid
     int prof_class;
     double bytes;                  // its algorithmic bytes (profiler)
     alignas(16) unsigned char arg[ZK_BATCH_ARG_BYTES];
@@ -309,6 +310,14 @@ struct zk_batch {
 // stream): hand the thread to the batch's driver, which runs the other lanes up to their own such points and flushes; without a driver (no
 // yield function) the lane flushes for itself.
 int32_t zk_batch_sync_point(zk_ctx *ctx);
+// hipStreamSynchronize for a wait that is part of a proof: a lane first lets the other lanes issue their work up to the same point, so that
+// the GPU runs all of it while the thread waits once (never call it with a lock held: the other lanes run on this thread)
+static inline hipError_t zk_stream_sync(zk_ctx *ctx) {
+    if (ctx->batch && zk_batch_sync_point(ctx) != ZK_OK) return hipErrorUnknown;
+    return hipStreamSynchronize(ctx->stream);
+}
+// a copy / fill on the context's stream
+#define ZK_STREAM(call) do { ZK_ORDER(); ZK_HIP(call); } while (0)
 // before anything that is not deferred goes onto the stream of a context: keep the lane's order
 #define ZK_ORDER() do { if (ctx->batch && ctx->n_pending) { int32_t rc_o_ = zk_batch_sync_point(ctx); if (rc_o_) return rc_o_; } } while (0)
 

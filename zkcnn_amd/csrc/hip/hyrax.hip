@@ -118,6 +118,7 @@ static void msm_destroy_one(zk_ctx *ctx) {
 
 static int32_t regrow(zk_ctx *ctx, void **p, size_t *cap, size_t bytes) {
     if (*cap >= bytes) return ZK_OK;
+    ZK_ORDER();                        // (a lane of a batch: launches it has deferred may still read the buffer that is let go)
     if (*p) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(*p)); *p = nullptr; *cap = 0; }
     ZK_HIP(hipMalloc(p, bytes));
     *cap = bytes;
@@ -132,7 +133,7 @@ static int32_t ensure_state(zk_ctx *ctx) {
     msm_state *s = ctx->msm;
     if (!s->exc) {
         ZK_HIP(hipMalloc((void **) &s->exc, 64));
-        ZK_HIP(hipMemsetAsync(s->exc, 0, 64, ctx->stream));
+        ZK_STREAM(hipMemsetAsync(s->exc, 0, 64, ctx->stream));
     }
     return ZK_OK;
 }
@@ -140,6 +141,7 @@ static int32_t ensure_state(zk_ctx *ctx) {
 // window tables for `m` affine generators (host pointer, C-ABI layout): looked up in / added to the registry of generator sets
 static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
     msm_state *s = ctx->msm;
+    ZK_ORDER();                        // nothing of this lane may be deferred while a table is built under the set's lock (the other lanes run on this thread)
     if (s->gt && s->m == m && s->gens_host.size() == m * 12 && std::memcmp(s->gens_host.data(), gens, m * 96) == 0) {
         std::lock_guard<std::mutex> g(s->gt->mtx);
         ++s->gt->uses;
@@ -168,15 +170,21 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
     ++e->uses;
     if (!e->tables) {
         ZK_HIP(hipMalloc((void **) &e->tables, (size_t) MSM_WINDOWS * m * sizeof(g1a_t)));
-        ZK_HIP(hipMemcpyAsync(e->tables, gens, m * sizeof(g1a_t), hipMemcpyHostToDevice, ctx->stream));
-        const size_t need = (size_t) (MSM_WINDOWS - 1) * m * (sizeof(g1j_t) + sizeof(fp_t));
-        int32_t rc = regrow(ctx, &s->tbl_scratch, &s->tbl_scratch_cap, need);
-        if (rc) return rc;
-        g1j_t *J = (g1j_t *) s->tbl_scratch;
-        fp_t *pre = (fp_t *) (J + (size_t) (MSM_WINDOWS - 1) * m);
-        ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_window_tables, dim3((uint32_t) ((m + 63) / 64)), dim3(64), e->tables, J, pre, (uint32_t) m);
-        ZK_HIP(hipGetLastError());
-        ZK_HIP(hipStreamSynchronize(ctx->stream));      // other contexts read the tables from their own streams
+        // (a failure below must not leave the entry looking built: every context that looks the set up adopts e->tables)
+        auto build = [&]() -> int32_t {
+            ZK_STREAM(hipMemcpyAsync(e->tables, gens, m * sizeof(g1a_t), hipMemcpyHostToDevice, ctx->stream));
+            const size_t need = (size_t) (MSM_WINDOWS - 1) * m * (sizeof(g1j_t) + sizeof(fp_t));
+            int32_t rc = regrow(ctx, &s->tbl_scratch, &s->tbl_scratch_cap, need);
+            if (rc) return rc;
+            g1j_t *J = (g1j_t *) s->tbl_scratch;
+            fp_t *pre = (fp_t *) (J + (size_t) (MSM_WINDOWS - 1) * m);
+            ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_window_tables, dim3((uint32_t) ((m + 63) / 64)), dim3(64), e->tables, J, pre, (uint32_t) m);
+            ZK_HIP(hipGetLastError());
+            ZK_HIP(hipStreamSynchronize(ctx->stream));      // other contexts read the tables from their own streams
+            return ZK_OK;
+        };
+        const int32_t rc = build();
+        if (rc) { (void) hipStreamSynchronize(ctx->stream); (void) hipFree(e->tables); e->tables = nullptr; return rc; }
         ++g_gen_builds;
     }
     gen_adopt(s);
@@ -186,6 +194,7 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
 static int32_t ensure_rows(zk_ctx *ctx, uint32_t rows) {
     msm_state *s = ctx->msm;
     if (s->rows_cap >= rows) return ZK_OK;
+    ZK_ORDER();
     if (s->rowsJ) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->rowsJ)); ZK_HIP(hipFree(s->rowsA)); s->rowsJ = nullptr; }
     ZK_HIP(hipMalloc((void **) &s->rowsJ, (size_t) rows * sizeof(g1j_t)));
     ZK_HIP(hipMalloc((void **) &s->rowsA, (size_t) rows * sizeof(g1a_t)));
@@ -215,6 +224,7 @@ static int32_t ensure_full_table(zk_ctx *ctx) {
     msm_state *s = ctx->msm;
     gen_tables *e = s->gt;
     if (!e || s->full_ready || s->no_full || s->m > MSM_FULL_MAX_M) return ZK_OK;
+    ZK_ORDER();
     std::lock_guard<std::mutex> g(e->mtx);
     if (!e->full_ready && !e->full_failed && e->uses >= 2) {
         const uint32_t m = (uint32_t) e->m;
@@ -232,7 +242,7 @@ static int32_t ensure_full_table(zk_ctx *ctx) {
                 const uint32_t n8 = m / 8;
                 if (hipMalloc((void **) &e->t8, (size_t) 256 * n8 * sizeof(g1a_t)) != hipSuccess) { (void) hipGetLastError(); e->t8 = nullptr; }
                 else {
-                    ZK_HIP(hipMemsetAsync(e->t8, 0, (size_t) n8 * sizeof(g1a_t), ctx->stream));            // mask 0: the point at infinity, never looked up
+                    ZK_STREAM(hipMemsetAsync(e->t8, 0, (size_t) n8 * sizeof(g1a_t), ctx->stream));            // mask 0: the point at infinity, never looked up
                     ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_subset_table, dim3((n8 + 63) / 64, 255), dim3(64), e->t8, (const g1a_t *) (e->full + (size_t) 1 * m), n8);
                     ZK_HIP(hipGetLastError());
                     e->t8_ready = true;
@@ -252,13 +262,14 @@ static int32_t ensure_digit_table(zk_ctx *ctx) {
     msm_state *s = ctx->msm;
     gen_tables *e = s->gt;
     if (s->digit_ready) return ZK_OK;
+    ZK_ORDER();
     std::lock_guard<std::mutex> g(e->mtx);
     if (!e->digit_ready) {
         const uint32_t m = (uint32_t) e->m;
         ZK_HIP(hipMalloc((void **) &e->digit, (size_t) 256 * m * sizeof(g1a_t)));
         int32_t rc = build_digit_table(ctx, e->digit, e->tables, m);
-        if (rc) return rc;
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "digit table: stream synchronisation failed"; rc = ZK_ERR_HIP; }
+        if (rc) { (void) hipFree(e->digit); e->digit = nullptr; return rc; }     // (not built: nobody may adopt it, and the next attempt allocates again)
         e->digit_ready = true;
     }
     gen_adopt(s);
@@ -268,10 +279,10 @@ static int32_t ensure_digit_table(zk_ctx *ctx) {
 // sums the `n` partial points of every row (row-major in `src`) into dst[row]
 static int32_t reduce_rows(zk_ctx *ctx, const g1j_t *src, uint32_t n, uint32_t rows, g1j_t *dst) {
     if (n == 1) {
-        ZK_HIP(hipMemcpyAsync(dst, src, (size_t) rows * sizeof(g1j_t), hipMemcpyDeviceToDevice, ctx->stream));
+        ZK_STREAM(hipMemcpyAsync(dst, src, (size_t) rows * sizeof(g1j_t), hipMemcpyDeviceToDevice, ctx->stream));
         return ZK_OK;
     }
-    ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_reduce_rows16, dim3((rows + 3) / 4), dim3(MSM_BLOCK), dst, src, n, rows);
+    zk_launch_d<k_reduce_rows16, MSM_BLOCK>(ctx, PC_MSM_FINISH, 0.0, dim3((rows + 3) / 4), dst, src, n, rows);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -283,7 +294,7 @@ static int32_t scalar_mags(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const 
     if (rc) return rc;
     for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
         const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
-        ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_scalar_mags, dim3(std::min<uint32_t>((cols + 255) / 256, 64), nr), dim3(256), s->mag + (size_t) r0 * cols,
+        zk_launch_d<k_scalar_mags, 256>(ctx, PC_MSM_PLANES, 0.0, dim3(std::min<uint32_t>((cols + 255) / 256, 64), nr), s->mag + (size_t) r0 * cols,
                   row_map ? scalars : scalars + (size_t) r0 * ld, ld, row_map ? row_map + r0 : nullptr, cols);
     }
     ZK_HIP(hipGetLastError());
@@ -316,10 +327,10 @@ static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32
             const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
             const double bytes = 32.0 * (double) nr * (double) cols;
             if (s->safe)
-                ZK_LAUNCH(PC_MSM_PLANES, bytes, k_msm_windows<true>, dim3(n, nr), dim3(MSM_BLOCK), s->partials + (size_t) r0 * n, s->exc, s->mag + (size_t) r0 * cols,
+                zk_launch_d<k_msm_windows<true>, MSM_BLOCK>(ctx, PC_MSM_PLANES, bytes, dim3(n, nr), s->partials + (size_t) r0 * n, s->exc, s->mag + (size_t) r0 * cols,
                           ld, idx ? idx + (size_t) r0 * ld : nullptr, s->full, (uint32_t) s->m, cols, cpt, w_lo, nwin);
             else
-                ZK_LAUNCH(PC_MSM_PLANES, bytes, k_msm_windows<false>, dim3(n, nr), dim3(MSM_BLOCK), s->partials + (size_t) r0 * n, s->exc, s->mag + (size_t) r0 * cols,
+                zk_launch_d<k_msm_windows<false>, MSM_BLOCK>(ctx, PC_MSM_PLANES, bytes, dim3(n, nr), s->partials + (size_t) r0 * n, s->exc, s->mag + (size_t) r0 * cols,
                           ld, idx ? idx + (size_t) r0 * ld : nullptr, s->full, (uint32_t) s->m, cols, cpt, w_lo, nwin);
         }
         ZK_HIP(hipGetLastError());
@@ -328,7 +339,7 @@ static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32
             g1j_t *cur = s->partials;
             if (n > 256) {
                 const uint32_t n2 = (n + 63) / 64;
-                ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_tree_reduce, dim3(n2, rows), dim3(MSM_BLOCK), s->parts2, cur, n);
+                zk_launch_d<k_tree_reduce, MSM_BLOCK>(ctx, PC_MSM_FINISH, 0.0, dim3(n2, rows), s->parts2, cur, n);
                 cur = s->parts2;
                 n = n2;
             }
@@ -338,16 +349,16 @@ static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32
         g1j_t *cur = s->partials, *nxt = s->parts2;
         while (n > 64) {
             const uint32_t n2 = (n + 63) / 64;
-            ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_tree_reduce, dim3(n2, rows), dim3(MSM_BLOCK), nxt, cur, n);
+            zk_launch_d<k_tree_reduce, MSM_BLOCK>(ctx, PC_MSM_FINISH, 0.0, dim3(n2, rows), nxt, cur, n);
             std::swap(cur, nxt);
             n = n2;
         }
         ZK_HIP(hipGetLastError());
         std::vector<zkff::G1> part((size_t) rows * n);
         uint32_t exc = 0;
-        ZK_HIP(hipMemcpyAsync(part.data(), cur, part.size() * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(hipMemcpyAsync(&exc, s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        ZK_STREAM(hipMemcpyAsync(part.data(), cur, part.size() * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_STREAM(hipMemcpyAsync(&exc, s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(zk_stream_sync(ctx));
         if (exc && !s->safe) return ZK_RETRY_SAFE;
         for (uint32_t r = 0; r < rows; ++r) {
             zkff::G1 acc = part[(size_t) r * n];
@@ -403,12 +414,13 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
     const uint32_t nv = wide_cap * (MSM_WINDOWS - 1), rows_all = rows + nv;
     if ((rc = ensure_rows(ctx, rows_all))) return rc;
     if (s->flags_cap < rows + 1) {
+        ZK_ORDER();
         if (s->hi_flags) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->hi_flags)); ZK_HIP(hipFree(s->row_list)); }
         ZK_HIP(hipMalloc((void **) &s->hi_flags, ((size_t) rows + 1) * 4));                  // [rows] = number of flagged rows
         ZK_HIP(hipMalloc((void **) &s->row_list, ((size_t) rows + 1) * 4));
         s->flags_cap = rows + 1;
     }
-    ZK_HIP(hipMemsetAsync(s->hi_flags, 0, ((size_t) rows + 1) * 4, ctx->stream));
+    ZK_STREAM(hipMemsetAsync(s->hi_flags, 0, ((size_t) rows + 1) * 4, ctx->stream));
     if ((rc = regrow(ctx, (void **) &s->codes, &s->codes_cap, (size_t) rows_all * cols * 2))) return rc;
     // columns per lane: 64 would give one wave per row, but the ~2 250 full rows of a vgg11 commitment do not divide evenly over 1 024 SIMDs
     // (some get three such waves, some two: the kernel lasts as long as three); with half rows the spread is 5 against 4.4 on average
@@ -420,17 +432,17 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
     uint32_t *n_wide = s->hi_flags + rows;
     const dim3 cgrid(std::min<uint32_t>((cols + 255) / 256, 64), 1);
     for (uint32_t r0 = 0; r0 < rows; r0 += 32768)
-        ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_scalar_codes, dim3(cgrid.x, std::min<uint32_t>(32768, rows - r0)), dim3(256), s->codes + (size_t) r0 * cols,
+        zk_launch_d<k_scalar_codes, 256>(ctx, PC_MSM_PLANES, 0.0, dim3(cgrid.x, std::min<uint32_t>(32768, rows - r0)), s->codes + (size_t) r0 * cols,
                   s->hi_flags + r0, scalars + (size_t) r0 * ld, ld, cols);
     if (wide_cap) {
-        ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_compact_flags, dim3(1), dim3(1024), s->row_list, n_wide, s->hi_flags, rows, wide_cap);
-        ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_scalar_codes_wide, dim3(cgrid.x, wide_cap), dim3(256), s->codes + (size_t) rows * cols, scalars, ld, s->row_list, n_wide, cols);
+        zk_launch_d<k_compact_flags, 1024>(ctx, PC_MSM_PLANES, 0.0, dim3(1), s->row_list, n_wide, s->hi_flags, rows, wide_cap);
+        zk_launch_d<k_scalar_codes_wide, 256>(ctx, PC_MSM_PLANES, 0.0, dim3(cgrid.x, wide_cap), s->codes + (size_t) rows * cols, scalars, ld, s->row_list, n_wide, cols);
     }
     // rows of bits go through the subset-sum table: 8 columns per lookup (only when one block owns a whole row and the table is there)
     const bool bits = s->full_ready && s->t8_ready && s->t8_m == s->m && cols == s->m && rows_all <= 65535 && (cols / 8 / MSM_BLOCK) % chunks == 0 && cols % (MSM_BLOCK * cpt) == 0;
     if (bits) {
         if ((rc = regrow(ctx, (void **) &s->masks, &s->masks_cap, (size_t) rows * (cols / 8) * 2))) return rc;
-        ZK_LAUNCH(PC_MSM_PLANES, 0.0, k_bit_masks, dim3(2, rows), dim3(256), s->masks, (const uint16_t *) s->codes, (const uint32_t *) s->hi_flags, cols);
+        zk_launch_d<k_bit_masks, 256>(ctx, PC_MSM_PLANES, 0.0, dim3(2, rows), s->masks, (const uint16_t *) s->codes, (const uint32_t *) s->hi_flags, cols);
     }
     const uint32_t *bflags = bits ? s->hi_flags : nullptr;
     const uint16_t *bmasks = bits ? s->masks : nullptr;
@@ -439,23 +451,23 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
         const uint32_t nr = std::min<uint32_t>(65535, rows_all - r0), n_real = std::min<uint32_t>(nr, r0 < rows ? rows - r0 : 0);
         const double bytes = 32.0 * (double) std::min(nr, n_real) * (double) cols;
         if (s->safe)
-            ZK_LAUNCH(PC_MSM_PLANES, bytes, k_msm_codes<true>, dim3(chunks, nr), dim3(MSM_BLOCK), s->partials + (size_t) r0 * n, s->exc,
+            zk_launch_d<k_msm_codes<true>, MSM_BLOCK>(ctx, PC_MSM_PLANES, bytes, dim3(chunks, nr), s->partials + (size_t) r0 * n, s->exc,
                       s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, n_real, n_wide, bflags, bmasks, bT8);
         else
-            ZK_LAUNCH(PC_MSM_PLANES, bytes, k_msm_codes<false>, dim3(chunks, nr), dim3(MSM_BLOCK), s->partials + (size_t) r0 * n, s->exc,
+            zk_launch_d<k_msm_codes<false>, MSM_BLOCK>(ctx, PC_MSM_PLANES, bytes, dim3(chunks, nr), s->partials + (size_t) r0 * n, s->exc,
                       s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, n_real, n_wide, bflags, bmasks, bT8);
     }
     ZK_HIP(hipGetLastError());
     if ((rc = reduce_rows(ctx, s->partials, n, rows_all, s->rowsJ))) return rc;         // rowsJ[rows + v] = sum of virtual row v
     if (wide_cap) {
         if ((rc = reduce_rows(ctx, s->rowsJ + rows, MSM_WINDOWS - 1, wide_cap, s->tmpJ))) return rc;
-        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_add_rows, dim3((wide_cap + 63) / 64), dim3(64), s->rowsJ, s->tmpJ, s->row_list, wide_cap, n_wide);
+        zk_launch_d<k_add_rows, 64>(ctx, PC_MSM_FINISH, 0.0, dim3((wide_cap + 63) / 64), s->rowsJ, s->tmpJ, s->row_list, wide_cap, n_wide);
         ZK_HIP(hipGetLastError());
     }
     std::vector<uint32_t> flags((size_t) rows + 2), list;
-    ZK_HIP(hipMemcpyAsync(flags.data(), s->hi_flags, ((size_t) rows + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(&flags[rows + 1], s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_STREAM(hipMemcpyAsync(flags.data(), s->hi_flags, ((size_t) rows + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_STREAM(hipMemcpyAsync(&flags[rows + 1], s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(zk_stream_sync(ctx));
     if (flags[rows + 1] && !s->safe) return ZK_RETRY_SAFE;
     if (wide_cap && flags[rows] <= wide_cap) return ZK_OK;       // every wide row went through the virtual rows
     for (uint32_t r = 0; r < rows; ++r) if (flags[r] & MSM_ROW_WIDE) list.push_back(r);
@@ -463,11 +475,11 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
     // separate pass: all wide rows when there was no byte table, the ones beyond the list otherwise (list rows are ascending on both sides)
     if (wide_cap) list.erase(list.begin(), list.begin() + wide_cap);
     const uint32_t nl = (uint32_t) list.size();
-    ZK_HIP(hipMemcpyAsync(s->row_list, list.data(), (size_t) nl * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZK_STREAM(hipMemcpyAsync(s->row_list, list.data(), (size_t) nl * 4, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = regrow(ctx, (void **) &s->tmpJ, &s->tmp_cap, (size_t) nl * sizeof(g1j_t)))) return rc;
     if ((rc = scalar_mags(ctx, scalars, ld, s->row_list, nl, cols))) return rc;
     if ((rc = msm_windows(ctx, nullptr, cols, nl, cols, 1, s->tmpJ))) return rc;
-    ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_add_rows, dim3((nl + 63) / 64), dim3(64), s->rowsJ, s->tmpJ, s->row_list, nl, (const uint32_t *) nullptr);
+    zk_launch_d<k_add_rows, 64>(ctx, PC_MSM_FINISH, 0.0, dim3((nl + 63) / 64), s->rowsJ, s->tmpJ, s->row_list, nl, (const uint32_t *) nullptr);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -482,36 +494,36 @@ static int32_t fetch_points(zk_ctx *ctx, uint32_t rows, uint64_t *out) {
         int32_t rc = regrow(ctx, &s->aff_scratch, &s->aff_cap, ((size_t) rows + 3 * (size_t) nseg + 2) * sizeof(fp_t));
         if (rc) return rc;
         fp_t *pre = (fp_t *) s->aff_scratch, *seg = pre + rows, *seg_pre = seg + nseg, *seg_suf = seg_pre + nseg, *tot = seg_suf + nseg;
-        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_aff_prefix, dim3((nseg + 63) / 64), dim3(64), pre, seg, s->rowsJ, rows, AFF_SEG);
-        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_aff_scan, dim3(1), dim3(1024), seg_pre, seg_suf, tot, seg, nseg);
+        zk_launch_d<k_aff_prefix, 64>(ctx, PC_MSM_FINISH, 0.0, dim3((nseg + 63) / 64), pre, seg, s->rowsJ, rows, AFF_SEG);
+        zk_launch_d<k_aff_scan, 1024>(ctx, PC_MSM_FINISH, 0.0, dim3(1), seg_pre, seg_suf, tot, seg, nseg);
         ZK_HIP(hipGetLastError());
         zkff::Fp total, inv;
-        ZK_HIP(hipMemcpyAsync(&total, tot, sizeof(fp_t), hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        ZK_STREAM(hipMemcpyAsync(&total, tot, sizeof(fp_t), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(zk_stream_sync(ctx));
         zkff::Fp::invert(inv, total);                      // the one sequential inversion: O(1) host work, like add_term
-        ZK_HIP(hipMemcpyAsync(tot + 1, &inv, sizeof(fp_t), hipMemcpyHostToDevice, ctx->stream));
-        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_aff_finish, dim3((nseg + 63) / 64), dim3(64), s->rowsA, s->rowsJ, pre, seg_pre, seg_suf, tot + 1, rows, AFF_SEG);
+        ZK_STREAM(hipMemcpyAsync(tot + 1, &inv, sizeof(fp_t), hipMemcpyHostToDevice, ctx->stream));
+        zk_launch_d<k_aff_finish, 64>(ctx, PC_MSM_FINISH, 0.0, dim3((nseg + 63) / 64), s->rowsA, s->rowsJ, pre, seg_pre, seg_suf, tot + 1, rows, AFF_SEG);
         ZK_HIP(hipGetLastError());
-        ZK_HIP(hipMemcpyAsync(out, s->rowsA, (size_t) rows * sizeof(g1a_t), hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(hipMemcpyAsync(&exc, s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        ZK_STREAM(hipMemcpyAsync(out, s->rowsA, (size_t) rows * sizeof(g1a_t), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_STREAM(hipMemcpyAsync(&exc, s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(zk_stream_sync(ctx));
         return exc && !s->safe ? ZK_RETRY_SAFE : ZK_OK;
     }
     if (rows > 8) {
-        ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_to_affine, dim3((rows + 63) / 64), dim3(64), s->rowsA, s->rowsJ, rows);
+        zk_launch_d<k_to_affine, 64>(ctx, PC_MSM_FINISH, 0.0, dim3((rows + 63) / 64), s->rowsA, s->rowsJ, rows);
         ZK_HIP(hipGetLastError());
-        ZK_HIP(hipMemcpyAsync(out, s->rowsA, (size_t) rows * sizeof(g1a_t), hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(hipMemcpyAsync(&exc, s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        ZK_STREAM(hipMemcpyAsync(out, s->rowsA, (size_t) rows * sizeof(g1a_t), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_STREAM(hipMemcpyAsync(&exc, s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(zk_stream_sync(ctx));
         return exc && !s->safe ? ZK_RETRY_SAFE : ZK_OK;
     }
     zkff::G1 pj[8];
     if (s->host_rows_valid) {
         for (uint32_t i = 0; i < rows; ++i) pj[i] = s->host_rows[i];
     } else {
-        ZK_HIP(hipMemcpyAsync(pj, s->rowsJ, (size_t) rows * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(hipMemcpyAsync(&exc, s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        ZK_STREAM(hipMemcpyAsync(pj, s->rowsJ, (size_t) rows * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_STREAM(hipMemcpyAsync(&exc, s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(zk_stream_sync(ctx));
         if (exc && !s->safe) return ZK_RETRY_SAFE;
     }
     for (uint32_t i = 0; i < rows; ++i) {
@@ -526,11 +538,11 @@ template <class Body>
 static int32_t with_safe_retry(zk_ctx *ctx, Body body) {
     msm_state *s = ctx->msm;
     s->safe = false;
-    ZK_HIP(hipMemsetAsync(s->exc, 0, 4, ctx->stream));
+    ZK_STREAM(hipMemsetAsync(s->exc, 0, 4, ctx->stream));
     int32_t rc = body();
     if (rc != ZK_RETRY_SAFE) return rc;
     s->safe = true;
-    ZK_HIP(hipMemsetAsync(s->exc, 0, 4, ctx->stream));
+    ZK_STREAM(hipMemsetAsync(s->exc, 0, 4, ctx->stream));
     rc = body();
     s->safe = false;
     return rc;
@@ -550,13 +562,13 @@ static int32_t add_blinds(zk_ctx *ctx, const uint64_t *blinds, uint32_t rows, ui
     fr_t *d_bl = (fr_t *) ctx->scratch.p;
     uint32_t *d_idx = (uint32_t *) (d_bl + rows);
     std::vector<uint32_t> idx(rows, h_index);
-    ZK_HIP(hipMemcpyAsync(d_bl, blinds, (size_t) rows * 32, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(d_idx, idx.data(), (size_t) rows * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZK_STREAM(hipMemcpyAsync(d_bl, blinds, (size_t) rows * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_STREAM(hipMemcpyAsync(d_idx, idx.data(), (size_t) rows * 4, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));          // idx is a local
     if ((rc = regrow(ctx, (void **) &s->tmpJ, &s->tmp_cap, (size_t) rows * sizeof(g1j_t)))) return rc;
     if ((rc = scalar_mags(ctx, d_bl, 1, nullptr, rows, 1))) return rc;
     if ((rc = msm_windows(ctx, d_idx, 1, rows, 1, 0, s->tmpJ))) return rc;
-    ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_add_rows, dim3((rows + 63) / 64), dim3(64), s->rowsJ, s->tmpJ, (const uint32_t *) nullptr, rows, (const uint32_t *) nullptr);
+    zk_launch_d<k_add_rows, 64>(ctx, PC_MSM_FINISH, 0.0, dim3((rows + 63) / 64), s->rowsJ, s->tmpJ, (const uint32_t *) nullptr, rows, (const uint32_t *) nullptr);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -622,8 +634,8 @@ extern "C" int32_t zk_hyrax_combine_rows(zk_ctx *ctx, const uint64_t *x, uint32_
     const HFr *xs = reinterpret_cast<const HFr *>(x);
     if ((rc = zk_eq_table1_dev(ctx, Lrow, s->rb, xs + s->cb, HFr::one()))) return rc;
     if ((rc = zk_col_combine_dev(ctx, w, L0.val, Lrow, m, rows))) return rc;
-    ZK_HIP(hipMemcpyAsync(out_w, w, (size_t) m * 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_STREAM(hipMemcpyAsync(out_w, w, (size_t) m * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(zk_stream_sync(ctx));
     return ZK_OK;
 }
 
@@ -648,7 +660,7 @@ extern "C" int32_t zk_hyrax_open_init(zk_ctx *ctx, const uint64_t *x, uint32_t n
     if ((rc = zk_eq_table1_dev(ctx, s->Lrow, s->rb, xs + s->cb, HFr::one()))) return rc;
     if ((rc = zk_eq_table1_dev(ctx, s->b, s->cb, xs, HFr::one()))) return rc;
     if ((rc = zk_col_combine_dev(ctx, s->a, L0.val, s->Lrow, m, rows))) return rc;        // w = L^T Z
-    ZK_LAUNCH(PC_IPA, 0.0, k_fill, dim3((m + 255) / 256), dim3(256), s->coef, to_dev(HFr::one()), m);
+    zk_launch_d<k_fill, 256>(ctx, PC_IPA, 0.0, dim3((m + 255) / 256), s->coef, to_dev(HFr::one()), m);
     ZK_HIP(hipGetLastError());
     s->len = m;
     return ZK_OK;
@@ -659,8 +671,8 @@ extern "C" int32_t zk_hyrax_open_round(zk_ctx *ctx, uint64_t Lp[12], uint64_t Rp
     msm_state *s = ctx->msm;
     if (!s || s->len < 2) return ZK_ERR_STATE;
     const uint32_t m = 1u << s->cb, h = s->len >> 1;
-    ZK_LAUNCH(PC_IPA, 0.0, k_ipa_scalars, dim3((m + 255) / 256), dim3(256), s->sL, s->idxL, s->sR, s->idxR, s->a, s->coef, m, s->len);
-    ZK_LAUNCH(PC_IPA, 0.0, k_ipa_dots, dim3(1), dim3(256), s->d_y, s->a, s->b, h);
+    zk_launch_d<k_ipa_scalars, 256>(ctx, PC_IPA, 0.0, dim3((m + 255) / 256), s->sL, s->idxL, s->sR, s->idxR, s->a, s->coef, m, s->len);
+    zk_launch_d<k_ipa_dots, 256>(ctx, PC_IPA, 0.0, dim3(1), s->d_y, s->a, s->b, h);
     ZK_HIP(hipGetLastError());
     // two MSMs over m/2 generators each = the two rows of one batch (row stride m/2 for scalars and indices)
     int32_t rc;
@@ -670,8 +682,8 @@ extern "C" int32_t zk_hyrax_open_round(zk_ctx *ctx, uint64_t Lp[12], uint64_t Rp
         return r ? r : fetch_points(ctx, 2, pts);
     });
     if (rc) return rc;
-    ZK_HIP(hipMemcpyAsync(ctx->h_result, s->d_y, 64, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_STREAM(hipMemcpyAsync(ctx->h_result, s->d_y, 64, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(zk_stream_sync(ctx));
     std::memcpy(Lp, pts, 96);
     std::memcpy(Rp, pts + 12, 96);
     std::memcpy(yL, &ctx->h_result[0], 32);
@@ -684,7 +696,7 @@ extern "C" int32_t zk_hyrax_open_fold(zk_ctx *ctx, const uint64_t c[4]) {
     msm_state *s = ctx->msm;
     if (!s || s->len < 2) return ZK_ERR_STATE;
     const uint32_t m = 1u << s->cb;
-    ZK_LAUNCH(PC_IPA, 0.0, k_ipa_fold, dim3((m + 255) / 256), dim3(256), s->a, s->b, s->coef, to_dev(H(c)), m, s->len);
+    zk_launch_d<k_ipa_fold, 256>(ctx, PC_IPA, 0.0, dim3((m + 255) / 256), s->a, s->b, s->coef, to_dev(H(c)), m, s->len);
     ZK_HIP(hipGetLastError());
     s->len >>= 1;
     return ZK_OK;
@@ -695,8 +707,8 @@ extern "C" int32_t zk_hyrax_open_final(zk_ctx *ctx, uint64_t *a, uint32_t cap, u
     msm_state *s = ctx->msm;
     if (!s || !s->len || !a || !n) return ZK_ERR_STATE;
     if (s->len > cap) { ctx->err = "open_final: buffer too small"; return ZK_ERR_ARG; }
-    ZK_HIP(hipMemcpyAsync(a, s->a, (size_t) s->len * 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_STREAM(hipMemcpyAsync(a, s->a, (size_t) s->len * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(zk_stream_sync(ctx));
     *n = s->len;
     return ZK_OK;
 }
@@ -710,7 +722,7 @@ extern "C" int32_t zk_verifier_msm(zk_ctx *ctx, uint64_t out[12], const uint64_t
         if (!s || !s->tables || n > s->m || std::memcmp(s->gens_host.data(), bases, n * 96) != 0) { ctx->err = "verifier MSM: these are not the cached generators"; return ZK_ERR_STATE; }
         { std::lock_guard<std::mutex> g(s->gt->mtx); ++s->gt->uses; }
         if ((rc = zk_scratch(ctx, n * 32))) return rc;
-        ZK_HIP(hipMemcpyAsync(ctx->scratch.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+        ZK_STREAM(hipMemcpyAsync(ctx->scratch.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
         return with_safe_retry(ctx, [&]() -> int32_t {
             int32_t r = run_msm(ctx, (const fr_t *) ctx->scratch.p, n, nullptr, 1, (uint32_t) n);
             return r ? r : fetch_points(ctx, 1, out);
@@ -741,7 +753,7 @@ extern "C" int32_t zk_k_msm(zk_ctx *ctx, uint64_t out[12], const uint64_t *scala
     int32_t rc;
     if ((rc = ensure_state(ctx)) || (rc = ensure_tables(ctx, bases, n))) return rc;
     if ((rc = zk_scratch(ctx, n * 32))) return rc;
-    ZK_HIP(hipMemcpyAsync(ctx->scratch.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_STREAM(hipMemcpyAsync(ctx->scratch.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
     return with_safe_retry(ctx, [&]() -> int32_t {
         int32_t r = run_msm(ctx, (const fr_t *) ctx->scratch.p, n, nullptr, 1, (uint32_t) n);
         return r ? r : fetch_points(ctx, 1, out);
@@ -756,7 +768,7 @@ extern "C" int32_t zk_k_commit_rows(zk_ctx *ctx, uint64_t *out, const uint64_t *
     int32_t rc;
     if ((rc = ensure_state(ctx)) || (rc = ensure_tables(ctx, bases, cols))) return rc;
     if ((rc = zk_scratch(ctx, rows * cols * 32))) return rc;
-    ZK_HIP(hipMemcpyAsync(ctx->scratch.p, scalars, rows * cols * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_STREAM(hipMemcpyAsync(ctx->scratch.p, scalars, rows * cols * 32, hipMemcpyHostToDevice, ctx->stream));
     return with_safe_retry(ctx, [&]() -> int32_t {
         int32_t r = commit_rows(ctx, (const fr_t *) ctx->scratch.p, cols, (uint32_t) rows, (uint32_t) cols);
         return r ? r : fetch_points(ctx, (uint32_t) rows, out);

@@ -452,7 +452,7 @@ struct k_fold_f {
 __device__ __forceinline__ fr_t cubic_ms(const fr_t *Ms, const fr_t *Ms_raw, uint32_t i, const fr_t &r) {
     return Ms_raw ? fr_lerp(fr_load(Ms_raw + 2 * (size_t) i), fr_load(Ms_raw + 2 * (size_t) i + 1), r) : fr_load(Ms + i);
 }
-__global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, const fr_t *V1in, fr_t *V0out, fr_t *V1out,
+__device__ __forceinline__ void k_round_cubic(const fr_t *V0in, const fr_t *V1in, fr_t *V0out, fr_t *V1out,
                                                           const fr_t *Ms, uint32_t ls, uint64_t n, fr_t r, int first,
                                                           fr_t *partials, uint32_t *counter, host_slot *slot,
                                                           unsigned long long seq, const fr_t *Ms_raw, fr_t *Ms_out, uint64_t x_live, int fill) {
@@ -554,7 +554,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_round_cubic(const fr_t *V0in, cons
 // K6: FFT / IFFT layer claim combine  V[u] = sum_g val[g * stride + u] * beta[g]
 // reference src/prover.cpp:190-197.   grid = (u tiles, g chunks); partial sums per g chunk.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_strided_matvec(fr_t *out, const fr_t *val, const fr_t *beta, uint32_t len, uint32_t stride, uint32_t cnt,
+__device__ __forceinline__ void k_strided_matvec(fr_t *out, const fr_t *val, const fr_t *beta, uint32_t len, uint32_t stride, uint32_t cnt,
                                  uint32_t g_per_chunk) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= len) return;
@@ -567,7 +567,7 @@ __global__ void k_strided_matvec(fr_t *out, const fr_t *val, const fr_t *beta, u
 // K7: MLE of the DFT matrix, closed form  phi[u] = scale * prod_j (1 - rx_j + rx_j w^{(u 2^j) mod N})
 // reference src/utils.cpp:61-103 (recursive there).  pw = powers of the 2^n-th root (or its inverse)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_phi(fr_t *out, const fr_t *pw, fr_vec rx, fr_t scale, int n, int vars, uint32_t cnt) {
+__device__ __forceinline__ void k_phi(fr_t *out, const fr_t *pw, fr_vec rx, fr_t scale, int n, int vars, uint32_t cnt) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= cnt) return;
     const uint32_t N1 = (1u << n) - 1;
@@ -587,7 +587,7 @@ __global__ void k_phi(fr_t *out, const fr_t *pw, fr_vec rx, fr_t scale, int n, i
 //  phase 2: V1[v]     = sum_t F[(v,t)] * eq(r_k, t)                      reference src/prover.cpp:277-284
 // ------------------------------------------------------------------------------------------------
 // gates sorted by u; row_ptr[u]..row_ptr[u+1] delimit the gates of one u. grid = (t tiles, u rows)
-__global__ void k_dot_v0(fr_t *V0, const fr_t *F, const fr_t *beta_g, const gate_rec *recs, const uint32_t *row_ptr, int fft_bl) {
+__device__ __forceinline__ void k_dot_v0(fr_t *V0, const fr_t *F, const fr_t *beta_g, const gate_rec *recs, const uint32_t *row_ptr, int fft_bl) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, u = blockIdx.y;
     if (t >= (1u << fft_bl)) return;
     fr_t acc = fr_zero();
@@ -611,7 +611,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_dot_s(fr_t *part, const fr_t *F, c
         acc = fr_add(acc, fr_mul(fr_load(beta_lo + co), fr_load(F + (((size_t) (pp + co) * CI + ci) << fft_bl) + t)));
     fr_store(part + (((size_t) blockIdx.z * CI + ci) << fft_bl) + t, acc);
 }
-__global__ void __launch_bounds__(ZK_BLOCK) k_dot_v0s(fr_t *V0, const fr_t *part, const fr_t *beta_hi, uint32_t pp, uint32_t CI, uint32_t chunks, int fft_bl) {
+__device__ __forceinline__ void k_dot_v0s(fr_t *V0, const fr_t *part, const fr_t *beta_hi, uint32_t pp, uint32_t CI, uint32_t chunks, int fft_bl) {
     const uint32_t t = blockIdx.x * ZK_BLOCK + threadIdx.x, ci = blockIdx.y;
     if (t >= (1u << fft_bl)) return;
     fr_t s = fr_load(part + ((size_t) ci << fft_bl) + t);
@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_dot_v0s(fr_t *V0, const fr_t *part
     for (uint32_t p = 0; p < pp; ++p) fr_store(V0 + (((size_t) p * CI + ci) << fft_bl) + t, fr_mul(fr_load(beta_hi + p), s));
 }
 // one wave per row v
-__global__ void __launch_bounds__(ZK_BLOCK) k_row_dot(fr_t *out, const fr_t *F, const fr_t *w, uint32_t rows, int fft_bl) {
+__device__ __forceinline__ void k_row_dot(fr_t *out, const fr_t *F, const fr_t *w, uint32_t rows, int fft_bl) {
     const uint32_t v = blockIdx.x * (ZK_BLOCK / 64) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (v >= rows) return;
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_row_dot(fr_t *out, const fr_t *F, 
 }
 
 // w[j] = <L, Z[:, j]>: Hyrax opening vector (rows x cols, row-major), partial sums over row chunks
-__global__ void k_col_combine(fr_t *out, const fr_t *Z, const fr_t *L, uint32_t cols, uint32_t rows, uint32_t rows_per_chunk) {
+__device__ __forceinline__ void k_col_combine(fr_t *out, const fr_t *Z, const fr_t *L, uint32_t cols, uint32_t rows, uint32_t rows_per_chunk) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= cols) return;
     const uint32_t i0 = blockIdx.y * rows_per_chunk, i1 = min(rows, i0 + rows_per_chunk);

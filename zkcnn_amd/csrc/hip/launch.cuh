@@ -7,9 +7,11 @@
 // travel by value in the kernel argument segment (scalar loads, like any argument) -- or, when eight of them exceed its 4 KB, through a ring
 // of pinned host memory that the kernel reads in place (k_run_p).
 //
-// What a body may assume: blockIdx.x / blockIdx.y as in its own launch, and gridDim.x / gridDim.y AT LEAST as large as its own launch's
-// (a fused launch takes the largest grid any lane asked for): grid-stride loops and `if (i >= n) return` guards are fine as they are; a
-// body that counts arrivals or splits the grid into block ranges carries its own block count in its arguments.
+// What a functor's body may assume: blockIdx.x / blockIdx.y as in its own launch, and gridDim.x / gridDim.y AT LEAST as large as its own
+// launch's (a fused launch takes the largest grid any lane asked for -- the lanes' live prefixes differ with their witnesses): grid-stride
+// loops and `if (i >= n) return` guards are fine as they are; a body that counts arrivals or splits the grid into block ranges carries its
+// own block count in its arguments. Bodies launched through zk_launch_d (positional parameters, written for exactly their own grid) are only
+// fused with lanes that asked for the SAME grid. No body may use gridDim.z / blockIdx.z: that is the lane.
 // reference: each functor names the lines of src/prover.cpp it computes, as the kernels did.
 #pragma once
 #include <type_traits>
@@ -54,7 +56,7 @@ static int32_t launch_lanes(zk_batch *b, const batch_item *const *items, uint32_
 // launches functor f on ctx's stream, or defers it when ctx is a lane (then nothing is on the stream until the batch is flushed: callers
 // that need the result go through zk_batch_sync_point -- wait_slot and ZK_ORDER do)
 template <class F, int BLOCK = ZK_BLOCK>
-static inline void zk_launch_f(zk_ctx *ctx, int cls, double bytes, dim3 grid, const F &f) {
+static inline void zk_launch_f(zk_ctx *ctx, int cls, double bytes, dim3 grid, const F &f, bool exact_grid = false) {
     static_assert(std::is_trivially_copyable<F>::value && sizeof(F) <= ZK_BATCH_ARG_BYTES && sizeof(F) <= 4096, "a kernel functor is a small POD");
     if (ctx->batch) {
         ctx->batch->pending.emplace_back();
@@ -63,6 +65,7 @@ static inline void zk_launch_f(zk_ctx *ctx, int cls, double bytes, dim3 grid, co
         it.ctx = ctx;
         it.gen = ctx->n_pending++;
         it.gx = grid.x; it.gy = grid.y;
+        it.exact = exact_grid;
         it.prof_class = cls;
         it.bytes = bytes;
         std::memcpy(it.arg, (const void *) &f, sizeof(F));
@@ -71,4 +74,36 @@ static inline void zk_launch_f(zk_ctx *ctx, int cls, double bytes, dim3 grid, co
     prof_begin(ctx, cls, bytes);
     hipLaunchKernelGGL((k_run<F, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, f);
     prof_end(ctx, cls);
+}
+
+// ---- the same for a kernel body written as a __device__ function with positional parameters: zk_launch_d<body, BLOCK>(ctx, class, bytes, grid,
+// arguments...) packs the arguments into a functor whose operator() calls the body (the commitment's kernels: msm_kernels.cuh) ----
+template <class... T> struct pack_t;
+template <> struct pack_t<> {};
+template <class H, class... T> struct pack_t<H, T...> {
+    H head;
+    pack_t<T...> tail;
+};
+template <class... T> static inline pack_t<> make_pack() { return pack_t<>{}; }
+template <class H, class... T> static inline pack_t<H, T...> make_pack(const H &h, const T &...t) {
+    pack_t<H, T...> p;
+    p.head = h;
+    p.tail = make_pack<T...>(t...);
+    return p;
+}
+template <auto Body, class... Got>
+__device__ __forceinline__ void unpack_call(const pack_t<> &, const Got &...got) { Body(got...); }
+template <auto Body, class H, class... T, class... Got>
+__device__ __forceinline__ void unpack_call(const pack_t<H, T...> &p, const Got &...got) { unpack_call<Body>(p.tail, got..., p.head); }
+
+template <auto Body, class... A>
+struct call_f {
+    pack_t<A...> args;
+    __device__ __forceinline__ void operator()() const { unpack_call<Body>(args); }
+};
+template <auto Body, int BLOCK, class... A>
+static inline void zk_launch_d(zk_ctx *ctx, int cls, double bytes, dim3 grid, const A &...a) {
+    call_f<Body, A...> f;
+    f.args = make_pack<A...>(a...);
+    zk_launch_f<call_f<Body, A...>, BLOCK>(ctx, cls, bytes, grid, f, true);      // (a positional body was written for its own grid)
 }

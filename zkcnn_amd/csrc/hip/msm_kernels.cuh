@@ -18,6 +18,7 @@
 // host re-runs a flagged batch with the SAFE variant that handles them in place. No scratch memory in any of these kernels.
 #pragma once
 #include "g1_dev.cuh"
+#include "launch.cuh"
 
 #define MSM_WINDOWS 32
 #define MSM_PLANES 8
@@ -118,7 +119,7 @@ __device__ __forceinline__ void g1_accumulate(fp_t &X, fp_t &Y, fp_t &Z, bool &e
 // ------------------------------------------------------------------------------------------------
 // codes[row * cols + c]: bits 0..7 low byte of |s| (|s| <= (r-1)/2), MSM_CODE_NEG, MSM_CODE_WIDE when |s| >= 256;
 // row_flags[row] = 1 if the row holds a wide scalar (the caller then adds that row's higher windows, see k_scalar_codes_wide)
-__global__ void __launch_bounds__(256) k_scalar_codes(uint16_t *codes, uint32_t *row_flags, const fr_t *scalars, uint64_t ld, uint32_t cols) {
+__device__ __forceinline__ void k_scalar_codes(uint16_t *codes, uint32_t *row_flags, const fr_t *scalars, uint64_t ld, uint32_t cols) {
     const uint32_t row = blockIdx.y;
     bool wide = false, nonbit = false;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(256) k_scalar_codes(uint16_t *codes, uint32_t 
 // masks[row * 512 + s * 64 + j] = sum_k bit(codes[row][s * 512 + k * 64 + j]) << k  -- the eight columns lane j of the commitment kernel owns inside
 // span s -- and T8[mask][s * 64 + j] = the sum of those generators (k_subset_table). The commitment kernel then runs such a row as a row
 // of 512 "columns" with byte codes over T8: 512 mixed additions instead of ~2048. cols must be a multiple of 512. grid (2, rows), 256 threads
-__global__ void __launch_bounds__(256) k_bit_masks(uint16_t *masks, const uint16_t *codes, const uint32_t *row_flags, uint32_t cols) {
+__device__ __forceinline__ void k_bit_masks(uint16_t *masks, const uint16_t *codes, const uint32_t *row_flags, uint32_t cols) {
     const uint32_t row = blockIdx.y;
     if (row_flags[row] & MSM_ROW_NONBIT) return;
     const uint32_t spans = cols / 512;
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(64) k_subset_table(g1a_t *T8, const g1a_t *G, 
 
 // row_list[0 .. *count) = the rows whose flag is set, ascending (single block; rows <= a few 10^4); *count may exceed `cap`: the
 // list then holds the first `cap` of them and the caller takes its slow path
-__global__ void __launch_bounds__(1024) k_compact_flags(uint32_t *row_list, uint32_t *count, const uint32_t *flags, uint32_t rows, uint32_t cap) {
+__device__ __forceinline__ void k_compact_flags(uint32_t *row_list, uint32_t *count, const uint32_t *flags, uint32_t rows, uint32_t cap) {
     __shared__ uint32_t s_wave[16], s_base;
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(1024) k_compact_flags(uint32_t *row_list, uint
 // The higher windows of the rows that hold wide scalars (biases, maxima, the picture: whole rows of 2..4-byte values), as VIRTUAL rows
 // of the same hot kernel: codes[(ri * 31 + w - 1) * cols + c] = byte w of |scalars[row_list[ri]][c]| with its sign, w = 1..31.
 // k_msm_codes takes virtual row v through window table 1 + v % 31; windows no scalar reaches are rows of zeros that cost nothing.
-__global__ void __launch_bounds__(256) k_scalar_codes_wide(uint16_t *codes, const fr_t *scalars, uint64_t ld, const uint32_t *row_list,
+__device__ __forceinline__ void k_scalar_codes_wide(uint16_t *codes, const fr_t *scalars, uint64_t ld, const uint32_t *row_list,
                                                            const uint32_t *count, uint32_t cols) {
     const uint32_t ri = blockIdx.y;
     if (ri >= *count) return;                           // the grid covers the list's capacity
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(256) k_scalar_codes_wide(uint16_t *codes, cons
 }
 
 // mag[ri * cols + c] = |s| of scalars[row][c] as a canonical integer, sign in bit 255 (|s| < 2^254); row = row_map ? row_map[ri] : ri
-__global__ void __launch_bounds__(256) k_scalar_mags(fr_t *mag, const fr_t *scalars, uint64_t ld, const uint32_t *row_map, uint32_t cols) {
+__device__ __forceinline__ void k_scalar_mags(fr_t *mag, const fr_t *scalars, uint64_t ld, const uint32_t *row_map, uint32_t cols) {
     const uint32_t ri = blockIdx.y, row = row_map ? row_map[ri] : ri;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
         const fr_t raw = fr_load(scalars + (size_t) row * ld + c);
@@ -252,7 +253,7 @@ __device__ __forceinline__ bool mag_neg(const fr_t *mag, size_t i) { return (rei
 // the full byte table F[w][d][j] = d 2^(8w) g_j, of which D is window 0; only the first 31 * *n_wide of them exist.
 // ------------------------------------------------------------------------------------------------
 template <bool SAFE>
-__global__ void __launch_bounds__(MSM_BLOCK) k_msm_codes(g1j_t *out, uint32_t *exc_flag, const uint16_t *codes, const g1a_t *D, uint32_t m, uint32_t cols,
+__device__ __forceinline__ void k_msm_codes(g1j_t *out, uint32_t *exc_flag, const uint16_t *codes, const g1a_t *D, uint32_t m, uint32_t cols,
                                                          uint32_t cpt, uint32_t n_real, const uint32_t *n_wide,
                                                          const uint32_t *row_flags, const uint16_t *masks, const g1a_t *T8) {
     // the virtual rows come FIRST in the grid (their few long chains then run alongside the heavy rows instead of forming a tail);
@@ -354,7 +355,7 @@ __device__ __forceinline__ g1j_t g1_add_any(const g1j_t &p, const g1j_t &q) {
 // out[row] = sum of the n partial points in[row * n ..]: 16 lanes per row (4 rows per wave), lane l adds partials l, l + 16, ...
 // one after the other, then a 4-level tree through LDS. One launch instead of log(n) dependent ones: the chain is n / 16 - 1 + 4
 // additions deep (7 for the 64 lane sums of a commitment row) and all 64 lanes of a wave work until the tree starts.
-__global__ void __launch_bounds__(MSM_BLOCK) k_reduce_rows16(g1j_t *out, const g1j_t *in, uint32_t n, uint32_t rows) {
+__device__ __forceinline__ void k_reduce_rows16(g1j_t *out, const g1j_t *in, uint32_t n, uint32_t rows) {
     __shared__ g1j_t sm[MSM_BLOCK];
     const uint32_t l = threadIdx.x & 15, row = blockIdx.x * 4 + (threadIdx.x >> 4);
     g1j_t acc = g1_inf();
@@ -378,7 +379,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_reduce_rows16(g1j_t *out, const g
 // few-row, latency-bound MSMs of the opening and the rare wide rows of a commitment). out[row * gridDim.x + blockIdx.x]
 // ------------------------------------------------------------------------------------------------
 template <bool SAFE>
-__global__ void __launch_bounds__(MSM_BLOCK) k_msm_windows(g1j_t *out, uint32_t *exc_flag, const fr_t *mag, uint64_t ld, const uint32_t *idx_base,
+__device__ __forceinline__ void k_msm_windows(g1j_t *out, uint32_t *exc_flag, const fr_t *mag, uint64_t ld, const uint32_t *idx_base,
                                                            const g1a_t *F, uint32_t m, uint32_t cols, uint32_t cpt, uint32_t w_lo, uint32_t nwin) {
     __shared__ g1j_t sm[MSM_BLOCK];
     const uint32_t row = blockIdx.y, lane = threadIdx.x;
@@ -414,7 +415,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_windows(g1j_t *out, uint32_t 
 }
 
 // out[row * gridDim.x + b] = sum of in[row * nin + 64 b .. 64 b + 63]  (one tree level of width 64 per launch)
-__global__ void __launch_bounds__(MSM_BLOCK) k_tree_reduce(g1j_t *out, const g1j_t *in, uint32_t nin) {
+__device__ __forceinline__ void k_tree_reduce(g1j_t *out, const g1j_t *in, uint32_t nin) {
     __shared__ g1j_t sm[MSM_BLOCK];
     const uint32_t row = blockIdx.y, p = blockIdx.x * MSM_BLOCK + threadIdx.x;
     sm[threadIdx.x] = p < nin ? in[(size_t) row * nin + p] : g1_inf();
@@ -503,7 +504,7 @@ __global__ void __launch_bounds__(512) k_msm_finish(g1j_t *outJ, const g1j_t *pa
 }
 
 // rows[list[i]] += extra[i], i < min(n, *count)   (list == NULL: rows[i] += extra[i])
-__global__ void __launch_bounds__(MSM_BLOCK) k_add_rows(g1j_t *rows, const g1j_t *extra, const uint32_t *list, uint32_t n, const uint32_t *count) {
+__device__ __forceinline__ void k_add_rows(g1j_t *rows, const g1j_t *extra, const uint32_t *list, uint32_t n, const uint32_t *count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && (!count || i < *count)) {
         const uint32_t r = list ? list[i] : i;
@@ -600,7 +601,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_digit_affine(g1a_t *D, const g1j_
 // ---- batched Jacobian -> affine: ONE field inversion for all rows (Montgomery's trick), and that single inversion -- a
 // chain of ~570 dependent products, 1 ms on one GPU lane -- is done by the host between two small kernels (27 us on a CPU core).
 // per thread: running products inside its segment of AFF_SEG points (4 for up to 4096 points: short chains, the scan takes 1024 segments); seg[t] = product of the segment's Z (infinity counts as 1)
-__global__ void __launch_bounds__(MSM_BLOCK) k_aff_prefix(fp_t *pre, fp_t *seg, const g1j_t *in, uint32_t n, uint32_t AFF_SEG) {
+__device__ __forceinline__ void k_aff_prefix(fp_t *pre, fp_t *seg, const g1j_t *in, uint32_t n, uint32_t AFF_SEG) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t * AFF_SEG >= n) return;
     fp_t run = fp_one();
@@ -612,7 +613,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_aff_prefix(fp_t *pre, fp_t *seg, 
     seg[t] = run;
 }
 // single block: exclusive prefix and suffix products over the nseg segment products (in place), total product to *total
-__global__ void __launch_bounds__(1024) k_aff_scan(fp_t *seg_pre, fp_t *seg_suf, fp_t *total, const fp_t *seg, uint32_t nseg) {
+__device__ __forceinline__ void k_aff_scan(fp_t *seg_pre, fp_t *seg_suf, fp_t *total, const fp_t *seg, uint32_t nseg) {
     __shared__ fp_t a[1024], b[1024];
     const uint32_t t = threadIdx.x;
     a[t] = t < nseg ? seg[t] : fp_one();                      // inclusive prefix
@@ -632,7 +633,7 @@ __global__ void __launch_bounds__(1024) k_aff_scan(fp_t *seg_pre, fp_t *seg_suf,
     }
     if (t == 0) *total = a[nseg - 1];
 }
-__global__ void __launch_bounds__(MSM_BLOCK) k_aff_finish(g1a_t *out, const g1j_t *in, const fp_t *pre, const fp_t *seg_pre, const fp_t *seg_suf,
+__device__ __forceinline__ void k_aff_finish(g1a_t *out, const g1j_t *in, const fp_t *pre, const fp_t *seg_pre, const fp_t *seg_suf,
                                                           const fp_t *total_inv, uint32_t n, uint32_t AFF_SEG) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t * AFF_SEG >= n) return;
@@ -653,7 +654,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_aff_finish(g1a_t *out, const g1j_
     }
 }
 
-__global__ void __launch_bounds__(MSM_BLOCK) k_to_affine(g1a_t *out, const g1j_t *in, uint32_t n) {
+__device__ __forceinline__ void k_to_affine(g1a_t *out, const g1j_t *in, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = g1_to_affine(in[i]);
 }
@@ -663,7 +664,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_to_affine(g1a_t *out, const g1j_t
 // ------------------------------------------------------------------------------------------------
 // scalars of the two cross terms of one round, expressed over the ORIGINAL generators:
 //   g^(k)_i = sum_{j = i mod len} coef[j] g_j, so  L = <a_lo, g_hi> = sum_{j: (j mod len) >= h} a[(j mod len) - h] coef[j] g_j
-__global__ void k_ipa_scalars(fr_t *sL, uint32_t *idxL, fr_t *sR, uint32_t *idxR, const fr_t *a, const fr_t *coef, uint32_t m,
+__device__ __forceinline__ void k_ipa_scalars(fr_t *sL, uint32_t *idxL, fr_t *sR, uint32_t *idxR, const fr_t *a, const fr_t *coef, uint32_t m,
                               uint32_t len) {      // sL/sR and idxL/idxR are the two rows of one (2 x m/2) batch
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
@@ -679,7 +680,7 @@ __global__ void k_ipa_scalars(fr_t *sL, uint32_t *idxL, fr_t *sR, uint32_t *idxR
 }
 
 // y[0] = <a_lo, b_hi>, y[1] = <a_hi, b_lo>; single block
-__global__ void __launch_bounds__(256) k_ipa_dots(fr_t *y, const fr_t *a, const fr_t *b, uint32_t h) {
+__device__ __forceinline__ void k_ipa_dots(fr_t *y, const fr_t *a, const fr_t *b, uint32_t h) {
     __shared__ fr_t smem[2 * 256 / 64];
     fr_t acc[2] = {fr_zero(), fr_zero()};
     for (uint32_t i = threadIdx.x; i < h; i += 256) {
@@ -691,7 +692,7 @@ __global__ void __launch_bounds__(256) k_ipa_dots(fr_t *y, const fr_t *a, const 
 }
 
 // a' = a_lo + c a_hi, b' = c b_lo + b_hi (in place), coef[j] *= c for generators in the low half
-__global__ void k_ipa_fold(fr_t *a, fr_t *b, fr_t *coef, fr_t c, uint32_t m, uint32_t len) {
+__device__ __forceinline__ void k_ipa_fold(fr_t *a, fr_t *b, fr_t *coef, fr_t c, uint32_t m, uint32_t len) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t h = len >> 1;
     if (j < m && (j & (len - 1)) < h) fr_store(coef + j, fr_mul(fr_load(coef + j), c));
@@ -701,7 +702,7 @@ __global__ void k_ipa_fold(fr_t *a, fr_t *b, fr_t *coef, fr_t c, uint32_t m, uin
     }
 }
 
-__global__ void k_fill(fr_t *dst, fr_t v, uint32_t n) {
+__device__ __forceinline__ void k_fill(fr_t *dst, fr_t v, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) fr_store(dst + i, v);
 }

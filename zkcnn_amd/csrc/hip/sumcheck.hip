@@ -112,9 +112,9 @@ int32_t zk_col_combine_dev(zk_ctx *ctx, fr_t *out, const fr_t *Z, const fr_t *L,
     if (rc) return rc;
     fr_t *part = chunks == 1 ? out : (fr_t *) ctx->scratch.p;
     dim3 grid((cols + ZK_BLOCK - 1) / ZK_BLOCK, chunks);
-    ZK_LAUNCH(PC_MATVEC, 0.0, k_col_combine, grid, dim3(ZK_BLOCK), part, Z, L, cols, rows, per);
+    zk_launch_d<k_col_combine, ZK_BLOCK>(ctx, PC_MATVEC, 0.0, grid, part, Z, L, cols, rows, per);
     if (chunks > 1)
-        ZK_LAUNCH(PC_MATVEC, 0.0, k_sum_rows, dim3((cols + 63) / 64), dim3(1024), out, part, cols, chunks);
+        zk_launch_f<k_sum_rows_f, 1024>(ctx, PC_MATVEC, 0.0, dim3((cols + 63) / 64), k_sum_rows_f{out, (const fr_t *) part, cols, chunks});
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -285,7 +285,7 @@ static int32_t phi_table(zk_ctx *ctx, fr_t *out, const HFr *rx, const HFr &scale
     const uint32_t cnt = inverse ? 1u << n : 1u << (n - 1);
     fr_vec R;
     for (int j = 0; j < vars; ++j) R.v[j] = to_dev(rx[j]);
-    ZK_LAUNCH(PC_PHI, 0.0, k_phi, dim3((cnt + ZK_BLOCK - 1) / ZK_BLOCK), dim3(ZK_BLOCK), out, pw, R, to_dev(scale), n, vars, cnt);
+    zk_launch_d<k_phi, ZK_BLOCK>(ctx, PC_PHI, 0.0, dim3((cnt + ZK_BLOCK - 1) / ZK_BLOCK), out, (const fr_t *) pw, R, to_dev(scale), n, vars, cnt);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -301,9 +301,9 @@ static int32_t strided_matvec(zk_ctx *ctx, fr_t *out, const fr_t *val, const fr_
     if (rc) return rc;
     fr_t *part = chunks == 1 ? out : (fr_t *) ctx->scratch.p;
     dim3 grid((len + ZK_BLOCK - 1) / ZK_BLOCK, chunks);
-    ZK_LAUNCH(PC_MATVEC, 0.0, k_strided_matvec, grid, dim3(ZK_BLOCK), part, val, beta, len, stride, cnt, per);
+    zk_launch_d<k_strided_matvec, ZK_BLOCK>(ctx, PC_MATVEC, 0.0, grid, part, val, beta, len, stride, cnt, per);
     if (chunks > 1)
-        ZK_LAUNCH(PC_MATVEC, 0.0, k_sum_rows, dim3((len + 63) / 64), dim3(1024), out, part, len, chunks);
+        zk_launch_f<k_sum_rows_f, 1024>(ctx, PC_MATVEC, 0.0, dim3((len + 63) / 64), k_sum_rows_f{out, (const fr_t *) part, len, chunks});
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -530,7 +530,7 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
     if (padding) {
         const int fft_blh = d.fft_bit_length - 1;
         fr_t *src = ctx->beta_g[ctx->beta_g_cur], *dst = ctx->beta_g[ctx->beta_g_cur ^ 1];
-        ZK_LAUNCH(PC_EQ, 0.0, k_outer_expand, dim3(grid_for(cur.val_len)), dim3(ZK_BLOCK), dst, src, ctx->beta_gs, fft_blh, cur.val_len);
+        zk_launch_f(ctx, PC_EQ, 0.0, dim3(grid_for(cur.val_len)), k_outer_expand_f{dst, (const fr_t *) src, (const fr_t *) ctx->beta_gs, fft_blh, cur.val_len});
         ZK_HIP(hipGetLastError());
         ctx->beta_g_cur ^= 1;
     }
@@ -601,12 +601,13 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
         P2.eq1(hi, (int) ctx->bg_r.size() - k_lo, ctx->bg_r.data() + k_lo, ctx->bg_alpha);
         if ((rc = P2.launch(ctx))) return rc;
         const uint32_t tiles = (len + ZK_BLOCK - 1) / ZK_BLOCK;
+        // (k_dot_s spreads its chunks over gridDim.z, which a fused launch needs for the lanes: it stays a launch per lane)
         ZK_LAUNCH(PC_DOT, 0.0, k_dot_s, dim3(tiles, CI, chunks), dim3(ZK_BLOCK), ctx->dot_part, (const fr_t *) prev.val, (const fr_t *) lo, pp, CO, CI, per, fft_bl);
-        ZK_LAUNCH(PC_DOT, 0.0, k_dot_v0s, dim3(tiles, CI), dim3(ZK_BLOCK), ctx->tp[0].V[0], (const fr_t *) ctx->dot_part, (const fr_t *) hi, pp, CI, chunks, fft_bl);
+        zk_launch_d<k_dot_v0s, ZK_BLOCK>(ctx, PC_DOT, 0.0, dim3(tiles, CI), ctx->tp[0].V[0], (const fr_t *) ctx->dot_part, (const fr_t *) hi, pp, CI, chunks, fft_bl);
         ZK_HIP(hipGetLastError());
     } else if (cur.d1_live_rows) {
         dim3 grid(((1u << fft_bl) + ZK_BLOCK - 1) / ZK_BLOCK, cur.d1_live_rows);
-        ZK_LAUNCH(PC_DOT, 0.0, k_dot_v0, grid, dim3(ZK_BLOCK), ctx->tp[0].V[0], prev.val, ctx->beta_g[ctx->beta_g_cur], cur.d1, cur.d1_rowptr, fft_bl);
+        zk_launch_d<k_dot_v0, ZK_BLOCK>(ctx, PC_DOT, 0.0, grid, ctx->tp[0].V[0], (const fr_t *) prev.val, (const fr_t *) ctx->beta_g[ctx->beta_g_cur], (const gate_rec *) cur.d1, (const uint32_t *) cur.d1_rowptr, fft_bl);
         ZK_HIP(hipGetLastError());
     }
     return ZK_OK;
@@ -675,7 +676,7 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
         fill |= 2;
     }
     const uint32_t g = std::min<uint32_t>(grid_for((fill & 2) || first ? std::max<uint64_t>(first ? std::min<uint64_t>(npairs, (x_live + 1) / 2) : pl, 1) : npairs, 1024), ctx->partial_blocks);
-    ZK_LAUNCH(PC_ROUND_CUBIC, (first ? 32.0 : 48.0) * (double) (n + x_live), k_round_cubic, dim3(g), dim3(ZK_BLOCK), t0.V[t0.cur], vin(t1),
+    zk_launch_d<k_round_cubic, ZK_BLOCK>(ctx, PC_ROUND_CUBIC, (first ? 32.0 : 48.0) * (double) (n + x_live), dim3(g), (const fr_t *) t0.V[t0.cur], vin(t1),
               t0.V[t0.cur ^ 1], t1.V[t1.cur ^ 1], (const fr_t *) ctx->small[ctx->small_cur], ctx->small_len, n, to_dev(r), first ? 1 : 0, ctx->partials,
               ctx->d_counter, (host_slot *) ctx->d_slot, seq, ms_raw, ms_out, x_live, fill);
     ZK_HIP(hipGetLastError());
@@ -765,7 +766,7 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
         if (rows < t.len) P.zero(t.V[0] + rows, t.len - rows);              // (k_row_dot writes one entry per row)
         if (cur.p2_cov[1] < t.len) P.zero(t.M[0] + cur.p2_cov[1], t.len - cur.p2_cov[1]);
         if ((rc = P.launch(ctx))) return rc;
-        ZK_LAUNCH(PC_DOT, 0.0, k_row_dot, dim3((rows + 3) / 4), dim3(ZK_BLOCK), t.V[0], prev.val, ctx->beta_gs, rows, fft_bl);
+        zk_launch_d<k_row_dot, ZK_BLOCK>(ctx, PC_DOT, 0.0, dim3((rows + 3) / 4), t.V[0], (const fr_t *) prev.val, (const fr_t *) ctx->beta_gs, rows, fft_bl);
         ZK_HIP(hipGetLastError());
         gate_job j = {t.M[0], cur.p2[1], cur.n_p2[1], cur.n_p2_real[1], 0, cur.p2_G[1], cur.p2_uniform[1], t.len};
         return gate_multi(ctx, 2, prev, &j, 1, nullptr);
