@@ -260,6 +260,17 @@ extern "C" int32_t zk_batch_detach(zk_batch *b, zk_ctx *ctx) {
 }
 extern "C" void zk_batch_destroy(zk_batch *b) {
     if (!b) return;
+    if (getenv("ZKCNN_BATCH_TRACE")) {
+        fprintf(stderr, "[zkcnn batch] %llu fused launches for %llu lane launches, %llu flushes (%llu empty)\n", (unsigned long long) b->n_launches,
+                (unsigned long long) b->n_lane_launches, (unsigned long long) b->n_flushes, (unsigned long long) b->n_empty_flushes);
+        for (const auto &kv : b->by_kernel) {
+            std::string nm = kv.first;
+            const size_t at = nm.find("F = ");
+            if (at != std::string::npos) nm = nm.substr(at + 4);
+            if (nm.size() > 90) nm.resize(90);
+            fprintf(stderr, "[zkcnn batch]   %8llu launches %8llu lanes  %s\n", (unsigned long long) kv.second.first, (unsigned long long) kv.second.second, nm.c_str());
+        }
+    }
     while (!b->lanes.empty()) (void) zk_batch_detach(b, b->lanes.back());
     (void) hipSetDevice(b->device);
     if (b->stream) { (void) hipStreamSynchronize(b->stream); (void) hipStreamDestroy(b->stream); }
@@ -330,6 +341,9 @@ extern "C" int32_t zk_batch_flush(zk_batch *b) {
             prof_end(ctx, items[i].prof_class);
             ++b->n_launches;
             b->n_lane_launches += n;
+            std::pair<uint64_t, uint64_t> &st = b->by_kernel[items[i].name];
+            ++st.first;
+            st.second += n;
         }
     if (rc != ZK_OK && b->err.empty()) b->err = "a fused launch failed";
     return rc;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 #include "../../../include/zkcnn_hip.h"
@@ -283,6 +284,7 @@ struct batch_item {
     uint32_t gen;                  // position in the lane's own sequence of deferred launches
     uint32_t gx, gy;               // the grid this lane's launch would have had
     bool exact;                    // the body relies on gridDim being its own launch's: fused only with lanes that asked for the same grid
+    const char *name;              // the functor's type, as the compiler spells it (fusion report)
     int prof_class;
     double bytes;                  // its algorithmic bytes (profiler)
     alignas(16) unsigned char arg[ZK_BATCH_ARG_BYTES];
@@ -305,6 +307,7 @@ struct zk_batch {
     bool ring_ev_set[4] = {false, false, false, false};
     // statistics: launches issued by flushes, lane launches they stood for, flushes, flushes that found nothing to do
     uint64_t n_launches = 0, n_lane_launches = 0, n_flushes = 0, n_empty_flushes = 0;
+    std::map<const char *, std::pair<uint64_t, uint64_t>> by_kernel;       // fusion report (ZKCNN_BATCH_TRACE=1: printed when the batch is destroyed)
 };
 // Every point where a lane needs its deferred launches on the stream (it is about to wait for a result, or to put something else on the
 // stream): hand the thread to the batch's driver, which runs the other lanes up to their own such points and flushes; without a driver (no
@@ -320,6 +323,14 @@ static inline hipError_t zk_stream_sync(zk_ctx *ctx) {
 #define ZK_STREAM(call) do { ZK_ORDER(); ZK_HIP(call); } while (0)
 // before anything that is not deferred goes onto the stream of a context: keep the lane's order
 #define ZK_ORDER() do { if (ctx->batch && ctx->n_pending) { int32_t rc_o_ = zk_batch_sync_point(ctx); if (rc_o_) return rc_o_; } } while (0)
+
+// (for a `void` context -- the timing lambdas of the micro-benchmarks, which never run on a lane: no ordering check, no status)
+#define ZK_LAUNCH_RAW(cls, bytes, kern, grid, block, ...)                                \
+    do {                                                                                  \
+        prof_begin(ctx, cls, bytes);                                                      \
+        hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, __VA_ARGS__);               \
+        prof_end(ctx, cls);                                                               \
+    } while (0)
 
 #define ZK_HIP(call)                                                                           \
     do {                                                                                       \

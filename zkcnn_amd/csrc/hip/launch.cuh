@@ -66,6 +66,7 @@ static inline void zk_launch_f(zk_ctx *ctx, int cls, double bytes, dim3 grid, co
         it.gen = ctx->n_pending++;
         it.gx = grid.x; it.gy = grid.y;
         it.exact = exact_grid;
+        it.name = __PRETTY_FUNCTION__;
         it.prof_class = cls;
         it.bytes = bytes;
         std::memcpy(it.arg, (const void *) &f, sizeof(F));

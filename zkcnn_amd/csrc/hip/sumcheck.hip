@@ -1667,7 +1667,7 @@ extern "C" int32_t zk_bench_fr_mul(zk_ctx *ctx, uint64_t n_threads, uint32_t mul
     if ((rc = eq_table1(ctx, (fr_t *) ctx->scratch.p, lg, r.data(), HFr(77LL)))) return rc;
     const uint32_t blocks = (uint32_t) ((n_threads + ZK_BLOCK - 1) / ZK_BLOCK);
     return time_launches(ctx, iters, sec, [&] {
-        ZK_LAUNCH(PC_MISC, 0.0, k_bench_fr_mul, dim3(blocks), dim3(ZK_BLOCK), (fr_t *) ctx->scratch.p, muls_per_thread, n_threads);
+        ZK_LAUNCH_RAW(PC_MISC, 0.0, k_bench_fr_mul, dim3(blocks), dim3(ZK_BLOCK), (fr_t *) ctx->scratch.p, muls_per_thread, n_threads);
     });
 }
 
@@ -1678,7 +1678,7 @@ extern "C" int32_t zk_bench_copy(zk_ctx *ctx, uint64_t bytes, uint32_t iters, do
     uint4 *src = (uint4 *) ctx->scratch.p, *dst = src + bytes / 16;
     ZK_HIP(hipMemsetAsync(src, 1, bytes, ctx->stream));
     return time_launches(ctx, iters, sec, [&] {
-        ZK_LAUNCH(PC_MISC, 0.0, k_bench_copy, dim3(4096), dim3(ZK_BLOCK), dst, src, bytes / 16);
+        ZK_LAUNCH_RAW(PC_MISC, 0.0, k_bench_copy, dim3(4096), dim3(ZK_BLOCK), dst, src, bytes / 16);
     });
 }
 
@@ -1717,7 +1717,7 @@ extern "C" int32_t zk_bench_round_quadratic(zk_ctx *ctx, uint32_t log_n, uint32_
     *algorithmic_bytes = 96.0 * (double) n;
     rc = time_launches(ctx, iters, sec_per_launch, [&] {
         A.seq = ++ctx->slot_seq;
-        ZK_LAUNCH(PC_ROUND_QUAD, 96.0 * (double) n, k_round_quad2, dim3(A.blocks[0]), dim3(ZK_BLOCK), A);
+        ZK_LAUNCH_RAW(PC_ROUND_QUAD, 96.0 * (double) n, k_round_quad2, dim3(A.blocks[0]), dim3(ZK_BLOCK), A);
     });
     if (rc) return rc;
     return wait_slot(ctx, ctx->slot_seq);
