@@ -258,20 +258,35 @@ def test_bench_launches_its_own_ranks(tmp_path):
 
 
 def test_bench_parent_prints_the_last_line_its_child_left(monkeypatch, capsys):
-    """`python bench.py` at N = 1 measures in a child process that leaves its line in a file after every stage; the parent prints the last one --
-    also when the child dies in a late stage (seen once on the GPU box: a memory fault behind the timed region) -- and fails only if there is none"""
+    """`python bench.py` at N = 1 measures in a child process that leaves its line in a file after every stage; the parent prints the last one.
+    A child that dies in the LAST, optional stage (the PMC counter passes: it marks the line before it starts them) costs roofline.traffic, not the
+    run; a child that dies anywhere else -- a byte-parity mismatch, a crash in a companion -- is a FAILED run: the line is printed with the child's
+    exit code in it and the parent exits non-zero (round-3 advisor finding: it used to exit 0)."""
+    import json
     import bench
 
-    def child_that_dies_late(cmd, env):
-        assert "--inner" in cmd and cmd[-2:] == ["--steps", "3"]
-        with open(env["ZKCNN_BENCH_RESULT"], "w") as f:
-            f.write('{"metric": "m", "value": 1.5, "incomplete_after": "companions"}')
-        return -6
+    def child(line, rc):
+        def run(cmd, env):
+            assert "--inner" in cmd and cmd[-2:] == ["--steps", "3"]
+            with open(env["ZKCNN_BENCH_RESULT"], "w") as f:
+                f.write(line)
+            return rc
+        return run
 
-    monkeypatch.setattr(bench, "_run_child", child_that_dies_late)
+    monkeypatch.setattr(bench, "_run_child", child('{"metric": "m", "value": 1.5, "incomplete_after": "CPU baseline; PMC", "only_optional_stages_left": true}', -6))
     assert bench.supervise(["--steps", "3"]) == 0
     out = capsys.readouterr()
-    assert out.out.strip() == '{"metric": "m", "value": 1.5, "incomplete_after": "companions"}' and "-6" in out.err
+    d = json.loads(out.out.strip())
+    assert d["value"] == 1.5 and d["child_rc"] == -6 and "-6" in out.err
+    monkeypatch.setattr(bench, "_run_child", child('{"metric": "m", "value": 1.5, "incomplete_after": "FAILED: the GPU transcript differs", "transcript_equal_to_cpu_oracle": false}', 1))
+    assert bench.supervise(["--steps", "3"]) == 1
+    d = json.loads(capsys.readouterr().out.strip())
+    assert d["child_rc"] == 1 and d["transcript_equal_to_cpu_oracle"] is False
+    monkeypatch.setattr(bench, "_run_child", child('{"metric": "m", "value": 1.5, "incomplete_after": "companions"}', -11))
+    assert bench.supervise(["--steps", "3"]) != 0                          # a crash in a companion stage: the line is there, the run failed
+    capsys.readouterr()
+    monkeypatch.setattr(bench, "_run_child", child('{"metric": "m", "value": 2.5}', 0))
+    assert bench.supervise(["--steps", "3"]) == 0 and json.loads(capsys.readouterr().out.strip()) == {"metric": "m", "value": 2.5}
     monkeypatch.setattr(bench, "_run_child", lambda cmd, env: 3)            # a child that left nothing (no GPU, bad arguments)
     with pytest.raises(SystemExit) as e:
         bench.supervise([])
