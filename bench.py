@@ -50,8 +50,8 @@ WORKLOADS = {
     "vgg11_half": ("vgg:32 M 64 M 128 128 M 256 256 M 256 256 M", (32, 32, 3), 1),
 }
 # kernel classes whose algorithmic byte count is defined; the dominant one is reported
-ROOFLINE_CLASSES = ["gate_reduce", "round_quad", "round_cubic", "msm_planes"]
-HBM_CLASSES = ["gate_reduce", "round_quad", "round_cubic"]
+ROOFLINE_CLASSES = ["gate_reduce", "round_quad", "round_fine", "round_cubic", "msm_planes"]
+HBM_CLASSES = ["gate_reduce", "round_quad", "round_fine", "round_cubic"]
 DATA_SEED = 20260928         # synthetic picture + weights
 PARITY_SEED = 0x5EED0001     # challenge stream of the proof whose transcript is compared with the CPU oracle's, byte for byte
 
@@ -68,15 +68,23 @@ def launch_command(argv, n_gpus, port=None, python=None):
 
 
 # kernels behind each byte-counted class of the built-in profiler (names as rocprofv3 reports them)
-CLASS_KERNELS = {"round_quad": ("k_round_quad2", "k_round_quad_fine"), "round_tail": ("k_tail",), "round_cubic": ("k_round_cubic",),
+# (kernels are functors launched through k_run<F> / k_run_b<F>: the functor's name is part of the kernel's)
+CLASS_KERNELS = {"round_quad": ("k_round_quad2_f",), "round_fine": ("k_round_fine_f",), "round_tail": ("k_tail",), "round_cubic": ("k_round_cubic",),
                  "gate_reduce": ("k_gate_multi", "k_conv_wa", "k_conv_m1", "k_conv_e", "k_conv_ae", "k_conv_m2"),
                  "msm_planes": ("k_msm_codes", "k_msm_windows", "k_msm_planes", "k_scalar_codes", "k_scalar_mags", "k_bit_masks", "k_compact_flags")}
 
 
-def measure_pmc_traffic(workload, kernels, timeout_s=150):
-    """HBM bytes per launch of `kernels`, measured NOW: two short child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE
-    in separate passes, as MI355X_MICROARCH.md prescribes: they do not fit one pass; KB counters; FETCH_SIZE doubled -- gfx950 tallies the 128-byte
-    requests of wide coalesced reads at 64 bytes). One session, a few proofs. None if rocprofv3 is missing or anything goes wrong."""
+CALIBRATION_KERNEL = "k_round_quad2(round2_args)"      # the plain kernel zk_bench_round_quadratic launches: 2 x 2^24 entries, known byte count
+CALIBRATION_LOG_N = 24
+
+
+def measure_pmc_traffic(workload, kernels, timeout_s=200):
+    """HBM bytes per launch of `kernels`, measured NOW: two short child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in
+    separate passes, as MI355X_MICROARCH.md prescribes: they do not fit one pass; KB counters). The guide's gfx950 correction (FETCH_SIZE x 2) is
+    calibrated for 16-byte-per-lane streaming reads only and tells callers to calibrate their own access pattern: the child therefore ALSO runs the
+    round kernel on two device-resident 2^24-entry tables (1 GiB read, 0.5 GiB written per launch: known, and far beyond the 256 MiB Infinity Cache),
+    and the raw counters of the proof's launches are scaled by (known bytes / raw counter) of those calibration launches -- no hard-coded factor.
+    One session, four proofs with every round a launch. None if rocprofv3 is missing or anything goes wrong."""
     import csv
     import glob
     import shutil
@@ -84,9 +92,10 @@ def measure_pmc_traffic(workload, kernels, timeout_s=150):
     import tempfile
     if not shutil.which("rocprofv3"):
         return None
-    total, launches = {}, 0
+    known = {"FETCH_SIZE": 64.0 * (1 << CALIBRATION_LOG_N), "WRITE_SIZE": 32.0 * (1 << CALIBRATION_LOG_N)}     # bytes per calibration launch
+    total, launches, factor = {}, 0, {}
     try:
-        for counter, scale in (("FETCH_SIZE", 2 * 1024.0), ("WRITE_SIZE", 1024.0)):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             with tempfile.TemporaryDirectory(prefix="zkcnn_pmc_") as tmp:
                 cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
                        sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", workload]
@@ -101,31 +110,39 @@ def measure_pmc_traffic(workload, kernels, timeout_s=150):
                     os.killpg(proc.pid, signal.SIGKILL)
                     proc.wait()
                     return None
-                val, n = 0.0, 0
+                val, n, cal, n_cal = 0.0, 0, 0.0, 0
                 for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                     for r in csv.DictReader(open(f)):
                         if r.get("Counter_Name") != counter:
                             continue
                         name = r["Kernel_Name"].replace("void ", "")
-                        if any(name.startswith(k) for k in kernels):
+                        if name.startswith(CALIBRATION_KERNEL.split("(")[0] + "("):
+                            cal += float(r["Counter_Value"])
+                            n_cal += 1
+                        elif any(k in name for k in kernels):
                             val += float(r["Counter_Value"])
                             n += 1
-                if not n:
+                if not n or not n_cal or cal <= 0:
                     return None
-                total[counter], launches = val * scale, n
-        return {"bytes_per_launch": (total["FETCH_SIZE"] + total["WRITE_SIZE"]) / launches, "fetch_bytes_x2": total["FETCH_SIZE"], "write_bytes": total["WRITE_SIZE"],
-                "launches": launches, "kernels": list(kernels)}
+                factor[counter] = known[counter] / (cal / n_cal)          # bytes per counter unit, for this kernel's access pattern
+                total[counter], launches = val * factor[counter], n
+        return {"bytes_per_launch": (total["FETCH_SIZE"] + total["WRITE_SIZE"]) / launches, "fetch_bytes": total["FETCH_SIZE"], "write_bytes": total["WRITE_SIZE"],
+                "launches": launches, "kernels": list(kernels),
+                "bytes_per_counter_unit": {k: round(v, 1) for k, v in factor.items()}}
     except Exception:       # noqa: BLE001 - an optional measurement
         return None
 
 
 def pmc_child(workload):
-    """what measure_pmc_traffic profiles: one session, four proofs in the modes of the timed steps"""
+    """what measure_pmc_traffic profiles: the calibration launches (known bytes), then one session, four proofs with every round a launch"""
     import zkcnn_amd
     model, pic, pp = WORKLOADS[workload]
+    hc = zkcnn_amd.HipContext(0)
+    hc.bench_round_quadratic(CALIBRATION_LOG_N, 4)
+    hc.close()
     with zkcnn_amd.Session(model, pic, pp, data_seed=DATA_SEED) as s:
         for k in range(4):
-            s.prove(seed=0x5EED3000 + k, mode=zkcnn_amd.MODE_DRIVE_ONLY | zkcnn_amd.MODE_REUSE_GENS, want_transcript=False)
+            s.prove(seed=0x5EED3000 + k, mode=zkcnn_amd.MODE_DRIVE_ONLY | zkcnn_amd.MODE_REUSE_GENS | zkcnn_amd.MODE_HOST_ROUNDS, want_transcript=False)
 
 
 HOST_BYTES_PER_SESSION = 6e9      # a vgg11 session holds 2.7 GB on the host, 4.3 GB at its peak while it is built (host_peak_rss_gb_while_building)
@@ -504,7 +521,7 @@ def main():
             indep = {"proofs_per_s_independent_streams": round(n_ind * args.steps / (time.perf_counter() - t_i), 3), "independent_streams": n_ind}
 
     # ---- lock-step batches: LANES sessions share one host thread, one stream and one launch per round (zkcnn_amd.BatchSession) ----
-    batches = []
+    batches, batch_table = [], None
     if LANES > 1:
         batches = [zkcnn_amd.BatchSession(sessions[j * LANES:(j + 1) * LANES]) for j in range(B)]
 
@@ -522,6 +539,13 @@ def main():
         [t.join() for t in th_b]
         if errs_b:
             raise errs_b[0]
+        # one batch proof with nothing else on the GPU and events on every class: what a FUSED launch of each kernel class costs uncontended
+        sess.profile("all")
+        batches[0].prove(seeds=[0x5EED0A80 + i for i in range(LANES)], mode=drive, want_transcript=False)
+        batch_table = sess.profile_report(reset=True)
+        sess.profile([dominant])
+        if os.environ.get("ZKCNN_BENCH_NOEVENTS"):
+            sess.profile(None)
         fusion0 = batches[0].stats()
 
     stage("timed steps")
@@ -582,6 +606,14 @@ def main():
             gatherer.submit(rank, dp.pack([(rank * K + i, tr) for i, (_, tr) in enumerate(batch)]))
     [t.join() for t in workers]
     rank_busy_s = time.perf_counter() - t_start          # this rank's own proving time (no collective, no other rank in it)
+    fusion = {}
+    if batches:
+        f1 = batches[0].stats()
+        fusion = {"fused_launches_per_proof": round((f1["fused_launches"] - fusion0["fused_launches"]) / args.steps / LANES, 1),
+                  "fused_launches_per_batch_proof": round((f1["fused_launches"] - fusion0["fused_launches"]) / args.steps, 1),
+                  "lanes_per_fused_launch": round((f1["lane_launches"] - fusion0["lane_launches"]) / max(f1["fused_launches"] - fusion0["fused_launches"], 1), 2),
+                  "rounds_per_proof": firsts[0].n_rounds,
+                  "note": "batch 0 over the timed steps: every deferred launch of a batch proof is ONE launch over all its lanes"}
     last_proofs = [tr for _, tr in batch]          # the last timed proof of every stream, checked after the clock stops
     gather_wait_s = 0.0
     if gatherer is not None:
@@ -730,9 +762,10 @@ def main():
                 try:
                     for k in range(ref_steps):
                         if LANES > 1:
-                            batches[j].prove(seeds=[0x5EED4000 + 16 * k + i for i in range(LANES)], mode=fresh_mode, want_transcript=True)
+                            # (a seed of its own for every proof: the verifier draws the generators from its seeded stream)
+                            batches[j].prove(seeds=[0x5EED4000 + 4096 * j + 16 * k + i for i in range(LANES)], mode=fresh_mode, want_transcript=True)
                         else:
-                            sessions[j].prove(seed=0x5EED4000 + k, mode=fresh_mode, want_transcript=True)
+                            sessions[j].prove(seed=0x5EED4000 + 4096 * j + k, mode=fresh_mode, want_transcript=True)
                 except BaseException as e:      # noqa: BLE001
                     errs_r.append(e)
             th_r = [threading.Thread(target=run_r, args=(j,)) for j in range(B if LANES > 1 else K)]
@@ -744,13 +777,6 @@ def main():
             ref_mode = {"proofs_per_s_fresh_gens_full_ipa": round(K * ref_steps / (time.perf_counter() - t_rf), 3)}
         except Exception as e:      # noqa: BLE001 - the headline does not depend on this
             ref_mode = {"fresh_gens_full_ipa_error": str(e)}
-    fusion = {}
-    if batches:
-        f1 = batches[0].stats()
-        n_bp = args.steps + (args.steps if new_image.get("proofs_per_s_new_picture_each_proof") else 0) + (ref_steps if ref_mode.get("proofs_per_s_fresh_gens_full_ipa") else 0)
-        fusion = {"fused_launches_per_proof": round((f1["fused_launches"] - fusion0["fused_launches"]) / max(n_bp, 1) / LANES, 1),
-                  "lanes_per_fused_launch": round((f1["lane_launches"] - fusion0["lane_launches"]) / max(f1["fused_launches"] - fusion0["fused_launches"], 1), 2),
-                  "rounds_per_proof": first.n_rounds}
     for x in batches:
         x.close()
     batches = []
@@ -789,6 +815,19 @@ def main():
         except Exception as e:      # the headline numbers do not depend on this extra measurement
             roofline["streaming_launch"] = {"error": str(e)}
 
+    if roofline is not None and batch_table:
+        # every byte-counted class of ONE batch proof that had the GPU to itself (fused launches over all lanes): launches, time, bytes -> GB/s
+        cls = {}
+        for c in ROOFLINE_CLASSES:
+            t = batch_table[c]
+            if t["launches"]:
+                gbs = t["bytes"] / max(t["ms"] * 1e-3, 1e-12) / 1e9
+                cls[c] = {"launches_per_batch_proof": t["launches"], "ms_per_batch_proof": round(t["ms"], 3), "algorithmic_GB": round(t["bytes"] / 1e9, 3),
+                          "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(t["ms"] / t["launches"], 4)}
+        roofline["classes"] = cls
+        roofline["classes_note"] = (f"one batch proof ({LANES} lanes) alone on the GPU, HIP events on every launch: round_quad = the product kernel on tables above 2^16 entries "
+                                    "(the streaming class: read against the HBM roof / the multiplier ceiling), round_fine = the 4-lanes-per-quad latency kernel of the small rounds "
+                                    "(one launch per round for all lanes: a dependent chain, not a stream), msm_planes = the commitment (integer ALU)")
     if roofline is not None:
         # whole-GPU view of the multi-stream regime: algorithmic bytes of one proof (all byte-counted classes) x proofs/s of this GPU
         per_gpu = K * args.steps / elapsed
@@ -855,7 +894,7 @@ def main():
         #   gate sums: 80 B per multiplication gate = ~1.5 products (the gather operand, the scale)
         #   eq tables: ~2 products per entry of every layer table (one per claim point); commitment: one mixed addition = 11 Fp products
         #   (12-limb: 288 + 288 MACs against the 136 + 136 of an Fr product = 2.12 Fr equivalents) per non-zero scalar byte, ~0.72 of the scalars
-        fr_muls = (bytes_of["round_quad"] / 96.0 * 1.5 + bytes_of["round_cubic"] / 96.0 * 1.75 + bytes_of["gate_reduce"] / 80.0 * 1.5 +
+        fr_muls = ((bytes_of["round_quad"] + bytes_of["round_fine"]) / 96.0 * 1.5 + bytes_of["round_cubic"] / 96.0 * 1.75 + bytes_of["gate_reduce"] / 80.0 * 1.5 +
                    2.0 * float(first.table_entries) + bytes_of["msm_planes"] / 32.0 * 0.72 * 11 * 2.12)
         per_gpu = K * args.steps / elapsed
         if mul_ceiling:
@@ -935,8 +974,9 @@ def main():
         pmc = measure_pmc_traffic(args.workload, CLASS_KERNELS[dominant])
         if pmc:
             roofline["traffic"] = round(pmc["bytes_per_launch"], 1)
-            roofline["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH doubled, the gfx950 correction of "
-                                          f"MI355X_MICROARCH.md) over {pmc['launches']} launches of {', '.join(pmc['kernels'])} in four single-stream proofs")
+            roofline["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over {pmc['launches']} launches of {', '.join(pmc['kernels'])} in four "
+                                          f"single-stream proofs with every round a launch; counter units calibrated IN THE SAME PASS on the same kernel's 2 x 2^24-entry launch (known bytes): "
+                                          f"{pmc['bytes_per_counter_unit']} bytes per unit (the guide's x2 for FETCH_SIZE holds for 16-byte-per-lane streams; this kernel's lanes read 128 contiguous bytes each)")
             roofline["traffic_over_algorithmic"] = round(pmc["bytes_per_launch"] / max(lat_prof["bytes"] / max(lat_prof["launches"], 1), 1.0), 3)
         else:
             roofline["traffic_source"] = "rocprofv3 not available (or the counter pass failed): not measured"

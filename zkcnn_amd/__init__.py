@@ -357,7 +357,7 @@ class _SessionBase:
 
 
 PROFILE_CLASSES = ["eq_table", "gather", "gate_reduce", "gate_fixup", "gate_sum", "sum_partials", "round_quad", "round_cubic", "fold",
-                   "matvec", "phi", "dot_prod", "liu_scatter", "msm_planes", "msm_finish", "msm_tables", "ipa", "misc", "round_tail"]
+                   "matvec", "phi", "dot_prod", "liu_scatter", "msm_planes", "msm_finish", "msm_tables", "ipa", "misc", "round_tail", "round_fine"]
 
 
 def sharing_stats():

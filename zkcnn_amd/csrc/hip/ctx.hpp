@@ -86,10 +86,10 @@ struct zk_batch;                   // below: a lock-step batch of contexts on on
 
 // kernel classes of the built-in profiler (HIP events on the context's stream)
 enum prof_class { PC_EQ = 0, PC_GATHER, PC_GATE, PC_GATE_FIX, PC_GATE_SUM, PC_SUM, PC_ROUND_QUAD, PC_ROUND_CUBIC, PC_FOLD, PC_MATVEC,
-                  PC_PHI, PC_DOT, PC_LIU, PC_MSM_PLANES, PC_MSM_FINISH, PC_MSM_TABLES, PC_IPA, PC_MISC, PC_TAIL, PC_COUNT };
+                  PC_PHI, PC_DOT, PC_LIU, PC_MSM_PLANES, PC_MSM_FINISH, PC_MSM_TABLES, PC_IPA, PC_MISC, PC_TAIL, PC_ROUND_FINE, PC_COUNT };
 static const char *const prof_names[PC_COUNT] = {"eq_table", "gather", "gate_reduce", "gate_fixup", "gate_sum", "sum_partials", "round_quad",
                                                  "round_cubic", "fold", "matvec", "phi", "dot_prod", "liu_scatter", "msm_planes",
-                                                 "msm_finish", "msm_tables", "ipa", "misc", "round_tail"};
+                                                 "msm_finish", "msm_tables", "ipa", "misc", "round_tail", "round_fine"};
 struct prof_pending { hipEvent_t e0, e1; int cls; double bytes; };
 
 struct zk_ctx {

@@ -1354,7 +1354,7 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
         // (a lane of a batch defers the launch: one launch runs this round of every lane -- launch.cuh; wait_slot below hands over to the driver)
         if (fine) {
             const uint32_t blocks = (uint32_t) ((fine_items + ZK_BLOCK / 4 - 1) / (ZK_BLOCK / 4));
-            zk_launch_f(ctx, PC_ROUND_QUAD, alg_bytes, dim3(blocks), k_round_fine_f{A});
+            zk_launch_f(ctx, PC_ROUND_FINE, alg_bytes, dim3(blocks), k_round_fine_f{A});      // (its own profiler class: the latency kernel of the small rounds)
         } else zk_launch_f(ctx, PC_ROUND_QUAD, alg_bytes, dim3(A.blocks[0] + A.blocks[1]), k_round_quad2_f{A});
         ZK_HIP(hipGetLastError());
         for (int b = 0; b < 2; ++b) {
