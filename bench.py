@@ -540,6 +540,7 @@ def main():
         if errs_b:
             raise errs_b[0]
         # one batch proof with nothing else on the GPU and events on every class: what a FUSED launch of each kernel class costs uncontended
+        sess.profile_report(reset=True)          # (events the session collected on its own before it became a lane)
         sess.profile("all")
         batches[0].prove(seeds=[0x5EED0A80 + i for i in range(LANES)], mode=drive, want_transcript=False)
         batch_table = sess.profile_report(reset=True)

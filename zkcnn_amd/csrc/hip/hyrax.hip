@@ -13,6 +13,7 @@
 #include <atomic>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include "ctx.hpp"
 #include "msm_kernels.cuh"
 #include "../ff/g1.hpp"
@@ -71,6 +72,22 @@ struct gen_tables {
     g1a_t *t8 = nullptr; bool t8_ready = false;
 };
 static std::mutex g_gen_mtx;
+// The lock of a generator set, taken by a context. A lane of a lock-step batch may be PARKED while it holds the lock (the tables of a fresh set are
+// built with deferred launches, so that the lanes' builds fuse), and the other lanes run on the same thread: whoever finds the lock taken hands
+// the thread on (zk_batch_sync_point) instead of blocking in it.
+struct set_lock {
+    gen_tables *e;
+    int32_t rc = ZK_OK;
+    set_lock(zk_ctx *ctx, gen_tables *entry) : e(entry) {
+        while (!e->mtx.try_lock()) {
+            if (ctx->batch) { if ((rc = zk_batch_sync_point(ctx))) { e = nullptr; return; } }
+            else std::this_thread::yield();
+        }
+    }
+    ~set_lock() { if (e) e->mtx.unlock(); }
+    set_lock(const set_lock &) = delete;
+    set_lock &operator=(const set_lock &) = delete;
+};
 static std::vector<gen_tables *> g_gen_sets;
 static std::atomic<uint64_t> g_gen_builds{0}, g_gen_full_builds{0};
 extern "C" void zk_generator_table_stats(uint64_t *window_table_builds, uint64_t *byte_table_builds) {
@@ -119,7 +136,7 @@ static void msm_destroy_one(zk_ctx *ctx) {
 static int32_t regrow(zk_ctx *ctx, void **p, size_t *cap, size_t bytes) {
     if (*cap >= bytes) return ZK_OK;
     ZK_ORDER();                        // (a lane of a batch: launches it has deferred may still read the buffer that is let go)
-    if (*p) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(*p)); *p = nullptr; *cap = 0; }
+    if (*p) { ZK_HIP(zk_stream_sync(ctx)); ZK_HIP(hipFree(*p)); *p = nullptr; *cap = 0; }
     ZK_HIP(hipMalloc(p, bytes));
     *cap = bytes;
     return ZK_OK;
@@ -143,11 +160,12 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
     msm_state *s = ctx->msm;
     ZK_ORDER();                        // nothing of this lane may be deferred while a table is built under the set's lock (the other lanes run on this thread)
     if (s->gt && s->m == m && s->gens_host.size() == m * 12 && std::memcmp(s->gens_host.data(), gens, m * 96) == 0) {
-        std::lock_guard<std::mutex> g(s->gt->mtx);
+        set_lock g(ctx, s->gt);
+        if (g.rc) return g.rc;
         ++s->gt->uses;
         return ZK_OK;
     }
-    ZK_HIP(hipStreamSynchronize(ctx->stream));          // (nothing of this context may still read the set that is let go)
+    ZK_HIP(zk_stream_sync(ctx));          // (nothing of this context may still read the set that is let go)
     gen_release(ctx, s);
     gen_tables *e = nullptr;
     {
@@ -166,7 +184,8 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
     s->gt = e;
     s->gens_host.assign(gens, gens + m * 12);
     s->m = m;
-    std::lock_guard<std::mutex> g(e->mtx);
+    set_lock g(ctx, e);
+    if (g.rc) return g.rc;
     ++e->uses;
     if (!e->tables) {
         ZK_HIP(hipMalloc((void **) &e->tables, (size_t) MSM_WINDOWS * m * sizeof(g1a_t)));
@@ -178,13 +197,13 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
             if (rc) return rc;
             g1j_t *J = (g1j_t *) s->tbl_scratch;
             fp_t *pre = (fp_t *) (J + (size_t) (MSM_WINDOWS - 1) * m);
-            ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_window_tables, dim3((uint32_t) ((m + 63) / 64)), dim3(64), e->tables, J, pre, (uint32_t) m);
+            zk_launch_d<k_window_tables, 64>(ctx, PC_MSM_TABLES, 0.0, dim3((uint32_t) ((m + 63) / 64)), e->tables, J, pre, (uint32_t) m);
             ZK_HIP(hipGetLastError());
-            ZK_HIP(hipStreamSynchronize(ctx->stream));      // other contexts read the tables from their own streams
+            ZK_HIP(zk_stream_sync(ctx));      // other contexts read the tables from their own streams
             return ZK_OK;
         };
         const int32_t rc = build();
-        if (rc) { (void) hipStreamSynchronize(ctx->stream); (void) hipFree(e->tables); e->tables = nullptr; return rc; }
+        if (rc) { (void) zk_stream_sync(ctx); (void) hipFree(e->tables); e->tables = nullptr; return rc; }
         ++g_gen_builds;
     }
     gen_adopt(s);
@@ -195,7 +214,7 @@ static int32_t ensure_rows(zk_ctx *ctx, uint32_t rows) {
     msm_state *s = ctx->msm;
     if (s->rows_cap >= rows) return ZK_OK;
     ZK_ORDER();
-    if (s->rowsJ) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->rowsJ)); ZK_HIP(hipFree(s->rowsA)); s->rowsJ = nullptr; }
+    if (s->rowsJ) { ZK_HIP(zk_stream_sync(ctx)); ZK_HIP(hipFree(s->rowsJ)); ZK_HIP(hipFree(s->rowsA)); s->rowsJ = nullptr; }
     ZK_HIP(hipMalloc((void **) &s->rowsJ, (size_t) rows * sizeof(g1j_t)));
     ZK_HIP(hipMalloc((void **) &s->rowsA, (size_t) rows * sizeof(g1a_t)));
     s->rows_cap = rows;
@@ -211,9 +230,9 @@ static int32_t build_digit_table(zk_ctx *ctx, g1a_t *dst, const g1a_t *base, uin
     fp_t *pre = (fp_t *) (J + (size_t) 256 * m);
     for (uint32_t level = 0; level < 8; ++level) {
         const uint32_t work = (1u << level) * m;
-        ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_digit_level, dim3((work + 63) / 64), dim3(64), J, base, m, level);
+        zk_launch_d<k_digit_level, 64>(ctx, PC_MSM_TABLES, 0.0, dim3((work + 63) / 64), J, base, m, level);
     }
-    ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_digit_affine, dim3((16 * m + 63) / 64), dim3(64), dst, J, pre, m);
+    zk_launch_d<k_digit_affine, 64>(ctx, PC_MSM_TABLES, 0.0, dim3((16 * m + 63) / 64), dst, (const g1j_t *) J, pre, m);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -225,7 +244,8 @@ static int32_t ensure_full_table(zk_ctx *ctx) {
     gen_tables *e = s->gt;
     if (!e || s->full_ready || s->no_full || s->m > MSM_FULL_MAX_M) return ZK_OK;
     ZK_ORDER();
-    std::lock_guard<std::mutex> g(e->mtx);
+    set_lock g(ctx, e);
+    if (g.rc) return g.rc;
     if (!e->full_ready && !e->full_failed && e->uses >= 2) {
         const uint32_t m = (uint32_t) e->m;
         if (hipMalloc((void **) &e->full, (size_t) MSM_WINDOWS * 256 * m * sizeof(g1a_t)) != hipSuccess) {
@@ -243,12 +263,12 @@ static int32_t ensure_full_table(zk_ctx *ctx) {
                 if (hipMalloc((void **) &e->t8, (size_t) 256 * n8 * sizeof(g1a_t)) != hipSuccess) { (void) hipGetLastError(); e->t8 = nullptr; }
                 else {
                     ZK_STREAM(hipMemsetAsync(e->t8, 0, (size_t) n8 * sizeof(g1a_t), ctx->stream));            // mask 0: the point at infinity, never looked up
-                    ZK_LAUNCH(PC_MSM_TABLES, 0.0, k_subset_table, dim3((n8 + 63) / 64, 255), dim3(64), e->t8, (const g1a_t *) (e->full + (size_t) 1 * m), n8);
+                    zk_launch_d<k_subset_table, 64>(ctx, PC_MSM_TABLES, 0.0, dim3((n8 + 63) / 64, 255), e->t8, (const g1a_t *) (e->full + (size_t) 1 * m), n8);
                     ZK_HIP(hipGetLastError());
                     e->t8_ready = true;
                 }
             }
-            ZK_HIP(hipStreamSynchronize(ctx->stream));
+            ZK_HIP(zk_stream_sync(ctx));
             e->full_ready = true;
             ++g_gen_full_builds;
         }
@@ -263,12 +283,13 @@ static int32_t ensure_digit_table(zk_ctx *ctx) {
     gen_tables *e = s->gt;
     if (s->digit_ready) return ZK_OK;
     ZK_ORDER();
-    std::lock_guard<std::mutex> g(e->mtx);
+    set_lock g(ctx, e);
+    if (g.rc) return g.rc;
     if (!e->digit_ready) {
         const uint32_t m = (uint32_t) e->m;
         ZK_HIP(hipMalloc((void **) &e->digit, (size_t) 256 * m * sizeof(g1a_t)));
         int32_t rc = build_digit_table(ctx, e->digit, e->tables, m);
-        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "digit table: stream synchronisation failed"; rc = ZK_ERR_HIP; }
+        if (!rc && zk_stream_sync(ctx) != hipSuccess) { ctx->err = "digit table: stream synchronisation failed"; rc = ZK_ERR_HIP; }
         if (rc) { (void) hipFree(e->digit); e->digit = nullptr; return rc; }     // (not built: nobody may adopt it, and the next attempt allocates again)
         e->digit_ready = true;
     }
@@ -375,13 +396,13 @@ static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32
     cpt = std::max<uint32_t>(cpt, 1);
     const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt), nparts = chunks * wsplit;
     if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * MSM_PLANES * nparts * sizeof(g1j_t)))) return rc;
-    for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {      // gridDim.z is limited to 65535
-        const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
-        ZK_LAUNCH(PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, k_msm_planes, dim3(nparts, MSM_PLANES, nr), dim3(MSM_BLOCK),
-                  s->partials + (size_t) r0 * MSM_PLANES * nparts, s->mag + (size_t) r0 * cols, ld, idx ? idx + (size_t) r0 * ld : nullptr, s->tables,
+    for (uint32_t r0 = 0; r0 < rows; r0 += 8191) {       // (plane, row) share gridDim.y, which is limited to 65535
+        const uint32_t nr = std::min<uint32_t>(8191, rows - r0);
+        zk_launch_d<k_msm_planes, MSM_BLOCK>(ctx, PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, dim3(nparts, MSM_PLANES * nr),
+                  s->partials + (size_t) r0 * MSM_PLANES * nparts, (const fr_t *) (s->mag + (size_t) r0 * cols), ld, idx ? idx + (size_t) r0 * ld : (const uint32_t *) nullptr, (const g1a_t *) s->tables,
                   (uint32_t) s->m, cols, cpt, wsplit, w_lo);
     }
-    ZK_LAUNCH(PC_MSM_FINISH, 0.0, k_msm_finish, dim3(rows), dim3(512), outJ ? outJ : s->rowsJ, s->partials, nparts);
+    zk_launch_d<k_msm_finish, 512>(ctx, PC_MSM_FINISH, 0.0, dim3(rows), outJ ? outJ : s->rowsJ, (const g1j_t *) s->partials, nparts);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -415,7 +436,7 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
     if ((rc = ensure_rows(ctx, rows_all))) return rc;
     if (s->flags_cap < rows + 1) {
         ZK_ORDER();
-        if (s->hi_flags) { ZK_HIP(hipStreamSynchronize(ctx->stream)); ZK_HIP(hipFree(s->hi_flags)); ZK_HIP(hipFree(s->row_list)); }
+        if (s->hi_flags) { ZK_HIP(zk_stream_sync(ctx)); ZK_HIP(hipFree(s->hi_flags)); ZK_HIP(hipFree(s->row_list)); }
         ZK_HIP(hipMalloc((void **) &s->hi_flags, ((size_t) rows + 1) * 4));                  // [rows] = number of flagged rows
         ZK_HIP(hipMalloc((void **) &s->row_list, ((size_t) rows + 1) * 4));
         s->flags_cap = rows + 1;
@@ -564,7 +585,7 @@ static int32_t add_blinds(zk_ctx *ctx, const uint64_t *blinds, uint32_t rows, ui
     std::vector<uint32_t> idx(rows, h_index);
     ZK_STREAM(hipMemcpyAsync(d_bl, blinds, (size_t) rows * 32, hipMemcpyHostToDevice, ctx->stream));
     ZK_STREAM(hipMemcpyAsync(d_idx, idx.data(), (size_t) rows * 4, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));          // idx is a local
+    ZK_HIP(zk_stream_sync(ctx));          // idx is a local
     if ((rc = regrow(ctx, (void **) &s->tmpJ, &s->tmp_cap, (size_t) rows * sizeof(g1j_t)))) return rc;
     if ((rc = scalar_mags(ctx, d_bl, 1, nullptr, rows, 1))) return rc;
     if ((rc = msm_windows(ctx, d_idx, 1, rows, 1, 0, s->tmpJ))) return rc;
@@ -606,7 +627,7 @@ extern "C" int32_t zk_commit_vector(zk_ctx *ctx, const uint64_t *scalars, uint64
         return ZK_ERR_ARG;
     }
     int32_t rc;
-    { std::lock_guard<std::mutex> g(s->gt->mtx); ++s->gt->uses; }      // the cached set is in use again: worth its byte table
+    { set_lock g(ctx, s->gt); if (g.rc) return g.rc; ++s->gt->uses; }      // the cached set is in use again: worth its byte table
     fr_t *d_v = nullptr;                              // its own buffer: commit_rows and add_blinds use the context's scratch
     ZK_HIP(hipMalloc((void **) &d_v, (size_t) n_rows * cols * 32));
     hipError_t e = hipMemcpyAsync(d_v, scalars, (size_t) n_rows * cols * 32, hipMemcpyHostToDevice, ctx->stream);
@@ -616,7 +637,7 @@ extern "C" int32_t zk_commit_vector(zk_ctx *ctx, const uint64_t *scalars, uint64
         if (!r && blinds) r = add_blinds(ctx, blinds, (uint32_t) n_rows, (uint32_t) cols);
         return r ? r : fetch_points(ctx, (uint32_t) n_rows, out);
     });
-    hipStreamSynchronize(ctx->stream);
+    (void) zk_stream_sync(ctx);
     hipFree(d_v);
     return rc;
 }
@@ -720,7 +741,7 @@ extern "C" int32_t zk_verifier_msm(zk_ctx *ctx, uint64_t out[12], const uint64_t
     if (bases_are_generators) {
         msm_state *s = ctx->msm;
         if (!s || !s->tables || n > s->m || std::memcmp(s->gens_host.data(), bases, n * 96) != 0) { ctx->err = "verifier MSM: these are not the cached generators"; return ZK_ERR_STATE; }
-        { std::lock_guard<std::mutex> g(s->gt->mtx); ++s->gt->uses; }
+        { set_lock g(ctx, s->gt); if (g.rc) return g.rc; ++s->gt->uses; }
         if ((rc = zk_scratch(ctx, n * 32))) return rc;
         ZK_STREAM(hipMemcpyAsync(ctx->scratch.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
         return with_safe_retry(ctx, [&]() -> int32_t {

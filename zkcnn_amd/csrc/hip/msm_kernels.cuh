@@ -162,7 +162,7 @@ __device__ __forceinline__ void k_bit_masks(uint16_t *masks, const uint16_t *cod
 }
 // T8[mask * n + t] = sum of the generators G[s * 512 + k * 64 + j] over the set bits k of mask, t = s * 64 + j, n = spans * 64; affine,
 // (0, 0) for mask 0. One thread per entry: <= 7 additions and its own inversion; built once per generator set. grid (ceil(n / 64), 255)
-__global__ void __launch_bounds__(64) k_subset_table(g1a_t *T8, const g1a_t *G, uint32_t n) {
+__device__ __forceinline__ void k_subset_table(g1a_t *T8, const g1a_t *G, uint32_t n) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x, mask = blockIdx.y + 1;
     if (t >= n) return;
     const uint32_t s = t >> 6, j = t & 63;
@@ -433,10 +433,10 @@ __device__ __forceinline__ void k_tree_reduce(g1j_t *out, const g1j_t *in, uint3
 // result is sum_k 2^k S_k (k_msm_finish). One block = (row, bit plane, column chunk x window group).
 // out[(row * 8 + plane) * nparts + part]
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(MSM_BLOCK) k_msm_planes(g1j_t *out, const fr_t *mag, uint64_t ld, const uint32_t *idx_base, const g1a_t *T,
+__device__ __forceinline__ void k_msm_planes(g1j_t *out, const fr_t *mag, uint64_t ld, const uint32_t *idx_base, const g1a_t *T,
                                                           uint32_t m, uint32_t cols, uint32_t cpt, uint32_t wsplit, uint32_t w_lo) {
     __shared__ g1j_t sm[MSM_BLOCK];
-    const uint32_t plane = blockIdx.y, row = blockIdx.z, lane = threadIdx.x;
+    const uint32_t plane = blockIdx.y % MSM_PLANES, row = blockIdx.y / MSM_PLANES, lane = threadIdx.x;      // (gridDim.z belongs to the lanes of a fused launch: launch.cuh)
     const uint32_t wg = blockIdx.x % wsplit, chunk = blockIdx.x / wsplit;
     const uint32_t wpg = MSM_WINDOWS / wsplit, w0 = max(wg * wpg, w_lo), w1 = (wg + 1) * wpg;
     const uint32_t *idx = idx_base ? idx_base + (size_t) row * ld : nullptr;
@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_planes(g1j_t *out, const fr_t
 
 // One block per row, one wave per bit plane: wave k sums the partial points of plane k (lane-strided, then a tree through LDS) and
 // pre-multiplies by 2^k (k doublings, the waves run concurrently); a final 3-level tree adds the 8 weighted plane sums.
-__global__ void __launch_bounds__(512) k_msm_finish(g1j_t *outJ, const g1j_t *partials, uint32_t nparts) {
+__device__ __forceinline__ void k_msm_finish(g1j_t *outJ, const g1j_t *partials, uint32_t nparts) {
     __shared__ g1j_t sm[MSM_PLANES][32];
     const uint32_t row = blockIdx.x, lane = threadIdx.x & 63, k = threadIdx.x >> 6;
     g1j_t acc = g1_inf();
@@ -517,7 +517,7 @@ __device__ __forceinline__ void k_add_rows(g1j_t *rows, const g1j_t *extra, cons
 // ------------------------------------------------------------------------------------------------
 // T[0][j] = g_j is already in place; fills T[w][j] = 2^(8w) g_j for w >= 1, converted to affine with
 // one field inversion per generator (Montgomery's trick over the 31 Jacobian points of that thread).
-__global__ void __launch_bounds__(MSM_BLOCK) k_window_tables(g1a_t *T, g1j_t *J, fp_t *pre, uint32_t m) {
+__device__ __forceinline__ void k_window_tables(g1a_t *T, g1j_t *J, fp_t *pre, uint32_t m) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const g1a_t g = T[j];
@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_window_tables(g1a_t *T, g1j_t *J,
 }
 
 // digit table by levels: D[1] = g, D[d] = 2 D[d/2] (+ g if d is odd); every entry of a level is independent
-__global__ void __launch_bounds__(MSM_BLOCK) k_digit_level(g1j_t *J, const g1a_t *G, uint32_t m, uint32_t level) {
+__device__ __forceinline__ void k_digit_level(g1j_t *J, const g1a_t *G, uint32_t m, uint32_t level) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t cnt = 1u << level;
     if (tid >= cnt * m) return;
@@ -570,7 +570,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_digit_level(g1j_t *J, const g1a_t
     g1j_store(J + (size_t) d * m + j, X, Y, Z, empty);
 }
 // Jacobian -> affine for 16 consecutive digits of one generator with one inversion (Montgomery's trick)
-__global__ void __launch_bounds__(MSM_BLOCK) k_digit_affine(g1a_t *D, const g1j_t *J, fp_t *pre, uint32_t m) {
+__device__ __forceinline__ void k_digit_affine(g1a_t *D, const g1j_t *J, fp_t *pre, uint32_t m) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= 16 * m) return;
     const uint32_t j = tid % m, d0 = (tid / m) * 16;
