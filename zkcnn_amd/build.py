@@ -70,12 +70,12 @@ def build_host(force=False):
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, os.path.basename(s) + ".o")
         if force or _newer(obj, [src] + hdrs):
-            _run([cxx, "-O3", "-DNDEBUG", "-std=c++14", "-fPIC", "-Wall", "-Wno-unused-function", "-I" + CSRC,
+            _run([cxx, "-O3", "-DNDEBUG", "-std=c++14", "-fPIC", "-pthread", "-Wall", "-Wno-unused-function", "-I" + CSRC,
                   "-I" + os.path.join(CSRC, "host"), "-c", src, "-o", obj])
         objs.append(obj)
     out = os.path.join(LIB, "libzkcnn_host.so")
     if force or _newer(out, objs + [os.path.join(LIB, "libzkcnn_hip.so")]):
-        _run([cxx, "-shared", "-o", out] + objs + ["-L" + LIB, "-lzkcnn_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-Bsymbolic"])
+        _run([cxx, "-shared", "-pthread", "-o", out] + objs + ["-L" + LIB, "-lzkcnn_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-Bsymbolic"])
     return out
 
 

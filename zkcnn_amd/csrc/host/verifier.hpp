@@ -10,6 +10,7 @@
 // same prover calls but skips the verifier's own (gate-walking) work so a bench can time the prover.
 #pragma once
 #include <stdexcept>
+#include <thread>
 #include "circuit.h"
 #include "polynomial.h"
 #include "utils.hpp"
@@ -46,34 +47,54 @@ struct proofTranscript : public hyrax_bls12_381::transcriptSink {
     void put(const cubic_poly &p) { put(p.a); put(p.b); put(p.c); put(p.d); }
 };
 
-// random multiples of the base point (reference src/verifier.cpp:121-126), via a fixed-base table
-inline void drawGenerators(std::vector<G1> &gens, size_t count) {
-    static thread_local std::vector<G1Affine> table;      // table[w * 16 + d] = d * 16^w * G
-    if (table.empty()) {
-        std::vector<G1> jac(64 * 16);
+// random multiples of the base point (reference src/verifier.cpp:121-126: gens[i] = G * k_i with k_i from the CSPRNG), via a fixed-base table of
+// byte windows -- 32 mixed additions per generator -- and a few helper threads: the scalars are drawn first, in order, from the caller's
+// challenge stream (so the generators are what a sequential loop gives); the 4096 independent scalar multiplications of a vgg11 proof then take
+// ~10 ms instead of ~250 ms on one core. (With several proofs driven by one host thread -- batchSessionT -- this loop was what bounded proofs
+// with fresh generators: the GPU waited for the verifier.)
+inline const std::vector<G1Affine> &generatorBaseTable() {
+    static const std::vector<G1Affine> table = [] {      // table[w * 255 + d - 1] = d * 256^w * G
+        std::vector<G1> jac(32 * 255);
         G1 base = G1::generator();
-        for (int w = 0; w < 64; ++w) {
-            jac[w * 16] = G1();
-            for (int d = 1; d < 16; ++d) G1::add(jac[w * 16 + d], jac[w * 16 + d - 1], base);
+        for (int w = 0; w < 32; ++w) {
+            jac[w * 255] = base;
+            for (int d = 2; d <= 255; ++d) G1::add(jac[w * 255 + d - 1], jac[w * 255 + d - 2], base);
             G1 nb;
-            G1::add(nb, jac[w * 16 + 15], base);
+            G1::add(nb, jac[w * 255 + 254], base);
             base = nb;
         }
-        zkff::batchToAffine(jac, table);
-    }
-    gens.resize(count);
-    for (auto &x : gens) {
+        std::vector<G1Affine> t;
+        zkff::batchToAffine(jac, t);
+        return t;
+    }();
+    return table;
+}
+inline void drawGenerators(std::vector<G1> &gens, size_t count) {
+    const std::vector<G1Affine> &table = generatorBaseTable();
+    std::vector<uint64_t> e(4 * count);
+    for (size_t i = 0; i < count; ++i) {
         Fr k;
         k.setByCSPRNG();
-        uint64_t e[4];
-        k.toCanonical(e);
-        G1 acc;
-        for (int w = 0; w < 64; ++w) {
-            unsigned d = (e[w >> 4] >> ((w & 15) * 4)) & 15;
-            if (d) G1::addMixed(acc, acc, table[w * 16 + d]);
-        }
-        x = acc;
+        k.toCanonical(&e[4 * i]);
     }
+    gens.resize(count);
+    auto work = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            G1 acc;
+            for (int w = 0; w < 32; ++w) {
+                const unsigned d = (unsigned) (e[4 * i + (w >> 3)] >> ((w & 7) * 8)) & 255u;
+                if (d) G1::addMixed(acc, acc, table[(size_t) w * 255 + d - 1]);
+            }
+            gens[i] = acc;
+        }
+    };
+    size_t nt = std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), count / 256);
+    if (nt <= 1) { work(0, count); return; }
+    std::vector<std::thread> th;
+    const size_t per = (count + nt - 1) / nt;
+    for (size_t t = 1; t < nt; ++t) th.emplace_back(work, std::min(count, t * per), std::min(count, (t + 1) * per));
+    work(0, std::min(count, per));
+    for (auto &x : th) x.join();
 }
 
 // Optional accelerator for the verifier's wiring predicates (the only part of the verifier that walks every gate:
