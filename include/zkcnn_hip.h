@@ -71,6 +71,11 @@ typedef struct {
 } zk_conv_hint;
 int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul, int32_t n_two_mul,
                                  const zk_conv_hint *hints, uint32_t n_hints);
+/* A second context on the SAME resident circuit holding a copy of src's witness (layer values copied in HBM; the witness program, if the circuit
+ * has one, adopted): no host copy of the circuit is needed, nothing is sorted or uploaded. What a caller uses to prove many pictures of one model
+ * side by side -- the lanes of a batch below -- where the reference builds circuit and witness per picture (reference src/neuralNetwork.cpp:60-142).
+ * The clone is independent of src afterwards (src may be destroyed first: the circuit is reference counted). */
+int32_t zk_ctx_clone(zk_ctx *src, zk_ctx **out);
 /* Test hook: overwrite ONE resident value (an INVALID witness on purpose: the proof must then be rejected, and -- seeded -- still be
  * byte-identical to the CPU oracle's proof of the same corrupted witness). Keeps the bookkeeping of zk_upload_layer_values exact. */
 int32_t zk_poke_layer_value(zk_ctx *ctx, int32_t layer, uint64_t index, const uint64_t value[4]);

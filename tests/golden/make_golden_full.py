@@ -1,0 +1,42 @@
+"""Digests of the CPU oracle's transcripts for the two per-GPU circuits of BASELINE.json configs 4 / 5 at FULL size -- vgg11 with pic_cnt = 8 and
+vgg16 with pic_cnt = 4 as ONE circuit each (reference src/models.cpp:43-146; FFT convolutions because pic_cnt > 1, src/neuralNetwork.cpp:46;
+layer 0 = 2^26 entries) -- merged into tests/golden/transcripts.json under "full_size". tests/test_timed_path_gpu.py compares the GPU prover's
+transcripts with them byte for byte (through SHA-256 + length); the oracle needs minutes and tens of GB per circuit, which is why this is a
+committed fixture and not a test-time computation.
+
+    python tests/golden/make_golden_full.py [vgg11_pp8] [vgg16_pp4]        (data seed 20260928; challenge seeds as in the test)
+
+Modes: 0 = interactive with fresh seeded generators (drive-only: the transcript is the one the full verifier sees, test asserts that on the GPU side);
+2 = ZKCNN_MODE_REUSE_GENS (public hash-to-curve generators)."""
+import hashlib
+import json
+import os
+import resource
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tests import oracle_ffi  # noqa: E402
+
+CASES = {"vgg11_pp8": ("vgg11", (32, 32, 3), 8), "vgg16_pp4": ("vgg16", (32, 32, 3), 4)}
+RUNS = [("interactive", 0x5EED0001, 0), ("reuse_gens", 0x5EED0007, 2)]
+DRIVE = 1
+
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "transcripts.json")
+out_path = os.environ.get("GOLDEN_OUT", path)
+for key in (sys.argv[1:] or list(CASES)):
+    model, pic, pp = CASES[key]
+    t0 = time.time()
+    entry = {"model": model, "pic": list(pic), "pic_cnt": pp, "data_seed": 20260928}
+    with oracle_ffi.OracleSession(model, pic, pp, data_seed=20260928) as o:
+        for name, seed, mode in RUNS:
+            res, tr = o.prove(seed=seed, mode=mode | DRIVE)
+            entry[name] = {"challenge_seed": seed, "mode": mode, "sha256": hashlib.sha256(tr).hexdigest(), "transcript_len": len(tr)}
+            entry.update(n_layers=res.n_layers, input_bits=res.input_bits, n_rounds=res.n_rounds)
+            print(key, name, entry[name]["sha256"][:16], len(tr), f"{time.time() - t0:.0f} s", flush=True)
+    entry["oracle_wall_s"] = round(time.time() - t0)
+    entry["oracle_peak_rss_gb"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)
+    doc = json.load(open(out_path)) if os.path.exists(out_path) else {}
+    doc.setdefault("full_size", {})[key] = entry
+    json.dump(doc, open(out_path, "w"), indent=1, sort_keys=True)

@@ -23,14 +23,15 @@ CASES = [
 ]
 
 
-def _lanes(model, pic, pp, k):
-    """k sessions on ONE resident circuit (the first one's quantisation scales), each with its own picture"""
+def _lanes(model, pic, pp, k, clones=False):
+    """k sessions on ONE resident circuit (the first one's quantisation scales), each with its own picture; clones: sessions 1.. are clones of
+    the first (zkcnn_session_clone: no host circuit of their own) instead of sessions built from the data under the first one's scales"""
     first = M.Session(model, pic, pp)
     stmt = first.statement()
     ss, seeds = [first], [0]
     try:
         for i in range(1, k):
-            s = M.Session(model, pic, pp, calibrated=stmt)
+            s = first.clone() if clones else M.Session(model, pic, pp, calibrated=stmt)
             ss.append(s)
             for ps in range(1000 * i, 1000 * i + 64):
                 if s.new_image(ps)[0] == 0:
@@ -53,7 +54,7 @@ def _oracle(model, pic, pp, stmt, picture_seed, seed, mode):
 
 @pytest.mark.parametrize("model,pic,pp,k", CASES)
 def test_every_lane_of_a_batch_equals_the_oracle(built, model, pic, pp, k):
-    ss, pics, stmt = _lanes(model, pic, pp, k)
+    ss, pics, stmt = _lanes(model, pic, pp, k, clones=(k == 8))          # (the batches of eight are made the way bench.py makes them: one session + clones)
     try:
         seeds = [0x5EED0B00 + 3 * i for i in range(k)]
         want = [_oracle(model, pic, pp, stmt, pics[i], seeds[i], REUSE) for i in range(k)]
@@ -190,3 +191,43 @@ def test_attach_refuses_other_circuits(built):
     finally:
         a.close()
         b.close()
+
+
+def test_clones_share_the_circuit_and_nothing_else(built):
+    """zkcnn_session_clone: a context of its own on the parent's resident circuit, a copy of the witness, no host circuit. The clone proves what the
+    parent proves, takes pictures of its own, outlives the parent, verifies serialized proofs (GPU predicates) -- and refuses the modes that need the
+    gate lists on the host."""
+    model, pic, pp = "custom:C4:3:1:s C8:3:1:s M C8:3:1:s F5", (8, 8, 2), 1
+    before = M.sharing_stats()
+    a = M.Session(model, pic, pp)
+    stmt = a.statement()
+    b = a.clone()
+    c = b.clone()                                  # a clone of a clone
+    try:
+        mid = M.sharing_stats()
+        assert mid["circuit_builds"] == before["circuit_builds"] + 1 and mid["circuit_attaches"] == before["circuit_attaches"] + 2
+        ra, ta = a.prove(seed=5, mode=REUSE)
+        rb, tb = b.prove(seed=5, mode=REUSE)
+        assert ra.accepted == 1 and rb.accepted == 1 and ta == tb
+        assert rb.gate_cnt_bin == ra.gate_cnt_bin and rb.gate_cnt_uni == ra.gate_cnt_uni
+        fa, fta = a.prove(mode=M.MODE_FIAT_SHAMIR)
+        fb, ftb = b.prove(mode=M.MODE_FIAT_SHAMIR)          # the statement hash needs the wiring digest and the gate counts: the structure copy carries them
+        assert fa.accepted == 1 and fb.accepted == 1 and fta == ftb
+        assert b.verify(fta, mode=M.MODE_FIAT_SHAMIR).accepted == 1
+        for ps in range(3000, 3064):
+            if c.new_image(ps)[0] == 0:
+                break
+        else:
+            pytest.skip("no fitting picture")
+        a.close()                                  # the parent goes away: the clones keep the circuit and the witness program
+        a = None
+        rc_, tc = c.prove(seed=6, mode=REUSE)
+        assert rc_.accepted == 1 and tc == _oracle(model, pic, pp, stmt, ps, 6, REUSE)[1]
+        assert b.prove(seed=5, mode=REUSE)[1] == ta
+        for bad_mode in (M.MODE_HOST_PRED, M.MODE_CROSS_PRED):
+            r, _ = b.prove(seed=7, mode=REUSE | bad_mode)
+            assert r.accepted == 0 and b"structure copy" in r.message
+    finally:
+        for s in (a, b, c):
+            if s is not None:
+                s.close()

@@ -20,7 +20,7 @@ import zkcnn_amd
 pytestmark = pytest.mark.gpu
 
 MODEL, PIC, PP = "vgg11", (32, 32, 3), 1
-REUSE, DRIVE = zkcnn_amd.MODE_REUSE_GENS, zkcnn_amd.MODE_DRIVE_ONLY
+REUSE, DRIVE, FULL_IPA = zkcnn_amd.MODE_REUSE_GENS, zkcnn_amd.MODE_DRIVE_ONLY, zkcnn_amd.MODE_FULL_IPA
 SEED, SEED_BAD = 0x5EED0001, 0x5EED0041
 RELU = 4
 
@@ -47,8 +47,10 @@ def test_full_size_vgg11_identical_to_oracle(built, oracle):
             if ty == RELU:
                 relu = (i, size - 1, one)
             i += 1
-        jobs = [(0, SEED, None), (REUSE | DRIVE, SEED, None), (REUSE, SEED_BAD, relu)]
-        with mp.get_context("spawn").Pool(3) as pool:
+        # ... and the reference's own semantics -- fresh generators drawn by the verifier for this proof, the inner-product argument run down to length 1
+        # (reference src/verifier.cpp:119-128) -- plus the full argument over the session's public generators: the companions bench.py reports
+        jobs = [(0, SEED, None), (REUSE | DRIVE, SEED, None), (REUSE, SEED_BAD, relu), (FULL_IPA | DRIVE, SEED + 1, None), (REUSE | FULL_IPA | DRIVE, SEED + 2, None)]
+        with mp.get_context("spawn").Pool(5) as pool:
             pending = pool.map_async(_oracle_job, jobs)
 
             def digest(tr):
@@ -60,10 +62,72 @@ def test_full_size_vgg11_identical_to_oracle(built, oracle):
             res, timed = s.prove(seed=SEED, mode=REUSE | DRIVE)           # second use: the byte table -- the path bench.py times
             assert res.accepted == -1
             assert first_use == timed, "drive-only transcript differs from the verified one"
+            res, full_fresh = s.prove(seed=SEED + 1, mode=FULL_IPA)        # fresh generators, 12 argument rounds, fully verified
+            assert res.accepted == 1, res.message.decode()
+            res, full_reuse = s.prove(seed=SEED + 2, mode=REUSE | FULL_IPA)
+            assert res.accepted == 1, res.message.decode()
             s.poke(*relu)
             bad_res, bad = s.prove(seed=SEED_BAD, mode=REUSE)
-            (acc0, sha0, len0), (acc1, sha1, len1), (acc2, sha2, len2) = pending.get(timeout=900)
+            (acc0, sha0, len0), (acc1, sha1, len1), (acc2, sha2, len2), (_, sha3, len3), (_, sha4, len4) = pending.get(timeout=900)
     assert acc0 == 1 and (sha0, len0) == digest(plain), "full-size vgg11, interactive mode: GPU transcript differs from the CPU oracle's"
     assert acc1 == -1 and (sha1, len1) == digest(timed), "full-size vgg11, REUSE_GENS | DRIVE_ONLY (bench mode): GPU transcript differs from the CPU oracle's"
     assert acc2 == 0 and bad_res.accepted == 0, "a non-zero constraint row at full size must be rejected (oracle and GPU)"
     assert (sha2, len2) == digest(bad), "full-size vgg11 with a corrupted witness: GPU transcript differs from the CPU oracle's"
+    assert (sha3, len3) == digest(full_fresh), "full-size vgg11, fresh generators + full inner-product argument (reference semantics): GPU transcript differs from the CPU oracle's"
+    assert (sha4, len4) == digest(full_reuse), "full-size vgg11, session generators + full inner-product argument: GPU transcript differs from the CPU oracle's"
+
+
+def _oracle_lane_job(job):
+    """(picture seed, statement, challenge seed, mode) -> (sha256, length) of the oracle's transcript for that picture on the calibrated circuit"""
+    from tests import oracle_ffi
+    picture_seed, stmt, seed, mode = job
+    with oracle_ffi.OracleSession(MODEL, PIC, PP, picture_seed=picture_seed, calibrated=stmt) as o:
+        res, tr = o.prove(seed=seed, mode=mode)
+    return hashlib.sha256(tr).hexdigest(), len(tr)
+
+
+@pytest.mark.parametrize("k", [2, 8])
+def test_full_size_vgg11_lock_step_batch_identical_to_oracle(built, k):
+    """BASELINE.json configs[2] as bench.py times it since round 4: k sessions of the full vgg11 circuit as the lanes of ONE lock-step batch (one host
+    thread, one stream, one launch per sumcheck round for all lanes: reference src/prover.cpp:360-426 once per round per lane). Every lane's
+    transcript -- its own picture, its own challenge seed -- must be the CPU oracle's, byte for byte (k oracle processes side by side), in the
+    bench's modes; and a full round count of fused launches."""
+    import threading
+    first = zkcnn_amd.Session(MODEL, PIC, PP)
+    stmt = first.statement()
+    ss, pics = [first] + [None] * (k - 1), [0] * k
+
+    def build(i):
+        ss[i] = first.clone()                     # (a lane as bench.py makes it: no host circuit of its own)
+        for ps in range(1000 * i, 1000 * i + 64):
+            if ss[i].new_image(ps)[0] == 0:
+                pics[i] = ps
+                return
+        ss[i].close()
+        ss[i] = None
+    th = [threading.Thread(target=build, args=(i,)) for i in range(1, k)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    try:
+        assert all(s is not None for s in ss), "no synthetic picture with the circuit's quantisation scales among 64"
+        seeds = [SEED + 16 + i for i in range(k)]
+        with mp.get_context("spawn").Pool(k) as pool:
+            pending = pool.map_async(_oracle_lane_job, [(pics[i], stmt, seeds[i], REUSE | DRIVE) for i in range(k)])
+            with zkcnn_amd.BatchSession(ss) as B:
+                ver = B.prove(seeds=seeds, mode=REUSE)                     # fully verified (first use of the generators: window / digit tables)
+                assert [r.accepted for r, _ in ver] == [1] * k, [r.message for r, _ in ver]
+                B.prove(seeds=seeds, mode=REUSE | DRIVE)                   # second use: the byte table is built
+                before = B.stats()
+                got = B.prove(seeds=seeds, mode=REUSE | DRIVE)             # the timed path of bench.py
+                st = B.stats()
+            want = pending.get(timeout=900)
+        for i in range(k):
+            assert ver[i][1] == got[i][1], f"lane {i}: drive-only transcript differs from the verified one"
+            assert (hashlib.sha256(got[i][1]).hexdigest(), len(got[i][1])) == want[i], f"lane {i}: full-size batch transcript differs from the CPU oracle's"
+        fused, lanes = st["fused_launches"] - before["fused_launches"], st["lane_launches"] - before["lane_launches"]
+        assert lanes == k * fused, (fused, lanes)
+        assert fused <= 1.35 * got[0][0].n_rounds, f"{fused} fused launches for a proof of {got[0][0].n_rounds} rounds"
+    finally:
+        for s in ss:
+            if s is not None:
+                s.close()

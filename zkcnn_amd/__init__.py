@@ -380,6 +380,17 @@ class Session(_SessionBase):
     def __init__(self, model, pic=(32, 32, 1), pic_cnt=1, data_seed=20260928, device=0, statement=None, picture_seed=0, calibrated=None):
         super().__init__(host_lib(), model, pic, pic_cnt, data_seed, device, statement, picture_seed, calibrated)
 
+    def clone(self):
+        """a second session on the same resident circuit with a copy of this session's witness and no host copy of the circuit
+        (zkcnn_session_clone): nothing is generated, sorted or uploaded. Give it a picture of its own with new_image."""
+        other = object.__new__(Session)
+        other.lib, other.model, other.pic, other.pic_cnt, other.data_seed, other.picture_seed, other.desc = self.lib, self.model, self.pic, self.pic_cnt, self.data_seed, self.picture_seed, self.desc
+        self.lib.zkcnn_session_clone.restype = ctypes.c_void_p
+        other.h = self.lib.zkcnn_session_clone(ctypes.c_void_p(self.h))
+        if not other.h:
+            raise RuntimeError("zkcnn_session_clone failed")
+        return other
+
     def new_image(self, picture_seed=None, pixels=None):
         """the next picture on the resident circuit (zkcnn_session_new_image): the synthetic picture of `picture_seed`, or `pixels`
         (channel, x, y order). Layer values and auxiliary witnesses are recomputed in HBM -- no circuit generation, no upload.

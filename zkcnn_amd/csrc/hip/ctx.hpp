@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../../include/zkcnn_hip.h"
@@ -242,6 +243,38 @@ struct zk_ctx {
     uint64_t prof_cnt[PC_COUNT] = {0};
 };
 
+// ---- one resident circuit per GPU, shared by its sessions (upload.hip; reference src/prover.hpp:47-48: one layeredCircuit per prover) ----
+// Everything a circuit's upload produces that does not depend on the witness -- sorted and padded gate lists, subset maps, the layer-0 CSR,
+// the checked convolution patterns, buffer sizes -- lives in a ref-counted registry entry keyed by a digest of the upload's input. The
+// first context that uploads a circuit builds the entry (counting sort of 1.2e8 gates + 1.9 GB of lists for vgg11); every later context of
+// the same process and device that uploads the SAME circuit attaches to it and only allocates its own values, tables and scratch.
+struct shared_circuit {
+    int device = 0;
+    uint64_t key[2] = {0, 0};
+    int refs = 0;
+    bool ready = false, failed = false;
+    uint64_t bytes = 0;             // device memory of the static part
+    std::mutex mtx;                 // held while the entry is being built
+    std::vector<void *> owned;      // device allocations of the static part
+    std::vector<dev_layer> L;       // (val == nullptr)
+    fr_t *two_mul = nullptr;
+    int n_two_mul = 0;
+    uint32_t *liu_ptr = nullptr; void *liu_ent = nullptr; uint32_t liu_ntabs = 0;
+    std::vector<int> liu_tab_layer, liu_tab_side;
+    uint32_t conv_layers = 0;
+    circuit_sizes sz;
+    // the static part of the resident witness program (witness.hip: zk_witness_program_upload): gate lists grouped by output live in L[i].ev_*,
+    // the operations, windows and steps here; built by the first context that uploads the program, adopted by every other (and by clones)
+    bool wp_ready = false;
+    void *wp_ops = nullptr; uint32_t *wp_windows = nullptr;
+    uint64_t wp_n_ops = 0, wp_n_windows = 0;
+    std::vector<zk_witness_step> wp_steps;
+    uint32_t wp_n_ranges = 0;
+    uint64_t wp_max_out = 1, wp_max_blocks = 1, wp_max_conv_part = 0, wp_max_conv_in = 0, wp_conv_w_total = 0;
+    std::vector<uint64_t> wp_conv_w_off;
+};
+
+
 static inline void prof_begin(zk_ctx *ctx, int cls, double bytes) {
     if (!((ctx->prof_mask >> cls) & 1u)) return;
     prof_pending p;
@@ -380,6 +413,7 @@ static inline int32_t zk_upload(zk_ctx *ctx, T **dst, const std::vector<T> &src)
     return ZK_OK;
 }
 void zk_circuit_release(zk_ctx *ctx);                                                 // upload.hip
+int32_t zk_witness_program_adopt(zk_ctx *ctx);                                        // witness.hip: the per-session side of the circuit's witness program
 void zk_set_create_error(const std::string &msg);                                     // context.hip
 // sumcheck.hip
 int32_t zk_eq_table_dev(zk_ctx *ctx, fr_t *out, int n, const HFr *r0, const HFr &a, const HFr *r1, const HFr &b, uint64_t tail_start, const HFr &tail_scale, uint64_t limit);

@@ -178,22 +178,6 @@ extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, i
 // the checked convolution patterns, buffer sizes -- lives in a ref-counted registry entry keyed by a digest of the upload's input. The
 // first context that uploads a circuit builds the entry (counting sort of 1.2e8 gates + 1.9 GB of lists for vgg11); every later context of
 // the same process and device that uploads the SAME circuit attaches to it and only allocates its own values, tables and scratch.
-struct shared_circuit {
-    int device = 0;
-    uint64_t key[2] = {0, 0};
-    int refs = 0;
-    bool ready = false, failed = false;
-    uint64_t bytes = 0;             // device memory of the static part
-    std::mutex mtx;                 // held while the entry is being built
-    std::vector<void *> owned;      // device allocations of the static part
-    std::vector<dev_layer> L;       // (val == nullptr)
-    fr_t *two_mul = nullptr;
-    int n_two_mul = 0;
-    uint32_t *liu_ptr = nullptr; void *liu_ent = nullptr; uint32_t liu_ntabs = 0;
-    std::vector<int> liu_tab_layer, liu_tab_side;
-    uint32_t conv_layers = 0;
-    circuit_sizes sz;
-};
 static std::mutex g_circ_mtx;
 static std::vector<shared_circuit *> g_circuits;
 static std::atomic<uint64_t> g_circ_builds{0}, g_circ_attaches{0}, g_circ_bytes{0};
@@ -246,6 +230,16 @@ static void circuit_key(uint64_t key[2], const zk_layer_desc *layers, int32_t n_
 static int32_t build_static(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul, int32_t n_two_mul,
                             const zk_conv_hint *hints, uint32_t n_hints);
 static int32_t alloc_session(zk_ctx *ctx);
+
+// what a context takes over from a resident circuit it attaches to (its own values, tables and scratch come from alloc_session)
+static void adopt_circuit(zk_ctx *ctx, const shared_circuit *e) {
+    ctx->L = e->L;
+    ctx->two_mul = e->two_mul; ctx->n_two_mul = e->n_two_mul;
+    ctx->liu_ptr = e->liu_ptr; ctx->liu_ent = e->liu_ent; ctx->liu_ntabs = e->liu_ntabs;
+    ctx->liu_tab_layer = e->liu_tab_layer; ctx->liu_tab_side = e->liu_tab_side;
+    ctx->conv_layers = e->conv_layers;
+    ctx->sz = e->sz;
+}
 
 void zk_circuit_release(zk_ctx *ctx) {
     shared_circuit *e = (shared_circuit *) ctx->circuit;
@@ -304,12 +298,7 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
                 ++g_circ_builds;
             } else e->failed = true;
         } else if (e->ready) {
-            ctx->L = e->L;
-            ctx->two_mul = e->two_mul; ctx->n_two_mul = e->n_two_mul;
-            ctx->liu_ptr = e->liu_ptr; ctx->liu_ent = e->liu_ent; ctx->liu_ntabs = e->liu_ntabs;
-            ctx->liu_tab_layer = e->liu_tab_layer; ctx->liu_tab_side = e->liu_tab_side;
-            ctx->conv_layers = e->conv_layers;
-            ctx->sz = e->sz;
+            adopt_circuit(ctx, e);
             ++g_circ_attaches;
         } else { ctx->err = "the circuit's first upload failed"; rc = ZK_ERR_STATE; }
     }
@@ -318,6 +307,48 @@ extern "C" int32_t zk_upload_circuit_hinted(zk_ctx *ctx, const zk_layer_desc *la
     ctx->dot_layers = 0;
     for (const dev_layer &D : ctx->L) ctx->dot_layers += D.dot_ok ? 1 : 0;
     ctx->circuit_ready = true;
+    return ZK_OK;
+}
+
+// A second context on the resident circuit of `src`, holding a COPY of its witness: what a caller wants who proves many pictures of one model
+// (reference src/main_demo_vgg.cpp builds circuit and witness per picture) -- no host copy of the circuit, no gate sort, no digest over 1.2e8
+// gates: the new context attaches to the registry entry, allocates its own values / tables / scratch, copies the layer values in HBM and
+// adopts the witness program if the circuit has one (zk_witness_rerun then gives it a picture of its own).
+extern "C" int32_t zk_ctx_clone(zk_ctx *src, zk_ctx **out) {
+    if (!src || !out) return ZK_ERR_ARG;
+    *out = nullptr;
+    shared_circuit *e = (shared_circuit *) src->circuit;
+    if (!src->circuit_ready || !e) { src->err = "zk_ctx_clone: the context holds no circuit"; return ZK_ERR_STATE; }
+    zk_ctx *ctx = nullptr;
+    int32_t rc = zk_ctx_create(src->device, &ctx);
+    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> g(g_circ_mtx);
+        ++e->refs;
+    }
+    ctx->circuit = e;
+    adopt_circuit(ctx, e);
+    ++g_circ_attaches;
+    rc = alloc_session(ctx);
+    if (rc == ZK_OK && (hipSetDevice(src->device) != hipSuccess || hipStreamSynchronize(src->stream) != hipSuccess)) rc = ZK_ERR_HIP;     // (the values copied below are complete)
+    for (size_t i = 0; rc == ZK_OK && i < ctx->L.size(); ++i) {
+        if (hipMemcpyAsync(ctx->L[i].val, src->L[i].val, ctx->L[i].val_len * 32, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = ZK_ERR_HIP;
+        ctx->L[i].val_live = src->L[i].val_live;
+    }
+    if (rc == ZK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ZK_ERR_HIP;
+    if (rc == ZK_OK) {
+        ctx->dot_layers = 0;
+        for (const dev_layer &D : ctx->L) ctx->dot_layers += D.dot_ok ? 1 : 0;
+        ctx->circuit_ready = true;
+        if (e->wp_ready) rc = zk_witness_program_adopt(ctx);
+    }
+    if (rc != ZK_OK) {
+        zk_set_create_error(ctx->err.empty() ? "zk_ctx_clone failed" : ctx->err);
+        src->err = ctx->err.empty() ? "zk_ctx_clone failed" : ctx->err;
+        zk_ctx_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
     return ZK_OK;
 }
 
@@ -617,7 +648,7 @@ extern "C" int32_t zk_upload_layer_values(zk_ctx *ctx, int32_t layer, const uint
     if (!ctx || !ctx->circuit_ready || layer < 0 || layer >= (int) ctx->L.size()) return ZK_ERR_ARG;
     dev_layer &D = ctx->L[layer];
     if (n > D.val_len) { ctx->err = "more values than the layer holds"; return ZK_ERR_ARG; }
-    ZK_HIP(hipSetDevice(ctx->device));
+    ZK_CHECK_CTX();                     // (a resident round kernel of an abandoned phase leaves first; a lane's deferred launches go ahead of the copy)
     if (n) ZK_HIP(hipMemcpyAsync(D.val, values, n * 32, hipMemcpyHostToDevice, ctx->stream));
     if (n < D.val_len) ZK_HIP(hipMemsetAsync(D.val + n, 0, (D.val_len - n) * 32, ctx->stream));
     uint64_t last = n;
@@ -632,7 +663,7 @@ extern "C" int32_t zk_poke_layer_value(zk_ctx *ctx, int32_t layer, uint64_t inde
     if (!ctx || !ctx->circuit_ready || layer < 0 || layer >= (int) ctx->L.size() || !value) return ZK_ERR_ARG;
     dev_layer &D = ctx->L[layer];
     if (index >= D.d.size) { ctx->err = "poke: index behind the layer"; return ZK_ERR_ARG; }
-    ZK_HIP(hipSetDevice(ctx->device));
+    ZK_CHECK_CTX();
     ZK_HIP(hipMemcpyAsync(D.val + index, value, 32, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     if ((value[0] | value[1] | value[2] | value[3]) && index + 1 > D.val_live) D.val_live = index + 1;      // (an upper bound stays an upper bound)

@@ -212,12 +212,40 @@ static uint32_t conv_eval_chunks(const conv_desc &c, uint64_t n_out) {
 // ------------------------------------------------------------------------------------------------
 // resident witness program: the next picture without the host round trip of the layer values
 // ------------------------------------------------------------------------------------------------
+// The program has a static part -- the validated steps, the operations and windows, the gate lists grouped by output: functions of the CIRCUIT --
+// and a per-session part (work buffers, the integer copies of the tensors, the range words). The static part belongs to the resident circuit's
+// registry entry: the first context that uploads the program builds it there (under the entry's lock), every other context of the circuit -- one
+// that uploads the same program later, or a clone (zk_ctx_clone) that never sees the host data -- adopts it and allocates only its own buffers.
+static int32_t wp_build_static(zk_ctx *ctx, shared_circuit *e, const zk_witness_op *ops, uint64_t n_ops, const uint32_t *windows, uint64_t n_windows,
+                               const zk_witness_step *steps, uint32_t n_steps, const zk_layer_desc *layers, int32_t n_layers);
+
 extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *ops, uint64_t n_ops, const uint32_t *windows, uint64_t n_windows,
                                              const zk_witness_step *steps, uint32_t n_steps, const zk_layer_desc *layers, int32_t n_layers) {
     ZK_CHECK_READY();
     static_assert(sizeof(zk_witness_op) == sizeof(wit_op) && sizeof(zk_witness_op) == 12 && sizeof(zk_witness_step) == 48, "program records");
     if (ctx->wp_ready) { ctx->err = "witness program already uploaded"; return ZK_ERR_STATE; }
     if (n_layers != (int32_t) ctx->L.size() || !steps || !n_steps || (n_ops && !ops) || (n_windows && !windows)) return ZK_ERR_ARG;
+    shared_circuit *e = (shared_circuit *) ctx->circuit;
+    if (!e) return ZK_ERR_STATE;
+    {
+        std::lock_guard<std::mutex> g(e->mtx);
+        if (!e->wp_ready) {
+            const std::vector<dev_layer> keep = ctx->L;          // (a failed build leaves the context as it was)
+            ctx->alloc_sink = &e->owned;
+            ctx->sink_bytes = 0;
+            int32_t rc = wp_build_static(ctx, e, ops, n_ops, windows, n_windows, steps, n_steps, layers, n_layers);
+            ctx->alloc_sink = nullptr;
+            if (rc == ZK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "witness program upload failed"; rc = ZK_ERR_HIP; }
+            if (rc) { ctx->L = keep; return rc; }
+            e->bytes += ctx->sink_bytes;
+            e->wp_ready = true;
+        }
+    }
+    return zk_witness_program_adopt(ctx);
+}
+
+static int32_t wp_build_static(zk_ctx *ctx, shared_circuit *e, const zk_witness_op *ops, uint64_t n_ops, const uint32_t *windows, uint64_t n_windows,
+                               const zk_witness_step *steps, uint32_t n_steps, const zk_layer_desc *layers, int32_t n_layers) {
     const uint64_t n0 = ctx->L[0].d.size;
     int32_t rc;
     // ---- the steps: every index an operation touches must exist ----
@@ -335,10 +363,44 @@ extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *o
     std::vector<zk_witness_op> vops(ops, ops + n_ops);
     std::vector<uint32_t> vwin(windows, windows + n_windows);
     zk_witness_op *d_ops = nullptr;
-    if ((rc = zk_upload(ctx, &d_ops, vops)) || (rc = zk_upload(ctx, &ctx->wp_windows, vwin))) return rc;
-    ctx->wp_ops = d_ops;
-    ctx->wp_n_ops = n_ops;
-    ctx->wp_n_windows = n_windows;
+    if ((rc = zk_upload(ctx, &d_ops, vops)) || (rc = zk_upload(ctx, &e->wp_windows, vwin))) return rc;
+    e->wp_ops = d_ops;
+    e->wp_n_ops = n_ops;
+    e->wp_n_windows = n_windows;
+    e->wp_steps.assign(steps, steps + n_steps);
+    e->wp_n_ranges = n_ranges;
+    e->wp_max_out = max_out; e->wp_max_blocks = max_blocks; e->wp_max_conv_part = max_conv_part; e->wp_max_conv_in = max_conv_in;
+    e->wp_conv_w_total = conv_w_total; e->wp_conv_w_off = conv_w_off;
+    for (int i = 1; i < n_layers; ++i) {                 // the lists grouped by output belong to the circuit: whoever attaches finds them in the entry
+        dev_layer &S = e->L[i];
+        const dev_layer &D = ctx->L[i];
+        S.ev_uni = D.ev_uni; S.ev_bin = D.ev_bin; S.n_ev_uni = D.n_ev_uni; S.n_ev_bin = D.n_ev_bin;
+        S.ev_dot = D.ev_dot; S.ev_dot_ptr = D.ev_dot_ptr; S.ev_conv = D.ev_conv;
+    }
+    return ZK_OK;
+}
+
+// the per-session side: the circuit's program (built above, by this context or by another) becomes this context's
+int32_t zk_witness_program_adopt(zk_ctx *ctx) {
+    shared_circuit *e = (shared_circuit *) ctx->circuit;
+    if (!e || !e->wp_ready) { ctx->err = "the resident circuit has no witness program"; return ZK_ERR_STATE; }
+    if (ctx->wp_ready) return ZK_OK;
+    int32_t rc;
+    const int32_t n_layers = (int32_t) ctx->L.size();
+    for (int i = 1; i < n_layers; ++i) {
+        const dev_layer &S = e->L[i];
+        dev_layer &D = ctx->L[i];
+        D.ev_uni = S.ev_uni; D.ev_bin = S.ev_bin; D.n_ev_uni = S.n_ev_uni; D.n_ev_bin = S.n_ev_bin;
+        D.ev_dot = S.ev_dot; D.ev_dot_ptr = S.ev_dot_ptr; D.ev_conv = S.ev_conv;
+    }
+    ctx->wp_ops = e->wp_ops;
+    ctx->wp_windows = e->wp_windows;
+    ctx->wp_n_ops = e->wp_n_ops;
+    ctx->wp_n_windows = e->wp_n_windows;
+    const uint64_t max_out = e->wp_max_out, max_blocks = e->wp_max_blocks, max_conv_part = e->wp_max_conv_part, max_conv_in = e->wp_max_conv_in,
+                   conv_w_total = e->wp_conv_w_total;
+    const std::vector<uint64_t> &conv_w_off = e->wp_conv_w_off;
+    const uint32_t n_ranges = e->wp_n_ranges;
     if (max_conv_part && (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_conv_part, max_conv_part * 32))) return rc;
     if (conv_w_total) {
         if ((rc = zk_dev_alloc(ctx, (void **) &ctx->wp_in64, max_conv_in * 8)) || (rc = zk_dev_alloc(ctx, (void **) &ctx->wp_w64, conv_w_total * 8)) ||
@@ -362,7 +424,7 @@ extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *o
         ctx->wp_segments = d_seg;
     }
     ctx->wp_n_ranges = n_ranges;
-    ctx->wp_steps.assign(steps, steps + n_steps);
+    ctx->wp_steps = e->wp_steps;
     ctx->wp_ready = true;
     return ZK_OK;
 }

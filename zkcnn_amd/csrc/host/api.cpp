@@ -101,9 +101,7 @@ struct gpuSession : public sessionT<prover> {
         if (!nn->quantisePicture(pixels, picture)) return 1;
         const witnessProgram &pg = nn->program();
         if (picture.size() != pg.picture_values) throw std::runtime_error("picture size differs from the circuit's");
-        if (!p.hasWitnessProgram())
-            p.uploadWitnessProgram(reinterpret_cast<const zk_witness_op *>(pg.ops.data()), pg.ops.size(), pg.windows.data(), pg.windows.size(),
-                                   reinterpret_cast<const zk_witness_step *>(pg.steps.data()), pg.steps.size());
+        ensureProgram();
         size_t n_ranges = 0;
         for (const witnessStep &st : pg.steps) n_ranges += st.what == witnessStep::RANGE;
         vector<u64> raw;
@@ -125,6 +123,13 @@ struct gpuSession : public sessionT<prover> {
         good_picture.swap(picture);
         has_witness = true;
         return 0;
+    }
+    // the witness program on the GPU (recorded by the circuit generator): uploaded with the first new picture, or before the session is cloned
+    void ensureProgram() {
+        if (p.hasWitnessProgram() || !nn || nn->program().steps.empty()) return;
+        const witnessProgram &pg = nn->program();
+        p.uploadWitnessProgram(reinterpret_cast<const zk_witness_op *>(pg.ops.data()), pg.ops.size(), pg.windows.data(), pg.windows.size(),
+                               reinterpret_cast<const zk_witness_step *>(pg.steps.data()), pg.steps.size());
     }
     bool ever_had_witness = false;     // set once a build with picture + weights succeeded (a verifier-only session never gets there)
     vector<F> good_picture;            // quantised picture of the witness in HBM (what a refused new_image restores)
@@ -248,6 +253,29 @@ void *zkcnn_session_create_calibrated(const zkcnn_model_desc *desc, const int32_
     }
 }
 
+
+void *zkcnn_session_clone(void *session) {
+    if (!session) return nullptr;
+    gpuSession *src = (gpuSession *) session;
+    try {
+        if (!src->ever_had_witness || !src->has_witness) return nullptr;            // (a verifier-only session, or one whose last picture was refused)
+        src->ensureProgram();                       // the clone adopts it with the circuit (it has no gate lists to build it from)
+        std::unique_ptr<gpuSession> s(new gpuSession(src->dev));
+        s->nn = src->nn;
+        s->gens = src->gens;
+        s->model_name = src->model_name;
+        s->pic_cnt = src->pic_cnt; s->pic_x = src->pic_x; s->pic_y = src->pic_y; s->pic_channel = src->pic_channel;
+        s->data_seed = src->data_seed;
+        s->p.cloneFrom(src->p);
+        s->good_picture = src->good_picture;
+        s->ever_had_witness = true;
+        s->has_witness = true;
+        return s.release();
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkcnn_session_clone: %s\n", e.what());
+        return nullptr;
+    }
+}
 
 int32_t zkcnn_session_prove(void *session, uint64_t seed, uint32_t mode, uint8_t *transcript, uint64_t cap, zkcnn_result *out) {
     if (!session || !out) return -1;

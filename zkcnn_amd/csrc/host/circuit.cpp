@@ -1,4 +1,5 @@
 #include "circuit.h"
+#include <cstring>
 #include "utils.hpp"
 
 // two_mul table and layer storage (behaviour of reference src/circuit.cpp:90-100)
@@ -125,4 +126,29 @@ const uint8_t *layeredCircuit::wiringDigest() const {
     top.digest(wiring_digest);
     wiring_digest_ok = true;
     return wiring_digest;
+}
+
+layeredCircuit layeredCircuit::structureCopy() const {
+    (void) wiringDigest();                       // computed from the gate lists while they are there; the copy carries it
+    layeredCircuit out;
+    out.size = size;
+    out.two_mul = two_mul;
+    std::memcpy(out.wiring_digest, wiring_digest, 32);
+    out.wiring_digest_ok = wiring_digest_ok;
+    out.circuit.resize(circuit.size());
+    for (size_t i = 0; i < circuit.size(); ++i) {
+        const layer &S = circuit[i];
+        layer &D = out.circuit[i];
+        D.ty = S.ty; D.size = S.size;
+        for (int b = 0; b < 2; ++b) {
+            D.size_u[b] = S.size_u[b]; D.size_v[b] = S.size_v[b];
+            D.bit_length_u[b] = S.bit_length_u[b]; D.bit_length_v[b] = S.bit_length_v[b];
+        }
+        D.bit_length = S.bit_length; D.max_bl_u = S.max_bl_u; D.max_bl_v = S.max_bl_v;
+        D.need_phase2 = S.need_phase2; D.zero_start_id = S.zero_start_id;
+        D.n_uni_kept = S.uniCount(); D.n_bin_kept = S.binCount();
+        D.ori_id_u = S.ori_id_u; D.ori_id_v = S.ori_id_v;
+        D.fft_bit_length = S.fft_bit_length; D.scale = S.scale;
+    }
+    return out;
 }

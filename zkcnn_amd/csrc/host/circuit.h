@@ -43,6 +43,12 @@ public:
     u32 zero_start_id = 0;               // rows >= this are constraint rows (must evaluate to 0)
     std::vector<uniGate> uni_gates;
     std::vector<binGate> bin_gates;
+    // a STRUCTURE COPY of a circuit (layeredCircuit::structureCopy: what a session keeps that shares another session's resident circuit) holds
+    // no gate lists, only how many there were: everything but the host-side wiring predicates works from the counts
+    u64 n_uni_kept = 0, n_bin_kept = 0;
+    u64 uniCount() const { return uni_gates.empty() ? n_uni_kept : (u64) uni_gates.size(); }
+    u64 binCount() const { return bin_gates.empty() ? n_bin_kept : (u64) bin_gates.size(); }
+    bool gatesDropped() const { return (uni_gates.empty() && n_uni_kept) || (bin_gates.empty() && n_bin_kept); }
     vector<u32> ori_id_u, ori_id_v;      // subset index -> layer-0 index
     i8 fft_bit_length = -1;
     F scale = F_ONE;                     // 1/N for IFFT, 1/pool^2 for average pooling
@@ -64,6 +70,9 @@ public:
     // SHA-256 tree over the gate lists and subset maps of every layer (leaves of 2^20 records, hashed on several host threads);
     // computed on first use and kept: what a Fiat-Shamir transcript absorbs as "the wiring"
     const uint8_t *wiringDigest() const;
+    // the circuit without its gate lists (shapes, subset maps, scales, the wiring digest): ~2% of the memory of a vgg11 circuit
+    layeredCircuit structureCopy() const;
+    bool gatesDropped() const { for (const layer &L : circuit) if (L.gatesDropped()) return true; return false; }
 private:
     mutable uint8_t wiring_digest[32];
     mutable bool wiring_digest_ok = false;

@@ -74,6 +74,21 @@ void prover::ensureContext() {
     }
 }
 
+void prover::cloneFrom(prover &parent) {
+    if (!parent.ctx || !parent.resident) throw std::runtime_error("prover::cloneFrom: the parent's circuit is not resident (call init() first)");
+    if (ctx) throw std::runtime_error("prover::cloneFrom: this prover already has a context");
+    zk_ctx *c = nullptr;
+    if (zk_ctx_clone(parent.ctx, &c) != ZK_OK) throw std::runtime_error(string("zk_ctx_clone failed: ") + zk_last_error(parent.ctx));
+    ctx = c;
+    device_id = parent.device_id;
+    C = parent.C.structureCopy();
+    vector<vector<F>>().swap(val);
+    resident = true;
+    program_resident = parent.program_resident;
+    prove_timer.clear();
+    check(zk_prover_init(ctx), "zk_prover_init");
+}
+
 vector<zk_layer_desc> prover::layerDescs() const {
     static_assert(sizeof(layerType) == sizeof(int), "layerType is passed as int32");
     vector<zk_layer_desc> desc(C.size);
@@ -123,6 +138,7 @@ void prover::rerunWitness(const vector<F> &picture, vector<u64> &ranges, size_t 
 void prover::init() {
     ensureContext();
     if (!resident) {
+        if (C.gatesDropped()) throw std::runtime_error("prover::init: this prover holds a structure copy of its circuit (a clone): nothing to upload");
         upload_timer.start();
         // a context holds one circuit; a changed circuit gets a fresh one
         vector<zk_layer_desc> desc = layerDescs();

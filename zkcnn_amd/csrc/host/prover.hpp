@@ -66,6 +66,9 @@ public:
     zk_ctx *context() const { return ctx; }     // for the profiler entry points of include/zkcnn_hip.h
 
     void ensureContext();                       // creates the GPU context (and its stream) without uploading anything
+    // This prover becomes a CLONE of `parent`: a context of its own on parent's resident circuit with a copy of parent's witness (include/zkcnn_hip.h:
+    // zk_ctx_clone), C = the structure copy of parent's circuit (no gate lists on the host). Nothing is generated, sorted or uploaded.
+    void cloneFrom(prover &parent);
     // non-interactive mode: the verifier's challenge chain (8 state words, count of unhashed bytes); the GPU then runs the small rounds of
     // every phase by itself (include/zkcnn_hip.h: zk_fs_attach). NULL, NULL detaches.
     void attachFiatShamir(const uint32_t *state, const uint64_t *pending);

@@ -52,8 +52,8 @@ public:
         absorb(&nl, 8);
         for (int i = 0; i < C.size; ++i) {
             const layer &L = C.circuit[i];
-            int64_t rec[16] = {(int64_t) L.ty, L.size, L.bit_length, L.fft_bit_length, L.zero_start_id, (int64_t) L.uni_gates.size(),
-                               (int64_t) L.bin_gates.size(), L.size_u[0], L.size_u[1], L.size_v[0], L.size_v[1], L.bit_length_u[0],
+            int64_t rec[16] = {(int64_t) L.ty, L.size, L.bit_length, L.fft_bit_length, L.zero_start_id, (int64_t) L.uniCount(),
+                               (int64_t) L.binCount(), L.size_u[0], L.size_u[1], L.size_v[0], L.size_v[1], L.bit_length_u[0],
                                L.bit_length_u[1], L.bit_length_v[0], L.bit_length_v[1], L.need_phase2};
             absorb(rec, sizeof(rec));
             uint8_t sb[32];

@@ -23,7 +23,7 @@ struct sessionT {
     sessionT() {}
     template <class A> explicit sessionT(const A &prover_arg) : p(prover_arg) {}      // e.g. the GPU index of the HIP-backed prover
     ProverT p;
-    std::unique_ptr<neuralNetwork> nn;
+    std::shared_ptr<neuralNetwork> nn;     // (shared by the clones of a session: everything a proof or a new picture asks of it is const)
     std::vector<G1> gens;
     string model_name;
     int pic_cnt = 1, pic_x = 0, pic_y = 0, pic_channel = 0;
@@ -177,7 +177,7 @@ struct sessionT {
         u64 nu = 0, nb = 0, tbl = 0;
         for (int i = 0; i < p.C.size; ++i) {
             const layer &L = p.C.circuit[i];
-            if (i) { rounds += L.max_bl_u + L.max_bl_v; nu += L.uni_gates.size(); nb += L.bin_gates.size(); }
+            if (i) { rounds += L.max_bl_u + L.max_bl_v; nu += L.uniCount(); nb += L.binCount(); }
             tbl += (u64) 1 << L.bit_length;
         }
         out->n_rounds = rounds + p.C.circuit[0].bit_length;

@@ -145,6 +145,8 @@ public:
         const u8 logn = C.circuit[0].bit_length;
         const size_t n_sqrt = (size_t) 1 << (logn - (logn >> 1));
         const size_t n_gens = n_sqrt + (zk ? 1 : 0);                 // zero-knowledge mode: one more generator, H
+        if (!drive_only && (!accel || cross_check) && C.gatesDropped())
+            return fail("the wiring predicates on the host need the gate lists: this session holds a structure copy of the circuit (a clone): use the GPU predicates");
         if (fixed_gens) gens = *fixed_gens;
         else drawGenerators(gens, n_gens);
         if (gens.size() != n_gens) return false;
