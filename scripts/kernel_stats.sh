@@ -7,31 +7,36 @@ TAG=${1:-prof}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for S in 1 8; do
+# S = proofs in flight: 1 = a lone proof (resident round kernels), 32 = four lock-step batches of eight lanes (the default bench shape)
+for S in 1 32; do
   D=$OUT/${TAG}_s$S
   rm -rf $D
-  rocprofv3 --kernel-trace --stats -d $D -o trace -- python $ROOT/bench.py --inner --steps 5 --warmup 2 --streams $S --no-cpu-baseline --no-companions > $OUT/${TAG}_s$S.log 2>&1 || true
+  LANES=8; [ $S = 1 ] && LANES=1
+  rocprofv3 --kernel-trace --stats -d $D -o trace -- python $ROOT/bench.py --inner --steps 5 --warmup 2 --streams $S --lanes $LANES --no-cpu-baseline --no-companions --no-pmc > $OUT/${TAG}_s$S.log 2>&1 || true
   python - <<PY
 import glob, sqlite3, json
 dbs = glob.glob("$D/**/*.db", recursive=True)
 out = open("$OUT/${TAG}_s$S.md", "w")
 line = [l for l in open("$OUT/${TAG}_s$S.log") if l.startswith("{")]
-out.write("# rocprofv3 --kernel-trace --stats -- python bench.py --inner --steps 5 --warmup 2 --streams $S --no-cpu-baseline --no-companions\n\n")
+out.write("# rocprofv3 --kernel-trace --stats -- python bench.py --inner --steps 5 --warmup 2 --streams $S --lanes " + ("1" if "$S" == "1" else "8") + " --no-cpu-baseline --no-companions --no-pmc\n\n")
 if line:
     d = json.loads(line[-1])
     out.write("bench line under the profiler: value %.2f proofs/s, prover_ms_per_image %.1f, roofline %s\n\n" % (d["value"], d["prover_ms_per_image"], json.dumps({k: d["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")})))
 for db in dbs:
     con = sqlite3.connect(db)
     try:
-        rows = con.execute("select name, calls, total_duration, average, percentage from top_kernels order by total_duration desc limit 30").fetchall()
+        rows = con.execute("select name, calls, total_duration, average, percentage from top_kernels order by total_duration desc limit 40").fetchall()
         cols = ["name", "calls", "total_ns", "avg_ns", "pct"]
     except Exception as e:
-        rows = con.execute("select * from top_kernels limit 30").fetchall()
+        rows = con.execute("select * from top_kernels limit 40").fetchall()
         cols = [c[1] for c in con.execute("pragma table_info(top_kernels)")]
     out.write("| " + " | ".join(cols) + " |\n|" + "---|" * len(cols) + "\n")
     for r in rows:
         r = list(r)
-        r[0] = str(r[0]).split("(")[0][:60]
+        import re
+        r[0] = re.sub(r"^void ", "", str(r[0]))
+        r[0] = re.sub(r"call_f<&\(?(void )?", "", r[0])
+        r[0] = r[0].split("(")[0][:70] if not r[0].startswith("k_run") else r[0][:70]
         out.write("| " + " | ".join(str(x) if not isinstance(x, float) else "%.1f" % x for x in r) + " |\n")
 out.close()
 print(open("$OUT/${TAG}_s$S.md").read())

@@ -1,6 +1,6 @@
 """Digests of the CPU oracle's transcripts for the two per-GPU circuits of BASELINE.json configs 4 / 5 at FULL size -- vgg11 with pic_cnt = 8 and
 vgg16 with pic_cnt = 4 as ONE circuit each (reference src/models.cpp:43-146; FFT convolutions because pic_cnt > 1, src/neuralNetwork.cpp:46;
-layer 0 = 2^26 entries) -- merged into tests/golden/transcripts.json under "full_size". tests/test_timed_path_gpu.py compares the GPU prover's
+layer 0 = 2^26 entries) -- kept in tests/golden/full_size.json. tests/test_timed_path_gpu.py compares the GPU prover's
 transcripts with them byte for byte (through SHA-256 + length); the oracle needs minutes and tens of GB per circuit, which is why this is a
 committed fixture and not a test-time computation.
 
@@ -23,7 +23,7 @@ CASES = {"vgg11_pp8": ("vgg11", (32, 32, 3), 8), "vgg16_pp4": ("vgg16", (32, 32,
 RUNS = [("interactive", 0x5EED0001, 0), ("reuse_gens", 0x5EED0007, 2)]
 DRIVE = 1
 
-path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "transcripts.json")
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "full_size.json")
 out_path = os.environ.get("GOLDEN_OUT", path)
 for key in (sys.argv[1:] or list(CASES)):
     model, pic, pp = CASES[key]

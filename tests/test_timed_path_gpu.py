@@ -95,19 +95,33 @@ FULL = [
 ]
 
 
+FULL_GOLDEN = __import__("json").load(open(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "full_size.json")))["full_size"]
+
+
 @pytest.mark.parametrize("model,pic,pp,shape", FULL)
 def test_full_size_fft_conv_circuits(built, model, pic, pp, shape):
-    """size-independent properties at full size (layer 0 = 2^26 entries, cubic rounds on 2^26-entry tables): the verifier checks the
-    round identity in every round, every wiring predicate (on the GPU and, cross-checked, on the host) and the Hyrax opening."""
+    """BYTE parity at full size (layer 0 = 2^26 entries, cubic rounds on 2^26-entry tables) through committed fixtures: the CPU oracle's transcripts
+    of these two circuits take ~10 minutes and ~30 GB each, so their SHA-256 and length are kept in tests/golden/full_size.json (made by
+    tests/golden/make_golden_full.py) -- plus the size-independent properties: the verifier checks the round identity in every round, every wiring
+    predicate (on the GPU and, cross-checked, on the host) and the Hyrax opening; corrupted messages are rejected."""
+    golden = FULL_GOLDEN.get(f"{model}_pp{pp}")
     with zkcnn_amd.Session(model, pic, pp) as s:
         res, t1 = s.prove(seed=0x5EED0001)
         assert res.accepted == 1, res.message.decode()
         assert res.n_layers == shape["n_layers"] and res.input_bits == shape["input_bits"]
+        if golden:
+            g = golden["interactive"]
+            assert g["challenge_seed"] == 0x5EED0001 and (hashlib.sha256(t1).hexdigest(), len(t1)) == (g["sha256"], g["transcript_len"]), \
+                f"{model} pic_cnt={pp} at full size: GPU transcript differs from the CPU oracle's (tests/golden/full_size.json)"
         r2, t2 = s.prove(seed=0x5EED0001, mode=DRIVE)
         assert t2 == t1                                           # deterministic, drive-only makes the same calls
         r3, t3 = s.prove(seed=0x5EED0007, mode=REUSE)
         r4, t4 = s.prove(seed=0x5EED0007, mode=REUSE | DRIVE)      # byte-table path at full size
         assert r3.accepted == 1 and t4 == t3
+        if golden:
+            g = golden["reuse_gens"]
+            assert g["challenge_seed"] == 0x5EED0007 and (hashlib.sha256(t3).hexdigest(), len(t3)) == (g["sha256"], g["transcript_len"]), \
+                f"{model} pic_cnt={pp} at full size, public generators: GPU transcript differs from the CPU oracle's"
         assert s.verify(t3, seed=0x5EED0007, mode=REUSE).accepted == 1
         n = res.n_messages
         for k in (n // 3, n - 1, n + 2):                          # a sumcheck message in the middle, the last one, an opening message
