@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <mutex>
 #include "ctx.hpp"
 #include "tail_types.hpp"
 
@@ -170,8 +171,20 @@ extern "C" int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries) {
     return ZK_OK;
 }
 static std::atomic<int> g_active_proofs[64];
+// The FIRST proof of a process runs alone: HIP loads a kernel's code lazily at its first launch, and dozens of host threads racing through the first
+// launch of the same kernels is the one thing the failing runs of rounds 3 and 4 had in common (one GPU memory fault in ~25 bench runs, one SIGSEGV
+// inside hipLaunchKernel under rocprofv3 -- both while 8 / 32 sessions ran their first proofs side by side; 6e6 launches with 3.3 KB argument blocks
+// from 32 threads did NOT reproduce it: scripts/exp/kernarg_stress.hip). Whoever begins the first proof holds this lock until it ends; proofs that
+// begin meanwhile wait. (Lanes of a batch share a thread and do not take part: a batch's sessions have proved alone before, or prove one by one anyway.)
+static std::mutex g_first_proof_mtx;
+static std::atomic<int> g_first_proof_done{0};
 extern "C" int32_t zk_proof_begin(zk_ctx *ctx) {
     if (!ctx) return ZK_ERR_ARG;
+    if (!g_first_proof_done.load() && !ctx->batch && !ctx->holds_first_proof) {
+        g_first_proof_mtx.lock();
+        if (g_first_proof_done.load()) g_first_proof_mtx.unlock();
+        else ctx->holds_first_proof = true;
+    }
     if (!ctx->counted_active) { ++g_active_proofs[ctx->device & 63]; ctx->counted_active = true; }
     // resident kernels only for a proof that is alone on its GPU when it starts: their workgroups wait for one another (k_mid) and for the host,
     // which is only safe -- and only profitable -- while nothing else competes for the CUs and the hardware queue for long
@@ -180,6 +193,11 @@ extern "C" int32_t zk_proof_begin(zk_ctx *ctx) {
 }
 extern "C" int32_t zk_proof_end(zk_ctx *ctx) {
     if (!ctx) return ZK_ERR_ARG;
+    if (ctx->holds_first_proof) {
+        ctx->holds_first_proof = false;
+        g_first_proof_done.store(1);
+        g_first_proof_mtx.unlock();
+    }
     if (ctx->counted_active) { --g_active_proofs[ctx->device & 63]; ctx->counted_active = false; }
     ctx->live_now = !ctx->batch;
     return ZK_OK;

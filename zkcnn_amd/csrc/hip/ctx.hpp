@@ -192,6 +192,7 @@ struct zk_ctx {
     void *d_bcast = nullptr;       // mid_bcast: k_mid's challenge line in device memory
     bool live_now = true;          // decided per proof (zk_proof_begin): does this proof have a hardware queue to itself?
     bool counted_active = false;
+    bool holds_first_proof = false; // this context runs the process's first proof (zk_proof_begin): others wait for it
     int live_count = 0, live_cursor = 0;
     uint32_t live_seq32 = 16;
     uint64_t live_rounds_total = 0, live_phases_total = 0;
