@@ -381,36 +381,47 @@ def main():
     # Large single-circuit workloads do not fit 8 times: a probe session measures what the first and what one more session cost in HBM.
     free0, _ = torch.cuda.mem_get_info(local_rank)
     hbm_first_gb = hbm_extra_gb = None
-    if pp > 1 or "vgg16" in model:
+    # Session 0 generates the circuit (host), sorts and uploads it; with lock-step batches every other session is a CLONE of it (zkcnn_session_clone):
+    # a context of its own on the resident circuit with a copy of the witness in HBM and NO host copy of the circuit -- 0.1 s and ~0.1 GB of host
+    # memory each instead of 3.5 s and 2.7 GB (round 3 built K full sessions side by side: K host circuits per rank). A probe clone measures what one
+    # more session costs in HBM: large single-circuit workloads do not fit 32 times. Independent streams (--lanes 1) keep the round-3 shape: there the
+    # order in which the sessions' streams are created matters.
+    if LANES > 1:
         build(0)
         free1, _ = torch.cuda.mem_get_info(local_rank)
-        probe = zkcnn_amd.Session(model, pic, pp, data_seed=DATA_SEED, device=local_rank)
+        probe = sessions[0].clone()
         free2, _ = torch.cuda.mem_get_info(local_rank)
         probe.close()
-        sessions[0].close()
-        sessions[0] = None
         hbm_first_gb, hbm_extra_gb = round((free0 - free1) / 1e9, 2), round((free1 - free2) / 1e9, 2)
         K_fit = 1 + max(0, int((0.85 * free1 - 8e9) / (max(free1 - free2, 1) * 1.3)))       # margin: MSM scratch and the byte table come with the first proofs
         if K_fit < K:
             print(f"[bench] HBM allows {K_fit} sessions of this workload, not the {K} asked for", file=sys.stderr)
             K = K_fit
-            sessions = sessions[:K]
-    LANES = min(LANES, K)
-    K = (K // LANES) * LANES                # whole batches
-    B = K // LANES
-    sessions = sessions[:K]
-    # Session 0 generates the circuit (host), sorts and uploads it; every other session is a CLONE of it (zkcnn_session_clone): a context of its own on
-    # the resident circuit with a copy of the witness in HBM and NO host copy of the circuit -- 0.1 s and ~0.1 GB of host memory each instead of 3.5 s
-    # and 2.7 GB. (Round 3 built K full sessions side by side: K host circuits per rank.) Independent streams (--lanes 1) keep the round-3 shape:
-    # there the order in which the sessions' streams are created matters.
-    if LANES > 1 and pp == 1:
-        build(0)
+        LANES = min(LANES, K)
+        K = (K // LANES) * LANES                # whole batches
+        B = K // LANES
+        sessions = sessions[:K]
 
         def build_clone(i):
             if i:
                 sessions[i] = sessions[0].clone()
         in_threads(build_clone)
     else:
+        if pp > 1 or "vgg16" in model:
+            build(0)
+            free1, _ = torch.cuda.mem_get_info(local_rank)
+            probe = zkcnn_amd.Session(model, pic, pp, data_seed=DATA_SEED, device=local_rank)
+            free2, _ = torch.cuda.mem_get_info(local_rank)
+            probe.close()
+            sessions[0].close()
+            sessions[0] = None
+            hbm_first_gb, hbm_extra_gb = round((free0 - free1) / 1e9, 2), round((free1 - free2) / 1e9, 2)
+            K_fit = 1 + max(0, int((0.85 * free1 - 8e9) / (max(free1 - free2, 1) * 1.3)))
+            if K_fit < K:
+                print(f"[bench] HBM allows {K_fit} sessions of this workload, not the {K} asked for", file=sys.stderr)
+                K = K_fit
+        B = K
+        sessions = sessions[:K]
         in_threads(build)
     if any(x is None for x in sessions):
         raise SystemExit("a session could not be built")
