@@ -8,6 +8,8 @@
 #include "tail_types.hpp"
 
 static std::string g_create_err;
+static std::atomic<int> g_live_contexts[64];
+int zk_contexts_on_device(int device) { return g_live_contexts[device & 63].load(); }
 void zk_set_create_error(const std::string &msg) { g_create_err = msg; }
 
 // ------------------------------------------------------------------------------------------------
@@ -81,6 +83,8 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
     std::memset((void *) ctx->h_aux, 0, sizeof(*ctx->h_aux));
     std::memset(ctx->h_tail, 0, std::max(sizeof(tail_out), sizeof(export_out)));
     std::memset(ctx->h_live_in, 0, sizeof(live_in));
+    ++g_live_contexts[device & 63];
+    ctx->counted_context = true;
     *out = ctx;
     return ZK_OK;
 }
@@ -89,6 +93,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->batch) (void) zk_batch_detach(ctx->batch, ctx);
+    if (ctx->counted_context) { --g_live_contexts[ctx->device & 63]; ctx->counted_context = false; }
     if (ctx->live_active) (void) zk_live_abort(ctx);
     (void) zk_proof_end(ctx);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);

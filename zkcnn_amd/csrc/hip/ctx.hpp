@@ -191,7 +191,17 @@ struct zk_ctx {
     bool live_with_add = false, live_first = false;
     void *d_bcast = nullptr;       // mid_bcast: k_mid's challenge line in device memory
     bool live_now = true;          // decided per proof (zk_proof_begin): does this proof have a hardware queue to itself?
+    // what it takes to run the current phase AGAIN with a launch per round, should its resident kernel be lost (a time-out, a stall behind somebody else's
+    // kernels): which phase it is, the arguments of its initialisation, the challenges it has answered so far
+    int phase_kind = 0;            // 0 none / not replayable, 1 phase 1 (generic), 2 phase 2, 3 layer-0 combine
+    int phase_bg_cur = 0;          // beta_g_cur when the phase began (a PADDING layer flips it)
+    std::vector<HFr> phase_r;      // challenge of every round call of the phase but the first
+    std::vector<uint64_t> phase_sig_u, phase_sig_v;    // layer-0 combine: its weights
+    bool phase_no_live = false;    // this phase runs on launches (it is being replayed, or has been)
+    bool live_lost = false;        // the resident kernel of the round in progress is gone: replay the phase
+    uint64_t live_fallbacks = 0;   // phases that were finished that way
     bool counted_active = false;
+    bool counted_context = false;  // counted among the live contexts of its device
     bool holds_first_proof = false; // this context runs the process's first proof (zk_proof_begin): others wait for it
     int live_count = 0, live_cursor = 0;
     uint32_t live_seq32 = 16;
@@ -404,6 +414,7 @@ int32_t zk_eq_table1_dev(zk_ctx *ctx, fr_t *out, int n, const HFr *r, const HFr 
 int32_t zk_col_combine_dev(zk_ctx *ctx, fr_t *out, const fr_t *Z, const fr_t *L, uint32_t cols, uint32_t rows);
 // a resident round kernel whose phase nobody finishes (a verifier that rejected mid-phase) must leave before anything else uses the stream
 int32_t zk_live_abort(zk_ctx *ctx);
+int zk_contexts_on_device(int device);      // context.hip: live contexts of this process on a device
 template <class T>
 static inline int32_t zk_upload(zk_ctx *ctx, T **dst, const std::vector<T> &src) {
     *dst = nullptr;

@@ -464,6 +464,7 @@ extern "C" int32_t zk_sumcheck_init_phase1(zk_ctx *ctx, const uint64_t relu_rou[
     ctx->add_pending = false;
     ctx->round = 0;
     ctx->conv_K = 0;
+    ctx->phase_kind = 1; ctx->phase_bg_cur = ctx->beta_g_cur; ctx->phase_r.clear(); ctx->phase_no_live = false;
     const HFr scale = H(d.scale);
     prep_plan P(ctx);
 
@@ -560,6 +561,7 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
     ctx->host_tail_active = false;
     ctx->last_poly_valid = false;
     ctx->round = 0;
+    ctx->phase_kind = 0; ctx->phase_r.clear(); ctx->phase_no_live = false;
     ctx->small_len = 1u << fft_bl;
     ctx->small_cur = 0;
     const uint64_t N = ctx->tp[1].len;
@@ -754,6 +756,7 @@ extern "C" int32_t zk_sumcheck_init_phase2(zk_ctx *ctx) {
     ctx->add_term.clear();
     ctx->add_pending = false;
     ctx->round = 0;
+    ctx->phase_kind = 2; ctx->phase_bg_cur = ctx->beta_g_cur; ctx->phase_r.clear(); ctx->phase_no_live = false;
     const HFr *ru = ctx->r_u[id].data();
     prep_plan P(ctx);
 
@@ -917,6 +920,16 @@ int32_t zk_live_abort(zk_ctx *ctx) {
 }
 // waits for the polynomial of round k of the running kernel; false if the kernel has left (status) or nothing arrives
 static int32_t live_wait(zk_ctx *ctx, int k, uint64_t out_abc[12]) {
+    // test hook (ZKCNN_TEST_HOOKS=1, ZKCNN_TEST_LIVE_FAIL=n): the n-th resident round of the process loses its kernel (as a time-out would)
+    static const long fail_at = (getenv("ZKCNN_TEST_HOOKS") && atoi(getenv("ZKCNN_TEST_HOOKS")) && getenv("ZKCNN_TEST_LIVE_FAIL")) ? atol(getenv("ZKCNN_TEST_LIVE_FAIL")) : -1;
+    static std::atomic<long> resident_rounds{0};
+    if (fail_at >= 0 && resident_rounds.fetch_add(1) == fail_at) {
+        (void) zk_live_abort(ctx);
+        for (int b = 0; b < 2; ++b) ctx->tp[b].len = 1;      // (zk_live_abort cleared them; the replay rebuilds every table)
+        ctx->err = "test hook: resident round kernel sent home";
+        ctx->live_lost = true;
+        return ZK_ERR_STATE;
+    }
     const tail_out *o = (const tail_out *) ctx->h_tail;
     const uint32_t want = ctx->live_seq32 + (uint32_t) k;
     uint32_t w[24];
@@ -937,6 +950,7 @@ static int32_t live_wait(zk_ctx *ctx, int k, uint64_t out_abc[12]) {
                 for (int j = 0; j < 8; ++j) if (((volatile const uint32_t *) o->live.c[j])[3] != want) late = false;
                 if (late) continue;
                 ctx->live_active = false;
+                ctx->live_lost = true;                 // (quad_round runs the phase again with a launch per round)
                 char msg[256];
                 const live_in *mi = (const live_in *) ctx->h_live_in;
                 std::snprintf(msg, sizeof(msg), "the resident round kernel left before the phase was over (%s, round %d of %d, status %#x, waiting for %#x, mailbox out %#x in %#x, stream %s)",
@@ -1233,7 +1247,60 @@ static void host_tail_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint6
     ++ctx->host_tail_rounds_total;
 }
 
+static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]);
+
+// A phase whose resident kernel was lost (it gave up after its time-out, or never got the CUs it waits for) is run AGAIN from its initialisation with
+// a launch per round: the challenges answered so far are replayed (same field elements, their polynomials are dropped), then the round that was
+// asked for is computed. Everything the initialisation needs is still in the context (the claim points, alpha / beta, V_u0 / V_u1, the weights of
+// the layer-0 combine); the tables of the phase are rebuilt from the layer values, which no round touches.
+static int32_t replay_phase(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]) {
+    const int kind = ctx->phase_kind, id = ctx->sumcheck_id;
+    if (kind < 1 || kind > 3) return ZK_ERR_STATE;
+    const std::vector<HFr> done = ctx->phase_r;                 // challenges of the calls so far (the current call's r is the last of them; none: the phase's first call)
+    if (done.size() != (size_t) ctx->round || (!done.empty() && std::memcmp(&done.back(), &r, 32) != 0)) return ZK_ERR_STATE;
+    const uint64_t proof_size = ctx->proof_size;
+    const std::vector<HFr> ru = ctx->r_u[id], rv = ctx->r_v[id];
+    const std::string why = ctx->err;
+    (void) hipStreamSynchronize(ctx->stream);
+    (void) hipMemsetAsync(ctx->d_counter, 0, 64, ctx->stream);
+    (void) hipMemsetAsync(ctx->d_bcast, 0, sizeof(mid_bcast), ctx->stream);
+    std::memset(ctx->h_live_in, 0, sizeof(live_in));
+    ctx->live_active = false;
+    ctx->live_mid = false;
+    ctx->beta_g_cur = ctx->phase_bg_cur;
+    int32_t rc;
+    if (kind == 1) { const HFr rr = ctx->relu_rou; rc = zk_sumcheck_init_phase1(ctx, reinterpret_cast<const uint64_t *>(&rr)); }
+    else if (kind == 2) rc = zk_sumcheck_init_phase2(ctx);
+    else rc = zk_sumcheck_liu_init(ctx, ctx->phase_sig_u.data(), ctx->phase_sig_v.data(), (uint32_t) (ctx->phase_sig_u.size() / 4));
+    if (rc) return rc;
+    ctx->phase_no_live = true;
+    ctx->r_u[id] = ru;
+    ctx->r_v[id] = rv;
+    uint64_t dummy[12];
+    // calls 0 .. n-1 were answered before (call j came with challenge c_j, call 0 with none); `done` = c_1 .. c_n, c_n being the call in progress
+    for (size_t j = 0; j < done.size() && rc == ZK_OK; ++j) {
+        const HFr prev = j ? done[j - 1] : HFr(0LL);
+        rc = quad_round_once(ctx, prev, with_add_term, dummy);
+    }
+    if (rc == ZK_OK) rc = quad_round_once(ctx, r, with_add_term, out_abc);
+    ctx->phase_r = done;
+    ctx->proof_size = proof_size + 32 * 3;
+    ++ctx->live_fallbacks;
+    if (rc == ZK_OK) fprintf(stderr, "[zkcnn] a resident round kernel was lost (%s); the phase was run again with a launch per round\n", why.c_str());
+    return rc;
+}
+
 static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]) {
+    if (ctx->round) ctx->phase_r.push_back(r);
+    int32_t rc = quad_round_once(ctx, r, with_add_term, out_abc);
+    if (rc == ZK_ERR_STATE && ctx->live_lost) {
+        ctx->live_lost = false;
+        rc = replay_phase(ctx, r, with_add_term, out_abc);
+    }
+    return rc;
+}
+
+static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]) {
     static const bool seg_timing = getenv("ZKCNN_TIMING") != nullptr;
     // the tail paths start from add_term: it must be there before they are considered (the plain round below picks it up behind its launch)
     if (ctx->add_pending && (ctx->host_tail_log >= 0 || ctx->fs_state)) { int32_t rc0 = resolve_add_term(ctx); if (rc0) return rc0; }
@@ -1249,7 +1316,8 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
     // quads of this round over both pairs (a first round works on pairs, not quads)
     const uint64_t round_quads = ctx->round == 0 ? (ctx->tp[0].len + ctx->tp[1].len) / 2 : (ctx->tp[0].len + ctx->tp[1].len) / 4;
     const bool in_phase = !ctx->live_active && !ctx->tail_active && ctx->phase_rounds > ctx->round && ctx->tp[0].len + ctx->tp[1].len > 0;
-    const bool resident_ok = ctx->live_rounds && ctx->live_now && !ctx->batch && ctx->host_tail_log < 0 && in_phase;
+    const bool resident_ok = ctx->live_rounds && ctx->live_now && !ctx->batch && !ctx->phase_no_live && ctx->host_tail_log < 0 && in_phase &&
+                             (ctx->counted_active || zk_contexts_on_device(ctx->device) == 1);     // (outside a proof's bracket: only for the device's one context)
     // The middle of a phase (more quads than the single-workgroup kernel takes, tables of at most 2^18 entries): a SEGMENT of rounds in one
     // resident multi-workgroup kernel (k_mid), as long as no table collapses or reaches its last pair. Returns the segment's length (0: none).
     auto plan_segment = [&]() -> int {
@@ -1505,6 +1573,11 @@ extern "C" int32_t zk_sumcheck_liu_init(zk_ctx *ctx, const uint64_t *s_u, const 
     ctx->add_term.clear();
     ctx->add_pending = false;
     ctx->round = 0;
+    ctx->phase_kind = 3; ctx->phase_r.clear(); ctx->phase_no_live = false;
+    if (s_u != ctx->phase_sig_u.data()) {           // (not when the phase is being replayed from these very vectors)
+        ctx->phase_sig_u.assign(s_u, s_u + 4 * (size_t) n);
+        ctx->phase_sig_v.assign(s_v, s_v + 4 * (size_t) n);
+    }
     table_pair &t = ctx->tp[1];
     t.Vsrc = L0.val;
     t.live = std::min<uint64_t>(t.len, L0.d.size);          // layer 0 is zero padded behind its size, and no layer refers to entries there
