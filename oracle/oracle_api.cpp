@@ -8,6 +8,7 @@
 #include "session.hpp"
 
 typedef sessionT<oracle::prover> oracleSession;
+typedef layer layer_t_alias;
 
 // For the host-logic test of batchSessionT (session.hpp) without a GPU: the CPU prover, except that every round call first gives up the thread when
 // it runs on a fiber -- the points at which the HIP-backed prover's lanes yield. K such sessions driven by one batchSessionT must produce
@@ -192,6 +193,24 @@ int64_t oracle_session_layer_size(void *session, int32_t layer, int32_t *type) {
     if (layer < 0 || layer >= C.size) return -1;
     if (type) *type = (int32_t) C.circuit[layer].ty;
     return (int64_t) C.circuit[layer].size;
+}
+// The circuit as the generator + initSubset left it, for tests/test_circuit_cpu.py (an independent restatement of reference src/circuit.cpp:4-88
+// in numpy is run on these gate lists): meta = {type, size, n_uni, n_bin, size_u0, size_u1, size_v0, size_v1, bl, bl_u0, bl_u1, bl_v0, bl_v1,
+// max_bl_u, max_bl_v, fft_bl, need_phase2, zero_start_id}; uni: 4 words per gate (g, u, lu, sc); bin: 5 (g, u, v, sc, l). NULL arrays: counts only.
+int32_t oracle_session_layer_dump(void *session, int32_t layer, int64_t meta[18], uint32_t *uni, uint32_t *bin, uint32_t *ori_u, uint32_t *ori_v) {
+    if (!session || !meta) return -1;
+    const layeredCircuit &C = ((oracleSession *) session)->p.C;
+    if (layer < 0 || layer >= C.size) return -1;
+    const layer_t_alias &L = C.circuit[layer];
+    const int64_t m[18] = {(int64_t) L.ty, L.size, (int64_t) L.uni_gates.size(), (int64_t) L.bin_gates.size(), L.size_u[0], L.size_u[1], L.size_v[0], L.size_v[1],
+                           L.bit_length, L.bit_length_u[0], L.bit_length_u[1], L.bit_length_v[0], L.bit_length_v[1], L.max_bl_u, L.max_bl_v, L.fft_bit_length,
+                           L.need_phase2, L.zero_start_id};
+    std::memcpy(meta, m, sizeof(m));
+    if (uni) for (size_t k = 0; k < L.uni_gates.size(); ++k) { const uniGate &g = L.uni_gates[k]; uni[4 * k] = g.g; uni[4 * k + 1] = g.u; uni[4 * k + 2] = g.lu; uni[4 * k + 3] = g.sc; }
+    if (bin) for (size_t k = 0; k < L.bin_gates.size(); ++k) { const binGate &g = L.bin_gates[k]; bin[5 * k] = g.g; bin[5 * k + 1] = g.u; bin[5 * k + 2] = g.v; bin[5 * k + 3] = g.sc; bin[5 * k + 4] = g.l; }
+    if (ori_u) std::memcpy(ori_u, L.ori_id_u.data(), L.ori_id_u.size() * 4);
+    if (ori_v) std::memcpy(ori_v, L.ori_id_v.data(), L.ori_id_v.size() * 4);
+    return 0;
 }
 int32_t oracle_session_poke(void *session, int32_t layer, uint64_t index, const uint64_t value[4]) {
     oracleSession *s = (oracleSession *) session;
