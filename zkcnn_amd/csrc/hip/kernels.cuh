@@ -545,6 +545,13 @@ __device__ __forceinline__ void k_round_cubic(const fr_t *V0in, const fr_t *V1in
             fr_store(V1out + 2 * p + 1, fr_lerp(fr_load(V1in + 4 * p + 2), fr_load(V1in + 4 * p + 3), r));
             if (fill & 1) { fr_store(V0out + 2 * p, fr_zero()); fr_store(V0out + 2 * p + 1, fr_zero()); }
         }
+    // X's live prefix after this fold is 2 pl entries; the next round reads whole quads, i.e. up to 4 ceil(2 pl / 4): when pl is odd that is one pair
+    // beyond what the loop above wrote -- a guard pair of zeros keeps stale buffer contents out of the next fold (round-3 advisor finding; with
+    // fill & 1 the loop behind the prefix has zeroed everything already)
+    if (!first && !(fill & 1) && blockIdx.x == 0 && threadIdx.x == 0 && (pl & 1) && 2 * pl + 2 <= n / 2) {
+        fr_store(V0out + 2 * pl, fr_zero());
+        fr_store(V0out + 2 * pl + 1, fr_zero());
+    }
     fr_block_sum<4>(acc, smem);
     __syncthreads();
     grid_finish<4>(acc, partials, counter, slot, seq, smem);
