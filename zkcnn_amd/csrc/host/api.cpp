@@ -119,7 +119,7 @@ struct gpuSession : public sessionT<prover> {
             }
             return 2;
         }
-        nn->setInferenceFrom(last);
+        inferred = nn->inferenceFrom(last);      // (this session's: the generator object is shared with its clones and stays untouched)
         good_picture.swap(picture);
         has_witness = true;
         return 0;
@@ -132,6 +132,7 @@ struct gpuSession : public sessionT<prover> {
                                reinterpret_cast<const zk_witness_step *>(pg.steps.data()), pg.steps.size());
     }
     bool ever_had_witness = false;     // set once a build with picture + weights succeeded (a verifier-only session never gets there)
+    vector<int> inferred;              // classes inferred for the picture in HBM (after a new_image)
     vector<F> good_picture;            // quantised picture of the witness in HBM (what a refused new_image restores)
 };
 

@@ -490,9 +490,9 @@ bool neuralNetwork::rangesFitScales(const vector<std::pair<u64, u64>> &ranges) c
     return k == ranges.size();
 }
 
-void neuralNetwork::setInferenceFrom(const vector<F> &last_layer) {
-    infer_result.clear();
-    if (full_conn.empty()) return;
+vector<int> neuralNetwork::inferenceFrom(const vector<F> &last_layer) const {
+    vector<int> out;
+    if (full_conn.empty()) return out;
     const int n_class = (int) full_conn.back().channel_out;
     for (int p = 0; p < pic_parallel; ++p) {
         int k = -1;
@@ -501,8 +501,9 @@ void neuralNetwork::setInferenceFrom(const vector<F> &last_layer) {
             const F &t = last_layer.at(matIdx(p, c, n_class));
             if (!t.isNegative() && (k == -1 || best < t)) { k = c; best = t; }
         }
-        infer_result.push_back(k);
+        out.push_back(k);
     }
+    return out;
 }
 
 // ---------------------------------------------------------------------------------------------

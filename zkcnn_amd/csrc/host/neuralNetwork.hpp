@@ -120,7 +120,8 @@ public:
     // resident backend found them: true iff every range FITS the circuit's scale (the scale this picture would get by itself is not smaller;
     // equal for the picture the circuit was built from, larger for one with a smaller range: it only loses precision)
     bool rangesFitScales(const vector<std::pair<u64, u64>> &ranges) const;
-    void setInferenceFrom(const vector<F> &last_layer);
+    // the classes the output layer of a replayed witness infers (const: clones of a session share this object, each keeps its own result)
+    vector<int> inferenceFrom(const vector<F> &last_layer) const;
     void setWitnessAccel(witnessAccel *a) { accel = a; }
 
     // The circuit's shape depends on the data only through the quantisation scales (bits kept per layer): a build records them,
