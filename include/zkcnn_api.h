@@ -80,7 +80,8 @@ void *zkcnn_session_create_calibrated(const zkcnn_model_desc *desc, const int32_
  * nothing is generated, sorted or uploaded (a vgg11 session costs 3.5 s and 2.7 GB of host memory to build; a clone ~0.1 s and ~0.1 GB). Proves what
  * `session` proves until zkcnn_session_new_image gives it a picture of its own: how the lanes of a batch are made. Independent of `session` afterwards
  * (either may be destroyed first). The clone keeps no gate lists on the host: the verifier's wiring predicates run on the GPU; ZKCNN_MODE_HOST_PRED /
- * ZKCNN_MODE_CROSS_PRED are rejected for it. NULL on error (a verifier-only session cannot be cloned). */
+ * ZKCNN_MODE_CROSS_PRED are rejected for it. NULL on error (a verifier-only session cannot be cloned). Several threads may clone one session at the
+ * same time; the session must not be proving or taking a new picture meanwhile. */
 void *zkcnn_session_clone(void *session);
 /* One proof. `transcript` may be NULL; at most `cap` bytes are written, the full length is reported. */
 int32_t zkcnn_session_prove(void *session, uint64_t challenge_seed, uint32_t mode, uint8_t *transcript,

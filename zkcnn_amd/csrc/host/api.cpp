@@ -1,5 +1,6 @@
 // C entry points of libzkcnn_host.so (include/zkcnn_api.h): circuit + witness on the host, the
 // prover on the GPU, the reference verifier driving it.
+#include <mutex>
 #include <stdexcept>
 #include <cstddef>
 #define ZKFIBER_IMPLEMENTATION
@@ -131,6 +132,7 @@ struct gpuSession : public sessionT<prover> {
         p.uploadWitnessProgram(reinterpret_cast<const zk_witness_op *>(pg.ops.data()), pg.ops.size(), pg.windows.data(), pg.windows.size(),
                                reinterpret_cast<const zk_witness_step *>(pg.steps.data()), pg.steps.size());
     }
+    std::mutex clone_mtx;              // zkcnn_session_clone: the parent's one-time preparations
     bool ever_had_witness = false;     // set once a build with picture + weights succeeded (a verifier-only session never gets there)
     vector<int> inferred;              // classes inferred for the picture in HBM (after a new_image)
     vector<F> good_picture;            // quantised picture of the witness in HBM (what a refused new_image restores)
@@ -260,7 +262,13 @@ void *zkcnn_session_clone(void *session) {
     gpuSession *src = (gpuSession *) session;
     try {
         if (!src->ever_had_witness || !src->has_witness) return nullptr;            // (a verifier-only session, or one whose last picture was refused)
-        src->ensureProgram();                       // the clone adopts it with the circuit (it has no gate lists to build it from)
+        {   // several threads may clone one session side by side (bench.py does): what a clone needs of its parent is made ONCE, under the parent's lock --
+            // the witness program on the GPU (the clone adopts it with the circuit: it has no gate lists to build it from) and the wiring digest
+            // (cached in the circuit; the structure copy carries it). Everything else a clone reads of its parent is read-only.
+            std::lock_guard<std::mutex> g(src->clone_mtx);
+            src->ensureProgram();
+            (void) src->p.C.wiringDigest();
+        }
         std::unique_ptr<gpuSession> s(new gpuSession(src->dev));
         s->nn = src->nn;
         s->gens = src->gens;
