@@ -44,6 +44,7 @@ WORKLOADS = {
     "vgg16": ("vgg16", (32, 32, 3), 1),
     "vgg11_pp8": ("vgg11", (32, 32, 3), 8),      # 8 pictures folded into ONE circuit (the reference's pic_cnt = 8; FFT convolutions)
     "vgg16_pp4": ("vgg16", (32, 32, 3), 4),
+    "vgg16_pp32": ("vgg16", (32, 32, 3), 32),    # BASELINE configs[4] as the reference itself would run it: ONE circuit over 32 pictures (layer 0 = 2^28 entries)
     # bounded CPU sample: vgg11 with every channel width divided by 4 (1/16 of the multiplication gates)
     "vgg11_quarter": ("vgg:16 M 32 M 64 64 M 128 128 M 128 128 M", (32, 32, 3), 1),
     # vgg11 with every channel width halved (1/4 of the multiplication gates): ~7 s of CPU prover time on one core
