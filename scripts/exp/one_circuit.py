@@ -8,6 +8,7 @@ import sys
 import time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("ZKCNN_TEST_HOOKS", "1")      # (the corrupted-message check below)
 import torch  # noqa: E402
 import zkcnn_amd as M  # noqa: E402
 torch.cuda.init()

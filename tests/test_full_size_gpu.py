@@ -131,3 +131,27 @@ def test_full_size_vgg11_lock_step_batch_identical_to_oracle(built, k):
         for s in ss:
             if s is not None:
                 s.close()
+
+
+def test_vgg16_thirty_two_pictures_as_one_circuit(built):
+    """BASELINE.json configs[4] in the reference's OWN meaning (reference src/main_demo_vgg.cpp:36: vgg16 with pic_cnt = 32 is ONE circuit; layer 0 =
+    2^28 entries, ~38 GB of layer values, 16 384 x 16 384 commitment matrix): it fits one MI355X (110 GB of HBM for circuit + witness + tables, 140 GB
+    with the generator tables). The CPU oracle cannot hold it in the build container, so the evidence is the verifier's -- every round identity, every
+    wiring predicate on the GPU, the Hyrax opening -- plus determinism, replay of the serialized proof and rejection of a corrupted message."""
+    try:
+        import psutil
+        if psutil.virtual_memory().available < 300e9:
+            pytest.skip("needs ~250 GB of host memory for the circuit and witness of 32 pictures")
+    except ImportError:
+        pass
+    TAMPER = zkcnn_amd.MODE_TAMPER
+    with zkcnn_amd.Session("vgg16", PIC, 32) as s:
+        res, tr = s.prove(seed=SEED, mode=REUSE)
+        assert res.accepted == 1, res.message.decode()
+        assert res.n_layers == 99 and res.input_bits == 28 and res.n_rounds == 2605
+        r2, tr2 = s.prove(seed=SEED, mode=REUSE | DRIVE)
+        assert tr2 == tr
+        assert s.verify(tr, seed=SEED, mode=REUSE).accepted == 1
+        bad, _ = s.prove(seed=SEED, mode=REUSE | TAMPER | ((res.n_messages // 2) << 8))
+        assert bad.accepted == 0
+        print(f"vgg16 pic_cnt=32 as one circuit: prover {1e3 * (r2.prove_s + r2.poly_prove_s):.1f} ms = {32 / (r2.prove_s + r2.poly_prove_s):.0f} pictures/s, proof {res.proof_kb + res.poly_proof_kb:.0f} KB")

@@ -35,7 +35,7 @@ struct conv_desc {
 
 // ---- layer-0 combine (k_eq_halves_multi / k_liu_gather) and the small eq tables of the structured convolutions ----
 struct liu_table { fr_vec r; fr_t init; int32_t n, fh, sh, pad_; };      // one per (layer, side) that touches layer 0
-#define LIU_HALF_STRIDE 4096u                                               // entries per half table (bit length of a subset table <= 24)
+#define LIU_HALF_STRIDE 8192u                                               // entries per half table (bit length of a subset table <= 26: vgg16 over 32 pictures)
 struct liu_entry { uint32_t h, t; };                                        // index h inside table (t & 0xffffff); t >> 24 = bits of the table's low half
 #define CONV_TAB_STRIDE 4096u           // entries per small eq table
 // table numbers inside the context's small-table buffer

@@ -545,7 +545,7 @@ static int32_t build_static(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_
                 const uint32_t sz = side ? S.size_v[0] : S.size_u[0];
                 const uint32_t *ori = side ? S.ori_id_v : S.ori_id_u;
                 if (bl < 0 || !sz) continue;
-                if (bl > 24) { ctx->err = "layer-0 subset table too large for the combined gather"; return ZK_ERR_ARG; }
+                if (bl > 26) { ctx->err = "layer-0 subset table too large for the combined gather"; return ZK_ERR_ARG; }
                 ctx->liu_tab_layer.push_back(i);
                 ctx->liu_tab_side.push_back(side);
                 for (uint32_t h = 0; h < sz; ++h) {
