@@ -17,6 +17,27 @@
 #include "prep_kernels.cuh"
 
 // ------------------------------------------------------------------------------------------------
+// launch policy: every size threshold of the state machine in one place, with the measurement behind it (all on vgg11-shaped circuits on one MI355X;
+// the FFT-convolution circuits were checked not to lose by them, not tuned for)
+// ------------------------------------------------------------------------------------------------
+namespace policy {
+// tables of up to 2^FINE_LOG entries take the 4-lanes-per-quad latency kernel (k_round_fine_f: a dependent chain of 2 products instead of 7); larger
+// ones the product kernel (k_round_quad2_f). Round 1: switch-over sizes 2^14 .. 2^18 measured, 2^16 best by ~1%.
+constexpr int FINE_LOG = 16;
+// k_round_quad2_f holds 3 waves per SIMD (132 VGPRs): 768 blocks of 4 waves are exactly one resident set of the 1 024 SIMDs -- no partial second wave of blocks
+constexpr uint32_t QUAD2_BLOCKS = 768;
+// tables of up to 2^FULL_TABLE_LOG entries are always complete (their readers -- k_round_fine_f, k_mid, k_tail -- know no live-prefix bound); larger ones
+// are built and folded up to their live prefix only. Also the largest table a resident segment kernel (k_mid) takes.
+constexpr int FULL_TABLE_LOG = 18;
+// a resident segment (k_mid) takes rounds of at most this many quads over both pairs: 65 536 quads = 1 024 chunks of 64 over its <= 256 workgroups
+constexpr uint64_t MID_MAX_QUADS = 65536;
+// DOT_PROD phase 1: once the folded tables hold at most 2^DOT_FILL_LOG entries the zeros behind X's live prefix are written out (the quadratic rounds
+// behind the collapse read whole tables); and Y's fold behind the prefix becomes a streaming launch of its own from 2^DOT_STREAM_LOG pairs on (4 TB/s
+// against ~2 inside the round kernel: DESIGN.md 4i)
+constexpr int DOT_FILL_LOG = 20, DOT_STREAM_LOG = 17;
+}
+
+// ------------------------------------------------------------------------------------------------
 // building blocks
 // ------------------------------------------------------------------------------------------------
 // ---- one launch for all table builders of a phase (prep_kernels.cuh) ----
@@ -215,7 +236,7 @@ static int32_t gate_multi(zk_ctx *ctx, int phase, const dev_layer &prev, const g
 
 // a table of more than 2^18 entries is first read by the round kernel that stops at the live prefix (rounded up to whole quads): its builders
 // stop there too (one guard quad behind it); smaller tables are read whole
-#define ZK_FULL_TABLE_LOG 18          // tables of up to 2^18 entries are always complete: their readers (k_round_quad_fine, k_mid, k_tail) know no bound
+#define ZK_FULL_TABLE_LOG policy::FULL_TABLE_LOG
 static inline uint64_t table_end(uint64_t len, uint64_t live) {
     return len <= (1ull << ZK_FULL_TABLE_LOG) ? len : std::min<uint64_t>(len, ((live + 3) & ~3ull) + 4);
 }
@@ -666,11 +687,11 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
     const unsigned long long seq = ++ctx->slot_seq;
     // X's live prefix (entries, pre-fold); once the folded tables are small the zeros behind it are written out (the quadratic rounds read whole tables)
     const uint64_t x_live = std::min<uint64_t>(t0.live, n);
-    int fill = (!first && n / 2 <= (1ull << 20)) ? 1 : 0;
+    int fill = (!first && n / 2 <= (1ull << policy::DOT_FILL_LOG)) ? 1 : 0;
     // Behind X's live prefix only Y is folded: for large tables that is a plain streaming fold (one output per thread, 64 contiguous bytes in, 32
     // out) in a launch of its own ahead of the round kernel, which then works on the live pairs alone
     const uint64_t pl = std::min<uint64_t>(npairs, (x_live + 3) / 4);
-    if (!first && npairs - pl >= (1ull << 17)) {
+    if (!first && npairs - pl >= (1ull << policy::DOT_STREAM_LOG)) {
         const uint64_t n_in = n - 4 * pl;
         zk_launch_f(ctx, PC_FOLD, 48.0 * (double) n_in, dim3(grid_for(n_in / 2, 8192)), k_fold_f{vin(t1) + 4 * pl, t1.V[t1.cur ^ 1] + 2 * pl, n_in, to_dev(r)});
         ZK_ORDER();
@@ -828,424 +849,8 @@ static int32_t resolve_add_term(zk_ctx *ctx) {
     return ZK_OK;
 }
 
-// One quadratic round over the live table pairs. reference src/prover.cpp:368-426.
-static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-// Non-interactive mode: all remaining rounds of the phase in one single-workgroup kernel (fs_tail.cuh). Called at the start of a round
-// whose live tables are small; fills the context's tail record and leaves every table pair either collapsed or down to its last pair.
-// (Round 2 also had CHAINED launches for tables of up to 2^16 entries -- one launch per round, the next challenge derived in its last block;
-// transcripts identical, 0.5 ms per vgg11 proof slower than host-driven rounds: removed in round 3.)
-static int32_t run_device_rounds(zk_ctx *ctx, const HFr &r, bool with_add_term) {
-    const bool first = ctx->round == 0;
-    const unsigned long long seq = ++ctx->tail_seq;
-    tail_args A;
-    std::memset(&A, 0, sizeof(A));
-    for (int b = 0; b < 2; ++b) {
-        table_pair &t = ctx->tp[b];
-        if (!t.len) continue;
-        A.Vin[b] = vin(t); A.Min[b] = t.M[t.cur];
-        A.Vbuf[b][0] = t.V[0]; A.Vbuf[b][1] = t.V[1];
-        A.Mbuf[b][0] = t.M[0]; A.Mbuf[b][1] = t.M[1];
-        A.out_idx[b] = t.cur ^ 1;
-        A.n[b] = t.len;
-    }
-    A.first = first ? 1 : 0;
-    A.rounds = ctx->phase_rounds - ctx->round;
-    A.with_add_term = with_add_term ? 1 : 0;
-    A.prev_r = to_dev(r);
-    A.add_term = to_dev(ctx->add_term);
-    std::memcpy(A.fs_state, ctx->fs_state, 32);
-    A.out = (tail_out *) ctx->d_tail;
-    A.seq = seq;
-    ZK_LAUNCH(PC_TAIL, 0.0, k_tail<false>, dim3(1), dim3(TAIL_THREADS), A);
-    ZK_HIP(hipGetLastError());
-    volatile unsigned long long *p = &((tail_out *) ctx->h_tail)->seq;
-    for (uint64_t spins = 0; *p != seq; ++spins) {
-        if (spins > (1ull << 24)) {
-            ZK_HIP(hipStreamSynchronize(ctx->stream));
-            if (*p != seq) { ctx->err = "device rounds were not published"; return ZK_ERR_STATE; }
-            break;
-        }
-        __builtin_ia32_pause();
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    const tail_out *o = (const tail_out *) ctx->h_tail;
-    for (int b = 0; b < 2; ++b) {
-        table_pair &t = ctx->tp[b];
-        if (!t.len) continue;
-        t.Vsrc = nullptr;
-        if (o->pair_state[b] == 1) {
-            t.len = 2;
-            std::memcpy(&t.tail_v[0], &o->tail_v[b][0], 32);
-            std::memcpy(&t.tail_v[1], &o->tail_v[b][1], 32);
-            t.tail_valid = true;
-        } else {
-            t.len = 0;
-            t.absorbed = true;
-            std::memcpy(&t.final_v, &o->final_v[b], 32);
-        }
-    }
-    std::memcpy(&ctx->add_term, &o->add_term, 32);
-    ctx->tail_active = true;
-    ctx->tail_count = A.rounds;
-    ctx->tail_cursor = 0;
-    ctx->last_poly_valid = false;          // (the rounds answered from the record do not maintain the running claim)
-    ctx->tail_rounds_total += (uint64_t) ctx->tail_count;
-    ++ctx->tail_phases_total;
-    return ZK_OK;
-}
-
-// ---- persistent rounds of the INTERACTIVE protocol (k_tail<true>, fs_tail.cuh): the kernel is resident for the rest of the phase, a round is
-// "challenge into the mailbox, polynomial out of the mailbox" ----
-static inline void live_post(zk_ctx *ctx, const HFr &r, uint32_t seq) {
-    uint32_t w[8];
-    std::memcpy(w, &r, 32);
-    live_in *m = (live_in *) ctx->h_live_in;
-    // one 16-byte store per chunk (the kernel reads a chunk with one 16-byte load and checks the number in each)
-    _mm_store_si128((__m128i *) m->c[0], _mm_set_epi32((int) seq, (int) w[2], (int) w[1], (int) w[0]));
-    _mm_store_si128((__m128i *) m->c[1], _mm_set_epi32((int) seq, (int) w[5], (int) w[4], (int) w[3]));
-    _mm_store_si128((__m128i *) m->c[2], _mm_set_epi32((int) seq, 0, (int) w[7], (int) w[6]));
-    _mm_sfence();
-}
-int32_t zk_live_abort(zk_ctx *ctx) {
-    if (!ctx->live_active) return ZK_OK;
-    live_post(ctx, HFr(0LL), TAIL_ABORT);
-    ctx->live_active = false;
-    ctx->live_mid = false;
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    ZK_HIP(hipMemsetAsync(ctx->d_counter, 0, 64, ctx->stream));          // (a segment kernel that was sent home may have left arrivals behind ...
-    ZK_HIP(hipMemsetAsync(ctx->d_bcast, 0, sizeof(mid_bcast), ctx->stream));   //  ... and the abort word in its broadcast line)
-    std::memset(ctx->h_live_in, 0, sizeof(live_in));
-    for (int b = 0; b < 2; ++b) ctx->tp[b].len = 0;
-    return ZK_OK;
-}
-// waits for the polynomial of round k of the running kernel; false if the kernel has left (status) or nothing arrives
-static int32_t live_wait(zk_ctx *ctx, int k, uint64_t out_abc[12]) {
-    // test hook (ZKCNN_TEST_HOOKS=1, ZKCNN_TEST_LIVE_FAIL=n): the n-th resident round of the process loses its kernel (as a time-out would)
-    static const long fail_at = (getenv("ZKCNN_TEST_HOOKS") && atoi(getenv("ZKCNN_TEST_HOOKS")) && getenv("ZKCNN_TEST_LIVE_FAIL")) ? atol(getenv("ZKCNN_TEST_LIVE_FAIL")) : -1;
-    static std::atomic<long> resident_rounds{0};
-    if (fail_at >= 0 && resident_rounds.fetch_add(1) == fail_at) {
-        (void) zk_live_abort(ctx);
-        for (int b = 0; b < 2; ++b) ctx->tp[b].len = 1;      // (zk_live_abort cleared them; the replay rebuilds every table)
-        ctx->err = "test hook: resident round kernel sent home";
-        ctx->live_lost = true;
-        return ZK_ERR_STATE;
-    }
-    const tail_out *o = (const tail_out *) ctx->h_tail;
-    const uint32_t want = ctx->live_seq32 + (uint32_t) k;
-    uint32_t w[24];
-    for (uint64_t spins = 0;; ++spins) {
-        bool ok = true;
-        for (int j = 0; j < 8; ++j) {
-            const __m128i c = _mm_load_si128((const __m128i *) o->live.c[j]);
-            alignas(16) uint32_t t[4];
-            _mm_store_si128((__m128i *) t, c);
-            if (t[3] != want) { ok = false; break; }
-            w[3 * j] = t[0]; w[3 * j + 1] = t[1]; w[3 * j + 2] = t[2];
-        }
-        if (ok) break;
-        if (spins > (1ull << 16) && (spins & 1023) == 0) {
-            if (*(volatile const uint32_t *) &o->status != 0 || hipStreamQuery(ctx->stream) == hipSuccess) {
-                // (a kernel that has left: one last look, its final message may have landed after the check above)
-                bool late = true;
-                for (int j = 0; j < 8; ++j) if (((volatile const uint32_t *) o->live.c[j])[3] != want) late = false;
-                if (late) continue;
-                ctx->live_active = false;
-                ctx->live_lost = true;                 // (quad_round runs the phase again with a launch per round)
-                char msg[256];
-                const live_in *mi = (const live_in *) ctx->h_live_in;
-                std::snprintf(msg, sizeof(msg), "the resident round kernel left before the phase was over (%s, round %d of %d, status %#x, waiting for %#x, mailbox out %#x in %#x, stream %s)",
-                              ctx->live_mid ? "k_mid" : "k_tail", k, ctx->live_count, (unsigned) o->status, (unsigned) want, (unsigned) o->live.c[0][3], (unsigned) mi->c[0][3],
-                              hipStreamQuery(ctx->stream) == hipSuccess ? "idle" : "busy");
-                ctx->err = msg;
-                ctx->live_mid = false;
-                return ZK_ERR_STATE;
-            }
-            if (spins > (1ull << 22)) sched_yield();
-        } else __builtin_ia32_pause();
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    std::memcpy(out_abc, w, 96);
-    return ZK_OK;
-}
-static int32_t live_start(zk_ctx *ctx, const HFr &r, bool with_add_term) {
-    tail_args A;
-    std::memset(&A, 0, sizeof(A));
-    for (int b = 0; b < 2; ++b) {
-        table_pair &t = ctx->tp[b];
-        if (!t.len) continue;
-        A.Vin[b] = vin(t); A.Min[b] = t.M[t.cur];
-        A.Vbuf[b][0] = t.V[0]; A.Vbuf[b][1] = t.V[1];
-        A.Mbuf[b][0] = t.M[0]; A.Mbuf[b][1] = t.M[1];
-        A.out_idx[b] = t.cur ^ 1;
-        A.n[b] = t.len;
-    }
-    A.first = ctx->round == 0 ? 1 : 0;
-    A.rounds = ctx->phase_rounds - ctx->round;
-    A.with_add_term = with_add_term ? 1 : 0;
-    A.prev_r = to_dev(r);
-    A.add_term = to_dev(ctx->add_term);
-    A.out = (tail_out *) ctx->d_tail;
-    A.in = (const live_in *) ctx->d_live_in;
-    // sequence numbers of this kernel's rounds: never 0 (a cleared mailbox), never the abort word, never one of the previous kernel's
-    ctx->live_seq32 += 64;
-    if (ctx->live_seq32 > 0xf0000000u) ctx->live_seq32 = 64;
-    A.seq32 = ctx->live_seq32;
-    ((tail_out *) ctx->h_tail)->status = 0;
-    ZK_LAUNCH(PC_TAIL, 0.0, k_tail<true>, dim3(1), dim3(TAIL_THREADS), A);
-    ZK_HIP(hipGetLastError());
-    ctx->live_active = true;
-    ctx->live_count = A.rounds;
-    ctx->live_cursor = 0;
-    ctx->last_poly_valid = false;          // (these rounds do not maintain the running claim)
-    ctx->live_rounds_total += (uint64_t) A.rounds;
-    ++ctx->live_phases_total;
-    return ZK_OK;
-}
-// a segment of mid-size rounds (k_mid): `rounds` consecutive rounds in which every present pair keeps at least two quads
-static int32_t mid_start(zk_ctx *ctx, const HFr &r, bool with_add_term, int rounds, uint32_t blocks) {
-    mid_args A;
-    std::memset(&A, 0, sizeof(A));
-    for (int b = 0; b < 2; ++b) {
-        table_pair &t = ctx->tp[b];
-        if (!t.len) continue;
-        A.Vin[b] = vin(t); A.Min[b] = t.M[t.cur];
-        A.Vbuf[b][0] = t.V[0]; A.Vbuf[b][1] = t.V[1];
-        A.Mbuf[b][0] = t.M[0]; A.Mbuf[b][1] = t.M[1];
-        A.out_idx[b] = t.cur ^ 1;
-        A.n[b] = t.len;
-    }
-    A.rounds = rounds;
-    A.with_add_term = with_add_term ? 1 : 0;
-    A.first = ctx->round == 0 ? 1 : 0;
-    A.prev_r = to_dev(r);
-    A.add_term = to_dev(ctx->add_term);
-    A.partials = ctx->partials;
-    A.arrive = ctx->d_counter + 2;
-    A.bc = (mid_bcast *) ctx->d_bcast;
-    A.out = (tail_out *) ctx->d_tail;
-    A.in = (const live_in *) ctx->d_live_in;
-    ctx->live_seq32 += 64;
-    if (ctx->live_seq32 > 0xf0000000u) ctx->live_seq32 = 64;
-    A.seq32 = ctx->live_seq32;
-    ((tail_out *) ctx->h_tail)->status = 0;
-    ZK_LAUNCH(PC_TAIL, 0.0, k_mid<true>, dim3(blocks), dim3(ZK_BLOCK), A);
-    ZK_HIP(hipGetLastError());
-    if (with_add_term) ctx->add_term = ctx->add_term * (HFr::one() - r);      // (the kernel's blocks apply the same factors to their copy)
-    ctx->live_active = true;
-    ctx->live_mid = true;
-    ctx->live_first = A.first != 0;
-    ctx->live_with_add = with_add_term;
-    ctx->live_count = rounds;
-    ctx->live_cursor = 0;
-    ctx->last_poly_valid = false;
-    ctx->live_rounds_total += (uint64_t) rounds;
-    ++ctx->live_phases_total;
-    return ZK_OK;
-}
-// the same segment in the non-interactive mode (k_mid<false>): the kernel derives the challenges itself, the host waits once and answers
-// the verifier's following calls from the record (like run_device_rounds)
-static int32_t run_device_mid(zk_ctx *ctx, const HFr &r, bool with_add_term, int rounds, uint32_t blocks) {
-    mid_args A;
-    std::memset(&A, 0, sizeof(A));
-    for (int b = 0; b < 2; ++b) {
-        table_pair &t = ctx->tp[b];
-        if (!t.len) continue;
-        A.Vin[b] = vin(t); A.Min[b] = t.M[t.cur];
-        A.Vbuf[b][0] = t.V[0]; A.Vbuf[b][1] = t.V[1];
-        A.Mbuf[b][0] = t.M[0]; A.Mbuf[b][1] = t.M[1];
-        A.out_idx[b] = t.cur ^ 1;
-        A.n[b] = t.len;
-    }
-    const bool first = ctx->round == 0;
-    A.rounds = rounds;
-    A.with_add_term = with_add_term ? 1 : 0;
-    A.first = first ? 1 : 0;
-    A.prev_r = to_dev(r);
-    A.add_term = to_dev(ctx->add_term);
-    A.partials = ctx->partials;
-    A.arrive = ctx->d_counter + 2;
-    A.bc = (mid_bcast *) ctx->d_bcast;
-    A.out = (tail_out *) ctx->d_tail;
-    ctx->live_seq32 += 64;
-    if (ctx->live_seq32 > 0xf0000000u) ctx->live_seq32 = 64;
-    A.seq32 = ctx->live_seq32;
-    std::memcpy(A.fs_state, ctx->fs_state, 32);
-    const unsigned long long seq = ++ctx->tail_seq;
-    A.seq = seq;
-    ZK_LAUNCH(PC_TAIL, 0.0, k_mid<false>, dim3(blocks), dim3(ZK_BLOCK), A);
-    ZK_HIP(hipGetLastError());
-    volatile unsigned long long *p = &((tail_out *) ctx->h_tail)->seq;
-    for (uint64_t spins = 0; *p != seq; ++spins) {
-        if (spins > (1ull << 24)) {
-            ZK_HIP(hipStreamSynchronize(ctx->stream));
-            if (*p != seq) { ctx->err = "device rounds were not published"; return ZK_ERR_STATE; }
-            break;
-        }
-        __builtin_ia32_pause();
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    const tail_out *o = (const tail_out *) ctx->h_tail;
-    // what the kernel's blocks did to their copies: add_term (1 - r) per round, one fold per round but the phase's first
-    if (with_add_term) {
-        ctx->add_term = ctx->add_term * (HFr::one() - r);
-        for (int k = 1; k < rounds; ++k) { HFr c; std::memcpy(&c, &o->chal[k - 1], 32); ctx->add_term = ctx->add_term * (HFr::one() - c); }
-    }
-    const int folds = rounds - (first ? 1 : 0);
-    for (int b = 0; b < 2; ++b) {
-        table_pair &t = ctx->tp[b];
-        if (!t.len || folds <= 0) continue;
-        t.Vsrc = nullptr;
-        if (folds & 1) t.cur ^= 1;
-        t.len >>= folds;
-        t.live = t.len;
-    }
-    ctx->tail_active = true;
-    ctx->tail_count = rounds;
-    ctx->tail_cursor = 0;
-    ctx->last_poly_valid = false;
-    ctx->tail_rounds_total += (uint64_t) rounds;
-    ++ctx->tail_phases_total;
-    return ZK_OK;
-}
-// one round of the resident kernel: r is the verifier's challenge for the previous polynomial (round 0 of the kernel got it as a launch argument)
-static int32_t live_round(zk_ctx *ctx, const HFr &r, uint64_t out_abc[12]) {
-    static const bool timing = getenv("ZKCNN_TIMING") != nullptr;
-    const int k = ctx->live_cursor;
-    const double t0 = timing ? now_s() : 0;
-    if (timing && k > 0) ctx->live_t_host += t0 - ctx->live_t_exit;
-    if (k > 0) {
-        live_post(ctx, r, ctx->live_seq32 + (uint32_t) k);
-        if (ctx->live_mid && ctx->live_with_add) ctx->add_term = ctx->add_term * (HFr::one() - r);
-    }
-    int32_t rc = live_wait(ctx, k, out_abc);
-    if (rc) return rc;
-    if (timing) {
-        ctx->live_t_exit = now_s();
-        if (k > 0) { ctx->live_t_gpu += ctx->live_t_exit - t0; ++ctx->live_timed_rounds; }
-    }
-    ++ctx->round;
-    ctx->proof_size += 32 * 3;
-    if (++ctx->live_cursor < ctx->live_count) return ZK_OK;
-    if (ctx->live_mid) {
-        // the segment is over: every table was folded live_count times (nothing collapsed, nothing is down to its last pair)
-        for (int b = 0; b < 2; ++b) {
-            table_pair &t = ctx->tp[b];
-            if (!t.len) continue;
-            const int folds = ctx->live_count - (ctx->live_first ? 1 : 0);
-            if (folds > 0) {
-                t.Vsrc = nullptr;
-                if (folds & 1) t.cur ^= 1;
-                t.len >>= folds;
-                t.live = t.len;
-            }
-        }
-        ctx->live_active = false;
-        ctx->live_mid = false;
-        return ZK_OK;
-    }
-    // the phase is over: the kernel has posted the bookkeeping scalar and what is left of the tables before its last polynomial, and leaves
-    const tail_out *o = (const tail_out *) ctx->h_tail;
-    for (int b = 0; b < 2; ++b) {
-        table_pair &t = ctx->tp[b];
-        if (!t.len) continue;
-        t.Vsrc = nullptr;
-        if (o->pair_state[b] == 1) {
-            t.len = 2;
-            std::memcpy(&t.tail_v[0], &o->tail_v[b][0], 32);
-            std::memcpy(&t.tail_v[1], &o->tail_v[b][1], 32);
-            t.tail_valid = true;
-        } else {
-            t.len = 0;
-            t.absorbed = true;
-            std::memcpy(&t.final_v, &o->final_v[b], 32);
-        }
-    }
-    std::memcpy(&ctx->add_term, &o->add_term, 32);
-    ctx->live_ticks_wait += o->ticks_wait;
-    ctx->live_ticks_total += o->ticks_total;
-    ctx->live_active = false;
-    return ZK_OK;
-}
-
-// Hybrid tail: the (small) live tables come to the host ...
-static int32_t host_tail_begin(zk_ctx *ctx) {
-    export_args A;
-    std::memset(&A, 0, sizeof(A));
-    for (int b = 0; b < 2; ++b) {
-        table_pair &t = ctx->tp[b];
-        A.V[b] = t.len ? vin(t) : nullptr;
-        A.M[b] = t.len ? t.M[t.cur] : nullptr;
-        A.n[b] = (uint32_t) t.len;
-    }
-    A.out = (export_out *) ctx->d_tail;
-    A.seq = ++ctx->tail_seq;
-    ZK_LAUNCH(PC_FOLD, 0.0, k_export_tables, dim3(1), dim3(512), A);
-    ZK_HIP(hipGetLastError());
-    const export_out *o = (const export_out *) ctx->h_tail;
-    if (ctx->batch) { int32_t rc = zk_batch_sync_point(ctx); if (rc) return rc; }
-    volatile const unsigned long long *p = &o->seq;
-    for (uint64_t spins = 0; *p != A.seq; ++spins) {
-        if (spins > (1ull << 24)) {
-            ZK_HIP(hipStreamSynchronize(ctx->stream));
-            if (*p != A.seq) { ctx->err = "tables were not published"; return ZK_ERR_STATE; }
-            break;
-        }
-        __builtin_ia32_pause();
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    for (int b = 0; b < 2; ++b) {
-        const uint64_t n = ctx->tp[b].len;
-        ctx->ht_V[b].resize(n);
-        ctx->ht_M[b].resize(n);
-        if (n) {
-            std::memcpy(ctx->ht_V[b].data(), o->V[b], n * 32);
-            std::memcpy(ctx->ht_M[b].data(), o->M[b], n * 32);
-        }
-    }
-    ctx->host_tail_active = true;
-    return ZK_OK;
-}
-// ... and one round there: the arithmetic of reference src/prover.cpp:368-426 on plain folded tables (what the round kernels compute)
-static void host_tail_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]) {
-    const bool first = ctx->round == 0;
-    ++ctx->round;
-    if (with_add_term) ctx->add_term = ctx->add_term * (HFr::one() - r);
-    HFr a(0LL), c(0LL), p1(0LL);
-    for (int b = 0; b < 2; ++b) {
-        table_pair &t = ctx->tp[b];
-        if (!t.len) continue;
-        std::vector<HFr> &V = ctx->ht_V[b], &M = ctx->ht_M[b];
-        if (!first) {
-            for (uint64_t j = 0; j < t.len / 2; ++j) {
-                V[j] = V[2 * j] + r * (V[2 * j + 1] - V[2 * j]);
-                M[j] = M[2 * j] + r * (M[2 * j + 1] - M[2 * j]);
-            }
-            t.len >>= 1;
-            t.Vsrc = nullptr;
-        }
-        if (t.len == 1) {                                   // the reference's `total == 1` case (prover.cpp:400-404)
-            t.final_v = V[0];
-            ctx->add_term = ctx->add_term + V[0] * M[0];
-            t.absorbed = true;
-            t.len = 0;
-            continue;
-        }
-        for (uint64_t j = 0; j < t.len / 2; ++j) {
-            const HFr &v0 = V[2 * j], &v1 = V[2 * j + 1], &m0 = M[2 * j], &m1 = M[2 * j + 1];
-            a = a + (v1 - v0) * (m1 - m0);
-            c = c + v0 * m0;
-            p1 = p1 + v1 * m1;
-        }
-        if (t.len == 2) { t.tail_v[0] = V[0]; t.tail_v[1] = V[1]; t.tail_valid = true; }
-    }
-    HFr bcoef = p1 - a - c;
-    if (with_add_term) { bcoef = bcoef - ctx->add_term; c = c + ctx->add_term; }
-    put(out_abc, a);
-    put(out_abc + 4, bcoef);
-    put(out_abc + 8, c);
-    ctx->proof_size += 32 * 3;
-    ++ctx->host_tail_rounds_total;
-}
+// the resident / device-side / hybrid round drivers (everything that is not "one launch per round")
+#include "rounds_resident.hpp"
 
 static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]);
 
@@ -1321,7 +926,7 @@ static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, ui
     // The middle of a phase (more quads than the single-workgroup kernel takes, tables of at most 2^18 entries): a SEGMENT of rounds in one
     // resident multi-workgroup kernel (k_mid), as long as no table collapses or reaches its last pair. Returns the segment's length (0: none).
     auto plan_segment = [&]() -> int {
-        if (!resident_ok || round_quads <= TAIL_QUADS || round_quads > 65536 || std::max(ctx->tp[0].len, ctx->tp[1].len) > (1ull << ZK_FULL_TABLE_LOG)) return 0;
+        if (!resident_ok || round_quads <= TAIL_QUADS || round_quads > policy::MID_MAX_QUADS || std::max(ctx->tp[0].len, ctx->tp[1].len) > (1ull << ZK_FULL_TABLE_LOG)) return 0;
         uint64_t L0 = ctx->tp[0].len, L1 = ctx->tp[1].len;
         int rounds = 0;
         bool f = ctx->round == 0;          // (a first round works on pairs and folds nothing)
@@ -1383,7 +988,7 @@ static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, ui
     HFr claim(0LL);
     if (skip_p1) claim = (ctx->last_poly[0] * r + ctx->last_poly[1]) * r + ctx->last_poly[2];
     // small tables are latency bound: spread each quad over 4 lanes (k_round_quad2, `fine`)
-    const int fine_log = 16;
+    const int fine_log = policy::FINE_LOG;
     // (one block per 64 quads and 3 partial sums per block: both pairs together must stay within the partials buffer)
     const uint64_t longest = std::max(ctx->tp[0].len, ctx->tp[1].len);
     const bool fine = longest <= (1ull << fine_log) && 2 * (longest / 4 / (ZK_BLOCK / 4) + 1) <= ctx->partial_blocks;
@@ -1404,7 +1009,7 @@ static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, ui
         A.fill[b] = (t.len / 2 <= (1ull << ZK_FULL_TABLE_LOG)) ? 1 : 0;
         const uint64_t work = fine ? npairs : std::max<uint64_t>(first ? (live + 1) / 2 : (live + 3) / 4, first ? 1 : (A.fill[b] ? npairs / 8 : 1));
         // (k_round_quad2 holds 3 waves per SIMD: 768 blocks of 4 waves are exactly one resident set of the 1 024 SIMDs -- no partial second wave of blocks)
-        const uint32_t quad_cap = 768;
+        const uint32_t quad_cap = policy::QUAD2_BLOCKS;
         A.blocks[b] = collapsed[b] ? 1 : std::min<uint32_t>(grid_for(work, fine ? 1024 : quad_cap), ctx->partial_blocks / 2);
         fine_items += collapsed[b] ? 1 : npairs;
         alg_bytes += (first ? 64.0 : 96.0) * (double) (fine ? t.len : live);      // entries the launch has to read: the live prefix
@@ -1616,183 +1221,4 @@ extern "C" int32_t zk_sumcheck_liu_finalize(zk_ctx *ctx, const uint64_t prev_r[4
     return ZK_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// kernel-level entry points (host arrays in / out)
-// ------------------------------------------------------------------------------------------------
-#define CHECK_CTX() ZK_CHECK_CTX()
-
-template <int OP>
-static int32_t binop(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n) {
-    CHECK_CTX();
-    int32_t rc = zk_scratch(ctx, 3 * n * 32);
-    if (rc) return rc;
-    fr_t *da = (fr_t *) ctx->scratch.p, *db = da + n, *dz = db + n;
-    ZK_HIP(hipMemcpyAsync(da, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(db, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    ZK_LAUNCH(PC_MISC, 0.0, k_fr_binop<OP>, dim3(grid_for(n)), dim3(ZK_BLOCK), dz, da, db, n);
-    ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpyAsync(out, dz, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    return ZK_OK;
-}
-extern "C" int32_t zk_k_fr_mul(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n) { return binop<0>(ctx, out, a, b, n); }
-extern "C" int32_t zk_k_fr_add(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n) { return binop<1>(ctx, out, a, b, n); }
-extern "C" int32_t zk_k_fr_sub(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n) { return binop<2>(ctx, out, a, b, n); }
-
-extern "C" int32_t zk_k_eq_table(zk_ctx *ctx, uint64_t *out, int32_t n, const uint64_t *r0, const uint64_t *r1,
-                                 const uint64_t alpha[4], const uint64_t beta[4]) {
-    CHECK_CTX();
-    if (n < 0 || n > ZK_MAX_VARS) return ZK_ERR_ARG;
-    const uint64_t len = 1ull << n;
-    int32_t rc = zk_scratch(ctx, len * 32);
-    if (rc) return rc;
-    rc = eq_table(ctx, (fr_t *) ctx->scratch.p, n, reinterpret_cast<const HFr *>(r0), H(alpha), reinterpret_cast<const HFr *>(r1),
-                  H(beta), ~0ull, HFr::one());
-    if (rc) return rc;
-    ZK_HIP(hipMemcpyAsync(out, ctx->scratch.p, len * 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    return ZK_OK;
-}
-
-extern "C" int32_t zk_k_phi_table(zk_ctx *ctx, uint64_t *out, const uint64_t *rx, const uint64_t scale[4], int32_t n,
-                                  int32_t inverse) {
-    CHECK_CTX();
-    if (n < 1 || n > 20) return ZK_ERR_ARG;
-    const uint64_t cnt = inverse ? 1ull << n : 1ull << (n - 1);
-    int32_t rc = zk_scratch(ctx, cnt * 32);
-    if (rc) return rc;
-    if ((rc = phi_table(ctx, (fr_t *) ctx->scratch.p, reinterpret_cast<const HFr *>(rx), H(scale), n, inverse != 0))) return rc;
-    ZK_HIP(hipMemcpyAsync(out, ctx->scratch.p, cnt * 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    return ZK_OK;
-}
-
-extern "C" int32_t zk_k_round_quadratic(zk_ctx *ctx, uint64_t *V, uint64_t *M, uint64_t n, const uint64_t r[4], int32_t first,
-                                        uint64_t out_abc[12], uint64_t *n_out) {
-    CHECK_CTX();
-    if (n < 2 || (n & (n - 1)) || (!first && n < 4)) return ZK_ERR_ARG;
-    int32_t rc = zk_scratch(ctx, 4 * n * 32);
-    if (rc) return rc;
-    fr_t *dV = (fr_t *) ctx->scratch.p, *dM = dV + n, *dV2 = dM + n, *dM2 = dV2 + n;
-    ZK_HIP(hipMemcpyAsync(dV, V, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipMemcpyAsync(dM, M, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    // the PRODUCT kernel (k_round_quad2 as quad_round launches it for tables above the fine-grained limit), one table pair
-    const uint64_t npairs = first ? n / 2 : n / 4;
-    round2_args A;
-    std::memset(&A, 0, sizeof(A));
-    A.Vin[0] = dV; A.Min[0] = dM; A.Vout[0] = dV2; A.Mout[0] = dM2;
-    A.n[0] = n;
-    A.nl[0] = n;
-    A.blocks[0] = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks / 2);
-    A.r = to_dev(H(r));
-    A.first = first ? 1 : 0;
-    A.partials = ctx->partials;
-    A.counter = ctx->d_counter;
-    A.slot = (host_slot *) ctx->d_slot;
-    A.seq = ++ctx->slot_seq;
-    ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_round_quad2, dim3(A.blocks[0]), dim3(ZK_BLOCK), A);
-    ZK_HIP(hipGetLastError());
-    if ((rc = wait_slot(ctx, A.seq))) return rc;
-    for (int k = 0; k < 3; ++k) ctx->h_result[k] = ctx->h_slot->v[k];
-    const uint64_t nn = first ? n : n / 2;
-    if (!first) {
-        ZK_HIP(hipMemcpy(V, dV2, nn * 32, hipMemcpyDeviceToHost));
-        ZK_HIP(hipMemcpy(M, dM2, nn * 32, hipMemcpyDeviceToHost));
-    }
-    HFr a = ctx->h_result[0], c = ctx->h_result[1], p1 = ctx->h_result[2];
-    put(out_abc, a);
-    put(out_abc + 4, p1 - a - c);
-    put(out_abc + 8, c);
-    *n_out = nn;
-    return ZK_OK;
-}
-
-// ---- micro-benchmarks (device resident, HIP events on the context's stream) ----
-template <class Launch>
-static int32_t time_launches(zk_ctx *ctx, uint32_t iters, double *sec, Launch launch) {
-    hipEvent_t e0, e1;
-    ZK_HIP(hipEventCreate(&e0));
-    ZK_HIP(hipEventCreate(&e1));
-    launch();                                   // warm-up
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    ZK_HIP(hipEventRecord(e0, ctx->stream));
-    for (uint32_t i = 0; i < iters; ++i) launch();
-    ZK_HIP(hipEventRecord(e1, ctx->stream));
-    ZK_HIP(hipEventSynchronize(e1));
-    ZK_HIP(hipGetLastError());
-    float ms = 0;
-    ZK_HIP(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    *sec = (double) ms * 1e-3 / iters;
-    return ZK_OK;
-}
-
-extern "C" int32_t zk_bench_fr_mul(zk_ctx *ctx, uint64_t n_threads, uint32_t muls_per_thread, uint32_t iters, double *sec) {
-    CHECK_CTX();
-    int32_t rc = zk_scratch(ctx, 2 * n_threads * 32);
-    if (rc) return rc;
-    int lg = 0;
-    while ((2ull << lg) <= n_threads) ++lg;
-    std::vector<HFr> r(lg, HFr(0x1234567LL));
-    for (int i = 0; i < lg; ++i) r[i] = r[i] * HFr((long long) (i * 7919 + 3)) + HFr(0x9e3779b9LL);
-    ZK_HIP(hipMemsetAsync(ctx->scratch.p, 0, 2 * n_threads * 32, ctx->stream));
-    if ((rc = eq_table1(ctx, (fr_t *) ctx->scratch.p, lg, r.data(), HFr(77LL)))) return rc;
-    const uint32_t blocks = (uint32_t) ((n_threads + ZK_BLOCK - 1) / ZK_BLOCK);
-    return time_launches(ctx, iters, sec, [&] {
-        ZK_LAUNCH_RAW(PC_MISC, 0.0, k_bench_fr_mul, dim3(blocks), dim3(ZK_BLOCK), (fr_t *) ctx->scratch.p, muls_per_thread, n_threads);
-    });
-}
-
-extern "C" int32_t zk_bench_copy(zk_ctx *ctx, uint64_t bytes, uint32_t iters, double *sec) {
-    CHECK_CTX();
-    int32_t rc = zk_scratch(ctx, 2 * bytes);
-    if (rc) return rc;
-    uint4 *src = (uint4 *) ctx->scratch.p, *dst = src + bytes / 16;
-    ZK_HIP(hipMemsetAsync(src, 1, bytes, ctx->stream));
-    return time_launches(ctx, iters, sec, [&] {
-        ZK_LAUNCH_RAW(PC_MISC, 0.0, k_bench_copy, dim3(4096), dim3(ZK_BLOCK), dst, src, bytes / 16);
-    });
-}
-
-// The dominant kernel of the FFT-conv configs in isolation: one non-first quadratic round (k_round_quad2, the product kernel) on two
-// 2^log_n-entry tables of pseudo-random elements. Algorithmic bytes = 96 * 2^log_n.
-extern "C" int32_t zk_bench_round_quadratic(zk_ctx *ctx, uint32_t log_n, uint32_t iters, double *sec_per_launch,
-                                            double *algorithmic_bytes) {
-    CHECK_CTX();
-    if (log_n < 2 || log_n > 28) return ZK_ERR_ARG;
-    const uint64_t n = 1ull << log_n;
-    int32_t rc = zk_scratch(ctx, 3 * n * 32);
-    if (rc) return rc;
-    fr_t *dV = (fr_t *) ctx->scratch.p, *dM = dV + n, *dO = dM + n;
-    // fill with field elements: eq tables of a fixed point are as good as random for timing purposes
-    std::vector<HFr> r(log_n);
-    zkff::Xoshiro g;
-    g.seed(0x5EED0002ULL);
-    for (auto &x : r) {
-        uint64_t t[4] = {g.next(), g.next(), g.next(), g.next() & 0x3fffffffffffffffULL};
-        x = HFr(zkff::MontField<zkff::FrParams>::fromCanonical(t));
-    }
-    if ((rc = eq_table1(ctx, dV, (int) log_n, r.data(), HFr(7LL)))) return rc;
-    if ((rc = eq_table1(ctx, dM, (int) log_n, r.data(), HFr(11LL)))) return rc;
-    // the product kernel exactly as quad_round launches it for one large table pair (fold + round sums + grid finish + host slot)
-    round2_args A;
-    std::memset(&A, 0, sizeof(A));
-    A.Vin[0] = dV; A.Min[0] = dM; A.Vout[0] = dO; A.Mout[0] = dO + n / 2;
-    A.n[0] = n;
-    A.nl[0] = n;
-    A.blocks[0] = std::min<uint32_t>(grid_for(n / 4, 1024), ctx->partial_blocks / 2);
-    A.r = to_dev(r[0]);
-    A.skip_p1 = 1;                        // as every round but the first of a phase runs: b comes from the running claim
-    A.partials = ctx->partials;
-    A.counter = ctx->d_counter;
-    A.slot = (host_slot *) ctx->d_slot;
-    *algorithmic_bytes = 96.0 * (double) n;
-    rc = time_launches(ctx, iters, sec_per_launch, [&] {
-        A.seq = ++ctx->slot_seq;
-        ZK_LAUNCH_RAW(PC_ROUND_QUAD, 96.0 * (double) n, k_round_quad2, dim3(A.blocks[0]), dim3(ZK_BLOCK), A);
-    });
-    if (rc) return rc;
-    return wait_slot(ctx, ctx->slot_seq);
-}
-
+#include "kernel_api.hpp"
