@@ -32,6 +32,9 @@ struct msm_state {
     fr_t *sL = nullptr, *sR = nullptr; uint32_t *idxL = nullptr, *idxR = nullptr;
     fr_t *d_y = nullptr;               // 2 elements
     void *tbl_scratch = nullptr; size_t tbl_scratch_cap = 0;
+    // window tables of a FRESH generator set are built beside the proof (ensure_tables): a stream and scratch of their own
+    hipStream_t aux = nullptr; hipEvent_t aux_ev = nullptr;
+    void *win_scratch = nullptr; size_t win_scratch_cap = 0;
     // commitment fast path: digit table D[d][j] = d * g_j (d = 1..255, affine), per-row "has wide scalars" flags (+ the exception word)
     g1a_t *digit = nullptr; uint64_t digit_m = 0; bool digit_ready = false;
     uint32_t *hi_flags = nullptr, *row_list = nullptr; size_t flags_cap = 0;
@@ -67,6 +70,7 @@ struct gen_tables {
     uint32_t uses = 0;                 // times a context selected the set: the byte table is built when a set is used AGAIN
     std::mutex mtx;                    // held while a table is built
     g1a_t *tables = nullptr;           // window tables T[w][j] = 2^(8w) g_j
+    hipEvent_t win_ev = nullptr;       // set: the windows above MSM_LOW_WINDOWS are (being) written on another stream -- whoever reads them makes its stream wait (wait_windows)
     g1a_t *digit = nullptr; bool digit_ready = false;
     g1a_t *full = nullptr; bool full_ready = false, full_failed = false;
     g1a_t *t8 = nullptr; bool t8_ready = false;
@@ -111,6 +115,7 @@ static void gen_release(zk_ctx *ctx, msm_state *s) {
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     std::lock_guard<std::mutex> g(g_gen_mtx);
     if (--e->refs > 0) return;
+    if (e->win_ev) { (void) hipEventSynchronize(e->win_ev); (void) hipEventDestroy(e->win_ev); }
     for (void *p : {(void *) e->tables, (void *) e->digit, (void *) e->full, (void *) e->t8}) if (p) hipFree(p);
     g_gen_sets.erase(std::remove(g_gen_sets.begin(), g_gen_sets.end(), e), g_gen_sets.end());
     delete e;
@@ -125,7 +130,11 @@ void zk_msm_destroy(zk_ctx *ctx) {
 static void msm_destroy_one(zk_ctx *ctx) {
     if (!ctx->msm) return;
     msm_state *s = ctx->msm;
+    if (s->aux) (void) hipStreamSynchronize(s->aux);
     gen_release(ctx, s);
+    if (s->aux_ev) (void) hipEventDestroy(s->aux_ev);
+    if (s->aux) (void) hipStreamDestroy(s->aux);
+    if (s->win_scratch) (void) hipFree(s->win_scratch);
     void *bufs[] = {s->partials, s->rowsJ, s->rowsA, s->a, s->b, s->coef, s->Lrow, s->sL, s->idxL, s->d_y, s->tbl_scratch,
                     s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch, s->parts2, s->codes, s->mag, s->exc, s->masks};
     for (void *p : bufs) if (p) hipFree(p);
@@ -190,23 +199,66 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
     if (!e->tables) {
         ZK_HIP(hipMalloc((void **) &e->tables, (size_t) MSM_WINDOWS * m * sizeof(g1a_t)));
         // (a failure below must not leave the entry looking built: every context that looks the set up adopts e->tables)
+        // The windows w >= 1 (248 doublings per generator, one thread each: 7.5 ms for 4096 generators on 64 of the 1024 SIMDs) are read by the
+        // OPENING's MSMs and by rows with wide scalars only; the commitment goes through the digit table of window 0. A context on its own builds
+        // them on a second stream, beside its sumcheck phases; readers order themselves behind the set's event (wait_windows). Lanes of a batch
+        // and profiled runs build in order (a lane's launches are deferred and fused with the other lanes' builds; the class table stays whole).
+        const bool beside = !ctx->batch && !((ctx->prof_mask >> PC_MSM_TABLES) & 1u);
         auto build = [&]() -> int32_t {
             ZK_STREAM(hipMemcpyAsync(e->tables, gens, m * sizeof(g1a_t), hipMemcpyHostToDevice, ctx->stream));
             const size_t need = (size_t) (MSM_WINDOWS - 1) * m * (sizeof(g1j_t) + sizeof(fp_t));
+            if (beside) {
+                if (!s->aux) { ZK_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking)); ZK_HIP(hipEventCreateWithFlags(&s->aux_ev, hipEventDisableTiming)); }
+                if (s->win_scratch_cap < need) {
+                    ZK_HIP(hipStreamSynchronize(s->aux));
+                    if (s->win_scratch) { ZK_HIP(hipFree(s->win_scratch)); s->win_scratch = nullptr; s->win_scratch_cap = 0; }
+                    ZK_HIP(hipMalloc(&s->win_scratch, need));
+                    s->win_scratch_cap = need;
+                }
+                // windows 1 .. MSM_LOW_WINDOWS in order (1.5 ms: what rows of 2..8-byte scalars need at the commitment), the rest beside the proof
+                g1j_t *J = (g1j_t *) s->win_scratch;
+                fp_t *pre = (fp_t *) (J + (size_t) (MSM_WINDOWS - 1) * m);
+                zk_launch_d<k_window_tables, 64>(ctx, PC_MSM_TABLES, 0.0, dim3((uint32_t) ((m + 63) / 64)), e->tables, J, pre, (uint32_t) m, 1u, MSM_LOW_WINDOWS + 1u);
+                ZK_HIP(hipGetLastError());
+                ZK_HIP(hipEventCreateWithFlags(&e->win_ev, hipEventDisableTiming));
+                ZK_HIP(hipEventRecord(s->aux_ev, ctx->stream));
+                ZK_HIP(hipStreamWaitEvent(s->aux, s->aux_ev, 0));
+                call_f<k_window_tables, g1a_t *, g1j_t *, fp_t *, uint32_t, uint32_t, uint32_t> f;
+                f.args = make_pack<g1a_t *, g1j_t *, fp_t *, uint32_t, uint32_t, uint32_t>(e->tables, J + (size_t) MSM_LOW_WINDOWS * m, pre + (size_t) MSM_LOW_WINDOWS * m, (uint32_t) m,
+                                                                                         MSM_LOW_WINDOWS + 1u, (uint32_t) MSM_WINDOWS);
+                hipLaunchKernelGGL((k_run<decltype(f), 64>), dim3((uint32_t) ((m + 63) / 64)), dim3(64), 0, s->aux, f);
+                ZK_HIP(hipGetLastError());
+                ZK_HIP(hipEventRecord(e->win_ev, s->aux));
+                ZK_HIP(zk_stream_sync(ctx));      // (window 0: `gens` is the caller's buffer; other contexts read it from their own streams)
+                return ZK_OK;
+            }
             int32_t rc = regrow(ctx, &s->tbl_scratch, &s->tbl_scratch_cap, need);
             if (rc) return rc;
             g1j_t *J = (g1j_t *) s->tbl_scratch;
             fp_t *pre = (fp_t *) (J + (size_t) (MSM_WINDOWS - 1) * m);
-            zk_launch_d<k_window_tables, 64>(ctx, PC_MSM_TABLES, 0.0, dim3((uint32_t) ((m + 63) / 64)), e->tables, J, pre, (uint32_t) m);
+            zk_launch_d<k_window_tables, 64>(ctx, PC_MSM_TABLES, 0.0, dim3((uint32_t) ((m + 63) / 64)), e->tables, J, pre, (uint32_t) m, 1u, (uint32_t) MSM_WINDOWS);
             ZK_HIP(hipGetLastError());
             ZK_HIP(zk_stream_sync(ctx));      // other contexts read the tables from their own streams
             return ZK_OK;
         };
         const int32_t rc = build();
-        if (rc) { (void) zk_stream_sync(ctx); (void) hipFree(e->tables); e->tables = nullptr; return rc; }
+        if (rc) {
+            (void) zk_stream_sync(ctx);
+            if (s->aux) (void) hipStreamSynchronize(s->aux);
+            if (e->win_ev) { (void) hipEventDestroy(e->win_ev); e->win_ev = nullptr; }
+            (void) hipFree(e->tables); e->tables = nullptr;
+            return rc;
+        }
         ++g_gen_builds;
     }
     gen_adopt(s);
+    return ZK_OK;
+}
+
+// before this context's stream reads a window above MSM_LOW_WINDOWS of its generator set
+static int32_t wait_windows(zk_ctx *ctx) {
+    gen_tables *e = ctx->msm->gt;
+    if (e && e->win_ev) ZK_STREAM(hipStreamWaitEvent(ctx->stream, e->win_ev, 0));
     return ZK_OK;
 }
 
@@ -253,6 +305,7 @@ static int32_t ensure_full_table(zk_ctx *ctx) {
             e->full = nullptr;
             e->full_failed = true;             // not enough memory for the table: stay on the bit-plane path
         } else {
+            { int32_t rc = wait_windows(ctx); if (rc) return rc; }
             for (uint32_t w = 0; w < MSM_WINDOWS; ++w) {
                 int32_t rc = build_digit_table(ctx, e->full + (size_t) w * 256 * m, e->tables + (size_t) w * m, m);
                 if (rc) return rc;
@@ -325,7 +378,7 @@ static int32_t scalar_mags(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const 
 // rows independent MSMs over the cached generator tables, every window >= w_lo of every scalar; scalars are read from s->mag
 // (scalar_mags ran before). idx (optional): generator index of every column, rows `ld` apart. Results (Jacobian) in `outJ` or, for
 // at most 8 rows without outJ, as short lists that fetch_points sums on the host.
-static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32_t rows, uint32_t cols, uint32_t w_lo, g1j_t *outJ) {
+static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32_t rows, uint32_t cols, uint32_t w_lo, g1j_t *outJ, bool low_windows_only = false) {
     msm_state *s = ctx->msm;
     int32_t rc;
     const uint32_t nwin = MSM_WINDOWS - w_lo;
@@ -396,6 +449,7 @@ static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32
     cpt = std::max<uint32_t>(cpt, 1);
     const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt), nparts = chunks * wsplit;
     if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * MSM_PLANES * nparts * sizeof(g1j_t)))) return rc;
+    if (!low_windows_only && (rc = wait_windows(ctx))) return rc;      // (a window no scalar reaches is never read: k_msm_planes skips zero bytes)
     for (uint32_t r0 = 0; r0 < rows; r0 += 8191) {       // (plane, row) share gridDim.y, which is limited to 65535
         const uint32_t nr = std::min<uint32_t>(8191, rows - r0);
         zk_launch_d<k_msm_planes, MSM_BLOCK>(ctx, PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, dim3(nparts, MSM_PLANES * nr),
@@ -491,7 +545,8 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
     ZK_HIP(zk_stream_sync(ctx));
     if (flags[rows + 1] && !s->safe) return ZK_RETRY_SAFE;
     if (wide_cap && flags[rows] <= wide_cap) return ZK_OK;       // every wide row went through the virtual rows
-    for (uint32_t r = 0; r < rows; ++r) if (flags[r] & MSM_ROW_WIDE) list.push_back(r);
+    bool high = false;
+    for (uint32_t r = 0; r < rows; ++r) if (flags[r] & MSM_ROW_WIDE) { list.push_back(r); high |= (flags[r] & MSM_ROW_HIGH) != 0; }
     if (list.empty()) return ZK_OK;
     // separate pass: all wide rows when there was no byte table, the ones beyond the list otherwise (list rows are ascending on both sides)
     if (wide_cap) list.erase(list.begin(), list.begin() + wide_cap);
@@ -499,7 +554,7 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
     ZK_STREAM(hipMemcpyAsync(s->row_list, list.data(), (size_t) nl * 4, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = regrow(ctx, (void **) &s->tmpJ, &s->tmp_cap, (size_t) nl * sizeof(g1j_t)))) return rc;
     if ((rc = scalar_mags(ctx, scalars, ld, s->row_list, nl, cols))) return rc;
-    if ((rc = msm_windows(ctx, nullptr, cols, nl, cols, 1, s->tmpJ))) return rc;
+    if ((rc = msm_windows(ctx, nullptr, cols, nl, cols, 1, s->tmpJ, !high))) return rc;
     zk_launch_d<k_add_rows, 64>(ctx, PC_MSM_FINISH, 0.0, dim3((nl + 63) / 64), s->rowsJ, s->tmpJ, s->row_list, nl, (const uint32_t *) nullptr);
     ZK_HIP(hipGetLastError());
     return ZK_OK;

@@ -27,6 +27,8 @@
 #define MSM_CODE_WIDE 0x200u
 #define MSM_ROW_WIDE 1u              // row flags of k_scalar_codes
 #define MSM_ROW_NONBIT 2u
+#define MSM_ROW_HIGH 4u              // a scalar of the row reaches beyond window MSM_LOW_WINDOWS (|s| >= 2^64)
+#define MSM_LOW_WINDOWS 7u           // windows 1..7 of a fresh generator set are built in order, the rest beside the proof (hyrax.hip: ensure_tables)
 
 // ---- exceptional-case aware in-place point operations on separate coordinate registers ----
 // doubling, a = 0 (dbl-2009-l); Z == 0 stays Z == 0
@@ -121,7 +123,7 @@ __device__ __forceinline__ void g1_accumulate(fp_t &X, fp_t &Y, fp_t &Z, bool &e
 // row_flags[row] = 1 if the row holds a wide scalar (the caller then adds that row's higher windows, see k_scalar_codes_wide)
 __device__ __forceinline__ void k_scalar_codes(uint16_t *codes, uint32_t *row_flags, const fr_t *scalars, uint64_t ld, uint32_t cols) {
     const uint32_t row = blockIdx.y;
-    bool wide = false, nonbit = false;
+    bool wide = false, nonbit = false, high = false;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
         const fr_t raw = fr_load(scalars + (size_t) row * ld + c);
         uint32_t code = 0;
@@ -134,12 +136,13 @@ __device__ __forceinline__ void k_scalar_codes(uint16_t *codes, uint32_t *row_fl
             code = (s.v[0] & 0xffu) | (neg ? MSM_CODE_NEG : 0u) | (rest ? MSM_CODE_WIDE : 0u);
             wide |= rest != 0;
             nonbit |= code != 1u;
+            high |= (s.v[2] | s.v[3] | s.v[4] | s.v[5] | s.v[6] | s.v[7]) != 0;
         }
         codes[(size_t) row * cols + c] = (uint16_t) code;
     }
     // bit 0: a wide scalar in the row; bit 1: an entry other than 0 / 1 (rows without it are rows of bits: k_bit_masks, k_msm_codes)
     // (one atomic per wave, not per thread: every entry of a weight row sets the second bit)
-    const uint32_t f = (__any(wide) ? MSM_ROW_WIDE : 0u) | (__any(nonbit) ? MSM_ROW_NONBIT : 0u);
+    const uint32_t f = (__any(wide) ? MSM_ROW_WIDE : 0u) | (__any(nonbit) ? MSM_ROW_NONBIT : 0u) | (__any(high) ? MSM_ROW_HIGH : 0u);
     if (f && (threadIdx.x & 63) == 0) atomicOr(row_flags + row, f);
 }
 
@@ -515,28 +518,28 @@ __device__ __forceinline__ void k_add_rows(g1j_t *rows, const g1j_t *extra, cons
 // ------------------------------------------------------------------------------------------------
 // tables
 // ------------------------------------------------------------------------------------------------
-// T[0][j] = g_j is already in place; fills T[w][j] = 2^(8w) g_j for w >= 1, converted to affine with
-// one field inversion per generator (Montgomery's trick over the 31 Jacobian points of that thread).
-__device__ __forceinline__ void k_window_tables(g1a_t *T, g1j_t *J, fp_t *pre, uint32_t m) {
+// T[w0 - 1][j] is in place (T[0][j] = g_j); fills T[w][j] = 2^(8w) g_j for w0 <= w < w1, converted to affine with
+// one field inversion per generator (Montgomery's trick over the Jacobian points of that thread). J, pre: (w1 - w0) * m entries.
+__device__ __forceinline__ void k_window_tables(g1a_t *T, g1j_t *J, fp_t *pre, uint32_t m, uint32_t w0, uint32_t w1) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
-    const g1a_t g = T[j];
+    const g1a_t g = T[(size_t) (w0 - 1) * m + j];
     if (g1a_is_inf(g)) {
-        for (int w = 1; w < MSM_WINDOWS; ++w) T[(size_t) w * m + j] = g;
+        for (uint32_t w = w0; w < w1; ++w) T[(size_t) w * m + j] = g;
         return;
     }
     fp_t X = g.x, Y = g.y, Z = fp_one();
     fp_t run = fp_one();
-    for (int w = 1; w < MSM_WINDOWS; ++w) {
+    for (uint32_t w = w0; w < w1; ++w) {
         for (int d = 0; d < 8; ++d) g1_dbl_ip(X, Y, Z);
-        g1j_store(J + (size_t) (w - 1) * m + j, X, Y, Z, false);
-        pre[(size_t) (w - 1) * m + j] = run;
+        g1j_store(J + (size_t) (w - w0) * m + j, X, Y, Z, false);
+        pre[(size_t) (w - w0) * m + j] = run;
         run = fp_mul(run, Z);
     }
     fp_t inv = fp_inv(run);
-    for (int w = MSM_WINDOWS - 1; w >= 1; --w) {
-        const g1j_t Q = J[(size_t) (w - 1) * m + j];
-        const fp_t zi = fp_mul(inv, pre[(size_t) (w - 1) * m + j]);
+    for (uint32_t w = w1 - 1; w >= w0; --w) {
+        const g1j_t Q = J[(size_t) (w - w0) * m + j];
+        const fp_t zi = fp_mul(inv, pre[(size_t) (w - w0) * m + j]);
         inv = fp_mul(inv, Q.Z);
         const fp_t zi2 = fp_sqr(zi);
         g1a_t a;
