@@ -271,6 +271,8 @@ int32_t zk_k_phi_table(zk_ctx *ctx, uint64_t *out, const uint64_t *rx, const uin
 int32_t zk_k_round_quadratic(zk_ctx *ctx, uint64_t *V, uint64_t *M, uint64_t n, const uint64_t r[4], int32_t first,
                              uint64_t out_abc[12], uint64_t *n_out);
 int32_t zk_k_msm(zk_ctx *ctx, uint64_t out[12], const uint64_t *scalars, const uint64_t *bases, uint64_t n);
+/* out[i] = in[i]^-1 in the base field Fp (6 words each, Montgomery form, R = 2^384; the inverse of 0 is 0): the inversion the table kernels use */
+int32_t zk_k_fp_inv(zk_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t n);
 /* the commitInput data path on caller data: `rows` Pedersen commitments of `cols` scalars each over `cols` bases */
 int32_t zk_k_commit_rows(zk_ctx *ctx, uint64_t *out, const uint64_t *scalars, const uint64_t *bases, uint64_t rows, uint64_t cols);
 /* device-resident micro-benchmarks: seconds per launch, averaged over `iters` launches with HIP events */

@@ -108,6 +108,38 @@ def test_msm_matches_cpu_pippenger(hip, oracle, n, kind):
     assert np.array_equal(hip.msm(sc2, bases), oracle.msm(sc2, bases))
 
 
+def test_fp_inverse_binary_gcd_against_python(hip):
+    """the table kernels' field inversion (binary extended Euclid on the Montgomery representation, g1_dev.cuh: fp_inv) against pow(a, -1, p):
+    edge values (0 -> 0, 1, p - 1, 2, powers of two, values just below p and around 2^380) and random elements"""
+    P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+    RR = 1 << 384
+    rng = np.random.default_rng(381)
+    vals = [0, 1, 2, 3, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 1 << 380, (1 << 380) - 1, (1 << 381) % P, P - (1 << 200)]
+    vals += [1 << k for k in range(0, 380, 19)]
+    vals += [int.from_bytes(rng.bytes(48), "little") % P for _ in range(700)]
+
+    def pack(xs):
+        a = np.zeros((len(xs), 6), dtype=np.uint64)
+        for i, x in enumerate(xs):
+            m = x * RR % P
+            for k in range(6):
+                a[i, k] = (m >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+        return a
+
+    got = hip.fp_inv(pack(vals))
+    want = pack([pow(v, -1, P) if v else 0 for v in vals])
+    assert np.array_equal(got, want)
+    # ... and on the Montgomery representation's own edge: elements whose REPRESENTATION aR mod p is 1, 2, p - 1 (the algorithm runs on it)
+    reps = [1, 2, P - 1, P - 2, 1 << 380]
+    a = np.zeros((len(reps), 6), dtype=np.uint64)
+    for i, m in enumerate(reps):
+        for k in range(6):
+            a[i, k] = (m >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    inv_r = pow(RR, -1, P)
+    want2 = pack([pow(m * inv_r % P, -1, P) for m in reps])
+    assert np.array_equal(hip.fp_inv(a), want2)
+
+
 def test_commit_rows_digit_table_and_high_byte_rows(hip, oracle):
     """the commitInput data path: signed-byte witnesses through the digit table, rows with larger scalars through the
     bit-plane path for their remaining windows; every row against the CPU Pippenger"""

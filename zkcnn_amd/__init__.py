@@ -161,6 +161,13 @@ class HipContext:
         self._check(self.lib.zk_k_msm(self.ctx, u64p(out), u64p(scalars), u64p(bases), ctypes.c_uint64(scalars.shape[0])), "zk_k_msm")
         return out
 
+    def fp_inv(self, a):
+        """a: (n, 6) uint64 base-field elements in Montgomery form; element-wise inverse (0 -> 0)"""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        out = np.zeros_like(a)
+        self._check(self.lib.zk_k_fp_inv(self.ctx, u64p(out), u64p(a), ctypes.c_uint64(a.shape[0])), "zk_k_fp_inv")
+        return out
+
     def witness_ntt(self, src, logn, inverse, count):
         """count transforms of length 2^logn (forward: half-length inputs zero padded; inverse: first half kept)"""
         length = 1 << logn

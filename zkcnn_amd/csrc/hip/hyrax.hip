@@ -836,6 +836,20 @@ extern "C" int32_t zk_k_msm(zk_ctx *ctx, uint64_t out[12], const uint64_t *scala
     });
 }
 
+extern "C" int32_t zk_k_fp_inv(zk_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t n) {
+    if (!ctx || !out || !in || !n || n > (1u << 20)) return ZK_ERR_ARG;
+    ZK_HIP(hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = zk_scratch(ctx, 2 * n * sizeof(fp_t)))) return rc;
+    fp_t *d_in = (fp_t *) ctx->scratch.p, *d_out = d_in + n;
+    ZK_STREAM(hipMemcpyAsync(d_in, in, n * sizeof(fp_t), hipMemcpyHostToDevice, ctx->stream));
+    zk_launch_d<k_fp_inv, 64>(ctx, PC_MSM_FINISH, 0.0, dim3((uint32_t) ((n + 63) / 64)), d_out, (const fp_t *) d_in, (uint32_t) n);
+    ZK_HIP(hipGetLastError());
+    ZK_STREAM(hipMemcpyAsync(out, d_out, n * sizeof(fp_t), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(zk_stream_sync(ctx));
+    return ZK_OK;
+}
+
 // rows x cols row commitments over `cols` arbitrary bases: the commitInput data path on caller-supplied data
 extern "C" int32_t zk_k_commit_rows(zk_ctx *ctx, uint64_t *out, const uint64_t *scalars, const uint64_t *bases, uint64_t rows,
                                     uint64_t cols) {

@@ -549,6 +549,12 @@ __device__ __forceinline__ void k_window_tables(g1a_t *T, g1j_t *J, fp_t *pre, u
     }
 }
 
+// out[i] = in[i]^-1 (kernel-level entry point of the parity tests)
+__device__ __forceinline__ void k_fp_inv(fp_t *out, const fp_t *in, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fp_inv(in[i]);
+}
+
 // digit table by levels: D[1] = g, D[d] = 2 D[d/2] (+ g if d is odd); every entry of a level is independent
 __device__ __forceinline__ void k_digit_level(g1j_t *J, const g1a_t *G, uint32_t m, uint32_t level) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
