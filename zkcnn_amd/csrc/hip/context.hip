@@ -172,6 +172,10 @@ extern "C" int32_t zk_fs_attach(zk_ctx *ctx, const uint32_t *state, const uint64
 }
 extern "C" int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries) {
     if (!ctx || log_entries > 8) return ZK_ERR_ARG;
+    if (log_entries >= 0) {                 // (experiments: another hand-over size, 1..8)
+        const char *e = std::getenv("ZKCNN_HOST_TAIL_LOG");
+        if (e && std::atoi(e) >= 1 && std::atoi(e) <= 8) log_entries = std::atoi(e);
+    }
     ctx->host_tail_log = log_entries < 0 ? -1 : log_entries;
     return ZK_OK;
 }

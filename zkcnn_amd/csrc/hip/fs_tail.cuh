@@ -691,16 +691,19 @@ __global__ void __launch_bounds__(ZK_BLOCK) k_mid(mid_args a) {
 
 // Hybrid tail: the live tables of a phase (at most 256 entries each) to mapped host memory in one small launch; seq is written last.
 struct export_args { const fr_t *V[2], *M[2]; uint32_t n[2]; export_out *out; unsigned long long seq; };
-__global__ void __launch_bounds__(512) k_export_tables(export_args a) {
-    const uint32_t b = threadIdx.x >> 8, i = threadIdx.x & 255;
-    if (i < a.n[b]) {
-        fr_store(&a.out->V[b][i], fr_load(a.V[b] + i));
-        fr_store(&a.out->M[b][i], fr_load(a.M[b] + i));
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
+struct k_export_f {                    // (a functor: the lanes of a batch export in ONE launch, launch.cuh)
+    export_args a;
+    __device__ __forceinline__ void operator()() const {
+        const uint32_t b = threadIdx.x >> 8, i = threadIdx.x & 255;
+        if (i < a.n[b]) {
+            fr_store(&a.out->V[b][i], fr_load(a.V[b] + i));
+            fr_store(&a.out->M[b][i], fr_load(a.M[b] + i));
+        }
         __threadfence_system();
-        *((volatile unsigned long long *) &a.out->seq) = a.seq;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            *((volatile unsigned long long *) &a.out->seq) = a.seq;
+        }
     }
-}
+};

@@ -355,7 +355,9 @@ static int32_t host_tail_begin(zk_ctx *ctx) {
     }
     A.out = (export_out *) ctx->d_tail;
     A.seq = ++ctx->tail_seq;
-    ZK_LAUNCH(PC_FOLD, 0.0, k_export_tables, dim3(1), dim3(512), A);
+    k_export_f f;
+    f.a = A;
+    zk_launch_f<k_export_f, 512>(ctx, PC_FOLD, 0.0, dim3(1), f);
     ZK_HIP(hipGetLastError());
     const export_out *o = (const export_out *) ctx->h_tail;
     if (ctx->batch) { int32_t rc = zk_batch_sync_point(ctx); if (rc) return rc; }
