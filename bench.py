@@ -572,6 +572,7 @@ def main():
         if os.environ.get("ZKCNN_BENCH_NOEVENTS"):
             sess.profile(None)
         fusion0 = batches[0].stats()
+        host_rounds0 = sess.host_tail_rounds()
 
     stage("timed steps")
     # ---- timed region: `steps` steps, a step = K proofs in flight on this GPU (B batches of LANES lanes; or one per stream) ----
@@ -638,6 +639,10 @@ def main():
                   "fused_launches_per_batch_proof": round((f1["fused_launches"] - fusion0["fused_launches"]) / args.steps, 1),
                   "lanes_per_fused_launch": round((f1["lane_launches"] - fusion0["lane_launches"]) / max(f1["fused_launches"] - fusion0["fused_launches"], 1), 2),
                   "rounds_per_proof": firsts[0].n_rounds,
+                  "rounds_on_host_per_proof": round((sess.host_tail_rounds() - host_rounds0) / args.steps, 1),
+                  "host_tail": "a lane hands a phase's tables to the host once they hold <= 32 entries (2 KB): the phase's last 5 rounds are ~150 multiplications on the batch's "
+                               "host thread instead of 5 launches (sumcheck.hip: policy::LANE_TAIL_LOG; same field elements, transcripts byte-identical); "
+                               "proofs_per_s_every_round_on_gpu is the same run without it (ZKCNN_MODE_GPU_TAIL)",
                   "note": "batch 0 over the timed steps: every deferred launch of a batch proof is ONE launch over all its lanes"}
     last_proofs = [tr for _, tr in batch]          # the last timed proof of every stream, checked after the clock stops
     gather_wait_s = 0.0
@@ -771,6 +776,36 @@ def main():
                          "program_upload_and_scan_s": round(t_scan, 2)}
         except Exception as e:      # noqa: BLE001 - the headline does not depend on this
             new_image = {"new_image_error": str(e)}
+    # ---- companion: the timed configuration WITHOUT the lanes' hybrid tail: every round of every phase is a kernel launch (round 4's first shape) ----
+    gpu_tail = {}
+    if rank == 0 and world == 1 and not args.no_companions and LANES > 1:
+        try:
+            gt_steps = max(2, min(args.steps, 6))
+            for x in batches:            # (untimed: first use of the mode)
+                x.prove(seeds=[0x5EED5000] * LANES, mode=drive | zkcnn_amd.MODE_GPU_TAIL, want_transcript=False)
+            torch.cuda.synchronize()
+            t_gt = time.perf_counter()
+            errs_g = []
+            last_g = [None] * B
+
+            def run_g(j):
+                try:
+                    for k in range(gt_steps):
+                        last_g[j] = batches[j].prove(seeds=[0x5EED5100 + k] * LANES, mode=drive | zkcnn_amd.MODE_GPU_TAIL, want_transcript=True)
+                except BaseException as e:      # noqa: BLE001
+                    errs_g.append(e)
+            th_g = [threading.Thread(target=run_g, args=(j,)) for j in range(B)]
+            [t.start() for t in th_g]
+            [t.join() for t in th_g]
+            torch.cuda.synchronize()
+            t_gt = time.perf_counter() - t_gt
+            if errs_g:
+                raise errs_g[0]
+            # the two configurations produce the same bytes: lane 0 of batch 0 against a proof of the default configuration under the same seed
+            same = batches[0].prove(seeds=[0x5EED5100 + gt_steps - 1] * LANES, mode=drive, want_transcript=True)[0][1] == last_g[0][0][1]
+            gpu_tail = {"proofs_per_s_every_round_on_gpu": round(K * gt_steps / t_gt, 3), "every_round_on_gpu_transcript_identical": bool(same)}
+        except Exception as e:      # noqa: BLE001 - the headline does not depend on this
+            gpu_tail = {"every_round_on_gpu_error": str(e)}
     # ---- companion in the REFERENCE's semantics (reference src/verifier.cpp:119-128: new random generators for every proof; the inner-product
     # argument run down to length 1): nothing pre-built survives from proof to proof -- window / digit tables are built inside the clock ----
     ref_mode = {}
@@ -869,6 +904,7 @@ def main():
     extras = dict(new_image)
     extras.update(indep)
     extras.update(ref_mode)
+    extras.update(gpu_tail)
     if fusion:
         extras["fusion"] = fusion
     leave(build_out, "new-picture companion")

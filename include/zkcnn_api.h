@@ -42,6 +42,8 @@ typedef struct {
                                               rounds (Fiat-Shamir) -- A/B and parity of both */
 #define ZKCNN_MODE_HOST_TAIL (1u << 26)    /* hybrid tail (off by default): once a phase's tables have <= 64 entries they travel to the host and its last
                                             ~6 rounds run there (a few hundred host multiplications instead of six latency-bound launches) */
+#define ZKCNN_MODE_GPU_TAIL (1u << 28)     /* lanes of a lock-step batch: no hybrid tail either (their default: tables of <= 32 entries finish on the host,
+                                            * include/zkcnn_hip.h: zk_set_host_tail) -- every round of every phase is a kernel launch */
 #define ZKCNN_MODE_FS_DEVICE (1u << 27)    /* with ZKCNN_MODE_FIAT_SHAMIR: the GPU derives the challenges of the small and mid-size rounds itself
                                             (BLAKE2s chain on the device) instead of trading polynomials and challenges with the
                                             host, which hashes by default. Same transcript; slower since round 3 (the resident kernels' mailbox
@@ -140,6 +142,8 @@ int32_t zkcnn_session_row(void *session, char *buf, uint64_t cap);
 int32_t zkcnn_session_conv_paths(void *session, int32_t force_field, uint64_t out[3]);
 /* Product library only: sumcheck rounds / phases the GPU has run by itself in Fiat-Shamir mode so far (include/zkcnn_hip.h: zk_fs_attach) */
 int32_t zkcnn_session_fs_stats(void *session, uint64_t *rounds, uint64_t *phases);
+/* Product library only: sumcheck rounds the hybrid tail has run on the host so far (include/zkcnn_hip.h: zk_set_host_tail) */
+int32_t zkcnn_session_host_tail_rounds(void *session, uint64_t *rounds);
 
 /* Product library only: how many direct-convolution layers of the session's circuit run the factored gate sums (include/zkcnn_hip.h: zk_conv_hint) */
 int32_t zkcnn_session_structured_layers(void *session);

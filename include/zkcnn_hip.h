@@ -132,10 +132,13 @@ int32_t zk_witness_dotprod(zk_ctx *ctx, uint64_t *out, uint64_t n_out, const uin
  * one kernel as soon as the live tables have at most 2^12 entries, answer the following calls from that record and fail with
  * ZK_ERR_STATE if a challenge passed in differs from the one the kernel derived. ---- */
 int32_t zk_fs_attach(zk_ctx *ctx, const uint32_t *state, const uint64_t *pending);
-/* Hybrid tail (optional, off by default): tables of at most 2^log_entries entries (log_entries <= 8) are copied to the host when a phase
- * reaches them and its last rounds run there -- O(2^log_entries) host multiplications per round instead of a latency-bound launch and
- * hand-over. Same field elements either way. log_entries < 0 switches it off. */
+/* Hybrid tail: tables of at most 2^log_entries entries (log_entries <= 8) are copied to the host when a phase reaches them and its last
+ * rounds run there -- O(2^log_entries) host multiplications per round instead of a latency-bound launch and hand-over. Same field elements
+ * either way. log_entries = -1 (the state of a new context): the library's default -- off for a context on its own (its small rounds run in
+ * the resident kernels), 2^5 for a lane of a lock-step batch; log_entries <= -2: off, every round of every phase is a kernel. */
 int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries);
+/* rounds the hybrid tail has run on the host since the context was created (bench: rounds_on_host_per_proof) */
+int32_t zk_host_tail_stats(zk_ctx *ctx, uint64_t *rounds);
 /* Persistent rounds of the interactive protocol (on by default): once the live tables of a phase hold at most 1024 quads, ONE resident
  * single-workgroup kernel runs all remaining rounds of the phase; zk_sumcheck_update1/2 and zk_sumcheck_liu_update then exchange a round
  * polynomial and the verifier's next challenge with it through two mapped host mailboxes instead of launching a kernel per round

@@ -87,19 +87,23 @@ def test_every_lane_of_a_batch_equals_the_oracle(built, model, pic, pp, k):
             s.close()
 
 
-@pytest.mark.parametrize("mode", [0, M.MODE_FULL_IPA, M.MODE_FIAT_SHAMIR, M.MODE_ZK, M.MODE_ZK | M.MODE_FIAT_SHAMIR, REUSE | M.MODE_HOST_TAIL,
+@pytest.mark.parametrize("mode", [0, M.MODE_FULL_IPA, M.MODE_FIAT_SHAMIR, M.MODE_ZK, M.MODE_ZK | M.MODE_FIAT_SHAMIR, REUSE | M.MODE_HOST_TAIL, REUSE | M.MODE_GPU_TAIL,
                                   REUSE | M.MODE_CROSS_PRED, M.MODE_FIAT_SHAMIR | M.MODE_FS_DEVICE])
 def test_batch_in_every_protocol_mode(built, mode):
     """fresh generators per lane (drawn by each lane's verifier from its own seeded stream), the argument down to length 1, challenges hashed
-    from the transcript, masked rounds + blinded commitments (private coins per lane), the hybrid host tail, host + GPU predicates side by side,
+    from the transcript, masked rounds + blinded commitments (private coins per lane), the hybrid host tail at 64 entries / at the lanes' default 32 (every other mode) / not at
+    all (MODE_GPU_TAIL: every round a fused launch), host + GPU predicates side by side,
     and the device-side Fiat-Shamir chain (which a lane does not take: its driver hashes -- same bytes)"""
     model, pic, pp, k = "custom:C2:3:0:f C3:3:1:f M C2:3:1:s A F5 F3", (10, 10, 2), 2, 3
     ss, pics, stmt = _lanes(model, pic, pp, k)
     try:
         seeds = [0x5EED0C00 + 5 * i for i in range(k)]
-        want = [_oracle(model, pic, pp, stmt, pics[i], seeds[i], mode & ~(M.MODE_HOST_TAIL | M.MODE_CROSS_PRED | M.MODE_FS_DEVICE)) for i in range(k)]
+        want = [_oracle(model, pic, pp, stmt, pics[i], seeds[i], mode & ~(M.MODE_HOST_TAIL | M.MODE_GPU_TAIL | M.MODE_CROSS_PRED | M.MODE_FS_DEVICE)) for i in range(k)]
+        on_host = ss[0].host_tail_rounds()
         with M.BatchSession(ss) as B:
             got = B.prove(seeds=seeds, mode=mode)
+        # a lane's small rounds run on the host unless the mode says otherwise
+        assert (ss[0].host_tail_rounds() > on_host) == (not mode & M.MODE_GPU_TAIL)
         for i in range(k):
             assert got[i][0].accepted == 1, f"lane {i}: {got[i][0].message.decode()}"
             assert got[i][1] == want[i][1], f"lane {i}: transcript differs from the CPU oracle's"

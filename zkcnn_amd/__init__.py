@@ -22,6 +22,7 @@ MODE_VERIFY, MODE_DRIVE_ONLY, MODE_REUSE_GENS, MODE_TAMPER, MODE_HOST_PRED, MODE
 MODE_ZK = 1 << 24
 MODE_HOST_ROUNDS = 1 << 25
 MODE_HOST_TAIL = 1 << 26
+MODE_GPU_TAIL = 1 << 28       # lanes of a batch: every round on the GPU (no hybrid tail)
 MODE_FS_DEVICE = 1 << 27      # with MODE_FIAT_SHAMIR: BLAKE2s chain on the GPU (device-side rounds) instead of host-derived challenges over the resident kernels
 
 
@@ -444,6 +445,13 @@ class Session(_SessionBase):
         rc = self.lib.zkcnn_session_profile(ctypes.c_void_p(self.h), ctypes.c_uint32(mask))
         if rc != 0:
             raise RuntimeError("zkcnn_session_profile failed")
+
+    def host_tail_rounds(self):
+        """sumcheck rounds the hybrid tail has run on the host on this session so far (lanes of a batch: a phase's tables of <= 32 entries)"""
+        r = ctypes.c_uint64()
+        if self.lib.zkcnn_session_host_tail_rounds(ctypes.c_void_p(self.h), ctypes.byref(r)) != 0:
+            raise RuntimeError("zkcnn_session_host_tail_rounds failed")
+        return r.value
 
     def fs_stats(self):
         """(rounds, phases) the GPU has run by itself in Fiat-Shamir mode on this session so far"""

@@ -172,11 +172,7 @@ extern "C" int32_t zk_fs_attach(zk_ctx *ctx, const uint32_t *state, const uint64
 }
 extern "C" int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries) {
     if (!ctx || log_entries > 8) return ZK_ERR_ARG;
-    if (log_entries >= 0) {                 // (experiments: another hand-over size, 1..8)
-        const char *e = std::getenv("ZKCNN_HOST_TAIL_LOG");
-        if (e && std::atoi(e) >= 1 && std::atoi(e) <= 8) log_entries = std::atoi(e);
-    }
-    ctx->host_tail_log = log_entries < 0 ? -1 : log_entries;
+    ctx->host_tail_log = log_entries < -1 ? -2 : log_entries;          // -1: the default (off; 2^5 for a lane of a batch), -2: off
     return ZK_OK;
 }
 static std::atomic<int> g_active_proofs[64];
@@ -215,6 +211,11 @@ extern "C" int32_t zk_set_live_rounds(zk_ctx *ctx, int32_t on) {
     if (!ctx) return ZK_ERR_ARG;
     if (ctx->live_active) { int32_t rc = zk_live_abort(ctx); if (rc) return rc; }
     ctx->live_rounds = on != 0;
+    return ZK_OK;
+}
+extern "C" int32_t zk_host_tail_stats(zk_ctx *ctx, uint64_t *rounds) {
+    if (!ctx || !rounds) return ZK_ERR_ARG;
+    *rounds = ctx->host_tail_rounds_total;
     return ZK_OK;
 }
 extern "C" int32_t zk_fs_stats(zk_ctx *ctx, uint64_t *rounds, uint64_t *phases) {

@@ -212,7 +212,8 @@ struct zk_ctx {
     unsigned long long tail_seq = 0;
     uint64_t tail_rounds_total = 0, tail_phases_total = 0;
     // hybrid tail (zk_set_host_tail): once the live tables of a phase have at most 2^host_tail_log entries they travel to the host (a few KB)
-    // and the remaining rounds -- a few hundred multiplications each -- run there; -1 = off (every round is a kernel)
+    // and the remaining rounds -- a few hundred multiplications each -- run there; -1 = the default (off; on for a lane of a batch: sumcheck.hip,
+    // policy::LANE_TAIL_LOG), -2 = off (every round is a kernel)
     int host_tail_log = -1;
     bool host_tail_active = false;
     std::vector<HFr> ht_V[2], ht_M[2];

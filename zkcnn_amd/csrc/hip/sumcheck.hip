@@ -35,6 +35,15 @@ constexpr uint64_t MID_MAX_QUADS = 65536;
 // behind the collapse read whole tables); and Y's fold behind the prefix becomes a streaming launch of its own from 2^DOT_STREAM_LOG pairs on (4 TB/s
 // against ~2 inside the round kernel: DESIGN.md 4i)
 constexpr int DOT_FILL_LOG = 20, DOT_STREAM_LOG = 17;
+// a LANE of a lock-step batch hands a phase's tables to the host once they hold at most 2^LANE_TAIL_LOG entries (zk_set_host_tail's default for lanes): the
+// phase's last five rounds are ~150 multiplications on the lane's host thread instead of five fused launches -- 44% of a vgg11 proof's rounds by count,
+// 3e-5 of its products. 4 x 8 lanes on one box: 135 proofs/s with every round a launch, 139-143 / 144 / 144-147 / 144-147 with 2^3 / 2^4 / 2^5 / 2^6.
+constexpr int LANE_TAIL_LOG = 5;
+}
+// the hand-over size of the hybrid tail in force for this context (-1: none)
+static inline int host_tail_log(const zk_ctx *ctx) {
+    if (ctx->host_tail_log >= 0) return ctx->host_tail_log;
+    return ctx->host_tail_log == -1 && ctx->batch ? policy::LANE_TAIL_LOG : -1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -908,9 +917,10 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
 static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]) {
     static const bool seg_timing = getenv("ZKCNN_TIMING") != nullptr;
     // the tail paths start from add_term: it must be there before they are considered (the plain round below picks it up behind its launch)
-    if (ctx->add_pending && (ctx->host_tail_log >= 0 || ctx->fs_state)) { int32_t rc0 = resolve_add_term(ctx); if (rc0) return rc0; }
-    if (ctx->host_tail_log >= 0 && !ctx->host_tail_active && !ctx->tail_active && ctx->phase_rounds > ctx->round &&
-        std::max(ctx->tp[0].len, ctx->tp[1].len) <= (1ull << ctx->host_tail_log) && ctx->tp[0].len + ctx->tp[1].len > 0) {
+    const int ht_log = host_tail_log(ctx);
+    if (ctx->add_pending && (ht_log >= 0 || ctx->fs_state)) { int32_t rc0 = resolve_add_term(ctx); if (rc0) return rc0; }
+    if (ht_log >= 0 && !ctx->host_tail_active && !ctx->tail_active && ctx->phase_rounds > ctx->round &&
+        std::max(ctx->tp[0].len, ctx->tp[1].len) <= (1ull << ht_log) && ctx->tp[0].len + ctx->tp[1].len > 0) {
         int32_t rc = host_tail_begin(ctx);
         if (rc) return rc;
     }
@@ -921,7 +931,7 @@ static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, ui
     // quads of this round over both pairs (a first round works on pairs, not quads)
     const uint64_t round_quads = ctx->round == 0 ? (ctx->tp[0].len + ctx->tp[1].len) / 2 : (ctx->tp[0].len + ctx->tp[1].len) / 4;
     const bool in_phase = !ctx->live_active && !ctx->tail_active && ctx->phase_rounds > ctx->round && ctx->tp[0].len + ctx->tp[1].len > 0;
-    const bool resident_ok = ctx->live_rounds && ctx->live_now && !ctx->batch && !ctx->phase_no_live && ctx->host_tail_log < 0 && in_phase &&
+    const bool resident_ok = ctx->live_rounds && ctx->live_now && !ctx->batch && !ctx->phase_no_live && ht_log < 0 && in_phase &&
                              (ctx->counted_active || zk_contexts_on_device(ctx->device) == 1);     // (outside a proof's bracket: only for the device's one context)
     // The middle of a phase (more quads than the single-workgroup kernel takes, tables of at most 2^18 entries): a SEGMENT of rounds in one
     // resident multi-workgroup kernel (k_mid), as long as no table collapses or reaches its last pair. Returns the segment's length (0: none).

@@ -393,6 +393,12 @@ int32_t zkcnn_session_fs_stats(void *session, uint64_t *rounds, uint64_t *phases
     return 0;
 }
 
+int32_t zkcnn_session_host_tail_rounds(void *session, uint64_t *rounds) {
+    if (!session || !rounds) return -1;
+    *rounds = ((gpuSession *) session)->p.hostTailRounds();
+    return 0;
+}
+
 int32_t zkcnn_session_structured_layers(void *session) {
     if (!session) return -1;
     return ((gpuSession *) session)->p.structuredLayers();

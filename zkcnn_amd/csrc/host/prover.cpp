@@ -60,6 +60,11 @@ void prover::setLiveRounds(bool on) {
 void prover::setHostTail(int log_entries) {
     if (ctx) check(zk_set_host_tail(ctx, log_entries), "zk_set_host_tail");
 }
+uint64_t prover::hostTailRounds() const {
+    uint64_t r = 0;
+    if (ctx) (void) zk_host_tail_stats(ctx, &r);
+    return r;
+}
 void prover::tailStats(uint64_t &rounds, uint64_t &phases) const {
     rounds = phases = 0;
     if (ctx) zk_fs_stats(ctx, &rounds, &phases);

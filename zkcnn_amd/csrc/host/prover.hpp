@@ -73,7 +73,8 @@ public:
     // every phase by itself (include/zkcnn_hip.h: zk_fs_attach). NULL, NULL detaches.
     void attachFiatShamir(const uint32_t *state, const uint64_t *pending);
     void tailStats(uint64_t &rounds, uint64_t &phases) const;
-    void setHostTail(int log_entries);          // hybrid tail (include/zkcnn_hip.h: zk_set_host_tail); < 0 = off
+    void setHostTail(int log_entries);          // hybrid tail (include/zkcnn_hip.h: zk_set_host_tail); -1 = the library's default, -2 = off
+    uint64_t hostTailRounds() const;            // rounds it has run on the host so far
     void proofBegin();                          // bracket of one proof (include/zkcnn_hip.h: zk_proof_begin / zk_proof_end)
     void proofEnd();
     void setLiveRounds(bool on);                // resident round kernel of the interactive protocol (include/zkcnn_hip.h: zk_set_live_rounds)

@@ -99,7 +99,8 @@ struct sessionT {
         v.zk = zk;
         // ZKCNN_MODE_HOST_ROUNDS: every sumcheck round is a kernel launch driven from here (no resident round kernel, no device-side Fiat-Shamir rounds)
         setLiveRounds(p, !(mode & ZKCNN_MODE_HOST_ROUNDS));
-        setHostTail(p, (mode & ZKCNN_MODE_HOST_TAIL) ? 6 : -1);      // hybrid tail: tables of <= 64 entries finish their phase on the host
+        // hybrid tail: tables of <= 64 entries finish their phase on the host; otherwise the library's default (lanes of a batch: <= 32 entries) or none at all
+        setHostTail(p, (mode & ZKCNN_MODE_HOST_TAIL) ? 6 : (mode & ZKCNN_MODE_GPU_TAIL) ? -2 : -1);
         const zkff::publicGenerators *pg = nullptr;
         if (public_gens) {
             pg = &zkff::publicGeneratorSet(n_sqrt);
