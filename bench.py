@@ -149,8 +149,15 @@ def pmc_child(workload):
 HOST_BYTES_PER_SESSION = 6e9      # a vgg11 session holds 2.7 GB on the host, 4.3 GB at its peak while it is built (host_peak_rss_gb_while_building)
 
 
-def streams_that_fit(available_bytes, world, asked):
-    """sessions per rank the host's memory allows: every rank of the node builds its sessions side by side on the same host"""
+HOST_BYTES_PER_CLONE = 0.25e9     # a clone holds no circuit on the host: buffers of its picture, its transcript, its verifier's state (measured 0.03-0.1 GB)
+
+
+def streams_that_fit(available_bytes, world, asked, clones=False):
+    """sessions per rank the host's memory allows: every rank of the node builds its sessions side by side on the same host.
+    clones: one full session per rank, the others are clones of it (lock-step batches)"""
+    if clones:
+        per_rank = available_bytes / max(world, 1) - HOST_BYTES_PER_SESSION
+        return max(1, min(int(asked), 1 + int(max(per_rank, 0) / HOST_BYTES_PER_CLONE)))
     return max(1, min(int(asked), int(available_bytes / (HOST_BYTES_PER_SESSION * max(world, 1)))))
 
 
@@ -258,7 +265,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="vgg11", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=None, help="proofs in flight per GPU (default: 4 x --lanes; with --lanes 1: 8)")
+    ap.add_argument("--streams", type=int, default=None, help="proofs in flight per GPU (default: 7 x --lanes, i.e. 7 lock-step batches: 166 GB of the 288 GB of HBM for vgg11; 4 / 6 / 7 batches measured 147.6 / 148.3 / 151 proofs/s; with --lanes 1: 8)")
     ap.add_argument("--lanes", type=int, default=8, help="lanes of a lock-step batch: that many proofs share ONE host thread, ONE HIP stream and ONE kernel launch per round "
                                                           "(zkcnn_batch_*); --streams / --lanes batches per GPU. 1 = every proof its own thread and stream (the round-3 shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -315,10 +322,10 @@ def main():
 
     model, pic, pp = WORKLOADS[args.workload]
     LANES = max(1, min(args.lanes, 8))
-    K = max(1, args.streams if args.streams else (4 * LANES if LANES > 1 else 8))
+    K = max(1, args.streams if args.streams else (7 * LANES if LANES > 1 else 8))
     try:                                # do not overcommit a small node
         import psutil
-        K_ram = streams_that_fit(psutil.virtual_memory().available, world, K)
+        K_ram = streams_that_fit(psutil.virtual_memory().available, world, K, clones=LANES > 1)
         if K_ram < K:
             print(f"[bench] host memory allows {K_ram} sessions per rank, not the {K} asked for", file=sys.stderr)
             K = K_ram

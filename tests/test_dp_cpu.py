@@ -233,6 +233,8 @@ def test_session_count_respects_host_memory():
     import bench
     k_fit = bench.streams_that_fit
     assert k_fit(2e12, 8, 8) == 8 and k_fit(256e9, 8, 8) == 5 and k_fit(40e9, 8, 8) == 1 and k_fit(40e9, 1, 8) == 6
+    # lock-step batches: one full session per rank, the other lanes are clones (no host circuit): 8 ranks x 56 fit 256 GB, not 56 GB
+    assert k_fit(256e9, 8, 56, clones=True) == 56 and k_fit(56e9, 8, 56, clones=True) == 5 and k_fit(40e9, 8, 56, clones=True) == 1
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
