@@ -358,13 +358,19 @@ def main():
                 f.write(json.dumps(out))
             os.replace(result_file + ".tmp", result_file)
 
+    # at most this many sessions prove INDEPENDENTLY at a time (set-up, warm-up: every session on its own stream): the timed region drives 7 batches
+    # from 7 threads, and 56 threads launching side by side is a shape nothing needs -- under rocprofv3 it dies inside hipLaunchKernel, twice out
+    # of twice (profiles/r04_rocprof_sigsegv_56threads.log)
+    side_by_side = threading.Semaphore(16)
+
     def in_threads(fn):
         """fn(i) for every stream i on its own host thread (the C calls release the GIL); re-raises the first failure"""
         errs = []
 
         def run(i):
             try:
-                fn(i)
+                with side_by_side:
+                    fn(i)
             except BaseException as e:      # noqa: BLE001 - reported below
                 errs.append(e)
         th = [threading.Thread(target=run, args=(i,)) for i in range(K)]

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # S = proofs in flight: 1 = a lone proof (resident round kernels), 56 = seven lock-step batches of eight lanes (the default bench shape)
-for S in 1 56; do
+for S in ${SHAPES:-1 56}; do
   D=$OUT/${TAG}_s$S
   rm -rf $D
   LANES=8; [ $S = 1 ] && LANES=1
