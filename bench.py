@@ -75,7 +75,7 @@ CLASS_KERNELS = {"round_quad": ("k_round_quad2_f",), "round_fine": ("k_round_fin
                  "msm_planes": ("k_msm_codes", "k_msm_windows", "k_msm_planes", "k_scalar_codes", "k_scalar_mags", "k_bit_masks", "k_compact_flags")}
 
 
-CALIBRATION_KERNEL = "k_round_quad2(round2_args)"      # the plain kernel zk_bench_round_quadratic launches: 2 x 2^24 entries, known byte count
+CALIBRATION_KERNEL = "k_round_quad2<0>(round2_args)"      # the plain kernel zk_bench_round_quadratic launches (RQ_FOLD): 2 x 2^24 entries, known byte count
 CALIBRATION_LOG_N = 24
 
 
@@ -117,7 +117,7 @@ def measure_pmc_traffic(workload, kernels, timeout_s=200):
                         if r.get("Counter_Name") != counter:
                             continue
                         name = r["Kernel_Name"].replace("void ", "")
-                        if name.startswith(CALIBRATION_KERNEL.split("(")[0] + "("):
+                        if name.startswith(CALIBRATION_KERNEL.split("<")[0] + "<"):
                             cal += float(r["Counter_Value"])
                             n_cal += 1
                         elif any(k in name for k in kernels):

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstring>
 #include <mutex>
+#include <condition_variable>
 #include "ctx.hpp"
 #include "tail_types.hpp"
 
@@ -89,12 +90,14 @@ extern "C" int32_t zk_ctx_create(int32_t device, zk_ctx **out) {
     return ZK_OK;
 }
 
+static void first_gate_leave(zk_ctx *ctx, bool completed);
 extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->batch) (void) zk_batch_detach(ctx->batch, ctx);
     if (ctx->counted_context) { --g_live_contexts[ctx->device & 63]; ctx->counted_context = false; }
     if (ctx->live_active) (void) zk_live_abort(ctx);
+    first_gate_leave(ctx, false);       // (a context destroyed inside its first proof -- an error path that skipped zk_proof_end -- must not leave the others waiting)
     (void) zk_proof_end(ctx);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->n_seg) fprintf(stderr, "[zkcnn timing] quadratic round call: %.2f us between calls (verifier + wrappers), %.2f plan + launch, %.2f waiting for the result, %.2f after (averages over %llu rounds)\n",
@@ -180,16 +183,50 @@ static std::atomic<int> g_active_proofs[64];
 // launch of the same kernels is the one thing the failing runs of rounds 3 and 4 had in common (one GPU memory fault in ~25 bench runs, one SIGSEGV
 // inside hipLaunchKernel under rocprofv3 -- both while 8 / 32 sessions ran their first proofs side by side; 6e6 launches with 3.3 KB argument blocks
 // from 32 threads did NOT reproduce it: scripts/exp/kernarg_stress.hip). Whoever begins the first proof holds this lock until it ends; proofs that
-// begin meanwhile wait. (Lanes of a batch share a thread and do not take part: a batch's sessions have proved alone before, or prove one by one anyway.)
-static std::mutex g_first_proof_mtx;
-static std::atomic<int> g_first_proof_done{0};
+// begin meanwhile wait. Two gates, because the two launch forms load different kernels: one for the first proof of a context on its own (k_run<F>), one for
+// the first proof of a lock-step batch (k_run_b<F> / k_run_p<F>: a solo warm-up never loads those). A gate has no owning THREAD (round-4 advisor finding: a
+// std::mutex held across C-API calls is undefined behaviour when released from another thread, and is never released when a caller skips zk_proof_end): it is
+// a state word under a short-lived mutex plus a condition variable; the holder is a context or a batch (its lanes share a thread, so they all pass while their
+// batch holds the gate); zk_proof_end and zk_ctx_destroy release it, a failed first proof hands the role to the next one.
+struct first_gate {
+    std::mutex m;
+    std::condition_variable cv;
+    int state = 0;              // 0: nobody has begun, 1: the first proof is running, 2: done
+    const void *owner = nullptr;
+    int holders = 0;            // contexts of the owner inside their proofs
+};
+static first_gate g_first_gate[2];          // [0] solo contexts, [1] batches
+static std::atomic<int> g_first_done[2];
+static void first_gate_enter(zk_ctx *ctx) {
+    const int which = ctx->batch ? 1 : 0;
+    if (g_first_done[which].load(std::memory_order_acquire) || ctx->first_gate_held) return;
+    first_gate &g = g_first_gate[which];
+    const void *key = ctx->batch ? (const void *) ctx->batch : (const void *) ctx;
+    std::unique_lock<std::mutex> lk(g.m);
+    while (g.state == 1 && g.owner != key) g.cv.wait(lk);
+    if (g.state == 2) return;
+    g.state = 1;
+    g.owner = key;
+    ++g.holders;
+    ctx->first_gate_held = which + 1;
+}
+static void first_gate_leave(zk_ctx *ctx, bool completed) {
+    if (!ctx->first_gate_held) return;
+    const int which = ctx->first_gate_held - 1;
+    ctx->first_gate_held = 0;
+    first_gate &g = g_first_gate[which];
+    {
+        std::lock_guard<std::mutex> lk(g.m);
+        if (--g.holders > 0) return;
+        g.state = completed ? 2 : 0;          // (a first proof that did not complete has loaded who knows what: the next one is the first again)
+        g.owner = nullptr;
+        if (completed) g_first_done[which].store(1, std::memory_order_release);
+    }
+    g.cv.notify_all();
+}
 extern "C" int32_t zk_proof_begin(zk_ctx *ctx) {
     if (!ctx) return ZK_ERR_ARG;
-    if (!g_first_proof_done.load() && !ctx->batch && !ctx->holds_first_proof) {
-        g_first_proof_mtx.lock();
-        if (g_first_proof_done.load()) g_first_proof_mtx.unlock();
-        else ctx->holds_first_proof = true;
-    }
+    first_gate_enter(ctx);
     if (!ctx->counted_active) { ++g_active_proofs[ctx->device & 63]; ctx->counted_active = true; }
     // resident kernels only for a proof that is alone on its GPU when it starts: their workgroups wait for one another (k_mid) and for the host,
     // which is only safe -- and only profitable -- while nothing else competes for the CUs and the hardware queue for long
@@ -198,11 +235,7 @@ extern "C" int32_t zk_proof_begin(zk_ctx *ctx) {
 }
 extern "C" int32_t zk_proof_end(zk_ctx *ctx) {
     if (!ctx) return ZK_ERR_ARG;
-    if (ctx->holds_first_proof) {
-        ctx->holds_first_proof = false;
-        g_first_proof_done.store(1);
-        g_first_proof_mtx.unlock();
-    }
+    first_gate_leave(ctx, ctx->counted_active);
     if (ctx->counted_active) { --g_active_proofs[ctx->device & 63]; ctx->counted_active = false; }
     ctx->live_now = !ctx->batch;
     return ZK_OK;

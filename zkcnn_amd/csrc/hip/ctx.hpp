@@ -202,7 +202,7 @@ struct zk_ctx {
     uint64_t live_fallbacks = 0;   // phases that were finished that way
     bool counted_active = false;
     bool counted_context = false;  // counted among the live contexts of its device
-    bool holds_first_proof = false; // this context runs the process's first proof (zk_proof_begin): others wait for it
+    int first_gate_held = 0;        // 1 + index of the first-proof gate this context holds (context.hip: first_gate_enter): others of its kind wait for it
     int live_count = 0, live_cursor = 0;
     uint32_t live_seq32 = 16;
     uint64_t live_rounds_total = 0, live_phases_total = 0;

@@ -68,14 +68,15 @@ extern "C" int32_t zk_k_round_quadratic(zk_ctx *ctx, uint64_t *V, uint64_t *M, u
     A.Vin[0] = dV; A.Min[0] = dM; A.Vout[0] = dV2; A.Mout[0] = dM2;
     A.n[0] = n;
     A.nl[0] = n;
-    A.blocks[0] = std::min<uint32_t>(grid_for(npairs, 1024), ctx->partial_blocks / 2);
+    A.blocks[0] = std::min<uint32_t>((uint32_t) std::min<uint64_t>((npairs + 127) / 128, 1024), ctx->partial_blocks / 2);
     A.r = to_dev(H(r));
     A.first = first ? 1 : 0;
     A.partials = ctx->partials;
     A.counter = ctx->d_counter;
     A.slot = (host_slot *) ctx->d_slot;
     A.seq = ++ctx->slot_seq;
-    ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_round_quad2, dim3(A.blocks[0]), dim3(ZK_BLOCK), A);
+    if (first) ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_round_quad2<RQ_FIRST>, dim3(A.blocks[0]), dim3(ZK_BLOCK), A);
+    else ZK_LAUNCH(PC_ROUND_QUAD, 0.0, k_round_quad2<RQ_FOLD_P1>, dim3(A.blocks[0]), dim3(ZK_BLOCK), A);
     ZK_HIP(hipGetLastError());
     if ((rc = wait_slot(ctx, A.seq))) return rc;
     for (int k = 0; k < 3; ++k) ctx->h_result[k] = ctx->h_slot->v[k];
@@ -98,8 +99,13 @@ static int32_t time_launches(zk_ctx *ctx, uint32_t iters, double *sec, Launch la
     hipEvent_t e0, e1;
     ZK_HIP(hipEventCreate(&e0));
     ZK_HIP(hipEventCreate(&e1));
-    launch();                                   // warm-up
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    // warm-up: the clocks of a GPU that was idle while the host prepared the operands take milliseconds to come up (round 5: the 2^24-entry round
+    // measured 0.40 ms over the first 20 launches of a process against 0.33 ms in steady state) -- run untimed launches for ~50 ms first
+    const auto w0 = std::chrono::steady_clock::now();
+    do {
+        for (int i = 0; i < 4; ++i) launch();
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() < 0.05);
     ZK_HIP(hipEventRecord(e0, ctx->stream));
     for (uint32_t i = 0; i < iters; ++i) launch();
     ZK_HIP(hipEventRecord(e1, ctx->stream));
@@ -166,7 +172,7 @@ extern "C" int32_t zk_bench_round_quadratic(zk_ctx *ctx, uint32_t log_n, uint32_
     A.Vin[0] = dV; A.Min[0] = dM; A.Vout[0] = dO; A.Mout[0] = dO + n / 2;
     A.n[0] = n;
     A.nl[0] = n;
-    A.blocks[0] = std::min<uint32_t>(grid_for(n / 4, 1024), ctx->partial_blocks / 2);
+    A.blocks[0] = std::min<uint32_t>((uint32_t) std::min<uint64_t>((n / 4 + 127) / 128, 1024), ctx->partial_blocks / 2);
     A.r = to_dev(r[0]);
     A.skip_p1 = 1;                        // as every round but the first of a phase runs: b comes from the running claim
     A.partials = ctx->partials;
@@ -175,7 +181,7 @@ extern "C" int32_t zk_bench_round_quadratic(zk_ctx *ctx, uint32_t log_n, uint32_
     *algorithmic_bytes = 96.0 * (double) n;
     rc = time_launches(ctx, iters, sec_per_launch, [&] {
         A.seq = ++ctx->slot_seq;
-        ZK_LAUNCH_RAW(PC_ROUND_QUAD, 96.0 * (double) n, k_round_quad2, dim3(A.blocks[0]), dim3(ZK_BLOCK), A);
+        ZK_LAUNCH_RAW(PC_ROUND_QUAD, 96.0 * (double) n, k_round_quad2<RQ_FOLD>, dim3(A.blocks[0]), dim3(ZK_BLOCK), A);
     });
     if (rc) return rc;
     return wait_slot(ctx, ctx->slot_seq);

@@ -24,8 +24,10 @@ namespace policy {
 // tables of up to 2^FINE_LOG entries take the 4-lanes-per-quad latency kernel (k_round_fine_f: a dependent chain of 2 products instead of 7); larger
 // ones the product kernel (k_round_quad2_f). Round 1: switch-over sizes 2^14 .. 2^18 measured, 2^16 best by ~1%.
 constexpr int FINE_LOG = 16;
-// k_round_quad2_f holds 3 waves per SIMD (132 VGPRs): 768 blocks of 4 waves are exactly one resident set of the 1 024 SIMDs -- no partial second wave of blocks
-constexpr uint32_t QUAD2_BLOCKS = 768;
+// k_round_quad2_f holds 4 waves per SIMD (102 VGPRs, 32 KB of LDS staging per block): 1 024 blocks of 4 waves are exactly one resident set of the 1 024 SIMDs.
+// A wave takes tiles of 64 pairs per table (round_stream.cuh), i.e. a block 128 quads (256 pairs in a phase's first round) per step.
+constexpr uint32_t QUAD2_BLOCKS = 1024;
+constexpr uint64_t QUAD2_QUADS_PER_BLOCK = 128;
 // tables of up to 2^FULL_TABLE_LOG entries are always complete (their readers -- k_round_fine_f, k_mid, k_tail -- know no live-prefix bound); larger ones
 // are built and folded up to their live prefix only. Also the largest table a resident segment kernel (k_mid) takes.
 constexpr int FULL_TABLE_LOG = 18;
@@ -1018,9 +1020,9 @@ static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, ui
         A.nl[b] = live;
         A.fill[b] = (t.len / 2 <= (1ull << ZK_FULL_TABLE_LOG)) ? 1 : 0;
         const uint64_t work = fine ? npairs : std::max<uint64_t>(first ? (live + 1) / 2 : (live + 3) / 4, first ? 1 : (A.fill[b] ? npairs / 8 : 1));
-        // (k_round_quad2 holds 3 waves per SIMD: 768 blocks of 4 waves are exactly one resident set of the 1 024 SIMDs -- no partial second wave of blocks)
-        const uint32_t quad_cap = policy::QUAD2_BLOCKS;
-        A.blocks[b] = collapsed[b] ? 1 : std::min<uint32_t>(grid_for(work, fine ? 1024 : quad_cap), ctx->partial_blocks / 2);
+        // the streaming kernel: a block's four waves take 4 x 64 lane pairs per step = 128 quads (a first round: 128 "quads" = 256 pairs, two steps)
+        const uint32_t stream_blocks = (uint32_t) std::min<uint64_t>((work + policy::QUAD2_QUADS_PER_BLOCK - 1) / policy::QUAD2_QUADS_PER_BLOCK, policy::QUAD2_BLOCKS);
+        A.blocks[b] = collapsed[b] ? 1 : std::min<uint32_t>(fine ? grid_for(work, 1024) : std::max<uint32_t>(stream_blocks, 1), ctx->partial_blocks / 2);
         fine_items += collapsed[b] ? 1 : npairs;
         alg_bytes += (first ? 64.0 : 96.0) * (double) (fine ? t.len : live);      // entries the launch has to read: the live prefix
     }
@@ -1038,7 +1040,9 @@ static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, ui
         if (fine) {
             const uint32_t blocks = (uint32_t) ((fine_items + ZK_BLOCK / 4 - 1) / (ZK_BLOCK / 4));
             zk_launch_f(ctx, PC_ROUND_FINE, alg_bytes, dim3(blocks), k_round_fine_f{A});      // (its own profiler class: the latency kernel of the small rounds)
-        } else zk_launch_f(ctx, PC_ROUND_QUAD, alg_bytes, dim3(A.blocks[0] + A.blocks[1]), k_round_quad2_f{A});
+        } else if (first) zk_launch_f(ctx, PC_ROUND_QUAD, alg_bytes, dim3(A.blocks[0] + A.blocks[1]), k_round_quad2_f<RQ_FIRST>{A});
+        else if (skip_p1) zk_launch_f(ctx, PC_ROUND_QUAD, alg_bytes, dim3(A.blocks[0] + A.blocks[1]), k_round_quad2_f<RQ_FOLD>{A});
+        else zk_launch_f(ctx, PC_ROUND_QUAD, alg_bytes, dim3(A.blocks[0] + A.blocks[1]), k_round_quad2_f<RQ_FOLD_P1>{A});
         ZK_HIP(hipGetLastError());
         for (int b = 0; b < 2; ++b) {
             table_pair &t = ctx->tp[b];
