@@ -2,6 +2,8 @@
 // options of a context (Fiat-Shamir chain, hybrid tail, resident rounds) and the per-proof bracket behind the resident-kernel policy.
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <condition_variable>
@@ -138,17 +140,22 @@ extern "C" int32_t zk_profile_report(zk_ctx *ctx, char *buf, uint64_t cap, int32
     if (!ctx || !buf || !cap) return ZK_ERR_ARG;
     ZK_HIP(hipSetDevice(ctx->device));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
+    // ZKCNN_PROF_DUMP=<file>: every profiled launch as a line "class bytes ms" (scripts/exp/launch_sizes.py: time against size within a class)
+    static const char *dump_path = getenv("ZKCNN_PROF_DUMP");
+    FILE *dump = dump_path && !ctx->prof_q.empty() ? fopen(dump_path, "a") : nullptr;
     for (prof_pending &p : ctx->prof_q) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
             ctx->prof_ms[p.cls] += ms;
             ctx->prof_bytes[p.cls] += p.bytes;
             ++ctx->prof_cnt[p.cls];
+            if (dump) fprintf(dump, "%s %.0f %.6f\n", prof_names[p.cls], p.bytes, ms);
         }
         ctx->prof_pool.push_back(p.e0);
         ctx->prof_pool.push_back(p.e1);
     }
     ctx->prof_q.clear();
+    if (dump) fclose(dump);
     std::string js = "{";
     for (int c = 0; c < PC_COUNT; ++c) {
         char line[256];

@@ -28,6 +28,7 @@ constexpr int FINE_LOG = 16;
 // A wave takes tiles of 64 pairs per table (round_stream.cuh), i.e. a block 128 quads (256 pairs in a phase's first round) per step.
 constexpr uint32_t QUAD2_BLOCKS = 1024;
 constexpr uint64_t QUAD2_QUADS_PER_BLOCK = 128;
+constexpr uint32_t QUAD2_LANE_MIN_BLOCKS = 128;
 // tables of up to 2^FULL_TABLE_LOG entries are always complete (their readers -- k_round_fine_f, k_mid, k_tail -- know no live-prefix bound); larger ones
 // are built and folded up to their live prefix only. Also the largest table a resident segment kernel (k_mid) takes.
 constexpr int FULL_TABLE_LOG = 18;
@@ -1021,7 +1022,11 @@ static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, ui
         A.fill[b] = (t.len / 2 <= (1ull << ZK_FULL_TABLE_LOG)) ? 1 : 0;
         const uint64_t work = fine ? npairs : std::max<uint64_t>(first ? (live + 1) / 2 : (live + 3) / 4, first ? 1 : (A.fill[b] ? npairs / 8 : 1));
         // the streaming kernel: a block's four waves take 4 x 64 lane pairs per step = 128 quads (a first round: 128 "quads" = 256 pairs, two steps)
-        const uint32_t stream_blocks = (uint32_t) std::min<uint64_t>((work + policy::QUAD2_QUADS_PER_BLOCK - 1) / policy::QUAD2_QUADS_PER_BLOCK, policy::QUAD2_BLOCKS);
+        // A lane of a batch shares the launch with the other lanes' blocks: 2 resident sets over all lanes (at least 128 blocks each), so that a wave takes
+        // many tiles and the prologue -- first tile's latency, the 512-bit reductions, block totals -- is paid once per 2^14+ quads, not per 2^7
+        const uint32_t lanes = ctx->batch ? (uint32_t) std::max<size_t>(ctx->batch->lanes.size(), 1) : 1;
+        const uint32_t block_cap = lanes > 1 ? std::max<uint32_t>(policy::QUAD2_LANE_MIN_BLOCKS, 2 * policy::QUAD2_BLOCKS / lanes) : policy::QUAD2_BLOCKS;
+        const uint32_t stream_blocks = (uint32_t) std::min<uint64_t>((work + policy::QUAD2_QUADS_PER_BLOCK - 1) / policy::QUAD2_QUADS_PER_BLOCK, block_cap);
         A.blocks[b] = collapsed[b] ? 1 : std::min<uint32_t>(fine ? grid_for(work, 1024) : std::max<uint32_t>(stream_blocks, 1), ctx->partial_blocks / 2);
         fine_items += collapsed[b] ? 1 : npairs;
         alg_bytes += (first ? 64.0 : 96.0) * (double) (fine ? t.len : live);      // entries the launch has to read: the live prefix

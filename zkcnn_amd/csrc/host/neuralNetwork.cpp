@@ -33,7 +33,30 @@ private:
     bool own_picture;
 };
 
+// writes every value the generator draws, in draw order, as a decimal that parses back to the same double: a data file in the reference's format
+// (whitespace-separated numbers: src/neuralNetwork.cpp:805-893) of the stream behind it
+class teeSource : public dataSource {
+public:
+    teeSource(std::unique_ptr<dataSource> s, const string &name) : inner(std::move(s)), f(fopen(name.c_str(), "w")) {
+        if (!f) throw std::runtime_error("recordDataTo: cannot open " + name);
+    }
+    ~teeSource() override { if (f) fclose(f); }
+    double next(kind k, i64 fan_in) override {
+        const double x = inner->next(k, fan_in);
+        fprintf(f, "%.17g\n", x);
+        return x;
+    }
+private:
+    std::unique_ptr<dataSource> inner;
+    FILE *f;
+};
+
 } // namespace
+
+void neuralNetwork::recordDataTo(const string &filename) {
+    if (!src) throw std::runtime_error("recordDataTo: no data source yet");
+    src.reset(new teeSource(std::move(src), filename));
+}
 
 neuralNetwork::neuralNetwork(i64 psize_x, i64 psize_y, i64 pchannel, i64 pparallel, const string &i_filename,
                              const string &c_filename, const string &o_filename)

@@ -107,6 +107,9 @@ public:
     // picture_seed != 0: the picture comes from its own stream (the weight stream still skips as many draws), so that sessions with the
     // same `seed` share weights and differ in the picture
     void useSyntheticData(u64 seed, u64 picture_seed = 0);
+    // every value create() draws from the current source is also written to `filename` in the reference's data-file format (one decimal per line,
+    // picture first, then weights and biases in layer order): the same statement can then be given to the reference's generator, or read back here
+    void recordDataTo(const string &filename);
     // the pixel values synthetic stream `picture_seed` yields for this model's picture (what a caller would read from a file)
     vector<double> syntheticPicture(u64 picture_seed) const;
 

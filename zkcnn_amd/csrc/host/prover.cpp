@@ -79,6 +79,13 @@ void prover::ensureContext() {
     }
 }
 
+// This file also builds against the REFERENCE's circuit.h (tests/golden/make_gates_golden.py links the reference's unmodified generator with this
+// prover): the two members this repo's layeredCircuit adds -- structureCopy(), gatesDropped() -- are used where they exist.
+template <class LC> static auto circuit_structure_copy(const LC &c, int) -> decltype(c.structureCopy()) { return c.structureCopy(); }
+template <class LC> static LC circuit_structure_copy(const LC &c, long) { return c; }
+template <class LC> static auto circuit_gates_dropped(const LC &c, int) -> decltype(c.gatesDropped()) { return c.gatesDropped(); }
+template <class LC> static bool circuit_gates_dropped(const LC &, long) { return false; }
+
 void prover::cloneFrom(prover &parent) {
     if (!parent.ctx || !parent.resident) throw std::runtime_error("prover::cloneFrom: the parent's circuit is not resident (call init() first)");
     if (ctx) throw std::runtime_error("prover::cloneFrom: this prover already has a context");
@@ -86,7 +93,7 @@ void prover::cloneFrom(prover &parent) {
     if (zk_ctx_clone(parent.ctx, &c) != ZK_OK) throw std::runtime_error(string("zk_ctx_clone failed: ") + zk_last_error(parent.ctx));
     ctx = c;
     device_id = parent.device_id;
-    C = parent.C.structureCopy();
+    C = circuit_structure_copy(parent.C, 0);
     vector<vector<F>>().swap(val);
     resident = true;
     program_resident = parent.program_resident;
@@ -143,7 +150,7 @@ void prover::rerunWitness(const vector<F> &picture, vector<u64> &ranges, size_t 
 void prover::init() {
     ensureContext();
     if (!resident) {
-        if (C.gatesDropped()) throw std::runtime_error("prover::init: this prover holds a structure copy of its circuit (a clone): nothing to upload");
+        if (circuit_gates_dropped(C, 0)) throw std::runtime_error("prover::init: this prover holds a structure copy of its circuit (a clone): nothing to upload");
         upload_timer.start();
         // a context holds one circuit; a changed circuit gets a fresh one
         vector<zk_layer_desc> desc = layerDescs();
