@@ -885,6 +885,16 @@ def main():
                                             "algorithmic_bytes": nbytes, "achieved": round(nbytes / sec / 1e9, 1),
                                             "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
                                             "fr_mul_ceiling_G_per_s": round((1 << 20) * 256 / mul_sec / 1e9, 1)}
+            # products the launch performs: a quad (4 + 4 entries in, 2 + 2 out = 384 B) is 4 folds + 2 sum products (b comes from the running claim;
+            # 3 without it) -> 6 per quad; in multiply-accumulate steps 4 x 120 + 2 x 64 = 608 against the ceiling kernel's 128 per product
+            quads = (1 << 24) / 4
+            sl = roofline["streaming_launch"]
+            sl["fr_mul_per_s"] = round(quads * 6 / sec / 1e9, 1)
+            sl["frac_of_mul_ceiling"] = round(quads * 6 / sec / ((1 << 20) * 256 / mul_sec), 4)
+            sl["mac_steps_frac_of_ceiling"] = round(quads * 608 / sec / (128 * (1 << 20) * 256 / mul_sec), 4)
+            sl["note"] = ("6 Montgomery products per 384-B quad (fr_mul_per_s in G/s); the products of the streaming kernel are cheaper than the ceiling kernel's "
+                          "(uniform factor, 512-bit sums): mac_steps_frac_of_ceiling counts multiply-accumulate steps. The launch is bound by its memory side "
+                          "(profiles/r05_round_lab.md: the same accesses without arithmetic take 0.30 ms, the arithmetic without accesses 0.25 ms)")
         except Exception as e:      # the headline numbers do not depend on this extra measurement
             roofline["streaming_launch"] = {"error": str(e)}
 

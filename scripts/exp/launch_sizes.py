@@ -45,6 +45,7 @@ for line in open(dump):
     e = rows[c][int(math.log2(b)) if b > 0 else -1]
     e[0] += 1; e[1] += ms; e[2] += b
 print(f"{model} pic_cnt={pp}, {k} lanes, one batch proof alone: {1e3 * dt:.1f} ms wall (HIP events on every launch)")
+print("\nall classes: " + ", ".join(f"{c} {sum(e[1] for e in rows[c].values()):.2f} ms / {sum(e[0] for e in rows[c].values())}" for c in sorted(rows, key=lambda c: -sum(e[1] for e in rows[c].values()))))
 for c in want:
     if c not in rows:
         continue

@@ -608,15 +608,17 @@ __device__ __forceinline__ void k_dot_v0(fr_t *V0, const fr_t *F, const fr_t *be
 // beta_g[p CO + co] = beta_hi[p] beta_lo[co] (an eq table is a product over the bits of its index), so
 //     V0[(p CI + ci, t)] = beta_hi[p] * S[ci, t],   S[ci, t] = sum_co beta_lo[co] F[((pp + co) CI + ci, t)]
 // and S is summed once instead of once per picture: CO CI 2^fb + pp CI 2^fb products instead of pp CO CI 2^fb.
-// k_dot_s: grid (t tiles, CI, chunks of co): part[(chunk CI + ci) << fb | t]; k_dot_v0s: grid (t tiles, CI) adds the chunks and writes the pp rows.
-__global__ void __launch_bounds__(ZK_BLOCK) k_dot_s(fr_t *part, const fr_t *F, const fr_t *beta_lo, uint32_t pp, uint32_t CO, uint32_t CI, uint32_t per, int fft_bl) {
-    const uint32_t t = blockIdx.x * ZK_BLOCK + threadIdx.x, ci = blockIdx.y;
+// k_dot_s: grid (t tiles, chunks of co x CI): part[(chunk CI + ci) << fb | t]; k_dot_v0s: grid (t tiles, CI) adds the chunks and writes the pp rows.
+// (grid (t tiles, chunks x CI): the chunk index rides in blockIdx.y -- blockIdx.z is the lane of a fused launch, launch.cuh)
+__device__ __forceinline__ void k_dot_s(fr_t *part, const fr_t *F, const fr_t *beta_lo, uint32_t pp, uint32_t CO, uint32_t CI, uint32_t per, int fft_bl) {
+    const uint32_t t = blockIdx.x * ZK_BLOCK + threadIdx.x, chunk = blockIdx.y / CI, ci = blockIdx.y - chunk * CI;
     if (t >= (1u << fft_bl)) return;
-    const uint32_t co0 = blockIdx.z * per, co1 = min(CO, co0 + per);
+    const uint32_t co0 = chunk * per, co1 = min(CO, co0 + per);
+    if (co0 >= CO) return;                  // (a fused launch takes the largest grid any lane asked for)
     fr_t acc = fr_zero();
     for (uint32_t co = co0; co < co1; ++co)
         acc = fr_add(acc, fr_mul(fr_load(beta_lo + co), fr_load(F + (((size_t) (pp + co) * CI + ci) << fft_bl) + t)));
-    fr_store(part + (((size_t) blockIdx.z * CI + ci) << fft_bl) + t, acc);
+    fr_store(part + (((size_t) chunk * CI + ci) << fft_bl) + t, acc);
 }
 __device__ __forceinline__ void k_dot_v0s(fr_t *V0, const fr_t *part, const fr_t *beta_hi, uint32_t pp, uint32_t CI, uint32_t chunks, int fft_bl) {
     const uint32_t t = blockIdx.x * ZK_BLOCK + threadIdx.x, ci = blockIdx.y;

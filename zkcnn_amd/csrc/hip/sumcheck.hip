@@ -636,8 +636,7 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
         P2.eq1(hi, (int) ctx->bg_r.size() - k_lo, ctx->bg_r.data() + k_lo, ctx->bg_alpha);
         if ((rc = P2.launch(ctx))) return rc;
         const uint32_t tiles = (len + ZK_BLOCK - 1) / ZK_BLOCK;
-        // (k_dot_s spreads its chunks over gridDim.z, which a fused launch needs for the lanes: it stays a launch per lane)
-        ZK_LAUNCH(PC_DOT, 0.0, k_dot_s, dim3(tiles, CI, chunks), dim3(ZK_BLOCK), ctx->dot_part, (const fr_t *) prev.val, (const fr_t *) lo, pp, CO, CI, per, fft_bl);
+        zk_launch_d<k_dot_s, ZK_BLOCK>(ctx, PC_DOT, 0.0, dim3(tiles, CI * chunks), ctx->dot_part, (const fr_t *) prev.val, (const fr_t *) lo, pp, CO, CI, per, fft_bl);
         zk_launch_d<k_dot_v0s, ZK_BLOCK>(ctx, PC_DOT, 0.0, dim3(tiles, CI), ctx->tp[0].V[0], (const fr_t *) ctx->dot_part, (const fr_t *) hi, pp, CI, chunks, fft_bl);
         ZK_HIP(hipGetLastError());
     } else if (cur.d1_live_rows) {
