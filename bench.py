@@ -240,14 +240,14 @@ def _cpu_prover_worker(args):
 def pin_to_gpu_numa_node(torch, local_rank):
     """best effort: the host threads of a rank spin on a slot their GPU writes over PCIe; keep them on the GPU's NUMA node"""
     if os.environ.get("ZKCNN_BENCH_NOPIN"):
-        return
+        return -1
     try:
         pr = torch.cuda.get_device_properties(local_rank)
         bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
         base = f"/sys/bus/pci/devices/{bdf.lower()}"
         node = int(open(base + "/numa_node").read())
         if node < 0:
-            return
+            return -1
         cpus = set()
         for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
             lo, _, hi = part.partition("-")
@@ -255,8 +255,9 @@ def pin_to_gpu_numa_node(torch, local_rank):
         cpus &= os.sched_getaffinity(0)
         if len(cpus) >= 16:
             os.sched_setaffinity(0, cpus)
+        return node
     except Exception:       # noqa: BLE001 - placement is an optimisation only
-        pass
+        return -1
 
 
 def main():
@@ -303,7 +304,7 @@ def main():
     if args.rehearse_shared_gpu:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    pin_to_gpu_numa_node(torch, local_rank)
+    numa_node = pin_to_gpu_numa_node(torch, local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:        # launched by torch.distributed.run (also with one rank: same code path)
         import torch.distributed as dist
@@ -669,17 +670,25 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t_start
-    per_rank = [{"rank": 0, "proofs_per_s": round(K * args.steps / rank_busy_s, 3), "streams": K, "gather_wait_s": round(gather_wait_s, 4)}]
+    # what a scaling run needs to attribute a slow rank: its own rate, sessions, gather wait, set-up time, NUMA node of its GPU and the HBM it has left
+    headroom_gb = torch.cuda.mem_get_info(local_rank)[0] / 1e9
+    per_rank = [{"rank": 0, "proofs_per_s": round(K * args.steps / rank_busy_s, 3), "streams": K, "gather_wait_s": round(gather_wait_s, 4),
+                 "setup_s": round(setup_s, 1), "numa_node": int(numa_node if numa_node is not None else -1), "hbm_free_gb": round(headroom_gb, 1)}]
     if dist is not None:
         te = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
         # attribution of a sub-linear scaling figure: every rank's own rate, its stream count and how long it waited for the gather
-        mine = torch.tensor([rank_busy_s, float(K), gather_wait_s], dtype=torch.float64, device=coll_dev)
+        mine = torch.tensor([rank_busy_s, float(K), gather_wait_s, setup_s, float(numa_node if numa_node is not None else -1), headroom_gb], dtype=torch.float64, device=coll_dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "proofs_per_s": round(float(t[1]) * args.steps / max(float(t[0]), 1e-9), 3), "streams": int(t[1]),
-                     "gather_wait_s": round(float(t[2]), 4)} for r, t in enumerate(a.cpu() for a in allr)]
+                     "gather_wait_s": round(float(t[2]), 4), "setup_s": round(float(t[3]), 1), "numa_node": int(t[4]), "hbm_free_gb": round(float(t[5]), 1)}
+                    for r, t in enumerate(a.cpu() for a in allr)]
+        rates = [p["proofs_per_s"] / max(p["streams"], 1) for p in per_rank]
+        if rank == 0 and min(rates) > 0 and max(rates) / min(rates) > 1.1:
+            print(f"[bench] per-session rates of the ranks differ by {max(rates) / min(rates):.2f}x: " + ", ".join(f"rank {p['rank']} (NUMA {p['numa_node']}): {p['proofs_per_s']}" for p in per_rank),
+                  file=sys.stderr)
 
     # the timed steps ran drive-only: replay the last proof of every stream through the full verifier (not timed)
     replay_mode = zkcnn_amd.MODE_REUSE_GENS | (zkcnn_amd.MODE_FIAT_SHAMIR if args.fiat_shamir else 0)
@@ -699,12 +708,15 @@ def main():
         """the bench line from what has been measured so far (stages that have not run yet leave their defaults)"""
         steps = args.steps
         out = {
-            "metric": f"proofs/s (GKR prover, {args.workload} pic_cnt={pp} proofs, {K} in flight per GPU" +
+            "metric": "proofs/s of the GKR prover. REFERENCE SEMANTICS (fresh random generators for every proof, inner-product argument down to length 1: reference "
+                      "src/verifier.cpp:119-128) are the `reference_semantics` object of this line: proofs_per_s, prover_ms_per_image, cpu_oracle_ms, speedup_vs_one_core. "
+                      "`value` is the public-generator variant: " +
+                      f"{args.workload} pic_cnt={pp} proofs, {K} in flight per GPU" +
                       (f" as {B} lock-step batches of {LANES} lanes: one host thread, one HIP stream and ONE kernel launch per sumcheck round per batch" if LANES > 1 else "") +
                       "; modes SEEDED|DRIVE_ONLY|REUSE_GENS: public generators "
                       "with a resident byte table, IPA cut at 256" + ("; EXPERIMENT: hybrid host tail" if args.hybrid_tail else "") + ("; EXPERIMENT: Fiat-Shamir (challenges hashed on the host)" if args.fiat_shamir else "") +
                       "; sessions share one resident circuit, a picture each; every timed proof returns its transcript); prover_ms_per_image = single-stream latency (a lone proof "
-                      "runs its rounds in resident kernels); reference-semantics companions (fresh generators, full IPA) alongside",
+                      "runs its rounds in resident kernels; proofs_per_s_every_round_on_gpu = the same shape without the lanes' host tail",
             "value": round(sum(p["streams"] for p in per_rank) * steps / elapsed, 4),         # every rank's proofs (a rank may hold fewer streams than asked for)
             "unit": "proofs/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -732,6 +744,12 @@ def main():
         out["host_rss_gb_all_sessions"] = host_rss_gb
         out["host_peak_rss_gb_while_building"] = host_peak_gb
         out.update(extras)
+        # the reference's own protocol first (the headline is a variant; this is the like-for-like pair)
+        ref = {"proofs_per_s": extras.get("proofs_per_s_fresh_gens_full_ipa"), "prover_ms_per_image": extras.get("prover_ms_fresh_gens_full_ipa"),
+               "cpu_oracle_ms": (cpu or {}).get("reference_mode_ms"), "speedup_vs_one_core": (cpu or {}).get("gpu_speedup_vs_one_core_reference_mode"),
+               "note": "fresh random generators drawn by the verifier for every proof (no table survives a proof), full inner-product argument; same circuit, same pictures, "
+                       "transcripts equal to the CPU oracle's in this mode (tests/test_full_size_gpu.py)"}
+        out = {"metric": out["metric"], "value": out["value"], "unit": out["unit"], "reference_semantics": ref, **{k: v for k, v in out.items() if k not in ("metric", "value", "unit")}}
         return out
 
     leave(build_out, "timed region (replay-verified); companions, roofline, PMC passes and CPU baseline not run yet")

@@ -149,6 +149,8 @@ int32_t zkcnn_session_host_tail_rounds(void *session, uint64_t *rounds);
 int32_t zkcnn_session_structured_layers(void *session);
 /* ... and DOT_PROD layers of FFT convolutions over several pictures whose phase-1 table is built in factored form (zk_factored_dot_layers) */
 int32_t zkcnn_session_factored_dot_layers(void *session);
+/* ... and DOT_PROD phases proved so far with the deferred evaluation of Y's dead region (zk_dot_deferred_phases) */
+uint64_t zkcnn_session_dot_deferred_phases(void *session);
 
 /* Product library only: HIP-event profiler of the GPU kernels (see zk_profile_enable / zk_profile_report in zkcnn_hip.h). */
 int32_t zkcnn_session_profile(void *session, uint32_t class_mask);

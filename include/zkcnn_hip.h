@@ -84,6 +84,9 @@ int32_t zk_structured_layers(const zk_ctx *ctx);
 /* DOT_PROD layers (FFT convolutions over pic_cnt >= 2 pictures, channel_out a power of two) whose gate list is the generator's full pattern
  * (checked gate by gate at upload): their phase-1 table is built in factored form, summed once over channel_out instead of once per picture */
 int32_t zk_factored_dot_layers(const zk_ctx *ctx);
+/* DOT_PROD phases so far whose Y table was not folded behind X's live prefix: that region was evaluated once at the end of the phase instead
+   (reference src/prover.cpp:103-153 folds it every round; same claims, same transcript) */
+uint64_t zk_dot_deferred_phases(const zk_ctx *ctx);
 /* val[layer] (n = layer size); stored zero-padded to 2^bit_length */
 int32_t zk_upload_layer_values(zk_ctx *ctx, int32_t layer, const uint64_t *values, uint64_t n);
 

@@ -169,7 +169,7 @@ def _bench_shape_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import time
     import psutil
-    K, steps = 2, 2
+    K, steps = 2, 10
     sessions = [oracle_ffi.OracleSession("custom:C4:3:1:n M F8", (8, 8, 2), 1, data_seed=9000 + rank * K + i) for i in range(K)]
     g = dp.AsyncGather(dist, "cpu", K << 16)
     done = [queue.Queue() for _ in range(K)]
@@ -216,10 +216,11 @@ def test_eight_ranks_step_loop_shape(oracle):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert sorted(got) == [(step, r, [2 * r, 2 * r + 1]) for step in range(2) for r in range(world)]
+    assert sorted(got) == [(step, r, [2 * r, 2 * r + 1]) for step in range(10) for r in range(world)]
     # no rank straggles: the ranks prove side by side (ranks that serialised behind one another would finish up to 8x apart); the slack
     # covers 16 proving threads on however few cores this box has
-    assert max(busy) <= 1.2 * min(busy) + 2.0, busy
+    # (round-4 review: spread of the ranks' proving times <= 1.1x; the constant covers thread start-up on a box with fewer cores than proving threads)
+    assert max(busy) <= 1.1 * min(busy) + 0.3, busy
     # host-memory budget: the ranks together stay inside what bench.py's rule reserves for them (streams_that_fit: 6 GB per session)
     import bench
     assert sum(rss) <= world * 2 * bench.HOST_BYTES_PER_SESSION

@@ -10,6 +10,7 @@ The oracle needs ~27 s of one host core per full-size proof (+ ~10 s for its gat
 three processes.
 """
 import hashlib
+import os
 import multiprocessing as mp
 
 import numpy as np
@@ -140,10 +141,15 @@ def test_vgg16_thirty_two_pictures_as_one_circuit(built):
     wiring predicate on the GPU, the Hyrax opening -- plus determinism, replay of the serialized proof and rejection of a corrupted message."""
     try:
         import psutil
-        if psutil.virtual_memory().available < 300e9:
-            pytest.skip("needs ~250 GB of host memory for the circuit and witness of 32 pictures")
+        avail = psutil.virtual_memory().available
     except ImportError:
-        pass
+        avail = None
+    if avail is not None and avail < 300e9:
+        # (round-4 review: a green run on a smaller box must not look like coverage -- with ZKCNN_REQUIRE_BIG=1 the test FAILS instead of skipping)
+        msg = f"needs ~250 GB of host memory for the circuit and witness of 32 pictures; {avail / 1e9:.0f} GB available"
+        if os.environ.get("ZKCNN_REQUIRE_BIG") == "1":
+            pytest.fail("ZKCNN_REQUIRE_BIG=1: " + msg)
+        pytest.skip(msg)
     TAMPER = zkcnn_amd.MODE_TAMPER
     with zkcnn_amd.Session("vgg16", PIC, 32) as s:
         res, tr = s.prove(seed=SEED, mode=REUSE)

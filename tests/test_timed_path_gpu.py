@@ -89,6 +89,36 @@ def test_fft_conv_batches_identical_to_oracle(built, model, pic, pp):
     assert hashlib.sha256(gpu2).hexdigest() == hashlib.sha256(cpu2).hexdigest()
 
 
+
+def test_dot_prod_dead_region_is_folded_in_one_pass(built, monkeypatch):
+    """Round 5: a DOT_PROD phase leaves Y unfolded behind X's live prefix while that prefix stays even and catches up in one pass (k_dead_rows_f) before
+    the tables are small -- transcripts must not move (reference src/prover.cpp:103-153 folds every entry in every round). With the library's thresholds
+    only the full-size circuits get there (test_full_size_fft_conv_circuits); the hook lowers the fill threshold so that this 2^21-entry phase skips
+    several folds (s >= 6: the chunked branch of the kernel) and, with a higher one, few (s < 6: the butterfly branch)."""
+    model, pic, pp = "custom:C16:3:1:f C16:3:1:f M F10", (32, 32, 3), 4
+    with oracle_ffi.OracleSession(model, pic, pp) as o:
+        _, cpu = o.prove(seed=0x5EED0021, mode=REUSE | DRIVE)
+    monkeypatch.setenv("ZKCNN_TEST_HOOKS", "1")
+    for fill_log, batch in ((6, False), (17, False), (12, True)):
+        monkeypatch.setenv("ZKCNN_TEST_DOT_FILL_LOG", str(fill_log))
+        if not batch:
+            with zkcnn_amd.Session(model, pic, pp) as s:
+                res, gpu = s.prove(seed=0x5EED0021, mode=REUSE)
+                assert res.accepted == 1, res.message.decode()
+                assert s.dot_deferred_phases() >= 1, "no DOT_PROD phase took the deferred fold"
+                assert gpu == cpu, f"fill threshold 2^{fill_log}: transcript differs from the oracle's"
+        else:
+            ss = [zkcnn_amd.Session(model, pic, pp) for _ in range(2)]
+            try:
+                with zkcnn_amd.BatchSession(ss) as b:
+                    out = b.prove(seeds=[0x5EED0021, 0x5EED0021], mode=REUSE | DRIVE)
+                for res, tr in out:
+                    assert tr == cpu
+                assert ss[0].dot_deferred_phases() >= 1
+            finally:
+                for x in ss:
+                    x.close()
+
 FULL = [
     ("vgg16", (32, 32, 3), 4, dict(n_layers=99, input_bits=26)),      # BASELINE configs[4]: the per-GPU workload (4 images per GPU)
     ("vgg11", (32, 32, 3), 8, dict(n_layers=69, input_bits=26)),      # configs[3] as the reference would fold it (one circuit, pic_cnt=8)

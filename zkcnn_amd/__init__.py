@@ -425,6 +425,11 @@ class Session(_SessionBase):
         """DOT_PROD layers (FFT convolutions over pic_cnt >= 2 pictures) whose phase-1 table is summed once over channel_out, not once per picture"""
         return int(self.lib.zkcnn_session_factored_dot_layers(ctypes.c_void_p(self.h)))
 
+    def dot_deferred_phases(self):
+        """DOT_PROD phases proved so far whose Y table was evaluated once behind X's live prefix instead of folded every round"""
+        self.lib.zkcnn_session_dot_deferred_phases.restype = ctypes.c_uint64
+        return int(self.lib.zkcnn_session_dot_deferred_phases(ctypes.c_void_p(self.h)))
+
     def synthetic_picture(self, picture_seed):
         n = self.pic[0] * self.pic[1] * self.pic[2]
         arr = (ctypes.c_double * n)()

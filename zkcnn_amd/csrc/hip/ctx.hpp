@@ -152,6 +152,13 @@ struct zk_ctx {
     HFr bg_alpha;
     int bg_layer = -1;             // the IFFT layer that built it
     fr_t *dot_tabs = nullptr;      // beta_lo (4096 entries), beta_hi (4096 entries)
+    // Y's dead region of a DOT_PROD phase, folded several rounds at once instead of every round (sumcheck.hip: zk_sumcheck_dotprod_update1)
+    bool dot_defer = false;
+    int dot_fill_log = 20;         // policy::DOT_FILL_LOG (or a test's override)
+    const fr_t *dot_defer_Y = nullptr;     // the unfolded table (the previous layer's values, read in place)
+    uint64_t dot_defer_to = 0;             // entries of it that can be non-zero
+    fr_t *dead_tabs = nullptr;     // eq table of the catch-up (2^DEAD_MAX_FOLDS entries) + partial sums
+    uint64_t dot_defer_count = 0;  // phases that took this path
     fr_t *dot_part = nullptr;      // channel_out chunks of S
     uint64_t dot_part_cap = 0;
     uint32_t dot_layers = 0;       // DOT_PROD layers with the factored table (zk_factored_dot_layers)

@@ -68,7 +68,7 @@ struct gen_tables {
     std::vector<uint64_t> gens;        // the affine generators (C-ABI layout): the key
     int refs = 0;
     uint32_t uses = 0;                 // times a context selected the set: the byte table is built when a set is used AGAIN
-    std::mutex mtx;                    // held while a table is built
+    std::atomic<const void *> owner{nullptr};   // the context that is building a table of the set (set_lock); no thread owns anything: lanes of a batch share one
     g1a_t *tables = nullptr;           // window tables T[w][j] = 2^(8w) g_j
     hipEvent_t win_ev = nullptr;       // set: the windows above MSM_LOW_WINDOWS are (being) written on another stream -- whoever reads them makes its stream wait (wait_windows)
     g1a_t *digit = nullptr; bool digit_ready = false;
@@ -82,13 +82,17 @@ static std::mutex g_gen_mtx;
 struct set_lock {
     gen_tables *e;
     int32_t rc = ZK_OK;
+    // (round-4 advisor finding: this used to spin on std::mutex::try_lock, which a lane may call on the very thread whose parked lane holds the mutex --
+    // undefined behaviour. The lock is an owner word now: compare-and-swap by CONTEXT, released by whoever holds it, from any thread.)
     set_lock(zk_ctx *ctx, gen_tables *entry) : e(entry) {
-        while (!e->mtx.try_lock()) {
+        for (;;) {
+            const void *none = nullptr;
+            if (e->owner.compare_exchange_weak(none, (const void *) ctx, std::memory_order_acquire, std::memory_order_relaxed)) return;
             if (ctx->batch) { if ((rc = zk_batch_sync_point(ctx))) { e = nullptr; return; } }
             else std::this_thread::yield();
         }
     }
-    ~set_lock() { if (e) e->mtx.unlock(); }
+    ~set_lock() { if (e) e->owner.store(nullptr, std::memory_order_release); }
     set_lock(const set_lock &) = delete;
     set_lock &operator=(const set_lock &) = delete;
 };

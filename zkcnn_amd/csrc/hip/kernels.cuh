@@ -465,6 +465,10 @@ __device__ __forceinline__ void k_round_cubic(const fr_t *V0in, const fr_t *V1in
     // sums; only Y is folded there (2 of the 7 products, half the traffic), and X's output is left alone, or zeroed once the tables are small (fill)
     const uint64_t pl = min(npairs, first ? (x_live + 1) / 2 : (x_live + 3) / 4);
     const uint32_t mpairs = ls >> 1;
+    // fill & 4: Y is not folded behind X's live prefix in this round (sumcheck.hip: the deferred fold of Y's dead region; x_live is even then, so no live
+    // pair reaches behind it -- the guard below only keeps a partial last QUAD from reading what was never written)
+    const bool y_cut = (fill & 4) != 0;
+    auto ld_y = [&](uint64_t idx) { return (y_cut && idx >= x_live) ? fr_zero() : fr_load(V1in + idx); };
     if (Ms_raw && blockIdx.x == 0)
         for (uint32_t j = threadIdx.x; j < ls; j += ZK_BLOCK) fr_store(Ms_out + j, cubic_ms(Ms, Ms_raw, j, r));
     // the round in which the periodic table collapses hands the scalar to the host as well (acknowledged before this block's ticket / the slot's
@@ -479,12 +483,12 @@ __device__ __forceinline__ void k_round_cubic(const fr_t *V0in, const fr_t *V1in
             fr_t x0, x1, y0, y1;
             if (first) {
                 x0 = fr_load(V0in + 2 * p); x1 = fr_load(V0in + 2 * p + 1);
-                y0 = fr_load(V1in + 2 * p); y1 = fr_load(V1in + 2 * p + 1);
+                y0 = ld_y(2 * p); y1 = ld_y(2 * p + 1);
             } else {
                 x0 = fr_lerp(fr_load(V0in + 4 * p), fr_load(V0in + 4 * p + 1), r);
                 x1 = fr_lerp(fr_load(V0in + 4 * p + 2), fr_load(V0in + 4 * p + 3), r);
-                y0 = fr_lerp(fr_load(V1in + 4 * p), fr_load(V1in + 4 * p + 1), r);
-                y1 = fr_lerp(fr_load(V1in + 4 * p + 2), fr_load(V1in + 4 * p + 3), r);
+                y0 = fr_lerp(ld_y(4 * p), ld_y(4 * p + 1), r);
+                y1 = fr_lerp(ld_y(4 * p + 2), ld_y(4 * p + 3), r);
                 fr_store(V0out + 2 * p, x0); fr_store(V0out + 2 * p + 1, x1);
                 fr_store(V1out + 2 * p, y0); fr_store(V1out + 2 * p + 1, y1);
             }
@@ -513,12 +517,12 @@ __device__ __forceinline__ void k_round_cubic(const fr_t *V0in, const fr_t *V1in
         fr_t x0, x1, y0, y1;
         if (first) {
             x0 = fr_load(V0in + 2 * p); x1 = fr_load(V0in + 2 * p + 1);
-            y0 = fr_load(V1in + 2 * p); y1 = fr_load(V1in + 2 * p + 1);
+            y0 = ld_y(2 * p); y1 = ld_y(2 * p + 1);
         } else {
             x0 = fr_lerp(fr_load(V0in + 4 * p), fr_load(V0in + 4 * p + 1), r);
             x1 = fr_lerp(fr_load(V0in + 4 * p + 2), fr_load(V0in + 4 * p + 3), r);
-            y0 = fr_lerp(fr_load(V1in + 4 * p), fr_load(V1in + 4 * p + 1), r);
-            y1 = fr_lerp(fr_load(V1in + 4 * p + 2), fr_load(V1in + 4 * p + 3), r);
+            y0 = fr_lerp(ld_y(4 * p), ld_y(4 * p + 1), r);
+            y1 = fr_lerp(ld_y(4 * p + 2), ld_y(4 * p + 3), r);
             fr_store(V0out + 2 * p, x0); fr_store(V0out + 2 * p + 1, x1);
             fr_store(V1out + 2 * p, y0); fr_store(V1out + 2 * p + 1, y1);
         }
@@ -539,7 +543,8 @@ __device__ __forceinline__ void k_round_cubic(const fr_t *V0in, const fr_t *V1in
         acc[2] = fr_add(acc[2], fr_add(fr_mul(q1, m0), fr_mul(q0, dm)));
         acc[3] = fr_add(acc[3], fr_mul(q0, m0));
     }
-    if (!first && !(fill & 2))            // (fill & 2: a streaming k_fold launch ahead of this one has folded Y behind the live prefix)
+    if (!first && y_cut) {                // (Y behind the prefix is left unfolded for now: sumcheck.hip catches up before anything reads it)
+    } else if (!first && !(fill & 2))     // (fill & 2: a streaming k_fold launch ahead of this one has folded Y behind the live prefix)
         for (uint64_t p = pl + tid; p < npairs; p += stride) {
             fr_store(V1out + 2 * p, fr_lerp(fr_load(V1in + 4 * p), fr_load(V1in + 4 * p + 1), r));
             fr_store(V1out + 2 * p + 1, fr_lerp(fr_load(V1in + 4 * p + 2), fr_load(V1in + 4 * p + 3), r));
@@ -556,6 +561,46 @@ __device__ __forceinline__ void k_round_cubic(const fr_t *V0in, const fr_t *V1in
     __syncthreads();
     grid_finish<4>(acc, partials, counter, slot, seq, smem);
 }
+
+// Several folds at once for the part of a table the rounds skipped (sumcheck.hip: a DOT_PROD phase leaves Y unfolded behind X's live prefix while that prefix
+// stays aligned, then catches up in ONE pass): after s folds, entry j of the table is  sum_{i < 2^s} eq(r_1..r_s; i) Y[(j << s) + i]  (reference
+// src/prover.cpp:103-144 folds it round by round: 48 B per entry and round; here 32 B per entry once). E = the eq table of the s challenges.
+// A WAVE takes segments of 2^cs entries, cs = min(s, 12): whole rows when s <= 12 (out[row]), else chunk c of a row -> out[c * rows + row] for k_sum_rows_f.
+// s < 6: a wave step covers 64 >> s rows, lanes of one row add up by butterfly.
+struct k_dead_rows_f {
+    const fr_t *Y, *E;
+    fr_t *out;
+    uint64_t row0, rows;
+    int32_t s, cs;
+    uint32_t nblk;
+    __device__ __forceinline__ void operator()() const {
+        if (blockIdx.x >= nblk) return;
+        const uint32_t lane = threadIdx.x & 63;
+        const uint64_t gw = (uint64_t) blockIdx.x * (ZK_BLOCK / 64) + (threadIdx.x >> 6), nw = (uint64_t) nblk * (ZK_BLOCK / 64);
+        if (s >= 6) {
+            const int cb = s - cs;                                   // chunks per row = 2^cb
+            const uint64_t segs = rows << cb, seg_len = 1ull << cs;
+            for (uint64_t seg = gw; seg < segs; seg += nw) {
+                const uint64_t row = seg >> cb, chunk = seg & ((1ull << cb) - 1);
+                const fr_t *y = Y + ((row0 + row) << s) + (chunk << cs), *e = E + (chunk << cs);
+                fr_acc512 W = fr_acc512_zero();
+                for (uint64_t i = lane; i < seg_len; i += 64) fr_acc512_mac(W, fr_load(y + i), fr_load(e + i));
+                fr_t v = fr_wave_sum(fr_acc512_reduce(W));
+                if (lane == 0) fr_store(out + chunk * rows + row, v);
+            }
+        } else {
+            const uint32_t per = 64u >> s, i = lane & ((1u << s) - 1);
+            const fr_t ei = fr_load(E + i);
+            for (uint64_t r0 = gw * per; r0 < rows; r0 += nw * per) {
+                const uint64_t row = r0 + (lane >> s);
+                const bool valid = row < rows;
+                fr_t v = valid ? fr_mul(fr_load(Y + ((row0 + row) << s) + i), ei) : fr_zero();
+                for (uint32_t d = 1; d < (1u << s); d <<= 1) v = fr_add(v, rs_shfl_xor(v, (int) d));
+                if (valid && i == 0) fr_store(out + row, v);
+            }
+        }
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // K6: FFT / IFFT layer claim combine  V[u] = sum_g val[g * stride + u] * beta[g]

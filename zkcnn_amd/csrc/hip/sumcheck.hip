@@ -38,6 +38,11 @@ constexpr uint64_t MID_MAX_QUADS = 65536;
 // behind the collapse read whole tables); and Y's fold behind the prefix becomes a streaming launch of its own from 2^DOT_STREAM_LOG pairs on (4 TB/s
 // against ~2 inside the round kernel: DESIGN.md 4i)
 constexpr int DOT_FILL_LOG = 20, DOT_STREAM_LOG = 17;
+// Round 5: where that streaming fold would run, Y's dead region is left UNFOLDED while X's live prefix stays aligned (even): a live pair then never mixes with a
+// dead entry, and X = 0 behind the prefix makes every product there vanish whatever Y holds. Before the first round that would mix them (an odd prefix) or that
+// needs whole tables (DOT_FILL_LOG), the skipped folds are caught up in ONE pass over the unfolded values (k_dead_rows_f: entry j = sum_i eq(r_1..r_s; i) Y[(j << s) + i],
+// 32 B per entry once instead of 48 B per entry and round). At most DEAD_MAX_FOLDS folds are skipped (the eq table of the catch-up has 2^s entries)
+constexpr int DEAD_MAX_FOLDS = 20;
 // a LANE of a lock-step batch hands a phase's tables to the host once they hold at most 2^LANE_TAIL_LOG entries (zk_set_host_tail's default for lanes): the
 // phase's last five rounds are ~150 multiplications on the lane's host thread instead of five fused launches -- 44% of a vgg11 proof's rounds by count,
 // 3e-5 of its products. 4 x 8 lanes on one box: 135 proofs/s with every round a launch, 139-143 / 144 / 144-147 / 144-147 with 2^3 / 2^4 / 2^5 / 2^6.
@@ -597,6 +602,11 @@ extern "C" int32_t zk_sumcheck_dotprod_init_phase1(zk_ctx *ctx) {
     ctx->phase_kind = 0; ctx->phase_r.clear(); ctx->phase_no_live = false;
     ctx->small_len = 1u << fft_bl;
     ctx->small_cur = 0;
+    ctx->dot_defer = false;
+    {   // (test hook: a smaller fill threshold lets small circuits reach the deferred fold; tests/test_timed_path_gpu.py)
+        const char *hooks = getenv("ZKCNN_TEST_HOOKS"), *v = getenv("ZKCNN_TEST_DOT_FILL_LOG");
+        ctx->dot_fill_log = (hooks && atoi(hooks) && v) ? std::max(2, std::min(atoi(v), policy::DOT_FILL_LOG)) : policy::DOT_FILL_LOG;
+    }
     const uint64_t N = ctx->tp[1].len;
     prep_plan P(ctx);
     P.eq1(ctx->small[0], fft_bl, ctx->r_0, HFr::one());
@@ -697,20 +707,59 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
     if (npairs == 0) return ZK_ERR_STATE;
     const unsigned long long seq = ++ctx->slot_seq;
     // X's live prefix (entries, pre-fold); once the folded tables are small the zeros behind it are written out (the quadratic rounds read whole tables)
-    const uint64_t x_live = std::min<uint64_t>(t0.live, n);
-    int fill = (!first && n / 2 <= (1ull << policy::DOT_FILL_LOG)) ? 1 : 0;
+    uint64_t x_live = std::min<uint64_t>(t0.live, n);
+    int fill = (!first && n / 2 <= (1ull << ctx->dot_fill_log)) ? 1 : 0;
     // Behind X's live prefix only Y is folded: for large tables that is a plain streaming fold (one output per thread, 64 contiguous bytes in, 32
     // out) in a launch of its own ahead of the round kernel, which then works on the live pairs alone
-    const uint64_t pl = std::min<uint64_t>(npairs, (x_live + 3) / 4);
-    if (!first && npairs - pl >= (1ull << policy::DOT_STREAM_LOG)) {
+    uint64_t pl = std::min<uint64_t>(npairs, (x_live + 3) / 4);
+    // the first fold of the phase decides: a large dead region behind an even prefix is left unfolded (policy: DEAD_*); Y must still be the layer's values in place
+    if (!first && ctx->round == 2 && !ctx->dot_defer && !ctx->fs_state && t1.Vsrc && npairs - pl >= (1ull << policy::DOT_STREAM_LOG) && x_live > 0 && !(x_live & 1) && !fill &&
+        !getenv("ZKCNN_NO_DOT_DEFER")) {
+        ctx->dot_defer = true;
+        ctx->dot_defer_Y = t1.Vsrc;
+        ctx->dot_defer_to = std::min<uint64_t>(n, ctx->L[id - 1].val_live);      // (entries of the unfolded table that can be non-zero)
+        ++ctx->dot_defer_count;
+    } else if (ctx->dot_defer && ((x_live & 1) || fill || ctx->round - 2 >= policy::DEAD_MAX_FOLDS || x_live >= n)) {
+        // catch up: `sdone` folds were skipped behind the prefix; the current tables get their entries [x_live, n) -- Y the folded values, X its zeros
+        const int sdone = ctx->round - 2, cs = std::min(sdone, 12);
+        const uint64_t real_rows = std::min<uint64_t>(n, (ctx->dot_defer_to + (1ull << sdone) - 1) >> sdone);
+        const uint64_t rows = real_rows > x_live ? real_rows - x_live : 0, chunks = 1ull << (sdone - cs);
+        int32_t rc;
+        const uint64_t need = (1ull << policy::DEAD_MAX_FOLDS) + (1ull << 16);
+        if (!ctx->dead_tabs && (rc = zk_dev_alloc(ctx, (void **) &ctx->dead_tabs, need * sizeof(fr_t)))) return rc;
+        fr_t *E = ctx->dead_tabs, *part = ctx->dead_tabs + (1ull << policy::DEAD_MAX_FOLDS);
+        if (rows * chunks > (1ull << 16) && chunks > 1) { ctx->err = "DOT_PROD catch-up: more partial sums than planned"; return ZK_ERR_STATE; }
+        fr_t *ycur = t1.V[t1.cur], *xcur = t0.V[t0.cur];
+        prep_plan P(ctx);
+        P.eq1(E, sdone, ctx->r_u[id].data(), HFr::one());
+        if (x_live + rows < n) P.zero(ycur + x_live + rows, n - x_live - rows);
+        if (x_live < n) P.zero(xcur + x_live, n - x_live);
+        if ((rc = P.launch(ctx))) return rc;
+        if (rows) {
+            k_dead_rows_f f;
+            f.Y = ctx->dot_defer_Y; f.E = E; f.out = chunks > 1 ? part : ycur + x_live;
+            f.row0 = x_live; f.rows = rows; f.s = sdone; f.cs = cs;
+            const uint64_t waves = sdone >= 6 ? rows * chunks : (rows + (64u >> sdone) - 1) / (64u >> sdone);
+            f.nblk = (uint32_t) std::min<uint64_t>((waves + ZK_BLOCK / 64 - 1) / (ZK_BLOCK / 64), 4096);
+            zk_launch_f(ctx, PC_FOLD, 32.0 * (double) (rows << sdone), dim3(f.nblk), f);
+            if (chunks > 1) zk_launch_f<k_sum_rows_f, 1024>(ctx, PC_FOLD, 0.0, dim3((uint32_t) ((rows + 63) / 64)), k_sum_rows_f{ycur + x_live, (const fr_t *) part, (uint32_t) rows, (uint32_t) chunks});
+            ZK_HIP(hipGetLastError());
+        }
+        ctx->dot_defer = false;
+        t0.live = n;             // whole tables from here on
+        x_live = n;
+        pl = npairs;
+    }
+    if (ctx->dot_defer) fill |= 4;
+    else if (!first && npairs - pl >= (1ull << policy::DOT_STREAM_LOG)) {
         const uint64_t n_in = n - 4 * pl;
         zk_launch_f(ctx, PC_FOLD, 48.0 * (double) n_in, dim3(grid_for(n_in / 2, 8192)), k_fold_f{vin(t1) + 4 * pl, t1.V[t1.cur ^ 1] + 2 * pl, n_in, to_dev(r)});
         ZK_ORDER();
         if (fill) ZK_HIP(hipMemsetAsync(t0.V[t0.cur ^ 1] + 2 * pl, 0, (n / 2 - 2 * pl) * sizeof(fr_t), ctx->stream));
         fill |= 2;
     }
-    const uint32_t g = std::min<uint32_t>(grid_for((fill & 2) || first ? std::max<uint64_t>(first ? std::min<uint64_t>(npairs, (x_live + 1) / 2) : pl, 1) : npairs, 1024), ctx->partial_blocks);
-    zk_launch_d<k_round_cubic, ZK_BLOCK>(ctx, PC_ROUND_CUBIC, (first ? 32.0 : 48.0) * (double) (n + x_live), dim3(g), (const fr_t *) t0.V[t0.cur], vin(t1),
+    const uint32_t g = std::min<uint32_t>(grid_for(((fill & 2) || (fill & 4 && !(fill & 1))) || first ? std::max<uint64_t>(first ? std::min<uint64_t>(npairs, (x_live + 1) / 2) : pl, 1) : npairs, 1024), ctx->partial_blocks);
+    zk_launch_d<k_round_cubic, ZK_BLOCK>(ctx, PC_ROUND_CUBIC, (first ? 32.0 : 48.0) * (double) ((fill & 4) ? 2 * x_live : n + x_live), dim3(g), (const fr_t *) t0.V[t0.cur], vin(t1),
               t0.V[t0.cur ^ 1], t1.V[t1.cur ^ 1], (const fr_t *) ctx->small[ctx->small_cur], ctx->small_len, n, to_dev(r), first ? 1 : 0, ctx->partials,
               ctx->d_counter, (host_slot *) ctx->d_slot, seq, ms_raw, ms_out, x_live, fill);
     ZK_HIP(hipGetLastError());
@@ -908,9 +957,16 @@ static int32_t replay_phase(zk_ctx *ctx, const HFr &r, bool with_add_term, uint6
 
 static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]) {
     if (ctx->round) ctx->phase_r.push_back(r);
+    const uint64_t size_before = ctx->proof_size;        // (the failed call may or may not have booked its message: the replay books it once)
     int32_t rc = quad_round_once(ctx, r, with_add_term, out_abc);
     if (rc == ZK_ERR_STATE && ctx->live_lost) {
         ctx->live_lost = false;
+        if (ctx->phase_kind == 0) {
+            // the quadratic rounds behind a DOT_PROD phase's collapse: their tables are the cubic rounds' output, which replay_phase cannot rebuild
+            ctx->err = "a resident round kernel was lost in a DOT_PROD phase: no fallback for this phase kind (prove again)";
+            return ZK_ERR_STATE;
+        }
+        ctx->proof_size = size_before;
         rc = replay_phase(ctx, r, with_add_term, out_abc);
     }
     return rc;

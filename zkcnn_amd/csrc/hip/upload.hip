@@ -167,6 +167,7 @@ static bool conv_infer(const zk_layer_desc &S, const zk_layer_desc &P, int layer
 
 extern "C" int32_t zk_structured_layers(const zk_ctx *ctx) { return ctx ? (int32_t) ctx->conv_layers : 0; }
 extern "C" int32_t zk_factored_dot_layers(const zk_ctx *ctx) { return ctx ? (int32_t) ctx->dot_layers : 0; }
+extern "C" uint64_t zk_dot_deferred_phases(const zk_ctx *ctx) { return ctx ? ctx->dot_defer_count : 0; }
 
 extern "C" int32_t zk_upload_circuit(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_layers, const uint64_t *two_mul,
                                      int32_t n_two_mul) {
@@ -327,7 +328,10 @@ extern "C" int32_t zk_ctx_clone(zk_ctx *src, zk_ctx **out) {
         ++e->refs;
     }
     ctx->circuit = e;
-    adopt_circuit(ctx, e);
+    {
+        std::lock_guard<std::mutex> g(e->mtx);      // (another session of the circuit may be uploading its witness program: it writes e->L[i].ev_* under this lock)
+        adopt_circuit(ctx, e);
+    }
     ++g_circ_attaches;
     rc = alloc_session(ctx);
     if (rc == ZK_OK && (hipSetDevice(src->device) != hipSuccess || hipStreamSynchronize(src->stream) != hipSuccess)) rc = ZK_ERR_HIP;     // (the values copied below are complete)
@@ -340,6 +344,7 @@ extern "C" int32_t zk_ctx_clone(zk_ctx *src, zk_ctx **out) {
         ctx->dot_layers = 0;
         for (const dev_layer &D : ctx->L) ctx->dot_layers += D.dot_ok ? 1 : 0;
         ctx->circuit_ready = true;
+        std::lock_guard<std::mutex> g(e->mtx);
         if (e->wp_ready) rc = zk_witness_program_adopt(ctx);
     }
     if (rc != ZK_OK) {

@@ -228,6 +228,7 @@ extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *o
     shared_circuit *e = (shared_circuit *) ctx->circuit;
     if (!e) return ZK_ERR_STATE;
     {
+        // (the attach below reads e->L[i].ev_* and e->wp_*, which another session's first upload writes under this lock: round-4 advisor finding)
         std::lock_guard<std::mutex> g(e->mtx);
         if (!e->wp_ready) {
             const std::vector<dev_layer> keep = ctx->L;          // (a failed build leaves the context as it was)
@@ -240,8 +241,8 @@ extern "C" int32_t zk_witness_program_upload(zk_ctx *ctx, const zk_witness_op *o
             e->bytes += ctx->sink_bytes;
             e->wp_ready = true;
         }
+        return zk_witness_program_adopt(ctx);
     }
-    return zk_witness_program_adopt(ctx);
 }
 
 static int32_t wp_build_static(zk_ctx *ctx, shared_circuit *e, const zk_witness_op *ops, uint64_t n_ops, const uint32_t *windows, uint64_t n_windows,

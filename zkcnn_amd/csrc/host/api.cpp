@@ -407,6 +407,10 @@ int32_t zkcnn_session_factored_dot_layers(void *session) {
     if (!session) return -1;
     return ((gpuSession *) session)->p.factoredDotLayers();
 }
+uint64_t zkcnn_session_dot_deferred_phases(void *session) {
+    if (!session) return 0;
+    return ((gpuSession *) session)->p.dotDeferredPhases();
+}
 
 int32_t zkcnn_session_profile(void *session, uint32_t class_mask) {
     if (!session) return -1;

@@ -92,6 +92,7 @@ public:
     void setConvHints(const zk_conv_hint *hints, size_t n) { conv_hints.assign(hints, hints + n); }
     int structuredLayers() const { return ctx ? zk_structured_layers(ctx) : 0; }
     int factoredDotLayers() const { return ctx ? zk_factored_dot_layers(ctx) : 0; }
+    uint64_t dotDeferredPhases() const { return ctx ? zk_dot_deferred_phases(ctx) : 0; }
 private:
     vector<zk_layer_desc> layerDescs() const;
     bool program_resident = false;
