@@ -1014,9 +1014,11 @@ def main():
                                "note": "the commitment's scalar pre-pass and MSM kernels of one single-stream proof (HIP events): integer-ALU work, not HBM traffic"}
         small = roofline["frac"] < 0.15 and (not roofline.get("alu") or roofline["alu"]["frac_single_stream"] < 0.5)
         roofline["bound"] = "latency" if small else roofline["bound"]
-        roofline["bound_note"] = ("per launch the dominant class reaches a few percent of the HBM roof and the proof a fraction of the multiplier ceiling: its launches are "
-                                  "short dependent chains (two to seven Fr products) behind a launch and a host hand-over; the SAME kernel on a 2 x 2^24-entry launch "
-                                  "(streaming_launch) runs at the multiplier ceiling") if small else "see streaming_launch"
+        roofline["bound_note"] = ("per launch the dominant class reaches a fraction of the HBM roof: most of its launches are short dependent chains behind a launch and a host "
+                                  "hand-over, and in the timed shape they share the GPU with six other batches (classes.round_quad: the same launches uncontended; time against "
+                                  "size: profiles/r05_launch_sizes.md); the SAME kernel on a 2 x 2^24-entry launch (streaming_launch) runs at 0.6 of the HBM peak = 0.8 of a plain copy "
+                                  "with its read:write mix, and at streaming_launch.frac_of_mul_ceiling of the multiplier: neither roof is reached, VALU issue is the nearer one "
+                                  "(profiles/r05_round_quad_pmc.md)") if small else "see streaming_launch"
 
     leave(build_out, "roofline (HIP events); CPU baseline, the transcript comparison with it and the PMC traffic passes not run yet")
     stage("cpu baseline")
@@ -1078,7 +1080,7 @@ def main():
             roofline["traffic"] = round(pmc["bytes_per_launch"], 1)
             roofline["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over {pmc['launches']} launches of {', '.join(pmc['kernels'])} in four "
                                           f"single-stream proofs with every round a launch; counter units calibrated IN THE SAME PASS on the same kernel's 2 x 2^24-entry launch (known bytes): "
-                                          f"{pmc['bytes_per_counter_unit']} bytes per unit (the guide's x2 for FETCH_SIZE holds for 16-byte-per-lane streams; this kernel's lanes read 128 contiguous bytes each)")
+                                          f"{pmc['bytes_per_counter_unit']} bytes per unit (the guide's x2 for FETCH_SIZE is for 16-byte-per-lane streams; the calibration launch IS this kernel, so its own access width is what gets calibrated)")
             roofline["traffic_over_algorithmic"] = round(pmc["bytes_per_launch"] / max(lat_prof["bytes"] / max(lat_prof["launches"], 1), 1.0), 3)
         else:
             roofline["traffic_source"] = "rocprofv3 not available (or the counter pass failed): not measured"
