@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel trace of bench.py (single stream and default streams) -> gpurun_out/<tag>_{s1,sK}.md  (copy the ones to keep into profiles/)
-# usage: scripts/kernel_stats.sh <tag>
+# usage: [WORKLOAD=vgg11_pp8] [SHAPES="1 4:4 56"] scripts/kernel_stats.sh <tag>      (a shape is <proofs in flight>[:<lanes per batch>])
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 TAG=${1:-prof}
@@ -9,16 +9,17 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # S = proofs in flight: 1 = a lone proof (resident round kernels), 56 = seven lock-step batches of eight lanes (the default bench shape)
 for S in ${SHAPES:-1 56}; do
+  LANES=8; [ $S = 1 ] && LANES=1
+  case $S in *:*) LANES=${S#*:}; S=${S%:*};; esac
   D=$OUT/${TAG}_s$S
   rm -rf $D
-  LANES=8; [ $S = 1 ] && LANES=1
-  rocprofv3 --kernel-trace --stats -d $D -o trace -- python $ROOT/bench.py --inner --steps 5 --warmup 2 --streams $S --lanes $LANES --no-cpu-baseline --no-companions --no-pmc > $OUT/${TAG}_s$S.log 2>&1 || true
+  rocprofv3 --kernel-trace --stats -d $D -o trace -- python $ROOT/bench.py --inner ${WORKLOAD:+--workload $WORKLOAD} --steps ${STEPS:-5} --warmup 2 --streams $S --lanes $LANES --no-cpu-baseline --no-companions --no-pmc > $OUT/${TAG}_s$S.log 2>&1 || true
   python - <<PY
 import glob, sqlite3, json
 dbs = glob.glob("$D/**/*.db", recursive=True)
 out = open("$OUT/${TAG}_s$S.md", "w")
 line = [l for l in open("$OUT/${TAG}_s$S.log") if l.startswith("{")]
-out.write("# rocprofv3 --kernel-trace --stats -- python bench.py --inner --steps 5 --warmup 2 --streams $S --lanes " + ("1" if "$S" == "1" else "8") + " --no-cpu-baseline --no-companions --no-pmc\n\n")
+out.write("# rocprofv3 --kernel-trace --stats -- python bench.py --inner ${WORKLOAD:+--workload $WORKLOAD} --steps ${STEPS:-5} --warmup 2 --streams $S --lanes $LANES --no-cpu-baseline --no-companions --no-pmc\n\n")
 if line:
     d = json.loads(line[-1])
     out.write("bench line under the profiler: value %.2f proofs/s, prover_ms_per_image %.1f, roofline %s\n\n" % (d["value"], d["prover_ms_per_image"], json.dumps({k: d["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")})))

@@ -301,7 +301,10 @@ extern "C" int32_t zk_batch_attach(zk_batch *b, zk_ctx *ctx, int32_t *lane) {
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return ZK_ERR_HIP;
     ctx->fs_state = nullptr;
     ctx->fs_pending = nullptr;
-    ctx->own_stream = ctx->stream;
+    // A lane launches on the batch's stream; its own stream is not kept around idle: 56 lanes' streams next to 7 batch streams are 56 HIP streams (hardware-queue
+    // slots, profiler buffers -- rocprofv3 --kernel-trace crashed processes with >= 40 session streams in round 4) that nothing uses. It is created again at detach.
+    if (hipStreamDestroy(ctx->stream) != hipSuccess) return ZK_ERR_HIP;
+    ctx->own_stream = nullptr;
     ctx->stream = b->stream;
     ctx->batch = b;
     ctx->live_now = false;
@@ -315,8 +318,8 @@ extern "C" int32_t zk_batch_detach(zk_batch *b, zk_ctx *ctx) {
     (void) hipSetDevice(b->device);
     (void) zk_batch_flush(b);
     (void) hipStreamSynchronize(b->stream);
-    ctx->stream = ctx->own_stream;
-    ctx->own_stream = nullptr;
+    ctx->stream = nullptr;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->stream = nullptr; b->err = "zk_batch_detach: no stream for the detached context"; }
     ctx->batch = nullptr;
     ctx->n_pending = 0;
     ctx->live_now = true;

@@ -91,6 +91,14 @@ __device__ __forceinline__ void fp_store16(fp_t *p, const fp_t &a) {
     q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
     q[2] = make_uint4(a.v[8], a.v[9], a.v[10], a.v[11]);
 }
+__device__ __forceinline__ fp_t fp_load16(const fp_t *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    fp_t z;
+    z.v[0] = a.x; z.v[1] = a.y; z.v[2] = a.z; z.v[3] = a.w; z.v[4] = b.x; z.v[5] = b.y; z.v[6] = b.z; z.v[7] = b.w;
+    z.v[8] = c.x; z.v[9] = c.y; z.v[10] = c.z; z.v[11] = c.w;
+    return z;
+}
 __device__ __forceinline__ void g1j_store(g1j_t *p, const fp_t &X, const fp_t &Y, const fp_t &Z, bool empty) {
     fp_store16(&p->X, empty ? fp_zero() : X);
     fp_store16(&p->Y, empty ? fp_one() : Y);
@@ -114,6 +122,77 @@ __device__ __forceinline__ void g1_accumulate(fp_t &X, fp_t &Y, fp_t &Z, bool &e
             else empty = true;             // P + (-P)
         } else exc = true;                 // the host repeats the batch with SAFE = true
     }
+}
+
+// ---- the same step on XYZZ coordinates (x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2; madd-2008-s): 8 M + 2 S = 10 calls of the shared Fp product
+// instead of the 11 of the Jacobian mixed addition, for one more coordinate in registers (round 5: the commitment's hot kernel, which runs at the
+// multiplier's rate, i.e. 10 / 11 of the time). At most seven field elements live across a call. ----
+// Y lives in the lane's 48-byte LDS slot `park` between additions: it is needed twice per addition (R = S2 - Y, Y3 = R (Q - X3) - Y PPP) and never across
+// a product otherwise, so three coordinates stay in registers like the Jacobian form's -- the third wave per SIMD depends on it (180 VGPRs with Y in registers).
+__device__ __forceinline__ bool g1_madd_xyzz_ip(fp_t &X, fp_t *park, fp_t &ZZ, fp_t &ZZZ, fp_t &px, fp_t &py, bool *same) {
+    px = fp_mul(px, ZZ);                   // U2
+    py = fp_mul(py, ZZZ);                  // S2
+    px = fp_sub(px, X);                    // P
+    py = fp_sub(py, fp_load16(park));      // R
+    asm volatile("" ::: "memory");
+    if (fp_is_zero(px)) {
+        *same = fp_is_zero(py);
+        return false;
+    }
+    fp_t A = fp_sqr(px);                   // PP
+    ZZ = fp_mul(ZZ, A);
+    px = fp_mul(px, A);                    // PPP
+    A = fp_mul(X, A);                      // Q
+    X = fp_sqr(py);
+    X = fp_sub(fp_sub(X, px), fp_dbl(A));  // X3 = R^2 - PPP - 2 Q
+    A = fp_sub(A, X);
+    A = fp_mul(py, A);                     // R (Q - X3)
+    asm volatile("" ::: "memory");         // (a second, late load of Y: merged with the first one it would stay in registers across every product above)
+    py = fp_load16(park);
+    py = fp_mul(py, px);                   // Y1 PPP
+    fp_store16(park, fp_sub(A, py));
+    ZZZ = fp_mul(ZZZ, px);                 // (last: nothing else is live by now but X and ZZ)
+    return true;
+}
+// doubling on XYZZ (dbl-2008-s-1, a = 0): 6 M + 3 S; infinity (ZZ = 0) stays infinity
+__device__ __forceinline__ void g1_dbl_xyzz_ip(fp_t &X, fp_t *park, fp_t &ZZ, fp_t &ZZZ) {
+    fp_t Y = fp_load16(park);
+    fp_t U = fp_dbl(Y);
+    fp_t V = fp_sqr(U);
+    fp_t W = fp_mul(U, V);
+    fp_t S = fp_mul(X, V);
+    fp_t M = fp_sqr(X);
+    M = fp_add(fp_dbl(M), M);              // 3 X^2
+    X = fp_sub(fp_sqr(M), fp_dbl(S));
+    S = fp_sub(S, X);
+    S = fp_mul(M, S);
+    Y = fp_mul(W, Y);
+    fp_store16(park, fp_sub(S, Y));
+    ZZ = fp_mul(V, ZZ);
+    ZZZ = fp_mul(W, ZZZ);
+}
+template <bool SAFE>
+__device__ __forceinline__ void g1_accumulate_xyzz(fp_t &X, fp_t *park, fp_t &ZZ, fp_t &ZZZ, bool &empty, fp_t &px, fp_t &py, bool neg, bool &exc) {
+    if (fp_is_zero(px) && fp_is_zero(py)) return;          // (0, 0) = the point at infinity
+    if (neg) py = fp_neg(py);
+    if (empty) {
+        X = px; fp_store16(park, py); ZZ = fp_one(); ZZZ = fp_one();
+        empty = false;
+        return;
+    }
+    bool same = false;
+    if (!g1_madd_xyzz_ip(X, park, ZZ, ZZZ, px, py, &same)) {
+        if (SAFE) {
+            if (same) g1_dbl_xyzz_ip(X, park, ZZ, ZZZ);
+            else empty = true;             // P + (-P)
+        } else exc = true;
+    }
+}
+// the Jacobian point of an XYZZ accumulator: (X ZZ, Y ZZZ, ZZ)  [x = X ZZ / ZZ^2, y = Y ZZZ / ZZ^3]
+__device__ __forceinline__ void g1j_store_xyzz(g1j_t *p, const fp_t &X, const fp_t *park, const fp_t &ZZ, const fp_t &ZZZ, bool empty) {
+    if (empty) { g1j_store(p, X, X, ZZ, true); return; }
+    const fp_t jx = fp_mul(X, ZZ), jy = fp_mul(fp_load16(park), ZZZ);
+    g1j_store(p, jx, jy, ZZ, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -292,7 +371,8 @@ __device__ __forceinline__ void k_msm_codes(g1j_t *out, uint32_t *exc_flag, cons
         const uint32_t c = base_c + i * MSM_BLOCK;
         if (c < cols && (rc[c] & 0xffu)) mask |= 1ull << i;
     }
-    fp_t X = fp_zero(), Y = fp_zero(), Z = fp_zero();
+    __shared__ fp_t park[MSM_BLOCK];
+    fp_t X = fp_zero(), ZZ = fp_zero(), ZZZ = fp_zero();      // XYZZ accumulator (Y in the lane's LDS slot): 10 products per addition instead of 11
     bool empty = true, exc = false;
     // the code of the NEXT column is fetched one addition ahead (one register); the table point itself is loaded where it is used: its
     // latency (an L2 / Infinity-Cache hit: the digit table of 4096 generators is 100 MB) is a few percent of the ~14 us addition and the
@@ -316,10 +396,10 @@ __device__ __forceinline__ void k_msm_codes(g1j_t *out, uint32_t *exc_flag, cons
         if (cur) {
             fp_t px, py;
             g1a_load(px, py, D + (size_t) (code & 0xffu) * m + c);
-            g1_accumulate<SAFE>(X, Y, Z, empty, px, py, (code & MSM_CODE_NEG) != 0, exc);
+            g1_accumulate_xyzz<SAFE>(X, park + lane, ZZ, ZZZ, empty, px, py, (code & MSM_CODE_NEG) != 0, exc);
         }
     }
-    g1j_store(dst, X, Y, Z, empty);
+    g1j_store_xyzz(dst, X, park + lane, ZZ, ZZZ, empty);
     if (!SAFE && exc) *exc_flag = 1;
 }
 
