@@ -39,13 +39,18 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t
 ss[0].profile_report(reset=True)
 rows = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0, 0.0]))
+longest = collections.defaultdict(list)
 for line in open(dump):
     c, b, ms = line.split()
     b, ms = float(b), float(ms)
+    longest[c].append(ms)
     e = rows[c][int(math.log2(b)) if b > 0 else -1]
     e[0] += 1; e[1] += ms; e[2] += b
 print(f"{model} pic_cnt={pp}, {k} lanes, one batch proof alone: {1e3 * dt:.1f} ms wall (HIP events on every launch)")
 print("\nall classes: " + ", ".join(f"{c} {sum(e[1] for e in rows[c].values()):.2f} ms / {sum(e[0] for e in rows[c].values())}" for c in sorted(rows, key=lambda c: -sum(e[1] for e in rows[c].values()))))
+for c in sorted(longest):
+    ls = sorted(longest[c], reverse=True)
+    print(f"{c}: longest launches (us): " + " ".join(f"{1e3 * x:.0f}" for x in ls[:16]) + f" | {sum(1 for x in ls if x < 0.03)} launches under 30 us = {sum(x for x in ls if x < 0.03):.2f} ms")
 for c in want:
     if c not in rows:
         continue

@@ -21,6 +21,9 @@ void zk_set_create_error(const std::string &msg) { g_create_err = msg; }
 int32_t zk_dev_alloc(zk_ctx *ctx, void **p, size_t bytes) {
     if (bytes == 0) bytes = 32;
     ZK_HIP(hipMalloc(p, bytes));
+    // ZKCNN_ALLOC_TRACE=1: every tracked allocation of 64 MB or more on stderr (where a session's HBM goes: DESIGN.md section 6, round 5)
+    static const bool trace = getenv("ZKCNN_ALLOC_TRACE") != nullptr;
+    if (trace && bytes >= ((size_t) 64 << 20)) fprintf(stderr, "[zkcnn alloc] %s %.3f GB (allocation %zu of this context)\n", ctx->alloc_sink ? "shared" : "session", bytes / 1e9, ctx->owned.size());
     (ctx->alloc_sink ? *ctx->alloc_sink : ctx->owned).push_back(*p);       // (the static part of a circuit belongs to its registry entry)
     if (ctx->alloc_sink) ctx->sink_bytes += bytes;
     return ZK_OK;

@@ -1056,7 +1056,11 @@ static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, ui
     HFr claim(0LL);
     if (skip_p1) claim = (ctx->last_poly[0] * r + ctx->last_poly[1]) * r + ctx->last_poly[2];
     // small tables are latency bound: spread each quad over 4 lanes (k_round_quad2, `fine`)
-    const int fine_log = policy::FINE_LOG;
+    // (experiment switch: ZKCNN_TEST_HOOKS=1 ZKCNN_TEST_FINE_LOG=<14..18> moves the switch-over between the latency kernel and the streaming kernel)
+    static const int fine_log = [] {
+        const char *hooks = getenv("ZKCNN_TEST_HOOKS"), *v = getenv("ZKCNN_TEST_FINE_LOG");
+        return (hooks && atoi(hooks) && v) ? std::max(12, std::min(atoi(v), ZK_FULL_TABLE_LOG)) : policy::FINE_LOG;
+    }();
     // (one block per 64 quads and 3 partial sums per block: both pairs together must stay within the partials buffer)
     const uint64_t longest = std::max(ctx->tp[0].len, ctx->tp[1].len);
     const bool fine = longest <= (1ull << fine_log) && 2 * (longest / 4 / (ZK_BLOCK / 4) + 1) <= ctx->partial_blocks;
