@@ -17,7 +17,7 @@ model = sys.argv[1] if len(sys.argv) > 1 else "vgg11"
 pp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 want = sys.argv[4].split(",") if len(sys.argv) > 4 else ["round_quad", "round_cubic", "fold", "gate_reduce", "round_fine"]
-mode = M.MODE_REUSE_GENS | M.MODE_DRIVE_ONLY | M.MODE_SEEDED
+mode = int(os.environ["MODE_BITS"], 0) if os.environ.get("MODE_BITS") else (M.MODE_REUSE_GENS | M.MODE_DRIVE_ONLY | M.MODE_SEEDED)      # e.g. MODE_BITS=0x81: fresh generators, full argument
 ss = [M.Session(model, (32, 32, 3), pp) for _ in range(k)]
 for i, s in enumerate(ss[1:], 1):
     for ps in range(1000 * i, 1000 * i + 64):

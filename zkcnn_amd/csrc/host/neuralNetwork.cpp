@@ -539,19 +539,19 @@ void neuralNetwork::emitInput(layer &L) {
     loadPicture(L);
 }
 
-void neuralNetwork::emitPadding(layer &L, i64 &layer_id, i64 first_conv_id) {
+void neuralNetwork::emitPadding(layer &L, i64 &layer_id, i64 weight_base) {
     const i64 lenh = (1LL << fftBits()) >> 1;
     initLayer(L, lenh * channel_in * (pic_parallel + channel_out), layerType::PADDING);
     L.fft_bit_length = (i8) fftBits();
 
     // data: written reversed so that the linear convolution lands where ADD_BIAS reads it
-    const i64 lo = -padding, Rx = nx_in + padding, Ry = ny_in + padding;
+    const i64 lo = -padding, x_end = nx_in + padding, y_end = ny_in + padding;
     for (i64 p = 0; p < pic_parallel; ++p)
         for (i64 ci = 0; ci < channel_in; ++ci)
-            for (i64 x = lo; x < Rx; ++x)
-                for (i64 y = lo; y < Ry; ++y) {
+            for (i64 x = lo; x < x_end; ++x)
+                for (i64 y = lo; y < y_end; ++y) {
                     if (!check(x, y, nx_in, ny_in)) continue;
-                    i64 g = cubIdx(p, ci, matIdx(Rx - x - 1, Ry - y - 1, ny_padded_in), channel_in, lenh);
+                    i64 g = cubIdx(p, ci, matIdx(x_end - x - 1, y_end - y - 1, ny_padded_in), channel_in, lenh);
                     i64 u = tesIdx(p, ci, x, y, channel_in, nx_in, ny_in);
                     L.uni_gates.emplace_back((u32) g, (u32) u, (u8) (layer_id - 1), (u8) 0);
                 }
@@ -563,10 +563,10 @@ void neuralNetwork::emitPadding(layer &L, i64 &layer_id, i64 first_conv_id) {
                 for (i64 y = 0; y < ny_padded_in; ++y) {
                     if (!check(x, y, m, m)) continue;
                     i64 g = first + cubIdx(co, ci, matIdx(x, y, ny_padded_in), channel_in, lenh);
-                    i64 u = first_conv_id + tesIdx(co, ci, x, y, channel_in, m, m);
+                    i64 u = weight_base + tesIdx(co, ci, x, y, channel_in, m, m);
                     L.uni_gates.emplace_back((u32) g, (u32) u, (u8) 0, (u8) 0);
                 }
-    loadConvWeight(first_conv_id);
+    loadConvWeight(weight_base);
     evalGates(L, layer_id);
     ++layer_id;
 }
@@ -600,98 +600,98 @@ void neuralNetwork::emitIFFT(layer &L, i64 &layer_id) {
     ++layer_id;
 }
 
-void neuralNetwork::emitAddBias(layer &L, i64 &layer_id, i64 first_bias_id) {
+void neuralNetwork::emitAddBias(layer &L, i64 &layer_id, i64 bias_base) {
     initLayer(L, nx_out * ny_out * channel_out * pic_parallel, layerType::ADD_BIAS);
     const i64 lenh = (1LL << fftBits()) >> 1;
-    const i64 lo = -padding, Rx = nx_in + padding, Ry = ny_in + padding, st = 1LL << log_stride;
+    const i64 lo = -padding, x_end = nx_in + padding, y_end = ny_in + padding, st = 1LL << log_stride;
     for (i64 p = 0; p < pic_parallel; ++p)
         for (i64 co = 0; co < channel_out; ++co)
-            for (i64 x = lo; x + m <= Rx; x += st)
-                for (i64 y = lo; y + m <= Ry; y += st) {
-                    i64 u = cubIdx(p, co, matIdx(Rx - x - 1, Ry - y - 1, ny_padded_in), channel_out, lenh);
+            for (i64 x = lo; x + m <= x_end; x += st)
+                for (i64 y = lo; y + m <= y_end; y += st) {
+                    i64 u = cubIdx(p, co, matIdx(x_end - x - 1, y_end - y - 1, ny_padded_in), channel_out, lenh);
                     i64 g = tesIdx(p, co, (x - lo) >> log_stride, (y - lo) >> log_stride, channel_out, nx_out, ny_out);
-                    L.uni_gates.emplace_back((u32) g, (u32) (first_bias_id + co), (u8) 0, (u8) 0);
+                    L.uni_gates.emplace_back((u32) g, (u32) (bias_base + co), (u8) 0, (u8) 0);
                     L.uni_gates.emplace_back((u32) g, (u32) u, (u8) (layer_id - 1), (u8) 0);
                 }
-    loadBias(first_bias_id);
+    loadBias(bias_base);
     evalGates(L, layer_id);
     ++layer_id;
 }
 
-void neuralNetwork::emitConvFast(layer &L, i64 &layer_id, i64 first_conv_id, i64 first_bias_id) {
+void neuralNetwork::emitConvFast(layer &L, i64 &layer_id, i64 weight_base, i64 bias_base) {
     initLayer(L, nx_out * ny_out * channel_out * pic_parallel, layerType::NCONV);
     L.need_phase2 = true;
-    const i64 lo = -padding, Rx = nx_in + padding, Ry = ny_in + padding, st = 1LL << log_stride;
+    const i64 lo = -padding, x_end = nx_in + padding, y_end = ny_in + padding, st = 1LL << log_stride;
     const u8 lcode = (u8) (2 * (layer_id > 1));
     L.bin_gates.reserve((size_t) (pic_parallel * channel_out * channel_in * nx_out * ny_out * m * m));
     for (i64 p = 0; p < pic_parallel; ++p)
         for (i64 co = 0; co < channel_out; ++co)
             for (i64 ci = 0; ci < channel_in; ++ci)
-                for (i64 x = lo; x + m <= Rx; x += st)
-                    for (i64 y = lo; y + m <= Ry; y += st) {
+                for (i64 x = lo; x + m <= x_end; x += st)
+                    for (i64 y = lo; y + m <= y_end; y += st) {
                         i64 g = tesIdx(p, co, (x - lo) >> log_stride, (y - lo) >> log_stride, channel_out, nx_out, ny_out);
-                        if (ci == 0 && ~first_bias_id)
-                            L.uni_gates.emplace_back((u32) g, (u32) (first_bias_id + co), (u8) 0, (u8) 0);
-                        for (i64 tx = x; tx < x + m; ++tx)
-                            for (i64 ty = y; ty < y + m; ++ty) {
-                                if (!check(tx, ty, nx_in, ny_in)) continue;
-                                i64 u = tesIdx(p, ci, tx, ty, channel_in, nx_in, ny_in);
-                                i64 v = first_conv_id + tesIdx(co, ci, tx - x, ty - y, channel_in, m, m);
+                        if (ci == 0 && ~bias_base)
+                            L.uni_gates.emplace_back((u32) g, (u32) (bias_base + co), (u8) 0, (u8) 0);
+                        for (i64 wx = x; wx < x + m; ++wx)
+                            for (i64 wy = y; wy < y + m; ++wy) {
+                                if (!check(wx, wy, nx_in, ny_in)) continue;
+                                i64 u = tesIdx(p, ci, wx, wy, channel_in, nx_in, ny_in);
+                                i64 v = weight_base + tesIdx(co, ci, wx - x, wy - y, channel_in, m, m);
                                 L.bin_gates.emplace_back((u32) g, (u32) u, (u32) v, (u8) 0, lcode);
                             }
                     }
     {
         convHint h = {(i32) layer_id, (u32) pic_parallel, (u32) channel_out, (u32) channel_in, (u32) nx_in, (u32) ny_in, (u32) nx_out, (u32) ny_out,
-                      (u32) m, (u32) padding, (u32) log_stride, (u32) first_conv_id};
+                      (u32) m, (u32) padding, (u32) log_stride, (u32) weight_base};
         conv_hints.push_back(h);
     }
-    loadConvWeight(first_conv_id);
-    if (~first_bias_id) loadBias(first_bias_id);
+    loadConvWeight(weight_base);
+    if (~bias_base) loadBias(bias_base);
     evalGates(L, layer_id);
     ++layer_id;
 }
 
-void neuralNetwork::emitConvMul(layer &L, i64 &layer_id, i64 first_conv_id) {
-    const i64 lo = -padding, Rx = nx_in + padding, Ry = ny_in + padding, st = 1LL << log_stride;
+void neuralNetwork::emitConvMul(layer &L, i64 &layer_id, i64 weight_base) {
+    const i64 lo = -padding, x_end = nx_in + padding, y_end = ny_in + padding, st = 1LL << log_stride;
     const u8 lcode = (u8) (2 * (layer_id > 1));
     i64 g = 0;
     for (i64 p = 0; p < pic_parallel; ++p)
         for (i64 co = 0; co < channel_out; ++co)
             for (i64 ci = 0; ci < channel_in; ++ci)
-                for (i64 x = lo; x + m <= Rx; x += st)
-                    for (i64 y = lo; y + m <= Ry; y += st)
-                        for (i64 tx = x; tx < x + m; ++tx)
-                            for (i64 ty = y; ty < y + m; ++ty) {
-                                if (!check(tx, ty, nx_in, ny_in)) continue;
-                                i64 u = tesIdx(p, ci, tx, ty, channel_in, nx_in, ny_in);
-                                i64 v = first_conv_id + tesIdx(co, ci, tx - x, ty - y, channel_in, m, m);
+                for (i64 x = lo; x + m <= x_end; x += st)
+                    for (i64 y = lo; y + m <= y_end; y += st)
+                        for (i64 wx = x; wx < x + m; ++wx)
+                            for (i64 wy = y; wy < y + m; ++wy) {
+                                if (!check(wx, wy, nx_in, ny_in)) continue;
+                                i64 u = tesIdx(p, ci, wx, wy, channel_in, nx_in, ny_in);
+                                i64 v = weight_base + tesIdx(co, ci, wx - x, wy - y, channel_in, m, m);
                                 L.bin_gates.emplace_back((u32) g++, (u32) u, (u32) v, (u8) 0, lcode);
                             }
     initLayer(L, g, layerType::NCONV_MUL);
     L.need_phase2 = true;
-    loadConvWeight(first_conv_id);
+    loadConvWeight(weight_base);
     evalGates(L, layer_id);
     ++layer_id;
 }
 
-void neuralNetwork::emitConvAdd(layer &L, i64 &layer_id, i64 first_bias_id) {
+void neuralNetwork::emitConvAdd(layer &L, i64 &layer_id, i64 bias_base) {
     initLayer(L, nx_out * ny_out * channel_out * pic_parallel, layerType::NCONV_ADD);
-    const i64 lo = -padding, Rx = nx_in + padding, Ry = ny_in + padding, st = 1LL << log_stride;
+    const i64 lo = -padding, x_end = nx_in + padding, y_end = ny_in + padding, st = 1LL << log_stride;
     i64 u = 0;
     for (i64 p = 0; p < pic_parallel; ++p)
         for (i64 co = 0; co < channel_out; ++co)
             for (i64 ci = 0; ci < channel_in; ++ci)
-                for (i64 x = lo; x + m <= Rx; x += st)
-                    for (i64 y = lo; y + m <= Ry; y += st) {
+                for (i64 x = lo; x + m <= x_end; x += st)
+                    for (i64 y = lo; y + m <= y_end; y += st) {
                         i64 g = tesIdx(p, co, (x - lo) >> log_stride, (y - lo) >> log_stride, channel_out, nx_out, ny_out);
-                        if (ci == 0 && ~first_bias_id)
-                            L.uni_gates.emplace_back((u32) g, (u32) (first_bias_id + co), (u8) 0, (u8) 0);
-                        for (i64 tx = x; tx < x + m; ++tx)
-                            for (i64 ty = y; ty < y + m; ++ty)
-                                if (check(tx, ty, nx_in, ny_in))
+                        if (ci == 0 && ~bias_base)
+                            L.uni_gates.emplace_back((u32) g, (u32) (bias_base + co), (u8) 0, (u8) 0);
+                        for (i64 wx = x; wx < x + m; ++wx)
+                            for (i64 wy = y; wy < y + m; ++wy)
+                                if (check(wx, wy, nx_in, ny_in))
                                     L.uni_gates.emplace_back((u32) g, (u32) u++, (u8) (layer_id - 1), (u8) 0);
                     }
-    if (~first_bias_id) loadBias(first_bias_id);
+    if (~bias_base) loadBias(bias_base);
     evalGates(L, layer_id);
     ++layer_id;
 }
@@ -761,9 +761,9 @@ void neuralNetwork::emitAvgPool(layer &L, i64 &layer_id) {
                     i64 g = tesIdx(p, co, x >> pool_stride_bl, y >> pool_stride_bl, channel_out, new_nx_in, new_ny_in);
                     F sum = F_ZERO;
                     vector<u32> window;
-                    for (i64 tx = x; tx < x + pool_sz; ++tx)
-                        for (i64 ty = y; ty < y + pool_sz; ++ty) {
-                            i64 u = tesIdx(p, co, tx, ty, channel_out, nx_out, ny_out);
+                    for (i64 wx = x; wx < x + pool_sz; ++wx)
+                        for (i64 wy = y; wy < y + pool_sz; ++wy) {
+                            i64 u = tesIdx(p, co, wx, wy, channel_out, nx_out, ny_out);
                             L.uni_gates.emplace_back((u32) g, (u32) u, (u8) (layer_id - 1), (u8) 0);
                             if (!structure_only) sum = sum + val[layer_id - 1][u];
                             window.push_back((u32) u);
@@ -811,10 +811,10 @@ void neuralNetwork::emitMaxPool(layeredCircuit &C, i64 &layer_id) {
                     for (i64 y = 0; y + pool_sz <= ny_out; y += pool_stride) {
                         i64 i_max = tesIdx(p, co, x >> pool_stride_bl, y >> pool_stride_bl, channel_out, new_nx_in, new_ny_in);
                         i64 u_max = first_max_id + i_max;
-                        for (i64 tx = x; tx < x + pool_sz; ++tx)
-                            for (i64 ty = y; ty < y + pool_sz; ++ty) {
-                                i64 g = cubIdx(i_max, tx - x, ty - y, pool_sz, pool_sz);
-                                i64 u_g = tesIdx(p, co, tx, ty, channel_out, nx_out, ny_out);
+                        for (i64 wx = x; wx < x + pool_sz; ++wx)
+                            for (i64 wy = y; wy < y + pool_sz; ++wy) {
+                                i64 g = cubIdx(i_max, wx - x, wy - y, pool_sz, pool_sz);
+                                i64 u_g = tesIdx(p, co, wx, wy, channel_out, nx_out, ny_out);
                                 L.uni_gates.emplace_back((u32) g, (u32) u_max, (u8) 0, (u8) 0);
                                 L.uni_gates.emplace_back((u32) g, (u32) u_g, (u8) (layer_id - 1), (u8) (Q_BIT_SIZE + 1));
                                 putMax(layer_id - 1, u_g, u_max);
@@ -891,7 +891,7 @@ void neuralNetwork::emitMaxPool(layeredCircuit &C, i64 &layer_id) {
     }
 }
 
-void neuralNetwork::emitFC(layer &L, i64 &layer_id, i64 first_fc_id, i64 first_bias_id) {
+void neuralNetwork::emitFC(layer &L, i64 &layer_id, i64 first_fc_id, i64 bias_base) {
     initLayer(L, channel_out * pic_parallel, layerType::FCONN);
     L.need_phase2 = true;
     const u8 lcode = (u8) (2 * (layer_id > 1));
@@ -899,13 +899,13 @@ void neuralNetwork::emitFC(layer &L, i64 &layer_id, i64 first_fc_id, i64 first_b
     for (i64 p = 0; p < pic_parallel; ++p)
         for (i64 co = 0; co < channel_out; ++co) {
             i64 g = matIdx(p, co, channel_out);
-            L.uni_gates.emplace_back((u32) g, (u32) (first_bias_id + co), (u8) 0, (u8) 0);
+            L.uni_gates.emplace_back((u32) g, (u32) (bias_base + co), (u8) 0, (u8) 0);
             for (i64 ci = 0; ci < channel_in; ++ci)
                 L.bin_gates.emplace_back((u32) g, (u32) matIdx(p, ci, channel_in),
                                          (u32) (first_fc_id + matIdx(co, ci, channel_in)), (u8) 0, lcode);
         }
     loadFcWeight(first_fc_id);
-    loadBias(first_bias_id);
+    loadBias(bias_base);
     evalGates(L, layer_id);
     ++layer_id;
 }

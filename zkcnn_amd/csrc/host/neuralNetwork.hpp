@@ -233,17 +233,17 @@ private:
 
     // layer emitters
     void emitInput(layer &L);
-    void emitPadding(layer &L, i64 &layer_id, i64 first_conv_id);
+    void emitPadding(layer &L, i64 &layer_id, i64 weight_base);
     void emitFFT(layer &L, i64 &layer_id);
     void emitDotProd(layer &L, i64 &layer_id);
     void emitIFFT(layer &L, i64 &layer_id);
-    void emitAddBias(layer &L, i64 &layer_id, i64 first_bias_id);
-    void emitConvFast(layer &L, i64 &layer_id, i64 first_conv_id, i64 first_bias_id);
-    void emitConvMul(layer &L, i64 &layer_id, i64 first_conv_id);
-    void emitConvAdd(layer &L, i64 &layer_id, i64 first_bias_id);
+    void emitAddBias(layer &L, i64 &layer_id, i64 bias_base);
+    void emitConvFast(layer &L, i64 &layer_id, i64 weight_base, i64 bias_base);
+    void emitConvMul(layer &L, i64 &layer_id, i64 weight_base);
+    void emitConvAdd(layer &L, i64 &layer_id, i64 bias_base);
     void emitRelu(layer &L, i64 &layer_id, i64 block_len);
     void emitAvgPool(layer &L, i64 &layer_id);
     void emitMaxPool(layeredCircuit &C, i64 &layer_id);
-    void emitFC(layer &L, i64 &layer_id, i64 first_fc_id, i64 first_bias_id);
+    void emitFC(layer &L, i64 &layer_id, i64 first_fc_id, i64 bias_base);
     void reportInference(const layeredCircuit &C);
 };
