@@ -42,4 +42,5 @@ for db in dbs:
 out.close()
 print(open("$OUT/${TAG}_s$S.md").read())
 PY
+  rm -rf $D          # (the trace database is tens of MB; gpurun brings back at most 64 MiB)
 done
