@@ -573,8 +573,13 @@ def main():
             except BaseException as e:      # noqa: BLE001
                 errs_b.append(e)
         th_b = [threading.Thread(target=run_b, args=(j,)) for j in range(B)]
-        [t.start() for t in th_b]
-        [t.join() for t in th_b]
+        if os.environ.get("ZKCNN_BENCH_SERIAL_WARM"):          # experiment: the batches' first proofs (and with them the streams' first launches) one after the other
+            for t in th_b:
+                t.start()
+                t.join()
+        else:
+            [t.start() for t in th_b]
+            [t.join() for t in th_b]
         if errs_b:
             raise errs_b[0]
         # one batch proof with nothing else on the GPU and events on every class: what a FUSED launch of each kernel class costs uncontended
