@@ -260,6 +260,33 @@ def pin_to_gpu_numa_node(torch, local_rank):
         return -1
 
 
+def physical_cores(cpus):
+    """one logical CPU per physical core among `cpus` (the first SMT sibling of each), sorted"""
+    seen, out = set(), []
+    for c in sorted(cpus):
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            out.append(c)
+    return out
+
+
+def pin_worker(j, n_workers):
+    """ZKCNN_BENCH_PIN_WORKERS=1 (experiment): worker j of this rank on a physical core of its own inside the rank's CPU set -- the workers spin on their
+    GPU's mailboxes and never sleep, so wherever the scheduler put them first is where they stay"""
+    if not os.environ.get("ZKCNN_BENCH_PIN_WORKERS"):
+        return
+    try:
+        cores = physical_cores(os.sched_getaffinity(0))
+        if len(cores) > n_workers + 1:
+            os.sched_setaffinity(0, {cores[1 + j]})          # (core 0 of the set is left to the main thread)
+    except Exception:       # noqa: BLE001
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -323,7 +350,7 @@ def main():
 
     model, pic, pp = WORKLOADS[args.workload]
     LANES = max(1, min(args.lanes, 8))
-    K = max(1, args.streams if args.streams else (7 * LANES if LANES > 1 else 8))
+    K = max(1, args.streams if args.streams else (6 * LANES if LANES > 1 else 8))      # round 5: 6 batches of 8 (4 / 5 / 6 / 7 / 8 batches: 147 / 155 / 161-163 / 154-157, sometimes 165 / 155.5 proofs/s on one box)
     try:                                # do not overcommit a small node
         import psutil
         K_ram = streams_that_fit(psutil.virtual_memory().available, world, K, clones=LANES > 1)
@@ -627,6 +654,7 @@ def main():
 
     def batch_stream(j):
         try:
+            pin_worker(j, B)
             for k in range(args.steps):
                 if j == 0 and k == EVENT_STEPS:
                     prof_box["report"] = sess.profile_report(reset=True)[dominant]
