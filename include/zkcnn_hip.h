@@ -107,6 +107,12 @@ int32_t zk_sumcheck_finalize2(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t cl
 int32_t zk_sumcheck_liu_init(zk_ctx *ctx, const uint64_t *s_u, const uint64_t *s_v, uint32_t n);    /* sumcheckLiuInit :312 */
 int32_t zk_sumcheck_liu_update(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t out_abc[12]);        /* :385 */
 int32_t zk_sumcheck_liu_finalize(zk_ctx *ctx, const uint64_t prev_r[4], uint64_t claim_1[4]);       /* :487 */
+/* zero-knowledge mode, masked evaluation claims (no reference counterpart: reference README.md:5 "not fully zero-knowledge"; protocol in
+ * zkcnn_amd/csrc/host/zk_mask.hpp (2)). After the LAST update call of a phase: what multiplies each operand in that round, A_b(t) = out[3b] + out[3b+1] t +
+ * out[3b+2] t^2 for the operand pairs b = 0, 1 (6 field elements) -- the host adds Z' t (1 - t) sum_b M_b A_b(t) to the polynomial. After
+ * zk_sumcheck_finalize1 / zk_sumcheck_dotprod_finalize1: the claims left the prover as claim_b + d_b, phase 2 is initialised from the masked values. */
+int32_t zk_sumcheck_tail_pairs(zk_ctx *ctx, uint64_t out[24]);
+int32_t zk_sumcheck_claims_adjust(zk_ctx *ctx, const uint64_t d0[4], const uint64_t d1[4]);
 uint64_t zk_proof_bytes(const zk_ctx *ctx);                                            /* proof_size counter  prover.hpp:44 */
 
 /* ---- Hyrax commitment of layer 0 (protocol: zkcnn_amd/csrc/hyrax-bls12-381/polyCommit.hpp) ------ */

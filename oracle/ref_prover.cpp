@@ -26,6 +26,7 @@ void prover::sumcheckInit(const F &alpha_0, const F &beta_0) {                //
     prove_timer.start();
     alpha = alpha_0;
     beta = beta_0;
+    zkSetWeights(alpha_0, beta_0);
     r_0 = r_u[sumcheck_id].data();
     r_1 = r_v[sumcheck_id].data();
     --sumcheck_id;
@@ -58,7 +59,8 @@ void prover::sumcheckDotProdInitPhase1() {                                    //
             V_mult[0][iu].b = V_mult[0][iu].b + beta_g[gate.g] * prev[iv];
         }
     round = 0;
-    zkBeginInstance();            // zero-knowledge mode: the next masking polynomial (zk_mask.hpp); a no-op otherwise
+    absorbed[0] = absorbed[1] = false;
+    zkBeginInstance();            // zero-knowledge mode: the layer's masking polynomial (zk_mask.hpp); a no-op otherwise
     prove_timer.stop();
 }
 
@@ -96,7 +98,9 @@ void prover::sumcheckDotProdFinalize1(const F &previous_random, F &claim_1) { //
     prove_timer.start();
     r_u[sumcheck_id].at(round - 1) = previous_random;
     claim_1 = V_mult[1][0].eval(previous_random);
-    V_u1 = V_mult[1][0].eval(previous_random) * mult_array[1][0].eval(previous_random);
+    F none = F_ZERO, added[2];
+    zkMaskClaims(zkmask::SLOT_U0, previous_random, none, claim_1, added);       // zero-knowledge mode: the claim leaves masked, phase 2 is about the masked value
+    V_u1 = claim_1 * mult_array[1][0].eval(previous_random);
     prove_timer.stop();
     proof_size += F_BYTE_SIZE * 1;
 }
@@ -220,7 +224,7 @@ void prover::sumcheckInitPhase2() {                                           //
         }
     }
     round = 0;
-    zkBeginInstance();            // zero-knowledge mode: the next masking polynomial (zk_mask.hpp); a no-op otherwise
+    absorbed[0] = absorbed[1] = false;
     prove_timer.stop();
 }
 
@@ -259,7 +263,8 @@ void prover::sumcheckLiuInit(const vector<F> &s_u, const vector<F> &s_v) {    //
         }
     }
     round = 0;
-    zkBeginInstance();            // zero-knowledge mode: the next masking polynomial (zk_mask.hpp); a no-op otherwise
+    absorbed[0] = absorbed[1] = false;
+    zkBeginLiu(s_u, s_v);         // zero-knowledge mode: the Liu sumcheck's masking polynomial
     prove_timer.stop();
 }
 
@@ -272,6 +277,7 @@ quadratic_poly prover::update(const F &previous_random, vector<F> &r_arr) {   //
     ++round;
     quadratic_poly ret;
     add_term = add_term * (Fr::one() - previous_random);
+    for (int b = 0; b < 2; ++b) if (absorbed[b]) absorbed_m[b] = absorbed_m[b] * (Fr::one() - previous_random);
     for (int b = 0; b < 2; ++b) ret = ret + updateEach(previous_random, b);
     ret = ret + quadratic_poly(F_ZERO, -add_term, add_term);
     zkMask(ret, previous_random);
@@ -297,6 +303,8 @@ quadratic_poly prover::updateEach(const F &previous_random, bool idx) {       //
         tv[0] = tv[0].eval(previous_random);
         tm[0] = tm[0].eval(previous_random);
         add_term = add_term + tv[0].b * tm[0].b;
+        absorbed[idx] = true;                 // (zero-knowledge mode reads the multiplier of an absorbed pair: zkTailPairs)
+        absorbed_m[idx] = tm[0].b;
     }
     quadratic_poly ret;
     for (u32 i = 0; i < (total[idx] >> 1); ++i) {
@@ -310,6 +318,32 @@ quadratic_poly prover::updateEach(const F &previous_random, bool idx) {       //
     total[idx] >>= 1;
     total_size[idx] = (total_size[idx] + 1) >> 1;
     return ret;
+}
+
+// ---- zero-knowledge mode (zk_mask.hpp): what the masks of a phase's last round need from the tables ----
+void prover::zkRawRound(int kind, const F &prev_r, F c[5]) {
+    raw_kind = kind;
+    if (kind == zkmask::PH_DOT1) {
+        const cubic_poly q = sumcheckDotProdUpdate1(prev_r);
+        c[0] = q.d; c[1] = q.c; c[2] = q.b; c[3] = q.a;
+        return;
+    }
+    const quadratic_poly q = kind == zkmask::PH_ONE ? sumcheckUpdate1(prev_r) : kind == zkmask::PH_TWO ? sumcheckUpdate2(prev_r) : sumcheckLiuUpdate(prev_r);
+    c[0] = q.c; c[1] = q.b; c[2] = q.a;
+}
+
+void prover::zkTailPairs(F A[6]) {
+    for (int k = 0; k < 6; ++k) A[k] = F_ZERO;
+    if (raw_kind == zkmask::PH_DOT1) {
+        // phase 1 of a DOT_PROD layer: the claimed operand is V_mult[1]; what multiplies it is (periodic table) x (the other operand's sums)
+        const quadratic_poly m = mult_array[1][0] * V_mult[0][0];
+        A[3] = m.c; A[4] = m.b; A[5] = m.a;
+        return;
+    }
+    for (int b = 0; b < 2; ++b) {
+        if (total[b] == 1 && !mult_array[b].empty()) { A[3 * b] = mult_array[b][0].b; A[3 * b + 1] = mult_array[b][0].a; }
+        else if (absorbed[b]) { A[3 * b] = absorbed_m[b]; A[3 * b + 1] = -absorbed_m[b]; }
+    }
 }
 
 F prover::Vres(const vector<F>::const_iterator &r, u32 output_size, u8 r_size) {   // prover.cpp:434-457
@@ -335,8 +369,12 @@ void prover::sumcheckFinalize1(const F &previous_random, F &claim_0, F &claim_1)
     prove_timer.start();
     r_u[sumcheck_id].at(round - 1) = previous_random;
     const layer &cur = C.circuit[sumcheck_id];
-    V_u0 = claim_0 = total[0] ? V_mult[0][0].eval(previous_random) : (~cur.bit_length_u[0]) ? V_mult[0][0].b : F_ZERO;
-    V_u1 = claim_1 = total[1] ? V_mult[1][0].eval(previous_random) : (~cur.bit_length_u[1]) ? V_mult[1][0].b : F_ZERO;
+    claim_0 = total[0] ? V_mult[0][0].eval(previous_random) : (~cur.bit_length_u[0]) ? V_mult[0][0].b : F_ZERO;
+    claim_1 = total[1] ? V_mult[1][0].eval(previous_random) : (~cur.bit_length_u[1]) ? V_mult[1][0].b : F_ZERO;
+    F added[2];
+    zkMaskClaims(zkmask::SLOT_U0, previous_random, claim_0, claim_1, added);     // zero-knowledge mode: V + Z M leaves, and phase 2 is about it
+    V_u0 = claim_0;
+    V_u1 = claim_1;
     prove_timer.stop();
     for (int b = 0; b < 2; ++b) { mult_array[b].clear(); V_mult[b].clear(); }
     proof_size += F_BYTE_SIZE * 2;
@@ -348,6 +386,8 @@ void prover::sumcheckFinalize2(const F &previous_random, F &claim_0, F &claim_1)
     const layer &cur = C.circuit[sumcheck_id];
     claim_0 = total[0] ? V_mult[0][0].eval(previous_random) : (~cur.bit_length_v[0]) ? V_mult[0][0].b : F_ZERO;
     claim_1 = total[1] ? V_mult[1][0].eval(previous_random) : (~cur.bit_length_v[1]) ? V_mult[1][0].b : F_ZERO;
+    F added[2];
+    zkMaskClaims(zkmask::SLOT_V0, previous_random, claim_0, claim_1, added);
     prove_timer.stop();
     for (int b = 0; b < 2; ++b) { mult_array[b].clear(); V_mult[b].clear(); }
     proof_size += F_BYTE_SIZE * 2;
@@ -357,6 +397,7 @@ void prover::sumcheckLiuFinalize(const F &previous_random, F &claim_1) {      //
     prove_timer.start();
     r_u[sumcheck_id].at(round - 1) = previous_random;
     claim_1 = total[1] ? V_mult[1][0].eval(previous_random) : V_mult[1][0].b;
+    zkMaskInputClaim(previous_random, claim_1);
     prove_timer.stop();
     proof_size += F_BYTE_SIZE;
     mult_array[1].clear();

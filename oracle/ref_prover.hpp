@@ -72,6 +72,8 @@ public:
 private:
     hyrax_bls12_381::polyProverBase &zkBackend() override { return *poly_p; }
     const layeredCircuit &zkCircuit() const override { return C; }
+    void zkRawRound(int kind, const F &prev_r, F c[5]) override;
+    void zkTailPairs(F A[6]) override;
     quadratic_poly updateEach(const F &previous_random, bool idx);            // :396-426
     quadratic_poly update(const F &previous_random, vector<F> &r_arr);        // :368-383
     F cirValue(u8 layer_id, const vector<u32> &ori, u32 u) const {            // :499-501
@@ -81,7 +83,9 @@ private:
     const F *r_0 = nullptr, *r_1 = nullptr;
     vector<vector<F>> r_u, r_v;
     vector<F> beta_g, beta_gs, beta_u;       // beta_gs / beta_u are file-scope statics in the reference (:9)
-    F add_term;
+    F add_term, absorbed_m[2];
+    bool absorbed[2] = {false, false};
+    int raw_kind = -1;
     vector<linear_poly> mult_array[2], V_mult[2];
     F V_u0, V_u1, alpha, beta, relu_rou;
     u64 proof_size = 0;

@@ -71,6 +71,8 @@ struct table_pair {
     bool tail_valid = false;       // the two entries left in V are known on the host (sent along with the last round)
     HFr tail_v[2];
     HFr final_v;                   // value of V when it collapsed
+    HFr abs_m;                     // ... and of its multiplier, times (1 - r) of every round since (zero-knowledge mode: zk_sumcheck_tail_pairs)
+    bool abs_m_valid = false;
 };
 
 // buffer sizes (in field elements) a circuit asks of each of its sessions; computed once per circuit
@@ -141,6 +143,7 @@ struct zk_ctx {
     std::vector<std::vector<HFr>> r_u, r_v;
     const HFr *r_0 = nullptr, *r_1 = nullptr;
     HFr alpha, beta, relu_rou, add_term, V_u0, V_u1;
+    HFr vu1_scale;                 // V_u1 = claim_1 x this (a DOT_PROD phase 1: the periodic table's value; 1 otherwise): zk_sumcheck_claims_adjust
     HFr small_final;               // collapsed periodic table (DOT_PROD): the scalar m of the rounds behind the transform's variables
     bool small_final_valid = false;
     // DOT_PROD phase 1 behind the collapse: sum X Y m is a QUADRATIC sumcheck of the pair (V = Y, M = X) times the scalar m -- its rounds go through

@@ -387,7 +387,7 @@ static int32_t host_tail_begin(zk_ctx *ctx) {
 static void host_tail_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]) {
     const bool first = ctx->round == 0;
     ++ctx->round;
-    if (with_add_term) ctx->add_term = ctx->add_term * (HFr::one() - r);
+    if (with_add_term) { ctx->add_term = ctx->add_term * (HFr::one() - r); scale_absorbed(ctx, r); }
     HFr a(0LL), c(0LL), p1(0LL);
     for (int b = 0; b < 2; ++b) {
         table_pair &t = ctx->tp[b];
@@ -404,6 +404,8 @@ static void host_tail_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint6
         if (t.len == 1) {                                   // the reference's `total == 1` case (prover.cpp:400-404)
             t.final_v = V[0];
             ctx->add_term = ctx->add_term + V[0] * M[0];
+            t.abs_m = M[0];
+            t.abs_m_valid = true;
             t.absorbed = true;
             t.len = 0;
             continue;

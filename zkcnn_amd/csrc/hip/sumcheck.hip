@@ -288,7 +288,14 @@ static void reset_pairs(zk_ctx *ctx, int bl0, int bl1) {
         ctx->tp[b].live = ctx->tp[b].len;
         ctx->tp[b].absorbed = false;
         ctx->tp[b].final_v.clear();
+        ctx->tp[b].abs_m.clear();
+        ctx->tp[b].abs_m_valid = false;
     }
+}
+// the multipliers of absorbed pairs follow add_term: x (1 - r) every round
+static inline void scale_absorbed(zk_ctx *ctx, const HFr &r) {
+    for (int b = 0; b < 2; ++b)
+        if (ctx->tp[b].absorbed && ctx->tp[b].abs_m_valid) ctx->tp[b].abs_m = ctx->tp[b].abs_m * (HFr::one() - r);
 }
 
 static fr_t *powers_of_root(zk_ctx *ctx, int n, bool inverse);
@@ -796,6 +803,7 @@ extern "C" int32_t zk_sumcheck_dotprod_finalize1(zk_ctx *ctx, const uint64_t pre
             t1.len = 0;
             put(claim_1, ctx->h_result[0]);
             ctx->V_u1 = ctx->h_result[0] * ctx->h_result[1];
+            ctx->vu1_scale = ctx->h_result[1];
             ctx->proof_size += 32;
             return ZK_OK;
         }
@@ -817,6 +825,7 @@ extern "C" int32_t zk_sumcheck_dotprod_finalize1(zk_ctx *ctx, const uint64_t pre
     ctx->small_len = 1;
     put(claim_1, ctx->h_result[0]);
     ctx->V_u1 = ctx->h_result[0] * ctx->h_result[1];
+    ctx->vu1_scale = ctx->h_result[1];
     ctx->proof_size += 32;
     return ZK_OK;
 }
@@ -1046,6 +1055,7 @@ static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, ui
     ++ctx->round;
     const bool add_deferred = ctx->add_pending;
     if (with_add_term && !add_deferred) ctx->add_term = ctx->add_term * (HFr::one() - r);
+    if (with_add_term) scale_absorbed(ctx, r);
     bool collapsed[2] = {false, false};
     round2_args A;
     std::memset(&A, 0, sizeof(A));
@@ -1141,6 +1151,8 @@ static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, ui
             table_pair &t = ctx->tp[b];
             t.final_v = ctx->h_result[4 + 2 * b];
             ctx->add_term = ctx->add_term + t.final_v * ctx->h_result[5 + 2 * b];
+            t.abs_m = ctx->h_result[5 + 2 * b];
+            t.abs_m_valid = true;
             t.absorbed = true;
             t.len = 0;
         }
@@ -1222,6 +1234,7 @@ extern "C" int32_t zk_sumcheck_finalize1(zk_ctx *ctx, const uint64_t prev_r[4], 
     if (rc) return rc;
     ctx->V_u0 = c[0];
     ctx->V_u1 = c[1];
+    ctx->vu1_scale = HFr::one();
     put(claim_0, c[0]);
     put(claim_1, c[1]);
     ctx->proof_size += 32 * 2;
@@ -1296,6 +1309,69 @@ extern "C" int32_t zk_sumcheck_liu_finalize(zk_ctx *ctx, const uint64_t prev_r[4
     if (rc) return rc;
     put(claim_1, c[1]);
     ctx->proof_size += 32;
+    return ZK_OK;
+}
+
+// ---- zero-knowledge mode (host/zk_mask.hpp (2)): the masks of the evaluation claims vanish on the cube, so no kernel and no table changes; the host adds
+// Z's term to a phase's LAST round polynomial and needs, for that, what multiplies each operand in that round ----
+// After a phase's last update call: A_b(t) of both pairs as coefficients (t^0, t^1, t^2). A live pair: its multiplier table's last two entries (the hybrid
+// tail holds them on the host; otherwise two entries are read back); a pair absorbed earlier: its multiplier x (1 - t); a DOT_PROD phase 1: the periodic
+// table's value(s) times the other operand's pair.
+extern "C" int32_t zk_sumcheck_tail_pairs(zk_ctx *ctx, uint64_t out[24]) {
+    CHECK_READY();
+    if (!out || ctx->round < 1) return ZK_ERR_STATE;
+    HFr A[6];
+    for (HFr &x : A) x.clear();
+    auto read_pair = [&](const fr_t *src, uint64_t n, HFr v[2]) -> int32_t {
+        v[0].clear(); v[1].clear();
+        if (!src || !n) return ZK_OK;
+        ZK_HIP(hipMemcpyAsync(v, src, std::min<uint64_t>(n, 2) * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        return ZK_OK;
+    };
+    const bool dot1 = ctx->phase_kind == 0;            // (zk_sumcheck_dotprod_init_phase1)
+    if (dot1 && !ctx->dot_quad) {
+        // cubic rounds to the end: pair 0 = X (the other operand's sums), pair 1 = Y (the claimed operand), `small` = the periodic table
+        table_pair &x = ctx->tp[0];
+        if (x.len != 2 || ctx->tp[1].len != 2) { ctx->err = "zk_sumcheck_tail_pairs: the DOT_PROD phase is not at its last round"; return ZK_ERR_STATE; }
+        HFr xv[2], sv[2];
+        int32_t rc = read_pair(x.V[x.cur], 2, xv);
+        if (!rc) rc = read_pair(ctx->small[ctx->small_cur], std::max<uint32_t>(ctx->small_len, 1), sv);
+        if (rc) return rc;
+        if (ctx->small_len < 2) sv[1] = sv[0];
+        const HFr x1 = xv[1] - xv[0], s1 = sv[1] - sv[0];
+        A[3] = sv[0] * xv[0];
+        A[4] = sv[0] * x1 + s1 * xv[0];
+        A[5] = s1 * x1;
+    } else {
+        for (int b = 0; b < 2; ++b) {
+            table_pair &t = ctx->tp[b];
+            if (t.len == 2) {
+                HFr m[2];
+                if (ctx->host_tail_active && ctx->ht_M[b].size() >= 2) { m[0] = ctx->ht_M[b][0]; m[1] = ctx->ht_M[b][1]; }
+                else {
+                    if (ctx->live_active || ctx->tail_active) { ctx->err = "zk_sumcheck_tail_pairs: the phase's last pairs are inside a resident kernel (set a host tail)"; return ZK_ERR_STATE; }
+                    int32_t rc = read_pair(t.M[t.cur], 2, m);
+                    if (rc) return rc;
+                }
+                if (ctx->dot_quad) { m[0] = m[0] * ctx->small_final; m[1] = m[1] * ctx->small_final; }       // (the quadratic rounds behind a DOT_PROD phase's collapse)
+                A[3 * b] = m[0];
+                A[3 * b + 1] = m[1] - m[0];
+            } else if (t.absorbed) {
+                if (!t.abs_m_valid) { ctx->err = "zk_sumcheck_tail_pairs: an operand was absorbed inside a resident kernel (set a host tail)"; return ZK_ERR_STATE; }
+                A[3 * b] = t.abs_m;
+                A[3 * b + 1] = HFr(0LL) - t.abs_m;
+            } else if (t.len != 0) { ctx->err = "zk_sumcheck_tail_pairs: the phase is not at its last round"; return ZK_ERR_STATE; }
+        }
+    }
+    for (int k = 0; k < 6; ++k) put(out + 4 * k, A[k]);
+    return ZK_OK;
+}
+// after zk_sumcheck_finalize1 / zk_sumcheck_dotprod_finalize1: the claims left masked, phase 2 is about c + d
+extern "C" int32_t zk_sumcheck_claims_adjust(zk_ctx *ctx, const uint64_t d0[4], const uint64_t d1[4]) {
+    CHECK_READY();
+    ctx->V_u0 = ctx->V_u0 + H(d0);
+    ctx->V_u1 = ctx->V_u1 + H(d1) * ctx->vu1_scale;
     return ZK_OK;
 }
 

@@ -191,6 +191,7 @@ void prover::sumcheckInit(const F &alpha_0, const F &beta_0) {
     TIMED();
     prove_timer.start();
     check(zk_sumcheck_init(ctx, U(alpha_0), U(beta_0)), "zk_sumcheck_init");
+    zkSetWeights(alpha_0, beta_0);
     prove_timer.stop();
 }
 void prover::sumcheckDotProdInitPhase1() {
@@ -211,7 +212,6 @@ void prover::sumcheckInitPhase2() {
     TIMED();
     prove_timer.start();
     check(zk_sumcheck_init_phase2(ctx), "zk_sumcheck_init_phase2");
-    zkBeginInstance();
     prove_timer.stop();
 }
 cubic_poly prover::sumcheckDotProdUpdate1(const F &previous_random) {
@@ -257,31 +257,46 @@ void prover::sumcheckDotProdFinalize1(const F &previous_random, F &claim_1) {
     TIMED();
     prove_timer.start();
     check(zk_sumcheck_dotprod_finalize1(ctx, U(previous_random), U(claim_1)), "zk_sumcheck_dotprod_finalize1");
+    if (zkActive()) {            // zero-knowledge mode: the claim leaves masked, phase 2 is about the masked value (zk_mask.hpp (2))
+        F none = F_ZERO, added[2];
+        zkMaskClaims(zkmask::SLOT_U0, previous_random, none, claim_1, added);
+        check(zk_sumcheck_claims_adjust(ctx, U(added[0]), U(added[1])), "zk_sumcheck_claims_adjust");
+    }
     prove_timer.stop();
 }
 void prover::sumcheckFinalize1(const F &previous_random, F &claim_0, F &claim_1) {
     TIMED();
     prove_timer.start();
     check(zk_sumcheck_finalize1(ctx, U(previous_random), U(claim_0), U(claim_1)), "zk_sumcheck_finalize1");
+    if (zkActive()) {
+        F added[2];
+        zkMaskClaims(zkmask::SLOT_U0, previous_random, claim_0, claim_1, added);
+        check(zk_sumcheck_claims_adjust(ctx, U(added[0]), U(added[1])), "zk_sumcheck_claims_adjust");
+    }
     prove_timer.stop();
 }
 void prover::sumcheckFinalize2(const F &previous_random, F &claim_0, F &claim_1) {
     TIMED();
     prove_timer.start();
     check(zk_sumcheck_finalize2(ctx, U(previous_random), U(claim_0), U(claim_1)), "zk_sumcheck_finalize2");
+    if (zkActive()) {
+        F added[2];
+        zkMaskClaims(zkmask::SLOT_V0, previous_random, claim_0, claim_1, added);
+    }
     prove_timer.stop();
 }
 void prover::sumcheckLiuFinalize(const F &previous_random, F &claim_1) {
     TIMED();
     prove_timer.start();
     check(zk_sumcheck_liu_finalize(ctx, U(previous_random), U(claim_1)), "zk_sumcheck_liu_finalize");
+    zkMaskInputClaim(previous_random, claim_1);
     prove_timer.stop();
 }
 void prover::sumcheckLiuInit(const vector<F> &s_u, const vector<F> &s_v) {
     TIMED();
     prove_timer.start();
     check(zk_sumcheck_liu_init(ctx, U(s_u[0]), U(s_v[0]), (u32) s_u.size()), "zk_sumcheck_liu_init");
-    zkBeginInstance();
+    zkBeginLiu(s_u, s_v);
     prove_timer.stop();
 }
 quadratic_poly prover::sumcheckLiuUpdate(const F &previous_random) {
@@ -294,6 +309,20 @@ quadratic_poly prover::sumcheckLiuUpdate(const F &previous_random) {
     prove_timer.stop();
     return poly;
 }
+
+// ---- zero-knowledge mode (zk_mask.hpp): the backend side of a phase's last round ----
+void prover::zkRawRound(int kind, const F &prev_r, F c[5]) {
+    if (kind == zkmask::PH_DOT1) {
+        const cubic_poly q = sumcheckDotProdUpdate1(prev_r);
+        c[0] = q.d; c[1] = q.c; c[2] = q.b; c[3] = q.a;
+        return;
+    }
+    const quadratic_poly q = kind == zkmask::PH_ONE ? sumcheckUpdate1(prev_r) : kind == zkmask::PH_TWO ? sumcheckUpdate2(prev_r) : sumcheckLiuUpdate(prev_r);
+    c[0] = q.c; c[1] = q.b; c[2] = q.a;
+}
+void prover::zkTailPairs(F A[6]) { check(zk_sumcheck_tail_pairs(ctx, U(A[0])), "zk_sumcheck_tail_pairs"); }
+// the last pairs of a phase are on the host when its last rounds run there (hybrid tail) -- and no resident kernel holds them
+void prover::zkModeOn() { if (ctx) check(zk_set_host_tail(ctx, 5), "zk_set_host_tail"); }
 
 // reference src/prover.cpp:503-511. The HBM copy of val[0] is already zero padded to 2^bit_length.
 hyrax_bls12_381::polyProverBase &prover::commitInput(const vector<G> &gens) {

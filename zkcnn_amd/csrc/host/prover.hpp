@@ -99,6 +99,9 @@ private:
     vector<zk_conv_hint> conv_hints;
     hyrax_bls12_381::polyProverBase &zkBackend() override { return *poly_p; }
     const layeredCircuit &zkCircuit() const override { return C; }
+    void zkRawRound(int kind, const F &prev_r, F c[5]) override;
+    void zkTailPairs(F A[6]) override;                                  // include/zkcnn_hip.h: zk_sumcheck_tail_pairs
+    void zkModeOn() override;
     void check(int rc, const char *what) const;
 
     zk_ctx *ctx;

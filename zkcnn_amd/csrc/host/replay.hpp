@@ -168,16 +168,16 @@ public:
     F Vres(const vector<F>::const_iterator &, u32, u8) { return rd.fr(); }
     void sumcheckInitAll(const vector<F>::const_iterator &) {}
     void sumcheckInit(const F &, const F &) {}
-    void sumcheckDotProdInitPhase1() {}
-    void sumcheckInitPhase1(const F &) {}
+    void sumcheckDotProdInitPhase1() { ++inst; var = 0; }
+    void sumcheckInitPhase1(const F &) { ++inst; var = 0; }
     void sumcheckInitPhase2() {}
-    cubic_poly sumcheckDotProdUpdate1(const F &) { F a = rd.fr(), b = rd.fr(), c = rd.fr(), d = rd.fr(); return cubic_poly(a, b, c, d); }
+    cubic_poly sumcheckDotProdUpdate1(const F &) { ++var; F a = rd.fr(), b = rd.fr(), c = rd.fr(), d = rd.fr(); return cubic_poly(a, b, c, d); }
     quadratic_poly sumcheckUpdate1(const F &) { return quad(); }
     quadratic_poly sumcheckUpdate2(const F &) { return quad(); }
     void sumcheckDotProdFinalize1(const F &, F &claim_1) { claim_1 = rd.fr(); }
     void sumcheckFinalize1(const F &, F &claim_0, F &claim_1) { claim_0 = rd.fr(); claim_1 = rd.fr(); }
     void sumcheckFinalize2(const F &, F &claim_0, F &claim_1) { claim_0 = rd.fr(); claim_1 = rd.fr(); }
-    void sumcheckLiuInit(const vector<F> &, const vector<F> &) {}
+    void sumcheckLiuInit(const vector<F> &, const vector<F> &) { ++inst; var = 0; }
     quadratic_poly sumcheckLiuUpdate(const F &) { return quad(); }
     void sumcheckLiuFinalize(const F &, F &claim_1) { claim_1 = rd.fr(); }
     hyrax_bls12_381::polyProverBase &commitInput(const std::vector<G1> &) {
@@ -190,7 +190,8 @@ public:
         return *pp;
     }
     zkmask::maskCommitMsg zkMaskCommit() {
-        const zkmask::plan pl(*C);
+        pl = zkmask::plan(*C, pp->zkColumns());
+        inst = -1;
         mask_rows = (pl.total + pp->zkColumns() - 1) / pp->zkColumns();
         zkmask::maskCommitMsg m;
         m.commit.resize(mask_rows);
@@ -200,7 +201,14 @@ public:
         return m;
     }
     void zkSetRho(const F &) {}
-    F zkMaskEval(const F &) { return rd.fr(); }
+    F zkMaskEval() { return rd.fr(); }
+    // the last round of a phase: the plan's degree + 1 coefficients, highest first
+    zkmask::zkPoly zkLastRound(int, const F &) {
+        zkmask::zkPoly q;
+        q.deg = pl.items.at(inst).deg.at(var++);
+        for (int e = q.deg; e >= 0; --e) q.c[e] = rd.fr();
+        return q;
+    }
     hyrax_bls12_381::dotProofCommit zkMaskOpen1(const vector<F> &) { return pp->readDot1(mask_rows); }
     hyrax_bls12_381::dotProofResponse zkMaskOpen2(const F &) { return pp->readDot2(mask_rows); }
     double proveTime() const { return 0; }
@@ -213,5 +221,7 @@ private:
     proofReader rd;
     std::unique_ptr<replayPolyProver> pp;
     size_t mask_rows = 0;
-    quadratic_poly quad() { F a = rd.fr(), b = rd.fr(), c = rd.fr(); return quadratic_poly(a, b, c); }
+    zkmask::plan pl;
+    int inst = -1, var = 0;
+    quadratic_poly quad() { ++var; F a = rd.fr(), b = rd.fr(), c = rd.fr(); return quadratic_poly(a, b, c); }
 };

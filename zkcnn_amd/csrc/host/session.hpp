@@ -94,7 +94,13 @@ struct sessionT {
         const bool zk = (mode & ZKCNN_MODE_ZK) != 0;
         const u8 logn = p.C.circuit[0].bit_length;
         const size_t n_sqrt = ((size_t) 1 << (logn - (logn >> 1))) + (zk ? 1 : 0);       // zero-knowledge mode: one more generator, H
-        if (mode & ZKCNN_MODE_SEEDED) { Fr::seedCSPRNG(challenge_seed); zkff::privateCoins().seed(challenge_seed); }
+        // (test hook, ZKCNN_TEST_HOOKS=1: ZKCNN_TEST_COIN_SALT=<n> seeds the prover's coins apart from the challenges -- the same challenges with other
+        //  coins is how tests/test_zk_cpu.py shows that every message of the zero-knowledge mode depends on the coins)
+        uint64_t coin_salt = 0;
+        if (const char *hk = std::getenv("ZKCNN_TEST_HOOKS"))
+            if (std::atoi(hk) != 0)
+                if (const char *cs = std::getenv("ZKCNN_TEST_COIN_SALT")) coin_salt = std::strtoull(cs, nullptr, 0);
+        if (mode & ZKCNN_MODE_SEEDED) { Fr::seedCSPRNG(challenge_seed); zkff::privateCoins().seed(challenge_seed ^ coin_salt); }
         else { Fr::useOsRandom(); zkff::privateCoins().useOsRandom(); }
         v.zk = zk;
         // ZKCNN_MODE_HOST_ROUNDS: every sumcheck round is a kernel launch driven from here (no resident round kernel, no device-side Fiat-Shamir rounds)

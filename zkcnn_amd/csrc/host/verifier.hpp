@@ -182,25 +182,33 @@ private:
     hyrax_bls12_381::polyVerifier *poly_v;
     string fail_msg;
 
-    // ---- zero-knowledge mode: masking polynomials of the sumcheck instances (zk_mask.hpp) ----
+    // ---- zero-knowledge mode (zk_mask.hpp): masking polynomials of the sumcheck instances, masked evaluation claims ----
+    struct maskRecord {
+        size_t k;                                   // instance
+        vector<F> r;                                // its point
+        F E, v;                                     // prod (1 - r_i); the revealed rho g(r) + E K
+        vector<std::pair<size_t, F>> in;            // incoming claims: (layer * 4 + slot, weight)
+    };
     zkmask::plan mask_plan;
     std::vector<G1> mask_commit;
-    std::vector<F> mask_sums, mask_vals;
-    std::vector<vector<F>> mask_points;
-    F mask_rho;
+    std::vector<F> mask_sums, mask_z;               // mask_z[layer * 4 + slot] = Z of a masked claim (0: not masked)
+    std::vector<maskRecord> mask_recs;
+    zkmask::cursor mask_cur;
+    F mask_rho, mask_z_in;
     size_t mask_k = 0;
 
-    // the prover's commitment to every masking polynomial and their sums over the cube, then rho
+    // the prover's commitment to every private scalar of the mode and the masking polynomials' sums over the cube, then rho
     bool receiveMasks(size_t m) {
-        mask_plan = zkmask::plan(C);
+        mask_plan = zkmask::plan(C, m);
         zkmask::maskCommitMsg msg = p->zkMaskCommit();
         if (msg.commit.size() != (mask_plan.total + m - 1) / m || msg.sums.size() != mask_plan.items.size()) return fail("masking commitment of the wrong shape");
         for (const G1 &c : msg.commit) transcript.put(c);
         for (const F &x : msg.sums) transcript.put(x);
         mask_commit = msg.commit;
         mask_sums = msg.sums;
-        mask_vals.clear();
-        mask_points.clear();
+        mask_recs.clear();
+        mask_z.assign((size_t) C.size * 4, F_ZERO);
+        mask_z_in = F_ZERO;
         mask_k = 0;
         tic();
         mask_rho.setByCSPRNG();
@@ -208,32 +216,69 @@ private:
         p->zkSetRho(mask_rho);
         return true;
     }
-    // a sumcheck instance starts: its claim becomes H + rho G
-    void maskOpen(F &claim) { if (zk) claim = claim + mask_rho * mask_sums.at(mask_k); }
-    // ... and ends: the prover reveals g(r), the claim about f is what is left
-    void maskClose(F &claim, const vector<F> &point, const F &last_r) {
+    // a sumcheck instance starts: its claim becomes H + rho G (H already carries K: it is a combination of masked claims)
+    void maskOpen(F &claim, const vector<std::pair<size_t, F>> &in) {
         if (!zk) return;
-        F v = p->zkMaskEval(last_r);
+        claim = claim + mask_rho * mask_sums.at(mask_k);
+        mask_cur.reset();
+        maskRecord rec;
+        rec.k = mask_k;
+        rec.in = in;
+        mask_recs.push_back(rec);
+    }
+    vector<std::pair<size_t, F>> maskIncoming(int i, const F &alpha, const F &beta) const {
+        vector<std::pair<size_t, F>> in;
+        if (!zk) return in;
+        for (const zkmask::incoming &c : zkmask::incomingOf(C, i))
+            in.push_back(std::make_pair((size_t) c.layer * 4 + c.slot, c.w == 0 ? alpha : c.w == 1 ? beta : F_ONE));
+        return in;
+    }
+    // the last round of a phase in the mode: a polynomial of the plan's degree, sent highest coefficient first
+    bool maskLastRound(int kind, const F &previousRandom, F &at01, zkmask::zkPoly &poly) {
+        poly = p->zkLastRound(kind, previousRandom);
+        if (poly.deg != mask_plan.items.at(mask_k).deg.at(mask_cur.bound)) return fail("masked last round of the wrong degree");
+        if (hit()) poly.c[0] = poly.c[0] + F_ONE;
+        for (int e = poly.deg; e >= 0; --e) transcript.put(poly.c[e]);
+        at01 = poly.eval(F_ZERO) + poly.eval(F_ONE);
+        return true;
+    }
+    void maskBind(const F &r) { if (zk) mask_cur.bind(r); }
+    // a phase ends: Z of its point for the claims that left masked
+    void maskPhaseEnd(int layer, int slot0) {
+        if (!zk) return;
+        const F Z = mask_cur.zPhase(mask_cur.phase_r.size());
+        if (layer == 0) mask_z_in = Z;
+        else for (int b = 0; b < 2; ++b)
+            if (zkmask::slotActive(C, layer, slot0 + b)) mask_z[(size_t) layer * 4 + slot0 + b] = Z;
+        mask_cur.phase_r.clear();
+    }
+    // ... and the instance: the prover reveals v = rho g(r) + E K, the claim about f is what is left
+    void maskClose(F &claim) {
+        if (!zk) return;
+        F v = p->zkMaskEval();
         if (hit()) v = v + F_ONE;
         transcript.put(v);
-        claim = claim - mask_rho * v;
-        mask_vals.push_back(v);
-        mask_points.push_back(point);
+        claim = claim - v;
+        maskRecord &rec = mask_recs.back();
+        rec.v = v;
+        rec.r = mask_cur.r;
+        rec.E = mask_cur.E;
         ++mask_k;
     }
-    // one proof of dot product for all revealed evaluations: <a, sum_k gamma^k u_k> = sum_k gamma^k v_k against the commitment of a
+    // one proof of dot product for all revealed values: <a, sum_k gamma^k u_k> = sum_k gamma^k v_k against the commitment of a
     bool verifyMasks() {
         tic();
         F gamma, y = F_ZERO, w = F_ONE;
         gamma.setByCSPRNG();
         zkmask::evalVector ev(mask_plan);
-        for (size_t k = 0; k < mask_vals.size(); ++k) {
-            ev.add(k, mask_points[k], w);
-            y = y + w * mask_vals[k];
+        for (const maskRecord &rec : mask_recs) {
+            ev.addG(rec.k, rec.r, w * mask_rho);
+            for (const auto &c : rec.in) ev.addM((int) (c.first / 4), (int) (c.first % 4), w * rec.E * c.second * mask_z[c.first]);
+            y = y + w * rec.v;
             w = w * gamma;
         }
         toc();
-        if (mask_vals.size() != mask_plan.items.size()) return fail("masking: instance count");
+        if (mask_recs.size() != mask_plan.items.size()) return fail("masking: instance count");
         hyrax_bls12_381::dotProofCommit m1 = p->zkMaskOpen1(ev.u);
         if (hit()) m1.t = m1.t + F_ONE;
         for (const G1 &d : m1.delta) transcript.put(d);
@@ -366,10 +411,16 @@ private:
             else p->sumcheckInitPhase1(relu_rou);
 
             F previousRandom = F_ZERO;
-            maskOpen(previousSum);
+            maskOpen(previousSum, maskIncoming(i, alpha, beta));
             for (i8 j = 0; j < cur.max_bl_u; ++j) {
                 F at01, at_r;
-                if (dot) {
+                if (zk && j == cur.max_bl_u - 1) {
+                    zkmask::zkPoly poly;
+                    if (!maskLastRound(dot ? zkmask::PH_DOT1 : zkmask::PH_ONE, previousRandom, at01, poly)) return false;
+                    tic();
+                    if (lazy_challenges) r_u[i][j].setByCSPRNG();
+                    at_r = poly.eval(r_u[i][j]);
+                } else if (dot) {
                     cubic_poly poly = p->sumcheckDotProdUpdate1(previousRandom);
                     if (hit()) poly.d = poly.d + F_ONE;
                     transcript.put(poly);
@@ -390,9 +441,9 @@ private:
                     return fail("phase1, circuit " + std::to_string(i) + ", current bit " + std::to_string(j));
                 previousRandom = r_u[i][j];
                 previousSum = at_r;
+                maskBind(previousRandom);
                 toc();
             }
-            maskClose(previousSum, r_u[i], previousRandom);
             if (dot) {
                 p->sumcheckDotProdFinalize1(previousRandom, claim_u1);
                 if (hit()) claim_u1 = claim_u1 + F_ONE;
@@ -403,6 +454,7 @@ private:
                 transcript.put(final_claim_u0[i]);
                 transcript.put(claim_u1);
             }
+            maskPhaseEnd(i, zkmask::SLOT_U0);
 
             total_slow_timer.start();
             const bool host_pred = !drive_only && (!accel || cross_check);
@@ -416,24 +468,35 @@ private:
                 toc();
                 p->sumcheckInitPhase2();
                 previousRandom = F_ZERO;
-                maskOpen(previousSum);
                 for (i8 j = 0; j < cur.max_bl_v; ++j) {
-                    quadratic_poly poly = p->sumcheckUpdate2(previousRandom);
-                    if (hit()) poly.a = poly.a + F_ONE;
-                    transcript.put(poly);
-                    tic();
-                    if (lazy_challenges) r_v[i][j].setByCSPRNG();
-                    if (!drive_only && poly.eval(F_ZERO) + poly.eval(F_ONE) != previousSum)
+                    F at01, at_r;
+                    if (zk && j == cur.max_bl_v - 1) {
+                        zkmask::zkPoly poly;
+                        if (!maskLastRound(zkmask::PH_TWO, previousRandom, at01, poly)) return false;
+                        tic();
+                        if (lazy_challenges) r_v[i][j].setByCSPRNG();
+                        at_r = poly.eval(r_v[i][j]);
+                    } else {
+                        quadratic_poly poly = p->sumcheckUpdate2(previousRandom);
+                        if (hit()) poly.a = poly.a + F_ONE;
+                        transcript.put(poly);
+                        tic();
+                        if (lazy_challenges) r_v[i][j].setByCSPRNG();
+                        at01 = poly.eval(F_ZERO) + poly.eval(F_ONE);
+                        at_r = poly.eval(r_v[i][j]);
+                    }
+                    if (!drive_only && at01 != previousSum)
                         return fail("phase2, circuit level " + std::to_string(i) + ", current bit " + std::to_string(j));
                     previousRandom = r_v[i][j];
-                    previousSum = poly.eval(previousRandom);
+                    previousSum = at_r;
+                    maskBind(previousRandom);
                     toc();
                 }
-                maskClose(previousSum, r_v[i], previousRandom);
                 p->sumcheckFinalize2(previousRandom, final_claim_v0[i], claim_v1);
                 if (hit()) claim_v1 = claim_v1 + F_ONE;
                 transcript.put(final_claim_v0[i]);
                 transcript.put(claim_v1);
+                maskPhaseEnd(i, zkmask::SLOT_V0);
                 total_slow_timer.start();
                 if (host_pred) {
                     betaInitPhase2(i);
@@ -441,6 +504,7 @@ private:
                 }
                 total_timer.start();
             }
+            maskClose(previousSum);
             if (!drive_only && accel) {
                 total_slow_timer.start();
                 F uni[2], bin[3];
@@ -497,21 +561,38 @@ private:
 
         p->sumcheckLiuInit(sig_u, sig_v);
         F previousRandom = F_ZERO;
-        maskOpen(previousSum);
+        vector<std::pair<size_t, F>> in;
+        for (int i = 1; zk && i < C.size; ++i) {
+            if (zkmask::slotActive(C, i, zkmask::SLOT_U0)) in.push_back(std::make_pair((size_t) i * 4 + zkmask::SLOT_U0, sig_u[i - 1]));
+            if (zkmask::slotActive(C, i, zkmask::SLOT_V0)) in.push_back(std::make_pair((size_t) i * 4 + zkmask::SLOT_V0, sig_v[i - 1]));
+        }
+        maskOpen(previousSum, in);
         for (int j = 0; j < cur.bit_length; ++j) {
-            quadratic_poly poly = p->sumcheckLiuUpdate(previousRandom);
-            if (hit()) poly.b = poly.b + F_ONE;
-            transcript.put(poly);
-            if (lazy_challenges) r_u[0][j].setByCSPRNG();
-            if (!drive_only && poly.eval(F_ZERO) + poly.eval(F_ONE) != previousSum)
+            F at01, at_r;
+            if (zk && j == cur.bit_length - 1) {
+                zkmask::zkPoly poly;
+                if (!maskLastRound(zkmask::PH_LIU, previousRandom, at01, poly)) return false;
+                if (lazy_challenges) r_u[0][j].setByCSPRNG();
+                at_r = poly.eval(r_u[0][j]);
+            } else {
+                quadratic_poly poly = p->sumcheckLiuUpdate(previousRandom);
+                if (hit()) poly.b = poly.b + F_ONE;
+                transcript.put(poly);
+                if (lazy_challenges) r_u[0][j].setByCSPRNG();
+                at01 = poly.eval(F_ZERO) + poly.eval(F_ONE);
+                at_r = poly.eval(r_u[0][j]);
+            }
+            if (!drive_only && at01 != previousSum)
                 return fail("Liu, circuit 0, current bit " + std::to_string(j));
             previousRandom = r_u[0][j];
-            previousSum = poly.eval(previousRandom);
+            previousSum = at_r;
+            maskBind(previousRandom);
         }
-        maskClose(previousSum, r_u[0], previousRandom);
         p->sumcheckLiuFinalize(previousRandom, eval_in);
         if (hit()) eval_in = eval_in + F_ONE;
         transcript.put(eval_in);
+        maskPhaseEnd(0, 0);
+        maskClose(previousSum);
 
         if (!drive_only) {
             total_slow_timer.start();
@@ -552,7 +633,8 @@ private:
 
     // ---- stage 3: open the committed input at r_u[0] (reference src/verifier.cpp:359-373) ----
     bool verifyInput() {
-        if (!(zk ? poly_v->verifyZk(r_u[0], eval_in) : poly_v->verify(r_u[0], eval_in))) return fail("final input check fail");
+        // (zero-knowledge mode: eval_in is the MASKED value V_0(r) + Z <a_row0, eq(r_low)>: the opening is against P + Z D_0, D_0 = the mask commitment's first row)
+        if (!(zk ? poly_v->verifyZk(r_u[0], eval_in, &mask_commit.at(0), mask_z_in) : poly_v->verify(r_u[0], eval_in))) return fail("final input check fail");
         output_tb[POLY_PT_OUT_ID] = to_string_wp(p->polyProverTime());
         output_tb[POLY_VT_OUT_ID] = to_string_wp(poly_v->getVT());
         output_tb[POLY_PS_OUT_ID] = to_string_wp(p->polyProofSize());

@@ -157,16 +157,23 @@ public:
         eqTable(Lrow, x.data() + cb, rb, Fr::one());
         zk_w_blind = Fr(0LL);
         for (size_t i = 0; i < Lrow.size() && i < input_blinds.size(); ++i) zk_w_blind = zk_w_blind + Lrow[i] * input_blinds[i];
+        // the masked claim (host/zk_mask.hpp (2)): the opening is about w + Z a_row0, committed as P + Z D_0
+        for (size_t j = 0; j < open_extra_w.size() && j < zk_w.size(); ++j) zk_w[j] = zk_w[j] + open_extra_w[j];
+        zk_w_blind = zk_w_blind + open_extra_blind;
+        open_extra_w.clear();
+        open_extra_blind = Fr(0LL);
         return dotCommit(b, 1, rnd);
     }
     virtual dotProofResponse zkOpenRespond(const Fr &c) { return dotRespond(zk_w, std::vector<Fr>(1, zk_w_blind), c); }
+    // a committed row (already scaled) that the next zero-knowledge opening adds to the combined input row, with its blind
+    void setOpenExtra(const std::vector<Fr> &w, const Fr &blind) { open_extra_w = w; open_extra_blind = blind; }
 
 protected:
     size_t zk_m = 0;                       // columns of a commitment row (set by the backend when it is built for zero knowledge)
     std::vector<Fr> input_blinds;          // blinding factor of every input row
 private:
-    std::vector<Fr> dot_d, dot_s, zk_w;
-    Fr zk_w_blind;
+    std::vector<Fr> dot_d, dot_s, zk_w, open_extra_w;
+    Fr zk_w_blind, open_extra_blind = Fr(0LL);
 };
 
 // Optional accelerator for the verifier's two multi-scalar multiplications (reference src/verifier.cpp:360 ends in them: 0.14 s of a
@@ -287,7 +294,8 @@ public:
         return ok;
     }
     // zero-knowledge opening: gens = (g_0 .. g_{m-1}, H); proof of dot product <w, R> = eval against P = sum_i L_i C_i
-    bool verifyZk(const std::vector<Fr> &x, const Fr &eval) {
+    // (extra, extra_k): the opening is against P + extra_k * extra -- the committed row that masks the claimed value (host/zk_mask.hpp (2))
+    bool verifyZk(const std::vector<Fr> &x, const Fr &eval, const G1 *extra = nullptr, const Fr &extra_k = Fr(0LL)) {
         vt.start();
         const int n = (int) x.size();
         const int rb = n >> 1, cb = n - rb;
@@ -300,6 +308,7 @@ public:
             std::vector<G1Affine> commA;
             zkff::batchToAffine(comm, commA);
             P = msmAny(accel, cross_check, Lrow.data(), commA.data(), commA.size(), false);
+            if (extra) P = P + *extra * extra_k;
         }
         vt.stop();
         dotProofCommit m1 = p.zkOpenCommit(x, b);
