@@ -21,7 +21,7 @@
 //     LAST of a phase are untouched; the last one gains Z's degree,
 //         p_last(t) += Z' t (1 - t) sum_b M_b A_b(t),        Z' = prod_{j<l-1} r_j (1 - r_j),   A_b(t) = the operand's multiplier table at (r', t)
 //     (O(1) on the host from the phase's last table pairs: `zkTailPairs`), and phase 2 / the layer's final check are about the masked values
-//     (`zkAdjustClaims`). The layer BELOW starts from a combination of masked claims, alpha c~_u + beta c~_v = (the true sum) + K with
+//     (what `zkMaskClaims` added goes back to the backend: zk_sumcheck_claims_adjust). The layer BELOW starts from a combination of masked claims, alpha c~_u + beta c~_v = (the true sum) + K with
 //     K = alpha Z_u M_u + beta Z_v M_v: a committed quantity the moment the challenges are known, carried through that layer's sumcheck as the
 //     term K eq_0(x) above and removed at its end inside v -- never sent on its own. The INPUT's claim is masked by a committed ROW:
 //     M_in = <a_row0, eq(r_low)> (m fresh scalars, the first row of the mask commitment), so that the masked value is again a matrix opening --
