@@ -338,6 +338,37 @@ void oracle_msm(uint64_t *out_affine, const uint64_t *scalars, const uint64_t *b
     G1Affine a = r.toAffine();
     std::memcpy(out_affine, &a, 96);
 }
+// ---- the commitment scheme on its own (tests/test_hyrax_cpu.py re-verifies every message with Python integers) ----
+// Commits the table Z (2^n_bits entries) over `gens` (n_gens affine points; with `blinds`: the last one is H and every row is blinded), opens it at x
+// against `eval` with challenges from the stream seeded by chal_seed (oracle_fr_random(k, chal_seed) gives the same values) and writes every message in
+// order: the row commitments, then the opening's messages. Returns the verifier's verdict.
+int32_t oracle_hyrax_run(const uint64_t *Z, int32_t n_bits, const uint64_t *gens_affine, uint64_t n_gens, const uint64_t *blinds, const uint64_t *x,
+                         const uint64_t *eval, uint64_t chal_seed, uint64_t coin_seed, int32_t stop_len, int32_t tamper_at, uint8_t *out, uint64_t cap,
+                         uint64_t *out_len) {
+    struct sink : public hyrax_bls12_381::transcriptSink {
+        std::vector<u8> bytes;
+        void put(const Fr &v) override { size_t o = bytes.size(); bytes.resize(o + 32); v.toBytesLE(&bytes[o]); }
+        void put(const G1 &p) override { size_t o = bytes.size(); bytes.resize(o + 48); p.serialize(&bytes[o]); }
+    } rec;
+    std::vector<Fr> table((size_t) 1 << n_bits), pt(n_bits);
+    for (size_t i = 0; i < table.size(); ++i) table[i] = FR(Z, i);
+    for (int i = 0; i < n_bits; ++i) pt[i] = FR(x, i);
+    std::vector<G1> gens(n_gens);
+    for (size_t i = 0; i < n_gens; ++i) gens[i] = G1::fromAffine(*reinterpret_cast<const G1Affine *>(gens_affine + 12 * i));
+    std::vector<Fr> bl;
+    if (blinds) for (size_t i = 0; i < ((size_t) 1 << (n_bits >> 1)); ++i) bl.push_back(FR(blinds, i));
+    Fr::seedCSPRNG(chal_seed);
+    zkff::privateCoins().seed(coin_seed);
+    oracle::polyProverCPU pp(table, gens, blinds ? &bl : nullptr);
+    hyrax_bls12_381::polyVerifier pv(pp, gens, &rec);
+    pv.stop_len = (size_t) stop_len;
+    pv.tamper_at = tamper_at;
+    const bool ok = blinds ? pv.verifyZk(pt, FR(eval, 0)) : pv.verify(pt, FR(eval, 0));
+    *out_len = rec.bytes.size();
+    if (rec.bytes.size() <= cap) std::memcpy(out, rec.bytes.data(), rec.bytes.size());
+    return ok ? 1 : 0;
+}
+
 void oracle_g1_serialize(uint8_t *out48, const uint64_t *affine) {
     G1 p = G1::fromAffine(*reinterpret_cast<const G1Affine *>(affine));
     p.serialize(out48);

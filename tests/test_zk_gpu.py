@@ -41,6 +41,22 @@ def test_zero_knowledge_transcripts_identical_to_oracle(built, model, pic, pp):
         assert o.prove(seed=0x5EED0001)[1] == t_plain
 
 
+def test_every_message_of_the_gpu_prover_depends_on_the_coins(built, monkeypatch):
+    """the product path's twin of tests/test_zk_cpu.py::test_every_message_depends_on_the_coins: the same challenges with other prover coins
+    (ZKCNN_TEST_COIN_SALT) change every commitment, round polynomial, evaluation claim (V + Z M: zk_sumcheck_tail_pairs / zk_sumcheck_claims_adjust)
+    and revealed value -- what stays is the public output's value and the zero claims of operands a layer does not have"""
+    model, pic, pp = CASES[2]
+    with zkcnn_amd.Session(model, pic, pp) as s:
+        monkeypatch.setenv("ZKCNN_TEST_COIN_SALT", "0")
+        r1, t1 = s.prove(seed=21, mode=ZK | REUSE)
+        monkeypatch.setenv("ZKCNN_TEST_COIN_SALT", "777")
+        r2, t2 = s.prove(seed=21, mode=ZK | REUSE)
+        r3, t3 = s.prove(seed=21, mode=ZK | REUSE)
+        assert r1.accepted == 1 and r2.accepted == 1 and t2 == t3 and len(t1) == len(t2)
+        same = [k for k in range(0, len(t1), 16) if t1[k:k + 16] == t2[k:k + 16] and any(t1[k:k + 16])]
+        assert len(same) <= 2, (len(same), len(t1) // 16)
+
+
 def test_full_size_vgg11_zero_knowledge(built):
     with zkcnn_amd.Session("vgg11", (32, 32, 3), 1) as s:
         a, ta = s.prove(mode=ZK | REUSE)                      # OS randomness
