@@ -281,7 +281,7 @@ def test_zero_knowledge_golden_hash(oracle):
     """regression vector of the mode (made by this repo's oracle: parity unpinned like every other vector here)"""
     with oracle_ffi.OracleSession(*CASES[1]) as o:
         _, tr = o.prove(seed=0x5EED0001, mode=ZK | REUSE)
-    assert len(tr) == 40848 and hashlib.sha256(tr).hexdigest() == ZK_GOLDEN
+    assert len(tr) == 36672 and hashlib.sha256(tr).hexdigest() == ZK_GOLDEN
 
 
-ZK_GOLDEN = "60fc371a147be2406135bc74133618b24c25353de85f9e2e6846a396919af6f8"      # round 5: masked evaluation claims (was 411d4703.. / 36 432 bytes)
+ZK_GOLDEN = "eb87bddffa61a22837c7b9f12f9c205374048660b9c477c1b7476014c06cef2c"      # round 5: masked evaluation claims (was 411d4703.. / 36 432 bytes)

@@ -209,8 +209,8 @@ public:
         for (int e = q.deg; e >= 0; --e) q.c[e] = rd.fr();
         return q;
     }
-    hyrax_bls12_381::dotProofCommit zkMaskOpen1(const vector<F> &) { return pp->readDot1(mask_rows); }
-    hyrax_bls12_381::dotProofResponse zkMaskOpen2(const F &) { return pp->readDot2(mask_rows); }
+    hyrax_bls12_381::dotProofCommit zkMaskOpen1(const vector<F> &) { return pp->readDot1(mask_rows - 1); }
+    hyrax_bls12_381::dotProofResponse zkMaskOpen2(const F &) { return pp->readDot2(mask_rows - 1); }
     double proveTime() const { return 0; }
     double proofSize() const { return 0; }
     double polyProverTime() const { return 0; }

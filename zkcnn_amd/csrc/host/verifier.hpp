@@ -295,7 +295,9 @@ private:
         tic();
         std::vector<G1Affine> gA;
         zkff::batchToAffine(poly_v->generators(), gA);
-        const bool ok = hyrax_bls12_381::dotVerify(mask_commit, gA, ev.u, y, m1, c, m2, accel, cross_check);
+        // (rows 1 .. of the commitment: row 0 masks the input's claim and is opened with the input, verifyInput)
+        const bool ok = hyrax_bls12_381::dotVerify(std::vector<G1>(mask_commit.begin() + 1, mask_commit.end()), gA,
+                                                   std::vector<F>(ev.u.begin() + mask_plan.row, ev.u.end()), y, m1, c, m2, accel, cross_check);
         toc();
         return ok ? true : fail("masking polynomials: proof of dot product");
     }

@@ -330,8 +330,14 @@ public:
         zkBackend().addProofBytes(32);
         return zk_st.eval();
     }
-    hyrax_bls12_381::dotProofCommit zkMaskOpen1(const std::vector<Fr> &u) { return zkBackend().dotCommit(u, zk_blinds.size(), zkff::privateCoins()); }
-    hyrax_bls12_381::dotProofResponse zkMaskOpen2(const Fr &c) { return zkBackend().dotRespond(zk_st.a, zk_blinds, c); }
+    // the proof of dot product for the revealed values runs over rows 1 .. of the commitment: row 0 (the input claim's mask row) is opened with the input
+    // and has no part in any v -- leaving it out saves its m response scalars (131 KB of a vgg11 proof) and one MSM on either side
+    hyrax_bls12_381::dotProofCommit zkMaskOpen1(const std::vector<Fr> &u) {
+        return zkBackend().dotCommit(std::vector<Fr>(u.begin() + zk_st.pl.row, u.end()), zk_blinds.size() - 1, zkff::privateCoins());
+    }
+    hyrax_bls12_381::dotProofResponse zkMaskOpen2(const Fr &c) {
+        return zkBackend().dotRespond(std::vector<Fr>(zk_st.a.begin() + zk_st.pl.row, zk_st.a.end()), std::vector<Fr>(zk_blinds.begin() + 1, zk_blinds.end()), c);
+    }
 
 protected:
     virtual hyrax_bls12_381::polyProverBase &zkBackend() = 0;
