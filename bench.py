@@ -392,16 +392,37 @@ def main():
     side_by_side = threading.Semaphore(16)
 
     def in_threads(fn):
-        """fn(i) for every stream i on its own host thread (the C calls release the GIL); re-raises the first failure"""
+        """fn(i) for every stream i, at most 16 at a time, on a POOL of 16 host threads (the C calls release the GIL); re-raises the first failure.
+        (Until round 5 every i had a thread of its own behind a semaphore: K threads alive at once, each of which launches kernels sooner or later --
+        the one thing that separates the shapes rocprofv3 traces from those it dies in: 32 sessions trace, 40 / 48 / 56 die inside hipLaunchKernel
+        during this warm-up, old and new tree alike, `profiles/r05_rocprof_threads.md`.)"""
         errs = []
+        todo = queue.Queue()
+        for i in range(K):
+            todo.put(i)
 
-        def run(i):
-            try:
-                with side_by_side:
+        def worker():
+            while True:
+                try:
+                    i = todo.get_nowait()
+                except queue.Empty:
+                    return
+                try:
                     fn(i)
-            except BaseException as e:      # noqa: BLE001 - reported below
-                errs.append(e)
-        th = [threading.Thread(target=run, args=(i,)) for i in range(K)]
+                except BaseException as e:      # noqa: BLE001 - reported below
+                    errs.append(e)
+        if os.environ.get("ZKCNN_BENCH_THREAD_PER_SESSION"):      # the shape of rounds 3-5 (experiment switch)
+            def run(i):
+                try:
+                    with side_by_side:
+                        fn(i)
+                except BaseException as e:      # noqa: BLE001
+                    errs.append(e)
+            th = [threading.Thread(target=run, args=(i,)) for i in range(K)]
+        else:
+            # (under rocprofv3 -- its tool library is preloaded -- four: the fewer threads launch side by side, the rarer its crash; see the docstring)
+            traced = any("rocprof" in os.environ.get(v, "").lower() for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+            th = [threading.Thread(target=worker) for _ in range(min(int(os.environ.get("ZKCNN_BENCH_POOL", "4" if traced else "16")), K))]
         [t.start() for t in th]
         [t.join() for t in th]
         if errs:
