@@ -142,6 +142,7 @@ struct zk_ctx {
     // prover state machine (names follow reference src/prover.hpp:55-74)
     std::vector<std::vector<HFr>> r_u, r_v;
     const HFr *r_0 = nullptr, *r_1 = nullptr;
+    bool lane_tail = false;        // this context's resident tail runs inside a batch's fused launch (counted in zk_batch::tails_running)
     HFr alpha, beta, relu_rou, add_term, V_u0, V_u1;
     HFr vu1_scale;                 // V_u1 = claim_1 x this (a DOT_PROD phase 1: the periodic table's value; 1 otherwise): zk_sumcheck_claims_adjust
     HFr small_final;               // collapsed periodic table (DOT_PROD): the scalar m of the rounds behind the transform's variables
@@ -363,6 +364,10 @@ struct zk_batch {
     // statistics: launches issued by flushes, lane launches they stood for, flushes, flushes that found nothing to do
     uint64_t n_launches = 0, n_lane_launches = 0, n_flushes = 0, n_empty_flushes = 0;
     std::map<const char *, std::pair<uint64_t, uint64_t>> by_kernel;       // fusion report (ZKCNN_BATCH_TRACE=1: printed when the batch is destroyed)
+    // lanes whose resident tail (k_tail_live_f, one fused launch) is running: a lane that has left its tail waits for the others before it defers
+    // anything else, so that the next launch is a fused one again (rounds_resident.hpp: live_round)
+    int tails_running = 0;
+    uint64_t n_lane_tails = 0, n_lane_tail_rounds = 0;
 };
 // Every point where a lane needs its deferred launches on the stream (it is about to wait for a result, or to put something else on the
 // stream): hand the thread to the batch's driver, which runs the other lanes up to their own such points and flushes; without a driver (no

@@ -164,7 +164,7 @@ __device__ __forceinline__ void load48_sys(const void *p, zk_u32x4 &c0, zk_u32x4
 // A collapsing pair (the reference's `total == 1` case, prover.cpp:400-404) is a degenerate quad: role 0 / 2 fold its last V / M pair and
 // role 0's product is the term add_term takes over. add_term (1 - r) is the product of the one lane that is idle in the product step.
 template <bool LIVE>
-__global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
+__device__ __forceinline__ void tail_body(const tail_args &a) {
     __shared__ fr_t s_part[TAIL_THREADS / 64][3];
     __shared__ fr_t s_r, s_fin[2], s_prod[2], s_tail[2][2], s_add, s_addm;
     __shared__ uint32_t s_state[8];
@@ -407,6 +407,14 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) {
         *((volatile unsigned long long *) &o->seq) = a.seq;
     }
 }
+template <bool LIVE>
+__global__ void __launch_bounds__(TAIL_THREADS) k_tail(tail_args a) { tail_body<LIVE>(a); }
+// the interactive form as a functor (launch.cuh): the lanes of a lock-step batch run their tails as ONE launch, a workgroup per lane, each with its own
+// mailboxes -- inside the launch the lanes are independent (a lane's rounds go at its verifier's pace), the batch is in lock step again when all have left
+struct k_tail_live_f {
+    tail_args a;
+    __device__ __forceinline__ void operator()() const { tail_body<true>(a); }
+};
 
 // ------------------------------------------------------------------------------------------------
 // Resident MULTI-workgroup rounds of the interactive protocol: the middle of a phase, tables of 2^11 .. 2^16 entries (too large for the one

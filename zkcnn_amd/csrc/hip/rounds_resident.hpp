@@ -82,11 +82,24 @@ static inline void live_post(zk_ctx *ctx, const HFr &r, uint32_t seq) {
     _mm_store_si128((__m128i *) m->c[2], _mm_set_epi32((int) seq, 0, (int) w[7], (int) w[6]));
     _mm_sfence();
 }
+// a lane leaves the set of lanes whose tail is running (its last round, an abort, a lost kernel)
+static inline void lane_tail_done(zk_ctx *ctx) {
+    if (!ctx->lane_tail) return;
+    ctx->lane_tail = false;
+    if (ctx->batch && ctx->batch->tails_running > 0) --ctx->batch->tails_running;
+}
 int32_t zk_live_abort(zk_ctx *ctx) {
     if (!ctx->live_active) return ZK_OK;
     live_post(ctx, HFr(0LL), TAIL_ABORT);
     ctx->live_active = false;
     ctx->live_mid = false;
+    if (ctx->lane_tail) {
+        // the lane's workgroup of a fused tail: it sees the abort word and leaves on its own. No wait here -- the launch ends when the OTHER lanes'
+        // workgroups end, and those need this thread (the lanes share it) for their challenges
+        lane_tail_done(ctx);
+        for (int b = 0; b < 2; ++b) ctx->tp[b].len = 0;
+        return ZK_OK;
+    }
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     ZK_HIP(hipMemsetAsync(ctx->d_counter, 0, 64, ctx->stream));          // (a segment kernel that was sent home may have left arrivals behind ...
     ZK_HIP(hipMemsetAsync(ctx->d_bcast, 0, sizeof(mid_bcast), ctx->stream));   //  ... and the abort word in its broadcast line)
@@ -119,12 +132,19 @@ static int32_t live_wait(zk_ctx *ctx, int k, uint64_t out_abc[12]) {
             w[3 * j] = t[0]; w[3 * j + 1] = t[1]; w[3 * j + 2] = t[2];
         }
         if (ok) break;
-        if (spins > (1ull << 16) && (spins & 1023) == 0) {
+        if (ctx->lane_tail) {
+            // a lane: the thread goes to the other lanes (the first time round this is what gets the fused launch issued: zk_batch_sync_point)
+            int32_t rcy = zk_batch_sync_point(ctx);
+            if (rcy) { lane_tail_done(ctx); ctx->live_active = false; return rcy; }
+            if (spins < (1ull << 12) || (spins & 255) != 0 || ctx->n_pending) continue;
+        }
+        if ((ctx->lane_tail || spins > (1ull << 16)) && (spins & 1023) == 0) {
             if (*(volatile const uint32_t *) &o->status != 0 || hipStreamQuery(ctx->stream) == hipSuccess) {
                 // (a kernel that has left: one last look, its final message may have landed after the check above)
                 bool late = true;
                 for (int j = 0; j < 8; ++j) if (((volatile const uint32_t *) o->live.c[j])[3] != want) late = false;
                 if (late) continue;
+                lane_tail_done(ctx);
                 ctx->live_active = false;
                 ctx->live_lost = true;                 // (quad_round runs the phase again with a launch per round)
                 char msg[256];
@@ -167,8 +187,19 @@ static int32_t live_start(zk_ctx *ctx, const HFr &r, bool with_add_term) {
     if (ctx->live_seq32 > 0xf0000000u) ctx->live_seq32 = 64;
     A.seq32 = ctx->live_seq32;
     ((tail_out *) ctx->h_tail)->status = 0;
-    ZK_LAUNCH(PC_TAIL, 0.0, k_tail<true>, dim3(1), dim3(TAIL_THREADS), A);
-    ZK_HIP(hipGetLastError());
+    if (ctx->batch) {
+        // a lane: its tail is one workgroup of the batch's fused launch (issued when every lane has parked: the first live_wait)
+        live_in *mb = (live_in *) ctx->h_live_in;          // (an abort word left by zk_live_abort: that workgroup is long gone, this one must not read it)
+        if (mb->c[0][3] == TAIL_ABORT) std::memset(mb, 0, sizeof(live_in));
+        zk_launch_f<k_tail_live_f, TAIL_THREADS>(ctx, PC_TAIL, 0.0, dim3(1), k_tail_live_f{A});
+        ctx->lane_tail = true;
+        ++ctx->batch->tails_running;
+        ++ctx->batch->n_lane_tails;
+        ctx->batch->n_lane_tail_rounds += (uint64_t) A.rounds;
+    } else {
+        ZK_LAUNCH(PC_TAIL, 0.0, k_tail<true>, dim3(1), dim3(TAIL_THREADS), A);
+        ZK_HIP(hipGetLastError());
+    }
     ctx->live_active = true;
     ctx->live_count = A.rounds;
     ctx->live_cursor = 0;
@@ -340,6 +371,14 @@ static int32_t live_round(zk_ctx *ctx, const HFr &r, uint64_t out_abc[12]) {
     ctx->live_ticks_wait += o->ticks_wait;
     ctx->live_ticks_total += o->ticks_total;
     ctx->live_active = false;
+    if (ctx->lane_tail) {
+        // lock step again: a lane defers nothing before every lane of the batch has left its tail (else the next launches would go out lane by lane)
+        lane_tail_done(ctx);
+        while (ctx->batch && ctx->batch->tails_running > 0) {
+            int32_t rcy = zk_batch_sync_point(ctx);
+            if (rcy) return rcy;
+        }
+    }
     return ZK_OK;
 }
 

@@ -47,6 +47,9 @@ constexpr int DEAD_MAX_FOLDS = 20;
 // phase's last five rounds are ~150 multiplications on the lane's host thread instead of five fused launches -- 44% of a vgg11 proof's rounds by count,
 // 3e-5 of its products. 4 x 8 lanes on one box: 135 proofs/s with every round a launch, 139-143 / 144 / 144-147 / 144-147 with 2^3 / 2^4 / 2^5 / 2^6.
 constexpr int LANE_TAIL_LOG = 5;
+// ... or (round 5, experiment: off) the lanes' rounds on at most TAIL_QUADS quads as resident workgroups of ONE fused launch per phase, every lane trading
+// polynomials and challenges through its own mailboxes (k_tail_live_f; quad_round_once). Measured in profiles/r05_lane_resident.md.
+constexpr bool LANE_RESIDENT_TAIL = false;
 }
 // the hand-over size of the hybrid tail in force for this context (-1: none)
 static inline int host_tail_log(const zk_ctx *ctx) {
@@ -984,7 +987,12 @@ static int32_t quad_round(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_
 static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, uint64_t out_abc[12]) {
     static const bool seg_timing = getenv("ZKCNN_TIMING") != nullptr;
     // the tail paths start from add_term: it must be there before they are considered (the plain round below picks it up behind its launch)
-    const int ht_log = host_tail_log(ctx);
+    // A lane of a batch with a driver (zk_batch_set_yield) and no explicit tail setting: the rounds on at most TAIL_QUADS quads run in a resident
+    // workgroup of ONE fused launch per phase (fs_tail.cuh: k_tail_live_f) instead of a fused launch per round plus the hybrid tail on the host.
+    // ZKCNN_LANE_RESIDENT=0/1 overrides policy::LANE_RESIDENT_TAIL.
+    static const bool lane_resident = [] { const char *v = getenv("ZKCNN_LANE_RESIDENT"); return v ? atoi(v) != 0 : policy::LANE_RESIDENT_TAIL; }();
+    const bool lane_tail = lane_resident && ctx->batch && ctx->batch->yield_fn && ctx->host_tail_log == -1 && ctx->live_rounds && !ctx->fs_state && !ctx->phase_no_live;
+    const int ht_log = lane_tail ? -1 : host_tail_log(ctx);
     if (ctx->add_pending && (ht_log >= 0 || ctx->fs_state)) { int32_t rc0 = resolve_add_term(ctx); if (rc0) return rc0; }
     if (ht_log >= 0 && !ctx->host_tail_active && !ctx->tail_active && ctx->phase_rounds > ctx->round &&
         std::max(ctx->tp[0].len, ctx->tp[1].len) <= (1ull << ht_log) && ctx->tp[0].len + ctx->tp[1].len > 0) {
@@ -1033,6 +1041,10 @@ static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, ui
             rc = resolve_add_term(ctx);
             if (!rc) rc = live_start(ctx, r, with_add_term);
         }
+        if (rc) return rc;
+    } else if (lane_tail && in_phase && round_quads <= TAIL_QUADS) {
+        int32_t rc = resolve_add_term(ctx);
+        if (!rc) rc = live_start(ctx, r, with_add_term);
         if (rc) return rc;
     }
     if (ctx->live_active) return live_round(ctx, r, out_abc);
