@@ -367,6 +367,7 @@ struct zk_batch {
     // lanes whose resident tail (k_tail_live_f, one fused launch) is running: a lane that has left its tail waits for the others before it defers
     // anything else, so that the next launch is a fused one again (rounds_resident.hpp: live_round)
     int tails_running = 0;
+    uint64_t tails_open_at = 0;            // value of n_flushes from which the lanes that have left their tails go on (set by the last one out)
     uint64_t n_lane_tails = 0, n_lane_tail_rounds = 0;
 };
 // Every point where a lane needs its deferred launches on the stream (it is about to wait for a result, or to put something else on the

@@ -86,7 +86,8 @@ static inline void live_post(zk_ctx *ctx, const HFr &r, uint32_t seq) {
 static inline void lane_tail_done(zk_ctx *ctx) {
     if (!ctx->lane_tail) return;
     ctx->lane_tail = false;
-    if (ctx->batch && ctx->batch->tails_running > 0) --ctx->batch->tails_running;
+    zk_batch *b = ctx->batch;
+    if (b && b->tails_running > 0 && --b->tails_running == 0) b->tails_open_at = b->n_flushes + 1;     // (the last one out: the others may go on after the NEXT flush)
 }
 int32_t zk_live_abort(zk_ctx *ctx) {
     if (!ctx->live_active) return ZK_OK;
@@ -372,9 +373,11 @@ static int32_t live_round(zk_ctx *ctx, const HFr &r, uint64_t out_abc[12]) {
     ctx->live_ticks_total += o->ticks_total;
     ctx->live_active = false;
     if (ctx->lane_tail) {
-        // lock step again: a lane defers nothing before every lane of the batch has left its tail (else the next launches would go out lane by lane)
+        // lock step again: a lane defers nothing before every lane of the batch has left its tail, and all of them go on in the SAME pass of the batch's
+        // driver (the pass after the one in which the last lane left: the driver flushes once per pass, and whatever a lane defers on its own goes out
+        // on its own -- behind a tail that is still running it would starve the lanes that kernel waits for: wait_slot spins, it does not yield)
         lane_tail_done(ctx);
-        while (ctx->batch && ctx->batch->tails_running > 0) {
+        while (ctx->batch && (ctx->batch->tails_running > 0 || ctx->batch->n_flushes < ctx->batch->tails_open_at)) {
             int32_t rcy = zk_batch_sync_point(ctx);
             if (rcy) return rcy;
         }
