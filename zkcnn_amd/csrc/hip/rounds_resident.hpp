@@ -238,7 +238,7 @@ static int32_t mid_start(zk_ctx *ctx, const HFr &r, bool with_add_term, int roun
     ((tail_out *) ctx->h_tail)->status = 0;
     ZK_LAUNCH(PC_TAIL, 0.0, k_mid<true>, dim3(blocks), dim3(ZK_BLOCK), A);
     ZK_HIP(hipGetLastError());
-    if (with_add_term) ctx->add_term = ctx->add_term * (HFr::one() - r);      // (the kernel's blocks apply the same factors to their copy)
+    if (with_add_term) { ctx->add_term = ctx->add_term * (HFr::one() - r); scale_absorbed(ctx, r); }      // (the kernel's blocks apply the same factors to their copy)
     ctx->live_active = true;
     ctx->live_mid = true;
     ctx->live_first = A.first != 0;
@@ -323,7 +323,7 @@ static int32_t live_round(zk_ctx *ctx, const HFr &r, uint64_t out_abc[12]) {
     if (timing && k > 0) ctx->live_t_host += t0 - ctx->live_t_exit;
     if (k > 0) {
         live_post(ctx, r, ctx->live_seq32 + (uint32_t) k);
-        if (ctx->live_mid && ctx->live_with_add) ctx->add_term = ctx->add_term * (HFr::one() - r);
+        if (ctx->live_mid && ctx->live_with_add) { ctx->add_term = ctx->add_term * (HFr::one() - r); scale_absorbed(ctx, r); }
     }
     int32_t rc = live_wait(ctx, k, out_abc);
     if (rc) return rc;

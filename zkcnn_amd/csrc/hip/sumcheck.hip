@@ -1006,12 +1006,15 @@ static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, ui
     // quads of this round over both pairs (a first round works on pairs, not quads)
     const uint64_t round_quads = ctx->round == 0 ? (ctx->tp[0].len + ctx->tp[1].len) / 2 : (ctx->tp[0].len + ctx->tp[1].len) / 4;
     const bool in_phase = !ctx->live_active && !ctx->tail_active && ctx->phase_rounds > ctx->round && ctx->tp[0].len + ctx->tp[1].len > 0;
-    const bool resident_ok = ctx->live_rounds && ctx->live_now && !ctx->batch && !ctx->phase_no_live && ht_log < 0 && in_phase &&
-                             (ctx->counted_active || zk_contexts_on_device(ctx->device) == 1);     // (outside a proof's bracket: only for the device's one context)
+    // (a context with a hybrid tail -- an explicit zk_set_host_tail, the zero-knowledge mode -- still takes the resident SEGMENTS of a phase's middle: they end
+    //  above the tail's hand-over size with the tables in device memory; only the single-workgroup kernel that runs a phase to its end is the tail's alternative)
+    const bool mid_ok = ctx->live_rounds && ctx->live_now && !ctx->batch && !ctx->phase_no_live && in_phase &&
+                        (ctx->counted_active || zk_contexts_on_device(ctx->device) == 1);     // (outside a proof's bracket: only for the device's one context)
+    const bool resident_ok = mid_ok && ht_log < 0;
     // The middle of a phase (more quads than the single-workgroup kernel takes, tables of at most 2^18 entries): a SEGMENT of rounds in one
     // resident multi-workgroup kernel (k_mid), as long as no table collapses or reaches its last pair. Returns the segment's length (0: none).
-    auto plan_segment = [&]() -> int {
-        if (!resident_ok || round_quads <= TAIL_QUADS || round_quads > policy::MID_MAX_QUADS || std::max(ctx->tp[0].len, ctx->tp[1].len) > (1ull << ZK_FULL_TABLE_LOG)) return 0;
+    auto plan_segment = [&](bool allowed) -> int {
+        if (!allowed || round_quads <= TAIL_QUADS || round_quads > policy::MID_MAX_QUADS || std::max(ctx->tp[0].len, ctx->tp[1].len) > (1ull << ZK_FULL_TABLE_LOG)) return 0;
         uint64_t L0 = ctx->tp[0].len, L1 = ctx->tp[1].len;
         int rounds = 0;
         bool f = ctx->round == 0;          // (a first round works on pairs and folds nothing)
@@ -1027,17 +1030,17 @@ static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, ui
         // the tables are small (k_tail<false>: it takes over at TAIL_QUADS quads); the host answers the following calls from the record
         if (in_phase && *ctx->fs_pending == 0) {
             int32_t rc = ZK_OK;
-            if (const int rounds = plan_segment()) rc = run_device_mid(ctx, r, with_add_term, rounds, (uint32_t) std::min<uint64_t>((round_quads + 63) / 64, MID_MAX_BLOCKS));
+            if (const int rounds = plan_segment(resident_ok)) rc = run_device_mid(ctx, r, with_add_term, rounds, (uint32_t) std::min<uint64_t>((round_quads + 63) / 64, MID_MAX_BLOCKS));
             else if (round_quads <= TAIL_QUADS) rc = run_device_rounds(ctx, r, with_add_term);
             if (rc) return rc;
         }
-    } else if (resident_ok) {
+    } else if (mid_ok) {
         // interactive protocol: the same two kernels, trading polynomials and challenges with the verifier through mailboxes
         int32_t rc = ZK_OK;
-        if (const int rounds = plan_segment()) {
+        if (const int rounds = plan_segment(mid_ok)) {
             rc = resolve_add_term(ctx);
             if (!rc) rc = mid_start(ctx, r, with_add_term, rounds, (uint32_t) std::min<uint64_t>((round_quads + 63) / 64, MID_MAX_BLOCKS));
-        } else if (round_quads <= TAIL_QUADS) {
+        } else if (resident_ok && round_quads <= TAIL_QUADS) {
             rc = resolve_add_term(ctx);
             if (!rc) rc = live_start(ctx, r, with_add_term);
         }
