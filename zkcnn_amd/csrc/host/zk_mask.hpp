@@ -107,7 +107,6 @@ struct plan {
             for (int s = 0; s < 4; ++s) slot_off[(size_t) i * 4 + s] = total++;
     }
     size_t slot(int layer, int s) const { return slot_off.at((size_t) layer * 4 + s); }
-    size_t instanceOf(int layer) const { return layer ? (size_t) (size - 1 - layer) : items.size() - 1; }
 };
 
 // does the claim of (layer, slot) exist and have a variable to hide behind?
@@ -422,7 +421,6 @@ protected:
         for (Fr &x : b) x = rnd.next();
         return b;
     }
-    bool zkSuppressed() const { return zk_suppress; }
 
 private:
     void step(Fr *c, int n, const Fr &prev_r) {
