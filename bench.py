@@ -1022,6 +1022,9 @@ def main():
             print(f"[bench] companion mode {mode:#x}", file=sys.stderr, flush=True)
             return round(min(1e3 * (x.prove_s + x.poly_prove_s) for x in (sess.prove(seed=0x5EED0300 + k, mode=mode, want_transcript=False)[0] for k in range(3))), 3)
         extras["prover_ms_hybrid_tail"] = best(drive | zkcnn_amd.MODE_HOST_TAIL)          # tables of <= 64 entries finish their phase on the host
+        # the lone proof with EVERY round on the GPU (no hand-over of the last <= 32 entries of a phase to the host: the resident tail kernel runs each phase to its
+        # end, the shape of rounds 3-5): what prover_ms_per_image would be without the host's share of the small rounds (round-4 review: quote both)
+        extras["prover_ms_every_round_on_gpu"] = best(drive | zkcnn_amd.MODE_GPU_TAIL)
         fs = zkcnn_amd.MODE_FIAT_SHAMIR | zkcnn_amd.MODE_DRIVE_ONLY
         extras["prover_ms_fiat_shamir"] = best(fs)                                        # non-interactive: challenges hashed on the host, rounds in the resident kernels
         extras["prover_ms_fiat_shamir_device_rounds"] = best(fs | zkcnn_amd.MODE_FS_DEVICE)  # ... small rounds and their hash chain on the GPU by themselves

@@ -31,7 +31,8 @@ struct tail_args {
     tail_out *out;
     unsigned long long seq;           // FS: published when everything is written
     const live_in *in;                // LIVE: challenge mailbox
-    uint32_t seq32, pad2_;            // LIVE: round k is posted with seq32 + k; the challenge that follows it is expected with seq32 + k + 1
+    uint32_t seq32;                   // LIVE: round k is posted with seq32 + k; the challenge that follows it is expected with seq32 + k + 1
+    uint32_t export_tables;           // LIVE: `rounds` ends before the phase does: the last round's folded tables (<= TAIL_EXPORT_MAX entries each) go to out->exp_*
 };
 
 __device__ __forceinline__ bool fr_raw_ge_mod(const uint32_t t[8]) {
@@ -239,6 +240,8 @@ __device__ __forceinline__ void tail_body(const tail_args &a) {
                 X = fr_lerp(fr_load(src), fr_load(src + 1), r);
                 (role < 2 ? wV : wM)[wbase + 2 * q + (role & 1)] = X;
                 if (quads_b == 1 && role < 2) s_tail[b][role] = X;           // the pair the phase may end with
+                if (LIVE && a.export_tables && k == a.rounds - 1 && 2 * q + 1 < TAIL_EXPORT_MAX)      // a shortened tail: the host goes on from these
+                    fr_store_scoped((role < 2 ? a.out->exp_V[b] : a.out->exp_M[b]) + 2 * q + (role & 1), X, true);
             }
             if (!first || special) {
                 fr_t y1, y2, y3;
@@ -280,6 +283,7 @@ __device__ __forceinline__ void tail_body(const tail_args &a) {
             }
         }
         if (lane < 3) s_part[wave][lane == 2 ? 0 : lane + 1] = prod;       // accumulator order a, c, p(1); zero from a wave that sat out
+        if (LIVE && a.export_tables && k == a.rounds - 1) ZK_WAIT_STORES();  // (the exported entries are written before the barrier below, the last message after it)
         __syncthreads();
         if (wave == 0) {
             // lane 16 t + w holds accumulator t of wave w; a 4-step butterfly over w
@@ -337,6 +341,10 @@ __device__ __forceinline__ void tail_body(const tail_args &a) {
                         for (int b = 0; b < 2; ++b) {
                             uint32_t ps = pstate[b];
                             if (collapse[b]) ps = 2;
+                            else if (a.export_tables && ps == 1 && !first) {
+                                ps = 3;                                            // n[b] / 2 entries of V and of M were exported by this round's fold
+                                __hip_atomic_store(&o->exp_n[b], (uint32_t) (n[b] >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
                             __hip_atomic_store(&o->pair_state[b], ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             if (ps == 1) { fr_store_scoped(&o->tail_v[b][0], s_tail[b][0], true); fr_store_scoped(&o->tail_v[b][1], s_tail[b][1], true); }
                             if (ps == 2) fr_store_scoped(&o->final_v[b], s_fin[b], true);

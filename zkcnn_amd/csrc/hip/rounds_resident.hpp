@@ -164,7 +164,9 @@ static int32_t live_wait(zk_ctx *ctx, int k, uint64_t out_abc[12]) {
     std::memcpy(out_abc, w, 96);
     return ZK_OK;
 }
-static int32_t live_start(zk_ctx *ctx, const HFr &r, bool with_add_term) {
+// export_log >= 0: the kernel ends when the tables are down to 2^export_log entries and hands them to the host (the hybrid tail goes on from there) --
+// if the phase has that many rounds and the hand-over is behind a fold; otherwise the kernel runs the phase to its end as before
+static int32_t live_start(zk_ctx *ctx, const HFr &r, bool with_add_term, int export_log = -1) {
     tail_args A;
     std::memset(&A, 0, sizeof(A));
     for (int b = 0; b < 2; ++b) {
@@ -178,6 +180,13 @@ static int32_t live_start(zk_ctx *ctx, const HFr &r, bool with_add_term) {
     }
     A.first = ctx->round == 0 ? 1 : 0;
     A.rounds = ctx->phase_rounds - ctx->round;
+    if (export_log >= 0 && (1u << export_log) <= TAIL_EXPORT_MAX) {
+        // rounds until the longer table is down to 2^export_log entries: a first round folds nothing, every other one halves
+        uint64_t longest = std::max(ctx->tp[0].len, ctx->tp[1].len);
+        int m = A.first ? 1 : 0;
+        while (longest > (1ull << export_log)) { longest >>= 1; ++m; }
+        if (m >= 2 && m < A.rounds) { A.rounds = m; A.export_tables = 1; }
+    }
     A.with_add_term = with_add_term ? 1 : 0;
     A.prev_r = to_dev(r);
     A.add_term = to_dev(ctx->add_term);
@@ -357,7 +366,19 @@ static int32_t live_round(zk_ctx *ctx, const HFr &r, uint64_t out_abc[12]) {
         table_pair &t = ctx->tp[b];
         if (!t.len) continue;
         t.Vsrc = nullptr;
-        if (o->pair_state[b] == 1) {
+        if (o->pair_state[b] == 3) {
+            // a shortened tail: what is left of the pair comes to the host, which runs the phase's remaining rounds (host_tail_round)
+            const uint32_t n = o->exp_n[b];
+            if (n < 2 || n > TAIL_EXPORT_MAX) { ctx->err = "resident tail: exported table of unexpected length"; return ZK_ERR_STATE; }
+            ctx->ht_V[b].resize(n);
+            ctx->ht_M[b].resize(n);
+            std::memcpy(ctx->ht_V[b].data(), o->exp_V[b], (size_t) n * 32);
+            std::memcpy(ctx->ht_M[b].data(), o->exp_M[b], (size_t) n * 32);
+            t.len = n;
+            t.tail_valid = false;
+            if (n == 2) { std::memcpy(&t.tail_v[0], &o->exp_V[b][0], 32); std::memcpy(&t.tail_v[1], &o->exp_V[b][1], 32); t.tail_valid = true; }
+            ctx->host_tail_active = true;
+        } else if (o->pair_state[b] == 1) {
             t.len = 2;
             std::memcpy(&t.tail_v[0], &o->tail_v[b][0], 32);
             std::memcpy(&t.tail_v[1], &o->tail_v[b][1], 32);
@@ -365,6 +386,7 @@ static int32_t live_round(zk_ctx *ctx, const HFr &r, uint64_t out_abc[12]) {
         } else {
             t.len = 0;
             t.absorbed = true;
+            t.abs_m_valid = false;
             std::memcpy(&t.final_v, &o->final_v[b], 32);
         }
     }

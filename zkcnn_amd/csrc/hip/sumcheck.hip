@@ -50,6 +50,10 @@ constexpr int LANE_TAIL_LOG = 5;
 // ... or (round 5, experiment: off) the lanes' rounds on at most TAIL_QUADS quads as resident workgroups of ONE fused launch per phase, every lane trading
 // polynomials and challenges through its own mailboxes (k_tail_live_f; quad_round_once). Measured in profiles/r05_lane_resident.md.
 constexpr bool LANE_RESIDENT_TAIL = false;
+// a LONE proof's resident tail kernel (k_tail<true>) ends when the tables hold 2^SOLO_EXPORT_LOG entries and exports them; the host finishes the phase
+// (-1: the kernel runs every phase to its end, as in rounds 3-5 -- still what ZKCNN_MODE_GPU_TAIL asks for). A round of the last few entries costs the host
+// ~1 us and the mailboxes ~10: vgg11 lone proof 28.1 / 26.7 / 26.3 / 27.7 ms at -1 / 6 / 5 / 4 (profiles/r05_solo_export.md).
+constexpr int SOLO_EXPORT_LOG = 5;
 }
 // the hand-over size of the hybrid tail in force for this context (-1: none)
 static inline int host_tail_log(const zk_ctx *ctx) {
@@ -1041,8 +1045,11 @@ static int32_t quad_round_once(zk_ctx *ctx, const HFr &r, bool with_add_term, ui
             rc = resolve_add_term(ctx);
             if (!rc) rc = mid_start(ctx, r, with_add_term, rounds, (uint32_t) std::min<uint64_t>((round_quads + 63) / 64, MID_MAX_BLOCKS));
         } else if (resident_ok && round_quads <= TAIL_QUADS) {
+            // (a context of its own with the default tail setting: the resident kernel hands the tables to the host at 2^SOLO_EXPORT_LOG entries -- the last rounds
+            //  of a phase cost the host ~1 us each, a mailbox round trip ~10; ZKCNN_SOLO_EXPORT=<log, -1: never> overrides the policy)
+            static const int solo_export = [] { const char *v = getenv("ZKCNN_SOLO_EXPORT"); return v ? atoi(v) : policy::SOLO_EXPORT_LOG; }();
             rc = resolve_add_term(ctx);
-            if (!rc) rc = live_start(ctx, r, with_add_term);
+            if (!rc) rc = live_start(ctx, r, with_add_term, ctx->host_tail_log == -1 ? solo_export : -1);
         }
         if (rc) return rc;
     } else if (lane_tail && in_phase && round_quads <= TAIL_QUADS) {

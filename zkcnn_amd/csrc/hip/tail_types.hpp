@@ -10,6 +10,7 @@
 #define FS_TAIL_MAX_ROUNDS ZK_MAX_VARS
 #define TAIL_TIMEOUT_TICKS 300000000ull   // 3 s of s_memrealtime (100 MHz): a live kernel nobody talks to gives up
 #define TAIL_ABORT 0xffffffffu
+#define TAIL_EXPORT_MAX 64             // entries per table a shortened resident tail hands to the host
 #define MID_MAX_BLOCKS 256u           // k_mid's grid: its workgroups wait for one another, so the footprint is bounded (1024 waves) whatever the table size
 
 struct __align__(16) live_in {        // mapped host memory, written by the host: chunk j = {challenge words 3j, 3j+1, 3j+2, seq} (chunk 2: words 6, 7, 0)
@@ -32,6 +33,10 @@ struct tail_out {                     // pinned, mapped host memory
     unsigned long long ticks_wait, ticks_total;   // LIVE: 100 MHz ticks spent polling for challenges / in the whole kernel (diagnostics, written with the final state)
     unsigned long long seq;           // FS: written last
     live_out live;                    // LIVE: the round mailbox
+    // LIVE with tail_args::export_tables: the kernel ends BEFORE the phase does and hands what is left of the tables to the host (pair_state 3: exp_n[b] entries of
+    // V and M as its last round's fold left them); the host runs the remaining rounds itself (rounds_resident.hpp: host_tail_round)
+    fr_t exp_V[2][TAIL_EXPORT_MAX], exp_M[2][TAIL_EXPORT_MAX];
+    uint32_t exp_n[2];
 };
 
 struct __align__(16) mid_bcast {
