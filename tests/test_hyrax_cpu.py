@@ -7,7 +7,6 @@ cross terms AND the verifier's folding), the final check, and the zero-knowledge
 decompression and eq tables are Python's own. Nothing here calls the C++ verifier for the verdict it asserts."""
 import ctypes
 
-import numpy as np
 import pytest
 
 from zkcnn_amd import P_MOD, R_MOD, from_mont, to_mont, u64p
