@@ -212,6 +212,15 @@ int32_t oracle_session_layer_dump(void *session, int32_t layer, int64_t meta[18]
     if (ori_v) std::memcpy(ori_v, L.ori_id_v.data(), L.ori_id_v.size() * 4);
     return 0;
 }
+// the circuit's constants (tests/test_verifier_python_cpu.py restates the verifier): the two_mul table (n entries, at most cap written) and every layer's scale
+int32_t oracle_session_consts(void *session, uint64_t *two_mul, uint64_t cap, uint64_t *n, uint64_t *layer_scales) {
+    if (!session || !n) return -1;
+    const layeredCircuit &C = ((oracleSession *) session)->p.C;
+    *n = C.two_mul.size();
+    if (two_mul) for (size_t k = 0; k < C.two_mul.size() && k < cap; ++k) FR(two_mul, k) = C.two_mul[k];
+    if (layer_scales) for (int i = 0; i < C.size; ++i) FR(layer_scales, i) = C.circuit[i].scale;
+    return 0;
+}
 int32_t oracle_session_poke(void *session, int32_t layer, uint64_t index, const uint64_t value[4]) {
     oracleSession *s = (oracleSession *) session;
     if (!s || !value || layer < 0 || layer >= s->p.C.size || index >= s->p.val[layer].size()) return -1;

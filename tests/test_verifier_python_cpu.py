@@ -1,0 +1,339 @@
+"""An independent verifier, in Python, for a real zero-knowledge transcript (review r4, weak #1: prover, oracle and verifier share `host/verifier.hpp`,
+`host/zk_mask.hpp` and `hyrax-bls12-381/polyCommit.hpp`; nothing outside that C++ had ever checked a whole proof).
+
+The protocol is restated here from its definition -- the reference's verifier loop (src/verifier.cpp:118-373: challenge order, round checks, the final check
+of a layer from the wiring predicates, the layer-0 combine) and this repo's zero-knowledge extension (masked round polynomials, masked evaluation claims,
+one proof of dot product for the revealed values, the input's masked claim opened against P + Z D_0) -- with Python integers, Python's own curve arithmetic
+and the gate lists as data (`oracle_session_layer_dump`). It parses the bytes of a transcript the CPU oracle produced (the GPU prover's are byte-identical:
+tests/test_zk_gpu.py), redraws the verifier's challenges from the seeded stream in the order the protocol fixes, and accepts; it rejects the same
+transcript with one byte changed anywhere in the sumcheck part. Models with general layers only (fully connected, ReLU / truncation): the FFT-convolution
+layers' closed-form predicates stay with tests/test_field_cpu.py."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import zkcnn_amd
+from tests import oracle_ffi
+from tests.test_circuit_cpu import dump
+from tests.test_hyrax_cpu import _decompress, _eq, _msm, _padd, _pmul, _points
+from zkcnn_amd import R_MOD, from_mont, u64p
+
+ZK, REUSE = zkcnn_amd.MODE_ZK, zkcnn_amd.MODE_REUSE_GENS
+U0, U1, V0, V1 = 0, 1, 2, 3
+
+
+class Reject(Exception):
+    pass
+
+
+class _Stream:
+    """the verifier's challenge stream: the draws of the seeded generator, in order"""
+
+    def __init__(self, oracle, seed, n=4096):
+        self.v, self.k = from_mont(oracle.random(n, seed)), 0
+
+    def draw(self, n=None):
+        if n is None:
+            self.k += 1
+            return self.v[self.k - 1]
+        self.k += n
+        return self.v[self.k - n:self.k]
+
+
+class _Msgs:
+    def __init__(self, data):
+        self.d, self.o = data, 0
+
+    def fr(self):
+        self.o += 32
+        if self.o > len(self.d):
+            raise Reject("truncated")
+        v = int.from_bytes(self.d[self.o - 32:self.o], "little")
+        if v >= R_MOD:
+            raise Reject("non-canonical field element")
+        return v
+
+    def g1(self):
+        self.o += 48
+        if self.o > len(self.d):
+            raise Reject("truncated")
+        try:
+            return _decompress(self.d[self.o - 48:self.o])
+        except AssertionError:
+            raise Reject("bad point")
+
+
+def _ev(coef_high_first, t):
+    acc = 0
+    for c in coef_high_first:
+        acc = (acc * t + c) % R_MOD
+    return acc
+
+
+def _z(rs):
+    z = 1
+    for r in rs:
+        z = z * r * (1 - r) % R_MOD
+    return z
+
+
+def _circuit(o, size):
+    n = ctypes.c_uint64(0)
+    o.lib.oracle_session_consts(ctypes.c_void_p(o.h), None, ctypes.c_uint64(0), ctypes.byref(n), None)
+    tm, sc = np.zeros((n.value, 4), dtype=np.uint64), np.zeros((size, 4), dtype=np.uint64)
+    o.lib.oracle_session_consts(ctypes.c_void_p(o.h), u64p(tm), ctypes.c_uint64(n.value), ctypes.byref(n), u64p(sc))
+    keys = ("ty", "size", "n_uni", "n_bin", "size_u0", "size_u1", "size_v0", "size_v1", "bl", "bl_u0", "bl_u1", "bl_v0", "bl_v1", "max_u", "max_v", "fft_bl", "phase2", "zero_start")
+    layers = []
+    for i in range(size):
+        m, uni, bn, ou, ov = dump(o.lib, o.h, i)
+        L = dict(zip(keys, m))
+        L.update(uni=uni, bin=bn, ori_u=ou, ori_v=ov)
+        assert i == 0 or (L["ty"] not in (1, 2, 9, 10) and L["phase2"]), "general layers with two phases only"
+        layers.append(L)
+    return layers, from_mont(tm), from_mont(sc)
+
+
+def _active(L, s):
+    """zk_mask.hpp slotActive for general layers: the operand table exists and its phase has a variable"""
+    if s >= 2 and not L["phase2"]:
+        return False
+    if (L["max_v"] if s >= 2 else L["max_u"]) < 1:
+        return False
+    return (L["bl_u0"], L["bl_u1"], L["bl_v0"], L["bl_v1"])[s] >= 0
+
+
+def python_verify(oracle, o, transcript, seed, n_layers, zk=True):
+    """raises Reject; returns the number of messages checked. zk=False: the plain protocol (the reference's own: no masks, claims in the clear, the input opened
+    by the inner-product argument -- which for these small inputs stops before its first round: the prover sends the combined row)"""
+    layers, two_mul, scales = _circuit(o, n_layers)
+    size, logn = len(layers), layers[0]["bl"]
+    rb, cb = logn >> 1, logn - (logn >> 1)
+    m = 1 << cb
+    gens_mont, _ = oracle.public_generators(m + (1 if zk else 0))
+    pts = _points(oracle, gens_mont)
+    g, H = pts[:m], pts[m] if zk else None
+    rnd, tr = _Stream(oracle, seed), _Msgs(transcript)
+    comm = [tr.g1() for _ in range(1 << rb)]
+
+    # ---- the mode's plan (zk_mask.hpp: plan): row 0 | g of every instance | M of every claim ----
+    inst, total = [], m
+    for i in list(range(size - 1, 0, -1)) + [0]:
+        l1 = layers[i]["max_u"] if i else layers[0]["bl"]
+        l2 = layers[i]["max_v"] if i and layers[i]["phase2"] else 0
+        deg = [2 + (1 if zk and (j == l1 - 1 or j == l1 + l2 - 1) else 0) for j in range(l1 + l2)]
+        inst.append(dict(layer=i, off=total, deg=deg))
+        total += 1 + sum(deg)
+    slot = {}
+    for i in range(1, size):
+        for s in range(4):
+            slot[(i, s)] = total
+            total += 1
+    rows = (total + m - 1) // m if zk else 0
+    mask_commit = [tr.g1() for _ in range(rows)]
+    sums = [tr.fr() if zk else 0 for _ in inst]
+    rho = rnd.draw() if zk else 0
+    u_vec, zmask = [0] * total, {}
+    closed = []                                       # what every instance leaves for the proof of dot product (gamma is drawn after the last of them)
+
+    # ---- stage 1: the layers (reference src/verifier.cpp:132-266) ----
+    alpha, beta, relu_rou = 1, 0, 1
+    r_u, r_v = {size: rnd.draw(layers[size - 1]["bl"])}, {size: []}
+    claim_u0, claim_v0 = {}, {}
+    prev_sum = tr.fr()                                # Vres: the public output's value
+    claim_u1 = claim_v1 = 0
+    n_checked = 1
+    for k, i in enumerate(range(size - 1, 0, -1)):
+        L = layers[i]
+        r_u[i] = rnd.draw(L["max_u"])
+        relu_rou = rnd.draw() if L["zero_start"] < L["size"] else 1
+        incoming = []                                  # (slot key, weight) of the masked claims this layer starts from
+        if i < size - 1:
+            if _active(layers[i + 1], U1):
+                incoming.append(((i + 1, U1), alpha))
+            if _active(layers[i + 1], V1):
+                incoming.append(((i + 1, V1), beta))
+        claim = (prev_sum + rho * sums[k]) % R_MOD
+        point, E = [], 1
+        # phase 1, phase 2
+        finals = {}
+        for ph, (ell, rs, s0) in enumerate(((L["max_u"], r_u[i], U0), (L["max_v"], None, V0))):
+            if ph == 1:
+                r_v[i] = rnd.draw(L["max_v"])
+                rs = r_v[i]
+            for j in range(ell):
+                deg = inst[k]["deg"][len(point)]
+                coef = [tr.fr() for _ in range(deg + 1)]      # highest first
+                n_checked += 1
+                if (_ev(coef, 0) + _ev(coef, 1)) % R_MOD != claim:
+                    raise Reject(f"layer {i} phase {ph + 1} round {j}")
+                claim = _ev(coef, rs[j])
+                point.append(rs[j])
+                E = E * (1 - rs[j]) % R_MOD
+            c0, c1 = tr.fr(), tr.fr()
+            finals[s0], finals[s0 + 1] = c0, c1
+            for b in range(2):
+                if _active(L, s0 + b):
+                    zmask[(i, s0 + b)] = _z(rs[:ell])
+        v = tr.fr() if zk else 0
+        claim = (claim - v) % R_MOD
+        closed.append(dict(k=k, point=point, E=E, v=v, incoming=incoming))
+        # the layer's final check from the wiring predicates (src/verifier.cpp:36-116, :256-262)
+        bl, r0, r1 = L["bl"], r_u[i + 1], r_v[i + 1]
+        sc = scales[i]
+        bg = [alpha * sc * x % R_MOD for x in _eq(r0[:bl])]
+        if beta:
+            bg = [(p + beta * sc * q) % R_MOD for p, q in zip(bg, _eq(r1[:bl]))]
+        if L["zero_start"] < L["size"]:
+            bg = [x * relu_rou % R_MOD if gi >= L["zero_start"] else x for gi, x in enumerate(bg)]
+        bu, bv = _eq(r_u[i]), _eq(r_v[i])
+        uni = [0, 0]
+        for gg, uu, lu, s in L["uni"].tolist():
+            uni[1 if lu else 0] += bg[gg] * bu[uu] * two_mul[s]
+        uni = [x * bv[0] % R_MOD for x in uni]
+        binv = [0, 0, 0]
+        for gg, uu, vv, s, ll in L["bin"].tolist():
+            binv[ll] += bg[gg] * bu[uu] % R_MOD * bv[vv] % R_MOD * two_mul[s]
+        cu0, cu1, cv0, cv1 = finals[U0], finals[U1], finals[V0], finals[V1]
+        expect = (binv[0] * cu0 * cv0 + binv[1] * cu1 * cv1 + binv[2] * cu1 * cv0 + uni[0] * cu0 + uni[1] * cu1) % R_MOD
+        if claim != expect:
+            raise Reject(f"final check of layer {i}")
+        claim_u0[i], claim_v0[i], claim_u1, claim_v1 = cu0, cv0, cu1, cv1
+        alpha = rnd.draw() if L["bl_u1"] >= 0 else 0
+        beta = rnd.draw() if L["bl_v1"] >= 0 else 0
+        prev_sum = (alpha * claim_u1 + beta * claim_v1) % R_MOD
+
+    # ---- stage 2: all claims about layer 0 in one sumcheck (src/verifier.cpp:268-357) ----
+    sig_u, sig_v = rnd.draw(size - 1), rnd.draw(size - 1)
+    r_u[0] = rnd.draw(logn)
+    prev_sum, incoming = 0, []
+    for i in range(1, size):
+        if layers[i]["bl_u0"] >= 0:
+            prev_sum += sig_u[i - 1] * claim_u0[i]
+        if layers[i]["bl_v0"] >= 0:
+            prev_sum += sig_v[i - 1] * claim_v0[i]
+        if _active(layers[i], U0):
+            incoming.append(((i, U0), sig_u[i - 1]))
+        if _active(layers[i], V0):
+            incoming.append(((i, V0), sig_v[i - 1]))
+    k = len(inst) - 1
+    claim = (prev_sum + rho * sums[k]) % R_MOD
+    point, E = [], 1
+    for j in range(logn):
+        coef = [tr.fr() for _ in range(inst[k]["deg"][j] + 1)]
+        n_checked += 1
+        if (_ev(coef, 0) + _ev(coef, 1)) % R_MOD != claim:
+            raise Reject(f"layer-0 combine, round {j}")
+        claim = _ev(coef, r_u[0][j])
+        point.append(r_u[0][j])
+        E = E * (1 - r_u[0][j]) % R_MOD
+    eval_in = tr.fr()
+    z_in = _z(r_u[0])
+    v = tr.fr() if zk else 0
+    claim = (claim - v) % R_MOD
+    closed.append(dict(k=k, point=point, E=E, v=v, incoming=incoming))
+    bg0 = _eq(r_u[0])
+    gr = 0
+    for i in range(1, size):
+        L = layers[i]
+        for blk, ori, sig, pt in ((L["bl_u0"], L["ori_u"], sig_u[i - 1], r_u[i]), (L["bl_v0"], L["ori_v"], sig_v[i - 1], r_v[i])):
+            if blk >= 0:
+                e = _eq(pt[:blk])
+                gr += sig * sum(bg0[int(ori[j])] * e[j] for j in range(len(ori)))
+    if eval_in * gr % R_MOD != claim:
+        raise Reject("layer-0 combine, final check")
+
+    Lrow, b = _eq(r_u[0][cb:]), _eq(r_u[0][:cb])
+    if not zk:
+        # the inner-product argument (polyCommit.hpp) with m <= IPA_STOP_LEN: no round, the combined row w = L^T Z in the clear: P == <w, g>, eval == <w, b>
+        assert m <= 256
+        wrow = [tr.fr() for _ in range(m)]
+        if tr.o != len(transcript):
+            raise Reject("trailing bytes")
+        if _msm(Lrow, comm) != _msm(wrow, g):
+            raise Reject("input opening: commitment")
+        if sum(p * q for p, q in zip(wrow, b)) % R_MOD != eval_in:
+            raise Reject("input opening: value")
+        return n_checked
+
+    # ---- the revealed values against the commitment: one proof of dot product over rows 1 .. (zk_mask.hpp) ----
+    gamma = rnd.draw()
+    w, y = 1, 0
+    for rec in closed:
+        it = inst[rec["k"]]
+        u_vec[it["off"]] = (u_vec[it["off"]] + w * rho) % R_MOD
+        o_ = it["off"] + 1
+        for j, d in enumerate(it["deg"]):
+            pw = w * rho % R_MOD
+            for e in range(d):
+                pw = pw * rec["point"][j] % R_MOD
+                u_vec[o_ + e] = (u_vec[o_ + e] + pw) % R_MOD
+            o_ += d
+        for key, weight in rec["incoming"]:
+            u_vec[slot[key]] = (u_vec[slot[key]] + w * rec["E"] % R_MOD * weight % R_MOD * zmask[key]) % R_MOD
+        y = (y + w * rec["v"]) % R_MOD
+        w = w * gamma % R_MOD
+    delta, t = [tr.g1() for _ in range(rows - 1)], tr.fr()
+    c = rnd.draw()
+    z = [tr.fr() for _ in range((rows - 1) * m)]
+    z_blind = [tr.fr() for _ in range(rows - 1)]
+    for rr in range(rows - 1):
+        if _padd(_msm(z[rr * m:(rr + 1) * m], g), _pmul(z_blind[rr], H)) != _padd(_pmul(c, mask_commit[rr + 1]), delta[rr]):
+            raise Reject(f"masks: row {rr + 1} of the proof of dot product")
+    if sum(p * q for p, q in zip(z, u_vec[m:])) % R_MOD != (c * y + t) % R_MOD:
+        raise Reject("masks: value of the proof of dot product")
+
+    # ---- the input's masked claim: proof of dot product against P + Z D_0 (polyCommit.hpp: verifyZk) ----
+    P = _padd(_msm(Lrow, comm), _pmul(z_in, mask_commit[0]))
+    d1, t1 = tr.g1(), tr.fr()
+    c1 = rnd.draw()
+    z1, zs1 = [tr.fr() for _ in range(m)], tr.fr()
+    if tr.o != len(transcript):
+        raise Reject("trailing bytes")
+    if _padd(_msm(z1, g), _pmul(zs1, H)) != _padd(_pmul(c1, P), d1):
+        raise Reject("input opening: commitment")
+    if sum(p * q for p, q in zip(z1, b)) % R_MOD != (c1 * eval_in + t1) % R_MOD:
+        raise Reject("input opening: value")
+    return n_checked
+
+
+@pytest.mark.parametrize("model,pic", [("custom:F8 F4", (4, 4, 1)), ("custom:F6 F5 F3", (4, 4, 1))])
+def test_python_verifier_accepts_the_zero_knowledge_transcript_and_rejects_corruptions(oracle, model, pic):
+    with oracle_ffi.OracleSession(model, pic, 1) as o:
+        res, tr = o.prove(seed=0x5EED0042, mode=ZK | REUSE)
+        assert res.accepted == 1
+        n = python_verify(oracle, o, tr, 0x5EED0042, res.n_layers)
+        assert n == res.n_rounds + 1                                   # Vres and every round polynomial went through a check
+        # another proof of the same statement (other coins through the seed): accepted too, and not the same bytes
+        res2, tr2 = o.prove(seed=0x5EED0043, mode=ZK | REUSE)
+        assert tr2 != tr and python_verify(oracle, o, tr2, 0x5EED0043, res.n_layers) == n
+        # one flipped byte in the sumcheck part (behind the commitments, before the proofs of dot product): rejected wherever it lands
+        logn = res.input_bits
+        start = 48 * (1 << (logn >> 1))
+        import random
+        rnd = random.Random(9)
+        for _ in range(6):
+            pos = rnd.randrange(start, len(tr) - 32 * (1 << (logn - (logn >> 1))))
+            bad = bytearray(tr)
+            bad[pos] ^= 1 << rnd.randrange(8)
+            with pytest.raises(Reject):
+                python_verify(oracle, o, bytes(bad), 0x5EED0042, res.n_layers)
+        # the verifier of the product agrees on both counts
+        assert o.verify(tr, seed=0x5EED0042, mode=ZK | REUSE).accepted == 1
+
+
+@pytest.mark.parametrize("model,pic", [("custom:F8 F4", (4, 4, 1)), ("custom:F6 F5 F3", (4, 4, 1))])
+def test_python_verifier_accepts_the_plain_transcript_and_rejects_corruptions(oracle, model, pic):
+    """the same restatement without the zero-knowledge extension: the reference's protocol as it is (src/verifier.cpp:118-373), claims in the clear"""
+    with oracle_ffi.OracleSession(model, pic, 1) as o:
+        res, tr = o.prove(seed=0x5EED0044, mode=REUSE)
+        assert res.accepted == 1
+        assert python_verify(oracle, o, tr, 0x5EED0044, res.n_layers, zk=False) == res.n_rounds + 1
+        import random
+        rnd = random.Random(10)
+        for _ in range(8):
+            pos = rnd.randrange(len(tr))
+            bad = bytearray(tr)
+            bad[pos] ^= 1 << rnd.randrange(8)
+            with pytest.raises(Reject):
+                python_verify(oracle, o, bytes(bad), 0x5EED0044, res.n_layers, zk=False)
