@@ -47,8 +47,10 @@ def _decompress(b):
     """48 bytes, big-endian x; bit 7 = compressed, bit 6 = infinity, bit 5 = the larger of the two roots (the published BLS12-381 encoding)"""
     assert b[0] & 0x80
     if b[0] & 0x40:
+        assert b == bytes([0xc0]) + bytes(47)              # the one encoding of the point at infinity
         return None
     x = int.from_bytes(bytes([b[0] & 0x1f]) + b[1:], "big")
+    assert x < P_MOD
     y = pow((x ** 3 + 4) % P_MOD, (P_MOD + 1) // 4, P_MOD)
     assert (y * y - x ** 3 - 4) % P_MOD == 0
     if bool(b[0] & 0x20) != (y > P_MOD - y):
