@@ -6,8 +6,10 @@ of a layer from the wiring predicates, the layer-0 combine) and this repo's zero
 one proof of dot product for the revealed values, the input's masked claim opened against P + Z D_0) -- with Python integers, Python's own curve arithmetic
 and the gate lists as data (`oracle_session_layer_dump`). It parses the bytes of a transcript the CPU oracle produced (the GPU prover's are byte-identical:
 tests/test_zk_gpu.py), redraws the verifier's challenges from the seeded stream in the order the protocol fixes, and accepts; it rejects the same
-transcript with one byte changed anywhere in the sumcheck part. Models with general layers only (fully connected, direct convolution, pooling, ReLU /
-truncation, with and without a second phase): the FFT-convolution layers' closed-form predicates stay with tests/test_field_cpu.py."""
+transcript with one bit flipped -- with the same verdict as the product's verifier on every corrupted copy. Every layer type of the reference: fully
+connected, direct convolution, pooling, ReLU / truncation (with and without a second phase), and the FFT convolution's PADDING / FFT / DOT_PROD / IFFT layers
+with their closed-form predicates (the multilinear extension of the DFT matrix, the (vector, position) split of the padding layer, the cubic phase of the
+dot-product layer) over two pictures per circuit."""
 import ctypes
 
 import numpy as np
@@ -89,14 +91,18 @@ def _circuit(o, size):
         m, uni, bn, ou, ov = dump(o.lib, o.h, i)
         L = dict(zip(keys, m))
         L.update(uni=uni, bin=bn, ori_u=ou, ori_v=ov)
-        assert i == 0 or L["ty"] not in (1, 2, 9, 10), "general layers only (no FFT / IFFT / DOT_PROD / PADDING)"
         layers.append(L)
     return layers, from_mont(tm), from_mont(sc)
 
 
+FFT, IFFT, DOT_PROD, PADDING = 1, 2, 9, 10          # layerType (reference src/circuit.h:35-37)
+
+
 def _active(L, s):
-    """zk_mask.hpp slotActive for general layers: the operand table exists and its phase has a variable"""
+    """zk_mask.hpp slotActive: the operand table exists and its phase has a variable (a DOT_PROD layer's phase 1 ends in ONE claim)"""
     if s >= 2 and not L["phase2"]:
+        return False
+    if L["ty"] == DOT_PROD and s == 0:
         return False
     if (L["max_v"] if s >= 2 else L["max_u"]) < 1:
         return False
@@ -121,7 +127,8 @@ def python_verify(oracle, o, transcript, seed, n_layers, zk=True):
     for i in list(range(size - 1, 0, -1)) + [0]:
         l1 = layers[i]["max_u"] if i else layers[0]["bl"]
         l2 = layers[i]["max_v"] if i and layers[i]["phase2"] else 0
-        deg = [2 + (1 if zk and (j == l1 - 1 or j == l1 + l2 - 1) else 0) for j in range(l1 + l2)]
+        base1 = 3 if i and layers[i]["ty"] == DOT_PROD else 2          # a DOT_PROD layer's phase 1 is a cubic sumcheck (reference src/prover.cpp:103-144)
+        deg = [(base1 if j < l1 else 2) + (1 if zk and (j == l1 - 1 or j == l1 + l2 - 1) else 0) for j in range(l1 + l2)]
         inst.append(dict(layer=i, off=total, deg=deg))
         total += 1 + sum(deg)
     slot = {}
@@ -138,7 +145,7 @@ def python_verify(oracle, o, transcript, seed, n_layers, zk=True):
 
     # ---- stage 1: the layers (reference src/verifier.cpp:132-266) ----
     alpha, beta, relu_rou = 1, 0, 1
-    r_u, r_v = {size: rnd.draw(layers[size - 1]["bl"])}, {size: []}
+    r_u, r_v = {size: rnd.draw(layers[size - 1]["bl"]), size + 1: []}, {size: [], size + 1: []}
     claim_u0, claim_v0 = {}, {}
     prev_sum = tr.fr()                                # Vres: the public output's value
     claim_u1 = claim_v1 = 0
@@ -149,10 +156,14 @@ def python_verify(oracle, o, transcript, seed, n_layers, zk=True):
         relu_rou = rnd.draw() if L["zero_start"] < L["size"] else 1
         incoming = []                                  # (slot key, weight) of the masked claims this layer starts from
         if i < size - 1:
-            if _active(layers[i + 1], U1):
-                incoming.append(((i + 1, U1), alpha))
-            if _active(layers[i + 1], V1):
-                incoming.append(((i + 1, V1), beta))
+            if layers[i + 1]["ty"] in (FFT, IFFT):           # the transform's claim is carried as it is
+                if _active(layers[i + 1], U1):
+                    incoming.append(((i + 1, U1), 1))
+            else:
+                if _active(layers[i + 1], U1):
+                    incoming.append(((i + 1, U1), alpha))
+                if _active(layers[i + 1], V1):
+                    incoming.append(((i + 1, V1), beta))
         claim = (prev_sum + rho * sums[k]) % R_MOD
         point, E = [], 1
         # phase 1, phase 2
@@ -174,7 +185,10 @@ def python_verify(oracle, o, transcript, seed, n_layers, zk=True):
                 claim = _ev(coef, rs[j])
                 point.append(rs[j])
                 E = E * (1 - rs[j]) % R_MOD
-            c0, c1 = tr.fr(), tr.fr()
+            if L["ty"] == DOT_PROD and ph == 0:
+                c0, c1 = 0, tr.fr()                          # sumcheckDotProdFinalize1 (reference src/prover.cpp:146-153): the one operand table's value
+            else:
+                c0, c1 = tr.fr(), tr.fr()
             finals[s0], finals[s0 + 1] = c0, c1
             for b in range(2):
                 if _active(L, s0 + b):
@@ -184,30 +198,63 @@ def python_verify(oracle, o, transcript, seed, n_layers, zk=True):
         closed.append(dict(k=k, point=point, E=E, v=v, incoming=incoming))
         # the layer's final check from the wiring predicates (src/verifier.cpp:36-116, :256-262)
         bl, r0, r1 = L["bl"], r_u[i + 1], r_v[i + 1]
-        sc = scales[i]
-        bg = [alpha * sc * x % R_MOD for x in _eq(r0[:bl])]
-        if beta:
-            bg = [(p + beta * sc * q) % R_MOD for p, q in zip(bg, _eq(r1[:bl]))]
-        if L["zero_start"] < L["size"]:
-            bg = [x * relu_rou % R_MOD if gi >= L["zero_start"] else x for gi, x in enumerate(bg)]
+        sc, ty, fft_bl = scales[i], L["ty"], L["fft_bl"]
         bu = _eq(r_u[i])
-        uni = [0, 0]
-        for gg, uu, lu, s in L["uni"].tolist():
-            uni[1 if lu else 0] += bg[gg] * bu[uu] * two_mul[s]
-        binv = [0, 0, 0]
-        if L["phase2"]:
-            bv = _eq(r_v[i])
-            uni = [x * bv[0] % R_MOD for x in uni]
-            for gg, uu, vv, s, ll in L["bin"].tolist():
-                binv[ll] += bg[gg] * bu[uu] % R_MOD * bv[vv] % R_MOD * two_mul[s]
+        uni, binv = [0, 0], [0, 0, 0]
+        if ty in (FFT, IFFT):
+            # the transform as a layer: out[g] = scale sum_u w^{+-g u} in[u]; its predicate at (r0, r_u) is the multilinear extension of the DFT matrix
+            # (reference src/verifier.cpp:89-93 with the table of src/utils.cpp:61-103, restated from its definition as in tests/test_field_cpu.py)
+            w = from_mont(oracle.root_of_unity(fft_bl))[0]
+            gbits = fft_bl - 1 if ty == IFFT else fft_bl
+            if ty == IFFT:
+                w = pow(w, -1, R_MOD)
+            eg = _eq(r0[:gbits])
+            wp = [pow(w, e, R_MOD) for e in range(1 << fft_bl)]
+            for uu in range(1 << L["max_u"]):
+                phi = sc * sum(eg[gi] * wp[gi * uu % (1 << fft_bl)] for gi in range(1 << gbits)) % R_MOD
+                uni[1] += phi * bu[uu]
+        else:
+            if ty == PADDING:
+                # outputs are (vector, position): the vector part carries the two-point claim of the DOT_PROD layer two levels up, the position part the
+                # transform's sumcheck point (reference src/verifier.cpp:46-58)
+                fft_blh = fft_bl - 1
+                hi = [alpha * x % R_MOD for x in _eq(r_u[i + 2][fft_bl:fft_bl + bl - fft_blh])]
+                if beta:
+                    hi = [(p + beta * q) % R_MOD for p, q in zip(hi, _eq(r_v[i + 2][:bl - fft_blh]))]
+                lo = _eq(r0[:fft_blh])
+                bg = [hi[gi >> fft_blh] * lo[gi & ((1 << fft_blh) - 1)] % R_MOD for gi in range(1 << bl)]
+            elif ty == DOT_PROD:
+                # (reference src/verifier.cpp:59-69) output (vector, frequency): the vector part at the point two levels up, the frequency part tied to this
+                # layer's own point by eq
+                bg = [alpha * x % R_MOD for x in _eq(r_u[i + 2][fft_bl - 1:fft_bl - 1 + bl - fft_bl])]
+                same = 1
+                for j in range(fft_bl):
+                    same = same * (r0[j] * r_u[i][j] + (1 - r0[j]) * (1 - r_u[i][j])) % R_MOD
+                bu = [same * x % R_MOD for x in _eq(r_u[i][fft_bl:L["max_u"]])]
+            else:
+                bg = [alpha * sc * x % R_MOD for x in _eq(r0[:bl])]
+                if beta:
+                    bg = [(p + beta * sc * q) % R_MOD for p, q in zip(bg, _eq(r1[:bl]))]
+                if L["zero_start"] < L["size"]:
+                    bg = [x * relu_rou % R_MOD if gi >= L["zero_start"] else x for gi, x in enumerate(bg)]
+            for gg, uu, lu, s in L["uni"].tolist():
+                uni[1 if lu else 0] += bg[gg] * bu[uu] * two_mul[s]
+            if L["phase2"]:
+                bv = _eq(r_v[i])
+                uni = [x * bv[0] % R_MOD for x in uni]
+                for gg, uu, vv, s, ll in L["bin"].tolist():
+                    binv[ll] += bg[gg] * bu[uu] % R_MOD * bv[vv] % R_MOD * (1 if ty == DOT_PROD else two_mul[s])
         cu0, cu1, cv0, cv1 = finals[U0], finals[U1], finals[V0], finals[V1]
         expect = (binv[0] * cu0 * cv0 + binv[1] * cu1 * cv1 + binv[2] * cu1 * cv0 + uni[0] * cu0 + uni[1] * cu1) % R_MOD
         if claim != expect:
             raise Reject(f"final check of layer {i}")
         claim_u0[i], claim_v0[i], claim_u1, claim_v1 = cu0, cv0, cu1, cv1
-        alpha = rnd.draw() if L["bl_u1"] >= 0 else 0
-        beta = rnd.draw() if L["bl_v1"] >= 0 else 0
-        prev_sum = (alpha * claim_u1 + beta * claim_v1) % R_MOD
+        if ty in (FFT, IFFT):
+            prev_sum = claim_u1                              # carry the claim, alpha / beta stay as they are (reference src/verifier.cpp:228-230)
+        else:
+            alpha = rnd.draw() if L["bl_u1"] >= 0 else 0
+            beta = rnd.draw() if L["bl_v1"] >= 0 else 0
+            prev_sum = (alpha * claim_u1 + beta * claim_v1) % R_MOD
 
     # ---- stage 2: all claims about layer 0 in one sumcheck (src/verifier.cpp:268-357) ----
     sig_u, sig_v = rnd.draw(size - 1), rnd.draw(size - 1)
@@ -303,12 +350,13 @@ def python_verify(oracle, o, transcript, seed, n_layers, zk=True):
     return n_checked
 
 
-MODELS = [("custom:F8 F4", (4, 4, 1)), ("custom:F6 F5 F3", (4, 4, 1)), ("custom:C2:3:1:s M F4", (4, 4, 1)), ("custom:C2:3:1:n A F4", (4, 4, 2))]
+MODELS = [("custom:F8 F4", (4, 4, 1), 1), ("custom:F6 F5 F3", (4, 4, 1), 1), ("custom:C2:3:1:s M F4", (4, 4, 1), 1), ("custom:C2:3:1:n A F4", (4, 4, 2), 1),
+          ("custom:C2:3:1:f M F4", (4, 4, 1), 2)]          # the last one: an FFT convolution over two pictures (PADDING, FFT, DOT_PROD, IFFT layers)
 
 
-@pytest.mark.parametrize("model,pic", MODELS)
-def test_python_verifier_accepts_the_zero_knowledge_transcript_and_rejects_corruptions(oracle, model, pic):
-    with oracle_ffi.OracleSession(model, pic, 1) as o:
+@pytest.mark.parametrize("model,pic,pp", MODELS)
+def test_python_verifier_accepts_the_zero_knowledge_transcript_and_rejects_corruptions(oracle, model, pic, pp):
+    with oracle_ffi.OracleSession(model, pic, pp) as o:
         res, tr = o.prove(seed=0x5EED0042, mode=ZK | REUSE)
         assert res.accepted == 1
         n = python_verify(oracle, o, tr, 0x5EED0042, res.n_layers)
@@ -338,10 +386,10 @@ def test_python_verifier_accepts_the_zero_knowledge_transcript_and_rejects_corru
         assert o.verify(tr, seed=0x5EED0042, mode=ZK | REUSE).accepted == 1
 
 
-@pytest.mark.parametrize("model,pic", MODELS)
-def test_python_verifier_accepts_the_plain_transcript_and_rejects_corruptions(oracle, model, pic):
+@pytest.mark.parametrize("model,pic,pp", MODELS)
+def test_python_verifier_accepts_the_plain_transcript_and_rejects_corruptions(oracle, model, pic, pp):
     """the same restatement without the zero-knowledge extension: the reference's protocol as it is (src/verifier.cpp:118-373), claims in the clear"""
-    with oracle_ffi.OracleSession(model, pic, 1) as o:
+    with oracle_ffi.OracleSession(model, pic, pp) as o:
         res, tr = o.prove(seed=0x5EED0044, mode=REUSE)
         assert res.accepted == 1
         assert python_verify(oracle, o, tr, 0x5EED0044, res.n_layers, zk=False) == res.n_rounds + 1
