@@ -57,6 +57,20 @@ def test_every_message_of_the_gpu_prover_depends_on_the_coins(built, monkeypatch
         assert len(same) <= 2, (len(same), len(t1) // 16)
 
 
+def test_gpu_transcripts_pass_the_independent_python_verifier(built):
+    """tests/test_verifier_python_cpu.py restates the verifier (the reference's loop + the zero-knowledge extension) in Python; here it reads what the HIP
+    prover wrote: a fully connected model and an FFT convolution over two pictures, plain protocol and zero-knowledge mode"""
+    from tests.test_verifier_python_cpu import python_verify
+    orc = oracle_ffi.Oracle(oracle_ffi.load())
+    for model, pic, pp in (("custom:F8 F4", (4, 4, 1), 1), ("custom:C2:3:1:f M F4", (4, 4, 1), 2)):
+        with zkcnn_amd.Session(model, pic, pp) as s, oracle_ffi.OracleSession(model, pic, pp) as o:       # (the oracle session: the circuit's structure as data)
+            for zk in (False, True):
+                mode = (ZK if zk else 0) | REUSE
+                res, tr = s.prove(seed=0x5EED0050, mode=mode)
+                assert res.accepted == 1
+                assert python_verify(orc, o, tr, 0x5EED0050, res.n_layers, zk=zk) == res.n_rounds + 1
+
+
 def test_full_size_vgg11_zero_knowledge(built):
     with zkcnn_amd.Session("vgg11", (32, 32, 3), 1) as s:
         a, ta = s.prove(mode=ZK | REUSE)                      # OS randomness
