@@ -61,7 +61,7 @@ def test_gpu_transcripts_pass_the_independent_python_verifier(built):
     """tests/test_verifier_python_cpu.py restates the verifier (the reference's loop + the zero-knowledge extension) in Python; here it reads what the HIP
     prover wrote: a fully connected model and an FFT convolution over two pictures, plain protocol and zero-knowledge mode"""
     from tests.test_verifier_python_cpu import python_verify
-    orc = oracle_ffi.Oracle(oracle_ffi.load())
+    orc = oracle_ffi.load()
     for model, pic, pp in (("custom:F8 F4", (4, 4, 1), 1), ("custom:C2:3:1:f M F4", (4, 4, 1), 2)):
         with zkcnn_amd.Session(model, pic, pp) as s, oracle_ffi.OracleSession(model, pic, pp) as o:       # (the oracle session: the circuit's structure as data)
             for zk in (False, True):
