@@ -354,7 +354,7 @@ MODELS = [("custom:F8 F4", (4, 4, 1), 1), ("custom:F6 F5 F3", (4, 4, 1), 1), ("c
           ("custom:C2:3:1:f M F4", (4, 4, 1), 2)]          # the last one: an FFT convolution over two pictures (PADDING, FFT, DOT_PROD, IFFT layers)
 
 
-@pytest.mark.parametrize("model,pic,pp", MODELS)
+@pytest.mark.parametrize("model,pic,pp", [MODELS[0], MODELS[2], MODELS[4]])
 def test_python_verifier_accepts_the_zero_knowledge_transcript_and_rejects_corruptions(oracle, model, pic, pp):
     with oracle_ffi.OracleSession(model, pic, pp) as o:
         res, tr = o.prove(seed=0x5EED0042, mode=ZK | REUSE)
