@@ -221,6 +221,22 @@ int32_t oracle_session_consts(void *session, uint64_t *two_mul, uint64_t cap, ui
     if (layer_scales) for (int i = 0; i < C.size; ++i) FR(layer_scales, i) = C.circuit[i].scale;
     return 0;
 }
+// the bytes a non-interactive proof's hash chain starts from: the statement's encoding (host/replay.hpp: fiatShamir::absorbStatement) and the digest of the
+// public generators (n_gens of them), as the session's verifier absorbs them before the first message (tests/test_verifier_python_cpu.py hashes them itself)
+int32_t oracle_session_fs_statement(void *session, uint64_t n_gens, uint8_t *out, uint64_t cap, uint64_t *len) {
+    oracleSession *s = (oracleSession *) session;
+    if (!s || !len || !s->nn) return -1;
+    fiatShamir fs;
+    zkcnn_model_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.model = s->model_name.c_str();
+    d.pic_x = s->pic_x; d.pic_y = s->pic_y; d.pic_channel = s->pic_channel; d.pic_cnt = s->pic_cnt;
+    fs.absorbStatement(d, s->nn->scales(), s->p.C);
+    fs.absorb(zkff::publicGeneratorSet(n_gens).digest, 32);
+    *len = fs.pendingData().size();
+    if (out && *len <= cap) std::memcpy(out, fs.pendingData().data(), *len);
+    return 0;
+}
 int32_t oracle_session_poke(void *session, int32_t layer, uint64_t index, const uint64_t value[4]) {
     oracleSession *s = (oracleSession *) session;
     if (!s || !value || layer < 0 || layer >= s->p.C.size || index >= s->p.val[layer].size()) return -1;

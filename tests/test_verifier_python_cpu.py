@@ -40,12 +40,41 @@ class _Stream:
             self.k += 1
             return self.v[self.k - 1]
         self.k += n
-        return self.v[self.k - n:self.k]
+        return list(self.v[self.k - n:self.k])
+
+
+class _FsStream:
+    """the non-interactive mode's challenges (host/replay.hpp: fiatShamir): state <- BLAKE2s-256(state || everything absorbed since the last challenge), one step
+    per draw; the state with bit 255 cleared IS the challenge's Montgomery form if it is below r, else one more step on nothing. A field element is absorbed as
+    its Montgomery form (32 bytes), a group element as its 48-byte encoding; the chain starts from the statement's encoding and the generators' digest."""
+
+    def __init__(self, statement):
+        import hashlib
+        self.h = hashlib.blake2s
+        self.st = self.h(b"zkcnn-amd/fiat-shamir/v2").digest()
+        self.pending = bytearray(statement)
+        self.rinv = pow(1 << 256, -1, R_MOD)
+
+    def absorb_fr(self, v):
+        self.pending += ((v << 256) % R_MOD).to_bytes(32, "little")
+
+    def absorb(self, b):
+        self.pending += b
+
+    def draw(self, n=None):
+        if n is not None:
+            return [self.draw() for _ in range(n)]
+        while True:
+            self.st = self.h(self.st + bytes(self.pending)).digest()
+            self.pending = bytearray()
+            t = int.from_bytes(self.st, "little") & ((1 << 255) - 1)
+            if t < R_MOD:
+                return t * self.rinv % R_MOD
 
 
 class _Msgs:
-    def __init__(self, data):
-        self.d, self.o = data, 0
+    def __init__(self, data, tap=None):
+        self.d, self.o, self.tap = data, 0, tap
 
     def fr(self):
         self.o += 32
@@ -54,6 +83,8 @@ class _Msgs:
         v = int.from_bytes(self.d[self.o - 32:self.o], "little")
         if v >= R_MOD:
             raise Reject("non-canonical field element")
+        if self.tap:
+            self.tap.absorb_fr(v)
         return v
 
     def g1(self):
@@ -61,9 +92,12 @@ class _Msgs:
         if self.o > len(self.d):
             raise Reject("truncated")
         try:
-            return _decompress(self.d[self.o - 48:self.o])
+            pt = _decompress(self.d[self.o - 48:self.o])
         except AssertionError:
             raise Reject("bad point")
+        if self.tap:
+            self.tap.absorb(self.d[self.o - 48:self.o])
+        return pt
 
 
 def _ev(coef_high_first, t):
@@ -109,7 +143,7 @@ def _active(L, s):
     return (L["bl_u0"], L["bl_u1"], L["bl_v0"], L["bl_v1"])[s] >= 0
 
 
-def python_verify(oracle, o, transcript, seed, n_layers, zk=True):
+def python_verify(oracle, o, transcript, seed, n_layers, zk=True, fs_statement=None):
     """raises Reject; returns the number of messages checked. zk=False: the plain protocol (the reference's own: no masks, claims in the clear, the input opened
     by the inner-product argument -- which for these small inputs stops before its first round: the prover sends the combined row)"""
     layers, two_mul, scales = _circuit(o, n_layers)
@@ -119,7 +153,10 @@ def python_verify(oracle, o, transcript, seed, n_layers, zk=True):
     gens_mont, _ = oracle.public_generators(m + (1 if zk else 0))
     pts = _points(oracle, gens_mont)
     g, H = pts[:m], pts[m] if zk else None
-    rnd, tr = _Stream(oracle, seed), _Msgs(transcript)
+    # fs_statement: the non-interactive mode -- every challenge is a hash of the statement and of the messages so far, drawn AFTER the message it answers
+    lazy = fs_statement is not None
+    rnd = _FsStream(fs_statement) if lazy else _Stream(oracle, seed)
+    tr = _Msgs(transcript, rnd if lazy else None)
     comm = [tr.g1() for _ in range(1 << rb)]
 
     # ---- the mode's plan (zk_mask.hpp: plan): row 0 | g of every instance | M of every claim ----
@@ -180,6 +217,8 @@ def python_verify(oracle, o, transcript, seed, n_layers, zk=True):
                 deg = inst[k]["deg"][len(point)]
                 coef = [tr.fr() for _ in range(deg + 1)]      # highest first
                 n_checked += 1
+                if lazy:
+                    rs[j] = rnd.draw()                       # (the draws made up front are overwritten: reference order kept, values replaced)
                 if (_ev(coef, 0) + _ev(coef, 1)) % R_MOD != claim:
                     raise Reject(f"layer {i} phase {ph + 1} round {j}")
                 claim = _ev(coef, rs[j])
@@ -275,6 +314,8 @@ def python_verify(oracle, o, transcript, seed, n_layers, zk=True):
     for j in range(logn):
         coef = [tr.fr() for _ in range(inst[k]["deg"][j] + 1)]
         n_checked += 1
+        if lazy:
+            r_u[0][j] = rnd.draw()
         if (_ev(coef, 0) + _ev(coef, 1)) % R_MOD != claim:
             raise Reject(f"layer-0 combine, round {j}")
         claim = _ev(coef, r_u[0][j])
@@ -410,3 +451,41 @@ def test_python_verifier_accepts_the_plain_transcript_and_rejects_corruptions(or
             assert mine == (o.verify(bytes(bad), seed=0x5EED0044, mode=REUSE).accepted == 1), pos
             rejected += not mine
         assert rejected >= 8
+
+
+
+def _fs_statement(o, n_gens):
+    ln = ctypes.c_uint64(0)
+    buf = (ctypes.c_uint8 * (1 << 16))()
+    assert o.lib.oracle_session_fs_statement(ctypes.c_void_p(o.h), ctypes.c_uint64(n_gens), buf, ctypes.c_uint64(len(buf)), ctypes.byref(ln)) == 0
+    return bytes(buf[:ln.value])
+
+
+@pytest.mark.parametrize("model,pic,pp", [MODELS[0], MODELS[4]])
+@pytest.mark.parametrize("zk", [False, True])
+def test_python_verifier_accepts_non_interactive_proofs(oracle, model, pic, pp, zk):
+    """Fiat-Shamir: the proof is the transcript, every challenge a BLAKE2s chain step over the statement and the messages so far (hashlib here).
+    The statement's encoding is taken as bytes from the session; the chain, the challenges' derivation and every check are Python's own. One flipped bit
+    changes every later challenge: rejected, as by the product's off-line verifier."""
+    FS = zkcnn_amd.MODE_FIAT_SHAMIR
+    mode = FS | (ZK if zk else 0)
+    with oracle_ffi.OracleSession(model, pic, pp) as o:
+        res, tr = o.prove(mode=mode)
+        assert res.accepted == 1 and o.verify(tr, mode=mode).accepted == 1
+        cb = res.input_bits - (res.input_bits >> 1)
+        stmt = _fs_statement(o, (1 << cb) + (1 if zk else 0))
+        assert python_verify(oracle, o, tr, None, res.n_layers, zk=zk, fs_statement=stmt) == res.n_rounds + 1
+        import random
+        rnd = random.Random(12)
+        for _ in range(4):
+            bad = bytearray(tr)
+            bad[rnd.randrange(len(tr))] ^= 1 << rnd.randrange(8)
+            try:
+                python_verify(oracle, o, bytes(bad), None, res.n_layers, zk=zk, fs_statement=stmt)
+                mine = True
+            except Reject:
+                mine = False
+            assert mine == (o.verify(bytes(bad), mode=mode).accepted == 1)
+        # another statement (one byte of its encoding changed): unrelated challenges, the same proof does not verify
+        with pytest.raises(Reject):
+            python_verify(oracle, o, tr, None, res.n_layers, zk=zk, fs_statement=stmt[:-1] + bytes([stmt[-1] ^ 1]))

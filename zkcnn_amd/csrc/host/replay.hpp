@@ -37,6 +37,7 @@ public:
     bool rawMontgomery() const override { return true; }
     const uint32_t *stateWords() const { return st; }
     const uint64_t *pendingBytes() const { return &pending_len; }
+    const std::vector<uint8_t> &pendingData() const { return pending; }       // what the next challenge will hash behind the state (tests: the statement's encoding)
     // binds the statement: the whole model descriptor, every quantisation scale (they fix gate exponents, layer sizes and Q_MAX), the
     // shape of every layer and a digest of the wiring (gate lists, subset maps): statements that differ anywhere get unrelated challenges
     void absorbStatement(const zkcnn_model_desc &d, const vector<int> &scales, const layeredCircuit &C) {
