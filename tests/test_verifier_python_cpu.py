@@ -19,7 +19,7 @@ import zkcnn_amd
 from tests import oracle_ffi
 from tests.test_circuit_cpu import dump
 from tests.test_hyrax_cpu import _decompress, _eq, _msm, _padd, _pmul, _points
-from zkcnn_amd import R_MOD, from_mont, u64p
+from zkcnn_amd import P_MOD, R_MOD, from_mont, u64p
 
 ZK, REUSE = zkcnn_amd.MODE_ZK, zkcnn_amd.MODE_REUSE_GENS
 U0, U1, V0, V1 = 0, 1, 2, 3
@@ -143,20 +143,29 @@ def _active(L, s):
     return (L["bl_u0"], L["bl_u1"], L["bl_v0"], L["bl_v1"])[s] >= 0
 
 
-def python_verify(oracle, o, transcript, seed, n_layers, zk=True, fs_statement=None):
+G1_X = 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb      # the generator every BLS12-381 implementation publishes
+G1_Y = 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
+
+
+def python_verify(oracle, o, transcript, seed, n_layers, zk=True, fs_statement=None, fresh_gens=False):
     """raises Reject; returns the number of messages checked. zk=False: the plain protocol (the reference's own: no masks, claims in the clear, the input opened
     by the inner-product argument -- which for these small inputs stops before its first round: the prover sends the combined row)"""
     layers, two_mul, scales = _circuit(o, n_layers)
     size, logn = len(layers), layers[0]["bl"]
     rb, cb = logn >> 1, logn - (logn >> 1)
     m = 1 << cb
-    gens_mont, _ = oracle.public_generators(m + (1 if zk else 0))
-    pts = _points(oracle, gens_mont)
-    g, H = pts[:m], pts[m] if zk else None
     # fs_statement: the non-interactive mode -- every challenge is a hash of the statement and of the messages so far, drawn AFTER the message it answers
     lazy = fs_statement is not None
     rnd = _FsStream(fs_statement) if lazy else _Stream(oracle, seed)
     tr = _Msgs(transcript, rnd if lazy else None)
+    if fresh_gens:
+        # the reference's own set-up (src/verifier.cpp:119-128): the verifier draws a random multiple of the base point per column, before anything else
+        assert (G1_Y * G1_Y - G1_X ** 3 - 4) % P_MOD == 0
+        pts = [_pmul(k, (G1_X, G1_Y)) for k in rnd.draw(m + (1 if zk else 0))]
+    else:
+        gens_mont, _ = oracle.public_generators(m + (1 if zk else 0))
+        pts = _points(oracle, gens_mont)
+    g, H = pts[:m], pts[m] if zk else None
     comm = [tr.g1() for _ in range(1 << rb)]
 
     # ---- the mode's plan (zk_mask.hpp: plan): row 0 | g of every instance | M of every claim ----
@@ -489,3 +498,18 @@ def test_python_verifier_accepts_non_interactive_proofs(oracle, model, pic, pp, 
         # another statement (one byte of its encoding changed): unrelated challenges, the same proof does not verify
         with pytest.raises(Reject):
             python_verify(oracle, o, tr, None, res.n_layers, zk=zk, fs_statement=stmt[:-1] + bytes([stmt[-1] ^ 1]))
+
+
+def test_python_verifier_accepts_proofs_over_fresh_generators(oracle):
+    """the reference's semantics (src/verifier.cpp:119-128): the verifier draws the commitment generators itself, k_i G from its challenge stream, for every
+    proof -- the generators here are Python's own multiples of the published base point"""
+    model, pic, pp = MODELS[2]
+    with oracle_ffi.OracleSession(model, pic, pp) as o:
+        for zk in (False, True):
+            res, tr = o.prove(seed=0x5EED0060, mode=ZK if zk else 0)
+            assert res.accepted == 1
+            assert python_verify(oracle, o, tr, 0x5EED0060, res.n_layers, zk=zk, fresh_gens=True) == res.n_rounds + 1
+            bad = bytearray(tr)
+            bad[len(tr) // 3] ^= 4
+            with pytest.raises(Reject):
+                python_verify(oracle, o, bytes(bad), 0x5EED0060, res.n_layers, zk=zk, fresh_gens=True)
