@@ -147,7 +147,7 @@ G1_X = 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83
 G1_Y = 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
 
 
-def python_verify(oracle, o, transcript, seed, n_layers, zk=True, fs_statement=None, fresh_gens=False):
+def python_verify(oracle, o, transcript, seed, n_layers, zk=True, fs_statement=None, fresh_gens=False, full_ipa=False):
     """raises Reject; returns the number of messages checked. zk=False: the plain protocol (the reference's own: no masks, claims in the clear, the input opened
     by the inner-product argument -- which for these small inputs stops before its first round: the prover sends the combined row)"""
     layers, two_mul, scales = _circuit(o, n_layers)
@@ -348,14 +348,24 @@ def python_verify(oracle, o, transcript, seed, n_layers, zk=True, fs_statement=N
 
     Lrow, b = _eq(r_u[0][cb:]), _eq(r_u[0][:cb])
     if not zk:
-        # the inner-product argument (polyCommit.hpp) with m <= IPA_STOP_LEN: no round, the combined row w = L^T Z in the clear: P == <w, g>, eval == <w, b>
+        # the inner-product argument (polyCommit.hpp). The recursion stops at length 256 (no round at all for these inputs: the combined row w = L^T Z comes in
+        # the clear) or, full_ipa, at length 1: a round sends the cross terms, the verifier folds P, y and -- here, explicitly -- the generators and the eq vector
         assert m <= 256
-        wrow = [tr.fr() for _ in range(m)]
+        P, y, gg, bb = _msm(Lrow, comm), eval_in, list(g), list(b)
+        while full_ipa and len(gg) > 1:
+            h = len(gg) // 2
+            Lk, Rk, yL, yR = tr.g1(), tr.g1(), tr.fr(), tr.fr()
+            c = rnd.draw()
+            P = _padd(_padd(Lk, _pmul(c, P)), _pmul(c * c % R_MOD, Rk))
+            y = (yL + c * y + c * c * yR) % R_MOD
+            gg = [_padd(_pmul(c, gg[j]), gg[j + h]) for j in range(h)]
+            bb = [(c * bb[j] + bb[j + h]) % R_MOD for j in range(h)]
+        wrow = [tr.fr() for _ in range(len(gg))]
         if tr.o != len(transcript):
             raise Reject("trailing bytes")
-        if _msm(Lrow, comm) != _msm(wrow, g):
+        if P != _msm(wrow, gg):
             raise Reject("input opening: commitment")
-        if sum(p * q for p, q in zip(wrow, b)) % R_MOD != eval_in:
+        if sum(p * q for p, q in zip(wrow, bb)) % R_MOD != y:
             raise Reject("input opening: value")
         return n_checked
 
@@ -505,11 +515,13 @@ def test_python_verifier_accepts_proofs_over_fresh_generators(oracle):
     proof -- the generators here are Python's own multiples of the published base point"""
     model, pic, pp = MODELS[2]
     with oracle_ffi.OracleSession(model, pic, pp) as o:
-        for zk in (False, True):
-            res, tr = o.prove(seed=0x5EED0060, mode=ZK if zk else 0)
+        for zk, full in ((False, False), (True, False), (False, True)):      # the last one: the reference's semantics in full -- fresh generators, argument down to length 1
+            mode = (ZK if zk else 0) | (zkcnn_amd.MODE_FULL_IPA if full else 0)
+            res, tr = o.prove(seed=0x5EED0060, mode=mode)
             assert res.accepted == 1
-            assert python_verify(oracle, o, tr, 0x5EED0060, res.n_layers, zk=zk, fresh_gens=True) == res.n_rounds + 1
-            bad = bytearray(tr)
-            bad[len(tr) // 3] ^= 4
-            with pytest.raises(Reject):
-                python_verify(oracle, o, bytes(bad), 0x5EED0060, res.n_layers, zk=zk, fresh_gens=True)
+            assert python_verify(oracle, o, tr, 0x5EED0060, res.n_layers, zk=zk, fresh_gens=True, full_ipa=full) == res.n_rounds + 1
+            for pos in (len(tr) // 3, len(tr) - 40):
+                bad = bytearray(tr)
+                bad[pos] ^= 4
+                with pytest.raises(Reject):
+                    python_verify(oracle, o, bytes(bad), 0x5EED0060, res.n_layers, zk=zk, fresh_gens=True, full_ipa=full)
