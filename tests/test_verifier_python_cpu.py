@@ -348,11 +348,10 @@ def python_verify(oracle, o, transcript, seed, n_layers, zk=True, fs_statement=N
 
     Lrow, b = _eq(r_u[0][cb:]), _eq(r_u[0][:cb])
     if not zk:
-        # the inner-product argument (polyCommit.hpp). The recursion stops at length 256 (no round at all for these inputs: the combined row w = L^T Z comes in
-        # the clear) or, full_ipa, at length 1: a round sends the cross terms, the verifier folds P, y and -- here, explicitly -- the generators and the eq vector
-        assert m <= 256
+        # the inner-product argument (polyCommit.hpp). The recursion stops at length 256 (no round at all for the small inputs: the combined row w = L^T Z comes in
+        # the clear; one round for LeNet5's 512 columns) or, full_ipa, at length 1: a round sends the cross terms, the verifier folds P, y and -- here, explicitly -- the generators and the eq vector
         P, y, gg, bb = _msm(Lrow, comm), eval_in, list(g), list(b)
-        while full_ipa and len(gg) > 1:
+        while len(gg) > (1 if full_ipa else 256):
             h = len(gg) // 2
             Lk, Rk, yL, yR = tr.g1(), tr.g1(), tr.fr(), tr.fr()
             c = rnd.draw()
@@ -525,3 +524,21 @@ def test_python_verifier_accepts_proofs_over_fresh_generators(oracle):
                 bad[pos] ^= 4
                 with pytest.raises(Reject):
                     python_verify(oracle, o, bytes(bad), 0x5EED0060, res.n_layers, zk=zk, fresh_gens=True, full_ipa=full)
+
+
+def test_python_verifier_accepts_the_committed_lenet5_transcript(oracle):
+    """BASELINE.json configs[0] / [1]: LeNet5, pic_cnt = 1 (24 layers, 459 rounds, FFT convolutions, 2^18 inputs) in the reference's own set-up -- interactive,
+    generators drawn by the verifier. The transcript whose SHA-256 is committed in tests/golden/transcripts.json (and which the GPU prover reproduces:
+    tests/test_live_fallback_gpu.py, test_protocol_gpu.py) passes the independent verifier; a flipped bit does not."""
+    import hashlib
+    import json
+    import os
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transcripts.json")))["lenet5_pic1"]["sha256"]
+    with oracle_ffi.OracleSession("lenet", (32, 32, 1), 1) as o:
+        res, tr = o.prove(seed=0x5EED0001)
+        assert res.accepted == 1 and hashlib.sha256(tr).hexdigest() == golden
+        assert python_verify(oracle, o, tr, 0x5EED0001, res.n_layers, zk=False, fresh_gens=True) == res.n_rounds + 1
+        bad = bytearray(tr)
+        bad[len(tr) // 2] ^= 16
+        with pytest.raises(Reject):
+            python_verify(oracle, o, bytes(bad), 0x5EED0001, res.n_layers, zk=False, fresh_gens=True)
