@@ -479,8 +479,7 @@ def _fs_statement(o, n_gens):
     return bytes(buf[:ln.value])
 
 
-@pytest.mark.parametrize("model,pic,pp", [MODELS[0], MODELS[4]])
-@pytest.mark.parametrize("zk", [False, True])
+@pytest.mark.parametrize("model,pic,pp,zk", [MODELS[0] + (False,), MODELS[0] + (True,), MODELS[4] + (True,)])
 def test_python_verifier_accepts_non_interactive_proofs(oracle, model, pic, pp, zk):
     """Fiat-Shamir: the proof is the transcript, every challenge a BLAKE2s chain step over the statement and the messages so far (hashlib here).
     The statement's encoding is taken as bytes from the session; the chain, the challenges' derivation and every check are Python's own. One flipped bit
