@@ -25,15 +25,54 @@ def _padd(A, B):
     return x3, (lam * (x1 - x3) - y1) % P_MOD
 
 
+def _jdbl(P):
+    """Jacobian doubling on y^2 = x^3 + 4 (a = 0); None = infinity"""
+    if P is None:
+        return None
+    X, Y, Z = P
+    if Y == 0:
+        return None
+    A, B = X * X % P_MOD, Y * Y % P_MOD
+    C = B * B % P_MOD
+    D = 2 * ((X + B) * (X + B) - A - C) % P_MOD
+    E = 3 * A % P_MOD
+    X3 = (E * E - 2 * D) % P_MOD
+    return X3, (E * (D - X3) - 8 * C) % P_MOD, 2 * Y * Z % P_MOD
+
+
+def _jadd_affine(P, Q):
+    """Jacobian + affine (mixed addition), every special case through the general routines"""
+    if P is None:
+        return Q[0], Q[1], 1
+    X1, Y1, Z1 = P
+    x2, y2 = Q
+    Z1Z1 = Z1 * Z1 % P_MOD
+    U2, S2 = x2 * Z1Z1 % P_MOD, y2 * Z1 % P_MOD * Z1Z1 % P_MOD
+    if U2 == X1:
+        return _jdbl(P) if S2 == Y1 else None
+    H, Rr = (U2 - X1) % P_MOD, (S2 - Y1) % P_MOD
+    HH = H * H % P_MOD
+    HHH, V = H * HH % P_MOD, X1 * HH % P_MOD
+    X3 = (Rr * Rr - HHH - 2 * V) % P_MOD
+    return X3, (Rr * (V - X3) - Y1 * HHH) % P_MOD, Z1 * H % P_MOD
+
+
 def _pmul(k, A):
+    """k A by double-and-add on Jacobian coordinates, one inversion at the end (the affine _padd costs one per step)"""
     k %= R_MOD
+    if A is None or k == 0:
+        return None
     acc = None
-    while k:
-        if k & 1:
-            acc = _padd(acc, A)
-        A = _padd(A, A)
-        k >>= 1
-    return acc
+    for bit in bin(k)[2:]:
+        acc = _jdbl(acc)
+        if bit == "1":
+            acc = _jadd_affine(acc, A)
+    if acc is None:
+        return None
+    X, Y, Z = acc
+    zi = pow(Z, -1, P_MOD)
+    zi2 = zi * zi % P_MOD
+    return X * zi2 % P_MOD, Y * zi2 % P_MOD * zi % P_MOD
 
 
 def _msm(ks, pts):
