@@ -107,6 +107,12 @@ def _ev(coef_high_first, t):
     return acc
 
 
+def _chunks(gates, n=1 << 18):
+    """a gate list as Python tuples, a slice at a time (a large model has 10^8 gates)"""
+    for k in range(0, len(gates), n):
+        yield gates[k:k + n].tolist()
+
+
 def _z(rs):
     z = 1
     for r in rs:
@@ -285,13 +291,17 @@ def python_verify(oracle, o, transcript, seed, n_layers, zk=True, fs_statement=N
                     bg = [(p + beta * sc * q) % R_MOD for p, q in zip(bg, _eq(r1[:bl]))]
                 if L["zero_start"] < L["size"]:
                     bg = [x * relu_rou % R_MOD if gi >= L["zero_start"] else x for gi, x in enumerate(bg)]
-            for gg, uu, lu, s in L["uni"].tolist():
-                uni[1 if lu else 0] += bg[gg] * bu[uu] * two_mul[s]
+            for chunk in _chunks(L["uni"]):
+                for gg, uu, lu, s in chunk:
+                    uni[1 if lu else 0] += bg[gg] * bu[uu] * two_mul[s]
+                uni = [x % R_MOD for x in uni]
             if L["phase2"]:
                 bv = _eq(r_v[i])
                 uni = [x * bv[0] % R_MOD for x in uni]
-                for gg, uu, vv, s, ll in L["bin"].tolist():
-                    binv[ll] += bg[gg] * bu[uu] % R_MOD * bv[vv] % R_MOD * (1 if ty == DOT_PROD else two_mul[s])
+                for chunk in _chunks(L["bin"]):
+                    for gg, uu, vv, s, ll in chunk:
+                        binv[ll] += bg[gg] * bu[uu] % R_MOD * bv[vv] % R_MOD * (1 if ty == DOT_PROD else two_mul[s])
+                binv = [x % R_MOD for x in binv]
         cu0, cu1, cv0, cv1 = finals[U0], finals[U1], finals[V0], finals[V1]
         expect = (binv[0] * cu0 * cv0 + binv[1] * cu1 * cv1 + binv[2] * cu1 * cv0 + uni[0] * cu0 + uni[1] * cu1) % R_MOD
         if claim != expect:
