@@ -551,3 +551,25 @@ def test_python_verifier_accepts_the_committed_lenet5_transcript(oracle):
         bad[len(tr) // 2] ^= 16
         with pytest.raises(Reject):
             python_verify(oracle, o, bytes(bad), 0x5EED0001, res.n_layers, zk=False, fresh_gens=True)
+
+
+GOLDEN = ["fc_only", "naive_conv_maxpool", "naive_conv_mul_add_avgpool", "fft_conv_block_8x8_batch2", "mixed_22_layers"]
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_python_verifier_accepts_the_committed_golden_transcripts(oracle, name):
+    """tests/golden/transcripts.json holds the SHA-256 of every model's transcript in the reference's set-up (interactive, generators drawn by the verifier) and as
+    a non-interactive proof -- the vectors the GPU prover is held to (tests/test_protocol_gpu.py). The transcripts with exactly those digests pass the
+    independent verifier: every committed golden vector is a proof that an implementation sharing no code with the prover accepts."""
+    import hashlib
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transcripts.json")))[name]
+    with oracle_ffi.OracleSession(g["model"], tuple(g["pic"]), g["pic_cnt"]) as o:
+        res, tr = o.prove(seed=g["challenge_seed"])
+        assert hashlib.sha256(tr).hexdigest() == g["sha256"] and len(tr) == g["transcript_len"]
+        assert python_verify(oracle, o, tr, g["challenge_seed"], res.n_layers, zk=False, fresh_gens=True) == g["n_rounds"] + 1
+        res, tr = o.prove(mode=zkcnn_amd.MODE_FIAT_SHAMIR)
+        assert hashlib.sha256(tr).hexdigest() == g["fiat_shamir_sha256"]
+        cb = res.input_bits - (res.input_bits >> 1)
+        assert python_verify(oracle, o, tr, None, res.n_layers, zk=False, fs_statement=_fs_statement(o, 1 << cb)) == g["n_rounds"] + 1
