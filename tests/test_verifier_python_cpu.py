@@ -162,7 +162,7 @@ def python_verify(oracle, o, transcript, seed, n_layers, zk=True, fs_statement=N
     m = 1 << cb
     # fs_statement: the non-interactive mode -- every challenge is a hash of the statement and of the messages so far, drawn AFTER the message it answers
     lazy = fs_statement is not None
-    rnd = _FsStream(fs_statement) if lazy else _Stream(oracle, seed)
+    rnd = _FsStream(fs_statement) if lazy else _Stream(oracle, seed, 8192 + m)          # (the generators of the reference's set-up are drawn from it as well)
     tr = _Msgs(transcript, rnd if lazy else None)
     if fresh_gens:
         # the reference's own set-up (src/verifier.cpp:119-128): the verifier draws a random multiple of the base point per column, before anything else
