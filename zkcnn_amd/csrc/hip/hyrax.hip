@@ -6,9 +6,15 @@
 //   * per generator set, window tables T[w][j] = 2^(8w) g_j (affine) are built once, so a 255-bit
 //     scalar becomes 32 independent 8-bit digits and no doubling chain is left on the critical path;
 //   * scalars are folded to |s| <= (r-1)/2 with a sign, so quantised weights / bits only touch w = 0;
-//   * digit d contributes d * T[w][j] = sum_k bit_k(d) 2^k T[w][j]: for each of the 8 bit planes one
-//     block sums the selected table points (thread-sequential, then an LDS tree), and the row result
-//     is sum_k 2^k S_k (7 doublings). No buckets, no sorting, no atomics on 144-byte points.
+//   * digit d contributes d * T[w][j] = sum_k bit_k(d) 2^k T[w][j]: for each of the 8 bit planes the
+//     selected table points are summed (k_planes_acc: equal shares per lane, no tree in the streaming
+//     kernel), the lanes' partial sums go through row-cooperative trees (k_cl_tree, fpc_dev.cuh) and the
+//     row result is sum_k 2^k S_k (k_cl_horner). No buckets, no sorting, no atomics on 144-byte points.
+//   * a generator set that is used AGAIN gets a byte table F[w][d][j] = d 2^(8w) g_j (every non-zero
+//     scalar byte = one mixed addition); a FRESH set (the reference's semantics: new random generators
+//     for every proof, reference src/verifier.cpp:119-128) gets the digit table of window 0 only, for
+//     the commitment's 8-bit rows; rows with wider scalars sum every window through that same table
+//     and combine the window sums by doublings (k_cl_whorner).
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -16,6 +22,7 @@
 #include <thread>
 #include "ctx.hpp"
 #include "msm_kernels.cuh"
+#include "msm_cl.cuh"
 #include "../ff/g1.hpp"
 
 struct msm_state {
@@ -219,17 +226,15 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
                     ZK_HIP(hipMalloc(&s->win_scratch, need));
                     s->win_scratch_cap = need;
                 }
-                // windows 1 .. MSM_LOW_WINDOWS in order (1.5 ms: what rows of 2..8-byte scalars need at the commitment), the rest beside the proof
+                // every window above 0 beside the proof: the commitment goes through the digit table of window 0 (rows with wide scalars too: k_cl_whorner),
+                // the first reader is the opening -- a sumcheck later (round 5 built windows 1..7 in order, 1.5 ms, for the wide rows' bit planes)
                 g1j_t *J = (g1j_t *) s->win_scratch;
                 fp_t *pre = (fp_t *) (J + (size_t) (MSM_WINDOWS - 1) * m);
-                zk_launch_d<k_window_tables, 64>(ctx, PC_MSM_TABLES, 0.0, dim3((uint32_t) ((m + 63) / 64)), e->tables, J, pre, (uint32_t) m, 1u, MSM_LOW_WINDOWS + 1u);
-                ZK_HIP(hipGetLastError());
                 ZK_HIP(hipEventCreateWithFlags(&e->win_ev, hipEventDisableTiming));
                 ZK_HIP(hipEventRecord(s->aux_ev, ctx->stream));
                 ZK_HIP(hipStreamWaitEvent(s->aux, s->aux_ev, 0));
                 call_f<k_window_tables, g1a_t *, g1j_t *, fp_t *, uint32_t, uint32_t, uint32_t> f;
-                f.args = make_pack<g1a_t *, g1j_t *, fp_t *, uint32_t, uint32_t, uint32_t>(e->tables, J + (size_t) MSM_LOW_WINDOWS * m, pre + (size_t) MSM_LOW_WINDOWS * m, (uint32_t) m,
-                                                                                         MSM_LOW_WINDOWS + 1u, (uint32_t) MSM_WINDOWS);
+                f.args = make_pack<g1a_t *, g1j_t *, fp_t *, uint32_t, uint32_t, uint32_t>(e->tables, J, pre, (uint32_t) m, 1u, (uint32_t) MSM_WINDOWS);
                 hipLaunchKernelGGL((k_run<decltype(f), 64>), dim3((uint32_t) ((m + 63) / 64)), dim3(64), 0, s->aux, f);
                 ZK_HIP(hipGetLastError());
                 ZK_HIP(hipEventRecord(e->win_ev, s->aux));
@@ -446,21 +451,52 @@ static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32
         s->host_rows_valid = true;
         return ZK_OK;
     }
-    // first use of the generators: bit planes over the window tables
-    uint32_t wsplit, cpt;
-    if (rows >= 64 || w_lo) { wsplit = 1; cpt = std::min<uint32_t>(rows >= 64 ? 64 : 8, per); }   // wide rows of a commitment: few non-zero windows, one block walks them all
-    else { wsplit = MSM_WINDOWS; cpt = std::min<uint32_t>(8, per); }
-    cpt = std::max<uint32_t>(cpt, 1);
-    const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt), nparts = chunks * wsplit;
+    // no byte table (a fresh generator set: the reference's semantics): bit planes over the window tables (msm_cl.cuh). Every lane of k_planes_acc adds an
+    // equal share of its wave's selected (generator, window) pairs; the lanes' partial sums are added by row-cooperative trees of 64 and the eight plane
+    // sums of a row by k_cl_horner. 2 x 2048 generators with full-width scalars (a round of the opening): 0.52 ms, round 5's k_msm_planes + k_msm_finish 1.67 ms.
+    if ((rc = wait_windows(ctx))) return rc;
+    const uint32_t w_hi = low_windows_only ? MSM_LOW_WINDOWS + 1u : (uint32_t) MSM_WINDOWS, nw = w_hi - w_lo;
+    g1j_t *dst = outJ ? outJ : s->rowsJ;
+    if ((uint64_t) cols * nw <= 64) {
+        // a handful of pairs per row (the blinding term of a zero-knowledge commitment: one column): one block per (row, plane), a one-lane tree inside it
+        const uint32_t cpt = 1, chunks = (cols + MSM_BLOCK - 1) / MSM_BLOCK;
+        if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * MSM_PLANES * chunks * sizeof(g1j_t)))) return rc;
+        for (uint32_t r0 = 0; r0 < rows; r0 += 8191) {
+            const uint32_t nr = std::min<uint32_t>(8191, rows - r0);
+            zk_launch_d<k_msm_planes, MSM_BLOCK>(ctx, PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, dim3(chunks, MSM_PLANES * nr),
+                      s->partials + (size_t) r0 * MSM_PLANES * chunks, (const fr_t *) (s->mag + (size_t) r0 * cols), ld, idx ? idx + (size_t) r0 * ld : (const uint32_t *) nullptr, (const g1a_t *) s->tables,
+                      (uint32_t) s->m, cols, cpt, 1u, w_lo);
+        }
+        zk_launch_d<k_msm_finish, 512>(ctx, PC_MSM_FINISH, 0.0, dim3(rows), dst, (const g1j_t *) s->partials, chunks);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+    // pairs per lane: at most ACC_MAX_PAIRS (the wave's list), and few enough that a lone MSM still spreads over the SIMDs (~1 wave each)
+    uint32_t wsplit = 1, wpg = nw, cpt = std::max<uint32_t>(1, std::min<uint32_t>(ACC_MAX_PAIRS / wpg, (cols + MSM_BLOCK - 1) / MSM_BLOCK));
+    auto waves = [&]() { return (uint64_t) rows * MSM_PLANES * ((cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt)) * wsplit; };
+    while (waves() < 1024 && (cpt > 1 || wpg > 4)) {
+        if (cpt > 1) cpt = (cpt + 1) / 2;
+        else { wsplit *= 2; wpg = (nw + wsplit - 1) / wsplit; }
+    }
+    const uint32_t gx = ((cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt)) * wsplit, nparts = gx * MSM_BLOCK;
+    const uint32_t n2 = (nparts + 63) / 64;
     if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * MSM_PLANES * nparts * sizeof(g1j_t)))) return rc;
-    if (!low_windows_only && (rc = wait_windows(ctx))) return rc;      // (a window no scalar reaches is never read: k_msm_planes skips zero bytes)
+    if ((rc = regrow(ctx, (void **) &s->parts2, &s->parts2_cap, (size_t) rows * MSM_PLANES * n2 * sizeof(g1j_t)))) return rc;
     for (uint32_t r0 = 0; r0 < rows; r0 += 8191) {       // (plane, row) share gridDim.y, which is limited to 65535
         const uint32_t nr = std::min<uint32_t>(8191, rows - r0);
-        zk_launch_d<k_msm_planes, MSM_BLOCK>(ctx, PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, dim3(nparts, MSM_PLANES * nr),
+        zk_launch_d<k_planes_acc, MSM_BLOCK>(ctx, PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, dim3(gx, MSM_PLANES * nr),
                   s->partials + (size_t) r0 * MSM_PLANES * nparts, (const fr_t *) (s->mag + (size_t) r0 * cols), ld, idx ? idx + (size_t) r0 * ld : (const uint32_t *) nullptr, (const g1a_t *) s->tables,
-                  (uint32_t) s->m, cols, cpt, wsplit, w_lo);
+                  (uint32_t) s->m, cols, cpt, wsplit, w_lo, w_hi);
+        g1j_t *cur = s->partials + (size_t) r0 * MSM_PLANES * nparts, *nxt = s->parts2 + (size_t) r0 * MSM_PLANES * n2;
+        uint32_t n = nparts;
+        while (n > 1) {
+            const uint32_t n_in = std::min<uint32_t>(n, 64), blocks = (n + n_in - 1) / n_in;
+            zk_launch_d<k_cl_tree, 512>(ctx, PC_MSM_FINISH, 0.0, dim3(blocks, MSM_PLANES * nr), nxt, (const g1j_t *) cur, n, n_in);
+            std::swap(cur, nxt);
+            n = blocks;
+        }
+        zk_launch_d<k_cl_horner, 128>(ctx, PC_MSM_FINISH, 0.0, dim3(nr), dst + r0, (const g1j_t *) cur);
     }
-    zk_launch_d<k_msm_finish, 512>(ctx, PC_MSM_FINISH, 0.0, dim3(rows), outJ ? outJ : s->rowsJ, (const g1j_t *) s->partials, nparts);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -489,7 +525,10 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
     // Rows that hold wide scalars (biases, maxima, the picture: a few whole rows) get their windows 1..31 as 31 virtual rows each of
     // the SAME launches -- found on the device (flags -> compacted list), so nothing waits for the host; MSM_WIDE_CAP bounds the list,
     // more wide rows than that (or no byte table yet) take the separate pass below.
-    const uint32_t wide_cap = s->full_ready ? std::min<uint32_t>(MSM_WIDE_CAP, (65535u - std::min<uint32_t>(rows, 65535u)) / (MSM_WINDOWS - 1)) : 0;
+    // With the byte table a virtual row goes through ITS window's table; without it (a fresh generator set) every window goes through the digit table of
+    // window 0 and the window sums are combined by doublings afterwards (k_cl_whorner) -- no window table is read by a commitment.
+    const uint32_t wide_cap = std::min<uint32_t>(MSM_WIDE_CAP, (65535u - std::min<uint32_t>(rows, 65535u)) / (MSM_WINDOWS - 1));
+    const uint32_t vstride = s->full_ready ? 256u * (uint32_t) s->m : 0u;
     const uint32_t nv = wide_cap * (MSM_WINDOWS - 1), rows_all = rows + nv;
     if ((rc = ensure_rows(ctx, rows_all))) return rc;
     if (s->flags_cap < rows + 1) {
@@ -531,16 +570,19 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
         const double bytes = 32.0 * (double) std::min(nr, n_real) * (double) cols;
         if (s->safe)
             zk_launch_d<k_msm_codes<true>, MSM_BLOCK>(ctx, PC_MSM_PLANES, bytes, dim3(chunks, nr), s->partials + (size_t) r0 * n, s->exc,
-                      s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, n_real, n_wide, bflags, bmasks, bT8);
+                      s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, n_real, n_wide, vstride, bflags, bmasks, bT8);
         else
             zk_launch_d<k_msm_codes<false>, MSM_BLOCK>(ctx, PC_MSM_PLANES, bytes, dim3(chunks, nr), s->partials + (size_t) r0 * n, s->exc,
-                      s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, n_real, n_wide, bflags, bmasks, bT8);
+                      s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, n_real, n_wide, vstride, bflags, bmasks, bT8);
     }
     ZK_HIP(hipGetLastError());
     if ((rc = reduce_rows(ctx, s->partials, n, rows_all, s->rowsJ))) return rc;         // rowsJ[rows + v] = sum of virtual row v
-    if (wide_cap) {
+    if (wide_cap && vstride) {
         if ((rc = reduce_rows(ctx, s->rowsJ + rows, MSM_WINDOWS - 1, wide_cap, s->tmpJ))) return rc;
         zk_launch_d<k_add_rows, 64>(ctx, PC_MSM_FINISH, 0.0, dim3((wide_cap + 63) / 64), s->rowsJ, s->tmpJ, s->row_list, wide_cap, n_wide);
+        ZK_HIP(hipGetLastError());
+    } else if (wide_cap) {
+        zk_launch_d<k_cl_whorner, 512>(ctx, PC_MSM_FINISH, 0.0, dim3(wide_cap), s->rowsJ, rows, (const uint32_t *) s->row_list, (const uint32_t *) n_wide);
         ZK_HIP(hipGetLastError());
     }
     std::vector<uint32_t> flags((size_t) rows + 2), list;

@@ -1,0 +1,161 @@
+// Multi-scalar multiplication WITHOUT per-generator digit / byte tables (round 6): what a proof over a FRESH generator set runs
+// (reference semantics: the verifier draws new generators for every proof, reference src/verifier.cpp:119-128, and hands them to
+// commitInput, src/prover.cpp:503-511), and what the opening's full-width MSMs run whenever no byte table exists.
+//
+//   k_planes_acc   bit planes over the window tables T[w][j] = 2^(8w) g_j: every lane of a wave accumulates an EQUAL share of the
+//                  wave's selected (generator, window) pairs (the wave compacts them into an LDS list first), mixed additions on an
+//                  XYZZ accumulator, one Jacobian partial sum per lane -- no reduction tree inside the streaming kernel
+//   k_cl_tree      sums runs of partial points: 512 threads = 32 rows of row-cooperative arithmetic (fpc_dev.cuh), every row adds
+//                  its strided share, then a 5-level tree through LDS; ~10 us per level instead of the ~43 us of a one-lane addition
+//   k_cl_horner    row result = sum_k 2^k (plane sum k): plane k doubles k times in its own row, then a 3-level tree
+//
+// Round 5's path for the same job (k_msm_planes + k_msm_finish) ended every 64-lane block in a 6-level one-lane tree (two thirds of
+// the kernel's issue cycles, 13 % of the multiplier's rate in a batch) and summed the blocks' results in one 512-thread block per
+// row (0.98 ms per call, a chain of 11 one-lane additions and 7 doublings).
+#pragma once
+#include "fpc_dev.cuh"
+#include "msm_kernels.cuh"
+
+#define CL_ROWS 32                  // rows of a k_cl_tree block (512 threads)
+#define ACC_MAX_PAIRS 32u           // (columns per lane) x (windows per lane) of k_planes_acc: the wave's list holds 64 x this many entries
+
+// ---- k_planes_acc: grid (chunks * wsplit, rows * MSM_PLANES), one wave per block.
+// Block (x, y): row = y / 8, plane = y % 8, window group wg = x % wsplit (windows [w_lo + wg * wpg, min(w_lo + (wg + 1) * wpg, w_hi)),
+// wpg = ceil((w_hi - w_lo) / wsplit)), column chunk = x / wsplit (columns chunk * 64 * cpt + i * 64 + lane, i < cpt). cpt * wpg <= ACC_MAX_PAIRS.
+// mag: canonical magnitudes, sign in bit 255 (k_scalar_mags), dense rows of `cols`; idx (optional): generator of every column, rows `ld` apart.
+// out[((row * 8 + plane) * gridDim.x + x) * 64 + lane] = the lane's partial sum (Jacobian; infinity if it took nothing).
+// windows of `wmask` whose byte of the magnitude at `p` has bit `plane` set
+__device__ __forceinline__ uint32_t acc_select(const fr_t *p, uint32_t plane, uint32_t wmask) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    const uint4 lo = q[0], hi = q[1];
+    const uint32_t L[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t b = L[k] >> plane;             // bits 0, 8, 16, 24 = the plane bit of the limb's four bytes
+        s |= ((b & 1u) | ((b >> 7) & 2u) | ((b >> 14) & 4u) | ((b >> 21) & 8u)) << (4 * k);
+    }
+    return s & wmask;
+}
+__device__ __forceinline__ void k_planes_acc(g1j_t *out, const fr_t *mag, uint64_t ld, const uint32_t *idx_base, const g1a_t *T, uint32_t m, uint32_t cols,
+                                             uint32_t cpt, uint32_t wsplit, uint32_t w_lo, uint32_t w_hi) {
+    __shared__ uint32_t list[64 * ACC_MAX_PAIRS];
+    __shared__ fp_t park[MSM_BLOCK];
+    const uint32_t plane = blockIdx.y % MSM_PLANES, row = blockIdx.y / MSM_PLANES, lane = threadIdx.x;
+    const uint32_t wg = blockIdx.x % wsplit, chunk = blockIdx.x / wsplit;
+    const uint32_t wpg = (w_hi - w_lo + wsplit - 1) / wsplit, w0 = w_lo + wg * wpg, w1 = min(w0 + wpg, w_hi);
+    const uint32_t *idx = idx_base ? idx_base + (size_t) row * ld : nullptr;
+    // (bit 255 of a magnitude is the sign: not a digit bit)
+    const uint32_t wmask = w0 >= w1 ? 0u : (w1 >= 32 ? 0xffffffffu : ((1u << w1) - 1u)) & ~((1u << w0) - 1u) & (plane == 7 ? 0x7fffffffu : 0xffffffffu);
+    const fr_t *mrow = mag + (size_t) row * cols;
+    uint32_t count = 0;
+    for (uint32_t i = 0; i < cpt; ++i) {
+        const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + lane;
+        if (c < cols) count += (uint32_t) __popc(acc_select(mrow + c, plane, wmask));
+    }
+    // exclusive prefix of the lanes' counts
+    uint32_t incl = count;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t) __shfl_up((int) incl, d, 64);
+        if ((int) lane >= d) incl += t;
+    }
+    const uint32_t total = (uint32_t) __shfl((int) incl, 63, 64);
+    uint32_t pos = incl - count;
+    for (uint32_t i = 0; i < cpt; ++i) {
+        const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + lane;
+        if (c >= cols) continue;
+        uint32_t s = acc_select(mrow + c, plane, wmask);
+        if (!s) continue;
+        const uint32_t tag = (idx ? idx[c] : c) | (mag_neg(mag, (size_t) row * cols + c) ? 1u << 25 : 0u);
+        while (s) {
+            const uint32_t w = (uint32_t) __ffs((int) s) - 1u;
+            s &= s - 1u;
+            list[pos++] = tag | (w << 20);
+        }
+    }
+    __syncthreads();
+    fp_t X = fp_zero(), ZZ = fp_zero(), ZZZ = fp_zero();
+    bool empty = true, exc = false;
+    for (uint32_t k = lane; k < total; k += MSM_BLOCK) {
+        const uint32_t e = list[k];
+        fp_t px, py;
+        g1a_load(px, py, T + (size_t) ((e >> 20) & 31u) * m + (e & 0xfffffu));
+        g1_accumulate_xyzz<true>(X, park + lane, ZZ, ZZZ, empty, px, py, ((e >> 25) & 1u) != 0, exc);
+    }
+    g1j_store_xyzz(out + ((size_t) (row * MSM_PLANES + plane) * gridDim.x + blockIdx.x) * MSM_BLOCK + lane, X, park + lane, ZZ, ZZZ, empty);
+}
+
+// sum over the 32 rows of a 512-thread block (valid in row 0): 5 levels through LDS, whole waves drop out as the tree narrows
+__device__ __forceinline__ g1c_t cl_tree32(g1c_t acc, uint32_t (*sm)[3][16], uint32_t m) {
+    const uint32_t row = threadIdx.x >> 4, limb = threadIdx.x & 15, wave_row0 = (threadIdx.x >> 6) << 2;
+    for (uint32_t s = CL_ROWS / 2; s >= 1; s >>= 1) {
+        if (row >= s && row < 2 * s) { sm[row][0][limb] = acc.X; sm[row][1][limb] = acc.Y; sm[row][2][limb] = acc.Z; }
+        __syncthreads();
+        if (wave_row0 < s) {                          // (rows of such a wave at or beyond s compute on stale slots; their sums are never used)
+            const uint32_t r2 = (row + s) & (CL_ROWS - 1);
+            const g1c_t q = {sm[r2][0][limb], sm[r2][1][limb], sm[r2][2][limb]};
+            acc = g1c_add(acc, q, m);
+        }
+    }
+    return acc;
+}
+
+// ---- k_cl_tree: segment y = blockIdx.y holds n_seg points at in[y * n_seg ..]; block x sums its run [x * n_in, min((x + 1) * n_in, n_seg))
+// into out[y * gridDim.x + x]. 512 threads.
+__device__ __forceinline__ void k_cl_tree(g1j_t *out, const g1j_t *in, uint32_t n_seg, uint32_t n_in) {
+    __shared__ uint32_t sm[CL_ROWS][3][16];
+    const uint32_t row = threadIdx.x >> 4, wave_row0 = (threadIdx.x >> 6) << 2;
+    const uint32_t m = fpc_mod_limb();
+    const uint32_t first = blockIdx.x * n_in, n = min(n_in, n_seg - min(n_seg, first));
+    const g1j_t *src = in + (size_t) blockIdx.y * n_seg + first;
+    g1c_t acc = row < n ? g1c_load(src + row) : g1c_inf();
+    for (uint32_t k0 = CL_ROWS; k0 + wave_row0 < n; k0 += CL_ROWS) {      // (rows of the wave past the end add infinity)
+        const g1c_t q = k0 + row < n ? g1c_load(src + k0 + row) : g1c_inf();
+        acc = g1c_add(acc, q, m);
+    }
+    acc = cl_tree32(acc, sm, m);
+    if (row == 0) g1c_store(out + (size_t) blockIdx.y * gridDim.x + blockIdx.x, acc);
+}
+
+// ---- k_cl_horner: out[r] = sum_k 2^k in[r * 8 + k], r = blockIdx.x; 128 threads = one row per plane
+__device__ __forceinline__ void k_cl_horner(g1j_t *out, const g1j_t *in) {
+    __shared__ uint32_t sm[MSM_PLANES][3][16];
+    const uint32_t k = threadIdx.x >> 4, limb = threadIdx.x & 15, wave_k0 = (threadIdx.x >> 6) << 2;
+    const uint32_t m = fpc_mod_limb();
+    g1c_t acc = g1c_load(in + (size_t) blockIdx.x * MSM_PLANES + k);
+    for (uint32_t d = 0; d < wave_k0 + 3; ++d) {
+        const g1c_t dd = g1c_dbl(acc, m);
+        acc = g1c_select(d < k, dd, acc);
+    }
+    for (uint32_t s = MSM_PLANES / 2; s >= 1; s >>= 1) {
+        if (k >= s && k < 2 * s) { sm[k][0][limb] = acc.X; sm[k][1][limb] = acc.Y; sm[k][2][limb] = acc.Z; }
+        __syncthreads();
+        if (wave_k0 < s) {
+            const uint32_t k2 = (k + s) & (MSM_PLANES - 1);
+            const g1c_t q = {sm[k2][0][limb], sm[k2][1][limb], sm[k2][2][limb]};
+            acc = g1c_add(acc, q, m);
+        }
+    }
+    if (k == 0) g1c_store(out + blockIdx.x, acc);
+}
+
+// ---- k_cl_whorner: the commitment's rows with wide scalars when no byte table exists. Window w >= 1 of wide row row_list[ri] was summed
+// through the DIGIT table like a row of its own (virtual row ri * 31 + w - 1 behind the `rows` real ones: V_w = sum_j byte_w(s_j) g_j), so
+// rows[row] = V_0 + sum_w 2^(8w) V_w: CL row w doubles its point 8 w times (points at infinity -- windows no scalar reaches -- cost nothing,
+// and a wave stops as soon as none of its four windows has doublings left), then the 32 rows are summed. 512 threads, block ri < *count.
+__device__ __forceinline__ void k_cl_whorner(g1j_t *rows_pts, uint32_t rows, const uint32_t *row_list, const uint32_t *count) {
+    __shared__ uint32_t sm[CL_ROWS][3][16];
+    const uint32_t ri = blockIdx.x;
+    if (ri >= *count) return;
+    const uint32_t w = threadIdx.x >> 4, row = row_list[ri];
+    const uint32_t m = fpc_mod_limb();
+    g1c_t acc = g1c_load(w == 0 ? rows_pts + row : rows_pts + rows + (size_t) ri * (MSM_WINDOWS - 1) + (w - 1));
+    const bool live = !fpc_is_zero(acc.Z);
+    for (uint32_t d = 0; __any(live && d < 8 * w); ++d) {
+        const g1c_t dd = g1c_dbl(acc, m);
+        acc = g1c_select(d < 8 * w, dd, acc);
+    }
+    acc = cl_tree32(acc, sm, m);
+    if (w == 0) g1c_store(rows_pts + row, acc);
+}

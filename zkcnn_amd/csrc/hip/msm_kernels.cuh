@@ -332,11 +332,12 @@ __device__ __forceinline__ bool mag_neg(const fr_t *mag, size_t i) { return (rei
 // the commitment's hot kernel: signed-byte codes through a digit table. grid (chunks, rows), one wave per block; lane l owns columns
 // base + 64 i + l, i < cpt <= 64. out[(row * chunks + chunk) * 64 + lane] = the lane's partial sum.
 // Rows < n_real use D[d][j] = d g_j. Rows >= n_real are virtual rows (k_scalar_codes_wide): virtual row v uses window 1 + v % 31 of
-// the full byte table F[w][d][j] = d 2^(8w) g_j, of which D is window 0; only the first 31 * *n_wide of them exist.
+// the full byte table F[w][d][j] = d 2^(8w) g_j, of which D is window 0 (vstride = 256 m), or -- a fresh generator set, no byte table -- D itself
+// (vstride = 0; the caller multiplies the window sums by 2^(8w): k_cl_whorner); only the first 31 * *n_wide of them exist.
 // ------------------------------------------------------------------------------------------------
 template <bool SAFE>
 __device__ __forceinline__ void k_msm_codes(g1j_t *out, uint32_t *exc_flag, const uint16_t *codes, const g1a_t *D, uint32_t m, uint32_t cols,
-                                                         uint32_t cpt, uint32_t n_real, const uint32_t *n_wide,
+                                                         uint32_t cpt, uint32_t n_real, const uint32_t *n_wide, uint32_t vstride,
                                                          const uint32_t *row_flags, const uint16_t *masks, const g1a_t *T8) {
     // the virtual rows come FIRST in the grid (their few long chains then run alongside the heavy rows instead of forming a tail);
     // `row` is the logical row: real rows 0 .. n_real - 1, virtual rows behind them
@@ -362,7 +363,7 @@ __device__ __forceinline__ void k_msm_codes(g1j_t *out, uint32_t *exc_flag, cons
             g1j_store(dst, fp_zero(), fp_zero(), fp_zero(), true);
             return;
         }
-        D += (size_t) (1 + v % (MSM_WINDOWS - 1)) * 256 * m;
+        D += (size_t) (1 + v % (MSM_WINDOWS - 1)) * vstride;       // vstride = 256 m: the window's own table; 0: every window through D (k_cl_whorner shifts the sums)
     }
     // which of this lane's columns carry a non-zero byte: cpt independent 2-byte loads, then the loop below visits set bits only,
     // so a lane of a half-empty bit row is done after its ~cpt/2 additions instead of idling through cpt iterations
