@@ -83,7 +83,9 @@ __device__ __forceinline__ bool fpc_is_zero(uint32_t a) {
 //   q = (w_0 + d_0) * (-p^-1)  mod 2^32                          (lane 0's, broadcast)
 //   u = q p_i + (w mod 2^32) + d_i       (<= 2^64 - 1)          d_i <- u >> 32, T_i <- (u mod 2^32) of lane i + 1
 // so the two carry words never leave their lane and the only moves are one broadcast of b_j, one of lane 0's low word and one shift.
-__device__ __forceinline__ uint32_t fpc_mul(uint32_t a, uint32_t b, uint32_t m) {
+// ONE copy of the product per translation unit, reached by a call (three operands in, one result out, all in VGPRs): a point addition is 16 products,
+// and inlined they made k_cl_tree 65 KB of code -- the size of the instruction cache two CUs share; with the call it is ~6 KB.
+__device__ __noinline__ uint32_t fpc_mul(uint32_t a, uint32_t b, uint32_t m) {
     uint32_t T = 0, c = 0, d = 0;
 #define FPC_STEP(j) {                                                                  \
         const uint32_t bj = fpc_dpp<FPC_BCAST(j)>(b);                                  \

@@ -385,70 +385,57 @@ static int32_t scalar_mags(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const 
 }
 
 // rows independent MSMs over the cached generator tables, every window >= w_lo of every scalar; scalars are read from s->mag
-// (scalar_mags ran before). idx (optional): generator index of every column, rows `ld` apart. Results (Jacobian) in `outJ` or, for
-// at most 8 rows without outJ, as short lists that fetch_points sums on the host.
+// (scalar_mags ran before). idx (optional): generator index of every column, rows `ld` apart. Results (Jacobian) in `outJ` or s->rowsJ.
 static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32_t rows, uint32_t cols, uint32_t w_lo, g1j_t *outJ, bool low_windows_only = false) {
     msm_state *s = ctx->msm;
     int32_t rc;
     const uint32_t nwin = MSM_WINDOWS - w_lo;
-    const uint32_t per = (cols + MSM_BLOCK - 1) / MSM_BLOCK;
+    g1j_t *dst = outJ ? outJ : s->rowsJ;
+    // pairs (column, window) per lane <= ACC_MAX_PAIRS (the wave's list). A proof that is ALONE on the GPU spreads wide -- short chains of one-lane mixed additions
+    // (27 us each), the rest is row-cooperative trees; with several proofs in flight the SIMD time counts, and the streaming kernel's lanes are three times as
+    // efficient as the trees' rows, so chains are as long as the list allows.
+    auto shape = [&](uint32_t nw, uint32_t per_lane, uint64_t min_waves, uint32_t planes, uint32_t &cpt, uint32_t &wsplit) {
+        uint32_t wpg = nw;
+        wsplit = 1;
+        cpt = std::max<uint32_t>(1, std::min<uint32_t>(per_lane / std::min(per_lane, wpg), (cols + MSM_BLOCK - 1) / MSM_BLOCK));
+        while (wpg * cpt > per_lane && wpg > 1) { wsplit *= 2; wpg = (nw + wsplit - 1) / wsplit; }
+        auto waves = [&]() { return (uint64_t) rows * planes * ((cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt)) * wsplit; };
+        while (waves() < min_waves && (cpt > 1 || wpg > 2)) {
+            if (cpt > 1) cpt = (cpt + 1) / 2;
+            else { wsplit *= 2; wpg = (nw + wsplit - 1) / wsplit; }
+        }
+    };
+    // sums of the n partial points of each of `segs` segments (dense in `cur`) -> out[seg]; cur / nxt ping-pong
+    auto trees = [&](g1j_t *cur, g1j_t *nxt, uint32_t n, uint32_t segs, g1j_t *out) {
+        for (;;) {
+            const uint32_t n_in = std::min<uint32_t>(n, 64), blocks = (n + n_in - 1) / n_in;
+            g1j_t *o = blocks == 1 ? out : nxt;
+            zk_launch_d<k_cl_tree, 512>(ctx, PC_MSM_FINISH, 0.0, dim3(blocks, segs), o, (const g1j_t *) cur, n, n_in);
+            if (blocks == 1) return;
+            std::swap(cur, nxt);
+            n = blocks;
+        }
+    };
     if (s->full_ready) {
-        // (column chunk, window) blocks: one chunk per row for many rows. For FEW rows (the opening's two MSMs per round) the launch is a chain
-        // of dependent table gathers and additions: cpt per lane, then a 7-level tree inside the block in which most lanes idle while every
-        // wave still pays full price per level. A proof that is ALONE on the GPU spreads as wide as it can (one column per lane, <= 4096 blocks
-        // per row: the gathers overlap, 7.9 vs 8.35 ms commitment phase); with several proofs in flight the SIMD time of all those trees is
-        // what the other proofs wait for, so aim at one wave per SIMD instead (512 blocks: 99.7 vs 97 proofs/s with eight in flight).
-        uint32_t cpt = rows >= 64 ? std::min<uint32_t>(64, per) : 1;
-        if (ctx->live_now) { while (rows < 64 && (uint64_t) ((cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt)) * nwin > 4096) cpt *= 2; }
-        else { while (rows < 64 && cpt < per && (uint64_t) rows * ((cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt)) * nwin > 512) cpt *= 2; }
-        cpt = std::max<uint32_t>(cpt, 1);
-        const uint32_t chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt);
-        uint32_t n = chunks * nwin;
-        if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * n * sizeof(g1j_t)))) return rc;
-        if ((rc = regrow(ctx, (void **) &s->parts2, &s->parts2_cap, (size_t) rows * ((n + 63) / 64) * sizeof(g1j_t)))) return rc;
+        // byte table: every non-zero scalar byte is one mixed addition (k_bytes_acc), the lanes' partial sums go through row-cooperative trees
+        uint32_t cpt, wsplit;
+        shape(nwin, ctx->live_now ? 4u : ACC_MAX_PAIRS, ctx->live_now ? 512 : 1, 1, cpt, wsplit);
+        const uint32_t gx = ((cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt)) * wsplit, nparts = gx * MSM_BLOCK, n2 = (nparts + 63) / 64;
+        if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * nparts * sizeof(g1j_t)))) return rc;
+        if ((rc = regrow(ctx, (void **) &s->parts2, &s->parts2_cap, (size_t) rows * n2 * sizeof(g1j_t)))) return rc;
         for (uint32_t r0 = 0; r0 < rows; r0 += 32768) {
             const uint32_t nr = std::min<uint32_t>(32768, rows - r0);
             const double bytes = 32.0 * (double) nr * (double) cols;
+            g1j_t *part = s->partials + (size_t) r0 * nparts;
             if (s->safe)
-                zk_launch_d<k_msm_windows<true>, MSM_BLOCK>(ctx, PC_MSM_PLANES, bytes, dim3(n, nr), s->partials + (size_t) r0 * n, s->exc, s->mag + (size_t) r0 * cols,
-                          ld, idx ? idx + (size_t) r0 * ld : nullptr, s->full, (uint32_t) s->m, cols, cpt, w_lo, nwin);
+                zk_launch_d<k_bytes_acc<true>, MSM_BLOCK>(ctx, PC_MSM_PLANES, bytes, dim3(gx, nr), part, s->exc, (const fr_t *) (s->mag + (size_t) r0 * cols),
+                          ld, idx ? idx + (size_t) r0 * ld : (const uint32_t *) nullptr, (const g1a_t *) s->full, (uint32_t) s->m, cols, cpt, wsplit, w_lo, (uint32_t) MSM_WINDOWS);
             else
-                zk_launch_d<k_msm_windows<false>, MSM_BLOCK>(ctx, PC_MSM_PLANES, bytes, dim3(n, nr), s->partials + (size_t) r0 * n, s->exc, s->mag + (size_t) r0 * cols,
-                          ld, idx ? idx + (size_t) r0 * ld : nullptr, s->full, (uint32_t) s->m, cols, cpt, w_lo, nwin);
+                zk_launch_d<k_bytes_acc<false>, MSM_BLOCK>(ctx, PC_MSM_PLANES, bytes, dim3(gx, nr), part, s->exc, (const fr_t *) (s->mag + (size_t) r0 * cols),
+                          ld, idx ? idx + (size_t) r0 * ld : (const uint32_t *) nullptr, (const g1a_t *) s->full, (uint32_t) s->m, cols, cpt, wsplit, w_lo, (uint32_t) MSM_WINDOWS);
+            trees(part, s->parts2 + (size_t) r0 * n2, nparts, nr, dst + r0);
         }
         ZK_HIP(hipGetLastError());
-        if (outJ || rows > 8) {
-            // few rows with thousands of (mostly empty) partial points each: one 64-wide tree level first
-            g1j_t *cur = s->partials;
-            if (n > 256) {
-                const uint32_t n2 = (n + 63) / 64;
-                zk_launch_d<k_tree_reduce, MSM_BLOCK>(ctx, PC_MSM_FINISH, 0.0, dim3(n2, rows), s->parts2, cur, n);
-                cur = s->parts2;
-                n = n2;
-            }
-            return reduce_rows(ctx, cur, n, rows, outJ ? outJ : s->rowsJ);
-        }
-        // few rows: 64-wide trees, the last <= 64 partial points per row are summed on the host, where the result is needed anyway
-        g1j_t *cur = s->partials, *nxt = s->parts2;
-        while (n > 64) {
-            const uint32_t n2 = (n + 63) / 64;
-            zk_launch_d<k_tree_reduce, MSM_BLOCK>(ctx, PC_MSM_FINISH, 0.0, dim3(n2, rows), nxt, cur, n);
-            std::swap(cur, nxt);
-            n = n2;
-        }
-        ZK_HIP(hipGetLastError());
-        std::vector<zkff::G1> part((size_t) rows * n);
-        uint32_t exc = 0;
-        ZK_STREAM(hipMemcpyAsync(part.data(), cur, part.size() * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
-        ZK_STREAM(hipMemcpyAsync(&exc, s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(zk_stream_sync(ctx));
-        if (exc && !s->safe) return ZK_RETRY_SAFE;
-        for (uint32_t r = 0; r < rows; ++r) {
-            zkff::G1 acc = part[(size_t) r * n];
-            for (uint32_t k = 1; k < n; ++k) zkff::G1::add(acc, acc, part[(size_t) r * n + k]);
-            s->host_rows[r] = acc;
-        }
-        s->host_rows_valid = true;
         return ZK_OK;
     }
     // no byte table (a fresh generator set: the reference's semantics): bit planes over the window tables (msm_cl.cuh). Every lane of k_planes_acc adds an
@@ -456,7 +443,6 @@ static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32
     // sums of a row by k_cl_horner. 2 x 2048 generators with full-width scalars (a round of the opening): 0.52 ms, round 5's k_msm_planes + k_msm_finish 1.67 ms.
     if ((rc = wait_windows(ctx))) return rc;
     const uint32_t w_hi = low_windows_only ? MSM_LOW_WINDOWS + 1u : (uint32_t) MSM_WINDOWS, nw = w_hi - w_lo;
-    g1j_t *dst = outJ ? outJ : s->rowsJ;
     if ((uint64_t) cols * nw <= 64) {
         // a handful of pairs per row (the blinding term of a zero-knowledge commitment: one column): one block per (row, plane), a one-lane tree inside it
         const uint32_t cpt = 1, chunks = (cols + MSM_BLOCK - 1) / MSM_BLOCK;
@@ -471,31 +457,20 @@ static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32
         ZK_HIP(hipGetLastError());
         return ZK_OK;
     }
-    // pairs per lane: at most ACC_MAX_PAIRS (the wave's list), and few enough that a lone MSM still spreads over the SIMDs (~1 wave each)
-    uint32_t wsplit = 1, wpg = nw, cpt = std::max<uint32_t>(1, std::min<uint32_t>(ACC_MAX_PAIRS / wpg, (cols + MSM_BLOCK - 1) / MSM_BLOCK));
-    auto waves = [&]() { return (uint64_t) rows * MSM_PLANES * ((cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt)) * wsplit; };
-    while (waves() < 1024 && (cpt > 1 || wpg > 4)) {
-        if (cpt > 1) cpt = (cpt + 1) / 2;
-        else { wsplit *= 2; wpg = (nw + wsplit - 1) / wsplit; }
-    }
-    const uint32_t gx = ((cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt)) * wsplit, nparts = gx * MSM_BLOCK;
-    const uint32_t n2 = (nparts + 63) / 64;
+    uint32_t cpt, wsplit;
+    shape(nw, ctx->live_now ? 16u : ACC_MAX_PAIRS, ctx->live_now ? 1024 : 1, MSM_PLANES, cpt, wsplit);
+    const uint32_t gx = ((cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt)) * wsplit, nparts = gx * MSM_BLOCK, n2 = (nparts + 63) / 64;
     if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * MSM_PLANES * nparts * sizeof(g1j_t)))) return rc;
-    if ((rc = regrow(ctx, (void **) &s->parts2, &s->parts2_cap, (size_t) rows * MSM_PLANES * n2 * sizeof(g1j_t)))) return rc;
+    if ((rc = regrow(ctx, (void **) &s->parts2, &s->parts2_cap, (size_t) rows * MSM_PLANES * (n2 + 1) * sizeof(g1j_t)))) return rc;
     for (uint32_t r0 = 0; r0 < rows; r0 += 8191) {       // (plane, row) share gridDim.y, which is limited to 65535
         const uint32_t nr = std::min<uint32_t>(8191, rows - r0);
+        g1j_t *part = s->partials + (size_t) r0 * MSM_PLANES * nparts, *part2 = s->parts2 + (size_t) r0 * MSM_PLANES * (n2 + 1);
         zk_launch_d<k_planes_acc, MSM_BLOCK>(ctx, PC_MSM_PLANES, 32.0 * (double) nr * (double) cols, dim3(gx, MSM_PLANES * nr),
-                  s->partials + (size_t) r0 * MSM_PLANES * nparts, (const fr_t *) (s->mag + (size_t) r0 * cols), ld, idx ? idx + (size_t) r0 * ld : (const uint32_t *) nullptr, (const g1a_t *) s->tables,
+                  part, (const fr_t *) (s->mag + (size_t) r0 * cols), ld, idx ? idx + (size_t) r0 * ld : (const uint32_t *) nullptr, (const g1a_t *) s->tables,
                   (uint32_t) s->m, cols, cpt, wsplit, w_lo, w_hi);
-        g1j_t *cur = s->partials + (size_t) r0 * MSM_PLANES * nparts, *nxt = s->parts2 + (size_t) r0 * MSM_PLANES * n2;
-        uint32_t n = nparts;
-        while (n > 1) {
-            const uint32_t n_in = std::min<uint32_t>(n, 64), blocks = (n + n_in - 1) / n_in;
-            zk_launch_d<k_cl_tree, 512>(ctx, PC_MSM_FINISH, 0.0, dim3(blocks, MSM_PLANES * nr), nxt, (const g1j_t *) cur, n, n_in);
-            std::swap(cur, nxt);
-            n = blocks;
-        }
-        zk_launch_d<k_cl_horner, 128>(ctx, PC_MSM_FINISH, 0.0, dim3(nr), dst + r0, (const g1j_t *) cur);
+        g1j_t *planes = part2 + (size_t) MSM_PLANES * nr * n2;           // the plane sums: [row][plane], behind the trees' own intermediate results
+        trees(part, part2, nparts, MSM_PLANES * nr, planes);
+        zk_launch_d<k_cl_horner, 128>(ctx, PC_MSM_FINISH, 0.0, dim3(nr), dst + r0, (const g1j_t *) planes);
     }
     ZK_HIP(hipGetLastError());
     return ZK_OK;

@@ -86,10 +86,79 @@ __device__ __forceinline__ void k_planes_acc(g1j_t *out, const fr_t *mag, uint64
     g1j_store_xyzz(out + ((size_t) (row * MSM_PLANES + plane) * gridDim.x + blockIdx.x) * MSM_BLOCK + lane, X, park + lane, ZZ, ZZZ, empty);
 }
 
+// ---- k_bytes_acc: the same shape over the BYTE table F[w][d][j] = d 2^(8w) g_j of a generator set that is used again: every non-zero scalar byte is
+// one mixed addition and there are no planes. grid (chunks * wsplit, rows), one wave per block; the wave's list holds (column, window) of every
+// non-zero byte, every lane takes an equal share. out[(row * gridDim.x + x) * 64 + lane]. The fast variant flags P = +-Q (the host repeats the batch
+// with SAFE = true, like k_msm_codes).
+__device__ __forceinline__ uint32_t acc_nonzero_bytes(const fr_t *p, uint32_t wmask) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    const uint4 lo = q[0], hi = q[1];
+    const uint32_t L[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w & 0x7fffffffu};      // (bit 255 is the sign)
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t b = L[k] | (L[k] >> 4);
+        b |= b >> 2;
+        b |= b >> 1;                                  // bits 0, 8, 16, 24: the byte is not zero
+        s |= ((b & 1u) | ((b >> 7) & 2u) | ((b >> 14) & 4u) | ((b >> 21) & 8u)) << (4 * k);
+    }
+    return s & wmask;
+}
+template <bool SAFE>
+__device__ __forceinline__ void k_bytes_acc(g1j_t *out, uint32_t *exc_flag, const fr_t *mag, uint64_t ld, const uint32_t *idx_base, const g1a_t *F, uint32_t m,
+                                            uint32_t cols, uint32_t cpt, uint32_t wsplit, uint32_t w_lo, uint32_t w_hi) {
+    __shared__ uint16_t list[64 * ACC_MAX_PAIRS];
+    __shared__ fp_t park[MSM_BLOCK];
+    const uint32_t row = blockIdx.y, lane = threadIdx.x;
+    const uint32_t wg = blockIdx.x % wsplit, chunk = blockIdx.x / wsplit;
+    const uint32_t wpg = (w_hi - w_lo + wsplit - 1) / wsplit, w0 = w_lo + wg * wpg, w1 = min(w0 + wpg, w_hi);
+    const uint32_t *idx = idx_base ? idx_base + (size_t) row * ld : nullptr;
+    const uint32_t wmask = w0 >= w1 ? 0u : (w1 >= 32 ? 0xffffffffu : ((1u << w1) - 1u)) & ~((1u << w0) - 1u);
+    const fr_t *mrow = mag + (size_t) row * cols;
+    const uint32_t c0 = chunk * (MSM_BLOCK * cpt);
+    uint32_t count = 0;
+    for (uint32_t i = 0; i < cpt; ++i) {
+        const uint32_t c = c0 + i * MSM_BLOCK + lane;
+        if (c < cols) count += (uint32_t) __popc(acc_nonzero_bytes(mrow + c, wmask));
+    }
+    uint32_t incl = count;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t) __shfl_up((int) incl, d, 64);
+        if ((int) lane >= d) incl += t;
+    }
+    const uint32_t total = (uint32_t) __shfl((int) incl, 63, 64);
+    uint32_t pos = incl - count;
+    for (uint32_t i = 0; i < cpt; ++i) {
+        const uint32_t c = c0 + i * MSM_BLOCK + lane;
+        if (c >= cols) continue;
+        uint32_t s = acc_nonzero_bytes(mrow + c, wmask);
+        while (s) {
+            const uint32_t w = (uint32_t) __ffs((int) s) - 1u;
+            s &= s - 1u;
+            list[pos++] = (uint16_t) (((i * MSM_BLOCK + lane) << 5) | w);       // (column inside the chunk: < 64 cpt <= 2048)
+        }
+    }
+    __syncthreads();
+    fp_t X = fp_zero(), ZZ = fp_zero(), ZZZ = fp_zero();
+    bool empty = true, exc = false;
+    for (uint32_t k = lane; k < total; k += MSM_BLOCK) {
+        const uint32_t e = list[k], w = e & 31u, c = c0 + (e >> 5);
+        const size_t si = (size_t) row * cols + c;
+        fp_t px, py;
+        g1a_load(px, py, F + ((size_t) w * 256 + mag_byte(mag, si, w)) * m + (idx ? idx[c] : c));
+        g1_accumulate_xyzz<SAFE>(X, park + lane, ZZ, ZZZ, empty, px, py, mag_neg(mag, si), exc);
+    }
+    if (!SAFE && exc) *exc_flag = 1;
+    g1j_store_xyzz(out + ((size_t) row * gridDim.x + blockIdx.x) * MSM_BLOCK + lane, X, park + lane, ZZ, ZZZ, empty);
+}
+
 // sum over the 32 rows of a 512-thread block (valid in row 0): 5 levels through LDS, whole waves drop out as the tree narrows
-__device__ __forceinline__ g1c_t cl_tree32(g1c_t acc, uint32_t (*sm)[3][16], uint32_t m) {
+// (`live`: rows at or beyond it hold the point at infinity -- levels that would only add those are skipped)
+__device__ __forceinline__ g1c_t cl_tree32(g1c_t acc, uint32_t (*sm)[3][16], uint32_t m, uint32_t live = CL_ROWS) {
     const uint32_t row = threadIdx.x >> 4, limb = threadIdx.x & 15, wave_row0 = (threadIdx.x >> 6) << 2;
     for (uint32_t s = CL_ROWS / 2; s >= 1; s >>= 1) {
+        if (s >= live) continue;
         if (row >= s && row < 2 * s) { sm[row][0][limb] = acc.X; sm[row][1][limb] = acc.Y; sm[row][2][limb] = acc.Z; }
         __syncthreads();
         if (wave_row0 < s) {                          // (rows of such a wave at or beyond s compute on stale slots; their sums are never used)
@@ -114,7 +183,7 @@ __device__ __forceinline__ void k_cl_tree(g1j_t *out, const g1j_t *in, uint32_t 
         const g1c_t q = k0 + row < n ? g1c_load(src + k0 + row) : g1c_inf();
         acc = g1c_add(acc, q, m);
     }
-    acc = cl_tree32(acc, sm, m);
+    acc = cl_tree32(acc, sm, m, n);
     if (row == 0) g1c_store(out + (size_t) blockIdx.y * gridDim.x + blockIdx.x, acc);
 }
 
