@@ -52,8 +52,6 @@ struct msm_state {
     g1a_t *full = nullptr; uint64_t full_m = 0; bool full_ready = false;
     bool no_full = false;              // this state never takes a byte table (the verifier's second set: points that change with every proof)
     g1j_t *parts2 = nullptr; size_t parts2_cap = 0;
-    bool host_rows_valid = false;      // few-row MSMs end with a short sum on the host (like the single inversion of fetch_points)
-    zkff::G1 host_rows[8];
     // scalar pre-pass outputs: 16-bit codes of a whole matrix, canonical signed magnitudes of the rows that need every window
     // rows of bits: masks of 8 columns each (k_bit_masks) and the subset-sum table they index (k_subset_table; built with the full byte table)
     uint16_t *masks = nullptr; size_t masks_cap = 0;
@@ -62,7 +60,9 @@ struct msm_state {
     fr_t *mag = nullptr; size_t mag_cap = 0;
     uint32_t *exc = nullptr;           // device word set by a fast-variant kernel that met P = +-Q
     bool safe = false;                 // run the SAFE kernel variants (after a flagged batch)
+    unsigned char *h_stage = nullptr;  // pinned: the <= 8 points + the exception word a few-row MSM hands to the host (a pageable target costs a staged copy: ~70 us)
 };
+#define MSM_STAGE_BYTES (8 * sizeof(g1j_t) + 64)
 #define MSM_FULL_MAX_M 16384u
 #define MSM_WIDE_CAP 128u          // rows with wide scalars whose higher windows ride along as virtual rows of the commitment's launches
 #define ZK_RETRY_SAFE 0x5afe       // internal status: repeat the batch with the SAFE kernels
@@ -146,6 +146,7 @@ static void msm_destroy_one(zk_ctx *ctx) {
     if (s->aux_ev) (void) hipEventDestroy(s->aux_ev);
     if (s->aux) (void) hipStreamDestroy(s->aux);
     if (s->win_scratch) (void) hipFree(s->win_scratch);
+    if (s->h_stage) (void) hipHostFree(s->h_stage);
     void *bufs[] = {s->partials, s->rowsJ, s->rowsA, s->a, s->b, s->coef, s->Lrow, s->sL, s->idxL, s->d_y, s->tbl_scratch,
                     s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch, s->parts2, s->codes, s->mag, s->exc, s->masks};
     for (void *p : bufs) if (p) hipFree(p);
@@ -168,6 +169,7 @@ static int32_t regrow(zk_ctx *ctx, void **p, size_t *cap, size_t bytes) {
 static int32_t ensure_state(zk_ctx *ctx) {
     if (!ctx->msm) ctx->msm = new msm_state();
     msm_state *s = ctx->msm;
+    if (!s->h_stage) ZK_HIP(hipHostMalloc((void **) &s->h_stage, MSM_STAGE_BYTES));
     if (!s->exc) {
         ZK_HIP(hipMalloc((void **) &s->exc, 64));
         ZK_STREAM(hipMemsetAsync(s->exc, 0, 64, ctx->stream));
@@ -384,6 +386,16 @@ static int32_t scalar_mags(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const 
     return ZK_OK;
 }
 
+// pairs per lane of the streaming MSM kernels when several proofs share the GPU (experiment switch ZKCNN_ACC_PAIRS; see msm_windows)
+static uint32_t busy_pairs() {
+    static const uint32_t v = [] {
+        const char *e = getenv("ZKCNN_ACC_PAIRS");
+        const uint32_t x = e ? (uint32_t) atoi(e) : 32u;
+        return std::min<uint32_t>(std::max<uint32_t>(x, 1u), ACC_MAX_PAIRS);
+    }();
+    return v;
+}
+
 // rows independent MSMs over the cached generator tables, every window >= w_lo of every scalar; scalars are read from s->mag
 // (scalar_mags ran before). idx (optional): generator index of every column, rows `ld` apart. Results (Jacobian) in `outJ` or s->rowsJ.
 static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32_t rows, uint32_t cols, uint32_t w_lo, g1j_t *outJ, bool low_windows_only = false) {
@@ -419,7 +431,7 @@ static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32
     if (s->full_ready) {
         // byte table: every non-zero scalar byte is one mixed addition (k_bytes_acc), the lanes' partial sums go through row-cooperative trees
         uint32_t cpt, wsplit;
-        shape(nwin, ctx->live_now ? 4u : ACC_MAX_PAIRS, ctx->live_now ? 512 : 1, 1, cpt, wsplit);
+        shape(nwin, ctx->live_now ? 4u : busy_pairs(), ctx->live_now ? 512 : 1, 1, cpt, wsplit);
         const uint32_t gx = ((cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt)) * wsplit, nparts = gx * MSM_BLOCK, n2 = (nparts + 63) / 64;
         if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * nparts * sizeof(g1j_t)))) return rc;
         if ((rc = regrow(ctx, (void **) &s->parts2, &s->parts2_cap, (size_t) rows * n2 * sizeof(g1j_t)))) return rc;
@@ -458,7 +470,7 @@ static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32
         return ZK_OK;
     }
     uint32_t cpt, wsplit;
-    shape(nw, ctx->live_now ? 16u : ACC_MAX_PAIRS, ctx->live_now ? 1024 : 1, MSM_PLANES, cpt, wsplit);
+    shape(nw, ctx->live_now ? 16u : busy_pairs(), ctx->live_now ? 1024 : 1, MSM_PLANES, cpt, wsplit);
     const uint32_t gx = ((cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt)) * wsplit, nparts = gx * MSM_BLOCK, n2 = (nparts + 63) / 64;
     if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * MSM_PLANES * nparts * sizeof(g1j_t)))) return rc;
     if ((rc = regrow(ctx, (void **) &s->parts2, &s->parts2_cap, (size_t) rows * MSM_PLANES * (n2 + 1) * sizeof(g1j_t)))) return rc;
@@ -476,10 +488,9 @@ static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32
     return ZK_OK;
 }
 
-// rows independent MSMs with full-width scalars (Montgomery form, rows `ld` apart); results in s->rowsJ / s->host_rows
+// rows independent MSMs with full-width scalars (Montgomery form, rows `ld` apart); results in s->rowsJ
 static int32_t run_msm(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint32_t *idx, uint32_t rows, uint32_t cols) {
     msm_state *s = ctx->msm;
-    s->host_rows_valid = false;
     int32_t rc;
     if ((rc = ensure_full_table(ctx)) || (rc = ensure_rows(ctx, rows)) || (rc = scalar_mags(ctx, scalars, ld, nullptr, rows, cols))) return rc;
     return msm_windows(ctx, idx, ld, rows, cols, 0, nullptr);
@@ -490,7 +501,6 @@ static int32_t run_msm(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, const uint
 static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32_t rows, uint32_t cols) {
     msm_state *s = ctx->msm;
     int32_t rc;
-    s->host_rows_valid = false;
     if ((rc = ensure_full_table(ctx))) return rc;
     const g1a_t *D = s->full;                               // F[0][d][j] = d g_j
     if (!s->full_ready) {
@@ -614,19 +624,16 @@ static int32_t fetch_points(zk_ctx *ctx, uint32_t rows, uint64_t *out) {
         ZK_HIP(zk_stream_sync(ctx));
         return exc && !s->safe ? ZK_RETRY_SAFE : ZK_OK;
     }
-    zkff::G1 pj[8];
-    if (s->host_rows_valid) {
-        for (uint32_t i = 0; i < rows; ++i) pj[i] = s->host_rows[i];
-    } else {
-        ZK_STREAM(hipMemcpyAsync(pj, s->rowsJ, (size_t) rows * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
-        ZK_STREAM(hipMemcpyAsync(&exc, s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(zk_stream_sync(ctx));
-        if (exc && !s->safe) return ZK_RETRY_SAFE;
-    }
-    for (uint32_t i = 0; i < rows; ++i) {
-        zkff::G1Affine a = pj[i].toAffine();
-        std::memcpy(out + 12 * i, &a, 96);
-    }
+    std::vector<zkff::G1> pj(rows);
+    ZK_STREAM(hipMemcpyAsync(s->h_stage, s->rowsJ, (size_t) rows * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_STREAM(hipMemcpyAsync(s->h_stage + 8 * sizeof(g1j_t), s->exc, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(zk_stream_sync(ctx));
+    std::memcpy(&exc, s->h_stage + 8 * sizeof(g1j_t), 4);
+    if (exc && !s->safe) return ZK_RETRY_SAFE;
+    std::memcpy((void *) pj.data(), s->h_stage, (size_t) rows * sizeof(g1j_t));
+    std::vector<zkff::G1Affine> aff;
+    zkff::batchToAffine(pj, aff);                  // one field inversion for all of them
+    std::memcpy(out, aff.data(), (size_t) rows * 96);
     return ZK_OK;
 }
 
@@ -776,11 +783,11 @@ extern "C" int32_t zk_hyrax_open_round(zk_ctx *ctx, uint64_t Lp[12], uint64_t Rp
     uint64_t pts[24];
     rc = with_safe_retry(ctx, [&]() -> int32_t {
         int32_t r = run_msm(ctx, s->sL, m / 2, s->idxL, 2, m / 2);
-        return r ? r : fetch_points(ctx, 2, pts);
+        if (r) return r;
+        ZK_STREAM(hipMemcpyAsync(ctx->h_result, s->d_y, 64, hipMemcpyDeviceToHost, ctx->stream));      // (rides on the points' synchronisation: one host turn-around per round)
+        return fetch_points(ctx, 2, pts);
     });
     if (rc) return rc;
-    ZK_STREAM(hipMemcpyAsync(ctx->h_result, s->d_y, 64, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(zk_stream_sync(ctx));
     std::memcpy(Lp, pts, 96);
     std::memcpy(Rp, pts + 12, 96);
     std::memcpy(yL, &ctx->h_result[0], 32);

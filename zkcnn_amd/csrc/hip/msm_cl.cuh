@@ -2,7 +2,7 @@
 // (reference semantics: the verifier draws new generators for every proof, reference src/verifier.cpp:119-128, and hands them to
 // commitInput, src/prover.cpp:503-511), and what the opening's full-width MSMs run whenever no byte table exists.
 //
-//   k_planes_acc   bit planes over the window tables T[w][j] = 2^(8w) g_j: every lane of a wave accumulates an EQUAL share of the
+//   k_planes_acc   digit planes (non-adjacent form: digits -1 / 0 / +1) over the window tables T[w][j] = 2^(8w) g_j: every lane of a wave accumulates an EQUAL share of the
 //                  wave's selected (generator, window) pairs (the wave compacts them into an LDS list first), mixed additions on an
 //                  XYZZ accumulator, one Jacobian partial sum per lane -- no reduction tree inside the streaming kernel
 //   k_cl_tree      sums runs of partial points: 512 threads = 32 rows of row-cooperative arithmetic (fpc_dev.cuh), every row adds
@@ -17,24 +17,32 @@
 #include "msm_kernels.cuh"
 
 #define CL_ROWS 32                  // rows of a k_cl_tree block (512 threads)
-#define ACC_MAX_PAIRS 32u           // (columns per lane) x (windows per lane) of k_planes_acc: the wave's list holds 64 x this many entries
+#define ACC_MAX_PAIRS 128u          // (columns per lane) x (windows per lane) of k_planes_acc / k_bytes_acc: the wave's list holds 64 x this many entries (32 KB)
 
 // ---- k_planes_acc: grid (chunks * wsplit, rows * MSM_PLANES), one wave per block.
 // Block (x, y): row = y / 8, plane = y % 8, window group wg = x % wsplit (windows [w_lo + wg * wpg, min(w_lo + (wg + 1) * wpg, w_hi)),
 // wpg = ceil((w_hi - w_lo) / wsplit)), column chunk = x / wsplit (columns chunk * 64 * cpt + i * 64 + lane, i < cpt). cpt * wpg <= ACC_MAX_PAIRS.
 // mag: canonical magnitudes, sign in bit 255 (k_scalar_mags), dense rows of `cols`; idx (optional): generator of every column, rows `ld` apart.
 // out[((row * 8 + plane) * gridDim.x + x) * 64 + lane] = the lane's partial sum (Jacobian; infinity if it took nothing).
-// windows of `wmask` whose byte of the magnitude at `p` has bit `plane` set
-__device__ __forceinline__ uint32_t acc_select(const fr_t *p, uint32_t plane, uint32_t wmask) {
+// The magnitude at `p` in NON-ADJACENT FORM (digits -1 / 0 / +1, no two neighbours non-zero: a third of the positions instead of half of the bits, so a
+// third fewer additions): with h = x >> 1 and t = x + h, the positive digits are t & (h ^ t) and the negative ones h & (h ^ t). Returns the windows of
+// `wmask` whose byte has a digit at bit `plane`; *negw = those whose digit is -1. (|x| < 2^254, so t < 2^255: bit 255 stays free for the sign flag.)
+__device__ __forceinline__ uint32_t acc_select(const fr_t *p, uint32_t plane, uint32_t wmask, uint32_t *negw) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
     const uint4 lo = q[0], hi = q[1];
-    const uint32_t L[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    uint32_t s = 0;
+    const uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w & 0x7fffffffu};
+    uint32_t s = 0, n = 0;
+    unsigned c = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const uint32_t b = L[k] >> plane;             // bits 0, 8, 16, 24 = the plane bit of the limb's four bytes
+        const uint32_t h = (x[k] >> 1) | (k < 7 ? x[k + 1] << 31 : 0u);
+        const uint32_t t = __builtin_addc(x[k], h, c, &c);
+        const uint32_t d = h ^ t;
+        const uint32_t b = d >> plane, e = (h & d) >> plane;      // bits 0, 8, 16, 24 = the plane bit of the limb's four bytes
         s |= ((b & 1u) | ((b >> 7) & 2u) | ((b >> 14) & 4u) | ((b >> 21) & 8u)) << (4 * k);
+        n |= ((e & 1u) | ((e >> 7) & 2u) | ((e >> 14) & 4u) | ((e >> 21) & 8u)) << (4 * k);
     }
+    *negw = n;
     return s & wmask;
 }
 __device__ __forceinline__ void k_planes_acc(g1j_t *out, const fr_t *mag, uint64_t ld, const uint32_t *idx_base, const g1a_t *T, uint32_t m, uint32_t cols,
@@ -45,13 +53,12 @@ __device__ __forceinline__ void k_planes_acc(g1j_t *out, const fr_t *mag, uint64
     const uint32_t wg = blockIdx.x % wsplit, chunk = blockIdx.x / wsplit;
     const uint32_t wpg = (w_hi - w_lo + wsplit - 1) / wsplit, w0 = w_lo + wg * wpg, w1 = min(w0 + wpg, w_hi);
     const uint32_t *idx = idx_base ? idx_base + (size_t) row * ld : nullptr;
-    // (bit 255 of a magnitude is the sign: not a digit bit)
-    const uint32_t wmask = w0 >= w1 ? 0u : (w1 >= 32 ? 0xffffffffu : ((1u << w1) - 1u)) & ~((1u << w0) - 1u) & (plane == 7 ? 0x7fffffffu : 0xffffffffu);
+    const uint32_t wmask = w0 >= w1 ? 0u : (w1 >= 32 ? 0xffffffffu : ((1u << w1) - 1u)) & ~((1u << w0) - 1u);
     const fr_t *mrow = mag + (size_t) row * cols;
-    uint32_t count = 0;
+    uint32_t count = 0, negw;
     for (uint32_t i = 0; i < cpt; ++i) {
         const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + lane;
-        if (c < cols) count += (uint32_t) __popc(acc_select(mrow + c, plane, wmask));
+        if (c < cols) count += (uint32_t) __popc(acc_select(mrow + c, plane, wmask, &negw));
     }
     // exclusive prefix of the lanes' counts
     uint32_t incl = count;
@@ -65,13 +72,14 @@ __device__ __forceinline__ void k_planes_acc(g1j_t *out, const fr_t *mag, uint64
     for (uint32_t i = 0; i < cpt; ++i) {
         const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + lane;
         if (c >= cols) continue;
-        uint32_t s = acc_select(mrow + c, plane, wmask);
+        uint32_t s = acc_select(mrow + c, plane, wmask, &negw);
         if (!s) continue;
-        const uint32_t tag = (idx ? idx[c] : c) | (mag_neg(mag, (size_t) row * cols + c) ? 1u << 25 : 0u);
+        const uint32_t tag = idx ? idx[c] : c;
+        if (mag_neg(mag, (size_t) row * cols + c)) negw = ~negw;
         while (s) {
             const uint32_t w = (uint32_t) __ffs((int) s) - 1u;
             s &= s - 1u;
-            list[pos++] = tag | (w << 20);
+            list[pos++] = tag | (w << 20) | (((negw >> w) & 1u) << 25);
         }
     }
     __syncthreads();
@@ -107,7 +115,7 @@ __device__ __forceinline__ uint32_t acc_nonzero_bytes(const fr_t *p, uint32_t wm
 template <bool SAFE>
 __device__ __forceinline__ void k_bytes_acc(g1j_t *out, uint32_t *exc_flag, const fr_t *mag, uint64_t ld, const uint32_t *idx_base, const g1a_t *F, uint32_t m,
                                             uint32_t cols, uint32_t cpt, uint32_t wsplit, uint32_t w_lo, uint32_t w_hi) {
-    __shared__ uint16_t list[64 * ACC_MAX_PAIRS];
+    __shared__ uint32_t list[64 * ACC_MAX_PAIRS];
     __shared__ fp_t park[MSM_BLOCK];
     const uint32_t row = blockIdx.y, lane = threadIdx.x;
     const uint32_t wg = blockIdx.x % wsplit, chunk = blockIdx.x / wsplit;
@@ -136,7 +144,7 @@ __device__ __forceinline__ void k_bytes_acc(g1j_t *out, uint32_t *exc_flag, cons
         while (s) {
             const uint32_t w = (uint32_t) __ffs((int) s) - 1u;
             s &= s - 1u;
-            list[pos++] = (uint16_t) (((i * MSM_BLOCK + lane) << 5) | w);       // (column inside the chunk: < 64 cpt <= 2048)
+            list[pos++] = ((i * MSM_BLOCK + lane) << 5) | w;             // (column inside the chunk)
         }
     }
     __syncthreads();
