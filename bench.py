@@ -17,10 +17,12 @@ One JSON line on rank 0:
   cpu_baseline the CPU oracle (port of the reference prover) on the SAME workload, one core, plus the aggregate of several
                independent single-threaded provers running side by side on the host cores (the reference has no threads)
 
-Modes of the timed proofs (stated in `metric`): SEEDED (reproducible challenges) | DRIVE_ONLY | REUSE_GENS (public hash-to-curve
-generators; their byte table is built once per session outside the clock) with the inner-product argument cut at 256. The
-conservative companions are reported next to it: prover_ms_fresh_gens_full_ipa (new random generators for the proof, argument run
-down to length 1, nothing pre-built) and upload_sort_s (gate sort + upload, which the reference pays inside its prover timer).
+Modes of the timed proofs (stated in `metric`). Default, --semantics reference (since round 6): the REFERENCE's protocol -- the verifier draws
+new random generators for every proof (reference src/verifier.cpp:119-128: nothing built for one proof survives it, every table is built inside
+the prover's clock) and the inner-product argument runs down to length 1 -- SEEDED (reproducible challenges and generator scalars, a seed of its
+own for every proof) | DRIVE_ONLY | FULL_IPA. `value`, `prover_ms_per_image`, the roofline and the CPU baseline are all in that mode. The
+public-generator variant of rounds 1-5 (--semantics public: hash-to-curve generators with a resident byte table, argument cut at 256) is the
+`public_generators` object of the line. upload_sort_s = gate sort + upload, which the reference pays inside its prover timer.
 """
 import argparse
 import json
@@ -299,6 +301,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default=None, choices=sorted(WORKLOADS), help="CPU baseline workload (default: the bench workload itself)")
     ap.add_argument("--cpu-procs", type=int, default=8, help="independent CPU provers run side by side for the host throughput figure (0 = skip)")
+    ap.add_argument("--semantics", default="reference", choices=["reference", "public"],
+                    help="reference: new random generators for every proof + inner-product argument down to length 1 (reference src/verifier.cpp:119-128; the default "
+                         "since round 6); public: hash-to-curve generators with a resident byte table, argument cut at 256 (the headline of rounds 1-5)")
     ap.add_argument("--hybrid-tail", action="store_true", help="timed proofs with ZKCNN_MODE_HOST_TAIL (experiment; not the headline configuration)")
     ap.add_argument("--host-rounds", action="store_true", help="timed proofs with ZKCNN_MODE_HOST_ROUNDS: a kernel launch per round, no resident round kernel (experiment)")
     ap.add_argument("--fiat-shamir", action="store_true", help="timed proofs non-interactive (device-side rounds; experiment)")
@@ -359,7 +364,16 @@ def main():
             K = K_ram
     except ImportError:
         pass
-    drive = zkcnn_amd.MODE_DRIVE_ONLY | zkcnn_amd.MODE_REUSE_GENS
+    REF = args.semantics == "reference" and not args.fiat_shamir          # (Fiat-Shamir proofs are always over the public generators: their digest is part of the hashed statement)
+    public_mode = zkcnn_amd.MODE_DRIVE_ONLY | zkcnn_amd.MODE_REUSE_GENS
+    reference_mode = zkcnn_amd.MODE_DRIVE_ONLY | zkcnn_amd.MODE_FULL_IPA
+    drive = reference_mode if REF else public_mode
+    other_mode = public_mode if REF else reference_mode                   # the companion configuration
+
+    def proof_seed(base, i, k):
+        """challenge seed of proof k of session i. Reference semantics: a seed of its own for every proof -- the verifier draws the generators from its seeded
+        stream, and two proofs under one seed would share a generator set (and its tables)."""
+        return ((base << 20) | (i << 10) | k) if REF else base + k
     if args.hybrid_tail:
         drive |= zkcnn_amd.MODE_HOST_TAIL
     if args.fiat_shamir:
@@ -543,11 +557,11 @@ def main():
     def warm(i):
         for w in range(max(args.warmup, 2)):      # at least two: the second use of a generator set builds the MSM byte table
             if w == 0:
-                firsts[i], _ = sessions[i].prove(seed=0x5EED0001, mode=zkcnn_amd.MODE_REUSE_GENS, want_transcript=False)
+                firsts[i], _ = sessions[i].prove(seed=proof_seed(0x5EED0001, i, 0), mode=zkcnn_amd.MODE_FULL_IPA if REF else zkcnn_amd.MODE_REUSE_GENS, want_transcript=False)
                 if firsts[i].accepted != 1:
                     raise SystemExit(f"verifier rejected the GPU proof: {firsts[i].message.decode()}")
             else:
-                sessions[i].prove(seed=0x5EED0001 + w, mode=drive, want_transcript=False)
+                sessions[i].prove(seed=proof_seed(0x5EED0001, i, w), mode=drive, want_transcript=False)
     in_threads(warm)
     first, accepted = firsts[0], True
     # full-size byte parity inside the driver's evidence: session 0 of rank 0 proves its picture under the challenge seed and the modes the CPU
@@ -596,7 +610,7 @@ def main():
         def indep_stream(i):
             try:
                 for k in range(args.steps):
-                    sessions[i].prove(seed=0x5EED0900 + k, mode=drive, want_transcript=True)
+                    sessions[i].prove(seed=proof_seed(0x5EED0900, i, k), mode=drive, want_transcript=True)
             except BaseException as e:      # noqa: BLE001
                 errs_i.append(e)
         th_i = [threading.Thread(target=indep_stream, args=(i,)) for i in range(n_ind)]
@@ -612,7 +626,7 @@ def main():
         batches = [zkcnn_amd.BatchSession(sessions[j * LANES:(j + 1) * LANES]) for j in range(B)]
 
         def warm_batch(j):
-            batches[j].prove(seeds=[0x5EED0A00 + i for i in range(LANES)], mode=drive, want_transcript=False)
+            batches[j].prove(seeds=[proof_seed(0x5EED0A00, j * LANES + i, 0) if REF else 0x5EED0A00 + i for i in range(LANES)], mode=drive, want_transcript=False)
         errs_b = []
 
         def run_b(j):
@@ -633,7 +647,7 @@ def main():
         # one batch proof with nothing else on the GPU and events on every class: what a FUSED launch of each kernel class costs uncontended
         sess.profile_report(reset=True)          # (events the session collected on its own before it became a lane)
         sess.profile("all")
-        batches[0].prove(seeds=[0x5EED0A80 + i for i in range(LANES)], mode=drive, want_transcript=False)
+        batches[0].prove(seeds=[proof_seed(0x5EED0A80, i, 0) if REF else 0x5EED0A80 + i for i in range(LANES)], mode=drive, want_transcript=False)
         batch_table = sess.profile_report(reset=True)
         sess.profile([dominant])
         if os.environ.get("ZKCNN_BENCH_NOEVENTS"):
@@ -666,7 +680,7 @@ def main():
                 if i == 0 and k == EVENT_STEPS:
                     prof_box["report"] = sess.profile_report(reset=True)[dominant]
                     sess.profile(None)
-                done[i].put([sessions[i].prove(seed=0x5EED1000 + k, mode=drive, want_transcript=True)])
+                done[i].put([sessions[i].prove(seed=proof_seed(0x5EED1000, i, k), mode=drive, want_transcript=True)])
         except BaseException as e:          # noqa: BLE001
             fail.append(e)
             done[i].put(None)
@@ -680,7 +694,7 @@ def main():
                 if j == 0 and k == EVENT_STEPS:
                     prof_box["report"] = sess.profile_report(reset=True)[dominant]
                     sess.profile(None)
-                done[j].put(batches[j].prove(seeds=[0x5EED1000 + k] * LANES, mode=drive, want_transcript=True))
+                done[j].put(batches[j].prove(seeds=[proof_seed(0x5EED1000, j * LANES + i, k) for i in range(LANES)], mode=drive, want_transcript=True))
                 batch_wall[j] += batches[j].wall_s
         except BaseException as e:          # noqa: BLE001
             fail.append(e)
@@ -745,8 +759,8 @@ def main():
                   file=sys.stderr)
 
     # the timed steps ran drive-only: replay the last proof of every stream through the full verifier (not timed)
-    replay_mode = zkcnn_amd.MODE_REUSE_GENS | (zkcnn_amd.MODE_FIAT_SHAMIR if args.fiat_shamir else 0)
-    timed_ok = all(sessions[i].verify(last_proofs[i], seed=0x5EED1000 + args.steps - 1, mode=replay_mode).accepted == 1 for i in range(K))
+    replay_mode = (zkcnn_amd.MODE_FULL_IPA if REF else zkcnn_amd.MODE_REUSE_GENS) | (zkcnn_amd.MODE_FIAT_SHAMIR if args.fiat_shamir else 0)
+    timed_ok = all(sessions[i].verify(last_proofs[i], seed=proof_seed(0x5EED1000, i, args.steps - 1), mode=replay_mode).accepted == 1 for i in range(K))
     if not timed_ok:
         raise SystemExit("a proof produced inside the timed region does not verify")
 
@@ -762,15 +776,17 @@ def main():
         """the bench line from what has been measured so far (stages that have not run yet leave their defaults)"""
         steps = args.steps
         out = {
-            "metric": "proofs/s of the GKR prover. REFERENCE SEMANTICS (fresh random generators for every proof, inner-product argument down to length 1: reference "
-                      "src/verifier.cpp:119-128) are the `reference_semantics` object of this line: proofs_per_s, prover_ms_per_image, cpu_oracle_ms, speedup_vs_one_core. "
-                      "`value` is the public-generator variant: " +
+            "metric": ("proofs/s of the GKR prover in the REFERENCE's semantics: the verifier draws new random generators for every proof (reference src/verifier.cpp:119-128; "
+                       "every commitment table is built inside the prover's clock, none survives the proof) and the inner-product argument runs down to length 1; " if REF else
+                       "proofs/s of the GKR prover, PUBLIC-GENERATOR VARIANT (hash-to-curve generators with a resident byte table, inner-product argument cut at 256; the reference's "
+                       "own semantics are the `reference_semantics` object of this line); ") +
                       f"{args.workload} pic_cnt={pp} proofs, {K} in flight per GPU" +
                       (f" as {B} lock-step batches of {LANES} lanes: one host thread, one HIP stream and ONE kernel launch per sumcheck round per batch" if LANES > 1 else "") +
-                      "; modes SEEDED|DRIVE_ONLY|REUSE_GENS: public generators "
-                      "with a resident byte table, IPA cut at 256" + ("; EXPERIMENT: hybrid host tail" if args.hybrid_tail else "") + ("; EXPERIMENT: Fiat-Shamir (challenges hashed on the host)" if args.fiat_shamir else "") +
-                      "; sessions share one resident circuit, a picture each; every timed proof returns its transcript); prover_ms_per_image = single-stream latency (a lone proof "
-                      "runs its rounds in resident kernels; proofs_per_s_every_round_on_gpu = the same shape without the lanes' host tail",
+                      ("; modes SEEDED|DRIVE_ONLY|FULL_IPA, a challenge seed (= a generator set) of its own for every proof" if REF else "; modes SEEDED|DRIVE_ONLY|REUSE_GENS") +
+                      ("; EXPERIMENT: hybrid host tail" if args.hybrid_tail else "") + ("; EXPERIMENT: Fiat-Shamir (challenges hashed on the host)" if args.fiat_shamir else "") +
+                      "; sessions share one resident circuit, a picture each; every timed proof returns its transcript, the last of every session is replay-verified; prover_ms_per_image = "
+                      "single-stream latency in the same semantics (a lone proof runs its rounds in resident kernels); proofs_per_s_every_round_on_gpu = the same shape without the "
+                      "lanes' host tail" + ("; `public_generators` = the variant rounds 1-5 reported as `value`" if REF else ""),
             "value": round(sum(p["streams"] for p in per_rank) * steps / elapsed, 4),         # every rank's proofs (a rank may hold fewer streams than asked for)
             "unit": "proofs/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -798,12 +814,21 @@ def main():
         out["host_rss_gb_all_sessions"] = host_rss_gb
         out["host_peak_rss_gb_while_building"] = host_peak_gb
         out.update(extras)
-        # the reference's own protocol first (the headline is a variant; this is the like-for-like pair)
-        ref = {"proofs_per_s": extras.get("proofs_per_s_fresh_gens_full_ipa"), "prover_ms_per_image": extras.get("prover_ms_fresh_gens_full_ipa"),
-               "cpu_oracle_ms": (cpu or {}).get("reference_mode_ms"), "speedup_vs_one_core": (cpu or {}).get("gpu_speedup_vs_one_core_reference_mode"),
-               "note": "fresh random generators drawn by the verifier for every proof (no table survives a proof), full inner-product argument; same circuit, same pictures, "
-                       "transcripts equal to the CPU oracle's in this mode (tests/test_full_size_gpu.py)"}
-        out = {"metric": out["metric"], "value": out["value"], "unit": out["unit"], "reference_semantics": ref, **{k: v for k, v in out.items() if k not in ("metric", "value", "unit")}}
+        if REF:
+            # the variant rounds 1-5 reported as `value`, next to the reference's own protocol
+            pub = {"proofs_per_s": extras.get("proofs_per_s_public_generators"), "prover_ms_per_image": extras.get("prover_ms_public_generators"),
+                   "cpu_oracle_ms": (cpu or {}).get("other_mode_ms"), "speedup_vs_one_core": (cpu or {}).get("gpu_speedup_vs_one_core_other_mode"),
+                   "note": "public hash-to-curve generators (nobody knows a discrete log) shared by every proof, their byte table resident in HBM (built once, outside the clock), "
+                           "inner-product argument cut at 256 (the last 256 scalars travel in the clear): the configuration rounds 1-5 reported as `value`"}
+            out = {"metric": out["metric"], "value": out["value"], "unit": out["unit"], "semantics": "reference", "public_generators": pub,
+                   **{k: v for k, v in out.items() if k not in ("metric", "value", "unit")}}
+        else:
+            ref = {"proofs_per_s": extras.get("proofs_per_s_fresh_gens_full_ipa"), "prover_ms_per_image": extras.get("prover_ms_fresh_gens_full_ipa"),
+                   "cpu_oracle_ms": (cpu or {}).get("other_mode_ms"), "speedup_vs_one_core": (cpu or {}).get("gpu_speedup_vs_one_core_other_mode"),
+                   "note": "fresh random generators drawn by the verifier for every proof (no table survives a proof), full inner-product argument; same circuit, same pictures, "
+                           "transcripts equal to the CPU oracle's in this mode (tests/test_full_size_gpu.py)"}
+            out = {"metric": out["metric"], "value": out["value"], "unit": out["unit"], "semantics": "public", "reference_semantics": ref,
+                   **{k: v for k, v in out.items() if k not in ("metric", "value", "unit")}}
         return out
 
     leave(build_out, "timed region (replay-verified); companions, roofline, PMC passes and CPU baseline not run yet")
@@ -825,14 +850,14 @@ def main():
                 for k in range(args.steps):
                     if sessions[i].new_image(valid[i][k % 2])[0] != 0:
                         raise RuntimeError("new_image refused a picture it accepted before")
-                    ni_last[i] = sessions[i].prove(seed=0x5EED2000 + k, mode=drive, want_transcript=True)[1]
+                    ni_last[i] = sessions[i].prove(seed=proof_seed(0x5EED2000, i, k), mode=drive, want_transcript=True)[1]
 
             def batch_new(j):            # a new picture in every lane (its witness is replayed in HBM on the batch's stream), then the batch's proof
                 for k in range(args.steps):
                     for i in range(j * LANES, (j + 1) * LANES):
                         if sessions[i].new_image(valid[i][k % 2])[0] != 0:
                             raise RuntimeError("new_image refused a picture it accepted before")
-                    for i, (_, tr) in enumerate(batches[j].prove(seeds=[0x5EED2000 + k] * LANES, mode=drive, want_transcript=True)):
+                    for i, (_, tr) in enumerate(batches[j].prove(seeds=[proof_seed(0x5EED2000, j * LANES + i, k) for i in range(LANES)], mode=drive, want_transcript=True)):
                         ni_last[j * LANES + i] = tr
             torch.cuda.synchronize()
             t_ni = time.perf_counter()
@@ -853,7 +878,7 @@ def main():
                 in_threads(stream_new)
             torch.cuda.synchronize()
             t_ni = time.perf_counter() - t_ni
-            ok = all(sessions[i].verify(ni_last[i], seed=0x5EED2000 + args.steps - 1, mode=replay_mode).accepted == 1 for i in range(K))
+            ok = all(sessions[i].verify(ni_last[i], seed=proof_seed(0x5EED2000, i, args.steps - 1), mode=replay_mode).accepted == 1 for i in range(K))
             new_image = {"new_image_ms": round(single[len(single) // 2], 3),
                          "proofs_per_s_new_picture_each_proof": round(K * args.steps / t_ni, 3),
                          "new_picture_proofs_replay_verified": K if ok else 0,
@@ -867,7 +892,7 @@ def main():
         try:
             gt_steps = max(2, min(args.steps, 6))
             for x in batches:            # (untimed: first use of the mode)
-                x.prove(seeds=[0x5EED5000] * LANES, mode=drive | zkcnn_amd.MODE_GPU_TAIL, want_transcript=False)
+                x.prove(seeds=[proof_seed(0x5EED5000, batches.index(x) * LANES + i, 0) for i in range(LANES)], mode=drive | zkcnn_amd.MODE_GPU_TAIL, want_transcript=False)
             torch.cuda.synchronize()
             t_gt = time.perf_counter()
             errs_g = []
@@ -876,7 +901,7 @@ def main():
             def run_g(j):
                 try:
                     for k in range(gt_steps):
-                        last_g[j] = batches[j].prove(seeds=[0x5EED5100 + k] * LANES, mode=drive | zkcnn_amd.MODE_GPU_TAIL, want_transcript=True)
+                        last_g[j] = batches[j].prove(seeds=[proof_seed(0x5EED5100, j * LANES + i, k) for i in range(LANES)], mode=drive | zkcnn_amd.MODE_GPU_TAIL, want_transcript=True)
                 except BaseException as e:      # noqa: BLE001
                     errs_g.append(e)
             th_g = [threading.Thread(target=run_g, args=(j,)) for j in range(B)]
@@ -887,18 +912,30 @@ def main():
             if errs_g:
                 raise errs_g[0]
             # the two configurations produce the same bytes: lane 0 of batch 0 against a proof of the default configuration under the same seed
-            same = batches[0].prove(seeds=[0x5EED5100 + gt_steps - 1] * LANES, mode=drive, want_transcript=True)[0][1] == last_g[0][0][1]
+            same = batches[0].prove(seeds=[proof_seed(0x5EED5100, i, gt_steps - 1) for i in range(LANES)], mode=drive, want_transcript=True)[0][1] == last_g[0][0][1]
             gpu_tail = {"proofs_per_s_every_round_on_gpu": round(K * gt_steps / t_gt, 3), "every_round_on_gpu_transcript_identical": bool(same)}
         except Exception as e:      # noqa: BLE001 - the headline does not depend on this
             gpu_tail = {"every_round_on_gpu_error": str(e)}
-    # ---- companion in the REFERENCE's semantics (reference src/verifier.cpp:119-128: new random generators for every proof; the inner-product
-    # argument run down to length 1): nothing pre-built survives from proof to proof -- window / digit tables are built inside the clock ----
+    # ---- companion: the OTHER semantics. Timed steps in the reference's semantics (the default): the public-generator variant (hash-to-curve generators
+    # with a resident byte table, argument cut at 256: the headline of rounds 1-5). Timed steps over public generators: the reference's semantics
+    # (reference src/verifier.cpp:119-128: new random generators for every proof, argument down to length 1, every table built inside the clock) ----
     ref_mode = {}
     ref_steps = 0
+    other_key = "proofs_per_s_public_generators" if REF else "proofs_per_s_fresh_gens_full_ipa"
     if rank == 0 and world == 1 and not args.no_companions:
         try:
-            fresh_mode = zkcnn_amd.MODE_DRIVE_ONLY | zkcnn_amd.MODE_FULL_IPA
             ref_steps = max(2, min(args.steps, 4))
+
+            def other_seeds(j, k):
+                # (fresh generators: a seed of its own for every proof -- the verifier draws the generators from its seeded stream)
+                return [0x5EED4000 + k] * LANES if REF else [(0x5EED4000 << 20) | ((j * LANES + i) << 10) | k for i in range(LANES)]
+            if REF:                 # (untimed: the second use of the public generator set builds its byte table)
+                for w in range(2):
+                    for j in range(B if LANES > 1 else K):
+                        if LANES > 1:
+                            batches[j].prove(seeds=[0x5EED3F00 + w] * LANES, mode=other_mode, want_transcript=False)
+                        else:
+                            sessions[j].prove(seed=0x5EED3F00 + w, mode=other_mode, want_transcript=False)
             torch.cuda.synchronize()
             t_rf = time.perf_counter()
             errs_r = []
@@ -907,10 +944,9 @@ def main():
                 try:
                     for k in range(ref_steps):
                         if LANES > 1:
-                            # (a seed of its own for every proof: the verifier draws the generators from its seeded stream)
-                            batches[j].prove(seeds=[0x5EED4000 + 4096 * j + 16 * k + i for i in range(LANES)], mode=fresh_mode, want_transcript=True)
+                            batches[j].prove(seeds=other_seeds(j, k), mode=other_mode, want_transcript=True)
                         else:
-                            sessions[j].prove(seed=0x5EED4000 + 4096 * j + k, mode=fresh_mode, want_transcript=True)
+                            sessions[j].prove(seed=other_seeds(j, k)[0], mode=other_mode, want_transcript=True)
                 except BaseException as e:      # noqa: BLE001
                     errs_r.append(e)
             th_r = [threading.Thread(target=run_r, args=(j,)) for j in range(B if LANES > 1 else K)]
@@ -919,9 +955,9 @@ def main():
             torch.cuda.synchronize()
             if errs_r:
                 raise errs_r[0]
-            ref_mode = {"proofs_per_s_fresh_gens_full_ipa": round(K * ref_steps / (time.perf_counter() - t_rf), 3)}
+            ref_mode = {other_key: round(K * ref_steps / (time.perf_counter() - t_rf), 3)}
         except Exception as e:      # noqa: BLE001 - the headline does not depend on this
-            ref_mode = {"fresh_gens_full_ipa_error": str(e)}
+            ref_mode = {other_key + "_error": str(e)}
     for x in batches:
         x.close()
     batches = []
@@ -1010,14 +1046,16 @@ def main():
             raise KeyboardInterrupt
         fresh = []
         for k in range(2):          # new random generators per proof (no REUSE_GENS): tables rebuilt inside the prover's clock; IPA down to length 1
-            r, _ = sess.prove(seed=0x5EED0200 + k, mode=zkcnn_amd.MODE_DRIVE_ONLY | zkcnn_amd.MODE_FULL_IPA, want_transcript=False)
+            r, _ = sess.prove(seed=0x5EED0200 + k, mode=reference_mode, want_transcript=False)
             fresh.append(1e3 * (r.prove_s + r.poly_prove_s))
         extras["prover_ms_fresh_gens_full_ipa"] = round(min(fresh), 3)
-        r, _ = sess.prove(seed=0x5EED0210, mode=drive, want_transcript=False)      # back on the session generators (tables are rebuilt once)
-        r, _ = sess.prove(seed=0x5EED0211, mode=drive, want_transcript=False)
-        r, _ = sess.prove(seed=0x5EED0212, mode=drive | zkcnn_amd.MODE_FULL_IPA, want_transcript=False)
+        r, _ = sess.prove(seed=0x5EED0210, mode=public_mode, want_transcript=False)      # back on the session generators (tables are rebuilt once)
+        r, _ = sess.prove(seed=0x5EED0211, mode=public_mode, want_transcript=False)
+        pub = [sess.prove(seed=0x5EED0213 + k, mode=public_mode, want_transcript=False)[0] for k in range(3)]
+        extras["prover_ms_public_generators"] = round(min(1e3 * (x.prove_s + x.poly_prove_s) for x in pub), 3)
+        r, _ = sess.prove(seed=0x5EED0212, mode=public_mode | zkcnn_amd.MODE_FULL_IPA, want_transcript=False)
         extras["prover_ms_session_gens_full_ipa"] = round(1e3 * (r.prove_s + r.poly_prove_s), 3)
-        # other modes of the same prover, single stream, best of 3 (all with the session's public generators)
+        # other modes of the same prover, single stream, best of 3 (hybrid tail / every round on the GPU: the timed semantics; Fiat-Shamir and zero knowledge: public generators)
         def best(mode):
             print(f"[bench] companion mode {mode:#x}", file=sys.stderr, flush=True)
             return round(min(1e3 * (x.prove_s + x.poly_prove_s) for x in (sess.prove(seed=0x5EED0300 + k, mode=mode, want_transcript=False)[0] for k in range(3))), 3)
@@ -1029,7 +1067,9 @@ def main():
         extras["prover_ms_fiat_shamir"] = best(fs)                                        # non-interactive: challenges hashed on the host, rounds in the resident kernels
         extras["prover_ms_fiat_shamir_device_rounds"] = best(fs | zkcnn_amd.MODE_FS_DEVICE)  # ... small rounds and their hash chain on the GPU by themselves
         extras["prover_ms_fiat_shamir_host_rounds"] = best(fs | zkcnn_amd.MODE_HOST_ROUNDS)
-        extras["prover_ms_zero_knowledge"] = best(drive | zkcnn_amd.MODE_ZK)              # blinded commitments, masked rounds, proofs of dot product
+        extras["prover_ms_zero_knowledge"] = best(public_mode | zkcnn_amd.MODE_ZK)        # blinded commitments, masked rounds, proofs of dot product (public generators)
+        if REF:
+            extras["prover_ms_zero_knowledge_fresh_gens_full_ipa"] = best(reference_mode | zkcnn_amd.MODE_ZK)
         extras["fs_device_rounds_phases"] = list(sess.fs_stats())
     except KeyboardInterrupt:
         pass
@@ -1086,18 +1126,21 @@ def main():
         import multiprocessing as mp
         cm, cpic, cpp = WORKLOADS[args.cpu_sample or args.workload]
         job = (cm, cpic, cpp, DATA_SEED, drive)
-        # ... and in the reference's own semantics (fresh random generators drawn by the verifier, argument down to length 1), side by side on a second core
-        job_ref = (cm, cpic, cpp, DATA_SEED, zkcnn_amd.MODE_DRIVE_ONLY | zkcnn_amd.MODE_FULL_IPA)
+        # ... and in the other semantics (the public-generator variant next to the reference's, or the other way round), side by side on a second core
+        job_ref = (cm, cpic, cpp, DATA_SEED, other_mode)
         ctx = mp.get_context("spawn")
         with ctx.Pool(2) as pool:                          # (i) one core each, nothing else running
             (one_s, one_wall, gates, one_sum, one_poly, cpu_sha, cpu_len), ref_cpu = pool.map(_cpu_prover_worker, [job, job_ref])
+        other_ms = extras.get("prover_ms_public_generators" if REF else "prover_ms_fresh_gens_full_ipa")
         cpu = {"value": round(1e3 * one_s, 1), "unit": "prover ms/image", "cores": 1, "kind": "port",
                "sample": f"{args.cpu_sample or args.workload} ({cm}), pic_cnt={cpp}, {gates} mul gates -- the full bench workload: CPU oracle prover time "
-                         f"(sumcheck {1e3 * one_sum:.0f} ms + Hyrax {1e3 * one_poly:.0f} ms), same modes as the timed GPU proofs",
+                         f"(sumcheck {1e3 * one_sum:.0f} ms + Hyrax {1e3 * one_poly:.0f} ms), same modes as the timed GPU proofs"
+                         + (" (the reference's semantics: fresh generators, full argument)" if REF else ""),
                "gpu_speedup_vs_one_core": round(1e3 * one_s / max(1e3 * (lat_prove + lat_poly), 1e-9), 1),
-               "reference_mode_ms": round(1e3 * ref_cpu[0], 1),
-               "gpu_speedup_vs_one_core_reference_mode": (round(1e3 * ref_cpu[0] / extras["prover_ms_fresh_gens_full_ipa"], 1) if extras.get("prover_ms_fresh_gens_full_ipa") else None),
-               "reference_mode": "fresh random generators per proof (reference src/verifier.cpp:119-128), inner-product argument down to length 1: CPU oracle prover time over the GPU's prover_ms_fresh_gens_full_ipa",
+               "other_mode_ms": round(1e3 * ref_cpu[0], 1),
+               "gpu_speedup_vs_one_core_other_mode": round(1e3 * ref_cpu[0] / other_ms, 1) if other_ms else None,
+               "other_mode": ("the public-generator variant (argument cut at 256)" if REF else "fresh random generators per proof (reference src/verifier.cpp:119-128), inner-product argument down to length 1")
+                             + ": CPU oracle prover time over the GPU's lone proof in that mode",
                "host_cores_available": os.cpu_count()}
         if (args.cpu_sample or args.workload) == args.workload:
             parity = {"transcript_equal_to_cpu_oracle": bool(parity_sha == cpu_sha and parity_len == cpu_len), "transcript_sha256_gpu": parity_sha,

@@ -285,6 +285,13 @@ int32_t zk_k_round_quadratic(zk_ctx *ctx, uint64_t *V, uint64_t *M, uint64_t n, 
 int32_t zk_k_msm(zk_ctx *ctx, uint64_t out[12], const uint64_t *scalars, const uint64_t *bases, uint64_t n);
 /* out[i] = in[i]^-1 in the base field Fp (6 words each, Montgomery form, R = 2^384; the inverse of 0 is 0): the inversion the table kernels use */
 int32_t zk_k_fp_inv(zk_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t n);
+/* row-cooperative base-field arithmetic (one element per 16-lane row; hip/fpc_dev.cuh -- the arithmetic of the commitment's reduction trees, in place of
+ * mcl's Fp inside the absent hyrax-bls12-381): out[i] = a[i] b[i], out[n + i] = a[i] + b[i], out[2n + i] = a[i] - b[i]; 6 words per element, Montgomery form */
+int32_t zk_k_fpc_ops(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n);
+/* ... point arithmetic in that form: out[i] = p[i] + q[i] (infinity, p = q, p = -q handled), out[n + i] = 2 p[i]; Jacobian points of 18 words (Z = 0: infinity) */
+int32_t zk_k_cl_add(zk_ctx *ctx, uint64_t *out, const uint64_t *p, const uint64_t *q, uint64_t n);
+/* ... and the reduction tree of the MSM kernels: out[s] = sum of the n_seg points of segment s, runs of n_in points per 512-thread block and level */
+int32_t zk_k_cl_tree(zk_ctx *ctx, uint64_t *out, const uint64_t *pts, uint64_t n_seg, uint64_t segs, uint32_t n_in);
 /* the commitInput data path on caller data: `rows` Pedersen commitments of `cols` scalars each over `cols` bases */
 int32_t zk_k_commit_rows(zk_ctx *ctx, uint64_t *out, const uint64_t *scalars, const uint64_t *bases, uint64_t rows, uint64_t cols);
 /* device-resident micro-benchmarks: seconds per launch, averaged over `iters` launches with HIP events */

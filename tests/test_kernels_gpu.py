@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import zkcnn_amd
-from zkcnn_amd import R_MOD, from_mont, to_mont
+from zkcnn_amd import P_MOD, R_MOD, from_mont, to_mont
 
 pytestmark = pytest.mark.gpu
 
@@ -261,3 +261,104 @@ def test_witness_gates_rejects_out_of_range(hip, oracle):
     uni["u"] = 10                            # one past the end of layer 0
     with pytest.raises(RuntimeError):
         hip.witness_gates(4, uni, np.zeros(0, dtype=zkcnn_amd.HipContext.BIN_GATE), None, to_mont([1]), to_mont([1]))
+
+
+# ---- row-cooperative base-field / curve arithmetic (hip/fpc_dev.cuh: one element per 16-lane DPP row; the arithmetic of the commitment's reduction trees) ----
+_RR = 1 << 384
+
+
+def _fp_pack(xs):
+    a = np.zeros((len(xs), 6), dtype=np.uint64)
+    for i, x in enumerate(xs):
+        m = x * _RR % P_MOD
+        for k in range(6):
+            a[i, k] = (m >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    return a
+
+
+def _fp_unpack(a):
+    inv = pow(_RR, -1, P_MOD)
+    return [sum(int(row[k]) << (64 * k) for k in range(6)) * inv % P_MOD for row in a.reshape(-1, 6)]
+
+
+def _jac(points, zs):
+    """Jacobian (X z^2, Y z^3, z) of affine integer points (None = infinity), 18 words each"""
+    flat = []
+    for p, z in zip(points, zs):
+        flat += [0, 1, 0] if p is None else [p[0] * z * z % P_MOD, p[1] * z * z * z % P_MOD, z]
+    return _fp_pack(flat).reshape(-1, 18)
+
+
+def _affine(j):
+    out = []
+    for X, Y, Z in zip(*[iter(_fp_unpack(j))] * 3):
+        if Z == 0:
+            out.append(None)
+        else:
+            zi = pow(Z, -1, P_MOD)
+            out.append((X * zi * zi % P_MOD, Y * zi * zi * zi % P_MOD))
+    return out
+
+
+def test_row_cooperative_field_arithmetic_against_python(hip):
+    """products, sums and differences of the 16-lanes-per-element form against Python integers: 0, 1, p - 1, equal operands, operands whose sum is
+    exactly p, limbs of all ones (carries that ripple through a whole row), and random elements"""
+    rng = np.random.default_rng(950)
+    ones = (1 << 352) - 1
+    a = [0, 1, P_MOD - 1, P_MOD - 1, 5, P_MOD - 5, ones, ones, (1 << 380), P_MOD - 1 - ones, 0xffffffff, 1 << 32]
+    b = [7, P_MOD - 1, P_MOD - 1, 1, 5, 5, 1, ones, (1 << 380), ones + 1, 0xffffffff, (1 << 352) - (1 << 32)]
+    a += [int.from_bytes(rng.bytes(48), "little") % P_MOD for _ in range(2000)]
+    b += [int.from_bytes(rng.bytes(48), "little") % P_MOD for _ in range(2000)]
+    prod, tot, dif = hip.fpc_ops(_fp_pack(a), _fp_pack(b))
+    assert _fp_unpack(prod) == [x * y % P_MOD for x, y in zip(a, b)]
+    assert _fp_unpack(tot) == [(x + y) % P_MOD for x, y in zip(a, b)]
+    assert _fp_unpack(dif) == [(x - y) % P_MOD for x, y in zip(a, b)]
+    # canonical outputs (< p): the row form's results feed equality tests and the transcript
+    for arr in (prod, tot, dif):
+        assert all(sum(int(r[k]) << (64 * k) for k in range(6)) < P_MOD for r in arr)
+
+
+def test_row_cooperative_point_arithmetic_every_case(hip, oracle):
+    """general addition and doubling in row form against affine arithmetic with Python integers: generic pairs in different Jacobian scalings, either
+    or both operands at infinity, P = Q in the same and in different coordinates (the doubling branch), P = -Q"""
+    from tests.test_hyrax_cpu import _padd
+    rng = np.random.default_rng(951)
+    n = 96
+    g = oracle.generators(2 * n, 4242)
+    aff = [tuple(_fp_unpack(row.reshape(2, 6))) for row in g]
+    P, Q = aff[:n], aff[n:]
+    P[0] = None
+    Q[1] = None
+    P[2] = Q[2] = None
+    Q[3] = P[3]
+    Q[4] = P[4]
+    Q[5] = (P[5][0], (P_MOD - P[5][1]) % P_MOD)
+    Q[6] = (P[6][0], (P_MOD - P[6][1]) % P_MOD)
+    zp = [1] * n
+    zq = [1] * n
+    for i in range(n):
+        if i != 3 and i != 5 and i % 2 == 0:
+            zp[i] = int.from_bytes(rng.bytes(47), "little") % P_MOD or 1
+            zq[i] = int.from_bytes(rng.bytes(47), "little") % P_MOD or 1
+    got_sum, got_dbl = hip.cl_add(_jac(P, zp), _jac(Q, zq))
+    assert _affine(got_sum) == [_padd(p, q) for p, q in zip(P, Q)]
+    assert _affine(got_dbl) == [_padd(p, p) for p in P]
+
+
+@pytest.mark.parametrize("n_seg,segs,n_in", [(1, 7, 64), (5, 9, 64), (64, 4, 64), (100, 3, 64), (700, 2, 64), (129, 2, 32)])
+def test_row_cooperative_reduction_tree(hip, oracle, n_seg, segs, n_in):
+    """k_cl_tree: sums of runs of points (ragged last run, a point at infinity and a repeated point among them) against a Python chain of additions"""
+    from tests.test_hyrax_cpu import _padd
+    g = oracle.generators(n_seg * segs, 77 + n_seg)
+    aff = [tuple(_fp_unpack(row.reshape(2, 6))) for row in g]
+    if len(aff) > 4:
+        aff[2] = None
+        aff[4] = aff[3]
+    got = _affine(hip.cl_tree(_jac(aff, [1 + 3 * i for i in range(len(aff))]), segs, n_in))
+    want = []
+    for s in range(segs):
+        acc = None
+        for p in aff[s * n_seg:(s + 1) * n_seg]:
+            acc = _padd(acc, p)
+        want.append(acc)
+    assert got == want

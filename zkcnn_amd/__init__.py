@@ -169,6 +169,29 @@ class HipContext:
         self._check(self.lib.zk_k_fp_inv(self.ctx, u64p(out), u64p(a), ctypes.c_uint64(a.shape[0])), "zk_k_fp_inv")
         return out
 
+    def fpc_ops(self, a, b):
+        """row-cooperative Fp arithmetic on (n, 6) Montgomery-form elements: (a * b, a + b, a - b)"""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.zeros((3,) + a.shape, dtype=np.uint64)
+        self._check(self.lib.zk_k_fpc_ops(self.ctx, u64p(out), u64p(a), u64p(b), ctypes.c_uint64(a.shape[0])), "zk_k_fpc_ops")
+        return out[0], out[1], out[2]
+
+    def cl_add(self, p, q):
+        """row-cooperative point arithmetic on (n, 18) Jacobian points: (p + q, 2 p)"""
+        p = np.ascontiguousarray(p, dtype=np.uint64)
+        q = np.ascontiguousarray(q, dtype=np.uint64)
+        out = np.zeros((2,) + p.shape, dtype=np.uint64)
+        self._check(self.lib.zk_k_cl_add(self.ctx, u64p(out), u64p(p), u64p(q), ctypes.c_uint64(p.shape[0])), "zk_k_cl_add")
+        return out[0], out[1]
+
+    def cl_tree(self, pts, segs, n_in=64):
+        """sums of `segs` equal runs of the (n, 18) Jacobian points through the row-cooperative reduction tree"""
+        pts = np.ascontiguousarray(pts, dtype=np.uint64)
+        out = np.zeros((segs, 18), dtype=np.uint64)
+        self._check(self.lib.zk_k_cl_tree(self.ctx, u64p(out), u64p(pts), ctypes.c_uint64(pts.shape[0] // segs), ctypes.c_uint64(segs), ctypes.c_uint32(n_in)), "zk_k_cl_tree")
+        return out
+
     def witness_ntt(self, src, logn, inverse, count):
         """count transforms of length 2^logn (forward: half-length inputs zero padded; inverse: first half kept)"""
         length = 1 << logn

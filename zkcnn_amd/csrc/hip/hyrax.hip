@@ -878,6 +878,58 @@ extern "C" int32_t zk_k_fp_inv(zk_ctx *ctx, uint64_t *out, const uint64_t *in, u
     return ZK_OK;
 }
 
+// row-cooperative arithmetic (fpc_dev.cuh) on caller data: products / sums / differences of n pairs of Fp elements
+extern "C" int32_t zk_k_fpc_ops(zk_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n) {
+    if (!ctx || !out || !a || !b || !n || n > (1u << 20)) return ZK_ERR_ARG;
+    ZK_HIP(hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = zk_scratch(ctx, 5 * n * sizeof(fp_t)))) return rc;
+    fp_t *d_a = (fp_t *) ctx->scratch.p, *d_b = d_a + n, *d_o = d_b + n;
+    ZK_STREAM(hipMemcpyAsync(d_a, a, n * sizeof(fp_t), hipMemcpyHostToDevice, ctx->stream));
+    ZK_STREAM(hipMemcpyAsync(d_b, b, n * sizeof(fp_t), hipMemcpyHostToDevice, ctx->stream));
+    zk_launch_d<k_fpc_ops, 256>(ctx, PC_MSM_FINISH, 0.0, dim3((uint32_t) ((n * 16 + 255) / 256)), d_o, (const fp_t *) d_a, (const fp_t *) d_b, (uint32_t) n);
+    ZK_HIP(hipGetLastError());
+    ZK_STREAM(hipMemcpyAsync(out, d_o, 3 * n * sizeof(fp_t), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(zk_stream_sync(ctx));
+    return ZK_OK;
+}
+// ... sums p[i] + q[i] (out[0 .. n)) and doubles 2 p[i] (out[n .. 2n)) of n pairs of Jacobian points
+extern "C" int32_t zk_k_cl_add(zk_ctx *ctx, uint64_t *out, const uint64_t *p, const uint64_t *q, uint64_t n) {
+    if (!ctx || !out || !p || !q || !n || n > (1u << 18)) return ZK_ERR_ARG;
+    ZK_HIP(hipSetDevice(ctx->device));
+    int32_t rc;
+    if ((rc = zk_scratch(ctx, 4 * n * sizeof(g1j_t)))) return rc;
+    g1j_t *d_p = (g1j_t *) ctx->scratch.p, *d_q = d_p + n, *d_o = d_q + n;
+    ZK_STREAM(hipMemcpyAsync(d_p, p, n * sizeof(g1j_t), hipMemcpyHostToDevice, ctx->stream));
+    ZK_STREAM(hipMemcpyAsync(d_q, q, n * sizeof(g1j_t), hipMemcpyHostToDevice, ctx->stream));
+    zk_launch_d<k_cl_add, 256>(ctx, PC_MSM_FINISH, 0.0, dim3((uint32_t) ((n * 16 + 255) / 256)), d_o, (const g1j_t *) d_p, (const g1j_t *) d_q, (uint32_t) n);
+    ZK_HIP(hipGetLastError());
+    ZK_STREAM(hipMemcpyAsync(out, d_o, 2 * n * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(zk_stream_sync(ctx));
+    return ZK_OK;
+}
+// ... and the reduction tree: out[s] = sum of the n_seg points of segment s (k_cl_tree, runs of `n_in` per block, as many levels as it takes)
+extern "C" int32_t zk_k_cl_tree(zk_ctx *ctx, uint64_t *out, const uint64_t *pts, uint64_t n_seg, uint64_t segs, uint32_t n_in) {
+    if (!ctx || !out || !pts || !n_seg || !segs || segs > 65535 || n_seg * segs > (1u << 20) || !n_in) return ZK_ERR_ARG;
+    ZK_HIP(hipSetDevice(ctx->device));
+    int32_t rc;
+    const size_t total = n_seg * segs;
+    if ((rc = zk_scratch(ctx, 3 * total * sizeof(g1j_t)))) return rc;
+    g1j_t *cur = (g1j_t *) ctx->scratch.p, *nxt = cur + total, *res = nxt + total;
+    ZK_STREAM(hipMemcpyAsync(cur, pts, total * sizeof(g1j_t), hipMemcpyHostToDevice, ctx->stream));
+    for (uint32_t n = (uint32_t) n_seg;;) {
+        const uint32_t step = std::min<uint32_t>(n, n_in), blocks = (n + step - 1) / step;
+        zk_launch_d<k_cl_tree, 512>(ctx, PC_MSM_FINISH, 0.0, dim3(blocks, (uint32_t) segs), blocks == 1 ? res : nxt, (const g1j_t *) cur, n, step);
+        if (blocks == 1) break;
+        std::swap(cur, nxt);
+        n = blocks;
+    }
+    ZK_HIP(hipGetLastError());
+    ZK_STREAM(hipMemcpyAsync(out, res, segs * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(zk_stream_sync(ctx));
+    return ZK_OK;
+}
+
 // rows x cols row commitments over `cols` arbitrary bases: the commitInput data path on caller-supplied data
 extern "C" int32_t zk_k_commit_rows(zk_ctx *ctx, uint64_t *out, const uint64_t *scalars, const uint64_t *bases, uint64_t rows,
                                     uint64_t cols) {

@@ -236,3 +236,22 @@ __device__ __forceinline__ void k_cl_whorner(g1j_t *rows_pts, uint32_t rows, con
     acc = cl_tree32(acc, sm, m);
     if (w == 0) g1c_store(rows_pts + row, acc);
 }
+
+// ---- kernel-level entry points of the parity tests (zk_k_fpc_ops / zk_k_cl_add): one element / one point addition per row ----
+// out[i] = a[i] b[i], out[n + i] = a[i] + b[i], out[2 n + i] = a[i] - b[i]
+__device__ __forceinline__ void k_fpc_ops(fp_t *out, const fp_t *a, const fp_t *b, uint32_t n) {
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
+    const uint32_t m = fpc_mod_limb();
+    const bool on = i < n && l < 12;
+    const uint32_t x = on ? a[i].v[l] : 0u, y = on ? b[i].v[l] : 0u;
+    const uint32_t p = fpc_mul(x, y, m), s = fpc_add(x, y, m), d = fpc_sub(x, y, m);
+    if (on) { out[i].v[l] = p; out[(size_t) n + i].v[l] = s; out[2 * (size_t) n + i].v[l] = d; }
+}
+// out[i] = p[i] + q[i] (Jacobian, every special case), out[n + i] = 2 p[i]
+__device__ __forceinline__ void k_cl_add(g1j_t *out, const g1j_t *p, const g1j_t *q, uint32_t n) {
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint32_t m = fpc_mod_limb();
+    const g1c_t a = i < n ? g1c_load(p + i) : g1c_inf(), b = i < n ? g1c_load(q + i) : g1c_inf();
+    const g1c_t r = g1c_add(a, b, m), d = g1c_dbl(a, m);
+    if (i < n) { g1c_store(out + i, r); g1c_store(out + (size_t) n + i, d); }
+}
