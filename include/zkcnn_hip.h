@@ -146,6 +146,10 @@ int32_t zk_fs_attach(zk_ctx *ctx, const uint32_t *state, const uint64_t *pending
  * either way. log_entries = -1 (the state of a new context): the library's default -- off for a context on its own (its small rounds run in
  * the resident kernels), 2^5 for a lane of a lock-step batch; log_entries <= -2: off, every round of every phase is a kernel. */
 int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries);
+/* reusable = 0: the generators handed to zk_commit_input from now on are used by ONE proof only (the reference's semantics: its verifier draws new
+ * random generators for every proof, reference src/verifier.cpp:119-128) -- no byte table is ever built for them, whatever the proof does with the
+ * set; reusable != 0 (the state of a new context): a set that is used a second time gets its byte table. */
+int32_t zk_set_generator_reuse(zk_ctx *ctx, int32_t reusable);
 /* rounds the hybrid tail has run on the host since the context was created (bench: rounds_on_host_per_proof) */
 int32_t zk_host_tail_stats(zk_ctx *ctx, uint64_t *rounds);
 /* Persistent rounds of the interactive protocol (on by default): once the live tables of a phase hold at most 1024 quads, ONE resident

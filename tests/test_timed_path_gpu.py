@@ -119,6 +119,28 @@ def test_dot_prod_dead_region_is_folded_in_one_pass(built, monkeypatch):
                 for x in ss:
                     x.close()
 
+
+@pytest.mark.parametrize("model,pic,pp,must_defer", [("custom:C64:3:1:f F10", (48, 48, 3), 1, True), ("custom:C24:3:1:f F10", (40, 40, 5), 1, False),
+                                                     ("custom:C10:3:1:f F10", (32, 32, 6), 3, False)])
+def test_dot_prod_deferred_fold_when_the_live_prefix_stops_being_a_multiple_of_four(built, monkeypatch, model, pic, pp, must_defer):
+    """Round-5 advisor finding: the cubic round kernel folds QUADS, so a deferred Y (read as 0 behind X's live prefix) is only right while that prefix is a
+    multiple of 4, not merely even -- with prefixes like 6 = (pictures + output channels) x input channels x 2^-k the last live quad reached behind it and
+    claim_1 = Y(u) came out wrong (the verifier rejects an honest proof). Shapes whose prefix has a small 2-adic valuation, every fill threshold the hook
+    allows: accepted, and the bytes of the oracle."""
+    with oracle_ffi.OracleSession(model, pic, pp) as o:
+        _, cpu = o.prove(seed=0x5EED0022, mode=REUSE | DRIVE)
+    monkeypatch.setenv("ZKCNN_TEST_HOOKS", "1")
+    deferred = 0
+    for fill_log in (4, 7, 10, 13):
+        monkeypatch.setenv("ZKCNN_TEST_DOT_FILL_LOG", str(fill_log))
+        with zkcnn_amd.Session(model, pic, pp) as s:
+            res, gpu = s.prove(seed=0x5EED0022, mode=REUSE)
+            assert res.accepted == 1, f"fill threshold 2^{fill_log}: {res.message.decode()}"
+            assert gpu == cpu, f"fill threshold 2^{fill_log}: transcript differs from the oracle's"
+            deferred += s.dot_deferred_phases()
+    assert deferred >= 1 or not must_defer, "no DOT_PROD phase took the deferred fold: the test does not reach the code it is about"
+
+
 FULL = [
     ("vgg16", (32, 32, 3), 4, dict(n_layers=99, input_bits=26)),      # BASELINE configs[4]: the per-GPU workload (4 images per GPU)
     ("vgg11", (32, 32, 3), 8, dict(n_layers=69, input_bits=26)),      # configs[3] as the reference would fold it (one circuit, pic_cnt=8)

@@ -82,3 +82,21 @@ def test_full_size_vgg11_zero_knowledge(built):
         print(f"vgg11 zero-knowledge: prover {1e3 * (d.prove_s + d.poly_prove_s):.1f} ms (sumcheck {1e3 * d.prove_s:.1f} + commitments / openings "
               f"{1e3 * d.poly_prove_s:.1f}), proof {d.proof_kb + d.poly_proof_kb:.0f} KB")
         assert s.verify(tc, seed=9, mode=ZK | REUSE).accepted == 1
+
+
+def test_zero_knowledge_refuses_another_tail_policy(built):
+    """Round-5 advisor finding: the zero-knowledge mode fixes the host tail itself (the masks' share of a phase's last round polynomial is added on the
+    host from the last table pairs); ZKCNN_MODE_HOST_TAIL / ZKCNN_MODE_GPU_TAIL in the same proof used to be ignored silently -- the call is refused,
+    for a session on its own and for the lanes of a batch, and the session proves on afterwards."""
+    model, pic, pp = CASES[1]
+    with zkcnn_amd.Session(model, pic, pp) as s:
+        for flag in (zkcnn_amd.MODE_HOST_TAIL, zkcnn_amd.MODE_GPU_TAIL):
+            with pytest.raises(RuntimeError, match="host tail"):
+                s.prove(seed=5, mode=ZK | REUSE | flag)
+        res, _ = s.prove(seed=5, mode=ZK | REUSE)
+        assert res.accepted == 1
+        with zkcnn_amd.Session(model, pic, pp) as s2, zkcnn_amd.BatchSession([s, s2]) as b:
+            with pytest.raises(RuntimeError, match="host tail"):
+                b.prove(seeds=[5, 6], mode=ZK | REUSE | DRIVE | zkcnn_amd.MODE_GPU_TAIL)
+            out = b.prove(seeds=[5, 6], mode=ZK | REUSE)
+            assert all(r.accepted == 1 for r, _ in out)

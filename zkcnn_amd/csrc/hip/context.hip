@@ -322,7 +322,15 @@ extern "C" int32_t zk_batch_detach(zk_batch *b, zk_ctx *ctx) {
     (void) zk_batch_flush(b);
     (void) hipStreamSynchronize(b->stream);
     ctx->stream = nullptr;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->stream = nullptr; b->err = "zk_batch_detach: no stream for the detached context"; }
+    // (round-5 advisor finding: a detached context without a stream of its own would run everything on the legacy NULL stream, which orders differently
+    //  against the non-blocking streams -- it is marked unusable instead, and the caller is told)
+    const bool no_stream = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess;
+    if (no_stream) {
+        (void) hipGetLastError();
+        ctx->stream = nullptr;
+        ctx->circuit_ready = false;
+        ctx->err = b->err = "zk_batch_detach: no stream for the detached context (the context is unusable)";
+    }
     ctx->batch = nullptr;
     ctx->n_pending = 0;
     ctx->live_now = true;
@@ -330,7 +338,7 @@ extern "C" int32_t zk_batch_detach(zk_batch *b, zk_ctx *ctx) {
         if (b->lanes[i] == ctx) { b->lanes.erase(b->lanes.begin() + i); break; }
     for (size_t i = 0; i < b->lanes.size(); ++i) b->lanes[i]->lane = (int) i;
     ctx->lane = -1;
-    return ZK_OK;
+    return no_stream ? ZK_ERR_HIP : ZK_OK;
 }
 extern "C" void zk_batch_destroy(zk_batch *b) {
     if (!b) return;

@@ -677,6 +677,19 @@ static int32_t add_blinds(zk_ctx *ctx, const uint64_t *blinds, uint32_t rows, ui
     return ZK_OK;
 }
 
+// A generator set that will NOT come again (the reference's semantics: the verifier draws new generators for every proof, reference src/verifier.cpp:119-128)
+// never gets a byte table, however often the proof itself uses it (the zero-knowledge mode commits several vectors over one set).
+extern "C" int32_t zk_set_generator_reuse(zk_ctx *ctx, int32_t reusable) {
+    if (!ctx) return ZK_ERR_ARG;
+    ZK_HIP(hipSetDevice(ctx->device));
+    int32_t rc = ensure_state(ctx);
+    if (rc) return rc;
+    ctx->msm->no_full = !reusable;
+    if (ctx->msm->no_full) ctx->msm->full_ready = ctx->msm->t8_ready = false;
+    else if (ctx->msm->gt) gen_adopt(ctx->msm);
+    return ZK_OK;
+}
+
 static int32_t commit_input_impl(zk_ctx *ctx, const uint64_t *gens, uint64_t n_gens, const uint64_t *blinds, uint64_t *out_comm, uint64_t n_rows) {
     CHECK_READY();
     const dev_layer &L0 = ctx->L[0];

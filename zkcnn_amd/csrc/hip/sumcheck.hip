@@ -727,13 +727,16 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
     // out) in a launch of its own ahead of the round kernel, which then works on the live pairs alone
     uint64_t pl = std::min<uint64_t>(npairs, (x_live + 3) / 4);
     // the first fold of the phase decides: a large dead region behind an even prefix is left unfolded (policy: DEAD_*); Y must still be the layer's values in place
-    if (!first && ctx->round == 2 && !ctx->dot_defer && !ctx->fs_state && t1.Vsrc && npairs - pl >= (1ull << policy::DOT_STREAM_LOG) && x_live > 0 && !(x_live & 1) && !fill &&
-        !getenv("ZKCNN_NO_DOT_DEFER")) {
+    // (the round kernel reads QUADS: a live prefix that is not a multiple of 4 has a last quad that reaches behind it, where a deferred Y reads as 0 --
+    // round-5 advisor finding: the prefix must be a multiple of 4 to start deferring and to go on with it, not merely even)
+    static const bool no_defer = getenv("ZKCNN_NO_DOT_DEFER") != nullptr;
+    if (!first && ctx->round == 2 && !ctx->dot_defer && !ctx->fs_state && t1.Vsrc && npairs - pl >= (1ull << policy::DOT_STREAM_LOG) && x_live > 0 && !(x_live & 3) && !fill &&
+        !no_defer) {
         ctx->dot_defer = true;
         ctx->dot_defer_Y = t1.Vsrc;
         ctx->dot_defer_to = std::min<uint64_t>(n, ctx->L[id - 1].val_live);      // (entries of the unfolded table that can be non-zero)
         ++ctx->dot_defer_count;
-    } else if (ctx->dot_defer && ((x_live & 1) || fill || ctx->round - 2 >= policy::DEAD_MAX_FOLDS || x_live >= n)) {
+    } else if (ctx->dot_defer && ((x_live & 3) || fill || ctx->round - 2 >= policy::DEAD_MAX_FOLDS || x_live >= n)) {
         // catch up: `sdone` folds were skipped behind the prefix; the current tables get their entries [x_live, n) -- Y the folded values, X its zeros
         const int sdone = ctx->round - 2, cs = std::min(sdone, 12);
         const uint64_t real_rows = std::min<uint64_t>(n, (ctx->dot_defer_to + (1ull << sdone) - 1) >> sdone);
@@ -742,21 +745,23 @@ extern "C" int32_t zk_sumcheck_dotprod_update1(zk_ctx *ctx, const uint64_t prev_
         const uint64_t need = (1ull << policy::DEAD_MAX_FOLDS) + (1ull << 16);
         if (!ctx->dead_tabs && (rc = zk_dev_alloc(ctx, (void **) &ctx->dead_tabs, need * sizeof(fr_t)))) return rc;
         fr_t *E = ctx->dead_tabs, *part = ctx->dead_tabs + (1ull << policy::DEAD_MAX_FOLDS);
-        if (rows * chunks > (1ull << 16) && chunks > 1) { ctx->err = "DOT_PROD catch-up: more partial sums than planned"; return ZK_ERR_STATE; }
         fr_t *ycur = t1.V[t1.cur], *xcur = t0.V[t0.cur];
         prep_plan P(ctx);
         P.eq1(E, sdone, ctx->r_u[id].data(), HFr::one());
         if (x_live + rows < n) P.zero(ycur + x_live + rows, n - x_live - rows);
         if (x_live < n) P.zero(xcur + x_live, n - x_live);
         if ((rc = P.launch(ctx))) return rc;
-        if (rows) {
+        // (rows in blocks whose partial sums fit the 2^16-entry scratch: with more than 12 skipped folds a row is summed in chunks -- only the test hook gets there)
+        const uint64_t blk = chunks > 1 ? std::max<uint64_t>(1, (1ull << 16) / chunks) : rows;
+        for (uint64_t r0 = 0; r0 < rows; r0 += blk) {
+            const uint64_t nr = std::min<uint64_t>(blk, rows - r0);
             k_dead_rows_f f;
-            f.Y = ctx->dot_defer_Y; f.E = E; f.out = chunks > 1 ? part : ycur + x_live;
-            f.row0 = x_live; f.rows = rows; f.s = sdone; f.cs = cs;
-            const uint64_t waves = sdone >= 6 ? rows * chunks : (rows + (64u >> sdone) - 1) / (64u >> sdone);
+            f.Y = ctx->dot_defer_Y; f.E = E; f.out = chunks > 1 ? part : ycur + x_live + r0;
+            f.row0 = x_live + r0; f.rows = nr; f.s = sdone; f.cs = cs;
+            const uint64_t waves = sdone >= 6 ? nr * chunks : (nr + (64u >> sdone) - 1) / (64u >> sdone);
             f.nblk = (uint32_t) std::min<uint64_t>((waves + ZK_BLOCK / 64 - 1) / (ZK_BLOCK / 64), 4096);
-            zk_launch_f(ctx, PC_FOLD, 32.0 * (double) (rows << sdone), dim3(f.nblk), f);
-            if (chunks > 1) zk_launch_f<k_sum_rows_f, 1024>(ctx, PC_FOLD, 0.0, dim3((uint32_t) ((rows + 63) / 64)), k_sum_rows_f{ycur + x_live, (const fr_t *) part, (uint32_t) rows, (uint32_t) chunks});
+            zk_launch_f(ctx, PC_FOLD, 32.0 * (double) (nr << sdone), dim3(f.nblk), f);
+            if (chunks > 1) zk_launch_f<k_sum_rows_f, 1024>(ctx, PC_FOLD, 0.0, dim3((uint32_t) ((nr + 63) / 64)), k_sum_rows_f{ycur + x_live + r0, (const fr_t *) part, (uint32_t) nr, (uint32_t) chunks});
             ZK_HIP(hipGetLastError());
         }
         ctx->dot_defer = false;

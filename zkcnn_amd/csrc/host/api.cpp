@@ -180,10 +180,21 @@ void *zkcnn_batch_create(void *const *sessions, int32_t n) {
     }
 }
 
+// The zero-knowledge mode adds the masks' share of a phase's LAST round polynomial on the host, from the phase's last table pairs, so it fixes the
+// hand-over point itself (tables of <= 32 entries finish their phase on the host: prover::zkModeOn): asking for another tail policy in the same proof
+// used to be ignored silently (round-5 advisor finding) -- it is refused.
+static bool zk_tail_conflict(uint32_t mode) { return (mode & ZKCNN_MODE_ZK) && (mode & (ZKCNN_MODE_HOST_TAIL | ZKCNN_MODE_GPU_TAIL)); }
+static const char *const ZK_TAIL_MSG = "ZKCNN_MODE_ZK sets its own host tail (2^5 entries): not together with ZKCNN_MODE_HOST_TAIL / ZKCNN_MODE_GPU_TAIL";
+
 int32_t zkcnn_batch_prove(void *batch, const uint64_t *seeds, uint32_t mode, uint8_t *const *transcripts, const uint64_t *caps, zkcnn_result *out, double *wall_s) {
     if (!batch || !out) return -1;
     gpuBatch *g = (gpuBatch *) batch;
     if ((mode & ZKCNN_MODE_TAMPER) && !test_hooks_enabled()) return -4;
+    if (zk_tail_conflict(mode)) {
+        std::memset(out, 0, sizeof(*out));
+        std::snprintf(out[0].message, sizeof(out[0].message), "%s", ZK_TAIL_MSG);
+        return -4;
+    }
     const double t0 = gpuSession::now();
     int flush_rc = ZK_OK;
     zk_batch *b = g->b;
@@ -292,6 +303,11 @@ int32_t zkcnn_session_prove(void *session, uint64_t seed, uint32_t mode, uint8_t
     if ((mode & ZKCNN_MODE_TAMPER) && !test_hooks_enabled()) {
         std::memset(out, 0, sizeof(*out));
         std::snprintf(out->message, sizeof(out->message), "ZKCNN_MODE_TAMPER is a test hook: set ZKCNN_TEST_HOOKS=1");
+        return -4;
+    }
+    if (zk_tail_conflict(mode)) {
+        std::memset(out, 0, sizeof(*out));
+        std::snprintf(out->message, sizeof(out->message), "%s", ZK_TAIL_MSG);
         return -4;
     }
     try {

@@ -37,25 +37,34 @@ private:
 // (whitespace-separated numbers: src/neuralNetwork.cpp:805-893) of the stream behind it
 class teeSource : public dataSource {
 public:
-    teeSource(std::unique_ptr<dataSource> s, const string &name) : inner(std::move(s)), f(fopen(name.c_str(), "w")) {
-        if (!f) throw std::runtime_error("recordDataTo: cannot open " + name);
+    // (the file is opened by the caller BEFORE the source changes hands: a constructor that throws after taking `s` would destroy the data source)
+    teeSource(std::unique_ptr<dataSource> s, FILE *file, const string &name) : inner(std::move(s)), f(file), path(name) {}
+    ~teeSource() override {
+        // a short write (full disk) would leave a data file that reads as a DIFFERENT statement: say so, loudly, where it can still be said
+        if (f && (fclose(f) != 0 || failed)) fprintf(stderr, "recordDataTo: writing %s failed -- the file is incomplete\n", path.c_str());
     }
-    ~teeSource() override { if (f) fclose(f); }
     double next(kind k, i64 fan_in) override {
         const double x = inner->next(k, fan_in);
-        fprintf(f, "%.17g\n", x);
+        if (fprintf(f, "%.17g\n", x) < 0 || ferror(f)) {
+            failed = true;
+            throw std::runtime_error("recordDataTo: write to " + path + " failed");
+        }
         return x;
     }
 private:
     std::unique_ptr<dataSource> inner;
     FILE *f;
+    string path;
+    bool failed = false;
 };
 
 } // namespace
 
 void neuralNetwork::recordDataTo(const string &filename) {
     if (!src) throw std::runtime_error("recordDataTo: no data source yet");
-    src.reset(new teeSource(std::move(src), filename));
+    FILE *f = fopen(filename.c_str(), "w");
+    if (!f) throw std::runtime_error("recordDataTo: cannot open " + filename);       // (`src` is untouched)
+    src.reset(new teeSource(std::move(src), f, filename));
 }
 
 neuralNetwork::neuralNetwork(i64 psize_x, i64 psize_y, i64 pchannel, i64 pparallel, const string &i_filename,

@@ -57,6 +57,9 @@ void prover::proofEnd() { if (ctx) (void) zk_proof_end(ctx); }
 void prover::setLiveRounds(bool on) {
     if (ctx) check(zk_set_live_rounds(ctx, on ? 1 : 0), "zk_set_live_rounds");
 }
+void prover::setGeneratorReuse(bool reusable) {
+    if (ctx) check(zk_set_generator_reuse(ctx, reusable ? 1 : 0), "zk_set_generator_reuse");
+}
 void prover::setHostTail(int log_entries) {
     if (ctx) check(zk_set_host_tail(ctx, log_entries), "zk_set_host_tail");
 }

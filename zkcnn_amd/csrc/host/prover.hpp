@@ -77,6 +77,7 @@ public:
     uint64_t hostTailRounds() const;            // rounds it has run on the host so far
     void proofBegin();                          // bracket of one proof (include/zkcnn_hip.h: zk_proof_begin / zk_proof_end)
     void proofEnd();
+    void setGeneratorReuse(bool reusable);      // the commitment generators of the next proofs come again (public generators) or not (the reference's fresh ones): include/zkcnn_hip.h: zk_set_generator_reuse
     void setLiveRounds(bool on);                // resident round kernel of the interactive protocol (include/zkcnn_hip.h: zk_set_live_rounds)
 
     // ---- the next picture on the resident circuit (include/zkcnn_hip.h: zk_witness_program_upload / zk_witness_rerun). The program is
@@ -117,6 +118,7 @@ private:
 inline void attachFsChain(prover &p, const uint32_t *state, const uint64_t *pending) { p.attachFiatShamir(state, pending); }
 inline void setHostTail(prover &p, int log_entries) { p.setHostTail(log_entries); }
 inline void setLiveRounds(prover &p, bool on) { p.setLiveRounds(on); }
+inline void setGeneratorReuse(prover &p, bool reusable) { p.setGeneratorReuse(reusable); }
 inline void proofBegin(prover &p) { p.proofBegin(); }
 inline void proofEnd(prover &p) { p.proofEnd(); }
 template <class H> inline void setConvHints(prover &p, const std::vector<H> &hints) {

@@ -14,6 +14,7 @@
 template <class P> inline void attachFsChain(P &, const uint32_t *, const uint64_t *) {}
 template <class P> inline void setHostTail(P &, int) {}
 template <class P> inline void setLiveRounds(P &, bool) {}
+template <class P> inline void setGeneratorReuse(P &, bool) {}
 template <class P> inline void proofBegin(P &) {}
 template <class P> inline void proofEnd(P &) {}
 template <class P, class H> inline void setConvHints(P &, const std::vector<H> &) {}
@@ -107,6 +108,7 @@ struct sessionT {
         setLiveRounds(p, !(mode & ZKCNN_MODE_HOST_ROUNDS));
         // hybrid tail: tables of <= 64 entries finish their phase on the host; otherwise the library's default (lanes of a batch: <= 32 entries) or none at all
         setHostTail(p, (mode & ZKCNN_MODE_HOST_TAIL) ? 6 : (mode & ZKCNN_MODE_GPU_TAIL) ? -2 : -1);
+        if (for_prover) setGeneratorReuse(p, public_gens);     // fresh generators (the reference's semantics) die with the proof: no byte table for them
         const zkff::publicGenerators *pg = nullptr;
         if (public_gens) {
             pg = &zkff::publicGeneratorSet(n_sqrt);
