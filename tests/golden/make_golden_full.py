@@ -19,13 +19,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from tests import oracle_ffi  # noqa: E402
 
-CASES = {"vgg11_pp8": ("vgg11", (32, 32, 3), 8), "vgg16_pp4": ("vgg16", (32, 32, 3), 4)}
+# vgg16_pp32 = BASELINE configs[4] as the reference itself would run it (ONE circuit over 32 pictures, layer 0 = 2^28 entries): ~40 minutes and > 100 GB on
+# one core -- made on the GPU box's host (`GOLDEN_RUNS=reuse_gens GOLDEN_OUT=gpurun_out/full_size_pp32.json python tests/golden/make_golden_full.py vgg16_pp32`
+# through gpurun: the oracle is this repo's code and travels) and merged into full_size.json by hand
+CASES = {"vgg11_pp8": ("vgg11", (32, 32, 3), 8), "vgg16_pp4": ("vgg16", (32, 32, 3), 4), "vgg16_pp32": ("vgg16", (32, 32, 3), 32)}
 RUNS = [("interactive", 0x5EED0001, 0), ("reuse_gens", 0x5EED0007, 2)]
+if os.environ.get("GOLDEN_RUNS"):
+    RUNS = [r for r in RUNS if r[0] in os.environ["GOLDEN_RUNS"].split(",")]
 DRIVE = 1
 
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "full_size.json")
 out_path = os.environ.get("GOLDEN_OUT", path)
-for key in (sys.argv[1:] or list(CASES)):
+for key in (sys.argv[1:] or ["vgg11_pp8", "vgg16_pp4"]):
     model, pic, pp = CASES[key]
     t0 = time.time()
     entry = {"model": model, "pic": list(pic), "pic_cnt": pp, "data_seed": 20260928}

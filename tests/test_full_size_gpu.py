@@ -157,6 +157,14 @@ def test_vgg16_thirty_two_pictures_as_one_circuit(built):
         assert res.n_layers == 99 and res.input_bits == 28 and res.n_rounds == 2605
         r2, tr2 = s.prove(seed=SEED, mode=REUSE | DRIVE)
         assert tr2 == tr
+        # BYTE parity at 2^28 (round 6): the CPU oracle's transcript of this circuit was made once on a GPU box's host (tests/golden/make_golden_full.py
+        # vgg16_pp32: ~40 minutes and > 100 GB on one core) and its SHA-256 + length are a committed fixture
+        import json
+        gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "full_size.json")))["full_size"].get("vgg16_pp32")
+        if gold is not None:
+            g = gold["reuse_gens"]
+            _, tr3 = s.prove(seed=g["challenge_seed"], mode=REUSE | DRIVE)
+            assert len(tr3) == g["transcript_len"] and hashlib.sha256(tr3).hexdigest() == g["sha256"], "vgg16 pic_cnt = 32: transcript differs from the CPU oracle's"
         assert s.verify(tr, seed=SEED, mode=REUSE).accepted == 1
         bad, _ = s.prove(seed=SEED, mode=REUSE | TAMPER | ((res.n_messages // 2) << 8))
         assert bad.accepted == 0

@@ -669,8 +669,14 @@ static int32_t add_blinds(zk_ctx *ctx, const uint64_t *blinds, uint32_t rows, ui
     ZK_STREAM(hipMemcpyAsync(d_bl, blinds, (size_t) rows * 32, hipMemcpyHostToDevice, ctx->stream));
     ZK_STREAM(hipMemcpyAsync(d_idx, idx.data(), (size_t) rows * 4, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(zk_stream_sync(ctx));          // idx is a local
-    if ((rc = regrow(ctx, (void **) &s->tmpJ, &s->tmp_cap, (size_t) rows * sizeof(g1j_t)))) return rc;
     if ((rc = scalar_mags(ctx, d_bl, 1, nullptr, rows, 1))) return rc;
+    if (!s->full_ready) {
+        // no byte table (a fresh generator set): one row-cooperative double-and-add chain per row over H itself (msm_cl.cuh: k_cl_blind_rows)
+        zk_launch_d<k_cl_blind_rows, 256>(ctx, PC_MSM_PLANES, 32.0 * (double) rows, dim3((rows + 15) / 16), s->rowsJ, (const fr_t *) s->mag, (const g1a_t *) (s->tables + h_index), rows);
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+    if ((rc = regrow(ctx, (void **) &s->tmpJ, &s->tmp_cap, (size_t) rows * sizeof(g1j_t)))) return rc;
     if ((rc = msm_windows(ctx, d_idx, 1, rows, 1, 0, s->tmpJ))) return rc;
     zk_launch_d<k_add_rows, 64>(ctx, PC_MSM_FINISH, 0.0, dim3((rows + 63) / 64), s->rowsJ, s->tmpJ, (const uint32_t *) nullptr, rows, (const uint32_t *) nullptr);
     ZK_HIP(hipGetLastError());
