@@ -470,7 +470,7 @@ def main():
         free2, _ = torch.cuda.mem_get_info(local_rank)
         probe.close()
         hbm_first_gb, hbm_extra_gb = round((free0 - free1) / 1e9, 2), round((free1 - free2) / 1e9, 2)
-        K_fit = 1 + max(0, int((0.85 * free1 - 8e9) / (max(free1 - free2, 1) * 1.3)))       # margin: MSM scratch and the byte table come with the first proofs
+        K_fit = 1 + max(0, int((0.9 * free1 - 8e9) / (max(free1 - free2, 1) * 1.2)))        # margin: MSM scratch (~1.5 GB per session at 2^26 inputs) and the byte table come with the first proofs
         if K_fit < K:
             print(f"[bench] HBM allows {K_fit} sessions of this workload, not the {K} asked for", file=sys.stderr)
             K = K_fit
@@ -493,7 +493,7 @@ def main():
             sessions[0].close()
             sessions[0] = None
             hbm_first_gb, hbm_extra_gb = round((free0 - free1) / 1e9, 2), round((free1 - free2) / 1e9, 2)
-            K_fit = 1 + max(0, int((0.85 * free1 - 8e9) / (max(free1 - free2, 1) * 1.3)))
+            K_fit = 1 + max(0, int((0.9 * free1 - 8e9) / (max(free1 - free2, 1) * 1.2)))
             if K_fit < K:
                 print(f"[bench] HBM allows {K_fit} sessions of this workload, not the {K} asked for", file=sys.stderr)
                 K = K_fit

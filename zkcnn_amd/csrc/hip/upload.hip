@@ -398,10 +398,17 @@ static int32_t build_static(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_
         D.val_live = D.val_len;          // until the values arrive
         if (i == 0) { Z.tp_cap[1] = std::max<uint64_t>(Z.tp_cap[1], D.val_len); continue; }      // the layer-0 combine runs on pair 1
         if (i == n_layers - 1) Z.tp_cap[0] = std::max<uint64_t>(Z.tp_cap[0], D.val_len);          // Vres folds the output layer on pair 0
-        Z.bg = std::max<uint64_t>(Z.bg, D.val_len);
         // exact sizes of the bookkeeping buffers (round 3: a session's buffers used to be eight times the LARGEST table of the circuit)
         const uint64_t prev_len = 1ull << layers[i - 1].bit_length;
         const bool dotp = S.ty == ZK_DOT_PROD, xform = S.ty == ZK_FFT || S.ty == ZK_IFFT;
+        // beta_g holds what the layer's phase-1 initialisation writes (sumcheck.hip: zk_sumcheck_init_phase1; verifier.hip: zk_verifier_predicates, the same
+        // shapes): a transform layer's table runs over its "which vector" bits only, a DOT_PROD layer reads the IFFT layer's (the verifier splits one of
+        // 2^(bl - fft_bl)), every other layer -- PADDING's expanded table included -- one entry per output. Round 6: the two buffers were sized by the
+        // FFT layer's 2^26 outputs (2 x 2.1 GB per session of vgg11 with pic_cnt = 8) of which 2^-fft_bl were ever written.
+        uint64_t bg_need = D.val_len;
+        if (S.ty == ZK_FFT || dotp) bg_need = 1ull << std::max<int>(S.bit_length - S.fft_bit_length, 0);
+        else if (S.ty == ZK_IFFT) bg_need = 1ull << std::max<int>(S.bit_length - (S.fft_bit_length - 1), 0);
+        Z.bg = std::max<uint64_t>(Z.bg, bg_need);
         for (int b = 0; b < 2; ++b) {
             const int blu = dotp ? S.bit_length_u[1] : S.bit_length_u[b], blv = S.bit_length_v[b];
             for (int bl : {blu, blv}) {
@@ -412,7 +419,9 @@ static int32_t build_static(zk_ctx *ctx, const zk_layer_desc *layers, int32_t n_
                 if (b == 0 || len > prev_len || xform || dotp) Z.v0_cap[b] = std::max(Z.v0_cap[b], len);
             }
         }
-        Z.bu = std::max<uint64_t>(Z.bu, 1ull << std::max<int>(std::max<int>(S.max_bl_u, S.max_bl_v), 0));
+        // beta_u / the verifier's beta_v: eq tables over the u (v) variables of a phase 2. A DOT_PROD layer's phase 2 runs over the vector bits only
+        // (max_bl_v; the verifier's over max_bl_u - fft_bl): its max_bl_u -- every bit of the FFT layer's index -- sized this buffer at 2.1 GB before round 6
+        Z.bu = std::max<uint64_t>(Z.bu, 1ull << std::max<int>(dotp ? std::max<int>(S.max_bl_v, S.max_bl_u - S.fft_bit_length) : std::max<int>(S.max_bl_u, S.max_bl_v), 0));
         for (int bl : {(int) S.bit_length_u[0], (int) S.bit_length_v[0]}) if (bl >= 0) Z.sub = std::max<uint64_t>(Z.sub, 1ull << bl);
         if (S.fft_bit_length >= 0) Z.gs = std::max<uint64_t>(Z.gs, 1ull << S.fft_bit_length);
 
