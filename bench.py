@@ -74,7 +74,7 @@ def launch_command(argv, n_gpus, port=None, python=None):
 # (kernels are functors launched through k_run<F> / k_run_b<F>: the functor's name is part of the kernel's)
 CLASS_KERNELS = {"round_quad": ("k_round_quad2_f",), "round_fine": ("k_round_fine_f",), "round_tail": ("k_tail",), "round_cubic": ("k_round_cubic",),
                  "gate_reduce": ("k_gate_multi", "k_conv_wa", "k_conv_m1", "k_conv_e", "k_conv_ae", "k_conv_m2"),
-                 "msm_planes": ("k_msm_codes", "k_msm_windows", "k_msm_planes", "k_scalar_codes", "k_scalar_mags", "k_bit_masks", "k_compact_flags")}
+                 "msm_planes": ("k_msm_codes", "k_planes_acc", "k_bytes_acc", "k_msm_planes", "k_scalar_codes", "k_scalar_mags", "k_bit_masks", "k_compact_flags", "k_cl_blind_rows")}
 
 
 CALIBRATION_KERNEL = "k_round_quad2<0>(round2_args)"      # the plain kernel zk_bench_round_quadratic launches (RQ_FOLD): 2 x 2^24 entries, known byte count
@@ -802,6 +802,8 @@ def main():
             "prover_ms_per_image": round(1e3 * (lat_prove + lat_poly), 3),
             "prover_ms_sumcheck": round(1e3 * lat_prove, 3), "prover_ms_commit": round(1e3 * lat_poly, 3),
             "prover_ms_per_image_in_flight": round(1e3 * (sum(batch_wall) / (steps * B) if LANES > 1 else (prove_s + poly_s) / (steps * K)), 3),
+            # wall per batch proof of every batch (its host thread's view): batches that share a hardware queue with another show up here (variance study, profiles/r06_variance.md)
+            "batch_wall_ms": [round(1e3 * w / steps, 1) for w in batch_wall] if LANES > 1 else None,
             "verifier_pass": bool(accepted), "timed_proofs_replay_verified": K, "proof_kb": round(first.proof_kb + first.poly_proof_kb, 1),
             "setup_s": round(setup_s, 1), "witness_s": round(first.witness_s, 1), "upload_sort_s": round(max(f.upload_s for f in firsts), 2),
             "hbm_gb_all_sessions": hbm_all_gb, "hbm_gb_first_session": hbm_first_gb, "hbm_gb_per_extra_session": hbm_extra_gb, "sharing": dict(zkcnn_amd.sharing_stats(), shared_circuit_gb=shared_gb), "distinct_picture_per_session": bool(distinct_pictures),

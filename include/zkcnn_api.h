@@ -38,8 +38,8 @@ typedef struct {
                                      known challenge stream is a debugging aid, never evidence that a statement is true */
 #define ZKCNN_MODE_FULL_IPA  128u  /* inner-product argument down to length 1 (log2(m) rounds) instead of sending the last 256 scalars in the clear */
 #define ZKCNN_MODE_ZK  (1u << 24)  /* zero-knowledge mode: blinded commitments, masked round polynomials, masked evaluation claims, proofs of dot product.
-                                     It fixes the host tail itself (a phase's last <= 32 entries: the masks' share of the last round polynomial is added on the host);
-                                     together with ZKCNN_MODE_HOST_TAIL or ZKCNN_MODE_GPU_TAIL the call is refused (-4) */
+                                     It fixes the host tail itself (a phase's last <= 32 entries: the masks' share of the last round polynomial is added on the host):
+                                     ZKCNN_MODE_HOST_TAIL next to it changes nothing, together with ZKCNN_MODE_GPU_TAIL the call is refused (-4) */
 #define ZKCNN_MODE_HOST_ROUNDS (1u << 25)  /* every sumcheck round is a kernel launch driven from the host: no resident round kernel (interactive), no device-side
                                               rounds (Fiat-Shamir) -- A/B and parity of both */
 #define ZKCNN_MODE_HOST_TAIL (1u << 26)    /* hybrid tail (off by default): once a phase's tables have <= 64 entries they travel to the host and its last

@@ -362,12 +362,12 @@ static int32_t ensure_digit_table(zk_ctx *ctx) {
 }
 
 // sums the `n` partial points of every row (row-major in `src`) into dst[row]
-static int32_t reduce_rows(zk_ctx *ctx, const g1j_t *src, uint32_t n, uint32_t rows, g1j_t *dst) {
+static int32_t reduce_rows(zk_ctx *ctx, const g1j_t *src, uint32_t n, uint32_t rows, g1j_t *dst, uint32_t n_real = 0, const uint32_t *n_wide = nullptr) {
     if (n == 1) {
         ZK_STREAM(hipMemcpyAsync(dst, src, (size_t) rows * sizeof(g1j_t), hipMemcpyDeviceToDevice, ctx->stream));
         return ZK_OK;
     }
-    zk_launch_d<k_reduce_rows16, MSM_BLOCK>(ctx, PC_MSM_FINISH, 0.0, dim3((rows + 3) / 4), dst, src, n, rows);
+    zk_launch_d<k_reduce_rows16, MSM_BLOCK>(ctx, PC_MSM_FINISH, 0.0, dim3((rows + 3) / 4), dst, src, n, rows, n_real, n_wide);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -561,7 +561,7 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
                       s->codes + (size_t) r0 * cols, D, (uint32_t) s->m, cols, cpt, n_real, n_wide, vstride, bflags, bmasks, bT8);
     }
     ZK_HIP(hipGetLastError());
-    if ((rc = reduce_rows(ctx, s->partials, n, rows_all, s->rowsJ))) return rc;         // rowsJ[rows + v] = sum of virtual row v
+    if ((rc = reduce_rows(ctx, s->partials, n, rows_all, s->rowsJ, (rows + 3u) & ~3u, wide_cap ? n_wide : nullptr))) return rc;         // rowsJ[rows + v] = sum of virtual row v
     if (wide_cap && vstride) {
         if ((rc = reduce_rows(ctx, s->rowsJ + rows, MSM_WINDOWS - 1, wide_cap, s->tmpJ))) return rc;
         zk_launch_d<k_add_rows, 64>(ctx, PC_MSM_FINISH, 0.0, dim3((wide_cap + 63) / 64), s->rowsJ, s->tmpJ, s->row_list, wide_cap, n_wide);

@@ -439,9 +439,12 @@ __device__ __forceinline__ g1j_t g1_add_any(const g1j_t &p, const g1j_t &q) {
 // out[row] = sum of the n partial points in[row * n ..]: 16 lanes per row (4 rows per wave), lane l adds partials l, l + 16, ...
 // one after the other, then a 4-level tree through LDS. One launch instead of log(n) dependent ones: the chain is n / 16 - 1 + 4
 // additions deep (7 for the 64 lane sums of a commitment row) and all 64 lanes of a wave work until the tree starts.
-__device__ __forceinline__ void k_reduce_rows16(g1j_t *out, const g1j_t *in, uint32_t n, uint32_t rows) {
+// (n_real / n_wide, optional: the rows behind n_real are the virtual rows of a commitment -- 31 per wide row of the device-side list; those beyond the list
+//  hold nothing and are skipped: 3 968 row slots for ~24 wide rows of a vgg11 commitment)
+__device__ __forceinline__ void k_reduce_rows16(g1j_t *out, const g1j_t *in, uint32_t n, uint32_t rows, uint32_t n_real, const uint32_t *n_wide) {
     __shared__ g1j_t sm[MSM_BLOCK];
     const uint32_t l = threadIdx.x & 15, row = blockIdx.x * 4 + (threadIdx.x >> 4);
+    if (n_wide && blockIdx.x * 4 >= n_real + (MSM_WINDOWS - 1) * *n_wide) return;      // (the whole block: uniform)
     g1j_t acc = g1_inf();
     if (row < rows) {
         const g1j_t *src = in + (size_t) row * n;

@@ -180,11 +180,12 @@ void *zkcnn_batch_create(void *const *sessions, int32_t n) {
     }
 }
 
-// The zero-knowledge mode adds the masks' share of a phase's LAST round polynomial on the host, from the phase's last table pairs, so it fixes the
-// hand-over point itself (tables of <= 32 entries finish their phase on the host: prover::zkModeOn): asking for another tail policy in the same proof
-// used to be ignored silently (round-5 advisor finding) -- it is refused.
-static bool zk_tail_conflict(uint32_t mode) { return (mode & ZKCNN_MODE_ZK) && (mode & (ZKCNN_MODE_HOST_TAIL | ZKCNN_MODE_GPU_TAIL)); }
-static const char *const ZK_TAIL_MSG = "ZKCNN_MODE_ZK sets its own host tail (2^5 entries): not together with ZKCNN_MODE_HOST_TAIL / ZKCNN_MODE_GPU_TAIL";
+// The zero-knowledge mode adds the masks' share of a phase's LAST round polynomial on the host, from the phase's last table pairs, so it needs a host tail
+// and fixes the hand-over point itself (tables of <= 32 entries finish their phase on the host: prover::zkModeOn). ZKCNN_MODE_HOST_TAIL next to it is
+// harmless (a host tail either way; the zero-knowledge mode's size applies); ZKCNN_MODE_GPU_TAIL -- "every round of every phase is a kernel" -- cannot
+// be honoured and used to be ignored silently (round-5 advisor finding): it is refused.
+static bool zk_tail_conflict(uint32_t mode) { return (mode & ZKCNN_MODE_ZK) && (mode & ZKCNN_MODE_GPU_TAIL); }
+static const char *const ZK_TAIL_MSG = "ZKCNN_MODE_ZK needs its host tail (the masks of a phase's last round are added on the host): not together with ZKCNN_MODE_GPU_TAIL";
 
 int32_t zkcnn_batch_prove(void *batch, const uint64_t *seeds, uint32_t mode, uint8_t *const *transcripts, const uint64_t *caps, zkcnn_result *out, double *wall_s) {
     if (!batch || !out) return -1;
