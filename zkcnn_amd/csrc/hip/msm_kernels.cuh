@@ -11,8 +11,9 @@
 //   k_scalar_codes   scalar (Montgomery) -> 16-bit code: low byte of |s|, sign, "wide" flag; per-row wide flag      (HBM bound)
 //   k_msm_codes      one wave per row chunk; a lane walks ITS non-zero codes only (bit mask built up front), the next table point
 //                    is fetched while the current mixed addition runs; every lane leaves one Jacobian partial sum   (integer ALU)
-//   k_sum_groups     partial sums of a row, 4 at a time per thread, full lanes (no half-empty reduction tree in the hot kernel)
-//   k_scalar_mags + k_msm_windows   rows flagged wide: their windows >= 1 through F (or the bit-plane kernel on first use)
+//   k_reduce_rows16  the 64 lane sums of a row chunk: 16 lanes per row add strided, then a 4-level tree
+//   rows flagged wide: their windows >= 1 ride along as virtual rows of k_msm_codes (through F's windows, or -- no byte table -- through D with the window
+//   sums shifted by k_cl_whorner); the opening's full-width MSMs: msm_cl.cuh (k_bytes_acc / k_planes_acc + row-cooperative trees)
 // Mixed additions are written for register pressure: 11 calls of the one shared Fp product (g1_dev.cuh: fp_mul_r), at most six Fp
 // values live across a call, exceptional cases (P = +-Q, negligible for random generators) only flagged in the fast variant; the
 // host re-runs a flagged batch with the SAFE variant that handles them in place. No scratch memory in any of these kernels.
@@ -461,61 +462,8 @@ __device__ __forceinline__ void k_reduce_rows16(g1j_t *out, const g1j_t *in, uin
 }
 
 // ------------------------------------------------------------------------------------------------
-// generic kernel: one block = (row, column chunk, window); byte w of every scalar of the chunk through the full table
-// F[w][d][j] = d 2^(8w) g_j. grid (chunks * nwin, rows). The block's 64 lane sums are added by an LDS tree (this kernel serves the
-// few-row, latency-bound MSMs of the opening and the rare wide rows of a commitment). out[row * gridDim.x + blockIdx.x]
-// ------------------------------------------------------------------------------------------------
-template <bool SAFE>
-__device__ __forceinline__ void k_msm_windows(g1j_t *out, uint32_t *exc_flag, const fr_t *mag, uint64_t ld, const uint32_t *idx_base,
-                                                           const g1a_t *F, uint32_t m, uint32_t cols, uint32_t cpt, uint32_t w_lo, uint32_t nwin) {
-    __shared__ g1j_t sm[MSM_BLOCK];
-    const uint32_t row = blockIdx.y, lane = threadIdx.x;
-    const uint32_t w = w_lo + blockIdx.x % nwin, chunk = blockIdx.x / nwin;
-    const uint32_t *idx = idx_base ? idx_base + (size_t) row * ld : nullptr;
-    const g1a_t *Fw = F + (size_t) w * 256 * m;
-    fp_t X = fp_zero(), Y = fp_zero(), Z = fp_zero();
-    bool empty = true, exc = false;
-    for (uint32_t i = 0; i < cpt; ++i) {
-        const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + lane;
-        if (c >= cols) break;
-        const size_t si = (size_t) row * cols + c;              // magnitudes are dense rows of `cols`; index rows are `ld` apart
-        const uint32_t byte = mag_byte(mag, si, w);
-        if (!byte) continue;
-        const uint32_t j = idx ? idx[c] : c;
-        fp_t px, py;
-        g1a_load(px, py, Fw + (size_t) byte * m + j);
-        g1_accumulate<SAFE>(X, Y, Z, empty, px, py, mag_neg(mag, si), exc);
-    }
-    if (!SAFE && exc) *exc_flag = 1;
-    // blocks that selected no point at all (high windows of small scalars) skip the tree
-    if (!__syncthreads_or(!empty)) {
-        if (lane == 0) g1j_store(out + (size_t) row * gridDim.x + blockIdx.x, X, Y, Z, true);
-        return;
-    }
-    g1j_store(&sm[lane], X, Y, Z, empty);
-    __syncthreads();
-    for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
-        if (lane < s) sm[lane] = g1_add_any(sm[lane], sm[lane + s]);
-        __syncthreads();
-    }
-    if (lane == 0) out[(size_t) row * gridDim.x + blockIdx.x] = sm[0];
-}
-
-// out[row * gridDim.x + b] = sum of in[row * nin + 64 b .. 64 b + 63]  (one tree level of width 64 per launch)
-__device__ __forceinline__ void k_tree_reduce(g1j_t *out, const g1j_t *in, uint32_t nin) {
-    __shared__ g1j_t sm[MSM_BLOCK];
-    const uint32_t row = blockIdx.y, p = blockIdx.x * MSM_BLOCK + threadIdx.x;
-    sm[threadIdx.x] = p < nin ? in[(size_t) row * nin + p] : g1_inf();
-    __syncthreads();
-    for (uint32_t s = MSM_BLOCK / 2; s >= 1; s >>= 1) {
-        if (threadIdx.x < s) sm[threadIdx.x] = g1_add_any(sm[threadIdx.x], sm[threadIdx.x + s]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[(size_t) row * gridDim.x + blockIdx.x] = sm[0];
-}
-
-// ------------------------------------------------------------------------------------------------
-// first use of a generator set (no byte table yet): window tables T[w][j] = 2^(8w) g_j only. Digit d of window w contributes
+// Round 2-5's bit-plane kernel pair, kept for MSMs of a handful of terms (hyrax.hip: msm_windows, cols * windows <= 64); everything larger runs through
+// msm_cl.cuh. Window tables T[w][j] = 2^(8w) g_j only. Digit d of window w contributes
 // d T[w][j] = sum_k bit_k(d) 2^k T[w][j]: for each of the 8 bit planes one block sums the selected table points, and the row
 // result is sum_k 2^k S_k (k_msm_finish). One block = (row, bit plane, column chunk x window group).
 // out[(row * 8 + plane) * nparts + part]
