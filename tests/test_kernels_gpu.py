@@ -159,6 +159,34 @@ def test_commit_rows_digit_table_and_high_byte_rows(hip, oracle):
     assert not got[7].any()
 
 
+@pytest.mark.parametrize("wide_max", [1 << 20, 1 << 63, None])
+def test_commit_rows_more_wide_rows_than_the_virtual_row_list_holds(hip, oracle, wide_max):
+    """> 128 rows with scalars beyond one byte: the first 128 ride along as virtual rows of the hot kernel (window sums through the digit table, shifted by
+    k_cl_whorner), the rest take the separate pass over the window tables -- digit planes in non-adjacent form of the magnitude WITHOUT its low byte (that byte
+    went through the digit table; 0xff = 0x100 - 1 must not be recoded across the two paths), with room for the top digit one bit above the magnitude
+    (values below 2^64 reach bit 64). Low bytes of 0xff / 0x80 / 0x00 and values around 2^8, 2^16, 2^63, 2^64 in every row; first use of the generators
+    (no byte table) and second use (byte table)."""
+    rows, cols = 150, 128
+    rng = np.random.default_rng(17)
+    vals = np.zeros((rows, cols), dtype=object)
+    edge = [0xff, 0x100, 0x1ff, 0xff00, 0xffff, 0x10000, 0x80, 0x8000, (1 << 63) - 1, (1 << 64) - 1, 0x7fff_ffff_ffff_ff00]
+    for r in range(rows):
+        if wide_max is None:
+            row = [int.from_bytes(rng.bytes(31), "little") for _ in range(cols)]
+        else:
+            row = [int(x) for x in rng.integers(-wide_max, wide_max, cols, dtype=np.int64)]
+            row[:len(edge)] = [e if e < 2 * wide_max else e % wide_max for e in edge]
+            row[len(edge)] = -0xff
+            row[len(edge) + 1] = -0x100
+        vals[r, :] = row
+    sc = to_mont([int(v) % R_MOD for v in vals.reshape(-1)])
+    bases = oracle.generators(cols, 5151 + (0 if wide_max is None else wide_max % 97))
+    for use in range(2):
+        got = hip.commit_rows(sc, bases, rows, cols)
+        for r in (0, 1, 63, 127, 128, 129, 149):
+            assert np.array_equal(got[r], oracle.msm(sc[r * cols:(r + 1) * cols], bases)), f"use {use} row {r}"
+
+
 def test_commit_rows_byte_table_path(hip, oracle):
     """many rows over generators that are used again: every row through the full byte table (no bit planes, no high-byte pass)"""
     rows, cols = 80, 128

@@ -83,6 +83,33 @@ struct gen_tables {
     g1a_t *t8 = nullptr; bool t8_ready = false;
 };
 static std::mutex g_gen_mtx;
+// Window and digit tables of generator sets that have died, kept for the next set of the same size: in the reference's semantics EVERY proof brings a new set
+// (reference src/verifier.cpp:119-128), and hipFree / hipMalloc of its 113 MB per proof are device-wide synchronisations -- 48 proofs in flight stalled one
+// another's streams on them (round 6: profiles/r06_final_kernel_stats_s48.md). A buffer enters the pool only after its last user's stream has drained
+// (gen_release). The byte table of a reusable set (3.2 GB) is not pooled.
+struct pooled_table { int device; size_t bytes; void *p; };
+static std::mutex g_pool_mtx;
+static std::vector<pooled_table> g_table_pool;
+static hipError_t table_take(int device, size_t bytes, void **p) {
+    {
+        std::lock_guard<std::mutex> g(g_pool_mtx);
+        for (size_t i = 0; i < g_table_pool.size(); ++i)
+            if (g_table_pool[i].device == device && g_table_pool[i].bytes == bytes) {
+                *p = g_table_pool[i].p;
+                g_table_pool.erase(g_table_pool.begin() + i);
+                return hipSuccess;
+            }
+    }
+    return hipMalloc(p, bytes);
+}
+static void table_give(int device, size_t bytes, void *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_pool_mtx);
+        if (g_table_pool.size() < 256) { g_table_pool.push_back({device, bytes, p}); return; }
+    }
+    (void) hipFree(p);
+}
 // The lock of a generator set, taken by a context. A lane of a lock-step batch may be PARKED while it holds the lock (the tables of a fresh set are
 // built with deferred launches, so that the lanes' builds fuse), and the other lanes run on the same thread: whoever finds the lock taken hands
 // the thread on (zk_batch_sync_point) instead of blocking in it.
@@ -127,7 +154,9 @@ static void gen_release(zk_ctx *ctx, msm_state *s) {
     std::lock_guard<std::mutex> g(g_gen_mtx);
     if (--e->refs > 0) return;
     if (e->win_ev) { (void) hipEventSynchronize(e->win_ev); (void) hipEventDestroy(e->win_ev); }
-    for (void *p : {(void *) e->tables, (void *) e->digit, (void *) e->full, (void *) e->t8}) if (p) hipFree(p);
+    table_give(e->device, (size_t) MSM_WINDOWS * e->m * sizeof(g1a_t), e->tables);
+    table_give(e->device, (size_t) 256 * e->m * sizeof(g1a_t), e->digit);
+    for (void *p : {(void *) e->full, (void *) e->t8}) if (p) hipFree(p);
     g_gen_sets.erase(std::remove(g_gen_sets.begin(), g_gen_sets.end(), e), g_gen_sets.end());
     delete e;
 }
@@ -210,7 +239,7 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
     if (g.rc) return g.rc;
     ++e->uses;
     if (!e->tables) {
-        ZK_HIP(hipMalloc((void **) &e->tables, (size_t) MSM_WINDOWS * m * sizeof(g1a_t)));
+        ZK_HIP(table_take(e->device, (size_t) MSM_WINDOWS * m * sizeof(g1a_t), (void **) &e->tables));
         // (a failure below must not leave the entry looking built: every context that looks the set up adopts e->tables)
         // The windows w >= 1 (248 doublings per generator, one thread each: 7.5 ms for 4096 generators on 64 of the 1024 SIMDs) are read by the
         // OPENING's MSMs and by rows with wide scalars only; the commitment goes through the digit table of window 0. A context on its own builds
@@ -257,7 +286,7 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
             (void) zk_stream_sync(ctx);
             if (s->aux) (void) hipStreamSynchronize(s->aux);
             if (e->win_ev) { (void) hipEventDestroy(e->win_ev); e->win_ev = nullptr; }
-            (void) hipFree(e->tables); e->tables = nullptr;
+            table_give(e->device, (size_t) MSM_WINDOWS * e->m * sizeof(g1a_t), e->tables); e->tables = nullptr;
             return rc;
         }
         ++g_gen_builds;
@@ -351,10 +380,10 @@ static int32_t ensure_digit_table(zk_ctx *ctx) {
     if (g.rc) return g.rc;
     if (!e->digit_ready) {
         const uint32_t m = (uint32_t) e->m;
-        ZK_HIP(hipMalloc((void **) &e->digit, (size_t) 256 * m * sizeof(g1a_t)));
+        ZK_HIP(table_take(e->device, (size_t) 256 * m * sizeof(g1a_t), (void **) &e->digit));
         int32_t rc = build_digit_table(ctx, e->digit, e->tables, m);
         if (!rc && zk_stream_sync(ctx) != hipSuccess) { ctx->err = "digit table: stream synchronisation failed"; rc = ZK_ERR_HIP; }
-        if (rc) { (void) hipFree(e->digit); e->digit = nullptr; return rc; }     // (not built: nobody may adopt it, and the next attempt allocates again)
+        if (rc) { table_give(e->device, (size_t) 256 * m * sizeof(g1a_t), e->digit); e->digit = nullptr; return rc; }     // (not built: nobody may adopt it, and the next attempt allocates again)
         e->digit_ready = true;
     }
     gen_adopt(s);
@@ -454,7 +483,8 @@ static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32
     // equal share of its wave's selected (generator, window) pairs; the lanes' partial sums are added by row-cooperative trees of 64 and the eight plane
     // sums of a row by k_cl_horner. 2 x 2048 generators with full-width scalars (a round of the opening): 0.52 ms, round 5's k_msm_planes + k_msm_finish 1.67 ms.
     if ((rc = wait_windows(ctx))) return rc;
-    const uint32_t w_hi = low_windows_only ? MSM_LOW_WINDOWS + 1u : (uint32_t) MSM_WINDOWS, nw = w_hi - w_lo;
+    // (scalars below 2^64 reach windows 0..7; the top digit of their non-adjacent form may sit at bit 64: window 8)
+    const uint32_t w_hi = low_windows_only ? MSM_LOW_WINDOWS + 2u : (uint32_t) MSM_WINDOWS, nw = w_hi - w_lo;
     if ((uint64_t) cols * nw <= 64) {
         // a handful of pairs per row (the blinding term of a zero-knowledge commitment: one column): one block per (row, plane), a one-lane tree inside it
         const uint32_t cpt = 1, chunks = (cols + MSM_BLOCK - 1) / MSM_BLOCK;

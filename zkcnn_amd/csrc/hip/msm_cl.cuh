@@ -27,10 +27,20 @@
 // The magnitude at `p` in NON-ADJACENT FORM (digits -1 / 0 / +1, no two neighbours non-zero: a third of the positions instead of half of the bits, so a
 // third fewer additions): with h = x >> 1 and t = x + h, the positive digits are t & (h ^ t) and the negative ones h & (h ^ t). Returns the windows of
 // `wmask` whose byte has a digit at bit `plane`; *negw = those whose digit is -1. (|x| < 2^254, so t < 2^255: bit 255 stays free for the sign flag.)
-__device__ __forceinline__ uint32_t acc_select(const fr_t *p, uint32_t plane, uint32_t wmask, uint32_t *negw) {
+// Bytes below window w_lo are somebody else's (a commitment's wide rows: window 0 went through the digit table as a plain byte) and are cleared BEFORE the
+// recoding -- the non-adjacent form of x is not the form of its low byte followed by the form of the rest (0xff = 0x100 - 1). A magnitude below 2^k may have its
+// top digit at bit k: callers that bound the windows leave room for it.
+__device__ __forceinline__ uint32_t acc_select(const fr_t *p, uint32_t plane, uint32_t wmask, uint32_t w_lo, uint32_t *negw) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
     const uint4 lo = q[0], hi = q[1];
-    const uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w & 0x7fffffffu};
+    uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w & 0x7fffffffu};
+    if (w_lo) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t first = 4u * (uint32_t) k;              // the limb holds windows first .. first + 3
+            x[k] = w_lo >= first + 4 ? 0u : (w_lo > first ? x[k] & (0xffffffffu << (8u * (w_lo - first))) : x[k]);
+        }
+    }
     uint32_t s = 0, n = 0;
     unsigned c = 0;
 #pragma unroll
@@ -58,7 +68,7 @@ __device__ __forceinline__ void k_planes_acc(g1j_t *out, const fr_t *mag, uint64
     uint32_t count = 0, negw;
     for (uint32_t i = 0; i < cpt; ++i) {
         const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + lane;
-        if (c < cols) count += (uint32_t) __popc(acc_select(mrow + c, plane, wmask, &negw));
+        if (c < cols) count += (uint32_t) __popc(acc_select(mrow + c, plane, wmask, w_lo, &negw));
     }
     // exclusive prefix of the lanes' counts
     uint32_t incl = count;
@@ -72,7 +82,7 @@ __device__ __forceinline__ void k_planes_acc(g1j_t *out, const fr_t *mag, uint64
     for (uint32_t i = 0; i < cpt; ++i) {
         const uint32_t c = chunk * (MSM_BLOCK * cpt) + i * MSM_BLOCK + lane;
         if (c >= cols) continue;
-        uint32_t s = acc_select(mrow + c, plane, wmask, &negw);
+        uint32_t s = acc_select(mrow + c, plane, wmask, w_lo, &negw);
         if (!s) continue;
         const uint32_t tag = idx ? idx[c] : c;
         if (mag_neg(mag, (size_t) row * cols + c)) negw = ~negw;
