@@ -295,7 +295,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="vgg11", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=None, help="proofs in flight per GPU (default: 7 x --lanes, i.e. 7 lock-step batches: 166 GB of the 288 GB of HBM for vgg11; 4 / 6 / 7 batches measured 147.6 / 148.3 / 151 proofs/s; with --lanes 1: 8)")
+    ap.add_argument("--streams", type=int, default=None, help="proofs in flight per GPU (default: 8 x --lanes, i.e. 8 lock-step batches, two per hardware queue; with --lanes 1: 8)")
     ap.add_argument("--lanes", type=int, default=8, help="lanes of a lock-step batch: that many proofs share ONE host thread, ONE HIP stream and ONE kernel launch per round "
                                                           "(zkcnn_batch_*); --streams / --lanes batches per GPU. 1 = every proof its own thread and stream (the round-3 shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -355,7 +355,10 @@ def main():
 
     model, pic, pp = WORKLOADS[args.workload]
     LANES = max(1, min(args.lanes, 8))
-    K = max(1, args.streams if args.streams else (6 * LANES if LANES > 1 else 8))      # round 5: 6 batches of 8 (4 / 5 / 6 / 7 / 8 batches: 147 / 155 / 161-163 / 154-157, sometimes 165 / 155.5 proofs/s on one box)
+    # round 6: 8 batches of 8 -- two per hardware queue, evenly, since all batch streams are created back to back (BatchSession.group): every batch then proves at the same
+    # pace (profiles/r06_variance.md, r06_queues_grouped.txt: 4 / 6 / 8 batches 162.6 / 165.7 / 172.4 proofs/s over public generators, 84.6 / 98.0 / 101.8 in the reference's
+    # semantics). Round 5: 6 batches (made one by one they landed 2 + 2 + 1 + 1 on the four queues: 4 / 5 / 6 / 7 / 8 batches 147 / 155 / 161-163 / 154-157).
+    K = max(1, args.streams if args.streams else (8 * LANES if LANES > 1 else 8))
     try:                                # do not overcommit a small node
         import psutil
         K_ram = streams_that_fit(psutil.virtual_memory().available, world, K, clones=LANES > 1)
@@ -623,7 +626,9 @@ def main():
     # ---- lock-step batches: LANES sessions share one host thread, one stream and one launch per round (zkcnn_amd.BatchSession) ----
     batches, batch_table = [], None
     if LANES > 1:
-        batches = [zkcnn_amd.BatchSession(sessions[j * LANES:(j + 1) * LANES]) for j in range(B)]
+        # (all batch streams first, then the lanes: an even spread over the hardware queues -- profiles/r06_variance.md)
+        batches = (zkcnn_amd.BatchSession.group([sessions[j * LANES:(j + 1) * LANES] for j in range(B)]) if not os.environ.get("ZKCNN_BENCH_BATCHES_ONE_BY_ONE")
+                   else [zkcnn_amd.BatchSession(sessions[j * LANES:(j + 1) * LANES]) for j in range(B)])
 
         def warm_batch(j):
             batches[j].prove(seeds=[proof_seed(0x5EED0A00, j * LANES + i, 0) if REF else 0x5EED0A00 + i for i in range(LANES)], mode=drive, want_transcript=False)

@@ -122,6 +122,10 @@ int64_t zkcnn_session_synthetic_picture(void *session, uint64_t picture_seed, do
  * the K proofs is ONE kernel launch (include/zkcnn_hip.h: zk_batch_*). The sessions stay owned by the caller, must outlive the batch and must
  * not be proved individually from other threads while it exists. n <= 8. NULL on error (a session on another device or circuit). */
 void *zkcnn_batch_create(void *const *sessions, int32_t n);
+/* n_batches batches at once -- sessions[0 .. counts[0]) the lanes of the first, the next counts[1] of the second, ... -- with every batch's stream created
+ * before any lane is attached, so that the streams spread evenly over the hardware queues (streams that share one run their kernels one after the other:
+ * the step time of B batches is the most loaded queue's). out[j] = the handles (zkcnn_batch_prove / _stats / _destroy as for zkcnn_batch_create). 0 = ok. */
+int32_t zkcnn_batch_create_group(void *const *sessions, const int32_t *counts, int32_t n_batches, void **out);
 /* One proof per lane: seeds[k], transcripts[k] (may be NULL) / caps[k], out[k] as in zkcnn_session_prove; `mode` is shared. Each lane's
  * transcript is byte for byte what zkcnn_session_prove(sessions[k], seeds[k], mode) returns. The per-lane timers in out[k] (prove_s ...)
  * include the time the thread spent in other lanes; *wall_s (may be NULL) is the wall clock of the whole batch. */

@@ -503,16 +503,33 @@ class BatchSession:
     differ by picture_seed or new_image), i.e. one resident circuit; they stay usable for new_image between batch proofs and are closed
     by their owner AFTER the batch."""
 
-    def __init__(self, sessions):
+    def __init__(self, sessions, _handle=None):
         self.lib = host_lib()
         self.sessions = list(sessions)
-        arr = (ctypes.c_void_p * len(self.sessions))(*[s.h for s in self.sessions])
-        self.lib.zkcnn_batch_create.restype = ctypes.c_void_p
-        self.h = self.lib.zkcnn_batch_create(arr, ctypes.c_int32(len(self.sessions)))
-        if not self.h:
-            raise RuntimeError("zkcnn_batch_create failed (sessions of one model on one device, at most 8)")
+        if _handle is None:
+            arr = (ctypes.c_void_p * len(self.sessions))(*[s.h for s in self.sessions])
+            self.lib.zkcnn_batch_create.restype = ctypes.c_void_p
+            _handle = self.lib.zkcnn_batch_create(arr, ctypes.c_int32(len(self.sessions)))
+            if not _handle:
+                raise RuntimeError("zkcnn_batch_create failed (sessions of one model on one device, at most 8)")
+        self.h = _handle
         self._bufs = None
         self.wall_s = 0.0
+
+    @classmethod
+    def group(cls, session_lists):
+        """several batches at once (zkcnn_batch_create_group): every batch's stream exists before any lane is attached, so the streams spread evenly over the
+        hardware queues -- batches that share a queue run their kernels one after the other, and the step time is the most loaded queue's"""
+        lib = host_lib()
+        lists = [list(x) for x in session_lists]
+        flat = [s.h for x in lists for s in x]
+        arr = (ctypes.c_void_p * len(flat))(*flat)
+        counts = (ctypes.c_int32 * len(lists))(*[len(x) for x in lists])
+        out = (ctypes.c_void_p * len(lists))()
+        rc = lib.zkcnn_batch_create_group(arr, counts, ctypes.c_int32(len(lists)), out)
+        if rc != 0:
+            raise RuntimeError(f"zkcnn_batch_create_group failed ({rc})")
+        return [cls(x, _handle=out[j]) for j, x in enumerate(lists)]
 
     def prove(self, seeds=None, mode=MODE_VERIFY, want_transcript=True):
         """one proof per lane; returns [(Result, transcript bytes)] in lane order. seeds: one integer per lane (reproducible, MODE_SEEDED)

@@ -180,6 +180,47 @@ void *zkcnn_batch_create(void *const *sessions, int32_t n) {
     }
 }
 
+// Several batches at once: every batch's STREAM is created before any lane is attached. HIP spreads streams over GPU_MAX_HW_QUEUES hardware queues as they
+// are created, and streams that share a hardware queue run their kernels one after the other: made one by one (a batch stream, then its lanes' own streams
+// destroyed, then the next batch stream ...), six batches landed 2 + 2 + 1 + 1 on four queues and eight batches 1 + 3 + 2 + 2 -- the step time is the most
+// loaded queue's (round 6: profiles/r06_variance.md; scripts/exp/stream_pipes.hip shows the effect in isolation). Created back to back they spread evenly.
+int32_t zkcnn_batch_create_group(void *const *sessions, const int32_t *counts, int32_t n_batches, void **out) {
+    if (!sessions || !counts || !out || n_batches < 1) return -1;
+    std::vector<std::unique_ptr<gpuBatch>> gs;
+    try {
+        int32_t at = 0;
+        for (int32_t j = 0; j < n_batches; ++j) {
+            if (counts[j] < 1 || counts[j] > ZK_BATCH_MAX_LANES) return -1;
+            gpuSession *s0 = (gpuSession *) sessions[at];
+            if (!s0 || !s0->p.context()) return -1;
+            gs.emplace_back(new gpuBatch());
+            if (zk_batch_create(s0->dev, &gs.back()->b) != ZK_OK) {
+                fprintf(stderr, "zkcnn_batch_create_group: %s\n", zk_batch_last_error(nullptr));
+                return -2;
+            }
+            at += counts[j];
+        }
+        at = 0;
+        for (int32_t j = 0; j < n_batches; ++j) {
+            for (int32_t k = 0; k < counts[j]; ++k, ++at) {
+                gpuSession *s = (gpuSession *) sessions[at];
+                if (!s || !s->p.context()) return -1;
+                if (zk_batch_attach(gs[j]->b, s->p.context(), nullptr) != ZK_OK) {
+                    fprintf(stderr, "zkcnn_batch_create_group: batch %d lane %d: %s\n", (int) j, (int) k, zk_batch_last_error(gs[j]->b));
+                    return -2;
+                }
+                gs[j]->lanes.push_back(s);
+            }
+            zk_batch_set_yield(gs[j]->b, &gpuBatch::yieldLane, nullptr);
+        }
+        for (int32_t j = 0; j < n_batches; ++j) out[j] = gs[j].release();
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "zkcnn_batch_create_group: %s\n", e.what());
+        return -2;
+    }
+}
+
 // The zero-knowledge mode adds the masks' share of a phase's LAST round polynomial on the host, from the phase's last table pairs, so it needs a host tail
 // and fixes the hand-over point itself (tables of <= 32 entries finish their phase on the host: prover::zkModeOn). ZKCNN_MODE_HOST_TAIL next to it is
 // harmless (a host tail either way; the zero-knowledge mode's size applies); ZKCNN_MODE_GPU_TAIL -- "every round of every phase is a kernel" -- cannot
