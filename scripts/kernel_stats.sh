@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # S = proofs in flight: 1 = a lone proof (resident round kernels), 48 = six lock-step batches of eight lanes (the default bench shape)
-for S in ${SHAPES:-1 48}; do
+for S in ${SHAPES:-1 64}; do
   LANES=8; [ $S = 1 ] && LANES=1
   case $S in *:*) LANES=${S#*:}; S=${S%:*};; esac
   D=$OUT/${TAG}_s$S
