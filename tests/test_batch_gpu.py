@@ -186,6 +186,46 @@ def test_two_batches_side_by_side(built):
             s.close()
 
 
+def test_batches_created_as_a_group_in_the_reference_semantics(built):
+    """BatchSession.group (zkcnn_batch_create_group): every batch's stream exists before any lane is attached -- the shape bench.py times since round 6 -- and the
+    proofs run in the reference's semantics (a generator set of its own per proof, drawn from the proof's seed; inner-product argument down to length 1): every
+    lane's transcript is the oracle's, proof after proof (the second proof of a lane re-uses the pooled table buffers of the first one's dead generator set)."""
+    import threading
+    model, pic, pp = QUARTER_VGG11, (32, 32, 3), 1
+    FULL = M.MODE_FULL_IPA
+    ss, pics, stmt = _lanes(model, pic, pp, 4)
+    try:
+        seeds = [[41, 42, 43, 44], [51, 52, 53, 54]]
+        want = [[_oracle(model, pic, pp, stmt, pics[i], sd[i], FULL | DRIVE)[1] for i in range(4)] for sd in seeds]
+        A, B = M.BatchSession.group([ss[:2], ss[2:]])
+        try:
+            got, errs = {}, []
+
+            def run(name, batch, lo):
+                try:
+                    got[name] = [batch.prove(seeds=sd[lo:lo + 2], mode=FULL | DRIVE) for sd in seeds]
+                except BaseException as e:      # noqa: BLE001
+                    errs.append(e)
+            th = [threading.Thread(target=run, args=("a", A, 0)), threading.Thread(target=run, args=("b", B, 2))]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert not errs, errs
+            for step in range(2):
+                assert [t for _, t in got["a"][step]] == want[step][:2] and [t for _, t in got["b"][step]] == want[step][2:]
+            full = A.prove(seeds=[61, 62], mode=FULL)            # ... and with the verifier's checks on
+            assert [r.accepted for r, _ in full] == [1, 1]
+        finally:
+            A.close()
+            B.close()
+        with pytest.raises(RuntimeError):
+            M.BatchSession.group([[ss[0]], [ss[0]]])             # a session cannot be a lane of two batches
+        res, _ = ss[0].prove(seed=1, mode=REUSE)                 # (nothing is left attached by the failed attempt)
+        assert res.accepted == 1
+    finally:
+        for s in ss:
+            s.close()
+
+
 def test_attach_refuses_other_circuits(built):
     a = M.Session("custom:F8 F4", (4, 4, 1), 1)
     b = M.Session("custom:F8 F5", (4, 4, 1), 1)
