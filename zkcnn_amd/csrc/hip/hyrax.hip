@@ -78,6 +78,7 @@ struct gen_tables {
     std::atomic<const void *> owner{nullptr};   // the context that is building a table of the set (set_lock); no thread owns anything: lanes of a batch share one
     g1a_t *tables = nullptr;           // window tables T[w][j] = 2^(8w) g_j
     hipEvent_t win_ev = nullptr;       // set: the windows above MSM_LOW_WINDOWS are (being) written on another stream -- whoever reads them makes its stream wait (wait_windows)
+    bool windows_built = false;        // T[w >= 1] exist (or are being written: win_ev). A set that starts its life among several proofs in flight builds them when somebody asks (wait_windows)
     g1a_t *digit = nullptr; bool digit_ready = false;
     g1a_t *full = nullptr; bool full_ready = false, full_failed = false;
     g1a_t *t8 = nullptr; bool t8_ready = false;
@@ -119,6 +120,7 @@ struct set_lock {
     // (round-4 advisor finding: this used to spin on std::mutex::try_lock, which a lane may call on the very thread whose parked lane holds the mutex --
     // undefined behaviour. The lock is an owner word now: compare-and-swap by CONTEXT, released by whoever holds it, from any thread.)
     set_lock(zk_ctx *ctx, gen_tables *entry) : e(entry) {
+        if (e->owner.load(std::memory_order_relaxed) == (const void *) ctx) { e = nullptr; return; }      // held by this context further up the stack: theirs to release
         for (;;) {
             const void *none = nullptr;
             if (e->owner.compare_exchange_weak(none, (const void *) ctx, std::memory_order_acquire, std::memory_order_relaxed)) return;
@@ -206,7 +208,55 @@ static int32_t ensure_state(zk_ctx *ctx) {
     return ZK_OK;
 }
 
-// window tables for `m` affine generators (host pointer, C-ABI layout): looked up in / added to the registry of generator sets
+// The windows T[w][j] = 2^(8w) g_j, w >= 1, of the set `e` (window 0 = the generators is in place): 248 doublings per generator, one thread each -- 7.5 ms for
+// 4096 generators on 64 of the 1024 SIMDs. They are read by the OPENING's bit-plane MSMs (a proof on its own), by the byte table's construction and by
+// the odd fallback path; the commitment goes through the digit table of window 0. `beside`: on the context's second stream, next to its sumcheck phases --
+// readers order themselves behind the set's event (wait_windows). Otherwise in order on the context's stream (a lane's launches are deferred and fused with
+// the other lanes' builds; the class table of a profiled run stays whole). The caller holds the set's lock.
+static int32_t build_windows(zk_ctx *ctx, gen_tables *e, bool beside) {
+    msm_state *s = ctx->msm;
+    const uint64_t m = e->m;
+    const size_t need = (size_t) (MSM_WINDOWS - 1) * m * (sizeof(g1j_t) + sizeof(fp_t));
+    if (beside) {
+        if (!s->aux) { ZK_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking)); ZK_HIP(hipEventCreateWithFlags(&s->aux_ev, hipEventDisableTiming)); }
+        if (s->win_scratch_cap < need) {
+            ZK_HIP(hipStreamSynchronize(s->aux));
+            if (s->win_scratch) { ZK_HIP(hipFree(s->win_scratch)); s->win_scratch = nullptr; s->win_scratch_cap = 0; }
+            ZK_HIP(hipMalloc(&s->win_scratch, need));
+            s->win_scratch_cap = need;
+        }
+        g1j_t *J = (g1j_t *) s->win_scratch;
+        fp_t *pre = (fp_t *) (J + (size_t) (MSM_WINDOWS - 1) * m);
+        ZK_HIP(hipEventCreateWithFlags(&e->win_ev, hipEventDisableTiming));
+        ZK_HIP(hipEventRecord(s->aux_ev, ctx->stream));
+        ZK_HIP(hipStreamWaitEvent(s->aux, s->aux_ev, 0));
+        call_f<k_window_tables, g1a_t *, g1j_t *, fp_t *, uint32_t, uint32_t, uint32_t> f;
+        f.args = make_pack<g1a_t *, g1j_t *, fp_t *, uint32_t, uint32_t, uint32_t>(e->tables, J, pre, (uint32_t) m, 1u, (uint32_t) MSM_WINDOWS);
+        hipLaunchKernelGGL((k_run<decltype(f), 64>), dim3((uint32_t) ((m + 63) / 64)), dim3(64), 0, s->aux, f);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipEventRecord(e->win_ev, s->aux));
+        e->windows_built = true;
+        return ZK_OK;
+    }
+    int32_t rc = regrow(ctx, &s->tbl_scratch, &s->tbl_scratch_cap, need);
+    if (rc) return rc;
+    g1j_t *J = (g1j_t *) s->tbl_scratch;
+    fp_t *pre = (fp_t *) (J + (size_t) (MSM_WINDOWS - 1) * m);
+    zk_launch_d<k_window_tables, 64>(ctx, PC_MSM_TABLES, 0.0, dim3((uint32_t) ((m + 63) / 64)), e->tables, J, pre, (uint32_t) m, 1u, (uint32_t) MSM_WINDOWS);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(zk_stream_sync(ctx));      // other contexts read the tables from their own streams
+    e->windows_built = true;
+    return ZK_OK;
+}
+
+// With several proofs in flight the opening of a FRESH generator set sums its windows through the digit table (msm_windows: k_bytes_acc by window +
+// k_cl_whorner32) and the set never gets window tables (experiment switch ZKCNN_DIGIT_OPENING=0: round 6's first design, window tables for every set).
+static bool digit_opening() {
+    static const bool v = [] { const char *e = getenv("ZKCNN_DIGIT_OPENING"); return !e || atoi(e) != 0; }();
+    return v;
+}
+
+// tables for `m` affine generators (host pointer, C-ABI layout): looked up in / added to the registry of generator sets
 static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
     msm_state *s = ctx->msm;
     ZK_ORDER();                        // nothing of this lane may be deferred while a table is built under the set's lock (the other lanes run on this thread)
@@ -241,44 +291,16 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
     if (!e->tables) {
         ZK_HIP(table_take(e->device, (size_t) MSM_WINDOWS * m * sizeof(g1a_t), (void **) &e->tables));
         // (a failure below must not leave the entry looking built: every context that looks the set up adopts e->tables)
-        // The windows w >= 1 (248 doublings per generator, one thread each: 7.5 ms for 4096 generators on 64 of the 1024 SIMDs) are read by the
-        // OPENING's MSMs and by rows with wide scalars only; the commitment goes through the digit table of window 0. A context on its own builds
-        // them on a second stream, beside its sumcheck phases; readers order themselves behind the set's event (wait_windows). Lanes of a batch
-        // and profiled runs build in order (a lane's launches are deferred and fused with the other lanes' builds; the class table stays whole).
-        const bool beside = !ctx->batch && !((ctx->prof_mask >> PC_MSM_TABLES) & 1u);
         auto build = [&]() -> int32_t {
             ZK_STREAM(hipMemcpyAsync(e->tables, gens, m * sizeof(g1a_t), hipMemcpyHostToDevice, ctx->stream));
-            const size_t need = (size_t) (MSM_WINDOWS - 1) * m * (sizeof(g1j_t) + sizeof(fp_t));
-            if (beside) {
-                if (!s->aux) { ZK_HIP(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking)); ZK_HIP(hipEventCreateWithFlags(&s->aux_ev, hipEventDisableTiming)); }
-                if (s->win_scratch_cap < need) {
-                    ZK_HIP(hipStreamSynchronize(s->aux));
-                    if (s->win_scratch) { ZK_HIP(hipFree(s->win_scratch)); s->win_scratch = nullptr; s->win_scratch_cap = 0; }
-                    ZK_HIP(hipMalloc(&s->win_scratch, need));
-                    s->win_scratch_cap = need;
-                }
-                // every window above 0 beside the proof: the commitment goes through the digit table of window 0 (rows with wide scalars too: k_cl_whorner),
-                // the first reader is the opening -- a sumcheck later (round 5 built windows 1..7 in order, 1.5 ms, for the wide rows' bit planes)
-                g1j_t *J = (g1j_t *) s->win_scratch;
-                fp_t *pre = (fp_t *) (J + (size_t) (MSM_WINDOWS - 1) * m);
-                ZK_HIP(hipEventCreateWithFlags(&e->win_ev, hipEventDisableTiming));
-                ZK_HIP(hipEventRecord(s->aux_ev, ctx->stream));
-                ZK_HIP(hipStreamWaitEvent(s->aux, s->aux_ev, 0));
-                call_f<k_window_tables, g1a_t *, g1j_t *, fp_t *, uint32_t, uint32_t, uint32_t> f;
-                f.args = make_pack<g1a_t *, g1j_t *, fp_t *, uint32_t, uint32_t, uint32_t>(e->tables, J, pre, (uint32_t) m, 1u, (uint32_t) MSM_WINDOWS);
-                hipLaunchKernelGGL((k_run<decltype(f), 64>), dim3((uint32_t) ((m + 63) / 64)), dim3(64), 0, s->aux, f);
-                ZK_HIP(hipGetLastError());
-                ZK_HIP(hipEventRecord(e->win_ev, s->aux));
-                ZK_HIP(zk_stream_sync(ctx));      // (window 0: `gens` is the caller's buffer; other contexts read it from their own streams)
-                return ZK_OK;
-            }
-            int32_t rc = regrow(ctx, &s->tbl_scratch, &s->tbl_scratch_cap, need);
+            // a proof on its own: every window above 0 beside its sumcheck (the first reader is the opening); a profiled run: in order; a proof among others:
+            // not at all until somebody asks (wait_windows)
+            const bool profiled = (ctx->prof_mask >> PC_MSM_TABLES) & 1u;
+            int32_t rc = ZK_OK;
+            if (!ctx->batch && !profiled && (ctx->live_now || !digit_opening())) rc = build_windows(ctx, e, true);
+            else if (!digit_opening()) return build_windows(ctx, e, false);
             if (rc) return rc;
-            g1j_t *J = (g1j_t *) s->tbl_scratch;
-            fp_t *pre = (fp_t *) (J + (size_t) (MSM_WINDOWS - 1) * m);
-            zk_launch_d<k_window_tables, 64>(ctx, PC_MSM_TABLES, 0.0, dim3((uint32_t) ((m + 63) / 64)), e->tables, J, pre, (uint32_t) m, 1u, (uint32_t) MSM_WINDOWS);
-            ZK_HIP(hipGetLastError());
-            ZK_HIP(zk_stream_sync(ctx));      // other contexts read the tables from their own streams
+            ZK_HIP(zk_stream_sync(ctx));      // (window 0: `gens` is the caller's buffer; other contexts read it from their own streams)
             return ZK_OK;
         };
         const int32_t rc = build();
@@ -287,6 +309,7 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
             if (s->aux) (void) hipStreamSynchronize(s->aux);
             if (e->win_ev) { (void) hipEventDestroy(e->win_ev); e->win_ev = nullptr; }
             table_give(e->device, (size_t) MSM_WINDOWS * e->m * sizeof(g1a_t), e->tables); e->tables = nullptr;
+            e->windows_built = false;
             return rc;
         }
         ++g_gen_builds;
@@ -295,10 +318,17 @@ static int32_t ensure_tables(zk_ctx *ctx, const uint64_t *gens, uint64_t m) {
     return ZK_OK;
 }
 
-// before this context's stream reads a window above MSM_LOW_WINDOWS of its generator set
+// before this context's stream reads a window w >= 1 of its generator set: builds them if nobody has, waits for whoever is writing them
 static int32_t wait_windows(zk_ctx *ctx) {
     gen_tables *e = ctx->msm->gt;
-    if (e && e->win_ev) ZK_STREAM(hipStreamWaitEvent(ctx->stream, e->win_ev, 0));
+    if (!e) return ZK_OK;
+    if (!e->windows_built) {
+        ZK_ORDER();
+        set_lock g(ctx, e);
+        if (g.rc) return g.rc;
+        if (!e->windows_built) { int32_t rc = build_windows(ctx, e, false); if (rc) return rc; }
+    }
+    if (e->win_ev) ZK_STREAM(hipStreamWaitEvent(ctx->stream, e->win_ev, 0));
     return ZK_OK;
 }
 
@@ -425,6 +455,12 @@ static uint32_t busy_pairs() {
     return v;
 }
 
+// columns per lane of the opening's digit-table route (experiment switch ZKCNN_DIGIT_PAIRS)
+static uint32_t digit_pairs() {
+    static const uint32_t v = [] { const char *e = getenv("ZKCNN_DIGIT_PAIRS"); return e ? (uint32_t) std::max(1, atoi(e)) : 8u; }();
+    return v;
+}
+
 // rows independent MSMs over the cached generator tables, every window >= w_lo of every scalar; scalars are read from s->mag
 // (scalar_mags ran before). idx (optional): generator index of every column, rows `ld` apart. Results (Jacobian) in `outJ` or s->rowsJ.
 static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32_t rows, uint32_t cols, uint32_t w_lo, g1j_t *outJ, bool low_windows_only = false) {
@@ -470,11 +506,38 @@ static int32_t msm_windows(zk_ctx *ctx, const uint32_t *idx, uint64_t ld, uint32
             g1j_t *part = s->partials + (size_t) r0 * nparts;
             if (s->safe)
                 zk_launch_d<k_bytes_acc<true>, MSM_BLOCK>(ctx, PC_MSM_PLANES, bytes, dim3(gx, nr), part, s->exc, (const fr_t *) (s->mag + (size_t) r0 * cols),
-                          ld, idx ? idx + (size_t) r0 * ld : (const uint32_t *) nullptr, (const g1a_t *) s->full, (uint32_t) s->m, cols, cpt, wsplit, w_lo, (uint32_t) MSM_WINDOWS);
+                          ld, idx ? idx + (size_t) r0 * ld : (const uint32_t *) nullptr, (const g1a_t *) s->full, (uint32_t) s->m, cols, cpt, wsplit, w_lo, (uint32_t) MSM_WINDOWS, 256u * (uint32_t) s->m, 0u);
             else
                 zk_launch_d<k_bytes_acc<false>, MSM_BLOCK>(ctx, PC_MSM_PLANES, bytes, dim3(gx, nr), part, s->exc, (const fr_t *) (s->mag + (size_t) r0 * cols),
-                          ld, idx ? idx + (size_t) r0 * ld : (const uint32_t *) nullptr, (const g1a_t *) s->full, (uint32_t) s->m, cols, cpt, wsplit, w_lo, (uint32_t) MSM_WINDOWS);
+                          ld, idx ? idx + (size_t) r0 * ld : (const uint32_t *) nullptr, (const g1a_t *) s->full, (uint32_t) s->m, cols, cpt, wsplit, w_lo, (uint32_t) MSM_WINDOWS, 256u * (uint32_t) s->m, 0u);
             trees(part, s->parts2 + (size_t) r0 * n2, nparts, nr, dst + r0);
+        }
+        ZK_HIP(hipGetLastError());
+        return ZK_OK;
+    }
+    if (s->digit_ready && s->digit_m == s->m && !ctx->live_now && w_lo == 0 && !low_windows_only && digit_opening()) {
+        // no byte table (a fresh generator set: the reference's semantics) and other proofs in flight: V_w = sum_j byte_w(s_j) g_j of every window through the
+        // DIGIT table the commitment built -- one mixed addition per non-zero byte, a third of the bit planes' additions and no window tables 2^(8w) g_j at all
+        // (their 248 doublings per generator were 6.9 of a batch proof's ~80 GPU-ms) -- then row = sum_w 2^(8w) V_w by doublings (k_cl_whorner32: a 0.7 ms chain
+        // per round of the opening, which the other proofs' work hides; a proof on its own takes the planes below)
+        const uint32_t per_lane = std::min<uint32_t>(digit_pairs(), ACC_MAX_PAIRS);
+        const uint32_t cpt = std::max<uint32_t>(1, std::min<uint32_t>(per_lane, (cols + MSM_BLOCK - 1) / MSM_BLOCK)), chunks = (cols + MSM_BLOCK * cpt - 1) / (MSM_BLOCK * cpt);
+        const uint32_t nparts = chunks * MSM_BLOCK, n2 = (nparts + 63) / 64, segs_per_row = MSM_WINDOWS;
+        if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows * segs_per_row * nparts * sizeof(g1j_t)))) return rc;
+        if ((rc = regrow(ctx, (void **) &s->parts2, &s->parts2_cap, (size_t) rows * segs_per_row * (n2 + 1) * sizeof(g1j_t)))) return rc;
+        for (uint32_t r0 = 0; r0 < rows; r0 += 2047) {       // (window, row) share the trees' gridDim.y, which is limited to 65535
+            const uint32_t nr = std::min<uint32_t>(2047, rows - r0);
+            const double bytes = 32.0 * (double) nr * (double) cols;
+            g1j_t *part = s->partials + (size_t) r0 * segs_per_row * nparts, *part2 = s->parts2 + (size_t) r0 * segs_per_row * (n2 + 1);
+            if (s->safe)
+                zk_launch_d<k_bytes_acc<true>, MSM_BLOCK>(ctx, PC_MSM_PLANES, bytes, dim3(chunks * MSM_WINDOWS, nr), part, s->exc, (const fr_t *) (s->mag + (size_t) r0 * cols),
+                          ld, idx ? idx + (size_t) r0 * ld : (const uint32_t *) nullptr, (const g1a_t *) s->digit, (uint32_t) s->m, cols, cpt, (uint32_t) MSM_WINDOWS, 0u, (uint32_t) MSM_WINDOWS, 0u, 1u);
+            else
+                zk_launch_d<k_bytes_acc<false>, MSM_BLOCK>(ctx, PC_MSM_PLANES, bytes, dim3(chunks * MSM_WINDOWS, nr), part, s->exc, (const fr_t *) (s->mag + (size_t) r0 * cols),
+                          ld, idx ? idx + (size_t) r0 * ld : (const uint32_t *) nullptr, (const g1a_t *) s->digit, (uint32_t) s->m, cols, cpt, (uint32_t) MSM_WINDOWS, 0u, (uint32_t) MSM_WINDOWS, 0u, 1u);
+            g1j_t *V = part2 + (size_t) segs_per_row * nr * n2;            // the window sums: [row][window], behind the trees' own intermediate results
+            trees(part, part2, nparts, segs_per_row * nr, V);
+            zk_launch_d<k_cl_whorner32, 512>(ctx, PC_MSM_FINISH, 0.0, dim3(nr), dst + r0, (const g1j_t *) V);
         }
         ZK_HIP(hipGetLastError());
         return ZK_OK;

@@ -108,6 +108,9 @@ __device__ __forceinline__ void k_planes_acc(g1j_t *out, const fr_t *mag, uint64
 // one mixed addition and there are no planes. grid (chunks * wsplit, rows), one wave per block; the wave's list holds (column, window) of every
 // non-zero byte, every lane takes an equal share. out[(row * gridDim.x + x) * 64 + lane]. The fast variant flags P = +-Q (the host repeats the batch
 // with SAFE = true, like k_msm_codes).
+// wstride = 256 m: the byte table. wstride = 0: the DIGIT table D[d][j] = d g_j stands in for every window (a fresh generator set whose commitment has
+// built it) -- with wsplit = w_hi - w_lo every block sums ONE window, V_w = sum_j byte_w(s_j) g_j, and `by_window` lays the partial sums of a (row, window)
+// side by side, out[((row * wsplit + wg) * chunks + chunk) * 64 + lane], for the trees; k_cl_whorner32 weighs the window sums.
 __device__ __forceinline__ uint32_t acc_nonzero_bytes(const fr_t *p, uint32_t wmask) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
     const uint4 lo = q[0], hi = q[1];
@@ -124,7 +127,7 @@ __device__ __forceinline__ uint32_t acc_nonzero_bytes(const fr_t *p, uint32_t wm
 }
 template <bool SAFE>
 __device__ __forceinline__ void k_bytes_acc(g1j_t *out, uint32_t *exc_flag, const fr_t *mag, uint64_t ld, const uint32_t *idx_base, const g1a_t *F, uint32_t m,
-                                            uint32_t cols, uint32_t cpt, uint32_t wsplit, uint32_t w_lo, uint32_t w_hi) {
+                                            uint32_t cols, uint32_t cpt, uint32_t wsplit, uint32_t w_lo, uint32_t w_hi, uint32_t wstride, uint32_t by_window) {
     __shared__ uint32_t list[64 * ACC_MAX_PAIRS];
     __shared__ fp_t park[MSM_BLOCK];
     const uint32_t row = blockIdx.y, lane = threadIdx.x;
@@ -164,11 +167,12 @@ __device__ __forceinline__ void k_bytes_acc(g1j_t *out, uint32_t *exc_flag, cons
         const uint32_t e = list[k], w = e & 31u, c = c0 + (e >> 5);
         const size_t si = (size_t) row * cols + c;
         fp_t px, py;
-        g1a_load(px, py, F + ((size_t) w * 256 + mag_byte(mag, si, w)) * m + (idx ? idx[c] : c));
+        g1a_load(px, py, F + (size_t) w * wstride + (size_t) mag_byte(mag, si, w) * m + (idx ? idx[c] : c));
         g1_accumulate_xyzz<SAFE>(X, park + lane, ZZ, ZZZ, empty, px, py, mag_neg(mag, si), exc);
     }
     if (!SAFE && exc) *exc_flag = 1;
-    g1j_store_xyzz(out + ((size_t) row * gridDim.x + blockIdx.x) * MSM_BLOCK + lane, X, park + lane, ZZ, ZZZ, empty);
+    const size_t slot = by_window ? ((size_t) row * wsplit + wg) * (gridDim.x / wsplit) + chunk : (size_t) row * gridDim.x + blockIdx.x;
+    g1j_store_xyzz(out + slot * MSM_BLOCK + lane, X, park + lane, ZZ, ZZZ, empty);
 }
 
 // sum over the 32 rows of a 512-thread block (valid in row 0): 5 levels through LDS, whole waves drop out as the tree narrows
@@ -245,6 +249,24 @@ __device__ __forceinline__ void k_cl_whorner(g1j_t *rows_pts, uint32_t rows, con
     }
     acc = cl_tree32(acc, sm, m);
     if (w == 0) g1c_store(rows_pts + row, acc);
+}
+
+// ---- k_cl_whorner32: out[row] = sum_w 2^(8w) V[row][w] for the 32 window sums of an MSM that went through the digit table (k_bytes_acc, by_window):
+// CL row w doubles its point 8 w times, the 32 rows are summed. The longest chain is 248 doublings (~0.7 ms): the price of NOT building the window tables
+// 2^(8w) g_j of a generator set that one proof uses (248 doublings for each of its generators) -- paid where throughput counts (several proofs in flight,
+// other work fills the GPU); a proof on its own takes the window tables, built beside its sumcheck.
+__device__ __forceinline__ void k_cl_whorner32(g1j_t *out, const g1j_t *V) {
+    __shared__ uint32_t sm[CL_ROWS][3][16];
+    const uint32_t w = threadIdx.x >> 4;
+    const uint32_t m = fpc_mod_limb();
+    g1c_t acc = g1c_load(V + (size_t) blockIdx.x * MSM_WINDOWS + w);
+    const bool live = !fpc_is_zero(acc.Z);
+    for (uint32_t d = 0; __any(live && d < 8 * w); ++d) {
+        const g1c_t dd = g1c_dbl(acc, m);
+        acc = g1c_select(d < 8 * w, dd, acc);
+    }
+    acc = cl_tree32(acc, sm, m);
+    if (w == 0) g1c_store(out + blockIdx.x, acc);
 }
 
 // ---- k_cl_blind_rows: rows[i] += k_i H for ONE affine point H and a scalar per row (the blinding terms of a zero-knowledge commitment over a generator
