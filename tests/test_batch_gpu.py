@@ -226,6 +226,32 @@ def test_batches_created_as_a_group_in_the_reference_semantics(built):
             s.close()
 
 
+@pytest.mark.parametrize("switches", [{"ZKCNN_DIGIT_OPENING": "0"}, {"ZKCNN_DIGIT_PAIRS": "1"}, {"ZKCNN_DIGIT_PAIRS": "32"}, {"ZKCNN_DIGIT_AFFINE_PER": "64"}])
+def test_opening_through_the_digit_table_and_through_window_tables_agree(built, monkeypatch, switches):
+    """Lanes of a batch open a fresh generator set through the digit table of its commitment (k_bytes_acc by window + k_cl_whorner32: no window tables); a proof on its
+    own builds window tables and sums digit planes. Both are the oracle's bytes -- with the route switched off, with one column and with 32 columns per lane (ragged and
+    single-chunk grids), with 64 digits per inversion in the digit table's conversion -- and the verifier's own multiplications (a set that never had a commitment:
+    window tables built on demand) accept."""
+    model, pic, pp = QUARTER_VGG11, (32, 32, 3), 1
+    FULL = M.MODE_FULL_IPA
+    ss, pics, stmt = _lanes(model, pic, pp, 2)
+    try:
+        want = [_oracle(model, pic, pp, stmt, pics[i], 71 + i, FULL | DRIVE)[1] for i in range(2)]
+        lone = [ss[i].prove(seed=71 + i, mode=FULL | DRIVE)[1] for i in range(2)]          # window tables beside the proof, digit planes
+        assert lone == want
+        for k, v in switches.items():
+            monkeypatch.setenv(k, v)
+        b = M.BatchSession(ss)
+        try:
+            assert [t for _, t in b.prove(seeds=[71, 72], mode=FULL | DRIVE)] == want
+            assert [r.accepted for r, _ in b.prove(seeds=[73, 74], mode=FULL)] == [1, 1]
+        finally:
+            b.close()
+    finally:
+        for s in ss:
+            s.close()
+
+
 def test_attach_refuses_other_circuits(built):
     a = M.Session("custom:F8 F4", (4, 4, 1), 1)
     b = M.Session("custom:F8 F5", (4, 4, 1), 1)

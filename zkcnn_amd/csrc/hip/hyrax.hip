@@ -252,8 +252,8 @@ static int32_t build_windows(zk_ctx *ctx, gen_tables *e, bool beside) {
 // With several proofs in flight the opening of a FRESH generator set sums its windows through the digit table (msm_windows: k_bytes_acc by window +
 // k_cl_whorner32) and the set never gets window tables (experiment switch ZKCNN_DIGIT_OPENING=0: round 6's first design, window tables for every set).
 static bool digit_opening() {
-    static const bool v = [] { const char *e = getenv("ZKCNN_DIGIT_OPENING"); return !e || atoi(e) != 0; }();
-    return v;
+    const char *e = getenv("ZKCNN_DIGIT_OPENING");      // (read per call: scripts/exp/ab_inprocess.py alternates it between steps of one process)
+    return !e || atoi(e) != 0;
 }
 
 // tables for `m` affine generators (host pointer, C-ABI layout): looked up in / added to the registry of generator sets
@@ -343,6 +343,15 @@ static int32_t ensure_rows(zk_ctx *ctx, uint32_t rows) {
     return ZK_OK;
 }
 
+// digits per inversion of the digit table's conversion to affine when several proofs share the GPU (k_digit_affine; experiment switch ZKCNN_DIGIT_AFFINE_PER).
+// 64 digits per inversion are 0.39 of the issue slots of 16 and did NOT show: steps of one process alternating 16 / 64 / 128 gave 93.8 / 89.3-91.4 / 90.5 proofs/s
+// (scripts/exp/ab_inprocess.py, step-to-step spread +-4 %) -- the chain (928 against 592 dependent products) costs what the slots save. 16 stays.
+static uint32_t digit_affine_per() {
+    const char *e = getenv("ZKCNN_DIGIT_AFFINE_PER");
+    const uint32_t x = e ? (uint32_t) atoi(e) : 16u;
+    return x == 16 || x == 32 || x == 64 || x == 128 || x == 256 ? x : 16u;
+}
+
 // d * base_j for d = 1..255 of `m` affine points (levels of doubling / adding, then a batched conversion to affine)
 static int32_t build_digit_table(zk_ctx *ctx, g1a_t *dst, const g1a_t *base, uint32_t m) {
     msm_state *s = ctx->msm;
@@ -354,7 +363,8 @@ static int32_t build_digit_table(zk_ctx *ctx, g1a_t *dst, const g1a_t *base, uin
         const uint32_t work = (1u << level) * m;
         zk_launch_d<k_digit_level, 64>(ctx, PC_MSM_TABLES, 0.0, dim3((work + 63) / 64), J, base, m, level);
     }
-    zk_launch_d<k_digit_affine, 64>(ctx, PC_MSM_TABLES, 0.0, dim3((16 * m + 63) / 64), dst, (const g1j_t *) J, pre, m);
+    const uint32_t per = digit_affine_per();
+    zk_launch_d<k_digit_affine, 64>(ctx, PC_MSM_TABLES, 0.0, dim3(((256 / per) * m + 63) / 64), dst, (const g1j_t *) J, pre, m, per);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
 }
@@ -457,8 +467,8 @@ static uint32_t busy_pairs() {
 
 // columns per lane of the opening's digit-table route (experiment switch ZKCNN_DIGIT_PAIRS)
 static uint32_t digit_pairs() {
-    static const uint32_t v = [] { const char *e = getenv("ZKCNN_DIGIT_PAIRS"); return e ? (uint32_t) std::max(1, atoi(e)) : 8u; }();
-    return v;
+    const char *e = getenv("ZKCNN_DIGIT_PAIRS");
+    return e ? (uint32_t) std::max(1, atoi(e)) : 8u;
 }
 
 // rows independent MSMs over the cached generator tables, every window >= w_lo of every scalar; scalars are read from s->mag

@@ -610,20 +610,22 @@ __device__ __forceinline__ void k_digit_level(g1j_t *J, const g1a_t *G, uint32_t
     }
     g1j_store(J + (size_t) d * m + j, X, Y, Z, empty);
 }
-// Jacobian -> affine for 16 consecutive digits of one generator with one inversion (Montgomery's trick)
-__device__ __forceinline__ void k_digit_affine(g1a_t *D, const g1j_t *J, fp_t *pre, uint32_t m) {
+// Jacobian -> affine for `per` consecutive digits of one generator with one inversion (Montgomery's trick; per divides 256). The inversion is a chain of
+// ~480 products, a digit costs 7: per = 16 (592 products, 1 024 waves for 4 096 generators) is what the host launches; per = 64 does the same table in 0.39 of
+// the issue slots with a chain of 928, and measured no faster under load (hyrax.hip: digit_affine_per)
+__device__ __forceinline__ void k_digit_affine(g1a_t *D, const g1j_t *J, fp_t *pre, uint32_t m, uint32_t per) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= 16 * m) return;
-    const uint32_t j = tid % m, d0 = (tid / m) * 16;
+    if (tid >= (256 / per) * m) return;
+    const uint32_t j = tid % m, d0 = (tid / m) * per;
     fp_t run = fp_one();
-    for (uint32_t d = d0; d < d0 + 16; ++d) {
+    for (uint32_t d = d0; d < d0 + per; ++d) {
         if (d == 0) continue;
         const fp_t z = J[(size_t) d * m + j].Z;
         pre[(size_t) d * m + j] = run;
         if (!fp_is_zero(z)) run = fp_mul(run, z);
     }
     fp_t inv = fp_inv(run);
-    for (uint32_t d = d0 + 16; d-- > d0;) {
+    for (uint32_t d = d0 + per; d-- > d0;) {
         if (d == 0) continue;
         const g1j_t Q = J[(size_t) d * m + j];
         g1a_t a;
