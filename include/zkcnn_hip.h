@@ -150,6 +150,12 @@ int32_t zk_set_host_tail(zk_ctx *ctx, int32_t log_entries);
  * random generators for every proof, reference src/verifier.cpp:119-128) -- no byte table is ever built for them, whatever the proof does with the
  * set; reusable != 0 (the state of a new context): a set that is used a second time gets its byte table. */
 int32_t zk_set_generator_reuse(zk_ctx *ctx, int32_t reusable);
+/* out[i] = scalars[i] * B for ONE base point B given as its byte-window table, table_affine[w * 255 + d - 1] = d 256^w B (32 x 255 affine points, 12 words
+ * each, Montgomery form like the generators of zk_commit_input); scalars: n canonical integers of 4 words; out: n Jacobian points of 18 words (the host
+ * library's G1). This is the reference verifier's generator loop, src/verifier.cpp:121-126 (gens[i] = G * k_i, k_i from its CSPRNG), which an in-process run
+ * in the reference's semantics repeats for every proof: 4 096 scalar multiplications, ~10 ms of eight host threads per proof -- with eight proofs driven by
+ * one host thread (zk_batch_*) that loop was a third of a batch proof's wall time. The table is kept on the GPU from its first use. */
+int32_t zk_fixed_base_mul(zk_ctx *ctx, const uint64_t *table_affine, uint64_t table_points, const uint64_t *scalars, uint64_t n, uint64_t *out_jacobian);
 /* rounds the hybrid tail has run on the host since the context was created (bench: rounds_on_host_per_proof) */
 int32_t zk_host_tail_stats(zk_ctx *ctx, uint64_t *rounds);
 /* Persistent rounds of the interactive protocol (on by default): once the live tables of a phase hold at most 1024 quads, ONE resident

@@ -226,11 +226,13 @@ def test_batches_created_as_a_group_in_the_reference_semantics(built):
             s.close()
 
 
-@pytest.mark.parametrize("switches", [{"ZKCNN_DIGIT_OPENING": "0"}, {"ZKCNN_DIGIT_PAIRS": "1"}, {"ZKCNN_DIGIT_PAIRS": "32"}, {"ZKCNN_DIGIT_AFFINE_PER": "64"}])
+@pytest.mark.parametrize("switches", [{"ZKCNN_DIGIT_OPENING": "0"}, {"ZKCNN_DIGIT_PAIRS": "1"}, {"ZKCNN_DIGIT_PAIRS": "32"}, {"ZKCNN_DIGIT_AFFINE_PER": "64"}, {"ZKCNN_LOAD_SHAPES": "0"},
+                                      {"ZKCNN_HOST_GENERATORS": "1"}])
 def test_opening_through_the_digit_table_and_through_window_tables_agree(built, monkeypatch, switches):
     """Lanes of a batch open a fresh generator set through the digit table of its commitment (k_bytes_acc by window + k_cl_whorner32: no window tables); a proof on its
     own builds window tables and sums digit planes. Both are the oracle's bytes -- with the route switched off, with one column and with 32 columns per lane (ragged and
-    single-chunk grids), with 64 digits per inversion in the digit table's conversion -- and the verifier's own multiplications (a set that never had a commitment:
+    single-chunk grids), with 64 digits per inversion in the digit table's conversion, with a lone proof's launch shapes, with the verifier's generators multiplied on
+    host threads instead of the GPU (zk_fixed_base_mul; the oracle always multiplies on the host) -- and the verifier's own multiplications (a set that never had a commitment:
     window tables built on demand) accept."""
     model, pic, pp = QUARTER_VGG11, (32, 32, 3), 1
     FULL = M.MODE_FULL_IPA

@@ -60,6 +60,7 @@ struct msm_state {
     fr_t *mag = nullptr; size_t mag_cap = 0;
     uint32_t *exc = nullptr;           // device word set by a fast-variant kernel that met P = +-Q
     bool safe = false;                 // run the SAFE kernel variants (after a flagged batch)
+    void *fb_buf = nullptr; size_t fb_cap = 0;                // zk_fixed_base_mul: results + scalars
     unsigned char *h_stage = nullptr;  // pinned: the <= 8 points + the exception word a few-row MSM hands to the host (a pageable target costs a staged copy: ~70 us)
 };
 #define MSM_STAGE_BYTES (8 * sizeof(g1j_t) + 64)
@@ -179,7 +180,7 @@ static void msm_destroy_one(zk_ctx *ctx) {
     if (s->win_scratch) (void) hipFree(s->win_scratch);
     if (s->h_stage) (void) hipHostFree(s->h_stage);
     void *bufs[] = {s->partials, s->rowsJ, s->rowsA, s->a, s->b, s->coef, s->Lrow, s->sL, s->idxL, s->d_y, s->tbl_scratch,
-                    s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch, s->parts2, s->codes, s->mag, s->exc, s->masks};
+                    s->hi_flags, s->row_list, s->tmpJ, s->aff_scratch, s->parts2, s->codes, s->mag, s->exc, s->masks, s->fb_buf};
     for (void *p : bufs) if (p) hipFree(p);
     delete s;
     ctx->msm = nullptr;
@@ -341,6 +342,12 @@ static int32_t ensure_rows(zk_ctx *ctx, uint32_t rows) {
     ZK_HIP(hipMalloc((void **) &s->rowsA, (size_t) rows * sizeof(g1a_t)));
     s->rows_cap = rows;
     return ZK_OK;
+}
+
+// launch shapes for a GPU that other proofs share: fewer, smaller workgroups where a proof on its own takes many or large ones (experiment switch ZKCNN_LOAD_SHAPES=0)
+static bool load_shapes() {
+    const char *e = getenv("ZKCNN_LOAD_SHAPES");
+    return !e || atoi(e) != 0;
 }
 
 // digits per inversion of the digit table's conversion to affine when several proofs share the GPU (k_digit_affine; experiment switch ZKCNN_DIGIT_AFFINE_PER).
@@ -636,7 +643,9 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
     if ((rc = regrow(ctx, (void **) &s->partials, &s->partials_cap, (size_t) rows_all * n * sizeof(g1j_t)))) return rc;
     if ((rc = regrow(ctx, (void **) &s->tmpJ, &s->tmp_cap, (size_t) std::max<uint32_t>(wide_cap, 1) * sizeof(g1j_t)))) return rc;
     uint32_t *n_wide = s->hi_flags + rows;
-    const dim3 cgrid(std::min<uint32_t>((cols + 255) / 256, 64), 1);
+    // (a thread per scalar for a proof on its own; with other proofs in flight eight scalars per thread: an eighth of the workgroups to place -- the fused launch of
+    //  eight lanes took 11.5 ms against 8 x 0.2 ms alone)
+    const dim3 cgrid(!ctx->live_now && load_shapes() ? std::max<uint32_t>(1, (cols + 2047) / 2048) : std::min<uint32_t>((cols + 255) / 256, 64), 1);
     for (uint32_t r0 = 0; r0 < rows; r0 += 32768)
         zk_launch_d<k_scalar_codes, 256>(ctx, PC_MSM_PLANES, 0.0, dim3(cgrid.x, std::min<uint32_t>(32768, rows - r0)), s->codes + (size_t) r0 * cols,
                   s->hi_flags + r0, scalars + (size_t) r0 * ld, ld, cols);
@@ -697,7 +706,9 @@ static int32_t commit_rows(zk_ctx *ctx, const fr_t *scalars, uint64_t ld, uint32
 // few points: Jacobian -> affine on the host (one inversion each); many: on the device
 static int32_t fetch_points(zk_ctx *ctx, uint32_t rows, uint64_t *out) {
     msm_state *s = ctx->msm;
-    const uint32_t AFF_SEG = std::max<uint32_t>(4, (rows + 1023) / 1024);      // short per-thread chains; the single-block scan takes up to 1024 segments
+    // short per-thread chains; the single-block scan takes up to 1024 segments -- 256 when other proofs share the GPU (a small block finds a CU: k_aff_scan256)
+    const bool small_scan = !ctx->live_now && load_shapes() && rows <= 256 * 64;
+    const uint32_t AFF_SEG = std::max<uint32_t>(4, (rows + (small_scan ? 255 : 1023)) / (small_scan ? 256 : 1024));
     const uint32_t nseg = (rows + AFF_SEG - 1) / AFF_SEG;
     uint32_t exc = 0;                    // set by a fast-variant kernel that met P = +-Q: the caller repeats the batch with the SAFE kernels
     if (rows > 8 && nseg <= 1024) {
@@ -705,7 +716,8 @@ static int32_t fetch_points(zk_ctx *ctx, uint32_t rows, uint64_t *out) {
         if (rc) return rc;
         fp_t *pre = (fp_t *) s->aff_scratch, *seg = pre + rows, *seg_pre = seg + nseg, *seg_suf = seg_pre + nseg, *tot = seg_suf + nseg;
         zk_launch_d<k_aff_prefix, 64>(ctx, PC_MSM_FINISH, 0.0, dim3((nseg + 63) / 64), pre, seg, s->rowsJ, rows, AFF_SEG);
-        zk_launch_d<k_aff_scan, 1024>(ctx, PC_MSM_FINISH, 0.0, dim3(1), seg_pre, seg_suf, tot, seg, nseg);
+        if (small_scan) zk_launch_d<k_aff_scan256, 256>(ctx, PC_MSM_FINISH, 0.0, dim3(1), seg_pre, seg_suf, tot, seg, nseg);
+        else zk_launch_d<k_aff_scan, 1024>(ctx, PC_MSM_FINISH, 0.0, dim3(1), seg_pre, seg_suf, tot, seg, nseg);
         ZK_HIP(hipGetLastError());
         zkff::Fp total, inv;
         ZK_STREAM(hipMemcpyAsync(&total, tot, sizeof(fp_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -796,6 +808,39 @@ extern "C" int32_t zk_set_generator_reuse(zk_ctx *ctx, int32_t reusable) {
     ctx->msm->no_full = !reusable;
     if (ctx->msm->no_full) ctx->msm->full_ready = ctx->msm->t8_ready = false;
     else if (ctx->msm->gt) gen_adopt(ctx->msm);
+    return ZK_OK;
+}
+
+// ---- multiples of one base point through its byte-window table (the generators the reference's verifier draws for every proof) ----
+// One table per GPU and base point, uploaded when first seen (783 KB); scalars and results go through buffers of the context's MSM state.
+struct fixed_base_table { int device; std::vector<uint64_t> key; g1a_t *d_table; };
+static std::mutex g_fb_mtx;
+static std::vector<fixed_base_table> g_fb_tables;
+extern "C" int32_t zk_fixed_base_mul(zk_ctx *ctx, const uint64_t *table_affine, uint64_t table_points, const uint64_t *scalars, uint64_t n, uint64_t *out_jacobian) {
+    ZK_CHECK_CTX();
+    if (!table_affine || table_points != 32 * 255 || !scalars || !out_jacobian || !n || n > (1u << 24)) { ctx->err = "zk_fixed_base_mul: arguments"; return ZK_ERR_ARG; }
+    int32_t rc = ensure_state(ctx);
+    if (rc) return rc;
+    msm_state *s = ctx->msm;
+    g1a_t *T = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_fb_mtx);
+        for (const fixed_base_table &t : g_fb_tables)
+            if (t.device == ctx->device && std::memcmp(t.key.data(), table_affine, 12 * sizeof(uint64_t)) == 0) { T = t.d_table; break; }      // (entry 0 = the base point)
+        if (!T) {
+            ZK_HIP(hipMalloc((void **) &T, table_points * sizeof(g1a_t)));
+            if (hipMemcpy(T, table_affine, table_points * sizeof(g1a_t), hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree(T); ctx->err = "zk_fixed_base_mul: table upload"; return ZK_ERR_HIP; }
+            g_fb_tables.push_back({ctx->device, std::vector<uint64_t>(table_affine, table_affine + 12), T});
+        }
+    }
+    if ((rc = regrow(ctx, &s->fb_buf, &s->fb_cap, (size_t) n * (32 + sizeof(g1j_t))))) return rc;
+    g1j_t *d_out = (g1j_t *) s->fb_buf;
+    uint32_t *d_k = (uint32_t *) (d_out + n);
+    ZK_STREAM(hipMemcpyAsync(d_k, scalars, (size_t) n * 32, hipMemcpyHostToDevice, ctx->stream));
+    zk_launch_d<k_fixed_base, 64>(ctx, PC_MSM_TABLES, 0.0, dim3((uint32_t) ((n + 63) / 64)), d_out, (const uint32_t *) d_k, (const g1a_t *) T, (uint32_t) n);
+    ZK_HIP(hipGetLastError());
+    ZK_STREAM(hipMemcpyAsync(out_jacobian, d_out, (size_t) n * sizeof(g1j_t), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(zk_stream_sync(ctx));
     return ZK_OK;
 }
 

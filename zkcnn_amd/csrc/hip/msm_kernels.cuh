@@ -655,14 +655,17 @@ __device__ __forceinline__ void k_aff_prefix(fp_t *pre, fp_t *seg, const g1j_t *
     }
     seg[t] = run;
 }
-// single block: exclusive prefix and suffix products over the nseg segment products (in place), total product to *total
-__device__ __forceinline__ void k_aff_scan(fp_t *seg_pre, fp_t *seg_suf, fp_t *total, const fp_t *seg, uint32_t nseg) {
-    __shared__ fp_t a[1024], b[1024];
+// single block of N threads: exclusive prefix and suffix products over the nseg <= N segment products (in place), total product to *total.
+// N = 1024 (96 KB of LDS: a CU to itself) is the short chain of a proof on its own; with other proofs' kernels refilling every wave slot that frees up, such a
+// block waited 6 ms for a CU to drain (profiles/r06_final_kernel_stats_s64.md: 6.4 ms per launch against 0.11 ms alone) -- N = 256 (24 KB) fits into the gaps.
+template <int N>
+__device__ __forceinline__ void aff_scan_n(fp_t *seg_pre, fp_t *seg_suf, fp_t *total, const fp_t *seg, uint32_t nseg) {
+    __shared__ fp_t a[N], b[N];
     const uint32_t t = threadIdx.x;
     a[t] = t < nseg ? seg[t] : fp_one();                      // inclusive prefix
     b[t] = t < nseg ? seg[nseg - 1 - t] : fp_one();           // inclusive prefix of the reversed sequence = suffix
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
+    for (uint32_t d = 1; d < N; d <<= 1) {
         fp_t x, y;
         const bool on = t >= d;
         if (on) { x = fp_mul(a[t], a[t - d]); y = fp_mul(b[t], b[t - d]); }
@@ -676,6 +679,8 @@ __device__ __forceinline__ void k_aff_scan(fp_t *seg_pre, fp_t *seg_suf, fp_t *t
     }
     if (t == 0) *total = a[nseg - 1];
 }
+__device__ __forceinline__ void k_aff_scan(fp_t *seg_pre, fp_t *seg_suf, fp_t *total, const fp_t *seg, uint32_t nseg) { aff_scan_n<1024>(seg_pre, seg_suf, total, seg, nseg); }
+__device__ __forceinline__ void k_aff_scan256(fp_t *seg_pre, fp_t *seg_suf, fp_t *total, const fp_t *seg, uint32_t nseg) { aff_scan_n<256>(seg_pre, seg_suf, total, seg, nseg); }
 __device__ __forceinline__ void k_aff_finish(g1a_t *out, const g1j_t *in, const fp_t *pre, const fp_t *seg_pre, const fp_t *seg_suf,
                                                           const fp_t *total_inv, uint32_t n, uint32_t AFF_SEG) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -695,6 +700,24 @@ __device__ __forceinline__ void k_aff_finish(g1a_t *out, const g1j_t *in, const 
         }
         out[i] = r;
     }
+}
+
+// ---- fixed-base multiples k_i B for ONE base point (the verifier's fresh generators: reference src/verifier.cpp:121-126, gens[i] = G * k_i with k_i from its
+// CSPRNG). T[w * 255 + d - 1] = d 256^w B (affine); k: canonical integers, 8 words each. One thread per scalar: 32 table lookups and mixed additions
+// (exceptional cases handled in place: the SAFE form), Jacobian result.
+__device__ __forceinline__ void k_fixed_base(g1j_t *out, const uint32_t *k, const g1a_t *T, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fp_t X = fp_zero(), Y = fp_zero(), Z = fp_zero();
+    bool empty = true, exc = false;
+    for (uint32_t w = 0; w < 32; ++w) {
+        const uint32_t d = (k[(size_t) i * 8 + (w >> 2)] >> ((w & 3) * 8)) & 0xffu;
+        if (!d) continue;
+        fp_t px, py;
+        g1a_load(px, py, T + (size_t) w * 255 + d - 1);
+        g1_accumulate<true>(X, Y, Z, empty, px, py, false, exc);
+    }
+    g1j_store(out + i, X, Y, Z, empty);
 }
 
 __device__ __forceinline__ void k_to_affine(g1a_t *out, const g1j_t *in, uint32_t n) {

@@ -60,6 +60,14 @@ void prover::setLiveRounds(bool on) {
 void prover::setGeneratorReuse(bool reusable) {
     if (ctx) check(zk_set_generator_reuse(ctx, reusable ? 1 : 0), "zk_set_generator_reuse");
 }
+bool prover::fixedBaseMul(const std::vector<G1Affine> &table, const std::vector<uint64_t> &scalars, std::vector<G1> &out) {
+    if (!ctx) return false;
+    static_assert(sizeof(G1) == 18 * sizeof(uint64_t) && sizeof(G1Affine) == 12 * sizeof(uint64_t), "point layouts of the C-ABI");
+    const size_t n = scalars.size() / 4;
+    out.resize(n);
+    check(zk_fixed_base_mul(ctx, reinterpret_cast<const uint64_t *>(table.data()), table.size(), scalars.data(), n, reinterpret_cast<uint64_t *>(out.data())), "zk_fixed_base_mul");
+    return true;
+}
 void prover::setHostTail(int log_entries) {
     if (ctx) check(zk_set_host_tail(ctx, log_entries), "zk_set_host_tail");
 }

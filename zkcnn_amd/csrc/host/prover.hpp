@@ -77,6 +77,8 @@ public:
     uint64_t hostTailRounds() const;            // rounds it has run on the host so far
     void proofBegin();                          // bracket of one proof (include/zkcnn_hip.h: zk_proof_begin / zk_proof_end)
     void proofEnd();
+    // out[i] = k_i * B through B's byte-window table on the GPU (include/zkcnn_hip.h: zk_fixed_base_mul): the verifier's generator loop of an in-process run
+    bool fixedBaseMul(const std::vector<G1Affine> &table, const std::vector<uint64_t> &scalars, std::vector<G1> &out);
     void setGeneratorReuse(bool reusable);      // the commitment generators of the next proofs come again (public generators) or not (the reference's fresh ones): include/zkcnn_hip.h: zk_set_generator_reuse
     void setLiveRounds(bool on);                // resident round kernel of the interactive protocol (include/zkcnn_hip.h: zk_set_live_rounds)
 
@@ -119,6 +121,7 @@ inline void attachFsChain(prover &p, const uint32_t *state, const uint64_t *pend
 inline void setHostTail(prover &p, int log_entries) { p.setHostTail(log_entries); }
 inline void setLiveRounds(prover &p, bool on) { p.setLiveRounds(on); }
 inline void setGeneratorReuse(prover &p, bool reusable) { p.setGeneratorReuse(reusable); }
+inline bool fixedBaseMul(prover &p, const std::vector<G1Affine> &table, const std::vector<uint64_t> &scalars, std::vector<G1> &out) { return p.fixedBaseMul(table, scalars, out); }
 inline void proofBegin(prover &p) { p.proofBegin(); }
 inline void proofEnd(prover &p) { p.proofEnd(); }
 template <class H> inline void setConvHints(prover &p, const std::vector<H> &hints) {

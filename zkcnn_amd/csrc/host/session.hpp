@@ -120,6 +120,7 @@ struct sessionT {
         if (vaccel && !(mode & ZKCNN_MODE_HOST_PRED)) v.accel = vaccel;
         v.cross_check = (mode & ZKCNN_MODE_CROSS_PRED) != 0;
         v.full_ipa = (mode & ZKCNN_MODE_FULL_IPA) != 0;
+        if (const char *hg = std::getenv("ZKCNN_HOST_GENERATORS")) v.host_generators = std::atoi(hg) != 0;       // (A/B switch: the generator loop on host threads, as through round 5)
         if (fiat) {
             // non-interactive: every challenge is a hash of the statement (model, picture shape, quantisation scales, every layer's
             // shape, a digest of the wiring, the generators) and of all messages received so far

@@ -69,7 +69,11 @@ inline const std::vector<G1Affine> &generatorBaseTable() {
     }();
     return table;
 }
-inline void drawGenerators(std::vector<G1> &gens, size_t count) {
+// `device` (optional): hands (table, scalars) to the prover's GPU -- fixedBaseMul below -- and returns false if there is none: an in-process run whose prover
+// sits on a GPU does the 4 096 multiplications there (0.9 ms, fused over the lanes of a lock-step batch), any other verifier on its own cores.
+// The points are the same group elements either way (Jacobian coordinates may differ; nothing reads them but group operations).
+template <class Device>
+inline void drawGenerators(std::vector<G1> &gens, size_t count, Device device) {
     const std::vector<G1Affine> &table = generatorBaseTable();
     std::vector<uint64_t> e(4 * count);
     for (size_t i = 0; i < count; ++i) {
@@ -77,6 +81,7 @@ inline void drawGenerators(std::vector<G1> &gens, size_t count) {
         k.setByCSPRNG();
         k.toCanonical(&e[4 * i]);
     }
+    if (device(table, e, gens) && gens.size() == count) return;
     gens.resize(count);
     auto work = [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
@@ -96,6 +101,11 @@ inline void drawGenerators(std::vector<G1> &gens, size_t count) {
     work(0, std::min(count, per));
     for (auto &x : th) x.join();
 }
+inline void drawGenerators(std::vector<G1> &gens, size_t count) {
+    drawGenerators(gens, count, [](const std::vector<G1Affine> &, const std::vector<uint64_t> &, std::vector<G1> &) { return false; });
+}
+// a prover type without a GPU behind it (the replay of a recorded proof, the oracle's prover): the verifier multiplies on the host
+template <class P> inline bool fixedBaseMul(P &, const std::vector<G1Affine> &, const std::vector<uint64_t> &, std::vector<G1> &) { return false; }
 
 // Optional accelerator for the verifier's wiring predicates (the only part of the verifier that walks every gate:
 // reference src/verifier.cpp:36-116 and :304-325, `total_slow_timer`). The product driver plugs the HIP implementation
@@ -133,6 +143,7 @@ public:
     // zero-knowledge mode (zk_mask.hpp; no reference counterpart): blinded commitments over (g, H), masked round polynomials, proofs of dot
     // product instead of the inner-product argument. The checks of the reference protocol are unchanged underneath the masks.
     bool zk = false;
+    bool host_generators = false;            // draw the generators on the host even if the prover has a GPU (experiment switch ZKCNN_HOST_GENERATORS=1 through the session)
     bool full_ipa = false;                   // run the inner-product argument down to length 1 instead of stopping at IPA_STOP_LEN
     proofTranscript transcript;
     // test hook: add 1 to the k-th message received from the prover (a cheating prover); -1 = off.
@@ -148,7 +159,8 @@ public:
         if (!drive_only && (!accel || cross_check) && C.gatesDropped())
             return fail("the wiring predicates on the host need the gate lists: this session holds a structure copy of the circuit (a clone): use the GPU predicates");
         if (fixed_gens) gens = *fixed_gens;
-        else drawGenerators(gens, n_gens);
+        else drawGenerators(gens, n_gens, [this](const std::vector<G1Affine> &table, const std::vector<uint64_t> &k, std::vector<G1> &out) {
+            return !host_generators && fixedBaseMul(*p, table, k, out); });
         if (gens.size() != n_gens) return false;
         delete poly_v;
         poly_v = new hyrax_bls12_381::polyVerifier(zk ? p->commitInputZk(gens) : p->commitInput(gens), gens, &transcript);
