@@ -350,12 +350,13 @@ static bool load_shapes() {
     return !e || atoi(e) != 0;
 }
 
-// digits per inversion of the digit table's conversion to affine when several proofs share the GPU (k_digit_affine; experiment switch ZKCNN_DIGIT_AFFINE_PER).
-// 64 digits per inversion are 0.39 of the issue slots of 16 and did NOT show: steps of one process alternating 16 / 64 / 128 gave 93.8 / 89.3-91.4 / 90.5 proofs/s
-// (scripts/exp/ab_inprocess.py, step-to-step spread +-4 %) -- the chain (928 against 592 dependent products) costs what the slots save. 16 stays.
-static uint32_t digit_affine_per() {
+// digits per inversion of the digit table's conversion to affine (k_digit_affine; experiment switch ZKCNN_DIGIT_AFFINE_PER). A proof on its own: 16 (the short
+// chain). Several proofs in flight: 64 -- 0.39 of the issue slots for a chain of 928 instead of 592 products. While the batches' streams still waited for their host
+// threads most of the time that saving did not show (steps of one process alternating 16 / 64 / 128: 93.8 / 89.3-91.4 / 90.5 proofs/s); since the verifier's
+// generator loop runs on the GPU the streams are busy and it does: 133.2 / 135.4 / 134.9 proofs/s (profiles/r06_retune.txt).
+static uint32_t digit_affine_per(const zk_ctx *ctx) {
     const char *e = getenv("ZKCNN_DIGIT_AFFINE_PER");
-    const uint32_t x = e ? (uint32_t) atoi(e) : 16u;
+    const uint32_t x = e ? (uint32_t) atoi(e) : (ctx->live_now ? 16u : 64u);
     return x == 16 || x == 32 || x == 64 || x == 128 || x == 256 ? x : 16u;
 }
 
@@ -370,7 +371,7 @@ static int32_t build_digit_table(zk_ctx *ctx, g1a_t *dst, const g1a_t *base, uin
         const uint32_t work = (1u << level) * m;
         zk_launch_d<k_digit_level, 64>(ctx, PC_MSM_TABLES, 0.0, dim3((work + 63) / 64), J, base, m, level);
     }
-    const uint32_t per = digit_affine_per();
+    const uint32_t per = digit_affine_per(ctx);
     zk_launch_d<k_digit_affine, 64>(ctx, PC_MSM_TABLES, 0.0, dim3(((256 / per) * m + 63) / 64), dst, (const g1j_t *) J, pre, m, per);
     ZK_HIP(hipGetLastError());
     return ZK_OK;

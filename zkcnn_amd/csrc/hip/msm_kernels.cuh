@@ -611,8 +611,8 @@ __device__ __forceinline__ void k_digit_level(g1j_t *J, const g1a_t *G, uint32_t
     g1j_store(J + (size_t) d * m + j, X, Y, Z, empty);
 }
 // Jacobian -> affine for `per` consecutive digits of one generator with one inversion (Montgomery's trick; per divides 256). The inversion is a chain of
-// ~480 products, a digit costs 7: per = 16 (592 products, 1 024 waves for 4 096 generators) is what the host launches; per = 64 does the same table in 0.39 of
-// the issue slots with a chain of 928, and measured no faster under load (hyrax.hip: digit_affine_per)
+// ~480 products, a digit costs 7: per = 16 (592 products, 1 024 waves for 4 096 generators) for a proof on its own; per = 64 does the same table in 0.39 of
+// the issue slots with a chain of 928: several proofs in flight (hyrax.hip: digit_affine_per)
 __device__ __forceinline__ void k_digit_affine(g1a_t *D, const g1j_t *J, fp_t *pre, uint32_t m, uint32_t per) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= (256 / per) * m) return;
