@@ -782,7 +782,8 @@ def main():
         steps = args.steps
         out = {
             "metric": ("proofs/s of the GKR prover in the REFERENCE's semantics: the verifier draws new random generators for every proof (reference src/verifier.cpp:119-128; "
-                       "every commitment table is built inside the prover's clock, none survives the proof) and the inner-product argument runs down to length 1; " if REF else
+                       "every commitment table is built inside the prover's clock, none survives the proof; the verifier's own loop gens[i] = k_i G multiplies on the prover's GPU, "
+                       "zk_fixed_base_mul, ZKCNN_HOST_GENERATORS=1 keeps it on host threads) and the inner-product argument runs down to length 1; " if REF else
                        "proofs/s of the GKR prover, PUBLIC-GENERATOR VARIANT (hash-to-curve generators with a resident byte table, inner-product argument cut at 256; the reference's "
                        "own semantics are the `reference_semantics` object of this line); ") +
                       f"{args.workload} pic_cnt={pp} proofs, {K} in flight per GPU" +
